@@ -1,0 +1,120 @@
+"""TEST INFRASTRUCTURE -- numpy restatement of the reference's event -> voxel
+preprocessing.  Integer work: results must be
+bit-exact against the reference (pinned by tests/golden/events_*.npz, which
+were produced by calling the reference's own functions; see gen_golden.py).
+
+Events are passed as four parallel arrays (t sorted ascending, x, y, p), the
+struct-of-arrays form of the reference's structured array
+(yolox/utils/psee_loader/io/dat_events_tools.py:24-52: t:u4, x:u2, y:u2, p:u1).
+"""
+import numpy as np
+
+
+def slice_bounds(t, num_slice):
+    """[start, end) index pairs of the ``num_slice`` equal time windows.
+
+    Follows GEN1Dataset.slice_events (yolox/data/datasets/gen1.py:313-328;
+    identical copies at ncaltech.py:368-378, rvt_gen4.py:411-426,
+    gen4.py:445-460) with overlap = 0:
+        window = (t[-1] - t[0]) // num_slice            (integer floor, dtype of t)
+        start_k = t[0] + k * window ; end_k = start_k + window
+        indices = searchsorted(t, ., side='left')
+    Events with t >= t[0] + num_slice*window fall in no slice.  Empty input -> None.
+    """
+    t = np.asarray(t)
+    if t.shape[0] <= 0:
+        return None
+    window = (t[-1] - t[0]) // num_slice
+    starts = np.arange(num_slice, dtype=np.int64) * np.int64(window) + np.int64(t[0])
+    ends = starts + np.int64(window)
+    lo = np.searchsorted(t, starts, side='left')
+    hi = np.searchsorted(t, ends, side='left')
+    return list(zip(lo.tolist(), hi.tolist()))
+
+
+def aggregate_sum(x, y, p, height, width):
+    """Per-polarity event-count frame [2, H, W] (float64, like the reference).
+
+    Follows GEN1Dataset.agrregate(method='sum') (gen1.py:333-349): channel 0
+    counts p == 0, channel 1 counts p != 0, position = y * W + x.
+    ``x is None`` (no events) -> zeros.  N-Caltech's np.add.at form
+    (ncaltech.py:231-237 with count_measure) gives the same counts.
+    """
+    frame = np.zeros((2, height * width), dtype=np.float64)
+    if x is None or len(x) == 0:
+        return frame.reshape(2, height, width)
+    x = np.asarray(x).astype(np.int64)
+    y = np.asarray(y).astype(np.int64)
+    p = np.asarray(p)
+    neg = p == 0
+    for c, m in enumerate((neg, ~neg)):
+        pos = y[m] * width + x[m]
+        counts = np.bincount(pos, minlength=0)
+        frame[c, :counts.size] += counts
+    return frame.reshape(2, height, width)
+
+
+def micro_sum(t, x, y, p, num_micro, height, width):
+    """[Tm, 2, H, W] float64 count frames (gen1.py:355-360 'micro_sum')."""
+    bounds = slice_bounds(t, num_micro)
+    if bounds is None:
+        return np.zeros((num_micro, 2, height, width), dtype=np.float64)
+    return np.stack([aggregate_sum(x[a:b], y[a:b], p[a:b], height, width) for a, b in bounds])
+
+
+def micro_sum_batch(t, x, y, p, sample_offsets, num_micro, height, width):
+    """Batched form used to check the HIP kernel: events of sample b are
+    ``[sample_offsets[b], sample_offsets[b+1])``.  Returns int32 [B, Tm, 2, H, W]."""
+    B = len(sample_offsets) - 1
+    out = np.zeros((B, num_micro, 2, height, width), dtype=np.int32)
+    for b in range(B):
+        a, e = int(sample_offsets[b]), int(sample_offsets[b + 1])
+        out[b] = micro_sum(t[a:e], x[a:e], y[a:e], p[a:e], num_micro, height, width).astype(np.int32)
+    return out
+
+
+def voxel_grid(t, x, y, p_signed, n_time_bins, height, width):
+    """Bilinear-in-time voxel grid [nb, 1, H, W] float64.
+
+    Follows to_voxel_grid_numpy (yolox/utils/event_reps.py:30-89):
+        ts = nb * (t - t0) / (t_last - t0); ti = int(ts); dt = ts - ti
+        grid[ti]   += pol * (1 - dt)   if ti     < nb
+        grid[ti+1] += pol * dt         if ti + 1 < nb
+    with pol in {-1, +1}.  The reference rewrites ``p == 0 -> -1`` in place
+    (event_reps.py:60), which only has defined behaviour for a SIGNED polarity
+    dtype (as ncaltech.py:44 uses); that is the semantics restated here:
+    ``p_signed`` is an integer array, 0 is mapped to -1.
+    A single-timestamp stream divides by zero in the reference (nan/inf ts);
+    here it is declared invalid input and returns zeros.
+    """
+    if len(t) == 0:
+        return np.zeros((n_time_bins, 1, height, width), dtype=np.float64)
+    t = np.asarray(t)
+    grid = np.zeros(n_time_bins * height * width, dtype=np.float64)
+    span = float(t[-1]) - float(t[0])
+    if span == 0.0:
+        return grid.reshape(n_time_bins, 1, height, width)
+    ts = n_time_bins * (t.astype(np.float64) - float(t[0])) / span
+    xs = np.asarray(x).astype(np.int64)
+    ys = np.asarray(y).astype(np.int64)
+    pol = np.asarray(p_signed).astype(np.float64).copy()
+    pol[pol == 0] = -1.0
+    tis = ts.astype(np.int64)
+    dts = ts - tis
+    left = pol * (1.0 - dts)
+    right = pol * dts
+    v = tis < n_time_bins
+    np.add.at(grid, xs[v] + ys[v] * width + tis[v] * width * height, left[v])
+    v = (tis + 1) < n_time_bins
+    np.add.at(grid, xs[v] + ys[v] * width + (tis[v] + 1) * width * height, right[v])
+    return grid.reshape(n_time_bins, 1, height, width)
+
+
+def synth_events(n_events, height=240, width=304, t0=1_000_000, span_us=200_000, seed=0):
+    """Synthetic stream of BASELINE.md section 2 / SURVEY 8d config 1."""
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.integers(t0, t0 + span_us, size=n_events, dtype=np.int64)).astype(np.uint32)
+    x = rng.integers(0, width, size=n_events, dtype=np.int64).astype(np.uint16)
+    y = rng.integers(0, height, size=n_events, dtype=np.int64).astype(np.uint16)
+    p = (rng.random(n_events) < 0.5).astype(np.uint8)
+    return t, x, y, p

@@ -1,0 +1,370 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- golden-vector generator (runs ONLY in the build container).
+
+Imports the real reference from /root/reference (read-only, never copied) and
+writes small input/output fixtures to tests/golden/*.npz.  Nothing from the
+reference travels: the fixtures are data (inputs, expected outputs, gradients).
+
+    python -m oracle.gen_golden            # regenerate everything
+
+What stands in for what (none of it carries hot-path arithmetic except sj_ref):
+  * loguru / cv2 / torchvision / pycocotools / h5py / thop -> empty shims written to a temp dir
+    (the reference imports them at package import time).
+  * spikingjelly.activation_based -> oracle.sj_ref (spikingjelly==0.0.0.0.14 is not vendored;
+    parity at that boundary is UNPINNED, see oracle/sj_ref.py).
+"""
+import os
+import sys
+import tempfile
+import textwrap
+import types
+import zlib
+
+sys.dont_write_bytecode = True          # never write __pycache__ into /root/reference
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+_SHIMS = {
+    'loguru/__init__.py': '''
+        class _L:
+            def __getattr__(self, k):
+                if k == 'catch':
+                    return lambda f=None, **kw: f if callable(f) else (lambda g: g)
+                return lambda *a, **k: None
+        logger = _L()
+    ''',
+    'cv2/__init__.py': '''
+        INTER_LINEAR = 1; INTER_NEAREST = 0; INTER_AREA = 3; INTER_CUBIC = 2; INTER_LANCZOS4 = 4
+        def setNumThreads(n): pass
+        class ocl:
+            @staticmethod
+            def setUseOpenCL(b): pass
+    ''',
+    'torchvision/__init__.py': 'from . import ops\n',
+    'torchvision/ops.py': '''
+        def nms(*a, **k): raise NotImplementedError
+        def batched_nms(*a, **k): raise NotImplementedError
+    ''',
+    'pycocotools/__init__.py': '',
+    'pycocotools/coco.py': 'class COCO: pass\n',
+    'pycocotools/cocoeval.py': 'class COCOeval: pass\n',
+    'pycocotools/mask.py': '',
+    'h5py/__init__.py': 'class File: pass\n',
+    'thop/__init__.py': 'def profile(*a, **k): raise NotImplementedError\n',
+}
+
+
+def setup_reference_imports():
+    shim_dir = tempfile.mkdtemp(prefix='eas_shims_')
+    for rel, src in _SHIMS.items():
+        path = os.path.join(shim_dir, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            f.write(textwrap.dedent(src))
+    sys.path.insert(0, shim_dir)
+    from oracle import sj_ref
+    sj_ref.install_as_spikingjelly()
+    sys.path.insert(1, REF)
+    return shim_dir
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'  wrote {os.path.relpath(path)}  {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- K1 events
+def gen_events():
+    from types import SimpleNamespace
+    from yolox.data.datasets.gen1 import GEN1Dataset
+    from yolox.utils.event_reps import to_voxel_grid_numpy
+
+    dt = np.dtype([('t', 'u4'), ('x', 'u2'), ('y', 'u2'), ('p', 'u1')])
+    dts = np.dtype([('t', 'i8'), ('x', 'i2'), ('y', 'i2'), ('p', 'i1')])   # signed polarity (ncaltech.py:44)
+
+    def ref_micro_sum(t, x, y, p, Tm, H, W):
+        ev = np.zeros(len(t), dtype=dt)
+        ev['t'], ev['x'], ev['y'], ev['p'] = t, x, y, p
+        me = SimpleNamespace(img_size=(H, W), slice_args={'micro_slice': Tm})
+        me.slice_events = lambda e, n, overlap=0: GEN1Dataset.slice_events(me, e, n, overlap)
+        me.agrregate = lambda e, method: GEN1Dataset.agrregate(me, e, method)
+        return GEN1Dataset.agrregate(me, ev if len(t) else None, 'micro_sum')
+
+    def ref_voxel(t, x, y, p, nb, H, W):
+        ev = np.zeros(len(t), dtype=dts)
+        ev['t'], ev['x'], ev['y'], ev['p'] = t, x, y, p
+        return to_voxel_grid_numpy(ev, [W, H, 2], nb)
+
+    from oracle.events_ref import synth_events
+    rng = np.random.default_rng(7)
+    cases = {}
+
+    def add(name, t, x, y, p, Tm, H, W):
+        out = ref_micro_sum(t, x, y, p, Tm, H, W)
+        assert out.dtype == np.float64 and (out == np.round(out)).all()
+        cases[name] = dict(t=np.asarray(t, np.uint32), x=np.asarray(x, np.uint16), y=np.asarray(y, np.uint16),
+                           p=np.asarray(p, np.uint8), Tm=Tm, H=H, W=W, out=out.astype(np.int32))
+
+    t, x, y, p = synth_events(20000, 240, 304, seed=0)
+    add('gen1_20k_tm4', t, x, y, p, 4, 240, 304)
+    t, x, y, p = synth_events(3000, 24, 32, seed=1)
+    add('small_tm4', t, x, y, p, 4, 24, 32)
+    add('small_tm8', t, x, y, p, 8, 24, 32)
+    add('small_tm3', t, x, y, p, 3, 24, 32)                       # span not divisible -> tail dropped
+    add('small_tm1', t, x, y, p, 1, 24, 32)
+    add('empty', t[:0], x[:0], y[:0], p[:0], 4, 24, 32)
+    add('single_event', t[:1], x[:1], y[:1], p[:1], 4, 24, 32)    # window == 0
+    add('same_timestamp', np.full(50, 1234567, np.uint32), x[:50], y[:50], p[:50], 4, 24, 32)
+    add('fewer_than_tm', t[:3], x[:3], y[:3], p[:3], 4, 24, 32)
+    tt = t.copy()
+    tt[-5:] = tt[-1]                                              # several events on the last microsecond
+    add('last_us_cluster', tt, x, y, p, 4, 24, 32)
+    add('all_negative', t, x, y, np.zeros_like(p), 4, 24, 32)
+    add('all_positive', t, x, y, np.ones_like(p), 4, 24, 32)
+    add('one_pixel', t, np.full_like(x, 31), np.full_like(y, 23), p, 4, 24, 32)   # heavy collisions, last pixel
+    t2 = np.sort(rng.integers(0, 2 ** 32 - 1, 4000, dtype=np.uint64)).astype(np.uint32)
+    add('wide_timestamps', t2, x[:3000].repeat(2)[:4000], y[:3000].repeat(2)[:4000], p[:3000].repeat(2)[:4000],
+        4, 24, 32)
+    t3, x3, y3, p3 = synth_events(5000, 180, 240, seed=3)         # N-Caltech sensor
+    add('ncaltech_tm8', t3, x3, y3, p3, 8, 180, 240)
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f'{name}/{k}'] = np.asarray(v)
+    save('events_micro_sum', names=np.array(sorted(cases)), **flat)
+
+    # voxel grid
+    vox = {}
+    for name, (n, nb, H, W, seed) in {'vg_small_nb5': (3000, 5, 24, 32, 11), 'vg_small_nb10': (3000, 10, 24, 32, 12),
+                                      'vg_tiny_nb4': (7, 4, 8, 8, 13)}.items():
+        t, x, y, p = synth_events(n, H, W, seed=seed)
+        ps = p.astype(np.int8)
+        out = ref_voxel(t.astype(np.int64), x, y, ps.copy(), nb, H, W)
+        vox[name] = dict(t=t, x=x, y=y, p=p, nb=nb, H=H, W=W, out=out)
+    vox['vg_empty'] = dict(t=t[:0], x=x[:0], y=y[:0], p=p[:0], nb=4, H=8, W=8,
+                           out=ref_voxel(t[:0].astype(np.int64), x[:0], y[:0], p[:0].astype(np.int8), 4, 8, 8))
+    flat = {}
+    for name, c in vox.items():
+        for k, v in c.items():
+            flat[f'{name}/{k}'] = np.asarray(v)
+    save('events_voxel_grid', names=np.array(sorted(vox)), **flat)
+
+
+# ----------------------------------------------------------------------------- a5/a7 embeddings
+def gen_embeddings():
+    from yolox.models.embedding import (AdaptiveRSNNEmbedding, LIFEmbedding, SpikeCountEmbedding,
+                                        SpikingEmbedding)
+    from yolox.models.activation import Rectangle
+    from yolox.utils.util import warp_decay
+    from oracle.fill import poisson_events, procedural_fill_
+
+    def kwargs(Tm, thresh=1.0, vreset=0.0):
+        return {'nb_steps': Tm, 'vreset': vreset, 'thresh': thresh, 'spike_fn': Rectangle,
+                'decay': torch.nn.Parameter(warp_decay(0.5))}
+
+    variants = {
+        # name: (k, depth, Ts, readout, spike_attach, write_zero, abs, Tm, vreset, gain)
+        'readme': (5, 2, 1, 'sum', True, True, False, 4, 0.0, 2.0),
+        'ts3_sum': (5, 2, 3, 'sum', True, True, False, 4, 0.0, 3.0),
+        'ts3_last': (5, 1, 3, 'last', False, False, False, 4, 0.0, 3.0),
+        'ts2_avg': (7, 1, 2, 'avg', True, False, True, 6, 0.0, 3.0),
+        'ts1_plain': (5, 1, 1, 'sum', False, False, False, 4, 0.0, 2.0),
+        'soft_reset': (5, 2, 2, 'sum', True, True, False, 4, None, 3.0),
+        'ts7_tm8': (5, 2, 7, 'sum', True, True, False, 8, 0.0, 4.0),
+    }
+    for name, (k, depth, Ts, readout, sat, wz, ab, Tm, vreset, gain) in variants.items():
+        m = AdaptiveRSNNEmbedding(kernel_size=k, in_channel=2, out_channel=2, Ts=Ts, spike_attach=sat,
+                                  write_zero=wz, abs=ab, depth=depth, readout=readout, **kwargs(Tm, 1.0, vreset))
+        crc = procedural_fill_(m, conv_gain=gain)
+        x = torch.from_numpy(poisson_events((2, 1, Tm, 2, 24, 32), 0.6, seed=zlib.crc32(name.encode()) % 1000))
+        x.requires_grad_(True)
+        out, t_rec = m(x, record=True)
+        out = m(x)
+        gw = torch.from_numpy(np.random.default_rng(5).standard_normal(out.shape).astype(np.float32))
+        out.backward(gw)
+        grads = {f'grad/{n}': _np(p.grad) for n, p in m.named_parameters() if p.grad is not None}
+        save(f'arsnn_{name}', x=_np(x), out=_np(out), gout=_np(gw), gx=_np(x.grad), crc=np.uint32(crc),
+             t_record=_np(t_rec).astype(np.int8),
+             cfg=np.array([k, depth, Ts, int(sat), int(wz), int(ab), Tm, -1 if vreset is None else 0]),
+             readout=np.array(readout), gain=np.float32(gain), **grads)
+
+    # count / rsnn / snn
+    Tm = 4
+    x = torch.from_numpy(poisson_events((2, 1, Tm, 2, 24, 32), 0.6, seed=21))
+    save('emb_count', x=_np(x), out=_np(SpikeCountEmbedding(Tm)(x)))
+    for ro in ('sum', 'last'):
+        m = SpikingEmbedding(kernel_size=5, in_channel=2, out_channel=2, readout=ro, relu=(ro == 'last'), depth=2,
+                             **kwargs(Tm))
+        crc = procedural_fill_(m, conv_gain=2.0)
+        xx = x.clone().requires_grad_(True)
+        out = m(xx)
+        gw = torch.from_numpy(np.random.default_rng(6).standard_normal(out.shape).astype(np.float32))
+        out.backward(gw)
+        grads = {f'grad/{n}': _np(p.grad) for n, p in m.named_parameters() if p.grad is not None}
+        save(f'emb_rsnn_{ro}', x=_np(x), out=_np(out), gout=_np(gw), gx=_np(xx.grad), crc=np.uint32(crc), **grads)
+        m = LIFEmbedding(kernel_size=5, in_channel=2, out_channel=2, readout=ro, depth=2, **kwargs(Tm))
+        crc = procedural_fill_(m, conv_gain=2.0)
+        xx = x.clone().requires_grad_(True)
+        out = m(xx)
+        gw = torch.from_numpy(np.random.default_rng(6).standard_normal(out.shape).astype(np.float32))
+        out.backward(gw)
+        grads = {f'grad/{n}': _np(p.grad) for n, p in m.named_parameters() if p.grad is not None}
+        save(f'emb_snn_{ro}', x=_np(x), out=_np(out), gout=_np(gw), gx=_np(xx.grad), crc=np.uint32(crc), **grads)
+
+
+# ----------------------------------------------------------------------------- a9 cross-check from the in-repo LIFLayer
+def gen_lif_layer():
+    """The reference's own LIFLayer (layer.py:38-69 + cell.py:37-65) with the configuration quoted at
+    utils_snn.py:41-43: the same recurrence as the PLIF node (sigmoid(decay)=0.5, soft reset, thresh 1)
+    except '>' instead of '>=' at exact threshold -- inputs below avoid v == 1 exactly."""
+    from yolox.models.layer import LIFLayer
+    from yolox.models.activation import Rectangle
+    from yolox.utils.util import warp_decay
+    rng = np.random.default_rng(3)
+    T, M = 5, 4096
+    x = torch.from_numpy((rng.standard_normal((T, M)) * 1.0 + 0.5).astype(np.float32)).requires_grad_(True)
+    lay = LIFLayer(retain_v=True, nb_steps=T, vreset=None, thresh=1.0, spike_fn=Rectangle,
+                   decay=torch.nn.Parameter(warp_decay(0.5)))
+    s = lay(x)
+    g = torch.from_numpy(rng.standard_normal((T, M)).astype(np.float32))
+    s.backward(g)
+    save('lif_layer_inrepo', x=_np(x), spikes=_np(s), v_final=_np(lay.vmem), gout=_np(g), gx=_np(x.grad),
+         gdecay=_np(lay.cell.decay.grad))
+
+
+# ----------------------------------------------------------------------------- a12 blocks
+def gen_blocks():
+    from yolox.models.network_blocks import BaseConv, CSPLayer, SPPBottleneck
+    from yolox.utils.utils_snn import convert_to_spiking
+    from spikingjelly.activation_based import surrogate, functional
+    from oracle.fill import procedural_fill_
+    rng = np.random.default_rng(9)
+
+    def run(name, mod, x, train):
+        convert_to_spiking(mod, surrogate.ATan(2.0))
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eps, m.momentum = 1e-3, 0.03
+        crc = procedural_fill_(mod, conv_gain=2.5)
+        mod.train(train)
+        xx = torch.from_numpy(x).requires_grad_(True)
+        out = mod(xx)
+        extra = {}
+        if train:
+            g = torch.from_numpy(rng.standard_normal(out.shape).astype(np.float32))
+            out.backward(g)
+            extra = {'gout': _np(g), 'gx': _np(xx.grad)}
+            extra.update({f'grad/{n}': _np(p.grad) for n, p in mod.named_parameters()})
+            extra.update({f'buf/{n}': _np(b) for n, b in mod.named_buffers()})
+        functional.reset_net(mod)
+        save(name, x=x, out=_np(out), crc=np.uint32(crc), **extra)
+
+    T, N = 3, 2
+    spikes_in = (rng.random((T, N, 8, 12, 16)) < 0.3).astype(np.float32)
+    real_in = rng.standard_normal((T, N, 8, 12, 16)).astype(np.float32)
+    for train in (True, False):
+        tag = 'train' if train else 'eval'
+        run(f'block_baseconv1x1_{tag}', BaseConv(8, 16, 1, 1), spikes_in, train)
+        run(f'block_baseconv3x3s2_{tag}', BaseConv(8, 16, 3, 2), real_in, train)
+        run(f'block_csp_{tag}', CSPLayer(8, 8, n=2), spikes_in, train)
+        run(f'block_spp_{tag}', SPPBottleneck(8, 8), spikes_in, train)
+
+
+# ----------------------------------------------------------------------------- a8/a12/a13 whole model
+def gen_models():
+    from yolox.exp import get_exp
+    from spikingjelly.activation_based import functional
+    from oracle.fill import poisson_events, procedural_fill_
+
+    base_opts = ['T', '3', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1',
+                 'readout', 'sum', 'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True',
+                 'spike_fn', 'atan']
+
+    def build(exp_name, use_spike, extra=()):
+        exp = get_exp(None, exp_name)
+        exp.merge(base_opts + ['use_spike', use_spike] + list(extra))
+        torch.manual_seed(80)
+        return exp, exp.get_model()
+
+    def targets_for(B, H, W):
+        t = torch.zeros(B, 50, 5)
+        for b in range(B):
+            t[b, 0] = torch.tensor([0, W * 0.3, H * 0.4, W * 0.25, H * 0.3])
+            t[b, 1] = torch.tensor([1, W * 0.7, H * 0.6, W * 0.2, H * 0.35])
+        return t
+
+    runs = [
+        # name, exp, use_spike, extra opts, (B, H, W), conv gain
+        ('model_s_true_64', 'e-yolox-s', 'True', (), (2, 64, 64), 2.0),
+        ('model_s_full_64', 'e-yolox-s', 'full_spike', (), (2, 64, 64), 2.0),
+        ('model_s_fullv2_64', 'e-yolox-s', 'full_spike_v2', (), (2, 64, 64), 2.0),
+        ('model_s_false_64', 'e-yolox-s', 'False', (), (1, 64, 64), 1.0),
+        ('model_s_true_256x320', 'e-yolox-s', 'True', (), (1, 256, 320), 2.0),
+        ('model_m_fullv2_t5_64x96', 'e-yolox-m', 'full_spike_v2', ('T', '5'), (1, 64, 96), 2.0),
+        ('model_s_true_ts3_64', 'e-yolox-s', 'True', ('Ts', '3'), (1, 64, 64), 2.0),
+    ]
+    for name, exp_name, us, extra, (B, H, W), gain in runs:
+        exp, model = build(exp_name, us, extra)
+        nparam = sum(p.numel() for p in model.parameters())
+        crc = procedural_fill_(model, conv_gain=gain)
+        x = torch.from_numpy(poisson_events((B, 1, exp.Tm, 2, H, W), 0.5, seed=zlib.crc32(name.encode()) % 1000))
+        keys = np.array(list(model.state_dict().keys()))
+        model.eval()
+        with torch.no_grad():
+            logits = model(x)
+        functional.reset_net(model)
+        arrays = dict(x=_np(x), logits=_np(logits), crc=np.uint32(crc), nparam=np.int64(nparam), keys=keys,
+                      gain=np.float32(gain))
+        if name in ('model_s_true_64', 'model_s_fullv2_64'):
+            model.train()
+            model.head.use_l1 = True
+            tg = targets_for(B, H, W)
+            out = model(x, tg)
+            out['total_loss'].backward()
+            functional.reset_net(model)
+            for k in ('total_loss', 'iou_loss', 'l1_loss', 'conf_loss', 'cls_loss'):
+                arrays[f'loss/{k}'] = np.float32(float(out[k]))
+            arrays['loss/num_fg'] = np.float32(out['num_fg'])
+            arrays['targets'] = _np(tg)
+            picks = [n for n, p in model.named_parameters() if p.grad is not None and (
+                n.endswith('act.w') or 'embedding' in n or n.endswith('bn.weight') or p.numel() <= 4096)]
+            for n, p in model.named_parameters():
+                if n in picks:
+                    arrays[f'grad/{n}'] = _np(p.grad)
+            # every grad as a norm: cheap whole-model coverage
+            gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.grad is not None}
+            arrays['gradnorm_keys'] = np.array(list(gn))
+            arrays['gradnorm_vals'] = np.array(list(gn.values()), np.float32)
+            # BN running stats after one train step
+            for n, b in model.named_buffers():
+                if n.endswith('running_mean') and ('dark2' in n or 'dark5' in n):
+                    arrays[f'buf/{n}'] = _np(b)
+        save(name, **arrays)
+        print(f'    {name}: params {nparam / 1e6:.3f} M, logits {tuple(logits.shape)}')
+
+
+def main():
+    torch.set_num_threads(8)
+    setup_reference_imports()
+    which = sys.argv[1:] or ['events', 'embeddings', 'lif', 'blocks', 'models']
+    for w in which:
+        print(f'[{w}]')
+        {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
+         'models': gen_models}[w]()
+    assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
+
+
+if __name__ == '__main__':
+    main()
