@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- event-frames/sec of the SYOLOX-S (T=3) training step on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic raw events already resident in HBM:
+  K1 event histogram (4 micro-slices) -> canvas -> adaptive sampler (arsnn) -> spiking backbone (T=3) -> PAFPN ->
+  head -> SimOTA loss -> backward -> (DDP gradient all-reduce over RCCL) -> Adam step -> reset_net.
+Workload = BASELINE.json configs[1]: SYOLOX-S, Gen1 304x240 sensor (256x320 canvas), T=3, Tm=4, batch 64 per GPU.
+Multi-GPU: data parallel, weak scaling (64 samples per rank), launched by torch.distributed.run.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      achieved algorithmic GB/s of the dominant hand-written HIP kernel family, timed with HIP events
+                on the launch stream inside the timed region;
+  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference) timed on this host, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SENSOR = (240, 304)
+CANVAS = (256, 320)
+OPTS = ['T', '3', 'Tm', '4', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
+        'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True', 'use_spike', 'True', 'spike_fn', 'atan',
+        'input_size', '(256,320)', 'test_size', '(256,320)']
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='samples per GPU')
+    ap.add_argument('--events', type=int, default=200_000, help='events per sample')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(cpu_batch, n_events):
+    """The oracle (a port: torch-CPU restatement validated against the reference) on a bounded sample of the same
+    workload: same model/config, batch ``cpu_batch``, numpy event binning + fwd + bwd + Adam + reset per iteration."""
+    from oracle import events_ref, model_ref, sj_ref
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(80)
+    model = model_ref.build_model(use_spike='True')
+    model.head.use_l1 = True
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    streams = [events_ref.synth_events(n_events, *SENSOR, seed=100 + b) for b in range(cpu_batch)]
+    tg = torch.zeros(cpu_batch, 50, 5)
+    tg[:, 0] = torch.tensor([0, 0.3 * 320, 0.4 * 256, 0.25 * 320, 0.3 * 256])
+    tg[:, 1] = torch.tensor([1, 0.7 * 320, 0.6 * 256, 0.2 * 320, 0.35 * 256])
+
+    def step():
+        frames = np.zeros((cpu_batch, 1, 4, 2) + CANVAS, np.float32)
+        for b, (t, x, y, p) in enumerate(streams):
+            frames[b, 0, :, :, :SENSOR[0], :SENSOR[1]] = events_ref.micro_sum(t, x, y, p, 4, *SENSOR)
+        out = model(torch.from_numpy(frames), tg)
+        opt.zero_grad()
+        out['total_loss'].backward()
+        opt.step()
+        sj_ref.reset_net(model)
+
+    step()                                   # warm-up (allocator, thread pools)
+    n, t0 = 0, time.time()
+    while True:
+        step()
+        n += 1
+        el = time.time() - t0
+        if el > 12.0 or n >= 5:
+            break
+    return {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle (torch-CPU fp32) SYOLOX-S T=3 256x320 fwd+bwd+Adam, batch {cpu_batch}, {n} iterations, '
+                      f'{n_events} events/sample binned with numpy'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
+    assert world == args.gpus or world == 1, f'launched {world} ranks for --gpus {args.gpus}'
+
+    import eas_snn_amd
+    from eas_snn_amd import data, ops
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    eas_snn_amd.hip_library()
+    ops.set_state_writeback(False)           # every step ends with reset_net (as yolox/core/trainer.py:115-117)
+
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(OPTS)
+    torch.manual_seed(80)
+    model = exp.get_model().to(dev)
+    model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
+    opt = exp.get_optimizer(args.batch * world)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
+
+    ev = data.events_to_device(data.synth_event_batch(args.batch, args.events, *SENSOR, seed=rank), dev)
+    targets = data.synth_targets(args.batch, CANVAS, dev)
+
+    def step():
+        frames = data.events_to_frames(ev, exp.Tm, SENSOR, CANVAS)
+        out = net(frames, targets)
+        opt.zero_grad(set_to_none=True)
+        out['total_loss'].backward()
+        opt.step()
+        functional.reset_net(model)
+        return out['total_loss']
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer() if rank == 0 else None
+    ops.set_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el)
+    assert torch.isfinite(loss), 'training step produced a non-finite loss'
+
+    if rank == 0:
+        frames_total = args.batch * world * args.steps
+        summ = timer.summary()
+        fam = {k: dict(calls=v['calls'], ms_per_step=round(v['ms'] / args.steps, 4),
+                       GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None) for k, v in summ.items()}
+        dom = max(summ, key=lambda k: summ[k]['ms'])
+        d = summ[dom]
+        achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': dom,
+                    'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'hip_kernel_ms_per_step': fam,
+                    'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / (elapsed * 1e3), 4)}
+        line = {'metric': 'event-frames/sec (T=3) SYOLOX-S Gen1 304x240', 'value': round(frames_total / elapsed, 2),
+                'unit': 'event-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, batch 64/GPU, '
+                                       'raw events -> histogram -> fwd + bwd + Adam + reset_net',
+                           'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}'},
+                'roofline': roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.events)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

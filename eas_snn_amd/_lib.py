@@ -1,0 +1,93 @@
+"""ctypes binding of libeas_hip.so (the C ABI declared in include/eas_hip.h).
+
+There is NO CPU fallback: if the library is missing every op raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C eas_snn_amd/csrc``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeas_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_lib = None
+
+_f32p, _i32p, _u32p, _u16p, _u8p, _i64p, _f64p = (C.c_void_p,) * 7   # raw device addresses
+_P = C.c_void_p
+
+# name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
+PROTOTYPES = {
+    'eas_abi_version': (C.c_int, []),
+    'eas_status_string': (C.c_char_p, [C.c_int]),
+    'eas_event_histogram': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    'eas_counts_to_canvas': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'eas_event_voxel_grid': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'eas_lif_fwd': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P, _P, C.c_int, C.c_int64, _P]),
+    'eas_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
+                              _P, _P, _P, C.c_int, C.c_int64, _P]),
+    'eas_reduce_workspace_floats': (C.c_int64, [C.c_int64]),
+    'eas_time_mean': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
+    'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
+    'eas_bn_workspace_doubles': (C.c_int64, [C.c_int]),
+    'eas_bn_lif_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_bn_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                 C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, _P]),
+    'eas_arsnn_step_bwd': (C.c_int, [_P] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                                 C.c_float, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_arsnn_tail_fwd': (C.c_int, [_P] * 6 + [C.c_int] * 7 + [_P]),
+    'eas_arsnn_tail_bwd': (C.c_int, [_P] * 6 + [C.c_int] * 7 + [_P]),
+}
+
+
+class EasHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into eas_snn_amd/libeas_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise EasHipError('building libeas_hip.so failed')
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EasHipError(
+                f'{LIB_PATH} is missing: the HIP extension has not been built and eas_snn_amd has no CPU fallback. '
+                'Run `python -c "import __graft_entry__ as g; g.build()"`.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)      # AttributeError = ABI mismatch, also loud
+            fn.restype = res
+            fn.argtypes = args
+        if handle.eas_abi_version() != 1:
+            raise EasHipError('libeas_hip.so ABI version mismatch; rebuild')
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().eas_status_string(status).decode()
+        raise EasHipError(f'{what}: status {status} ({msg})')
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

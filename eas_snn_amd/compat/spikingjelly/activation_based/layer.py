@@ -1,0 +1,76 @@
+"""Multi-step containers (spikingjelly ``layer.SeqToANNContainer`` / ``layer.BatchNorm2d``), call sites
+yolox/utils/utils_snn.py:24-32.  ``BatchNorm2d`` stays a subclass of ``nn.BatchNorm2d`` (isinstance checks at
+yolox/exp/event_yolox_base.py:181,366,392 and yolox/utils/allreduce_norm.py:14-21 rely on it)."""
+import torch
+import torch.nn as nn
+
+from eas_snn_amd import ops
+
+from . import base, functional
+
+
+class SeqToANNContainer(nn.Sequential, base.StepModule):
+    """Folds [T, N] into the batch axis around stateless modules (child keys '0', '1', ... as upstream)."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self._step_mode = 'm'
+
+    def supported_step_mode(self):
+        return ('m',)
+
+    def forward(self, x_seq):
+        return functional.seq_to_ann_forward(x_seq, super().forward)
+
+
+class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, step_mode='s'):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.step_mode = step_mode
+
+    def extra_repr(self):
+        return super().extra_repr() + f', step_mode={self.step_mode}'
+
+    def forward(self, x):
+        if self.step_mode == 's':
+            if x.dim() != 4:
+                raise ValueError(f'expected x with shape [N, C, H, W], but got x with shape {x.shape}!')
+            return super().forward(x)
+        if x.dim() != 5:
+            raise ValueError(f'expected x with shape [T, N, C, H, W], but got x with shape {x.shape}!')
+        return functional.seq_to_ann_forward(x, super().forward)   # statistics over T*N*H*W per channel
+
+    # ---- fused path: BN + following LIF neuron in one HIP kernel pair (eas_bn_lif_*)
+    def _use_batch_stats(self):
+        return self.training or (self.running_mean is None and self.running_var is None)
+
+    def fused_with(self, node, y_seq, want_mean=False):
+        """spikes = node(self(y_seq)) for y_seq [T,N,C,H,W] without materialising the BN output."""
+        if not (self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
+                and (self.momentum is not None or not self.training)):
+            out = node(self(y_seq))
+            return (out, ops.time_mean(out)) if want_mean else out
+        batch = self._use_batch_stats()
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        a = node.lif_args()
+        update = batch and self.training and self.track_running_stats
+        spikes, v_out, mean = ops.bn_lif_multistep(
+            y_seq, self.weight, self.bias, self.running_mean if (update or not batch) else None,
+            self.running_var if (update or not batch) else None, batch, self.momentum if update else None, self.eps,
+            node._v_in(y_seq[0]), a['w'], a['k_const'], a['v_th'], a['v_reset'], a['flags'], a['surrogate'], a['alpha'],
+            want_mean=want_mean)
+        if v_out is not None:
+            node.v = v_out
+        return (spikes, mean) if want_mean else spikes
+
+
+class Conv2d(nn.Conv2d, base.StepModule):
+    def __init__(self, *args, step_mode='s', **kwargs):
+        super().__init__(*args, **kwargs)
+        self.step_mode = step_mode
+
+    def forward(self, x):
+        if self.step_mode == 's':
+            return super().forward(x)
+        return functional.seq_to_ann_forward(x, super().forward)

@@ -1,0 +1,98 @@
+"""Event -> frame embeddings in front of the network (reference: yolox/models/embedding.py).
+
+``AdaptiveRSNNEmbedding`` ("arsnn") is the adaptive sampling module: a recurrent conv-SNN over the Tm
+micro-slices whose spikes decide, per pixel, where one adaptive frame ends and the next begins.  Here the
+whole loop is one autograd node over HIP kernels (eas_snn_amd.ops.arsnn_forward); parameter names equal the
+reference's (``gate_conv.0.weight``, ``input_conv.2.bias``, ...).  The simpler embeddings ("count", "rsnn",
+"snn") are thin tensor programs around the same kernels."""
+import copy
+
+import torch
+import torch.nn as nn
+
+from eas_snn_amd import ops
+
+from .activation import Rectangle
+
+
+def _conv_stack(cin, cout, k, depth):
+    mods = [nn.Conv2d(cin, cout, k, padding=k // 2)]
+    for _ in range(int(depth) - 1):
+        mods += [nn.ReLU(inplace=True), nn.Conv2d(cout, cout, k, padding=k // 2)]
+    return nn.Sequential(*mods)
+
+
+def _stack_params(seq):
+    out = []
+    for m in seq:
+        if isinstance(m, nn.Conv2d):
+            out += [m.weight, m.bias]
+    return out
+
+
+def _time_major(events):
+    """[B,Tl,Tm,2,H,W] | [B,Tm,2,H,W] -> [Tm, N, 2, H, W] with the newest micro-slice first (embedding.py:147-156)."""
+    lead = None
+    if events.dim() > 5:
+        lead = events.shape[:-4]
+        events = events.flatten(end_dim=-5)
+    return torch.flip(events.transpose(0, 1), dims=[0]).contiguous(), lead
+
+
+def _check_spike_fn(kwargs_spikes):
+    fn = kwargs_spikes.get('spike_fn', Rectangle)
+    if fn is not Rectangle:
+        raise NotImplementedError('the HIP sampler implements the Rectangle spike function '
+                                  '(the only one EventExp.get_kwargs_spikes passes)')
+
+
+class SpikeCountEmbedding(nn.Module):
+    def __init__(self, nb_steps):
+        super().__init__()
+        self.nb_steps = nb_steps
+
+    def forward(self, events):
+        if events.dim() < 5:
+            return events.unsqueeze(0).expand(self.nb_steps, *events.shape).sum(0)
+        ev, _ = _time_major(events)
+        return ev.sum(axis=0)
+
+
+class AdaptiveRSNNEmbedding(nn.Module):
+    def __init__(self, kernel_size, in_channel=2, out_channel=2, Ts=1, split=False, spike_attach=False, write_zero=False,
+                 abs=False, depth=1, readout='sum', **kwargs_spikes):
+        super().__init__()
+        if split:
+            raise NotImplementedError('split=True builds extra convs the reference never uses in forward')
+        _check_spike_fn(kwargs_spikes)
+        self.kernel_size, self.Ts, self.abs, self.split, self.readout = kernel_size, Ts, abs, split, readout
+        self.write_zero, self.spike_attach = write_zero, spike_attach
+        self.kwargs_spikes = kwargs_spikes
+        self.nb_steps = kwargs_spikes['Tm'] if 'Tm' in kwargs_spikes else kwargs_spikes['nb_steps']
+        self.thresh = kwargs_spikes['thresh']
+        self.vreset = copy.deepcopy(kwargs_spikes['vreset'])
+        self.depth = int(depth)
+        self.gate_conv = _conv_stack(out_channel, out_channel * 2, kernel_size, self.depth)
+        self.input_conv = _conv_stack(in_channel, out_channel * 2, kernel_size, self.depth)
+        self._init_weight()
+
+    def _init_weight(self):
+        for m in self.input_conv.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.orthogonal_(m.weight, gain=nn.init.calculate_gain('relu'))
+        for m in self.gate_conv.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, nonlinearity='sigmoid')
+
+    def forward(self, events, record=False, v_record=False):
+        if events.dim() < 5:        # parameter-registration passthrough used by get_model_info (embedding.py:144-146)
+            return events.unsqueeze(0).expand(self.Ts, *events.shape)
+        if v_record:
+            raise NotImplementedError('v_record is a debugging output of the reference and is not provided')
+        ev, _ = _time_major(events)
+        if ev.shape[0] != self.nb_steps:
+            raise ValueError(f'expected {self.nb_steps} micro-slices, got {ev.shape[0]}')
+        agg, rec = ops.arsnn_forward(ev, _stack_params(self.input_conv), _stack_params(self.gate_conv), self.kernel_size,
+                                     self.Ts, self.readout, self.spike_attach, self.write_zero, self.abs,
+                                     float(self.thresh), None if self.vreset is None else float(self.vreset), record=record)
+        return (agg, rec.long()) if record else agg

@@ -1,0 +1,100 @@
+"""Conv/BN/activation topology of (spiking) YOLOX.  Mirrors the module and attribute names of the reference
+(yolox/models/network_blocks.py:31-213) so ``state_dict`` keys are identical and published checkpoints load.
+
+What is different: once ``convert_to_spiking`` has swapped ``bn``/``act`` for the multi-step BatchNorm and a
+spiking neuron, ``BaseConv.forward`` runs conv -> [BN + LIF fused in one HIP kernel pair] instead of three
+separate module calls."""
+import torch
+import torch.nn as nn
+
+from spikingjelly.activation_based import layer as sj_layer
+from spikingjelly.activation_based import neuron as sj_neuron
+
+
+def get_activation(name='silu', inplace=True):
+    table = {'silu': lambda: nn.SiLU(inplace=inplace), 'relu': lambda: nn.ReLU(inplace=inplace),
+             'lrelu': lambda: nn.LeakyReLU(0.1, inplace=inplace), 'idnt': nn.Identity}
+    if name not in table:
+        raise AttributeError('Unsupported act type: {}'.format(name))
+    return table[name]()
+
+
+class BaseConv(nn.Module):
+    """Conv2d -> BatchNorm -> activation (spiking: SeqToANNContainer(Conv2d) -> BN('m') -> PLIF)."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act='silu'):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=(ksize - 1) // 2,
+                              groups=groups, bias=bias)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.act = get_activation(act, inplace=True)
+        self.emit_rate = False     # spiking only: also return the firing rate (mean over T) from the fused kernel
+
+    def forward(self, x):
+        if isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d):
+            return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate)
+        return self.act(self.bn(self.conv(x)))
+
+    def fuseforward(self, x):
+        return self.act(self.conv(x))
+
+
+class DWConv(nn.Module):
+    def __init__(self, in_channels, out_channels, ksize, stride=1, act='silu'):
+        super().__init__()
+        self.dconv = BaseConv(in_channels, in_channels, ksize=ksize, stride=stride, groups=in_channels, act=act)
+        self.pconv = BaseConv(in_channels, out_channels, ksize=1, stride=1, groups=1, act=act)
+
+    def forward(self, x):
+        return self.pconv(self.dconv(x))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act='silu'):
+        super().__init__()
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = (DWConv if depthwise else BaseConv)(hidden, out_channels, 3, stride=1, act=act)
+        self.use_add = shortcut and in_channels == out_channels
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + x if self.use_add else y      # SEW residual: spike sums 0/1/2 when spiking
+
+
+class SPPBottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_sizes=(5, 9, 13), activation='silu'):
+        super().__init__()
+        hidden = in_channels // 2
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=activation)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=ks, stride=1, padding=ks // 2) for ks in kernel_sizes])
+        self.conv2 = BaseConv(hidden * (len(kernel_sizes) + 1), out_channels, 1, stride=1, act=activation)
+
+    def forward(self, x):
+        x = self.conv1(x)
+        return self.conv2(torch.cat([x] + [m(x) for m in self.m], dim=-3))
+
+
+class CSPLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, n=1, shortcut=True, expansion=0.5, depthwise=False, act='silu'):
+        super().__init__()
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
+        self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
+
+    def forward(self, x):
+        return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), dim=-3))
+
+
+class Focus(nn.Module):
+    """space-to-depth (2x2 -> 4C) followed by a conv; stays an ANN block inside the spiking backbone."""
+
+    def __init__(self, in_channels, out_channels, ksize=1, stride=1, act='silu'):
+        super().__init__()
+        self.conv = BaseConv(in_channels * 4, out_channels, ksize, stride, act=act)
+
+    def forward(self, x):
+        parts = (x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2])
+        return self.conv(torch.cat(parts, dim=1))

@@ -1,0 +1,204 @@
+"""Decoupled YOLOX head with the SimOTA loss (reference: yolox/models/yolo_head.py:18-560,
+spiking_yolo_head.py:18-270).  Module names equal the reference's (checkpoint keys).
+
+The loss is the same computation as the reference's per-image loop, restated batch-wide with masks so the
+step issues no device->host synchronisation (the reference syncs several times per image:
+``int(nlabel[b])``, ``.item()`` in simota_matching, boolean-mask indexing)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from eas_snn_amd import ops
+from yolox.utils.utils_snn import convert_to_spiking
+
+from .losses import IOUloss
+from .network_blocks import BaseConv, DWConv
+
+
+def _grid(h, w, device, dtype):
+    yv, xv = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
+    return torch.stack((xv, yv), 2).view(1, -1, 2).to(dtype)
+
+
+class YOLOXHead(nn.Module):
+    def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act='silu',
+                 depthwise=False):
+        super().__init__()
+        self.num_classes = num_classes
+        self.decode_in_inference = True
+        self.cls_convs, self.reg_convs = nn.ModuleList(), nn.ModuleList()
+        self.cls_preds, self.reg_preds, self.obj_preds = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.stems = nn.ModuleList()
+        Conv = DWConv if depthwise else BaseConv
+        hid = int(256 * width)
+        for c in in_channels:
+            self.stems.append(BaseConv(int(c * width), hid, ksize=1, stride=1, act=act))
+            self.cls_convs.append(nn.Sequential(Conv(hid, hid, 3, 1, act=act), Conv(hid, hid, 3, 1, act=act)))
+            self.reg_convs.append(nn.Sequential(Conv(hid, hid, 3, 1, act=act), Conv(hid, hid, 3, 1, act=act)))
+            self.cls_preds.append(nn.Conv2d(hid, self.num_classes, 1, 1, 0))
+            self.reg_preds.append(nn.Conv2d(hid, 4, 1, 1, 0))
+            self.obj_preds.append(nn.Conv2d(hid, 1, 1, 1, 0))
+        self.use_l1 = False
+        self.l1_loss = nn.L1Loss(reduction='none')
+        self.bcewithlog_loss = nn.BCEWithLogitsLoss(reduction='none')
+        self.iou_loss = IOUloss(reduction='none')
+        self.strides = strides
+        self.full_spike = False
+
+    def initialize_biases(self, prior_prob):
+        for preds in (self.cls_preds, self.obj_preds):
+            for m in preds.modules():
+                if isinstance(m, nn.Conv2d):
+                    b = m.bias.view(1, -1)
+                    b.data.fill_(-math.log((1 - prior_prob) / prior_prob))
+                    m.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    # ---- per-level raw predictions
+    def _level(self, k, x):
+        x = self.stems[k](x)
+        cls_feat = self.cls_convs[k](x)
+        reg_feat = self.reg_convs[k](x)
+        cls_out, reg_out, obj_out = self.cls_preds[k](cls_feat), self.reg_preds[k](reg_feat), self.obj_preds[k](reg_feat)
+        if self.full_spike:        # mean input current over T (spiking_yolo_head.py:175-178)
+            cls_out, reg_out, obj_out = ops.time_mean(cls_out), ops.time_mean(reg_out), ops.time_mean(obj_out)
+        return reg_out, obj_out, cls_out
+
+    def _prepare(self, x):
+        return x
+
+    def forward(self, xin, labels=None, imgs=None):
+        outputs, origin_preds, grids, strides = [], [], [], []
+        for k, (stride, x) in enumerate(zip(self.strides, xin)):
+            reg_out, obj_out, cls_out = self._level(k, self._prepare(x))
+            if self.training:
+                out = torch.cat([reg_out, obj_out, cls_out], 1)
+                B, Cn, H, W = out.shape
+                grid = _grid(H, W, out.device, out.dtype)
+                out = out.flatten(2).permute(0, 2, 1)                           # [B, H*W, 5+nc]
+                out = torch.cat([(out[..., :2] + grid) * stride, torch.exp(out[..., 2:4]) * stride, out[..., 4:]], -1)
+                grids.append(grid)
+                strides.append(torch.full((1, H * W), float(stride), device=out.device, dtype=out.dtype))
+                if self.use_l1:
+                    origin_preds.append(reg_out.flatten(2).permute(0, 2, 1))
+            else:
+                out = torch.cat([reg_out, obj_out.sigmoid(), cls_out.sigmoid()], 1)
+            outputs.append(out)
+        if self.training:
+            return self.get_losses(torch.cat(grids, 1), torch.cat(strides, 1), labels, torch.cat(outputs, 1),
+                                   torch.cat(origin_preds, 1) if self.use_l1 else None)
+        self.hw = [o.shape[-2:] for o in outputs]
+        out = torch.cat([o.flatten(start_dim=2) for o in outputs], dim=2).permute(0, 2, 1)
+        return self.decode_outputs(out, dtype=xin[0].type()) if self.decode_in_inference else out
+
+    def decode_outputs(self, outputs, dtype=None):
+        grids, strides = [], []
+        for (h, w), s in zip(self.hw, self.strides):
+            grids.append(_grid(h, w, outputs.device, outputs.dtype))
+            strides.append(torch.full((1, h * w, 1), float(s), device=outputs.device, dtype=outputs.dtype))
+        grids, strides = torch.cat(grids, 1), torch.cat(strides, 1)
+        return torch.cat([(outputs[..., 0:2] + grids) * strides, torch.exp(outputs[..., 2:4]) * strides, outputs[..., 4:]],
+                         dim=-1)
+
+    # ---- SimOTA, batch-wide
+    @torch.no_grad()
+    def _assign(self, grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds, obj_preds, cls_preds):
+        """gt_*: [B, G, ...] (padded, gt_valid marks real rows); preds: [B, A, ...].
+        Returns fg [B,A] bool, matched gt index [B,A], matched IoU [B,A]."""
+        B, G = gt_valid.shape
+        s = strides[0]                                                          # [A]
+        xc = ((grids[0, :, 0] + 0.5) * s)[None, None]                           # [1,1,A]
+        yc = ((grids[0, :, 1] + 0.5) * s)[None, None]
+        dist = (s * 1.5)[None, None]
+        gx, gy = gt_boxes[..., 0:1], gt_boxes[..., 1:2]                         # [B,G,1]
+        deltas = torch.stack([xc - (gx - dist), yc - (gy - dist), (gx + dist) - xc, (gy + dist) - yc], -1)
+        in_centers = (deltas.min(dim=-1).values > 0.0) & gt_valid[..., None]    # [B,G,A]
+        cand = in_centers.any(dim=1)                                            # [B,A] anchors kept by the geometry filter
+
+        # pairwise IoU (cxcywh), yolox/utils/boxes.py:80-104
+        a, b = gt_boxes[:, :, None, :], bbox_preds[:, None, :, :]
+        tl = torch.max(a[..., :2] - a[..., 2:] / 2, b[..., :2] - b[..., 2:] / 2)
+        br = torch.min(a[..., :2] + a[..., 2:] / 2, b[..., :2] + b[..., 2:] / 2)
+        en = (tl < br).to(tl.dtype).prod(dim=-1)
+        area_i = torch.prod(br - tl, -1) * en
+        ious = area_i / (torch.prod(a[..., 2:], -1) + torch.prod(b[..., 2:], -1) - area_i)
+        ious = torch.where(cand[:, None, :] & gt_valid[..., None], ious, torch.zeros_like(ious))
+        iou_cost = -torch.log(ious + 1e-8)
+
+        joint = (cls_preds.float().sigmoid() * obj_preds.float().sigmoid()).sqrt()            # [B,A,nc]
+        onehot = F.one_hot(gt_cls.to(torch.int64).clamp(0, self.num_classes - 1), self.num_classes).float()   # [B,G,nc]
+        cls_cost = F.binary_cross_entropy(joint[:, None].expand(B, G, -1, -1), onehot[:, :, None].expand(-1, -1, joint.shape[1], -1),
+                                          reduction='none').sum(-1)                          # [B,G,A]
+        cost = cls_cost + 3.0 * iou_cost + float(1e6) * (~in_centers)
+        big = torch.full_like(cost, 1e12)
+        cost = torch.where(cand[:, None, :] & gt_valid[..., None], cost, big)
+
+        kk = min(10, ious.shape[-1])
+        topk_ious, _ = torch.topk(ious, kk, dim=-1)
+        dyn_k = torch.clamp(topk_ious.sum(-1).int(), min=1)                                   # [B,G]
+        _, pos = torch.topk(cost, kk, dim=-1, largest=False)                                  # [B,G,kk]
+        take = (torch.arange(kk, device=cost.device)[None, None] < dyn_k[..., None]) & gt_valid[..., None]
+        match = torch.zeros_like(cost, dtype=torch.bool)
+        match.scatter_(-1, pos, take)
+        match &= cand[:, None, :]
+        per_anchor = match.sum(1)                                                             # [B,A]
+        multi = per_anchor > 1
+        best = cost.argmin(dim=1)                                                             # [B,A]
+        only_best = F.one_hot(best, G).permute(0, 2, 1).bool()                                # [B,G,A]
+        match = torch.where(multi[:, None, :], only_best, match)
+        fg = per_anchor > 0
+        matched = match.to(torch.int8).argmax(1)
+        matched_iou = (match * ious).sum(1)
+        return fg, matched, matched_iou
+
+    def get_losses(self, grids, strides, labels, outputs, origin_preds):
+        bbox_preds, obj_preds, cls_preds = outputs[:, :, :4], outputs[:, :, 4:5], outputs[:, :, 5:]
+        B, A = outputs.shape[:2]
+        nlabel = (labels.sum(dim=2) > 0).sum(dim=1)                                           # [B]
+        G = labels.shape[1]
+        if B * G * A * self.num_classes > (1 << 27):                                          # bound the [B,G,A,nc] cost tensor
+            G = max(int(nlabel.max()), 1)
+        gt_valid = torch.arange(G, device=labels.device)[None] < nlabel[:, None]
+        gt_cls, gt_boxes = labels[:, :G, 0], labels[:, :G, 1:5]
+        fg, matched, matched_iou = self._assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds.detach(),
+                                                obj_preds.detach(), cls_preds.detach())
+        num_fg = fg.sum().to(outputs.dtype).clamp(min=1)
+        num_gts = nlabel.sum().to(outputs.dtype).clamp(min=1)
+        fgf = fg.to(outputs.dtype)
+        idx = matched[..., None]
+        reg_t = torch.gather(gt_boxes, 1, idx.expand(-1, -1, 4))                              # [B,A,4]
+        cls_id = torch.gather(gt_cls, 1, matched).to(torch.int64).clamp(0, self.num_classes - 1)
+        cls_t = F.one_hot(cls_id, self.num_classes).to(outputs.dtype) * matched_iou[..., None]
+        safe_reg_t = torch.where(fg[..., None], reg_t, bbox_preds.detach())                   # keep masked rows finite
+        loss_iou = (self.iou_loss(bbox_preds.reshape(-1, 4), safe_reg_t.reshape(-1, 4)).view(B, A) * fgf).sum() / num_fg
+        loss_obj = self.bcewithlog_loss(obj_preds.reshape(-1, 1), fgf.reshape(-1, 1)).sum() / num_fg
+        loss_cls = (self.bcewithlog_loss(cls_preds, cls_t) * fgf[..., None]).sum() / num_fg
+        if self.use_l1:
+            s = strides[0][None, :, None]
+            l1_xy = reg_t[..., :2] / s - grids
+            l1_wh = torch.log(torch.where(fg[..., None], reg_t[..., 2:], torch.ones_like(reg_t[..., 2:])) / s + 1e-8)
+            l1_t = torch.cat([l1_xy, l1_wh], -1)
+            loss_l1 = (self.l1_loss(origin_preds, l1_t) * fgf[..., None]).sum() / num_fg
+        else:
+            loss_l1 = 0.0
+        reg_weight = 5.0
+        loss = reg_weight * loss_iou + loss_obj + loss_cls + loss_l1
+        return loss, reg_weight * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / num_gts
+
+
+class SpikingYOLOXHead(YOLOXHead):
+    """reference: yolox/models/spiking_yolo_head.py.  ``full_spike=False``: firing-rate input (mean over T) into the
+    ANN head; ``full_spike=True``: the head itself is converted and its output currents are averaged over T."""
+
+    def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act='silu',
+                 depthwise=False, spike_fn=None, full_spike=False):
+        super().__init__(num_classes, width, strides, in_channels, act, depthwise)
+        self.full_spike = full_spike
+        if full_spike:
+            convert_to_spiking(self, spike_fn=spike_fn)
+
+    def _prepare(self, x):
+        if self.full_spike:
+            return x
+        return x[1] if isinstance(x, tuple) else ops.time_mean(x)

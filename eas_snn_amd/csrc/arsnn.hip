@@ -1,0 +1,245 @@
+// K3: adaptive-sampling recurrent step (AdaptiveRSNNEmbedding), dense masked form.
+// The reference walks fired positions with nonzero() + six gathers/scatters and a host sync per
+// step (yolox/models/embedding.py:181-201).  Here every element updates its own state; each
+// element adds into agg[seg] at most once per step, in step order, so fp32 sums are identical.
+// HBM-bound: per (n,c,hw) per step 16 B conv outputs + 16 B (v, vsum r/w) + 4 B spike + 8 B int state
+// (+ 16 B saved for backward when training).
+#include "eas_common.h"
+
+namespace {
+
+constexpr int VEC = 4;
+
+struct StepCfg {
+    int t, Ts, readout, spike_attach, soft_reset;
+    float thresh, v_reset, sg_alpha;
+    int64_t plane;  // C2 * HW
+    int64_t total;  // N * C2 * HW
+};
+
+__device__ __forceinline__ void step_elem(float g_in, float c_in, float g_rec, float c_rec, float v, float vsum,
+                                          int32_t& seg, int32_t& tl, float* __restrict__ agg, int64_t i,
+                                          const StepCfg& c, float& v_out, float& vsum_out, float& spike, float& gate,
+                                          float& vn) {
+    gate = eas_sigmoidf(g_in + g_rec);
+    const float cur = c_in + c_rec;
+    vn = gate * v + cur;                                  // embedding.py:133
+    spike = (vn - c.thresh) > 0.0f ? 1.0f : 0.0f;         // Rectangle: strict >
+    v_out = c.soft_reset ? vn - c.thresh * spike : vn * (1.0f - spike) + c.v_reset * spike;
+    const float vs1 = vsum + vn;                          // :179
+    if (spike != 0.0f) {
+        if (seg < c.Ts) {
+            float val = c.readout == 0 ? vs1 : (c.readout == 1 ? v_out : vs1 / (float)(c.t - tl));
+            if (c.spike_attach) val = val * spike;
+            agg[(int64_t)seg * c.total + i] += val;       // :194
+        }
+        seg += 1;                                         // :195
+        tl = c.t;                                         // :196
+        vsum_out = 0.0f;                                  // :197
+    } else {
+        vsum_out = vs1;
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void arsnn_step_fwd_kernel(
+    const float* __restrict__ conv_in, const float* __restrict__ conv_rec, const float* __restrict__ v,
+    const float* __restrict__ vsum, int32_t* __restrict__ seg, int32_t* __restrict__ t_last, float* __restrict__ agg,
+    float* __restrict__ v_out, float* __restrict__ vsum_out, float* __restrict__ spike_out,
+    float* __restrict__ gate_save, float* __restrict__ vn_save, int32_t* __restrict__ seg_before,
+    int32_t* __restrict__ tl_before, StepCfg c) {
+    const int64_t ngroups = c.total / VEC;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = g * VEC;
+        const int64_t n = i / c.plane;
+        const int64_t r = i - n * c.plane;
+        const int64_t cb = n * 2 * c.plane + r;
+        const float4 gi = *reinterpret_cast<const float4*>(conv_in + cb);
+        const float4 ci = *reinterpret_cast<const float4*>(conv_in + cb + c.plane);
+        const float4 gr = *reinterpret_cast<const float4*>(conv_rec + cb);
+        const float4 cr = *reinterpret_cast<const float4*>(conv_rec + cb + c.plane);
+        const float4 vv = *reinterpret_cast<const float4*>(v + i);
+        const float4 vs = *reinterpret_cast<const float4*>(vsum + i);
+        int4 sg = *reinterpret_cast<const int4*>(seg + i);
+        int4 tl = *reinterpret_cast<const int4*>(t_last + i);
+        if (seg_before) *reinterpret_cast<int4*>(seg_before + i) = sg;
+        if (tl_before) *reinterpret_cast<int4*>(tl_before + i) = tl;
+        float4 vo, vso, sp, ga, vn;
+        step_elem(gi.x, ci.x, gr.x, cr.x, vv.x, vs.x, sg.x, tl.x, agg, i + 0, c, vo.x, vso.x, sp.x, ga.x, vn.x);
+        step_elem(gi.y, ci.y, gr.y, cr.y, vv.y, vs.y, sg.y, tl.y, agg, i + 1, c, vo.y, vso.y, sp.y, ga.y, vn.y);
+        step_elem(gi.z, ci.z, gr.z, cr.z, vv.z, vs.z, sg.z, tl.z, agg, i + 2, c, vo.z, vso.z, sp.z, ga.z, vn.z);
+        step_elem(gi.w, ci.w, gr.w, cr.w, vv.w, vs.w, sg.w, tl.w, agg, i + 3, c, vo.w, vso.w, sp.w, ga.w, vn.w);
+        *reinterpret_cast<float4*>(v_out + i) = vo;
+        *reinterpret_cast<float4*>(vsum_out + i) = vso;
+        *reinterpret_cast<float4*>(spike_out + i) = sp;
+        *reinterpret_cast<int4*>(seg + i) = sg;
+        *reinterpret_cast<int4*>(t_last + i) = tl;
+        if (gate_save) *reinterpret_cast<float4*>(gate_save + i) = ga;
+        if (vn_save) *reinterpret_cast<float4*>(vn_save + i) = vn;
+    }
+}
+
+// Backward of one step for one element.
+__device__ __forceinline__ void step_elem_bwd(float gv_out, float gvs_out, float gsp, const float* __restrict__ g_agg,
+                                              int64_t i, float v_prev, float vsum_prev, float gate, float vn, int32_t seg_b,
+                                              int32_t tl_b, const StepCfg& c, float& g_gatepre, float& g_cur,
+                                              float& g_v_prev, float& g_vsum_prev) {
+    const float spike = (vn - c.thresh) > 0.0f ? 1.0f : 0.0f;
+    const bool fired = spike != 0.0f;
+    const float vs1 = vsum_prev + vn;
+    float d_vs1 = fired ? 0.0f : gvs_out;   // vsum_out = fired ? 0 : vs1
+    float d_vout = gv_out;
+    float d_s = gsp;
+    if (fired && seg_b < c.Ts) {
+        const float ga = g_agg[(int64_t)seg_b * c.total + i];
+        float d_pre = ga;
+        if (c.spike_attach) {
+            const float v_out = c.soft_reset ? vn - c.thresh : c.v_reset;  // spike == 1 here
+            const float pre = c.readout == 0 ? vs1 : (c.readout == 1 ? v_out : vs1 / (float)(c.t - tl_b));
+            d_s += ga * pre;       // val = pre * spike
+            d_pre = ga * spike;
+        }
+        if (c.readout == 0) d_vs1 += d_pre;
+        else if (c.readout == 1) d_vout += d_pre;
+        else d_vs1 += d_pre / (float)(c.t - tl_b);
+    }
+    float d_vn = d_vs1;                      // vs1 = vsum_prev + vn
+    g_vsum_prev = d_vs1;
+    if (c.soft_reset) {                      // v_out = vn - thresh * s
+        d_vn += d_vout;
+        d_s += d_vout * (-c.thresh);
+    } else {                                 // v_out = vn * (1 - s) + v_reset * s
+        d_vn += d_vout * (1.0f - spike);
+        d_s += d_vout * (c.v_reset - vn);
+    }
+    d_vn += d_s * eas_surrogate_grad(EAS_SG_RECT, c.sg_alpha, vn - c.thresh);
+    g_cur = d_vn;                            // vn = gate * v + cur
+    g_v_prev = d_vn * gate;
+    g_gatepre = (d_vn * v_prev) * gate * (1.0f - gate);
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void arsnn_step_bwd_kernel(
+    const float* __restrict__ g_v_out, const float* __restrict__ g_vsum_out, const float* __restrict__ g_spike,
+    const float* __restrict__ g_agg, const float* __restrict__ v_prev, const float* __restrict__ vsum_prev,
+    const float* __restrict__ gate_save, const float* __restrict__ vn_save, const int32_t* __restrict__ seg_before,
+    const int32_t* __restrict__ tl_before, float* __restrict__ g_conv, float* __restrict__ g_v_prev,
+    float* __restrict__ g_vsum_prev, StepCfg c) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / c.plane;
+        const int64_t r = i - n * c.plane;
+        const int64_t cb = n * 2 * c.plane + r;
+        float gg, gc, gvp, gvsp;
+        step_elem_bwd(g_v_out ? g_v_out[i] : 0.f, g_vsum_out ? g_vsum_out[i] : 0.f, g_spike ? g_spike[i] : 0.f, g_agg, i,
+                      v_prev[i], vsum_prev[i], gate_save[i], vn_save[i], seg_before[i], tl_before[i], c, gg, gc, gvp, gvsp);
+        g_conv[cb] = gg;
+        g_conv[cb + c.plane] = gc;
+        g_v_prev[i] = gvp;
+        g_vsum_prev[i] = gvsp;
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void arsnn_tail_fwd_kernel(const float* __restrict__ v, const float* __restrict__ vsum,
+                                                                   const float* __restrict__ spike_last,
+                                                                   const int32_t* __restrict__ seg,
+                                                                   const int32_t* __restrict__ t_last, float* __restrict__ agg,
+                                                                   int Tm, int Ts, int readout, int write_zero, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (spike_last[i] != 0.0f) continue;
+        const int s = seg[i];
+        if (s >= Ts) continue;
+        float val = readout == 0 ? vsum[i] : (readout == 1 ? v[i] : vsum[i] / (float)(Tm - 1 - t_last[i]));
+        if (write_zero) val = val * 0.0f;   // RPD (embedding.py:215-216); keeps inf/nan -> nan like the reference
+        agg[(int64_t)s * total + i] += val;
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void arsnn_tail_bwd_kernel(const float* __restrict__ g_agg,
+                                                                   const float* __restrict__ spike_last,
+                                                                   const int32_t* __restrict__ seg,
+                                                                   const int32_t* __restrict__ t_last, float* __restrict__ g_v,
+                                                                   float* __restrict__ g_vsum, int Tm, int Ts, int readout,
+                                                                   int write_zero, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float gv = 0.f, gvs = 0.f;
+        const int s = seg[i];
+        if (spike_last[i] == 0.0f && s < Ts && !write_zero) {
+            const float ga = g_agg[(int64_t)s * total + i];
+            if (readout == 0) gvs = ga;
+            else if (readout == 1) gv = ga;
+            else gvs = ga / (float)(Tm - 1 - t_last[i]);
+        }
+        g_v[i] = gv;
+        g_vsum[i] = gvs;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float* v, const float* vsum,
+                       int32_t* seg, int32_t* t_last, float* agg, float* v_out, float* vsum_out, float* spike_out,
+                       float* gate_save, float* vn_save, int32_t* seg_before, int32_t* t_last_before, int t,
+                       int Ts, int readout, int spike_attach, float thresh, float v_reset, int soft_reset, int N,
+                       int C2, int HW, eas_stream_t stream) {
+    if (!conv_in || !conv_rec || !v || !vsum || !seg || !t_last || !agg || !v_out || !vsum_out || !spike_out)
+        return EAS_ERR_INVALID_ARG;
+    if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 2) return EAS_ERR_INVALID_ARG;
+    if (HW % VEC != 0) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)conv_in | (uintptr_t)conv_rec | (uintptr_t)v | (uintptr_t)vsum | (uintptr_t)seg | (uintptr_t)t_last |
+         (uintptr_t)v_out | (uintptr_t)vsum_out | (uintptr_t)spike_out | (uintptr_t)gate_save | (uintptr_t)vn_save |
+         (uintptr_t)seg_before | (uintptr_t)t_last_before) & 15)
+        return EAS_ERR_INVALID_ARG;
+    StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, 1.0f, (int64_t)C2 * HW, (int64_t)N * C2 * HW};
+    hipLaunchKernelGGL(arsnn_step_fwd_kernel, dim3(eas_grid_1d(c.total / VEC)), dim3(EAS_BLOCK), 0, eas_s(stream), conv_in,
+                       conv_rec, v, vsum, seg, t_last, agg, v_out, vsum_out, spike_out, gate_save, vn_save, seg_before,
+                       t_last_before, c);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const float* g_spike, const float* g_agg,
+                       const float* v_prev, const float* vsum_prev, const float* gate_save, const float* vn_save,
+                       const int32_t* seg_before, const int32_t* t_last_before, float* g_conv, float* g_v_prev,
+                       float* g_vsum_prev, int t, int Ts, int readout, int spike_attach, float thresh,
+                       float v_reset, int soft_reset, float sg_alpha, int N, int C2, int HW, eas_stream_t stream) {
+    if (!g_agg || !v_prev || !vsum_prev || !gate_save || !vn_save || !seg_before || !t_last_before || !g_conv ||
+        !g_v_prev || !g_vsum_prev)
+        return EAS_ERR_INVALID_ARG;
+    if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 2 || !(sg_alpha > 0.f))
+        return EAS_ERR_INVALID_ARG;
+    StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, sg_alpha, (int64_t)C2 * HW,
+              (int64_t)N * C2 * HW};
+    hipLaunchKernelGGL(arsnn_step_bwd_kernel, dim3(eas_grid_1d(c.total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_v_out,
+                       g_vsum_out, g_spike, g_agg, v_prev, vsum_prev, gate_save, vn_save, seg_before, t_last_before, g_conv,
+                       g_v_prev, g_vsum_prev, c);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_arsnn_tail_fwd(const float* v, const float* vsum, const float* spike_last, const int32_t* seg,
+                       const int32_t* t_last, float* agg, int Tm, int Ts, int readout, int write_zero, int N,
+                       int C2, int HW, eas_stream_t stream) {
+    if (!v || !vsum || !spike_last || !seg || !t_last || !agg || N < 1 || C2 < 1 || HW < 1 || Ts < 1 || readout < 0 ||
+        readout > 2)
+        return EAS_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)N * C2 * HW;
+    hipLaunchKernelGGL(arsnn_tail_fwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), v, vsum,
+                       spike_last, seg, t_last, agg, Tm, Ts, readout, write_zero, total);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int32_t* seg, const int32_t* t_last,
+                       float* g_v, float* g_vsum, int Tm, int Ts, int readout, int write_zero, int N, int C2,
+                       int HW, eas_stream_t stream) {
+    if (!g_agg || !spike_last || !seg || !t_last || !g_v || !g_vsum || N < 1 || C2 < 1 || HW < 1 || Ts < 1 ||
+        readout < 0 || readout > 2)
+        return EAS_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)N * C2 * HW;
+    hipLaunchKernelGGL(arsnn_tail_bwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_agg, spike_last,
+                       seg, t_last, g_v, g_vsum, Tm, Ts, readout, write_zero, total);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+}  // extern "C"

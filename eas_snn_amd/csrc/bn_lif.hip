@@ -1,0 +1,431 @@
+// K4 (second half): BatchNorm(step_mode='m') + multi-step LIF fused, forward and backward.
+//
+// Data: y = conv output, [T][N][C][HW] fp32.  BN statistics couple all of T*N*HW per channel, so
+// training needs a statistics pass before the fused apply pass (SURVEY "Hard parts").
+// Work decomposition for every kernel here: blockIdx.y = channel c, blockIdx.x = chunk of that
+// channel's N*HW/4 float4 groups.  Per-channel constants (scale, shift, means) are block-uniform,
+// reductions are per block -> per (channel, chunk) partial -> fixed-order finalize (deterministic).
+// Reads are contiguous runs of HW floats (one (n,c) plane), 16 B per lane.
+//
+// HBM traffic per neuron-step: stats 4 B (read y); fwd 8 B (read y, write s);
+// bwd 20 B (pass 1 reads y, grad_s; pass 2 reads them again and writes grad_y).  Only y is kept
+// for backward: h_t is recomputed in registers from y (T <= 8).
+#include "eas_common.h"
+
+namespace {
+
+constexpr int VEC = 4;
+constexpr int kMaxChunks = 64;
+constexpr int NW = EAS_BLOCK / EAS_WAVE;
+
+static inline int pick_chunks(int64_t groups_per_channel, int C) {
+    int64_t want = (groups_per_channel + EAS_BLOCK - 1) / EAS_BLOCK;  // one group per thread
+    int64_t cap = 8192 / (C > 0 ? C : 1);                                // keep the grid around <= 8k blocks
+    if (cap < 1) cap = 1;
+    if (cap > kMaxChunks) cap = kMaxChunks;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+// ------------------------------------------------------------------------------------------------ stats
+__global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial(const float* __restrict__ y, int TN, int C, int HW,
+                                                              double* __restrict__ part) {
+    __shared__ double red[NW];
+    const int c = blockIdx.y;
+    const int hw4 = HW / VEC;
+    const int64_t groups = (int64_t)TN * hw4;
+    double s = 0.0, ss = 0.0;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / hw4;
+        const int q = (int)(g - n * hw4);
+        const float4 v = reinterpret_cast<const float4*>(y + ((n * C + c) * (int64_t)HW))[q];
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    const double ts = eas_block_sum<double, NW>(s, red);
+    const double tss = eas_block_sum<double, NW>(ss, red);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 0] = ts;
+        part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 1] = tss;
+    }
+}
+
+// scalar path for HW % 4 != 0
+__global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial_scalar(const float* __restrict__ y, int TN, int C, int HW,
+                                                                     double* __restrict__ part) {
+    __shared__ double red[NW];
+    const int c = blockIdx.y;
+    const int64_t groups = (int64_t)TN * HW;
+    double s = 0.0, ss = 0.0;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / HW;
+        const int q = (int)(g - n * HW);
+        const float v = y[(n * C + c) * (int64_t)HW + q];
+        s += v;
+        ss += (double)v * v;
+    }
+    const double ts = eas_block_sum<double, NW>(s, red);
+    const double tss = eas_block_sum<double, NW>(ss, red);
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 0] = ts;
+        part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 1] = tss;
+    }
+}
+
+__global__ __launch_bounds__(EAS_WAVE) void bn_stats_finalize(const double* __restrict__ part, int nchunks, double count,
+                                                              float eps, float momentum, float* __restrict__ mean,
+                                                              float* __restrict__ invstd, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar) {
+    const int c = blockIdx.x;
+    double s = 0.0, ss = 0.0;
+    if ((int)threadIdx.x < nchunks) {
+        s = part[((int64_t)c * kMaxChunks + threadIdx.x) * 2 + 0];
+        ss = part[((int64_t)c * kMaxChunks + threadIdx.x) * 2 + 1];
+    }
+    s = eas_wave_sum(s);
+    ss = eas_wave_sum(ss);
+    if (threadIdx.x == 0) {
+        const double m = s / count;
+        double var = ss / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int T_, bool HARD, bool DI, bool STRICT>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* v_in, float* v_out,
+                                                               EasLifParams p, float* __restrict__ spikes,
+                                                               float* __restrict__ mean_out, int N, int C, int HW) {
+    const int c = blockIdx.y;
+    const float scale = gamma[c] * invstd[c];
+    const float shift = beta[c] - mean[c] * scale;
+    const float k = eas_lif_k(p);
+    const float omk = 1.0f - k;
+    const int hw4 = HW / VEC;
+    const int64_t groups = (int64_t)N * hw4;
+    const int64_t M = (int64_t)N * C * HW;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / hw4;
+        const int q = (int)(g - n * hw4);
+        const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        float4 ys[T_];
+#pragma unroll
+        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * M + base);
+        const float vr0 = HARD ? p.v_reset : 0.0f;
+        float4 v = v_in ? *reinterpret_cast<const float4*>(v_in + base) : make_float4(vr0, vr0, vr0, vr0);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < T_; ++t) {
+            float4 h, s;
+            eas_lif_step<HARD, DI, STRICT>(v.x, fmaf(ys[t].x, scale, shift), k, omk, p.v_th, p.v_reset, h.x, s.x);
+            eas_lif_step<HARD, DI, STRICT>(v.y, fmaf(ys[t].y, scale, shift), k, omk, p.v_th, p.v_reset, h.y, s.y);
+            eas_lif_step<HARD, DI, STRICT>(v.z, fmaf(ys[t].z, scale, shift), k, omk, p.v_th, p.v_reset, h.z, s.z);
+            eas_lif_step<HARD, DI, STRICT>(v.w, fmaf(ys[t].w, scale, shift), k, omk, p.v_th, p.v_reset, h.w, s.w);
+            *reinterpret_cast<float4*>(spikes + (int64_t)t * M + base) = s;
+            acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+        }
+        if (v_out) *reinterpret_cast<float4*>(v_out + base) = v;
+        if (mean_out) {
+            const float Tf = (float)T_;   // sum / T, like ATen's mean
+            *reinterpret_cast<float4*>(mean_out + base) = make_float4(acc.x / Tf, acc.y / Tf, acc.z / Tf, acc.w / Tf);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Recompute h_t from y, then walk the LIF backward: dz[t] = dL/dz_t (z = BN output), dk += dL/dk.
+template <int T_, bool HARD, bool DI, bool STRICT>
+__device__ __forceinline__ void recompute_dz(const float (&yv)[T_], const float (&gs)[T_], float v0, float scale,
+                                             float shift, float k, float omk, const EasLifParams& p, bool detach,
+                                             int sg_id, float alpha, float (&dz)[T_], float& dk) {
+    float h[T_], vprev[T_], z[T_];
+    float v = v0;
+#pragma unroll
+    for (int t = 0; t < T_; ++t) {
+        float s;
+        vprev[t] = v;
+        z[t] = fmaf(yv[t], scale, shift);
+        eas_lif_step<HARD, DI, STRICT>(v, z[t], k, omk, p.v_th, p.v_reset, h[t], s);
+    }
+    float gv = 0.f;
+#pragma unroll
+    for (int t = T_ - 1; t >= 0; --t) {
+        float dkt, gx;
+        eas_lif_step_bwd<HARD, DI, STRICT>(gs[t], gv, h[t], vprev[t], z[t], k, omk, p.v_th, p.v_reset, detach, sg_id,
+                                           alpha, dkt, gx);
+        dz[t] = gx;
+        dk += dkt;
+    }
+}
+
+template <int T_, bool HARD, bool DI, bool STRICT, bool APPLY>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
+    const float* __restrict__ grad_s, const float* __restrict__ grad_mean, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
+    int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+    float* __restrict__ grad_beta, int N, int C, int HW) {
+    __shared__ double red[NW];
+    __shared__ float bc[2];
+    const int c = blockIdx.y;
+    const float mu = mean[c], istd = invstd[c];
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
+    const float k = eas_lif_k(p);
+    const float omk = 1.0f - k;
+    const bool detach = (p.flags & EAS_LIF_DETACH_RESET) != 0;
+    const int hw4 = HW / VEC;
+    const int64_t groups = (int64_t)N * hw4;
+    const int64_t M = (int64_t)N * C * HW;
+    const float invT = 1.0f / (float)T_;
+    float m1 = 0.f, m2 = 0.f;
+    if (APPLY) {
+        // fixed-order reduction of this channel's chunk partials (every block computes the same value)
+        if (threadIdx.x < EAS_WAVE) {
+            double s1 = 0.0, s2 = 0.0;
+            if ((int)threadIdx.x < nchunks) {
+                s1 = part[((int64_t)c * kMaxChunks + threadIdx.x) * 4 + 0];
+                s2 = part[((int64_t)c * kMaxChunks + threadIdx.x) * 4 + 1];
+            }
+            s1 = eas_wave_sum(s1);
+            s2 = eas_wave_sum(s2);
+            if (threadIdx.x == 0) {
+                const double cnt = (double)T_ * N * HW;
+                bc[0] = (float)(s1 / cnt);
+                bc[1] = (float)(s2 / cnt);
+                if (blockIdx.x == 0) {
+                    grad_beta[c] = (float)s1;
+                    grad_gamma[c] = (float)s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
+    }
+    float s1 = 0.f, s2 = 0.f, dk = 0.f;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / hw4;
+        const int q = (int)(g - n * hw4);
+        const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        float4 ys[T_], gsv[T_];
+#pragma unroll
+        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * M + base);
+        float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grad_mean) {
+            gm = *reinterpret_cast<const float4*>(grad_mean + base);
+            gm.x *= invT; gm.y *= invT; gm.z *= invT; gm.w *= invT;
+        }
+#pragma unroll
+        for (int t = 0; t < T_; ++t) {
+            gsv[t] = gm;
+            if (grad_s) {
+                const float4 g4 = *reinterpret_cast<const float4*>(grad_s + (int64_t)t * M + base);
+                gsv[t].x += g4.x; gsv[t].y += g4.y; gsv[t].z += g4.z; gsv[t].w += g4.w;
+            }
+        }
+        const float vr0 = HARD ? p.v_reset : 0.0f;
+        float4 v0 = make_float4(vr0, vr0, vr0, vr0);
+        if (v_init) v0 = *reinterpret_cast<const float4*>(v_init + base);
+        float4 outv[T_];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float yv[T_], gs[T_], dz[T_];
+#pragma unroll
+            for (int t = 0; t < T_; ++t) {
+                yv[t] = reinterpret_cast<const float*>(&ys[t])[e];
+                gs[t] = reinterpret_cast<const float*>(&gsv[t])[e];
+            }
+            const float v0e = reinterpret_cast<const float*>(&v0)[e];
+            float dke = 0.f;
+            recompute_dz<T_, HARD, DI, STRICT>(yv, gs, v0e, scale, shift, k, omk, p, detach, sg_id, alpha, dz, dke);
+#pragma unroll
+            for (int t = 0; t < T_; ++t) {
+                const float xhat = (yv[t] - mu) * istd;
+                if (APPLY) {
+                    reinterpret_cast<float*>(&outv[t])[e] = scale * (dz[t] - m1 - xhat * m2);
+                } else {
+                    s1 += dz[t];
+                    s2 += dz[t] * xhat;
+                }
+            }
+            dk += dke;
+        }
+        if (APPLY) {
+#pragma unroll
+            for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * M + base) = outv[t];
+        }
+    }
+    if (!APPLY) {
+        const double t1 = eas_block_sum<double, NW>((double)s1, red);
+        const double t2 = eas_block_sum<double, NW>((double)s2, red);
+        const double t3 = eas_block_sum<double, NW>((double)dk, red);
+        if (threadIdx.x == 0) {
+            double* o = part + ((int64_t)c * kMaxChunks + blockIdx.x) * 4;
+            o[0] = t1; o[1] = t2; o[2] = t3;
+        }
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_gradw_finalize(const double* __restrict__ part, int C, int nchunks,
+                                                                   const float* __restrict__ w_logit,
+                                                                   float* __restrict__ grad_w) {
+    __shared__ double red[NW];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
+        const int c = i / nchunks, j = i - c * nchunks;
+        acc += part[((int64_t)c * kMaxChunks + j) * 4 + 2];
+    }
+    const double tot = eas_block_sum<double, NW>(acc, red);
+    if (threadIdx.x == 0) {
+        const float k = eas_sigmoidf(*w_logit);
+        *grad_w = (float)tot * (k * (1.0f - k));
+    }
+}
+
+template <int T_, bool HARD, bool DI, bool STRICT>
+int launch_fwd_t(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                 const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
+                 hipStream_t st) {
+    const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
+                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+template <bool HARD, bool DI, bool STRICT>
+int launch_fwd(int T, const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+               const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
+               hipStream_t st) {
+#define EAS_CASE(TT) \
+    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, st);
+    switch (T) {
+        EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
+        default: return EAS_ERR_UNSUPPORTED;
+    }
+#undef EAS_CASE
+}
+
+template <int T_, bool HARD, bool DI, bool STRICT>
+int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
+                 const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
+                 int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
+                 int C, int HW, hipStream_t st) {
+    const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
+                       grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
+                       grad_gamma, grad_beta, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
+                       grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
+                       grad_gamma, grad_beta, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    if (grad_w) {
+        hipLaunchKernelGGL(bn_lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, ws, C, chunks, p.w_logit, grad_w);
+        EAS_CHECK_LAUNCH();
+    }
+    return EAS_OK;
+}
+
+template <bool HARD, bool DI, bool STRICT>
+int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* y, const float* mean,
+               const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
+               float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
+               double* ws, int N, int C, int HW, hipStream_t st) {
+#define EAS_CASE(TT)                                                                                               \
+    case TT:                                                                                                       \
+        return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
+                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, st);
+    switch (T) {
+        EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
+        default: return EAS_ERR_UNSUPPORTED;
+    }
+#undef EAS_CASE
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t eas_bn_workspace_doubles(int C) { return (int64_t)C * kMaxChunks * 4; }
+
+int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                 float* running_mean, float* running_var, double* workspace, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !workspace || TN < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return EAS_ERR_INVALID_ARG;
+    if (C > 65535) return EAS_ERR_UNSUPPORTED;
+    hipStream_t st = eas_s(stream);
+    int chunks;
+    if (HW % VEC == 0 && (((uintptr_t)y) & 15) == 0) {
+        chunks = pick_chunks((int64_t)TN * (HW / VEC), C);
+        hipLaunchKernelGGL(bn_stats_partial, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
+    } else {
+        chunks = pick_chunks((int64_t)TN * HW, C);
+        hipLaunchKernelGGL(bn_stats_partial_scalar, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
+    }
+    EAS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
+                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || !spikes || T < 1 || N < 1 || C < 1 || HW < 1)
+        return EAS_ERR_INVALID_ARG;
+    if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out) & 15) return EAS_ERR_INVALID_ARG;
+    EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
+    const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
+    hipStream_t st = eas_s(stream);
+#define EAS_DISPATCH(H, D, S) \
+    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, st)
+    if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
+    if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
+    if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
+    if (hard && di && !strict) EAS_DISPATCH(true, true, false);
+    return EAS_ERR_UNSUPPORTED;  // strict '>' firing only exists in the sampler / in-repo LIFCell
+#undef EAS_DISPATCH
+}
+
+int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                   const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                   float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                   float* grad_w, double* workspace, int T, int N, int C, int HW, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
+        (!grad_s && !grad_mean) || T < 1 || N < 1 || C < 1 || HW < 1)
+        return EAS_ERR_INVALID_ARG;
+    if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_RECT || !(alpha > 0.f)) return EAS_ERR_INVALID_ARG;
+    if (grad_w && !w_logit) return EAS_ERR_INVALID_ARG;
+    if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)y | (uintptr_t)grad_s | (uintptr_t)grad_mean | (uintptr_t)v_init | (uintptr_t)grad_y) & 15)
+        return EAS_ERR_INVALID_ARG;
+    EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
+    const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
+    hipStream_t st = eas_s(stream);
+#define EAS_DISPATCH(H, D, S)                                                                                       \
+    return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
+                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, st)
+    if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
+    if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
+    if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
+    if (hard && di && !strict) EAS_DISPATCH(true, true, false);
+    return EAS_ERR_UNSUPPORTED;
+#undef EAS_DISPATCH
+}
+
+}  // extern "C"

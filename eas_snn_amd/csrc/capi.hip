@@ -1,0 +1,18 @@
+// ABI bookkeeping for libeas_hip.so.
+#include "eas_common.h"
+
+extern "C" {
+
+int eas_abi_version(void) { return 1; }
+
+const char* eas_status_string(int status) {
+    switch (status) {
+        case EAS_OK: return "ok";
+        case EAS_ERR_INVALID_ARG: return "invalid argument (null/misaligned pointer or bad size)";
+        case EAS_ERR_UNSUPPORTED: return "unsupported configuration for the HIP path";
+        case EAS_ERR_LAUNCH: return "HIP launch/memset failure";
+        default: return "unknown status";
+    }
+}
+
+}  // extern "C"

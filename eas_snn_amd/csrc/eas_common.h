@@ -1,0 +1,119 @@
+// Shared device helpers for libeas_hip.so (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/eas_hip.h"
+
+#define EAS_WAVE 64
+#define EAS_BLOCK 256
+
+#define EAS_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return EAS_ERR_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t eas_s(eas_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// memory-bound grids: cap at 256 CUs x 8 blocks and grid-stride the rest
+static inline int eas_grid_1d(int64_t work_items, int block = EAS_BLOCK, int max_blocks = 2048 * 4) {
+    int64_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+__device__ __forceinline__ float eas_sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// surrogate gradient g'(u), u = h - v_th
+__device__ __forceinline__ float eas_surrogate_grad(int id, float alpha, float u) {
+    if (id == EAS_SG_ATAN) {
+        const float q = 1.57079632679489661923f * alpha * u;
+        return alpha * 0.5f / (1.0f + q * q);
+    } else if (id == EAS_SG_SIGMOID) {
+        const float sg = eas_sigmoidf(alpha * u);
+        return (1.0f - sg) * sg * alpha;
+    } else {  // rectangle: [|u| < 0.5/alpha] * alpha
+        return (fabsf(u) < 0.5f / alpha) ? alpha : 0.0f;
+    }
+}
+
+// ---- wave / block reductions (wave64) ----------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T eas_wave_sum(T v) {
+#pragma unroll
+    for (int off = EAS_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, EAS_WAVE);
+    return v;  // valid in lane 0
+}
+
+// sum over a block of NW waves; result valid in thread 0. `smem` must hold NW values.
+template <typename T, int NW>
+__device__ __forceinline__ T eas_block_sum(T v, T* smem) {
+    const int lane = threadIdx.x & (EAS_WAVE - 1);
+    const int wid = threadIdx.x / EAS_WAVE;
+    v = eas_wave_sum(v);
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    T r = T(0);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += smem[i];
+    }
+    __syncthreads();
+    return r;
+}
+
+struct EasLifParams {
+    const float* w_logit;  // PLIF: k = sigmoid(*w_logit); else k_const
+    float k_const;
+    float v_th;
+    float v_reset;
+    int flags;
+};
+
+__device__ __forceinline__ float eas_lif_k(const EasLifParams& p) {
+    return p.w_logit ? eas_sigmoidf(*p.w_logit) : p.k_const;
+}
+
+// One LIF step, arithmetic ordered like the PyTorch expression it replaces
+// (-ffp-contract=off: every * and + rounds separately, as ATen elementwise kernels do).
+template <bool HARD, bool DI, bool STRICT>
+__device__ __forceinline__ void eas_lif_step(float& v, float x, float k, float omk, float v_th, float v_reset,
+                                             float& h, float& s) {
+    if (DI) {
+        h = HARD ? v + (x - (v - v_reset)) * k : v + (x - v) * k;
+    } else {
+        h = (HARD && v_reset != 0.0f) ? (v - (v - v_reset) * k) + x : v * omk + x;
+    }
+    const float u = h - v_th;
+    s = STRICT ? (u > 0.0f ? 1.0f : 0.0f) : (u >= 0.0f ? 1.0f : 0.0f);
+    v = HARD ? (1.0f - s) * h + s * v_reset : h - s * v_th;
+}
+
+// dL/dh of one step and the pieces the caller needs.
+//   gs: dL/ds_t from the output, gv: dL/dv_t from the future (updated to dL/dv_{t-1} on return)
+//   returns dh = dL/dh_t;  dk_term = dh * dh/dk (for grad of the decay)
+template <bool HARD, bool DI, bool STRICT>
+__device__ __forceinline__ float eas_lif_step_bwd(float gs, float& gv, float h, float v_prev, float x, float k,
+                                                  float omk, float v_th, float v_reset, bool detach, int sg_id,
+                                                  float alpha, float& dk_term, float& gx) {
+    const float u = h - v_th;
+    const float s = STRICT ? (u > 0.0f ? 1.0f : 0.0f) : (u >= 0.0f ? 1.0f : 0.0f);
+    const float sg = eas_surrogate_grad(sg_id, alpha, u);
+    float dvdh;
+    if (HARD) {
+        dvdh = detach ? (1.0f - s) : (1.0f - s) + (v_reset - h) * sg;
+    } else {
+        dvdh = detach ? 1.0f : 1.0f - v_th * sg;
+    }
+    const float dh = gs * sg + gv * dvdh;
+    if (DI) {
+        gx = dh * k;
+        dk_term = dh * (HARD ? (x - (v_prev - v_reset)) : (x - v_prev));
+    } else {
+        gx = dh;
+        dk_term = dh * ((HARD && v_reset != 0.0f) ? -(v_prev - v_reset) : -v_prev);
+    }
+    gv = dh * omk;
+    return dh;
+}

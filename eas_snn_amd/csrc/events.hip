@@ -1,0 +1,181 @@
+// K1: raw (t, x, y, p) event streams -> per-polarity count frames / voxel grids.
+// Integer scatter: HBM/atomic bound.  Algorithmic bytes per sample: 9 B per event read
+// (u32 t + u16 x + u16 y + u8 p) + 4*Tm*2*H*W B for the frames (zero-fill + result).
+// One thread handles 4 consecutive events (16-B / 8-B / 8-B / 4-B vector loads); the atomics are
+// int32 `global_atomic_add` without return, so results are bit-exact and order independent.
+#include "eas_common.h"
+
+namespace {
+
+// sample index of event i: largest b with offsets[b] <= i  (offsets ascending, offsets[B] = nev)
+__device__ __forceinline__ int find_sample(const int64_t* __restrict__ offsets, int B, int64_t i) {
+    int lo = 0, hi = B;  // invariant: offsets[lo] <= i < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+struct SampleWin {
+    uint32_t t0;
+    uint32_t win;  // 0 -> nothing is binned
+};
+
+__device__ __forceinline__ SampleWin sample_window(const uint32_t* __restrict__ t, const int64_t* __restrict__ offsets,
+                                                   int b, int Tm) {
+    const int64_t a = offsets[b], e = offsets[b + 1];
+    SampleWin w;
+    w.t0 = t[a];
+    w.win = (t[e - 1] - w.t0) / (uint32_t)Tm;
+    return w;
+}
+
+__device__ __forceinline__ void bin_one(uint32_t tt, uint32_t xx, uint32_t yy, uint32_t pp, const SampleWin& w, int b,
+                                        int Tm, int H, int W, int32_t* __restrict__ out, uint32_t* __restrict__ oob) {
+    if (w.win == 0) return;
+    const uint32_t k = (tt - w.t0) / w.win;
+    if (k >= (uint32_t)Tm) return;  // tail beyond t0 + Tm*win is dropped (gen1.py:321-326)
+    if (xx >= (uint32_t)W || yy >= (uint32_t)H) {
+        if (oob) atomicAdd(oob, 1u);
+        return;
+    }
+    const int c = pp != 0 ? 1 : 0;
+    const int64_t idx = ((((int64_t)b * Tm + k) * 2 + c) * H + yy) * W + xx;
+    atomicAdd(out + idx, 1);
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(EAS_BLOCK) void event_hist_kernel(const uint32_t* __restrict__ t, const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
+                                                               int64_t nev, const int64_t* __restrict__ offsets, int B,
+                                                               int Tm, int H, int W, int32_t* __restrict__ out,
+                                                               uint32_t* __restrict__ oob) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC4) {
+        const int64_t ngroups = nev / 4;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+            const uint4 tv = reinterpret_cast<const uint4*>(t)[g];
+            const ushort4 xv = reinterpret_cast<const ushort4*>(x)[g];
+            const ushort4 yv = reinterpret_cast<const ushort4*>(y)[g];
+            const uchar4 pv = reinterpret_cast<const uchar4*>(p)[g];
+            const int64_t i0 = g * 4;
+            int b = find_sample(offsets, B, i0);
+            SampleWin w = sample_window(t, offsets, b, Tm);
+            int64_t end = offsets[b + 1];
+            const uint32_t ts[4] = {tv.x, tv.y, tv.z, tv.w};
+            const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const uint32_t ys[4] = {yv.x, yv.y, yv.z, yv.w};
+            const uint32_t ps[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                while (i0 + e >= end) {  // group straddles a sample boundary (also skips empty samples)
+                    ++b;
+                    end = offsets[b + 1];
+                    if (i0 + e < end) w = sample_window(t, offsets, b, Tm);
+                }
+                bin_one(ts[e], xs[e], ys[e], ps[e], w, b, Tm, H, W, out, oob);
+            }
+        }
+        // the last nev % 4 events
+        if (blockIdx.x == 0 && threadIdx.x < (nev & 3)) {
+            const int64_t i = (nev & ~(int64_t)3) + threadIdx.x;
+            const int b = find_sample(offsets, B, i);
+            const SampleWin w = sample_window(t, offsets, b, Tm);
+            bin_one(t[i], x[i], y[i], p[i], w, b, Tm, H, W, out, oob);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += stride) {
+            const int b = find_sample(offsets, B, i);
+            const SampleWin w = sample_window(t, offsets, b, Tm);
+            bin_one(t[i], x[i], y[i], p[i], w, b, Tm, H, W, out, oob);
+        }
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void counts_to_canvas_kernel(const int32_t* __restrict__ counts, int64_t F, int H,
+                                                                     int W, int Hc, int Wc, float* __restrict__ out) {
+    const int64_t total = F * Hc * Wc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wc);
+        const int64_t r = i / Wc;
+        const int yy = (int)(r % Hc);
+        const int64_t f = r / Hc;
+        out[i] = (xx < W && yy < H) ? (float)counts[(f * H + yy) * W + xx] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void voxel_grid_kernel(const uint32_t* __restrict__ t, const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
+                                                               int64_t nev, const int64_t* __restrict__ offsets, int B,
+                                                               int nb, int H, int W, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = find_sample(offsets, B, i);
+        const int64_t a = offsets[b], e = offsets[b + 1];
+        const double t0 = (double)t[a];
+        const double span = (double)t[e - 1] - t0;
+        if (span == 0.0) continue;  // single-timestamp stream: declared invalid, left zero
+        const uint32_t xx = x[i], yy = y[i];
+        if (xx >= (uint32_t)W || yy >= (uint32_t)H) continue;
+        // same operation order as event_reps.py:53-57 in float64
+        const double ts = (double)nb * ((double)t[i] - t0) / span;
+        const int64_t ti = (int64_t)ts;
+        const double dt = ts - (double)ti;
+        const double pol = p[i] != 0 ? 1.0 : -1.0;
+        double* base = out + (int64_t)b * nb * H * W + (int64_t)yy * W + xx;
+        if (ti < nb) atomicAdd(base + ti * H * W, pol * (1.0 - dt));
+        if (ti + 1 < nb) atomicAdd(base + (ti + 1) * H * W, pol * dt);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                        const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
+                        uint32_t* oob_count, eas_stream_t stream) {
+    if (!out || !sample_offsets || B < 1 || Tm < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
+    if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    const size_t bytes = (size_t)B * Tm * 2 * H * W * sizeof(int32_t);
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (oob_count && hipMemsetAsync(oob_count, 0, sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (nev == 0) return EAS_OK;
+    const bool vec = (((uintptr_t)t & 15) | ((uintptr_t)x & 7) | ((uintptr_t)y & 7) | ((uintptr_t)p & 3)) == 0;
+    if (vec) {
+        hipLaunchKernelGGL(event_hist_kernel<true>, dim3(eas_grid_1d((nev + 3) / 4)), dim3(EAS_BLOCK), 0, st, t, x, y, p,
+                           nev, sample_offsets, B, Tm, H, W, out, oob_count);
+    } else {
+        hipLaunchKernelGGL(event_hist_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev,
+                           sample_offsets, B, Tm, H, W, out, oob_count);
+    }
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out,
+                         eas_stream_t stream) {
+    if (!counts || !out || F < 0 || H < 1 || W < 1 || Hc < H || Wc < W) return EAS_ERR_INVALID_ARG;
+    if (F == 0) return EAS_OK;
+    hipLaunchKernelGGL(counts_to_canvas_kernel, dim3(eas_grid_1d(F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
+                       F, H, W, Hc, Wc, out);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                         const int64_t* sample_offsets, int B, int n_bins, int H, int W, double* out,
+                         eas_stream_t stream) {
+    if (!out || !sample_offsets || B < 1 || n_bins < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
+    if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    if (hipMemsetAsync(out, 0, (size_t)B * n_bins * H * W * sizeof(double), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (nev == 0) return EAS_OK;
+    hipLaunchKernelGGL(voxel_grid_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets,
+                       B, n_bins, H, W, out);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+}  // extern "C"

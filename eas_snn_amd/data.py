@@ -1,0 +1,74 @@
+"""Synthetic event streams and their GPU-side preprocessing (no real datasets in scope).
+
+Stream definition = BASELINE.md section 2 / SURVEY.md 8d: per sample ``n_events`` events over a 200 ms window
+on the 240x304 Gen1 sensor, ``t`` sorted uniform, ``x``,``y`` uniform, ``p`` Bernoulli(0.5), numpy default_rng.
+Raw events (9 B/event) are what crosses PCIe; binning (K1) and canvas padding run on the GPU.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def synth_event_batch(batch, n_events=200_000, height=240, width=304, t0=1_000_000, span_us=200_000, seed=0):
+    """-> dict of numpy arrays (t u32, x u16, y u16, p u8, offsets i64[B+1])."""
+    rng = np.random.default_rng(seed)
+    n = batch * n_events
+    t = np.sort(rng.integers(t0, t0 + span_us, size=(batch, n_events), dtype=np.int64), axis=1).astype(np.uint32).reshape(-1)
+    x = rng.integers(0, width, size=n, dtype=np.int64).astype(np.uint16)
+    y = rng.integers(0, height, size=n, dtype=np.int64).astype(np.uint16)
+    p = (rng.random(n) < 0.5).astype(np.uint8)
+    off = np.arange(batch + 1, dtype=np.int64) * n_events
+    return dict(t=t, x=x, y=y, p=p, offsets=off)
+
+
+def events_to_device(ev, device):
+    return {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in ev.items()}
+
+
+def events_to_frames(ev_dev, Tm, sensor_hw, canvas_hw):
+    """Device events -> model input [B, Tl=1, Tm, 2, Hc, Wc] fp32 via the HIP histogram (K1)."""
+    H, W = sensor_hw
+    counts = ops.event_histogram(ev_dev['t'], ev_dev['x'], ev_dev['y'], ev_dev['p'], ev_dev['offsets'], Tm, H, W)
+    frames = ops.counts_to_canvas(counts, canvas_hw[0], canvas_hw[1])
+    return frames.unsqueeze(1)
+
+
+def synth_targets(batch, canvas_hw, device, n_boxes=2, max_labels=50):
+    """[B, 50, 5] rows (cls, cx, cy, w, h), zero padded (yolox/data/.../event_data_augment.py:19-65 contract)."""
+    Hc, Wc = canvas_hw
+    t = torch.zeros(batch, max_labels, 5)
+    boxes = [(0, 0.3, 0.4, 0.25, 0.3), (1, 0.7, 0.6, 0.2, 0.35), (0, 0.5, 0.5, 0.4, 0.4), (1, 0.2, 0.7, 0.15, 0.2)]
+    for i in range(min(n_boxes, len(boxes))):
+        c, cx, cy, w, h = boxes[i]
+        t[:, i] = torch.tensor([c, cx * Wc, cy * Hc, w * Wc, h * Hc])
+    return t.to(device)
+
+
+class SyntheticEventDataset:
+    def __init__(self, exp, length=1024, n_events=200_000):
+        self.exp, self.length, self.n_events = exp, length, n_events
+
+    def __len__(self):
+        return self.length
+
+
+class SyntheticEventLoader:
+    """Iterable of (frames [B,Tl,Tm,2,H,W] fp32 on the GPU, targets [B,50,5]); one 'epoch' = ``iters`` batches."""
+
+    def __init__(self, exp, batch_size, iters=16, n_events=200_000, sensor_hw=(240, 304)):
+        self.exp, self.batch_size, self.iters, self.n_events, self.sensor_hw = exp, batch_size, iters, n_events, sensor_hw
+        self.dataset = SyntheticEventDataset(exp)
+
+    def __len__(self):
+        return self.iters
+
+    def close_mosaic(self):
+        pass
+
+    def __iter__(self):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        for i in range(self.iters):
+            ev = events_to_device(synth_event_batch(self.batch_size, self.n_events, *self.sensor_hw, seed=i), dev)
+            frames = events_to_frames(ev, self.exp.Tm, self.sensor_hw, self.exp.input_size)
+            yield frames, synth_targets(self.batch_size, self.exp.input_size, dev)

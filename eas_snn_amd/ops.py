@@ -1,0 +1,411 @@
+"""Host-side operators over the C ABI (include/eas_hip.h): thin ``torch.autograd.Function`` wrappers that
+hand raw device pointers and the current HIP stream to libeas_hip.so.  PyTorch is plumbing here (memory,
+streams, autograd bookkeeping); all arithmetic of the hot path runs in the HIP kernels.
+
+No CPU path: CPU tensors raise.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+SURROGATE_IDS = {'atan': 0, 'sigmoid': 1, 'rect': 2}
+FLAG_HARD_RESET, FLAG_DECAY_INPUT, FLAG_DETACH_RESET, FLAG_FIRE_STRICT = 1, 2, 4, 8
+READOUT_IDS = {'sum': 0, 'last': 1, 'avg': 2}
+
+# Write the final membrane potential back after every multi-step call (spikingjelly semantics: ``node.v``
+# holds the state until ``reset_net``).  Training/eval loops that reset after every batch (the reference's
+# do: yolox/core/trainer.py:115-117, yolox/evaluators/event_evaluator.py:196-198) can switch this off and
+# save 4 B per neuron per layer; results are identical because the state is discarded by the reset.
+_STATE_WRITEBACK = True
+
+
+def set_state_writeback(flag):
+    global _STATE_WRITEBACK
+    _STATE_WRITEBACK = bool(flag)
+
+
+def state_writeback():
+    return _STATE_WRITEBACK
+
+
+class KernelTimer:
+    """Per-call HIP-event timing of the C-ABI entry points (bench.py roofline accounting).  Events are recorded on
+    the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def add(self, name, start, end, nbytes):
+        self.rec.setdefault(name, []).append((start, end, nbytes))
+
+    def summary(self):
+        out = {}
+        for name, items in self.rec.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in items)
+            out[name] = dict(calls=len(items), ms=ms, bytes=sum(b for _, _, b in items))
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _call(name, nbytes, fn, *args):
+    """Invoke one C-ABI entry point (optionally bracketed by HIP events) and check its status."""
+    if _TIMER is None:
+        check(fn(*args), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(fn(*args), name)
+    e.record()
+    _TIMER.add(name, s, e, nbytes)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.EasHipError('eas_snn_amd operators run on the GPU only (got a CPU tensor); there is no CPU fallback')
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise _lib.EasHipError(f'expected float32, got {t.dtype}')
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ K2
+class _LIFFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v):
+        _dev(x, v_in, w)
+        L = _lib.lib()
+        x = _f32c(x)
+        v_in = _f32c(v_in)
+        T, M = x.shape[0], x[0].numel()
+        need_grad = ctx.needs_input_grad[0] or (w is not None and ctx.needs_input_grad[2])
+        spikes = torch.empty_like(x)
+        h = torch.empty_like(x) if need_grad else None
+        v_out = torch.empty_like(x[0]) if write_v else None
+        mean = torch.empty_like(x[0]) if want_mean else None
+        _call('eas_lif_fwd', (8 + (4 if h is not None else 0)) * T * M, L.eas_lif_fwd, ptr(x), ptr(v_in), ptr(v_out), ptr(w),
+              k_const, v_th, v_reset, flags, ptr(spikes), ptr(h), ptr(mean), T, M, stream())
+        keep_x = x if (flags & FLAG_DECAY_INPUT) and w is not None else None
+        ctx.save_for_backward(h, v_in, w, keep_x)
+        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, T, M)
+        if v_out is not None:
+            ctx.mark_non_differentiable(v_out)
+        return spikes, v_out, mean
+
+    @staticmethod
+    def backward(ctx, g_s, g_v, g_mean):
+        h, v_in, w, x = ctx.saved_tensors
+        k_const, v_th, v_reset, flags, sg_id, alpha, T, M = ctx.cfg
+        L = _lib.lib()
+        if g_s is None and g_mean is None:
+            return (torch.zeros_like(h),) + (None,) * 10
+        g_s = _f32c(g_s)
+        g_mean = _f32c(g_mean)
+        gx = torch.empty_like(h)
+        want_w = w is not None and ctx.needs_input_grad[2]
+        gw = torch.empty_like(w) if want_w else None
+        ws = torch.empty(L.eas_reduce_workspace_floats(M), dtype=torch.float32, device=h.device) if want_w else None
+        _call('eas_lif_bwd', 12 * T * M, L.eas_lif_bwd, ptr(g_s), ptr(g_mean), ptr(h), ptr(v_in), ptr(x), ptr(w), k_const,
+              v_th, v_reset, flags, sg_id, alpha, ptr(gx), ptr(gw), ptr(ws), T, M, stream())
+        return gx, None, gw, None, None, None, None, None, None, None, None
+
+
+def lif_multistep(x_seq, v_in, w, k_const, v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None):
+    """Multi-step (P)LIF over x_seq [T, ...].  Returns (spikes, v_final|None, mean_over_T|None)."""
+    if write_v is None:
+        write_v = _STATE_WRITEBACK
+    return _LIFFn.apply(x_seq, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags),
+                        SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate), float(alpha),
+                        bool(want_mean), bool(write_v))
+
+
+def time_mean(x_seq):
+    """[T, ...] -> mean over T (firing-rate readout), differentiable."""
+    return _TimeMeanFn.apply(x_seq)
+
+
+class _TimeMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _f32c(x)
+        out = torch.empty_like(x[0])
+        ctx.T = x.shape[0]
+        check(_lib.lib().eas_time_mean(ptr(x), ptr(out), x.shape[0], out.numel(), stream()), 'eas_time_mean')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.T).unsqueeze(0).expand(ctx.T, *g.shape)
+
+
+# ------------------------------------------------------------------------------------------------ K4 (BN + LIF)
+class _BNLIFFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v):
+        running_mean, running_var, use_batch_stats, momentum, eps = bn_state
+        _dev(y, gamma, beta, v_in, w)
+        L = _lib.lib()
+        y = _f32c(y)
+        v_in = _f32c(v_in)
+        T, N, Cc = y.shape[0], y.shape[1], y.shape[2]
+        HW = y[0, 0, 0].numel()
+        dev = y.device
+        if use_batch_stats:
+            mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+            invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+            ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
+            _call('eas_bn_stats', 4 * y.numel(), L.eas_bn_stats, ptr(y), T * N, Cc, HW, eps,
+                  momentum if momentum is not None else 0.0, ptr(mean), ptr(invstd),
+                  ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None,
+                  ptr(ws), stream())
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        spikes = torch.empty_like(y)
+        v_out = torch.empty_like(y[0]) if write_v else None
+        mo = torch.empty_like(y[0]) if want_mean else None
+        _call('eas_bn_lif_fwd', 8 * y.numel(), L.eas_bn_lif_fwd, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in),
+              ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, stream())
+        ctx.save_for_backward(y, mean, invstd, gamma, beta, v_in, w)
+        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), T, N, Cc, HW)
+        if v_out is not None:
+            ctx.mark_non_differentiable(v_out)
+        return spikes, v_out, mo
+
+    @staticmethod
+    def backward(ctx, g_s, g_v, g_mean):
+        y, mean, invstd, gamma, beta, v_in, w = ctx.saved_tensors
+        k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW = ctx.cfg
+        L = _lib.lib()
+        nout = 14
+        if g_s is None and g_mean is None:
+            return (torch.zeros_like(y),) + (None,) * (nout - 1)
+        g_s = _f32c(g_s)
+        g_mean = _f32c(g_mean)
+        gy = torch.empty_like(y)
+        ggamma = torch.empty_like(gamma)
+        gbeta = torch.empty_like(beta)
+        want_w = w is not None and ctx.needs_input_grad[5]
+        gw = torch.empty_like(w) if want_w else None
+        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
+        _call('eas_bn_lif_bwd', 12 * y.numel(), L.eas_bn_lif_bwd, ptr(g_s), ptr(g_mean), ptr(y), ptr(mean), ptr(invstd),
+              ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy),
+              ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, stream())
+        return (gy, ggamma, gbeta, None, None, gw) + (None,) * (nout - 6)
+
+
+def bn_lif_supported(y_seq, T):
+    return y_seq.dim() == 5 and T <= 8 and (y_seq.shape[-1] * y_seq.shape[-2]) % 4 == 0
+
+
+def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_stats, momentum, eps, v_in, w, k_const,
+                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None):
+    """Fused BatchNorm(step_mode='m') + multi-step LIF on the conv output y_seq [T,N,C,H,W]."""
+    if write_v is None:
+        write_v = _STATE_WRITEBACK
+    state = (running_mean, running_var, bool(use_batch_stats), None if momentum is None else float(momentum), float(eps))
+    return _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags),
+                          SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate), float(alpha),
+                          bool(want_mean), bool(write_v))
+
+
+# ------------------------------------------------------------------------------------------------ K1
+def event_histogram(t, x, y, p, sample_offsets, Tm, H, W, return_oob=False):
+    """Per-sample micro-slice count frames: int32 [B, Tm, 2, H, W] (bit-exact 'micro_sum')."""
+    _dev(t, x, y, p, sample_offsets)
+    assert t.dtype == torch.uint32 or t.dtype == torch.int32, 't must be 32-bit timestamps'
+    assert x.dtype in (torch.uint16, torch.int16) and y.dtype in (torch.uint16, torch.int16) and p.dtype in (torch.uint8, torch.int8)
+    assert sample_offsets.dtype == torch.int64
+    B = sample_offsets.numel() - 1
+    out = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=t.device)
+    oob = torch.empty(1, dtype=torch.int32, device=t.device) if return_oob else None
+    _call('eas_event_histogram', 9 * t.numel() + 4 * out.numel(), _lib.lib().eas_event_histogram, ptr(t), ptr(x), ptr(y), ptr(p),
+          t.numel(), ptr(sample_offsets), B, Tm, H, W, ptr(out), ptr(oob), stream())
+    return (out, oob) if return_oob else out
+
+
+def counts_to_canvas(counts, Hc, Wc):
+    """int32 [..., H, W] -> float32 [..., Hc, Wc], zero padded bottom/right."""
+    _dev(counts)
+    assert counts.dtype == torch.int32
+    counts = counts.contiguous()
+    H, W = counts.shape[-2:]
+    F = counts.numel() // (H * W)
+    out = torch.empty(counts.shape[:-2] + (Hc, Wc), dtype=torch.float32, device=counts.device)
+    check(_lib.lib().eas_counts_to_canvas(ptr(counts), F, H, W, Hc, Wc, ptr(out), stream()), 'eas_counts_to_canvas')
+    return out
+
+
+def event_voxel_grid(t, x, y, p, sample_offsets, n_bins, H, W):
+    """float64 [B, n_bins, 1, H, W] bilinear-in-time voxel grid."""
+    _dev(t, x, y, p, sample_offsets)
+    B = sample_offsets.numel() - 1
+    out = torch.empty((B, n_bins, 1, H, W), dtype=torch.float64, device=t.device)
+    check(_lib.lib().eas_event_voxel_grid(ptr(t), ptr(x), ptr(y), ptr(p), t.numel(), ptr(sample_offsets), B, n_bins, H, W,
+                                          ptr(out), stream()), 'eas_event_voxel_grid')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def _conv_stack_fwd(x, params, k):
+    """Conv(k, pad k//2) [+ ReLU + Conv]*: returns (out, inputs of every conv)."""
+    ins = []
+    pad = k // 2
+    for i in range(0, len(params), 2):
+        if i > 0:
+            x = torch.relu(x)
+        ins.append(x)
+        x = torch.nn.functional.conv2d(x, params[i], params[i + 1], padding=pad)
+    return x, ins
+
+
+def _conv_dgrad(g, inp, w, pad, need_input=True, need_params=False):
+    gi, gw, gb = torch.ops.aten.convolution_backward(g, inp, w, [w.shape[0]], [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [need_input, need_params, need_params])
+    return gi, gw, gb
+
+
+class _ARSNNFn(torch.autograd.Function):
+    """Whole adaptive-sampler loop as ONE autograd node (embedding.py:141-226): conv stacks via MIOpen,
+    the per-step integrate / fire / reset / segment-write via eas_arsnn_step_*."""
+
+    @staticmethod
+    def forward(ctx, ev, cfg, *params):
+        _dev(ev, *params)
+        L = _lib.lib()
+        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record = cfg
+        ev = _f32c(ev)
+        Tm, N, Cin, H, W = ev.shape
+        pin, pg = params[:2 * depth], params[2 * depth:]
+        C2 = pg[0].shape[1]
+        HW = H * W
+        if HW % 4 != 0:
+            raise _lib.EasHipError('sampler needs H*W divisible by 4')
+        dev = ev.device
+        need_grad = any(ctx.needs_input_grad[2:])
+        st = stream()
+        X, in_ins = _conv_stack_fwd(ev.view(Tm * N, Cin, H, W), pin, k)
+        X = X.view(Tm, N, 2 * C2, H, W)
+        shape = (N, C2, H, W)
+        v = torch.zeros(shape, device=dev)
+        vsum = torch.zeros(shape, device=dev)
+        spike = torch.zeros(shape, device=dev)
+        seg = torch.zeros(shape, dtype=torch.int32, device=dev)
+        tl = torch.full(shape, -1, dtype=torch.int32, device=dev)
+        agg = torch.zeros((Ts,) + shape, device=dev)
+        saved = []
+        t_rec = []
+        for t in range(Tm):
+            R, g_ins = _conv_stack_fwd(spike, pg, k)
+            v_n, vs_n, sp_n = torch.empty_like(v), torch.empty_like(v), torch.empty_like(v)
+            if need_grad:
+                gate, vn = torch.empty_like(v), torch.empty_like(v)
+                seg_b, tl_b = torch.empty_like(seg), torch.empty_like(tl)
+            else:
+                gate = vn = seg_b = tl_b = None
+            _call('eas_arsnn_step_fwd', 38 * v.numel(), L.eas_arsnn_step_fwd, ptr(X[t]), ptr(R), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
+                  ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, readout, int(sat),
+                  thresh, v_reset, int(soft), N, C2, HW, st)
+            if need_grad:
+                saved.append((g_ins, v, vsum, gate, vn, seg_b, tl_b))
+            v, vsum, spike = v_n, vs_n, sp_n
+            if record:
+                t_rec.append(tl.clone())
+        check(L.eas_arsnn_tail_fwd(ptr(v), ptr(vsum), ptr(spike), ptr(seg), ptr(tl), ptr(agg), Tm, Ts, readout, int(wz), N, C2,
+                                   HW, st), 'eas_arsnn_tail_fwd')
+        pre_relu = None
+        if ab:
+            pre_relu = agg
+            agg = torch.relu(agg)
+        ctx.cfg = cfg
+        ctx.dims = (Tm, N, Cin, C2, H, W)
+        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu)
+        ctx.params = params
+        ctx.ev_needs_grad = ctx.needs_input_grad[0]
+        rec = torch.stack(t_rec) if record else None
+        if rec is not None:
+            ctx.mark_non_differentiable(rec)
+        return agg, rec
+
+    @staticmethod
+    def backward(ctx, g_agg, _g_rec):
+        L = _lib.lib()
+        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record = ctx.cfg
+        Tm, N, Cin, C2, H, W = ctx.dims
+        saved, in_ins, spike_last, seg, tl, pre_relu = ctx.saved
+        params = ctx.params
+        pin, pg = params[:2 * depth], params[2 * depth:]
+        pad = k // 2
+        HW = H * W
+        st = stream()
+        g_agg = _f32c(g_agg)
+        if ab:
+            g_agg = g_agg * (pre_relu > 0)
+        dev = g_agg.device
+        shape = (N, C2, H, W)
+        g_v = torch.empty(shape, device=dev)
+        g_vs = torch.empty(shape, device=dev)
+        check(L.eas_arsnn_tail_bwd(ptr(g_agg), ptr(spike_last), ptr(seg), ptr(tl), ptr(g_v), ptr(g_vs), Tm, Ts, readout, int(wz),
+                                   N, C2, HW, st), 'eas_arsnn_tail_bwd')
+        g_spike = None
+        gX = torch.empty((Tm, N, 2 * C2, H, W), device=dev)
+        # gradient reaching each conv of the gate stack at every step (batched weight-grad at the end)
+        g_stage = [[None] * Tm for _ in range(depth)]
+        for t in range(Tm - 1, -1, -1):
+            g_ins, v_prev, vs_prev, gate, vn, seg_b, tl_b = saved[t]
+            g_vp, g_vsp = torch.empty_like(g_v), torch.empty_like(g_v)
+            check(L.eas_arsnn_step_bwd(ptr(g_v), ptr(g_vs), ptr(g_spike), ptr(g_agg), ptr(v_prev), ptr(vs_prev), ptr(gate), ptr(vn),
+                                       ptr(seg_b), ptr(tl_b), ptr(gX[t]), ptr(g_vp), ptr(g_vsp), t, Ts, readout, int(sat), thresh,
+                                       v_reset, int(soft), 1.0, N, C2, HW, st), 'eas_arsnn_step_bwd')
+            g_v, g_vs = g_vp, g_vsp
+            g = gX[t]
+            for i in range(depth - 1, -1, -1):
+                g_stage[i][t] = g
+                if i == 0 and t == 0:
+                    break                      # spike input of step 0 is the constant 0
+                g, _, _ = _conv_dgrad(g, g_ins[i], pg[2 * i], pad, True, False)
+                if i > 0:
+                    g = g * (g_ins[i] > 0)     # ReLU in front of conv i
+            g_spike = g if t > 0 else None
+        grads_g = []
+        for i in range(depth):
+            gs = torch.cat(g_stage[i], 0)
+            xs = torch.cat([saved[t][0][i] for t in range(Tm)], 0)
+            _, gw, gb = _conv_dgrad(gs, xs, pg[2 * i], pad, False, True)
+            grads_g += [gw, gb]
+        # input conv stack, all Tm steps at once
+        grads_in = [None] * (2 * depth)
+        g = gX.view(Tm * N, 2 * C2, H, W)
+        for i in range(depth - 1, -1, -1):
+            need_in = i > 0 or ctx.ev_needs_grad
+            gi, gw, gb = _conv_dgrad(g, in_ins[i], pin[2 * i], pad, need_in, True)
+            grads_in[2 * i], grads_in[2 * i + 1] = gw, gb
+            if i > 0:
+                g = gi * (in_ins[i] > 0)
+            else:
+                g = gi
+        g_ev = g.view(Tm, N, Cin, H, W) if ctx.ev_needs_grad else None
+        return (g_ev, None) + tuple(grads_in) + tuple(grads_g)
+
+
+def arsnn_forward(ev_rev, input_params, gate_params, kernel_size, Ts, readout, spike_attach, write_zero, use_abs, thresh,
+                  v_reset, record=False):
+    """ev_rev: [Tm, N, 2, H, W] micro-slices, newest first.  *_params: [w0, b0, (w1, b1, ...)]."""
+    depth = len(input_params) // 2
+    soft = v_reset is None
+    cfg = (int(kernel_size), depth, int(Ts), READOUT_IDS[readout], bool(spike_attach), bool(write_zero), bool(use_abs),
+           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record))
+    return _ARSNNFn.apply(ev_rev, cfg, *input_params, *gate_params)

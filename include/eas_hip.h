@@ -1,0 +1,162 @@
+/*
+ * eas_hip.h -- C ABI of libeas_hip.so: the MI355X (gfx950) hot path of EAS-SNN.
+ *
+ * The reference (Windere/EAS-SNN) has NO native code on this path: everything below
+ * replaces chains of PyTorch/numpy calls.  Each entry point cites the reference
+ * code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions:
+ *   - every function is asynchronous on the caller-supplied HIP stream (hipStream_t passed as void*);
+ *   - all pointers are DEVICE pointers to contiguous row-major buffers owned by the caller
+ *     (the PyTorch allocator); nothing is allocated, freed or retained inside;
+ *   - return value: 0 = ok, negative = error (EAS_ERR_*), never throws, never exits;
+ *   - no host synchronisation inside (graph-capturable).
+ */
+#ifndef EAS_HIP_H
+#define EAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* eas_stream_t; /* hipStream_t */
+
+#define EAS_OK 0
+#define EAS_ERR_INVALID_ARG (-1)
+#define EAS_ERR_UNSUPPORTED (-2)
+#define EAS_ERR_LAUNCH (-3)
+
+/* surrogate gradient ids (spikingjelly surrogate.ATan / surrogate.Sigmoid, chosen at
+ * yolox/exp/event_yolox_base.py:144-151; Rectangle: yolox/models/activation.py:17-30) */
+#define EAS_SG_ATAN 0
+#define EAS_SG_SIGMOID 1
+#define EAS_SG_RECT 2
+
+/* neuron flags */
+#define EAS_LIF_HARD_RESET 1   /* v = (1-s)*h + s*v_reset ; else soft: v = h - s*v_th        */
+#define EAS_LIF_DECAY_INPUT 2  /* h = v + (x-(v-v_reset))*k ; else h = v - (v-v_reset)*k + x */
+#define EAS_LIF_DETACH_RESET 4 /* spike is a constant in the reset term during backward      */
+#define EAS_LIF_FIRE_STRICT 8  /* fire on h - v_th > 0 (in-repo LIFCell); else >= 0 (spikingjelly heaviside) */
+
+int eas_abi_version(void);
+const char* eas_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  event -> count frames.  Replaces GEN1Dataset.slice_events + agrregate('sum'|'micro_sum')
+ *     (yolox/data/datasets/gen1.py:313-328, 333-349, 355-360; same code in ncaltech.py:227-237,
+ *     368-378, rvt_gen4.py:411-426, gen4.py:445-460).
+ * Events of sample b are [sample_offsets[b], sample_offsets[b+1]) (t ascending inside a sample).
+ * out[b][k][c][y][x] (int32, zeroed by the call) counts events of micro-slice k and polarity
+ * channel c (c = 0 for p == 0, 1 otherwise) with
+ *     window = (t_last - t_first) / Tm  (integer floor),  k = (t - t_first) / window,
+ * dropped when window == 0 or k >= Tm.  Events with x >= W or y >= H are dropped and counted
+ * in *oob_count (may be NULL).  Integer atomics: bit-exact. */
+int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                        const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
+                        uint32_t* oob_count, eas_stream_t stream);
+
+/* int32 counts [F][H][W] -> fp32 canvas [F][Hc][Wc], zero padded bottom/right (top-left placement,
+ * as gen1.py:447-455 does with scale 1).  Replaces np.stack + astype + pad + trainer.py:99 cast. */
+int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out,
+                         eas_stream_t stream);
+
+/* Bilinear-in-time voxel grid, to_voxel_grid_numpy (yolox/utils/event_reps.py:30-89).
+ * out[b][bin][y][x] float64 (zeroed by the call); polarity 0 counts as -1. */
+int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                         const int64_t* sample_offsets, int B, int n_bins, int H, int W, double* out,
+                         eas_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  multi-step (P)LIF neuron.  Replaces spikingjelly ParametricLIFNode / LIFNode
+ *     multi_step_forward (call site yolox/utils/utils_snn.py:44-53): per step
+ *         h = charge(v, x_t);  s_t = H(h - v_th);  v = reset(h, s_t)
+ * x, spikes: [T][M] fp32.  v_in: [M] initial membrane potential (NULL = v_reset, the state after
+ * reset_net); v_out: [M] final membrane potential (NULL = not needed; may alias v_in).  decay: k = sigmoid(*w_logit) if w_logit != NULL (PLIF),
+ * else k = k_const (LIF: 1/tau).  h_save (nullable): [T][M] pre-fire potential kept for backward.
+ * mean_out (nullable): [M] mean of the spikes over T (firing-rate readout,
+ * yolox/models/spiking_yolo_pafpn.py:98).  */
+int eas_lif_fwd(const float* x, const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th,
+                float v_reset, int flags, float* spikes, float* h_save, float* mean_out, int T, int64_t M,
+                eas_stream_t stream);
+
+/* Backward of eas_lif_fwd.  grad_s: [T][M] (nullable), grad_mean: [M] (nullable, adds grad_mean/T
+ * to every step), h_save from forward, v_init: [M] initial state used in forward (NULL = v_reset),
+ * x: only read when EAS_LIF_DECAY_INPUT and w_logit != NULL.  Writes grad_x [T][M] and, when
+ * grad_w != NULL, *grad_w = dL/dw_logit (deterministic two-stage reduction through
+ * workspace, which must hold eas_reduce_workspace_floats(M) floats). */
+int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init,
+                const float* x, const float* w_logit, float k_const, float v_th, float v_reset, int flags,
+                int surrogate, float alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
+                eas_stream_t stream);
+
+int64_t eas_reduce_workspace_floats(int64_t M);
+
+/* mean over the leading T axis: [T][M] -> [M] (out_features[f].mean(axis=0)). */
+int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4 (BN + LIF half of the fused conv -> BN -> LIF step).  Replaces
+ * layer.BatchNorm2d(step_mode='m') + ParametricLIFNode after every converted BaseConv
+ * (yolox/models/network_blocks.py:52-53 after yolox/utils/utils_snn.py:28-53).
+ * y: conv output [T][N][C][HW] fp32.  Statistics are per channel over T*N*HW. */
+
+/* per-channel batch statistics: mean[C], invstd[C] (biased variance, eps inside), and the
+ * running-stat update running = (1-momentum)*running + momentum*batch (unbiased variance),
+ * skipped when running_mean == NULL.  workspace: eas_bn_workspace_doubles(C) doubles. */
+int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentum, float* mean, float* invstd,
+                 float* running_mean, float* running_var, double* workspace, eas_stream_t stream);
+int64_t eas_bn_workspace_doubles(int C);
+
+/* z = gamma*(y-mean)*invstd + beta, then the LIF recurrence over T (same neuron arguments as
+ * eas_lif_fwd).  Nothing but y needs to be kept for backward. */
+int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
+                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, eas_stream_t stream);
+
+/* Backward, pass 1: recompute the forward from y, run the LIF backward and reduce per channel
+ * sum(dz), sum(dz*xhat) (-> grad_beta, grad_gamma) and the neuron's grad_w.  Pass 2 (apply):
+ * grad_y = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) in training mode, or
+ * gamma*invstd*dz when batch_stats == 0 (eval / frozen BN).  Both passes are issued by this call.
+ * workspace: eas_bn_workspace_doubles(C) doubles. */
+int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                   const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                   float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                   float* grad_w, double* workspace, int T, int N, int C, int HW, eas_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  adaptive sampler step (AdaptiveRSNNEmbedding.forward loop body,
+ *     yolox/models/embedding.py:170-201 + update :132-139; tail :203-217), dense masked form.
+ * conv_in / conv_rec: [N][2*C2][HW] outputs of input_conv(ev[t]) / gate_conv(spike): channels
+ * [0,C2) gate pre-activation, [C2,2*C2) current.  State per (n,c,hw): v, vsum (fp32), seg, t_last
+ * (int32).  agg: [Ts][N][C2][HW].  readout: 0 sum, 1 last, 2 avg.  v_reset_mode: 0 hard reset to
+ * v_reset, 1 soft (v - thresh*spike).  Saved for backward: gate, vn (pre-reset), seg_before,
+ * t_last_before (all nullable in inference). */
+int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float* v, const float* vsum,
+                       int32_t* seg, int32_t* t_last, float* agg, float* v_out, float* vsum_out, float* spike_out,
+                       float* gate_save, float* vn_save, int32_t* seg_before, int32_t* t_last_before, int t,
+                       int Ts, int readout, int spike_attach, float thresh, float v_reset, int soft_reset, int N,
+                       int C2, int HW, eas_stream_t stream);
+
+int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const float* g_spike, const float* g_agg,
+                       const float* v_prev, const float* vsum_prev, const float* gate_save, const float* vn_save,
+                       const int32_t* seg_before, const int32_t* t_last_before, float* g_conv, float* g_v_prev,
+                       float* g_vsum_prev, int t, int Ts, int readout, int spike_attach, float thresh,
+                       float v_reset, int soft_reset, float sg_alpha, int N, int C2, int HW, eas_stream_t stream);
+
+/* tail write (embedding.py:203-217): at elements whose LAST spike is 0 and seg < Ts add
+ * (sum|last|avg readout) * (write_zero ? 0 : 1) into agg[seg]; optional relu (abs=True, :218-220)
+ * is applied by eas_relu_inplace. */
+int eas_arsnn_tail_fwd(const float* v, const float* vsum, const float* spike_last, const int32_t* seg,
+                       const int32_t* t_last, float* agg, int Tm, int Ts, int readout, int write_zero, int N,
+                       int C2, int HW, eas_stream_t stream);
+int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int32_t* seg, const int32_t* t_last,
+                       float* g_v, float* g_vsum, int Tm, int Ts, int readout, int write_zero, int N, int C2,
+                       int HW, eas_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAS_HIP_H */

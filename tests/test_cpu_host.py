@@ -1,0 +1,178 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/eas_hip.h declares, host-side logic
+(experiment options, module tree rewrite, checkpoint keys), and the multi-process path on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+import eas_snn_amd  # noqa: E402  (puts compat/ on sys.path)
+
+README_OPTS = ['T', '3', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
+               'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True', 'use_spike', 'True', 'spike_fn', 'atan',
+               'input_size', '(256,320)', 'test_size', '(256,320)']
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'eas_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(eas_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    path = eas_snn_amd.build()
+    assert os.path.exists(path)
+    handle = ctypes.CDLL(path)
+    names = _header_functions()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(handle, n), f'{n} declared in include/eas_hip.h but not exported'
+    assert sorted(eas_snn_amd._lib.PROTOTYPES) == names           # ctypes table covers exactly the header
+    lib = eas_snn_amd.hip_library()
+    assert lib.eas_abi_version() == 1
+    assert lib.eas_status_string(-1).decode().startswith('invalid argument')
+    assert lib.eas_bn_workspace_doubles(32) > 0 and lib.eas_reduce_workspace_floats(1 << 20) > 0
+
+
+def test_gfx950_code_object_only():
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/clang-offload-bundler', '--list', '--type=o',
+                          f'--input={eas_snn_amd._lib.LIB_PATH}'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    if 'gfx' in out:
+        assert 'gfx950' in out and 'gfx90a' not in out and 'gfx942' not in out
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from eas_snn_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.EasHipError, match='no CPU fallback'):
+        _lib.lib()
+
+
+def test_no_cpu_fallback_for_neurons_and_sampler():
+    from spikingjelly.activation_based import neuron, surrogate
+    from yolox.models.embedding import AdaptiveRSNNEmbedding
+    from yolox.models.activation import Rectangle
+    node = neuron.ParametricLIFNode(init_tau=2.0, decay_input=False, v_reset=None, surrogate_function=surrogate.ATan(), step_mode='m')
+    with pytest.raises(eas_snn_amd.EasHipError):
+        node(torch.zeros(3, 1, 2, 4, 4))
+    emb = AdaptiveRSNNEmbedding(5, nb_steps=4, thresh=1.0, vreset=0.0, spike_fn=Rectangle)
+    with pytest.raises(eas_snn_amd.EasHipError):
+        emb(torch.zeros(1, 1, 4, 2, 8, 8))
+    assert emb(torch.zeros(1, 2, 8, 8)).shape == (1, 1, 2, 8, 8)         # registration passthrough needs no kernel
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, 'eas_snn_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+
+
+def test_exp_merge_type_coercion_quirks():
+    from yolox.exp import get_exp
+    exp = get_exp(None, 'e-yolox-s')
+    assert (exp.depth, exp.width, exp.max_epoch) == (0.33, 0.50, 60)
+    exp.merge(README_OPTS + ['alpha', '1.5', 'abs', 'False', 'nonexistent_key', '1'])
+    assert exp.T == 3 and isinstance(exp.T, int)
+    assert exp.input_size == (256, 320) or list(exp.input_size) == [256, 320]
+    assert exp.use_spike == 'True' and isinstance(exp.use_spike, str)       # a string option
+    assert exp.abs is True                                                   # bool("False") is True, as upstream
+    assert exp.alpha == 1.5 and not hasattr(exp, 'nonexistent_key')
+    assert exp.get_slice_args()['window'] == (-200000, 0)
+
+
+@pytest.mark.parametrize('name,use_spike,extra', [('model_s_true_64', 'True', []), ('model_s_full_64', 'full_spike', []),
+                                                  ('model_s_fullv2_64', 'full_spike_v2', []), ('model_s_false_64', 'False', []),
+                                                  ('model_m_fullv2_t5_64x96', 'full_spike_v2', ['T', '5'])])
+def test_model_tree_and_checkpoint_keys_match_reference(name, use_spike, extra):
+    from spikingjelly.activation_based import layer, neuron
+    from yolox.exp import get_exp
+    g = load_golden(name)
+    exp = get_exp(None, 'e-yolox-m' if '_m_' in name else 'e-yolox-s')
+    exp.merge([o if o != 'True' or README_OPTS[i - 1] != 'use_spike' else use_spike for i, o in enumerate(README_OPTS)] + extra)
+    model = exp.get_model()
+    assert [str(k) for k in g['keys']] == list(model.state_dict().keys())
+    assert sum(p.numel() for p in model.parameters()) == int(g['nparam'])
+    n_plif = sum(isinstance(m, neuron.ParametricLIFNode) for m in model.modules())
+    assert n_plif == {'True': 34, 'full_spike': 58, 'full_spike_v2': 73, 'False': 0}[use_spike] or '_m_' in name
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            assert (m.eps, m.momentum) == (1e-3, 0.03)
+        if isinstance(m, layer.BatchNorm2d):
+            assert isinstance(m, torch.nn.BatchNorm2d) and m.step_mode == 'm'
+    if use_spike == 'True':
+        assert type(model.backbone.backbone.stem).__name__ == 'SeqToANNContainer'
+        assert isinstance(model.backbone.backbone.stem[0].conv.act, torch.nn.SiLU)          # stem stays ANN
+        opt = exp.get_optimizer(64)
+        assert [len(g_['params']) for g_ in opt.param_groups] == [74, 83, 83, 34, 8]
+
+
+def test_neuron_state_and_reset_semantics():
+    from spikingjelly.activation_based import functional, neuron, surrogate
+    node = neuron.ParametricLIFNode(init_tau=2.0, decay_input=False, v_threshold=1.0, v_reset=None,
+                                    surrogate_function=surrogate.ATan(2.0), step_mode='m', backend='torch')
+    assert node.v == 0. and float(node.w) == 0.0 and list(node.state_dict()) == ['w']
+    node.v = torch.ones(2, 2)
+    import copy
+    c = copy.deepcopy(node)
+    assert torch.equal(c.v, node.v) and c.v is not node.v
+    functional.reset_net(torch.nn.Sequential(node))
+    assert node.v == 0.
+    with pytest.raises(NotImplementedError):
+        node.backend = 'cupy'
+
+
+# ------------------------------------------------------------------------------------------------ multi-process (gloo)
+def _worker_main(tag, out_dir):
+    import torch.distributed as dist
+    import yolox.utils as U
+    from yolox.utils.allreduce_norm import all_reduce_norm
+    rank, world = U.get_rank(), U.get_world_size()
+    assert world == 2 and U.get_local_rank() == rank
+    torch.manual_seed(rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 1), torch.nn.BatchNorm2d(4))
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank + 1))
+        net[1].weight.fill_(float(10 * (rank + 1)))
+    all_reduce_norm(net)
+    assert torch.allclose(net[1].running_mean, torch.full((4,), 1.5)) and torch.allclose(net[1].weight, torch.full((4,), 15.0))
+    # weak-scaling bookkeeping used by bench.py: value = all ranks' units / max-over-ranks time
+    el = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    assert float(el) == 2.0
+    # DDP gradient averaging over the process group (the one hot collective)
+    ddp = torch.nn.parallel.DistributedDataParallel(torch.nn.Linear(3, 1, bias=False), broadcast_buffers=False)
+    with torch.no_grad():
+        ddp.module.weight.fill_(1.0)
+    ddp(torch.full((1, 3), float(rank + 1))).sum().backward()
+    assert torch.allclose(ddp.module.weight.grad, torch.full((1, 3), 1.5))
+    open(os.path.join(out_dir, f'ok_{tag}_{rank}'), 'w').write('ok')
+
+
+def test_launch_two_ranks_gloo(tmp_path):
+    """yolox.core.launch with world_size 2 on the gloo backend (the RCCL path differs only in the backend string)."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import eas_snn_amd\n"
+        "from yolox.core import launch\n"
+        "from test_cpu_host import _worker_main\n"
+        "if __name__ == '__main__':\n"
+        "    launch(_worker_main, 2, 1, 0, backend='gloo', dist_url='auto', args=('t', %r))\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), str(tmp_path))
+    script = tmp_path / 'run_launch.py'
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert (tmp_path / 'ok_t_0').exists() and (tmp_path / 'ok_t_1').exists()
