@@ -50,7 +50,8 @@ def cpu_baseline(cpu_batch, n_events):
     """The oracle (a port: torch-CPU restatement validated against the reference) on a bounded sample of the same
     workload: same model/config, batch ``cpu_batch``, numpy event binning + fwd + bwd + Adam + reset per iteration."""
     from oracle import events_ref, model_ref, sj_ref
-    threads = os.cpu_count() or 1
+    # intra-op threads: all host cores up to 32 (beyond that ATen's CPU convs at these sizes get slower, not faster)
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     torch.manual_seed(80)
     model = model_ref.build_model(use_spike='True')
@@ -71,13 +72,15 @@ def cpu_baseline(cpu_batch, n_events):
         opt.step()
         sj_ref.reset_net(model)
 
+    t0 = time.time()
     step()                                   # warm-up (allocator, thread pools)
+    warm = time.time() - t0
     n, t0 = 0, time.time()
     while True:
         step()
         n += 1
         el = time.time() - t0
-        if el > 12.0 or n >= 5:
+        if el > 12.0 or n >= 5 or warm > 20.0:   # bounded sample: ~10-30 s of CPU work
             break
     return {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port',
             'sample': f'oracle (torch-CPU fp32) SYOLOX-S T=3 256x320 fwd+bwd+Adam, batch {cpu_batch}, {n} iterations, '

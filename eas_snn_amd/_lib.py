@@ -58,6 +58,17 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _bind_host_hip_runtime():
+    """libeas_hip.so is linked without a HIP runtime (csrc/Makefile): make the runtime PyTorch uses visible to it.
+    Loading torch first and promoting its bundled libamdhip64 to the global symbol scope keeps ONE runtime in
+    the process, so device pointers and streams handed over from torch are valid inside the kernels' launches."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if not os.path.exists(cand):
+        cand = 'libamdhip64.so'
+    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises (loudly) when it has not been built."""
     global _lib
@@ -66,6 +77,7 @@ def lib():
             raise EasHipError(
                 f'{LIB_PATH} is missing: the HIP extension has not been built and eas_snn_amd has no CPU fallback. '
                 'Run `python -c "import __graft_entry__ as g; g.build()"`.')
+        _bind_host_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)      # AttributeError = ABI mismatch, also loud

@@ -32,10 +32,12 @@ __device__ __forceinline__ void step_elem(float g_in, float c_in, float g_rec, f
             float val = c.readout == 0 ? vs1 : (c.readout == 1 ? v_out : vs1 / (float)(c.t - tl));
             if (c.spike_attach) val = val * spike;
             agg[(int64_t)seg * c.total + i] += val;       // :194
+            // the reference filters spike_pos by seg < Ts BEFORE these two updates (:183-184, :195-196):
+            // segment counter and last-spike time freeze once an element has filled its Ts frames
+            seg += 1;
+            tl = c.t;
         }
-        seg += 1;                                         // :195
-        tl = c.t;                                         // :196
-        vsum_out = 0.0f;                                  // :197
+        vsum_out = 0.0f;                                  // :197 (every fired element)
     } else {
         vsum_out = vs1;
     }
@@ -190,6 +192,7 @@ int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float*
          (uintptr_t)seg_before | (uintptr_t)t_last_before) & 15)
         return EAS_ERR_INVALID_ARG;
     StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, 1.0f, (int64_t)C2 * HW, (int64_t)N * C2 * HW};
+    EAS_CLEAR_ERR();
     hipLaunchKernelGGL(arsnn_step_fwd_kernel, dim3(eas_grid_1d(c.total / VEC)), dim3(EAS_BLOCK), 0, eas_s(stream), conv_in,
                        conv_rec, v, vsum, seg, t_last, agg, v_out, vsum_out, spike_out, gate_save, vn_save, seg_before,
                        t_last_before, c);
@@ -209,6 +212,7 @@ int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const floa
         return EAS_ERR_INVALID_ARG;
     StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, sg_alpha, (int64_t)C2 * HW,
               (int64_t)N * C2 * HW};
+    EAS_CLEAR_ERR();
     hipLaunchKernelGGL(arsnn_step_bwd_kernel, dim3(eas_grid_1d(c.total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_v_out,
                        g_vsum_out, g_spike, g_agg, v_prev, vsum_prev, gate_save, vn_save, seg_before, t_last_before, g_conv,
                        g_v_prev, g_vsum_prev, c);
@@ -223,6 +227,7 @@ int eas_arsnn_tail_fwd(const float* v, const float* vsum, const float* spike_las
         readout > 2)
         return EAS_ERR_INVALID_ARG;
     const int64_t total = (int64_t)N * C2 * HW;
+    EAS_CLEAR_ERR();
     hipLaunchKernelGGL(arsnn_tail_fwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), v, vsum,
                        spike_last, seg, t_last, agg, Tm, Ts, readout, write_zero, total);
     EAS_CHECK_LAUNCH();
@@ -236,6 +241,7 @@ int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int32_
         readout < 0 || readout > 2)
         return EAS_ERR_INVALID_ARG;
     const int64_t total = (int64_t)N * C2 * HW;
+    EAS_CLEAR_ERR();
     hipLaunchKernelGGL(arsnn_tail_bwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_agg, spike_last,
                        seg, t_last, g_v, g_vsum, Tm, Ts, readout, write_zero, total);
     EAS_CHECK_LAUNCH();

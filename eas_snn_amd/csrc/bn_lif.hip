@@ -366,6 +366,7 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentu
     if ((running_mean == nullptr) != (running_var == nullptr)) return EAS_ERR_INVALID_ARG;
     if (C > 65535) return EAS_ERR_UNSUPPORTED;
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
     int chunks;
     if (HW % VEC == 0 && (((uintptr_t)y) & 15) == 0) {
         chunks = pick_chunks((int64_t)TN * (HW / VEC), C);
@@ -391,6 +392,7 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) \
     return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
@@ -417,6 +419,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
                                batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, st)

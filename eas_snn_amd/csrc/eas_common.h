@@ -8,8 +8,11 @@
 #define EAS_WAVE 64
 #define EAS_BLOCK 256
 
-#define EAS_CHECK_LAUNCH()                                   \
-    do {                                                     \
+// hipGetLastError() is sticky per thread and PyTorch leaves benign codes behind (hipErrorNotReady from
+// event/stream queries): EAS_CLEAR_ERR() at entry, EAS_CHECK_LAUNCH() right after each launch.
+#define EAS_CLEAR_ERR() (void)hipGetLastError()
+#define EAS_CHECK_LAUNCH()                                          \
+    do {                                                            \
         if (hipGetLastError() != hipSuccess) return EAS_ERR_LAUNCH; \
     } while (0)
 

@@ -138,6 +138,7 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
     if (!out || !sample_offsets || B < 1 || Tm < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
     if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
     const size_t bytes = (size_t)B * Tm * 2 * H * W * sizeof(int32_t);
     if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (oob_count && hipMemsetAsync(oob_count, 0, sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
@@ -158,6 +159,7 @@ int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc,
                          eas_stream_t stream) {
     if (!counts || !out || F < 0 || H < 1 || W < 1 || Hc < H || Wc < W) return EAS_ERR_INVALID_ARG;
     if (F == 0) return EAS_OK;
+    EAS_CLEAR_ERR();
     hipLaunchKernelGGL(counts_to_canvas_kernel, dim3(eas_grid_1d(F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
                        F, H, W, Hc, Wc, out);
     EAS_CHECK_LAUNCH();
@@ -170,6 +172,7 @@ int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y
     if (!out || !sample_offsets || B < 1 || n_bins < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
     if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
     if (hipMemsetAsync(out, 0, (size_t)B * n_bins * H * W * sizeof(double), st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (nev == 0) return EAS_OK;
     hipLaunchKernelGGL(voxel_grid_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets,

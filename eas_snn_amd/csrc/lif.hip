@@ -17,7 +17,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_fwd_kernel(const float* __restr
     const float k = eas_lif_k(p);
     const float omk = 1.0f - k;
     const int T = T_ > 0 ? T_ : T_rt;
-    const int64_t nvec = M / VEC;
+    const int64_t nvec = (M % VEC == 0 || T == 1) ? M / VEC : 0;   // rows of [T][M] must be 16-B aligned for float4
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
         const float vr0 = HARD ? p.v_reset : 0.0f;
@@ -57,9 +57,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_fwd_kernel(const float* __restr
             reinterpret_cast<float4*>(mean_out)[i] = make_float4(acc.x / Tf, acc.y / Tf, acc.z / Tf, acc.w / Tf);
         }
     }
-    // scalar tail (M % 4 elements), handled by block 0
-    if (blockIdx.x == 0) {
-        for (int64_t j = nvec * VEC + threadIdx.x; j < M; j += blockDim.x) {
+    // scalar remainder (M % 4 elements, or everything when rows are unaligned)
+    {
+        for (int64_t j = nvec * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
             float v = v_in ? v_in[j] : (HARD ? p.v_reset : 0.0f), acc = 0.f;
             for (int t = 0; t < T; ++t) {
                 float h, s;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_bwd_kernel(const float* __restr
     const bool detach = (p.flags & EAS_LIF_DETACH_RESET) != 0;
     const int T = T_ > 0 ? T_ : T_rt;
     const float invT = 1.0f / (float)T;
-    const int64_t nvec = M / VEC;
+    const int64_t nvec = (M % VEC == 0 || T == 1) ? M / VEC : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float dk = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_bwd_kernel(const float* __restr
             reinterpret_cast<float4*>(grad_x + (int64_t)t * M)[i] = make_float4(gx[0], gx[1], gx[2], gx[3]);
         }
     }
-    if (blockIdx.x == 0) {
-        for (int64_t j = nvec * VEC + threadIdx.x; j < M; j += blockDim.x) {
+    {
+        for (int64_t j = nvec * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
             float gv = 0.f;
             const float gm = grad_mean ? grad_mean[j] * invT : 0.f;
             for (int t = T - 1; t >= 0; --t) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_gradw_finalize(const float* __r
 
 __global__ __launch_bounds__(EAS_BLOCK) void time_mean_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                               int T, int64_t M) {
-    const int64_t nvec = M / VEC;
+    const int64_t nvec = (M % VEC == 0 || T == 1) ? M / VEC : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float Tf = (float)T;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void time_mean_kernel(const float* __res
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(a.x / Tf, a.y / Tf, a.z / Tf, a.w / Tf);
     }
-    if (blockIdx.x == 0) {
-        for (int64_t j = nvec * VEC + threadIdx.x; j < M; j += blockDim.x) {
+    {
+        for (int64_t j = nvec * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += stride) {
             float a = 0.f;
             for (int t = 0; t < T; ++t) a += x[(int64_t)t * M + j];
             out[j] = a / Tf;
@@ -210,7 +210,7 @@ constexpr int kReduceBlocks = 2048;
 template <bool HARD, bool DI, bool STRICT>
 int launch_fwd(const float* x, const float* v_in, float* v_out, EasLifParams p, float* spikes, float* h_save, float* mean_out, int T,
                int64_t M, hipStream_t st) {
-    const int grid = eas_grid_1d(M / VEC);
+    const int grid = eas_grid_1d(M % VEC == 0 ? M / VEC : M);
 #define EAS_CASE(TT)                                                                                              \
     case TT:                                                                                                      \
         hipLaunchKernelGGL((lif_fwd_kernel<TT, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, x, v_in, v_out, \
@@ -231,7 +231,7 @@ template <bool HARD, bool DI, bool STRICT>
 int launch_bwd(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init, const float* x,
                EasLifParams p, int sg, float alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
                hipStream_t st) {
-    int grid = eas_grid_1d(M / VEC);
+    int grid = eas_grid_1d(M % VEC == 0 ? M / VEC : M);
     if (grid > kReduceBlocks) grid = kReduceBlocks;
     float* partial = grad_w ? workspace : nullptr;
     hipLaunchKernelGGL((lif_bwd_kernel<0, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean,
@@ -256,10 +256,10 @@ int eas_lif_fwd(const float* x, const float* v_in, float* v_out, const float* w_
     if (M == 0) return EAS_OK;
     if (((uintptr_t)x | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)h_save | (uintptr_t)mean_out) & 15)
         return EAS_ERR_INVALID_ARG;
-    if (M % 4 != 0 && T > 1) return EAS_ERR_UNSUPPORTED;  // rows of [T][M] must stay 16-B aligned
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) return launch_fwd<H, D, S>(x, v_in, v_out, p, spikes, h_save, mean_out, T, M, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (!hard && !di && strict) EAS_DISPATCH(false, false, true);
@@ -283,11 +283,11 @@ int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save
     if (((uintptr_t)grad_s | (uintptr_t)grad_mean | (uintptr_t)h_save | (uintptr_t)v_init | (uintptr_t)x |
          (uintptr_t)grad_x) & 15)
         return EAS_ERR_INVALID_ARG;
-    if (M % 4 != 0 && T > 1) return EAS_ERR_UNSUPPORTED;
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     if (di && w_logit && grad_w && !x) return EAS_ERR_INVALID_ARG;
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) \
     return launch_bwd<H, D, S>(grad_s, grad_mean, h_save, v_init, x, p, surrogate, alpha, grad_x, grad_w, workspace, T, M, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
@@ -305,8 +305,8 @@ int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t str
     if (!x || !out || T < 1 || M < 0) return EAS_ERR_INVALID_ARG;
     if (M == 0) return EAS_OK;
     if (((uintptr_t)x | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
-    if (M % 4 != 0 && T > 1) return EAS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(time_mean_kernel, dim3(eas_grid_1d(M / VEC)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, T, M);
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(time_mean_kernel, dim3(eas_grid_1d(M % VEC == 0 ? M / VEC : M)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, T, M);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

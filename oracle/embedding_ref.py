@@ -95,7 +95,7 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_uniform_(m.weight, nonlinearity='sigmoid')
 
-    def forward(self, events):
+    def forward(self, events, record=False):
         if events.dim() < 5:  # parameter-registration passthrough (embedding.py:144-146)
             ev, _ = torch.broadcast_tensors(events, torch.zeros((self.Ts,) + events.shape))
             return ev
@@ -107,6 +107,7 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
         seg = torch.zeros_like(ev[0], dtype=torch.long)
         t_last = torch.full_like(seg, -1)
         agg = [torch.zeros_like(ev[0]) for _ in range(self.Ts)]
+        t_record = []
         for t in range(Tm):
             g_rec, c_rec = self.gate_conv(spike).chunk(2, dim=-3)
             g_in, c_in = self.input_conv(ev[t]).chunk(2, dim=-3)
@@ -133,9 +134,12 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
             for k in range(self.Ts):
                 m = fired & (seg == k)
                 agg[k] = agg[k] + torch.where(m, val, torch.zeros_like(val))   # :194
-            seg = seg + fired.long()                               # :195
-            t_last = torch.where(fired, torch.full_like(t_last, t), t_last)   # :196
-            vsum = torch.where(fired, torch.zeros_like(vsum), vsum)           # :197
+            live = fired & (seg < self.Ts)                         # spike_pos is filtered by seg < Ts first (:183-184)
+            seg = seg + live.long()                                # :195
+            t_last = torch.where(live, torch.full_like(t_last, t), t_last)    # :196
+            vsum = torch.where(fired, torch.zeros_like(vsum), vsum)           # :197 (all fired positions)
+            if record:
+                t_record.append(t_last.clone())
             if int(seg.min()) >= self.Ts:                          # :200-201
                 break
         # tail (embedding.py:203-217)
@@ -154,7 +158,7 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
         out = torch.stack(agg)
         if self.abs:
             out = F.relu(out)
-        return out
+        return (out, torch.stack(t_record)) if record else out
 
 
 class SpikeCountEmbeddingRef(nn.Module):

@@ -27,9 +27,15 @@ def _wave(key, numel, lo, hi):
     return (lo + (hi - lo) * u).astype(np.float32)
 
 
-def procedural_fill_(module, conv_gain=1.0, plif_w=None):
-    """Fill ``module``'s parameters/buffers in place. Returns crc32 over all filled values."""
+def procedural_fill_(module, conv_gain=1.0, plif_w=None, ann_regex=None, ann_gain=1.0):
+    """Fill ``module``'s parameters/buffers in place. Returns crc32 over all filled values.
+
+    ``conv_gain`` scales conv weights in front of spiking neurons (binary inputs need a larger gain to keep
+    firing through depth); keys matching ``ann_regex`` are real-valued ANN layers and get ``ann_gain`` and a
+    contracting BN gamma so activations stay O(1) through ~30 layers in eval mode."""
+    import re
     crc = 0
+    ann = re.compile(ann_regex) if ann_regex else None
     sd = module.state_dict()
     for key in sorted(sd.keys()):
         t = sd[key]
@@ -38,16 +44,17 @@ def procedural_fill_(module, conv_gain=1.0, plif_w=None):
             continue
         n = t.numel()
         leaf = key.rsplit('.', 1)[-1]
+        is_ann = ann is not None and ann.search(key) is not None
         if t.dim() == 4:                                   # conv weight: uniform, variance ~ gain^2 * 2 / fan_in
             fan_in = t.shape[1] * t.shape[2] * t.shape[3]
-            r = conv_gain * (6.0 / fan_in) ** 0.5
+            r = (ann_gain if is_ann else conv_gain) * (6.0 / fan_in) ** 0.5
             v = _wave(key, n, -r, r)
         elif leaf == 'running_var':
             v = _wave(key, n, 0.5, 1.5)
         elif leaf == 'running_mean':
             v = _wave(key, n, -0.2, 0.2)
         elif leaf == 'weight':                             # BN gamma
-            v = _wave(key, n, 0.8, 1.6)
+            v = _wave(key, n, 0.5, 1.0) if is_ann else _wave(key, n, 0.8, 1.6)
         elif leaf == 'bias':
             v = _wave(key, n, -0.1, 0.3)
         elif leaf == 'w':                                  # PLIF decay logit
@@ -66,3 +73,12 @@ def poisson_events(shape, lam=0.3, seed=0):
     """Synthetic micro-slice count frames (Poisson(0.3) counts)."""
     rng = np.random.default_rng(seed)
     return rng.poisson(lam, size=shape).astype(np.float32)
+
+
+# which state_dict keys are real-valued ANN layers, per EventExp.use_spike mode
+ANN_KEYS = {
+    'True': r'^(head\.|backbone\.(?!backbone\.dark))',       # spiking: backbone.backbone.dark2..5 only
+    'full_spike': r'^head\.',
+    'full_spike_v2': None,
+    'False': r'^(head|backbone)\.',
+}

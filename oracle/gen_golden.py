@@ -286,7 +286,7 @@ def gen_blocks():
 def gen_models():
     from yolox.exp import get_exp
     from spikingjelly.activation_based import functional
-    from oracle.fill import poisson_events, procedural_fill_
+    from oracle.fill import ANN_KEYS, poisson_events, procedural_fill_
 
     base_opts = ['T', '3', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1',
                  'readout', 'sum', 'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True',
@@ -310,7 +310,7 @@ def gen_models():
         ('model_s_true_64', 'e-yolox-s', 'True', (), (2, 64, 64), 2.0),
         ('model_s_full_64', 'e-yolox-s', 'full_spike', (), (2, 64, 64), 2.0),
         ('model_s_fullv2_64', 'e-yolox-s', 'full_spike_v2', (), (2, 64, 64), 2.0),
-        ('model_s_false_64', 'e-yolox-s', 'False', (), (1, 64, 64), 1.0),
+        ('model_s_false_64', 'e-yolox-s', 'False', (), (1, 64, 64), 2.0),
         ('model_s_true_256x320', 'e-yolox-s', 'True', (), (1, 256, 320), 2.0),
         ('model_m_fullv2_t5_64x96', 'e-yolox-m', 'full_spike_v2', ('T', '5'), (1, 64, 96), 2.0),
         ('model_s_true_ts3_64', 'e-yolox-s', 'True', ('Ts', '3'), (1, 64, 64), 2.0),
@@ -318,7 +318,7 @@ def gen_models():
     for name, exp_name, us, extra, (B, H, W), gain in runs:
         exp, model = build(exp_name, us, extra)
         nparam = sum(p.numel() for p in model.parameters())
-        crc = procedural_fill_(model, conv_gain=gain)
+        crc = procedural_fill_(model, conv_gain=gain, ann_regex=ANN_KEYS[us])
         x = torch.from_numpy(poisson_events((B, 1, exp.Tm, 2, H, W), 0.5, seed=zlib.crc32(name.encode()) % 1000))
         keys = np.array(list(model.state_dict().keys()))
         model.eval()
@@ -352,7 +352,8 @@ def gen_models():
                 if n.endswith('running_mean') and ('dark2' in n or 'dark5' in n):
                     arrays[f'buf/{n}'] = _np(b)
         save(name, **arrays)
-        print(f'    {name}: params {nparam / 1e6:.3f} M, logits {tuple(logits.shape)}')
+        print(f'    {name}: params {nparam / 1e6:.3f} M, logits {tuple(logits.shape)} absmax {float(logits.abs().max()):.3g} '
+              f'finite {bool(torch.isfinite(logits).all())}')
 
 
 def main():

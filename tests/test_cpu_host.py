@@ -28,6 +28,7 @@ def _header_functions():
 def test_library_builds_loads_and_exports_every_declared_symbol():
     path = eas_snn_amd.build()
     assert os.path.exists(path)
+    eas_snn_amd._lib._bind_host_hip_runtime()      # the library binds to the host process's HIP runtime
     handle = ctypes.CDLL(path)
     names = _header_functions()
     assert len(names) >= 17
