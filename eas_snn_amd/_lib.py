@@ -40,6 +40,10 @@ PROTOTYPES = {
                                                  C.c_float, C.c_int, C.c_int, C.c_int, _P]),
     'eas_arsnn_tail_fwd': (C.c_int, [_P] * 6 + [C.c_int] * 7 + [_P]),
     'eas_arsnn_tail_bwd': (C.c_int, [_P] * 6 + [C.c_int] * 7 + [_P]),
+    'eas_smallconv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 7 + [_P]),
+    'eas_smallconv_bwd_input': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
+    'eas_smallconv_bwd_weight': (C.c_int, [_P] * 5 + [C.c_int] * 6 + [_P]),
+    'eas_smallconv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 3),
 }
 
 

@@ -260,26 +260,51 @@ def event_voxel_grid(t, x, y, p, sample_offsets, n_bins, H, W):
 
 
 # ------------------------------------------------------------------------------------------------ K3
+def smallconv_fwd(x, w, b, relu=False):
+    """Direct LDS-tiled conv (stride 1, 'same' padding) for the sampler's tiny-channel stacks."""
+    x, w = _f32c(x), _f32c(w)
+    N, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[-1]
+    y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    _call('eas_smallconv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_smallconv_fwd, ptr(x), ptr(w), ptr(b), ptr(y), N, Cin, Cout,
+          H, W, k, int(relu), stream())
+    return y
+
+
+def smallconv_bwd_input(gy, w, relu_mask=None):
+    gy, w = _f32c(gy), _f32c(w)
+    N, Cout, H, W = gy.shape
+    Cin, k = w.shape[1], w.shape[-1]
+    gx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=gy.device)
+    _call('eas_smallconv_bwd_input', 4 * (gy.numel() + gx.numel()), _lib.lib().eas_smallconv_bwd_input, ptr(gy), ptr(w),
+          ptr(relu_mask), ptr(gx), N, Cin, Cout, H, W, k, stream())
+    return gx
+
+
+def smallconv_bwd_weight(gy, x, w):
+    gy, x = _f32c(gy), _f32c(x)
+    N, Cout, H, W = gy.shape
+    Cin, k = w.shape[1], w.shape[-1]
+    L = _lib.lib()
+    gw, gb = torch.empty_like(w), torch.empty(Cout, dtype=torch.float32, device=gy.device)
+    ws = torch.empty(L.eas_smallconv_wgrad_workspace_floats(Cin, Cout, k), dtype=torch.float32, device=gy.device)
+    _call('eas_smallconv_bwd_weight', 4 * (gy.numel() + x.numel()), L.eas_smallconv_bwd_weight, ptr(gy), ptr(x), ptr(gw), ptr(gb),
+          ptr(ws), N, Cin, Cout, H, W, k, stream())
+    return gw, gb
+
+
 def _conv_stack_fwd(x, params, k):
-    """Conv(k, pad k//2) [+ ReLU + Conv]*: returns (out, inputs of every conv)."""
+    """Conv(k, pad k//2) [+ ReLU + Conv]*: returns (out, inputs of every conv).  ReLU is fused into the producing conv."""
     ins = []
-    pad = k // 2
-    for i in range(0, len(params), 2):
-        if i > 0:
-            x = torch.relu(x)
+    n = len(params) // 2
+    for i in range(n):
         ins.append(x)
-        x = torch.nn.functional.conv2d(x, params[i], params[i + 1], padding=pad)
+        x = smallconv_fwd(x, params[2 * i], params[2 * i + 1], relu=(i < n - 1))
     return x, ins
 
 
-def _conv_dgrad(g, inp, w, pad, need_input=True, need_params=False):
-    gi, gw, gb = torch.ops.aten.convolution_backward(g, inp, w, [w.shape[0]], [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                     [need_input, need_params, need_params])
-    return gi, gw, gb
-
-
 class _ARSNNFn(torch.autograd.Function):
-    """Whole adaptive-sampler loop as ONE autograd node (embedding.py:141-226): conv stacks via MIOpen,
+    """Whole adaptive-sampler loop as ONE autograd node (embedding.py:141-226): conv stacks via eas_smallconv_*,
     the per-step integrate / fire / reset / segment-write via eas_arsnn_step_*."""
 
     @staticmethod
@@ -376,27 +401,23 @@ class _ARSNNFn(torch.autograd.Function):
                 g_stage[i][t] = g
                 if i == 0 and t == 0:
                     break                      # spike input of step 0 is the constant 0
-                g, _, _ = _conv_dgrad(g, g_ins[i], pg[2 * i], pad, True, False)
-                if i > 0:
-                    g = g * (g_ins[i] > 0)     # ReLU in front of conv i
+                g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None)   # ReLU in front of conv i fused as a mask
             g_spike = g if t > 0 else None
         grads_g = []
         for i in range(depth):
             gs = torch.cat(g_stage[i], 0)
             xs = torch.cat([saved[t][0][i] for t in range(Tm)], 0)
-            _, gw, gb = _conv_dgrad(gs, xs, pg[2 * i], pad, False, True)
+            gw, gb = smallconv_bwd_weight(gs, xs, pg[2 * i])
             grads_g += [gw, gb]
         # input conv stack, all Tm steps at once
         grads_in = [None] * (2 * depth)
         g = gX.view(Tm * N, 2 * C2, H, W)
         for i in range(depth - 1, -1, -1):
-            need_in = i > 0 or ctx.ev_needs_grad
-            gi, gw, gb = _conv_dgrad(g, in_ins[i], pin[2 * i], pad, need_in, True)
-            grads_in[2 * i], grads_in[2 * i + 1] = gw, gb
-            if i > 0:
-                g = gi * (in_ins[i] > 0)
+            grads_in[2 * i], grads_in[2 * i + 1] = smallconv_bwd_weight(g, in_ins[i], pin[2 * i])
+            if i > 0 or ctx.ev_needs_grad:
+                g = smallconv_bwd_input(g, pin[2 * i], in_ins[i] if i > 0 else None)
             else:
-                g = gi
+                g = None
         g_ev = g.view(Tm, N, Cin, H, W) if ctx.ev_needs_grad else None
         return (g_ev, None) + tuple(grads_in) + tuple(grads_g)
 

@@ -156,6 +156,25 @@ int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int32_
                        float* g_v, float* g_vsum, int Tm, int Ts, int readout, int write_zero, int N, int C2,
                        int HW, eas_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Direct convolution for the sampler's conv stacks, Conv2d(2->4,k,p=k/2) [+ReLU+Conv2d(4->4,k)]
+ * (yolox/models/embedding.py:106-111; replaces the F.conv2d calls and their autograd): stride 1, "same" zero
+ * padding, NCHW fp32, (Cin,Cout) in {(2,4),(4,4),(2,2)}, k in {3,5,7}.  LDS-tiled (16x64 output tile + halo for all
+ * input channels staged once; every output channel computed from registers).
+ * x: [N][Cin][H][W], w: [Cout][Cin][k][k], b: [Cout] (nullable), y: [N][Cout][H][W]; relu != 0 applies max(.,0). */
+int eas_smallconv_fwd(const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout, int H,
+                      int W, int k, int relu, eas_stream_t stream);
+/* grad_x = correlation of grad_y with the flipped, channel-transposed filter; when relu_mask != NULL
+ * (the ReLU OUTPUT that fed this conv's input... i.e. the tensor the gradient flows back into), grad_x is zeroed
+ * where relu_mask <= 0 (fused ReLU backward). */
+int eas_smallconv_bwd_input(const float* grad_y, const float* w, const float* relu_mask, float* grad_x, int N, int Cin,
+                            int Cout, int H, int W, int k, eas_stream_t stream);
+/* grad_w [Cout][Cin][k][k] and grad_b [Cout] (nullable); deterministic two-stage reduction through
+ * workspace (eas_smallconv_wgrad_workspace_floats(Cin,Cout,k) floats). */
+int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w, float* grad_b, float* workspace,
+                             int N, int Cin, int Cout, int H, int W, int k, eas_stream_t stream);
+int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k);
+
 #ifdef __cplusplus
 }
 #endif

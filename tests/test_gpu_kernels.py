@@ -289,3 +289,33 @@ def test_arsnn_golden(dev, name):
         np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=2e-3, atol=1e-3)
         for n, p in m.named_parameters():
             np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=2e-3, atol=2e-3, err_msg=n)
+
+
+# ------------------------------------------------------------------------------------------------ sampler convs
+@pytest.mark.parametrize('cin,cout,k,N,H,W', [(2, 4, 5, 3, 32, 64), (4, 4, 5, 2, 48, 80), (2, 4, 7, 2, 20, 36), (4, 4, 3, 1, 16, 64),
+                                               (2, 2, 5, 2, 17, 30), (4, 4, 7, 1, 256, 320), (2, 4, 3, 5, 33, 130)])
+def test_smallconv_vs_fp64_reference(dev, cin, cout, k, N, H, W):
+    """eas_smallconv_{fwd,bwd_input,bwd_weight} against an fp64 torch convolution on the CPU (tile edges, halos,
+    H/W not multiples of the 16x64 tile, W not a multiple of 4, fused ReLU / ReLU-mask epilogues)."""
+    from eas_snn_amd import ops
+    rng = np.random.default_rng(cin * 100 + cout * 10 + k)
+    x = rng.standard_normal((N, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    gy = rng.standard_normal((N, cout, H, W)).astype(np.float32)
+    mask = rng.standard_normal((N, cin, H, W)).astype(np.float32)
+    xd, wd, bd, gyd = (torch.from_numpy(a).double().requires_grad_(True) for a in (x, w, b, gy))
+    ref = torch.nn.functional.conv2d(xd, wd, bd, padding=k // 2)
+    ref.backward(gyd.detach())
+    for relu in (False, True):
+        y = ops.smallconv_fwd(_t(x, dev), _t(w, dev), _t(b, dev), relu=relu).cpu().numpy()
+        want = ref.detach().numpy()
+        np.testing.assert_allclose(y, np.maximum(want, 0) if relu else want, rtol=1e-5, atol=1e-5)
+    gx = ops.smallconv_bwd_input(_t(gy, dev), _t(w, dev)).cpu().numpy()
+    np.testing.assert_allclose(gx, xd.grad.numpy(), rtol=1e-5, atol=1e-5)
+    gxm = ops.smallconv_bwd_input(_t(gy, dev), _t(w, dev), _t(mask, dev)).cpu().numpy()
+    np.testing.assert_allclose(gxm, xd.grad.numpy() * (mask > 0), rtol=1e-5, atol=1e-5)
+    gw, gb = ops.smallconv_bwd_weight(_t(gy, dev), _t(x, dev), _t(w, dev))
+    scale = np.sqrt(N * H * W)
+    np.testing.assert_allclose(gw.cpu().numpy(), wd.grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3)), rtol=1e-4, atol=2e-5 * scale)
