@@ -28,12 +28,14 @@ PROTOTYPES = {
                               _P, _P, _P, C.c_int, C.c_int64, _P]),
     'eas_reduce_workspace_floats': (C.c_int64, [C.c_int64]),
     'eas_time_mean': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
-    'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
+    'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     'eas_bn_workspace_doubles': (C.c_int64, [C.c_int]),
     'eas_bn_lif_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
-                                 C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
-                                 C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+                                 C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_bn_silu_fwd': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
+    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 3 + [_P]),
     'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, _P]),
     'eas_arsnn_step_bwd': (C.c_int, [_P] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,

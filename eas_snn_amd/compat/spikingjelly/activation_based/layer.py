@@ -20,6 +20,15 @@ class SeqToANNContainer(nn.Sequential, base.StepModule):
         return ('m',)
 
     def forward(self, x_seq):
+        base = getattr(x_seq, '_eas_base', None)
+        if base is not None:
+            # x_seq is T identical frames (stride-0 broadcast of ``base``, spiking_yolox.py:52-57): a stateless module
+            # gives T identical results, so it runs once and the result is broadcast again (bit-identical, 1/T the work)
+            with ops.replicated(x_seq.shape[0]):      # BN inside sees N samples that stand for T*N
+                y0 = super().forward(base)
+            y = y0.unsqueeze(0).expand(x_seq.shape[0], *y0.shape)
+            y._eas_base = y0
+            return y
         return functional.seq_to_ann_forward(x_seq, super().forward)
 
 
@@ -48,6 +57,7 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
         """spikes = node(self(y_seq)) for y_seq [T,N,C,H,W] without materialising the BN output."""
         if not (self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
                 and (self.momentum is not None or not self.training)):
+            y_seq = y_seq.contiguous()
             out = node(self(y_seq))
             return (out, ops.time_mean(out)) if want_mean else out
         batch = self._use_batch_stats()
@@ -55,11 +65,12 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
             self.num_batches_tracked.add_(1)
         a = node.lif_args()
         update = batch and self.training and self.track_running_stats
+        base = getattr(y_seq, '_eas_base', None)       # conv output shared by all T steps (identical input frames)
         spikes, v_out, mean = ops.bn_lif_multistep(
-            y_seq, self.weight, self.bias, self.running_mean if (update or not batch) else None,
+            y_seq if base is None else base, self.weight, self.bias, self.running_mean if (update or not batch) else None,
             self.running_var if (update or not batch) else None, batch, self.momentum if update else None, self.eps,
             node._v_in(y_seq[0]), a['w'], a['k_const'], a['v_th'], a['v_reset'], a['flags'], a['surrogate'], a['alpha'],
-            want_mean=want_mean)
+            want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0])
         if v_out is not None:
             node.v = v_out
         return (spikes, mean) if want_mean else spikes

@@ -7,6 +7,7 @@ separate module calls."""
 import torch
 import torch.nn as nn
 
+from eas_snn_amd import ops
 from spikingjelly.activation_based import layer as sj_layer
 from spikingjelly.activation_based import neuron as sj_neuron
 
@@ -33,7 +34,11 @@ class BaseConv(nn.Module):
     def forward(self, x):
         if isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d):
             return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate)
-        return self.act(self.bn(self.conv(x)))
+        y = self.conv(x)
+        if (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
+                and (self.bn.momentum is not None or not self.bn.training)):
+            return ops.bn_silu(y, self.bn)          # one statistics pass + one fused normalise/SiLU pass (HIP)
+        return self.act(self.bn(y))
 
     def fuseforward(self, x):
         return self.act(self.conv(x))

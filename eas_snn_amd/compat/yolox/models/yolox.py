@@ -56,10 +56,10 @@ class SpikingYOLOX(nn.Module):
     def forward(self, x, targets=None):
         x = _run_embedding(self.embedding, x, 5)
         # one adaptive frame is repeated for all T steps; Ts > 1 must equal T (spiking_yolox.py:52-57)
-        if x.dim() == 4:
-            x = x.unsqueeze(0).expand(self.nb_steps, *x.shape)
-        elif x.shape[0] == 1:
-            x = x.expand(self.nb_steps, *x.shape[1:])
+        if x.dim() == 4 or x.shape[0] == 1:
+            base = x if x.dim() == 4 else x[0]
+            x = base.unsqueeze(0).expand(self.nb_steps, *base.shape)
+            x._eas_base = base          # lets stateless layers in front of the first neuron run once instead of T times
         else:
             assert x.shape[0] == self.nb_steps, 'the timestep of SNN is not matched with that of input'
         return _head_outputs(self, self.backbone(x), targets, x)

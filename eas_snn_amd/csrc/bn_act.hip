@@ -1,0 +1,160 @@
+// BatchNorm2d + SiLU fused, forward and backward, for the real-valued (ANN) BaseConv blocks of the stem, PAFPN neck
+// and head (yolox/models/network_blocks.py:52-53 with act = nn.SiLU).  Same decomposition as bn_lif.hip:
+// blockIdx.y = channel, blockIdx.x = chunk of that channel's N*HW/4 float4 groups; statistics come from
+// eas_bn_stats.  HBM traffic per element: fwd 8 B (read y, write out); bwd 20 B (two passes over y and grad_out
+// because the BN backward needs sum(dz) and sum(dz*xhat) first, then writes grad_y); nothing but y is saved.
+#include "eas_common.h"
+
+namespace {
+
+constexpr int VEC = 4;
+constexpr int kMaxChunks = 64;
+constexpr int NW = EAS_BLOCK / EAS_WAVE;
+
+static inline int pick_chunks(int64_t groups_per_channel, int C) {
+    int64_t want = (groups_per_channel + EAS_BLOCK - 1) / EAS_BLOCK;
+    int64_t cap = 8192 / (C > 0 ? C : 1);
+    if (cap < 1) cap = 1;
+    if (cap > kMaxChunks) cap = kMaxChunks;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+__device__ __forceinline__ float silu(float z) { return z * eas_sigmoidf(z); }
+__device__ __forceinline__ float silu_grad(float z) {
+    const float sg = eas_sigmoidf(z);
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ out, int N,
+                                                                int C, int HW) {
+    const int c = blockIdx.y;
+    const float scale = gamma[c] * invstd[c];
+    const float shift = beta[c] - mean[c] * scale;
+    const int hw4 = HW / VEC;
+    const int64_t groups = (int64_t)N * hw4;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / hw4;
+        const int q = (int)(g - n * hw4);
+        const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        const float4 v = *reinterpret_cast<const float4*>(y + base);
+        float4 o;
+        o.x = silu(fmaf(v.x, scale, shift)); o.y = silu(fmaf(v.y, scale, shift));
+        o.z = silu(fmaf(v.z, scale, shift)); o.w = silu(fmaf(v.w, scale, shift));
+        *reinterpret_cast<float4*>(out + base) = o;
+    }
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __restrict__ grad_out, const float* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int batch_stats, double* __restrict__ part, int nchunks,
+                                                                float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+                                                                float* __restrict__ grad_beta, int N, int C, int HW) {
+    __shared__ double red[NW];
+    __shared__ float bc[2];
+    const int c = blockIdx.y;
+    const float mu = mean[c], istd = invstd[c];
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
+    const int hw4 = HW / VEC;
+    const int64_t groups = (int64_t)N * hw4;
+    float m1 = 0.f, m2 = 0.f;
+    if (APPLY) {
+        if (threadIdx.x < EAS_WAVE) {
+            double s1 = 0.0, s2 = 0.0;
+            if ((int)threadIdx.x < nchunks) {
+                s1 = part[((int64_t)c * kMaxChunks + threadIdx.x) * 2 + 0];
+                s2 = part[((int64_t)c * kMaxChunks + threadIdx.x) * 2 + 1];
+            }
+            s1 = eas_wave_sum(s1);
+            s2 = eas_wave_sum(s2);
+            if (threadIdx.x == 0) {
+                const double cnt = (double)N * HW;
+                bc[0] = (float)(s1 / cnt);
+                bc[1] = (float)(s2 / cnt);
+                if (blockIdx.x == 0) {
+                    grad_beta[c] = (float)s1;
+                    grad_gamma[c] = (float)s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = g / hw4;
+        const int q = (int)(g - n * hw4);
+        const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        const float4 yv = *reinterpret_cast<const float4*>(y + base);
+        const float4 gv = *reinterpret_cast<const float4*>(grad_out + base);
+        const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dz = gs[e] * silu_grad(fmaf(ys[e], scale, shift));
+            const float xhat = (ys[e] - mu) * istd;
+            if (APPLY) {
+                o[e] = scale * (dz - m1 - xhat * m2);
+            } else {
+                s1 += dz;
+                s2 += dz * xhat;
+            }
+        }
+        if (APPLY) *reinterpret_cast<float4*>(grad_y + base) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (!APPLY) {
+        const double t1 = eas_block_sum<double, NW>((double)s1, red);
+        const double t2 = eas_block_sum<double, NW>((double)s2, red);
+        if (threadIdx.x == 0) {
+            part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 0] = t1;
+            part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 1] = t2;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    float* out, int N, int C, int HW, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || !out || N < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
+    if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)y | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                    double* workspace, int N, int C, int HW, eas_stream_t stream) {
+    if (!grad_out || !y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
+        N < 1 || C < 1 || HW < 1)
+        return EAS_ERR_INVALID_ARG;
+    if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)y | (uintptr_t)grad_out | (uintptr_t)grad_y) & 15) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    hipLaunchKernelGGL(bn_silu_bwd_kernel<false>, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
+                       batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_silu_bwd_kernel<true>, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
+                       batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+}  // extern "C"

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial_scalar(const float
 }
 
 __global__ __launch_bounds__(EAS_WAVE) void bn_stats_finalize(const double* __restrict__ part, int nchunks, double count,
-                                                              float eps, float momentum, float* __restrict__ mean,
+                                                              int replicas, float eps, float momentum, float* __restrict__ mean,
                                                               float* __restrict__ invstd, float* __restrict__ rmean,
                                                               float* __restrict__ rvar) {
     const int c = blockIdx.x;
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(EAS_WAVE) void bn_stats_finalize(const double* __re
         mean[c] = (float)m;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
         if (rmean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            const double full = count * replicas;   // identical replicas leave mean/var unchanged, only the sample count grows
+            const double unbiased = full > 1.0 ? var * full / (full - 1.0) : var;
             rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
             rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
         }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* v_in, float* v_out,
                                                                EasLifParams p, float* __restrict__ spikes,
-                                                               float* __restrict__ mean_out, int N, int C, int HW) {
+                                                               float* __restrict__ mean_out, int N, int C, int HW, int bcast) {
     const int c = blockIdx.y;
     const float scale = gamma[c] * invstd[c];
     const float shift = beta[c] - mean[c] * scale;
@@ -115,13 +116,14 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
     const int64_t M = (int64_t)N * C * HW;
+    const int64_t yts = bcast ? 0 : M;       // T identical input frames: one plane stands for all steps
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = g / hw4;
         const int q = (int)(g - n * hw4);
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         float4 ys[T_];
 #pragma unroll
-        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * M + base);
+        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + base);
         const float vr0 = HARD ? p.v_reset : 0.0f;
         float4 v = v_in ? *reinterpret_cast<const float4*>(v_in + base) : make_float4(vr0, vr0, vr0, vr0);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
     int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-    float* __restrict__ grad_beta, int N, int C, int HW) {
+    float* __restrict__ grad_beta, int N, int C, int HW, int bcast) {
     __shared__ double red[NW];
     __shared__ float bc[2];
     const int c = blockIdx.y;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const int64_t groups = (int64_t)N * hw4;
     const int64_t M = (int64_t)N * C * HW;
     const float invT = 1.0f / (float)T_;
+    const int64_t yts = bcast ? 0 : M;
     float m1 = 0.f, m2 = 0.f;
     if (APPLY) {
         // fixed-order reduction of this channel's chunk partials (every block computes the same value)
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         float4 ys[T_], gsv[T_];
 #pragma unroll
-        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * M + base);
+        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + base);
         float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
         if (grad_mean) {
             gm = *reinterpret_cast<const float4*>(grad_mean + base);
@@ -262,8 +265,15 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
             dk += dke;
         }
         if (APPLY) {
+            if (bcast) {                            // the T steps share one input plane: its gradient is their sum
+                float4 a = outv[0];
 #pragma unroll
-            for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * M + base) = outv[t];
+                for (int t = 1; t < T_; ++t) { a.x += outv[t].x; a.y += outv[t].y; a.z += outv[t].z; a.w += outv[t].w; }
+                *reinterpret_cast<float4*>(grad_y + base) = a;
+            } else {
+#pragma unroll
+                for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * M + base) = outv[t];
+            }
         }
     }
     if (!APPLY) {
@@ -296,10 +306,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_gradw_finalize(const double*
 template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_fwd_t(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                  const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-                 hipStream_t st) {
+                 int bcast, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
-                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW);
+                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -307,9 +317,9 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
 template <bool HARD, bool DI, bool STRICT>
 int launch_fwd(int T, const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-               hipStream_t st) {
+               int bcast, hipStream_t st) {
 #define EAS_CASE(TT) \
-    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, st);
+    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -321,15 +331,15 @@ template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
-                 int C, int HW, hipStream_t st) {
+                 int C, int HW, int bcast, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, N, C, HW);
+                       grad_gamma, grad_beta, N, C, HW, bcast);
     EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, N, C, HW);
+                       grad_gamma, grad_beta, N, C, HW, bcast);
     EAS_CHECK_LAUNCH();
     if (grad_w) {
         hipLaunchKernelGGL(bn_lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, ws, C, chunks, p.w_logit, grad_w);
@@ -342,11 +352,11 @@ template <bool HARD, bool DI, bool STRICT>
 int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* y, const float* mean,
                const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
                float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
-               double* ws, int N, int C, int HW, hipStream_t st) {
+               double* ws, int N, int C, int HW, int bcast, hipStream_t st) {
 #define EAS_CASE(TT)                                                                                               \
     case TT:                                                                                                       \
         return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
-                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, st);
+                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -360,9 +370,9 @@ extern "C" {
 
 int64_t eas_bn_workspace_doubles(int C) { return (int64_t)C * kMaxChunks * 4; }
 
-int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentum, float* mean, float* invstd,
-                 float* running_mean, float* running_var, double* workspace, eas_stream_t stream) {
-    if (!y || !mean || !invstd || !workspace || TN < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
+int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps, float momentum, float* mean,
+                 float* invstd, float* running_mean, float* running_var, double* workspace, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !workspace || TN < 1 || C < 1 || HW < 1 || replicas < 1) return EAS_ERR_INVALID_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return EAS_ERR_INVALID_ARG;
     if (C > 65535) return EAS_ERR_UNSUPPORTED;
     hipStream_t st = eas_s(stream);
@@ -376,7 +386,7 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentu
         hipLaunchKernelGGL(bn_stats_partial_scalar, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
     }
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, eps,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, replicas, eps,
                        momentum, mean, invstd, running_mean, running_var);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -384,7 +394,8 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentu
 
 int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
-                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, eas_stream_t stream) {
+                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
+                   eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !spikes || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
@@ -394,7 +405,7 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) \
-    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, st)
+    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -407,7 +418,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
                    const float* invstd, const float* gamma, const float* beta, const float* v_init,
                    const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                    float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                   float* grad_w, double* workspace, int T, int N, int C, int HW, eas_stream_t stream) {
+                   float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
         (!grad_s && !grad_mean) || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
@@ -422,7 +433,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
-                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, st)
+                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);

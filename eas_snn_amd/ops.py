@@ -154,33 +154,40 @@ class _TimeMeanFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ K4 (BN + LIF)
 class _BNLIFFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v):
+    def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v, t_bcast):
+        """y: [T,N,C,H,W], or [N,C,H,W] standing for ``t_bcast`` identical time steps."""
         running_mean, running_var, use_batch_stats, momentum, eps = bn_state
         _dev(y, gamma, beta, v_in, w)
         L = _lib.lib()
         y = _f32c(y)
         v_in = _f32c(v_in)
-        T, N, Cc = y.shape[0], y.shape[1], y.shape[2]
-        HW = y[0, 0, 0].numel()
+        if t_bcast:
+            T, (N, Cc) = int(t_bcast), y.shape[:2]
+            plane = y.shape
+        else:
+            T, N, Cc = y.shape[0], y.shape[1], y.shape[2]
+            plane = y.shape[1:]
+        HW = plane[-1] * plane[-2]
         dev = y.device
         if use_batch_stats:
             mean = torch.empty(Cc, dtype=torch.float32, device=dev)
             invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
             ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
-            _call('eas_bn_stats', 4 * y.numel(), L.eas_bn_stats, ptr(y), T * N, Cc, HW, eps,
+            _call('eas_bn_stats', 4 * y.numel(), L.eas_bn_stats, ptr(y), N if t_bcast else T * N, Cc, HW, T if t_bcast else 1, eps,
                   momentum if momentum is not None else 0.0, ptr(mean), ptr(invstd),
                   ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None,
                   ptr(ws), stream())
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-        spikes = torch.empty_like(y)
-        v_out = torch.empty_like(y[0]) if write_v else None
-        mo = torch.empty_like(y[0]) if want_mean else None
-        _call('eas_bn_lif_fwd', 8 * y.numel(), L.eas_bn_lif_fwd, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in),
-              ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, stream())
+        spikes = torch.empty((T,) + tuple(plane), dtype=torch.float32, device=dev)
+        v_out = torch.empty(plane, dtype=torch.float32, device=dev) if write_v else None
+        mo = torch.empty(plane, dtype=torch.float32, device=dev) if want_mean else None
+        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()), L.eas_bn_lif_fwd, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+              ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, int(bool(t_bcast)),
+              stream())
         ctx.save_for_backward(y, mean, invstd, gamma, beta, v_in, w)
-        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), T, N, Cc, HW)
+        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), T, N, Cc, HW, bool(t_bcast))
         if v_out is not None:
             ctx.mark_non_differentiable(v_out)
         return spikes, v_out, mo
@@ -188,9 +195,9 @@ class _BNLIFFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_s, g_v, g_mean):
         y, mean, invstd, gamma, beta, v_in, w = ctx.saved_tensors
-        k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW = ctx.cfg
+        k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW, bcast = ctx.cfg
         L = _lib.lib()
-        nout = 14
+        nout = 15
         if g_s is None and g_mean is None:
             return (torch.zeros_like(y),) + (None,) * (nout - 1)
         g_s = _f32c(g_s)
@@ -201,9 +208,11 @@ class _BNLIFFn(torch.autograd.Function):
         want_w = w is not None and ctx.needs_input_grad[5]
         gw = torch.empty_like(w) if want_w else None
         ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
-        _call('eas_bn_lif_bwd', 12 * y.numel(), L.eas_bn_lif_bwd, ptr(g_s), ptr(g_mean), ptr(y), ptr(mean), ptr(invstd),
-              ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy),
-              ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, stream())
+        nsteps = T * N * Cc * HW
+        _call('eas_bn_lif_bwd', 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel()), L.eas_bn_lif_bwd,
+              ptr(g_s), ptr(g_mean), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th,
+              v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW,
+              int(bcast), stream())
         return (gy, ggamma, gbeta, None, None, gw) + (None,) * (nout - 6)
 
 
@@ -212,14 +221,89 @@ def bn_lif_supported(y_seq, T):
 
 
 def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_stats, momentum, eps, v_in, w, k_const,
-                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None):
-    """Fused BatchNorm(step_mode='m') + multi-step LIF on the conv output y_seq [T,N,C,H,W]."""
+                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None, t_bcast=0):
+    """Fused BatchNorm(step_mode='m') + multi-step LIF on the conv output y_seq [T,N,C,H,W]
+    (or one plane [N,C,H,W] shared by ``t_bcast`` identical steps)."""
     if write_v is None:
         write_v = _STATE_WRITEBACK
     state = (running_mean, running_var, bool(use_batch_stats), None if momentum is None else float(momentum), float(eps))
     return _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags),
                           SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate), float(alpha),
-                          bool(want_mean), bool(write_v))
+                          bool(want_mean), bool(write_v), int(t_bcast))
+
+
+# Number of identical copies the current batch stands for (set by SeqToANNContainer while it runs a stateless block
+# ONCE for T identical time steps): batch-norm statistics are unchanged by replication except for the sample count
+# used in the unbiased running variance.
+_REPLICAS = 1
+
+
+class replicated:
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _REPLICAS
+        self.prev, _REPLICAS = _REPLICAS, self.n
+
+    def __exit__(self, *exc):
+        global _REPLICAS
+        _REPLICAS = self.prev
+
+
+class _BNSiLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, bn_state):
+        running_mean, running_var, use_batch_stats, momentum, eps, replicas = bn_state
+        _dev(y, gamma, beta)
+        L = _lib.lib()
+        y = _f32c(y)
+        N, Cc = y.shape[:2]
+        HW = y.shape[-1] * y.shape[-2]
+        dev = y.device
+        if use_batch_stats:
+            mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+            invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+            ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
+            _call('eas_bn_stats', 4 * y.numel(), L.eas_bn_stats, ptr(y), N, Cc, HW, replicas, eps, momentum if momentum is not None else 0.0,
+                  ptr(mean), ptr(invstd), ptr(running_mean) if momentum is not None else None,
+                  ptr(running_var) if momentum is not None else None, ptr(ws), stream())
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        out = torch.empty_like(y)
+        _call('eas_bn_silu_fwd', 8 * y.numel(), L.eas_bn_silu_fwd, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), N, Cc,
+              HW, stream())
+        ctx.save_for_backward(y, mean, invstd, gamma, beta)
+        ctx.cfg = (bool(use_batch_stats), N, Cc, HW)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, mean, invstd, gamma, beta = ctx.saved_tensors
+        batch_stats, N, Cc, HW = ctx.cfg
+        L = _lib.lib()
+        g = _f32c(g)
+        gy, ggamma, gbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
+        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
+        _call('eas_bn_silu_bwd', 12 * y.numel(), L.eas_bn_silu_bwd, ptr(g), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, stream())
+        return gy, ggamma, gbeta, None
+
+
+def bn_silu_supported(y):
+    return y.is_cuda and y.dim() == 4 and y.dtype == torch.float32 and (y.shape[-1] * y.shape[-2]) % 4 == 0
+
+
+def bn_silu(y, bn):
+    """silu(batch_norm(y)) for a plain ``nn.BatchNorm2d`` module ``bn`` (running statistics updated like F.batch_norm)."""
+    batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    update = batch and bn.training and bn.track_running_stats
+    if update and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    state = (bn.running_mean if (update or not batch) else None, bn.running_var if (update or not batch) else None, bool(batch),
+             float(bn.momentum) if update else None, float(bn.eps), _REPLICAS)
+    return _BNSiLUFn.apply(y, bn.weight, bn.bias, state)
 
 
 # ------------------------------------------------------------------------------------------------ K1

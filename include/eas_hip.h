@@ -104,16 +104,20 @@ int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t str
 
 /* per-channel batch statistics: mean[C], invstd[C] (biased variance, eps inside), and the
  * running-stat update running = (1-momentum)*running + momentum*batch (unbiased variance),
- * skipped when running_mean == NULL.  workspace: eas_bn_workspace_doubles(C) doubles. */
-int eas_bn_stats(const float* y, int TN, int C, int HW, float eps, float momentum, float* mean, float* invstd,
-                 float* running_mean, float* running_var, double* workspace, eas_stream_t stream);
+ * skipped when running_mean == NULL.  replicas >= 1: y stands for that many identical copies (the T-broadcast of
+ * one adaptive frame, spiking_yolox.py:52-57): mean/var are those of one copy, the unbiased-variance count is
+ * TN*HW*replicas.  workspace: eas_bn_workspace_doubles(C) doubles. */
+int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps, float momentum, float* mean,
+                 float* invstd, float* running_mean, float* running_var, double* workspace, eas_stream_t stream);
 int64_t eas_bn_workspace_doubles(int C);
 
 /* z = gamma*(y-mean)*invstd + beta, then the LIF recurrence over T (same neuron arguments as
- * eas_lif_fwd).  Nothing but y needs to be kept for backward. */
+ * eas_lif_fwd).  Nothing but y needs to be kept for backward.  y_bcast != 0: y is ONE plane [N][C][HW] that
+ * feeds all T steps (identical input frames); eas_bn_lif_bwd then returns grad_y [N][C][HW] summed over the steps. */
 int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
-                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, eas_stream_t stream);
+                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
+                   eas_stream_t stream);
 
 /* Backward, pass 1: recompute the forward from y, run the LIF backward and reduce per channel
  * sum(dz), sum(dz*xhat) (-> grad_beta, grad_gamma) and the neuron's grad_w.  Pass 2 (apply):
@@ -124,7 +128,17 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
                    const float* invstd, const float* gamma, const float* beta, const float* v_init,
                    const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                    float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                   float* grad_w, double* workspace, int T, int N, int C, int HW, eas_stream_t stream);
+                   float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
+
+/* BatchNorm2d + SiLU fused for the real-valued BaseConv blocks (stem, PAFPN neck, head:
+ * yolox/models/network_blocks.py:52-53 with nn.SiLU); y: conv output [N][C][HW]; mean/invstd from eas_bn_stats
+ * (training) or the running statistics (eval).  Backward = two passes like eas_bn_lif_bwd; only y is kept.
+ * workspace: eas_bn_workspace_doubles(C) doubles. */
+int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    float* out, int N, int C, int HW, eas_stream_t stream);
+int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                    double* workspace, int N, int C, int HW, eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  adaptive sampler step (AdaptiveRSNNEmbedding.forward loop body,

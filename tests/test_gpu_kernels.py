@@ -319,3 +319,81 @@ def test_smallconv_vs_fp64_reference(dev, cin, cout, k, N, H, W):
     scale = np.sqrt(N * H * W)
     np.testing.assert_allclose(gw.cpu().numpy(), wd.grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3)), rtol=1e-4, atol=2e-5 * scale)
+
+
+# ------------------------------------------------------------------------------------------------ BN + SiLU (ANN blocks)
+@pytest.mark.parametrize('N,C,H,W,train', [(4, 16, 12, 20, True), (4, 16, 12, 20, False), (1, 3, 2, 2, True), (64, 128, 32, 40, True)])
+def test_bn_silu_fused_vs_torch(dev, N, C, H, W, train):
+    from eas_snn_amd import ops
+    torch.manual_seed(N + C)
+    bn_r = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).to(dev)
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5); bn_r.bias.uniform_(-0.3, 0.3)
+        bn_r.running_mean.uniform_(-0.2, 0.2); bn_r.running_var.uniform_(0.5, 2.0)
+    import copy
+    bn_h = copy.deepcopy(bn_r)
+    bn_r.train(train); bn_h.train(train)
+    y = (torch.randn(N, C, H, W, device=dev) * 1.7 + 0.4)
+    g = torch.randn(N, C, H, W, device=dev)
+    yr = y.clone().double().requires_grad_(True)
+    bn64 = copy.deepcopy(bn_r).double()
+    ref = torch.nn.functional.silu(bn64(yr))
+    ref.backward(g.double())
+    yh = y.clone().requires_grad_(True)
+    out = ops.bn_silu(yh, bn_h)
+    out.backward(g)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(yh.grad.cpu().numpy(), yr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(bn_h.weight.grad.cpu().numpy(), bn64.weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bn_h.bias.grad.cpu().numpy(), bn64.bias.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(bn_h.running_mean.cpu().numpy(), bn64.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn_h.running_var.cpu().numpy(), bn64.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn_h.num_batches_tracked) == int(bn64.num_batches_tracked)
+
+
+def test_time_broadcast_dedup_is_exact(dev):
+    """T identical input frames: stem + first conv run once and BN+LIF reads one plane (y_bcast); spikes, BN
+    statistics and gradients must equal the explicit T-fold computation."""
+    from spikingjelly.activation_based import functional, surrogate
+    from yolox.models.network_blocks import BaseConv, Focus
+    from yolox.utils.utils_snn import convert_to_spiking
+    from oracle import fill
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = Focus(2, 8, ksize=3)
+            self.b1 = BaseConv(8, 16, 3, 2)
+            self.b2 = BaseConv(16, 16, 1, 1)
+
+        def forward(self, x):
+            return self.b2(self.b1(self.stem(x)))
+
+    def build():
+        net = convert_to_spiking(Net(), surrogate.ATan(2.0))
+        fill.procedural_fill_(net, conv_gain=2.0, ann_regex=r'^stem')
+        return net.to(dev).train()
+    T = 3
+    base = torch.rand(2, 2, 32, 48, device=dev) * 3
+    g = torch.randn(T, 2, 16, 8, 12, device=dev)
+    outs = []
+    for dedup in (True, False):
+        net = build()
+        b = base.clone().requires_grad_(True)
+        x = b.unsqueeze(0).expand(T, *b.shape)
+        if dedup:
+            x._eas_base = b
+        else:
+            x = x.contiguous()
+        out = net(x)
+        out.backward(g)
+        outs.append((out.detach(), b.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()},
+                     {n: v.clone() for n, v in net.named_buffers()}))
+        functional.reset_net(net)
+    assert torch.equal(outs[0][0], outs[1][0])
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-5)
+    for n in outs[0][2]:
+        torch.testing.assert_close(outs[0][2][n], outs[1][2][n], rtol=2e-4, atol=2e-5, msg=n)
+    for n in outs[0][3]:
+        torch.testing.assert_close(outs[0][3][n].float(), outs[1][3][n].float(), rtol=1e-5, atol=1e-6, msg=n)
