@@ -27,6 +27,24 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same
+# command, scripts/gpu_profile.sh; gfx950 corrections applied by scripts/pmc_summary.py).  C-ABI entry -> device kernels.
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
+PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
+               'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
+               'eas_event_histogram': ['event_hist_kernel'], 'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel'],
+               'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel'],
+               'eas_conv_fwd': ['conv_fwd_mfma_kernel'], 'eas_conv_wgrad': ['conv_wgrad_mfma_kernel']}
+
+
+def pmc_traffic(entry, launches_per_call):
+    """Average HBM bytes one call of ``entry`` moves (sum over its device launches), from the committed PMC summary."""
+    try:
+        with open(PMC_FILE) as fh:
+            pmc = json.load(fh)
+        return round(sum(pmc[k]['hbm_bytes_per_launch'] for k in PMC_KERNELS[entry]) * launches_per_call)
+    except (OSError, KeyError, ValueError):
+        return None
 SENSOR = (240, 304)
 CANVAS = (256, 320)
 OPTS = ['T', '3', 'Tm', '4', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
@@ -159,7 +177,8 @@ def main():
         d = summ[dom]
         achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': dom,
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, 2 if dom.endswith('_bwd') and 'bn_' in dom else 1),
+                    'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'kernel': dom,
                     'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'hip_kernel_ms_per_step': fam,
                     'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / (elapsed * 1e3), 4)}
         line = {'metric': 'event-frames/sec (T=3) SYOLOX-S Gen1 304x240', 'value': round(frames_total / elapsed, 2),
