@@ -46,6 +46,11 @@ PROTOTYPES = {
     'eas_smallconv_bwd_input': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
     'eas_smallconv_bwd_weight': (C.c_int, [_P] * 5 + [C.c_int] * 6 + [_P]),
     'eas_smallconv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 3),
+    'eas_conv_packed_weight_bytes': (C.c_int64, [C.c_int] * 4),
+    'eas_conv_pack_weights': (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),
+    'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
+    'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
+    'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
 }
 
 

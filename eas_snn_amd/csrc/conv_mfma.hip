@@ -1,0 +1,442 @@
+// K4 (conv half): implicit-GEMM 2-D convolution on the CDNA4 matrix cores for the conv -> BN -> LIF step
+// (reference: yolox/models/network_blocks.py:52-53 after yolox/utils/utils_snn.py:16-58).
+//
+// Tensors stay fp32 NCHW in HBM ([T*N, C, H, W], exactly the SeqToANNContainer view of the [T,N,C,H,W] spike tensors).
+// Arithmetic: every fp32 operand is split into bf16 terms (hi + mid + lo = the fp32 value exactly, 3 x 8 mantissa bits);
+// bf16 x bf16 products are exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, so the result is an fp32-accumulated
+// sum of the SAME products an fp32 conv forms (spike inputs {0,1,2,..} are one exact term; general fp32 inputs use the six
+// term pairs whose weight is >= 2^-16 relative, error of the dropped pairs <= 2^-23 relative per product).
+//
+//   forward :  y[n][co][ho][wo] = sum_{ci,kh,kw} w[co][ci][kh][kw] * x[n][ci][ho*S+kh-P][wo*S+kw-P]
+//     GEMM view: D[co][pixel] = A[co][(tap,ci)] * B[(tap,ci)][pixel];  A = weights, packed once per call into MFMA
+//     fragment order (conv_pack_weights_kernel), read straight from L2 into registers; B = the input patch, staged
+//     through LDS as [term][input pixel incl. zero halo][ci chunk] bf16, so each lane's 8 consecutive ci are one 16-byte
+//     ds_read_b128 and the KS*KS taps are plain address offsets into the same image.
+//   input gradient of a stride-1 conv is the same kernel on grad_y with the weights packed transposed + flipped.
+//
+// Block = 4 waves (one per SIMD, up to 512 registers each); wave tile = WM x WN MFMA tiles of 32x32, block tile =
+// (WVM*WM*32) output channels x (WVN*WN*32) output pixels = RT whole output rows (possibly several whole images).
+#include <stdlib.h>
+
+#include "eas_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvGeom {
+    int NI, Cin, Cout, Hi, Wi, Ho, Wo;
+    int RT;        // output rows (flattened over images) per block tile
+    int rows_seg;  // output rows per image segment inside a tile = min(RT, Ho)
+    int nseg;      // image segments per tile = RT / rows_seg
+    int rows_in;   // input rows staged per segment = (rows_seg-1)*S + KS
+    int RS;        // staged row stride in pixels = Wi + 2*pad
+    int Q;         // staged input pixels per tile = nseg*rows_in*RS
+    int MT;        // ceil(Cout/32)
+    int KSTEPS;    // ceil(Cin/16)
+    int total_rows;
+    int dbg;       // development ablation switches (EAS_CONV_DBG): 1 no output stores, 2 no staging after chunk 0, 4 weights from one address
+};
+
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    lo = (__bf16)r2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights [Cout][Cin][KS][KS] fp32 -> A fragments: wp[term][mt][kstep][tap][lane] (8 bf16 each)
+//   mode 0 (forward):        M = Cout, K = Cin :  A[m][k][tap] = w[m][k][tap]
+//   mode 1 (input gradient): M = Cin,  K = Cout:  A[m][k][tap] = w[k][m][TAPS-1-tap]      (transposed + flipped)
+__global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, int TAPS, int mode) {
+    const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    const int MT = (M + 31) / 32, KSTEPS = (K + 15) / 16;
+    const int total = MT * KSTEPS * TAPS * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63;
+        int rest = idx >> 6;
+        const int tap = rest % TAPS;
+        rest /= TAPS;
+        const int ks = rest % KSTEPS;
+        const int mt = rest / KSTEPS;
+        const int m = mt * 32 + (lane & 31);
+        bf16x8 t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * (lane >> 5) + j;
+            float v = 0.0f;
+            if (m < M && k < K) v = mode ? w[((size_t)k * Cin + m) * TAPS + (TAPS - 1 - tap)] : w[((size_t)m * Cin + k) * TAPS + tap];
+            __bf16 a, b, c;
+            split3(v, a, b, c);
+            t0[j] = a;
+            t1[j] = b;
+            t2[j] = c;
+        }
+        wp[idx] = t0;
+        wp[(size_t)total + idx] = t1;
+        wp[(size_t)2 * total + idx] = t2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 8 consecutive input channels of one staged pixel -> bf16 term(s) -> one 16-byte LDS store per term
+template <int XT>
+__device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride, const float (&v)[8], int* inexact) {
+    if constexpr (XT == 1) {
+        bf16x8 t0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t0[j] = (__bf16)v[j];
+        *(bf16x8*)dst = t0;
+    } else {
+        bf16x8 t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 a, b, c;
+            split3(v[j], a, b, c);
+            t0[j] = a;
+            t1[j] = b;
+            t2[j] = c;
+        }
+        *(bf16x8*)dst = t0;
+        *(bf16x8*)(dst + term_stride) = t1;
+        *(bf16x8*)(dst + 2 * term_stride) = t2;
+    }
+}
+
+// Staging: one item = VEC consecutive pixels of one staged row x 8 consecutive input channels = 8 vector loads (16 B per
+// lane for VEC = 4) and VEC 16-byte LDS stores per term.  The next chunk's items are all requested during the first MFMA
+// steps of the current chunk and written to the other LDS buffer during its last steps, so each load has several thousand
+// cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
+template <int KS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+__global__ __launch_bounds__(64 * WVM * WVN) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
+                                                            ConvGeom g) {
+    typedef float vecf __attribute__((ext_vector_type(VEC)));
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int PIXB = CCH * 2;  // bytes per staged pixel and term
+    constexpr int NSTEPS = (CCH / 16) * TAPS;
+    constexpr int NT = 64 * WVM * WVN;   // threads; NIT = staging items per thread per chunk (upper bound, surplus skipped block-uniformly)
+    constexpr bool SPREAD = NSTEPS >= 2 * NIT;   // commit item i after step NSTEPS-NIT+i, else after the last step
+    static_assert(WVM * WVN == 4 || WVM * WVN == 8, "4 or 8 waves per block");
+    static_assert(CCH % 16 == 0, "ci chunk is a multiple of the MFMA k");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int r = lane & 31, h = lane >> 5;
+    const int rho0 = blockIdx.x * g.RT;
+    const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
+    const int mt0 = (blockIdx.y * WVM + wm) * WM;
+    const int term_stride = g.Q * PIXB;
+    const int buf_bytes = term_stride * XT;
+    const int npix = g.RT * g.Wo;
+
+    // zero the halo columns of both buffers (never written again)
+    if (PAD > 0) {
+        const int rows = g.nseg * g.rows_in;
+        const int per_row = 2 * PAD * (PIXB / 16);
+        for (int i = tid; i < rows * per_row * XT * 2; i += NT) {
+            const int row = i / per_row, k = i - row * per_row;
+            const int bt = row / rows, rw = row - bt * rows;   // bt = buffer*XT + term
+            const int side = k / (PAD * (PIXB / 16)), kk = k - side * (PAD * (PIXB / 16));
+            const int col = side ? g.RS - PAD : 0;
+            *(uint4*)(smem + (size_t)bt * term_stride + ((size_t)rw * g.RS + col) * PIXB + kk * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // per-lane geometry of the WN pixel columns this lane owns
+    int qoff[WN];
+    long ybase[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int p = (wn * WN + j) * 32 + r;
+        const int pc = p < npix ? p : 0;
+        const int rl = pc / g.Wo, c = pc - rl * g.Wo;
+        const int seg = rl / g.rows_seg, rr = rl - seg * g.rows_seg;
+        qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S) * PIXB + h * 16;
+        const int rho = rho0 + rl;
+        const int img = rho / g.Ho, orow = rho - img * g.Ho;
+        ybase[j] = (p < npix && rho < g.total_rows) ? (((long)img * g.Cout * g.Ho + orow) * g.Wo + c) : -1;
+    }
+
+    // per-thread staging items (the same for every channel chunk)
+    const size_t plane = (size_t)g.Hi * g.Wi;
+    const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
+    const int nitems = units * (CCH / 8);
+    int gofs[NIT], lofs[NIT], gch[NIT];   // gofs < 0: row outside the image (zeros)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int item = it * NT + tid;
+        item = item < nitems ? item : nitems - 1;   // surplus threads of the last slice redo its last item (same bytes)
+        const int gi = item / units, u = item - gi * units;
+        const int seg = u / units_seg, rem = u - seg * units_seg;
+        const int rl = rem / units_row, cu = rem - rl * units_row;
+        const int ir = r0 * S - PAD + rl, img = img0 + seg;
+        const bool ok = ir >= 0 && ir < g.Hi && img < g.NI;
+        gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + cu * VEC) : -1;
+        lofs[it] = ((seg * g.rows_in + rl) * g.RS + PAD + cu * VEC) * PIXB + gi * 16;
+        gch[it] = gi * 8;
+    }
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // A fragments: linear in the step index st = kstep*TAPS + tap
+    const int steps_total = g.KSTEPS * TAPS;
+    const size_t a_term = (size_t)g.MT * steps_total * 64;
+    const bf16x8* ap[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int mt = (mt0 + i) < g.MT ? (mt0 + i) : (g.MT - 1);
+        ap[i] = wp + (size_t)mt * steps_total * 64 + lane;
+    }
+    bf16x8 a_cur[WM][3], a_nxt[WM][3];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a_cur[i][t] = ap[i][t * a_term];
+
+    // loads are unconditional (clamped to a valid address) so that nothing branches or waits around them; rows outside the
+    // image and channel groups past Cin are zeroed when the values are consumed (Cin % 8 == 0: a group is valid or not as a whole)
+    vecf L[NIT][8];
+    auto fetch = [&](int it, int c0) {
+        int cb = c0 + gch[it];
+        cb = cb < g.Cin - 8 ? cb : g.Cin - 8;
+        const float* src = x + (size_t)(gofs[it] >= 0 ? gofs[it] : 0) + (size_t)cb * plane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * plane);
+    };
+    auto commit = [&](unsigned char* buf, int it, int c0) {
+        const bool ok = gofs[it] >= 0 && c0 + gch[it] < g.Cin;
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ok ? L[it][j][p] : 0.0f;
+            stage_store<XT>(buf + lofs[it] + p * PIXB, term_stride, v, inexact);
+        }
+    };
+
+    // prologue: chunk 0 -> buffer 0
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+        if (it * NT < nitems) fetch(it, 0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+        if (it * NT < nitems) commit(smem, it, 0);
+    __syncthreads();
+
+    const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
+    int st = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned char* cur = smem + (c & 1) * buf_bytes;
+        unsigned char* nxt = smem + ((c + 1) & 1) * buf_bytes;
+        const bool more = c + 1 < nchunks && !(g.dbg & 2);
+        const int c1 = (c + 1) * CCH;
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const int kk = s / TAPS, tap = s - kk * TAPS;
+            ++st;
+            const int stn = (g.dbg & 4) ? 0 : (st < steps_total ? st : steps_total - 1);   // prefetch next step's weights (clamped at the end)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a_nxt[i][t] = ap[i][t * a_term + (size_t)stn * 64];
+            if (more) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if ((SPREAD ? it == s : s == 0) && it * NT < nitems) fetch(it, c1);
+            }
+            // keep the prefetch loads (next step's weights, the next patch) ahead of this step's MFMAs: without the fence
+            // the scheduler sinks them behind the last use of the registers they would share
+            __builtin_amdgcn_sched_barrier(0);
+            const int toff = ((tap / KS) * g.RS + (tap % KS)) * PIXB + kk * 32;
+            bf16x8 b[WN][XT];
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int t = 0; t < XT; ++t) b[j][t] = *(const bf16x8*)(cur + t * term_stride + ((g.dbg & 8) ? (lane * 16) : (qoff[j] + toff)));
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    // smallest products first; pairs (weight term, input term) with ta + tb <= 2
+                    if constexpr (XT == 1) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a_cur[i][t] = a_nxt[i][t];
+            if (SPREAD && more) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (s == NSTEPS - NIT + it && it * NT < nitems) commit(nxt, it, c1);
+            }
+        }
+        if (!SPREAD && more) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (it * NT < nitems) commit(nxt, it, c1);
+        }
+        if (!(g.dbg & 16)) __syncthreads();
+    }
+
+    // ---- epilogue: D tile (col = pixel = lane&31, row = (e&3) + 8*(e>>2) + 4*h) -> y NCHW
+    const long cstride = (long)g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        if (mt0 + i >= g.MT) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (ybase[j] < 0) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = (mt0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < g.Cout && (!(g.dbg & 1) || acc[i][j][e] == 12345.f)) y[ybase[j] + co * cstride] = acc[i][j][e] + (bias ? bias[co] : 0.0f);
+            }
+        }
+    }
+}
+
+template <int KS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
+    auto kern = conv_fwd_mfma_kernel<KS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
+    const size_t lds = (size_t)2 * g.Q * CCH * 2 * XT;
+    if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
+    return EAS_OK;
+}
+
+// rows per tile: the largest RT with RT*Wo <= BN such that tiles never straddle an image boundary mid-image
+int pick_rows(int Ho, int Wo, int BN) {
+    int best = 0;
+    const int maxrt = BN / Wo;
+    for (int rt = 1; rt <= maxrt; ++rt)
+        if (Ho % rt == 0 || rt % Ho == 0) best = rt;
+    return best;
+}
+
+typedef int (*launch_fn)(const float*, const bf16x8*, const float*, float*, int*, ConvGeom, hipStream_t);
+
+template <int KS, int S, int XT, int CCH, int VEC>
+int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
+    // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
+    // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
+    struct Cand { int wm, wvm, bn, threads, nit; launch_fn fn; };
+    constexpr int N8 = XT == 1 ? 2 : 1, N4 = XT == 1 ? 4 : 2;   // staging items per thread (register budget)
+    const Cand cands[7] = {
+        {1, 2, 640, 512, N8, launch_fwd<KS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, launch_fwd<KS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
+        {1, 8, 160, 512, N8, launch_fwd<KS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, launch_fwd<KS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
+        {1, 1, 640, 256, N4, launch_fwd<KS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, launch_fwd<KS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
+        {1, 4, 160, 256, N4, launch_fwd<KS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>}};
+    int best = -1;
+    long best_blocks = -1;
+    ConvGeom best_g = g;
+    static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
+    for (int i = 0; i < 7; ++i) {
+        const Cand& c = cands[i];
+        if (force >= 0 && i != force) continue;
+        if ((c.wvm * c.wm - 1) * 32 >= g.Cout && !(c.wvm == 1 && c.wm == 1)) continue;   // every wave row (and M-tile) has channels to compute
+        ConvGeom t = g;
+        bool fits = false;
+        for (int cap = c.bn; cap >= g.Wo && !fits; cap -= 32) {   // shrink the pixel tile until patch + staging slots fit
+            t.RT = pick_rows(g.Ho, g.Wo, cap);
+            if (t.RT == 0) break;
+            t.rows_seg = t.RT < g.Ho ? t.RT : g.Ho;
+            t.nseg = t.RT / t.rows_seg;
+            t.rows_in = (t.rows_seg - 1) * S + KS;
+            t.Q = t.nseg * t.rows_in * t.RS;
+            fits = (size_t)2 * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wi / VEC) * (CCH / 8) <= c.nit * c.threads;
+            cap = t.RT * g.Wo;
+        }
+        if (!fits) continue;
+        const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm));
+        if (blocks * c.threads >= 2 * 224 * 256) { best = i; best_g = t; break; }   // fills 256 CUs twice over: take the widest such tile
+        if (blocks * c.threads > best_blocks) { best = i; best_blocks = blocks * c.threads; best_g = t; }
+    }
+    if (best < 0) return EAS_ERR_UNSUPPORTED;
+    return cands[best].fn(x, wp, bias, y, inexact, best_g, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode) {
+    const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    return (int64_t)3 * ((M + 31) / 32) * ((K + 15) / 16) * ksize * ksize * 64 * 16;
+}
+
+int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int ksize, int mode, eas_stream_t stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || (mode != 0 && mode != 1)) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    const int total = ((M + 31) / 32) * ((K + 15) / 16) * ksize * ksize * 64;
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin,
+                       ksize * ksize, mode);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// y[NI,Cout,Ho,Wo] = conv2d(x[NI,Cin,Hi,Wi], weights packed with mode 0 (or mode 1 for the stride-1 input gradient, called
+// with grad_y as x and Cin/Cout swapped), padding ksize/2.  x_terms = 1: x holds small integers (spikes and their SEW sums,
+// exact in bf16; `inexact_flag`, if given, is set to 1 should any element not be); x_terms = 3: general fp32 input.
+int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                 int stride, int x_terms, int* inexact_flag, eas_stream_t stream) {
+    if (!x || !packed_w || !y || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || Wi % 2 != 0) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    ConvGeom g{};
+    const int pad = ksize / 2;
+    g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.Hi = Hi; g.Wi = Wi;
+    g.Ho = (Hi + 2 * pad - ksize) / stride + 1;
+    g.Wo = (Wi + 2 * pad - ksize) / stride + 1;
+    g.RS = Wi + 2 * pad;
+    g.MT = (Cout + 31) / 32;
+    g.KSTEPS = (Cin + 15) / 16;
+    g.total_rows = NI * g.Ho;
+    static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
+    g.dbg = dbg;
+    const bf16x8* wp = (const bf16x8*)packed_w;
+    hipStream_t st = eas_s(stream);
+    int rc = EAS_ERR_UNSUPPORTED;
+    const bool v4 = Wi % 4 == 0;
+#define EAS_CONV_DISPATCH(KS_, S_, CCH_)                                                                                          \
+    rc = x_terms == 1 ? (v4 ? dispatch_tile<KS_, S_, 1, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                             \
+                            : dispatch_tile<KS_, S_, 1, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))                            \
+                      : (v4 ? dispatch_tile<KS_, S_, 3, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                             \
+                            : dispatch_tile<KS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
+    if (ksize == 3 && stride == 1) { EAS_CONV_DISPATCH(3, 1, 16); }
+    else if (ksize == 3 && stride == 2) { EAS_CONV_DISPATCH(3, 2, 16); }
+    else if (ksize == 1 && stride == 1) { EAS_CONV_DISPATCH(1, 1, 32); }
+#undef EAS_CONV_DISPATCH
+    if (rc != EAS_OK) return rc;
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// K4 (conv half): weight gradient of the 3x3 convolutions of the conv -> BN -> LIF step on the CDNA4 matrix cores
+// (replaces ATen/MIOpen convolution_backward's grad_weight for nn.Conv2d inside BaseConv,
+// yolox/models/network_blocks.py:31-56 after yolox/utils/utils_snn.py:25-27).
+//
+//   dW[co][ci][kh][kw] = sum_{n,ho,wo} gy[n][co][ho][wo] * x[n][ci][ho*S+kh-1][wo*S+kw-1]
+//
+// GEMM view, one per tap: D_tap[co][ci] = sum_p A[co][p] * B_tap[p][ci] with the reduction index p = output pixel.
+// Both operands are staged pixel-major in LDS as exact bf16 terms ([term][32-channel plane][pixel][32 ch], 64-byte rows:
+// conflict-free for the transposing read), grad_y always as three terms (hi+mid+lo = the fp32 value), x as one term when
+// it holds spikes / small integers or three for general fp32.  Each lane's 8 consecutive reduction indices of one channel
+// come from two ds_read_b64_tr_b16 (4 pixel rows x 16 channel columns per 16-lane group, delivered column-major), and the
+// nine taps are plain address offsets into the same x image (zero halo staged with it).
+//
+// Block = 3*PM*PN waves: PM x PN (32 co x 32 ci) output tiles, three waves per tile (one kernel row kh each, 3 taps =
+// 48 accumulator registers).  A block owns one (co block, ci block) and every KSL-th 80-pixel tile of output rows; its
+// partial sums go to a slab that eas_conv_wgrad's second kernel reduces in fixed order (deterministic, no float atomics).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "eas_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int TP = 80;       // output pixels per tile (5 MFMA k-steps of 16)
+constexpr int KST = TP / 16;
+constexpr int ROWB = 64;     // bytes per staged pixel row of one 32-channel plane
+constexpr int A_PLANE = TP * ROWB;
+
+struct WgGeom {
+    int NI, Cin, Cout, Hi, Wi, Ho, Wo;
+    int RT, rows_seg, nseg, rows_in, RS, Q;
+    int total_rows, ntiles, kslices;
+    int ci_blocks;
+};
+
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    lo = (__bf16)r2;
+}
+
+// two transposing reads -> one MFMA operand fragment (8 reduction indices of this lane's channel)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int NTERMS>
+__device__ __forceinline__ void stage_terms(unsigned char* dst, int term_stride, const float (&v)[8]) {
+    if constexpr (NTERMS == 1) {
+        bf16x8 t0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t0[j] = (__bf16)v[j];
+        *(bf16x8*)dst = t0;
+    } else {
+        bf16x8 t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 a, b, c;
+            split3(v[j], a, b, c);
+            t0[j] = a;
+            t1[j] = b;
+            t2[j] = c;
+        }
+        *(bf16x8*)dst = t0;
+        *(bf16x8*)(dst + term_stride) = t1;
+        *(bf16x8*)(dst + 2 * term_stride) = t2;
+    }
+}
+
+template <int S, int XT, int PM, int PN, int VEC>
+__global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                        float* __restrict__ slabs, WgGeom g) {
+    typedef float vecf __attribute__((ext_vector_type(VEC)));
+    constexpr int NW = 3 * PM * PN, NT = 64 * NW, NIT = PM * PN == 4 ? 1 : 2;   // staging items per thread (register budget of 12-wave blocks)
+    constexpr int A_TERM = PM * A_PLANE, A_BYTES = 3 * A_TERM;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = wave % 3, pair = wave / 3, pm = pair / PN, pn = pair % PN;
+    const int cob = blockIdx.y / g.ci_blocks, cib = blockIdx.y - cob * g.ci_blocks;
+    const int co0 = cob * 32 * PM, ci0 = cib * 32 * PN;
+    const int b_plane = g.Q * ROWB, b_term = PN * b_plane;
+    const int buf_bytes = A_BYTES + XT * b_term;
+    const int npix = g.RT * g.Wo;
+
+    // zero the halo columns of the x image in both buffers (never written again)
+    {
+        const int rows = g.nseg * g.rows_in;
+        for (int i = tid; i < rows * 2 * 4 * PN * XT * 2; i += NT) {   // 2 sides x 4 16-byte pieces x planes x terms x buffers
+            int rest = i;
+            const int piece = rest & 3; rest >>= 2;
+            const int side = rest & 1; rest >>= 1;
+            const int row = rest % rows; rest /= rows;
+            const int pl = rest % (PN * XT), buf = rest / (PN * XT);
+            const int col = side ? g.RS - 1 : 0;
+            *(uint4*)(smem + (size_t)buf * buf_bytes + A_BYTES + (size_t)pl * b_plane + ((size_t)row * g.RS + col) * ROWB + piece * 16) =
+                make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // ---- per-lane transposing-read geometry: 16-lane group gq -> channel column block (gq&1)*16, reduction rows (gq>>1)*8 ..
+    const int gq = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
+    const int lane_col_bytes = ((gq & 1) * 16 + 4 * pcol) * 2;
+    const int kb = (gq >> 1) * 8 + qrow;                       // first reduction row (pixel) this lane addresses
+    const int a_lane = pm * A_PLANE + kb * ROWB + lane_col_bytes;   // + ks*16*ROWB + rd*4*ROWB + term*A_TERM
+    int b_lane[KST][2];
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int p = ks * 16 + kb + 4 * rd;
+            int q = 0;
+            if (p < npix) {
+                const int rl = p / g.Wo, c = p - rl * g.Wo;
+                const int seg = rl / g.rows_seg, rr = rl - seg * g.rows_seg;
+                q = (seg * g.rows_in + rr * S) * g.RS + c * S;
+            }
+            b_lane[ks][rd] = A_BYTES + pn * b_plane + q * ROWB + lane_col_bytes;   // + tap offset + term*b_term
+        }
+
+    // ---- staging items: item = VEC pixels x 8 channels; ids [0,nA) grad_y, [nA,nA+nB) x
+    const int unitsA = TP / VEC, nA = unitsA * 4 * PM;
+    const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, unitsB = g.nseg * units_seg, nB = unitsB * 4 * PN;
+    const int nitems = nA + nB;
+    const size_t planeY = (size_t)g.Ho * g.Wo, planeX = (size_t)g.Hi * g.Wi;
+    int it_kind[NIT], it_seg[NIT], it_row[NIT], it_col[NIT], it_ch[NIT], it_lofs[NIT];   // kind: 0 grad_y, 1 x, 2 padding (zeros)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int id = it * NT + tid;
+        id = id < nitems ? id : nitems - 1;
+        if (id < nA) {
+            const int gi = id / unitsA, u = id - gi * unitsA;
+            const int p0 = u * VEC;
+            const int rl = p0 / g.Wo, c = p0 - rl * g.Wo;
+            it_kind[it] = p0 < npix ? 0 : 2;
+            it_seg[it] = rl / g.rows_seg;
+            it_row[it] = rl - it_seg[it] * g.rows_seg;
+            it_col[it] = c;
+            it_ch[it] = gi * 8;
+            it_lofs[it] = (gi >> 2) * A_PLANE + p0 * ROWB + (gi & 3) * 16;
+        } else {
+            const int idb = id - nA;
+            const int gi = idb / unitsB, u = idb - gi * unitsB;
+            const int seg = u / units_seg, rem = u - seg * units_seg;
+            const int rl = rem / units_row, cu = rem - rl * units_row;
+            it_kind[it] = 1;
+            it_seg[it] = seg;
+            it_row[it] = rl;
+            it_col[it] = cu * VEC;
+            it_ch[it] = gi * 8;
+            it_lofs[it] = A_BYTES + (gi >> 2) * b_plane + ((seg * g.rows_in + rl) * g.RS + 1 + cu * VEC) * ROWB + (gi & 3) * 16;
+        }
+    }
+
+    vecf L[NIT][8];
+    bool Lok[NIT];
+    auto fetch = [&](int it, int tile) {
+        const int rho0 = tile * g.RT;
+        const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
+        const int img = img0 + it_seg[it];
+        const float* src;
+        size_t plane;
+        bool ok;
+        if (it_kind[it] == 1) {
+            const int ir = r0 * S - 1 + it_row[it];
+            ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin;
+            const int ch = ci0 + it_ch[it] < g.Cin ? ci0 + it_ch[it] : g.Cin - 8;
+            src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.Wi + it_col[it];
+            plane = planeX;
+        } else {
+            ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout;
+            const int ch = co0 + it_ch[it] < g.Cout ? co0 + it_ch[it] : g.Cout - 8;
+            src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.Wo + (ok ? it_col[it] : 0);
+            plane = planeY;
+        }
+        Lok[it] = ok;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * plane);
+    };
+    auto commit = [&](unsigned char* buf, int it) {
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = Lok[it] ? L[it][j][p] : 0.0f;
+            unsigned char* dst = buf + it_lofs[it] + p * ROWB;
+            if (it_kind[it] == 1) stage_terms<XT>(dst, b_term, v);
+            else stage_terms<3>(dst, A_TERM, v);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    int tile = blockIdx.x;
+    if (tile < g.ntiles) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (it * NT < nitems) fetch(it, tile);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (it * NT < nitems) commit(smem, it);
+    }
+    __syncthreads();
+
+    int par = 0;
+    for (; tile < g.ntiles; tile += g.kslices, par ^= 1) {
+        const unsigned char* cur = smem + par * buf_bytes;
+        unsigned char* nxt = smem + (par ^ 1) * buf_bytes;
+        const bool more = tile + g.kslices < g.ntiles;
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            if (ks == 0 && more) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (it * NT < nitems) fetch(it, tile + g.kslices);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 a[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const unsigned char* pa = cur + a_lane + t * A_TERM + ks * 16 * ROWB;
+                a[t] = tr_frag(pa, pa + 4 * ROWB);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int toff = (kh * g.RS + kw) * ROWB;
+                bf16x8 b[XT];
+#pragma unroll
+                for (int t = 0; t < XT; ++t) b[t] = tr_frag(cur + b_lane[ks][0] + toff + t * b_term, cur + b_lane[ks][1] + toff + t * b_term);
+                if constexpr (XT == 1) {
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[kw], 0, 0, 0);
+                } else {
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[kw], 0, 0, 0);
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[kw], 0, 0, 0);
+                }
+            }
+            if (ks == KST - 2 && more) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (it * NT < nitems) commit(nxt, it);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- partial sums of this block -> slab [kslice][co][ci][kh][kw]; D: col = ci = lane&31, row = co = (e&3)+8*(e>>2)+4*(lane>>5)
+    const int ci = ci0 + pn * 32 + (lane & 31);
+    float* slab = slabs + (size_t)blockIdx.x * g.Cout * g.Cin * 9;
+    if (ci < g.Cin) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + pm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (co < g.Cout) {
+                float* d = slab + ((size_t)co * g.Cin + ci) * 9 + kh * 3;
+                d[0] = acc[0][e];
+                d[1] = acc[1][e];
+                d[2] = acc[2][e];
+            }
+        }
+    }
+}
+
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int n, int kslices) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < kslices; ++k) s += (double)slabs[(size_t)k * n + i];
+    gw[i] = (float)s;
+}
+
+int pick_rows(int Ho, int Wo, int cap) {
+    int best = 0;
+    for (int rt = 1; rt * Wo <= cap; ++rt)
+        if (Ho % rt == 0 || rt % Ho == 0) best = rt;
+    return best;
+}
+
+template <int S, int XT, int PM, int PN, int VEC>
+int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStream_t st) {
+    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC>;
+    constexpr int NT = 192 * PM * PN;
+    const size_t lds = (size_t)2 * (3 * PM * A_PLANE + (size_t)XT * PN * g.Q * ROWB);
+    const int nitems = (TP / VEC) * 4 * PM + g.nseg * g.rows_in * (g.Wi / VEC) * 4 * PN;
+    if (lds > 160 * 1024 || nitems > (PM * PN == 4 ? 1 : 2) * NT) {
+        if (getenv("EAS_CONV_DBG")) fprintf(stderr, "wgrad launch: lds %zu nitems %d NT %d PM %d PN %d VEC %d RT %d Q %d\n", lds, nitems, NT, PM, PN, VEC, g.RT, g.Q);
+        return EAS_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    g.ci_blocks = (g.Cin + 32 * PN - 1) / (32 * PN);
+    const int co_blocks = (g.Cout + 32 * PM - 1) / (32 * PM);
+    dim3 grid(g.kslices, co_blocks * g.ci_blocks);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, x, gy, slabs, g);
+    return EAS_OK;
+}
+
+struct WgPlan { int pm, pn, kslices; };
+
+// block shape and number of pixel slices for a layer (shared by the workspace query and the launch)
+WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles) {
+    WgPlan p;
+    p.pm = Cout >= 64 ? 2 : 1;
+    p.pn = (Cin >= 64 && stride == 1 && x_terms == 1) ? 2 : 1;
+    const int yz = ((Cout + 32 * p.pm - 1) / (32 * p.pm)) * ((Cin + 32 * p.pn - 1) / (32 * p.pn));
+    const int per_cu = 4 / (p.pm * p.pn);                   // resident blocks per CU (12 waves of <= 168 registers)
+    int ks = (256 * per_cu + yz - 1) / yz;
+    if (ks > ntiles) ks = ntiles;
+    if (ks < 1) ks = 1;
+    p.kslices = ks;
+    return p;
+}
+
+bool wg_geom_cap(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int cap) {
+    g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.Hi = Hi; g.Wi = Wi;
+    g.Ho = (Hi + 2 - 3) / stride + 1;
+    g.Wo = (Wi + 2 - 3) / stride + 1;
+    g.RT = pick_rows(g.Ho, g.Wo, cap);
+    if (g.RT == 0) return false;
+    g.rows_seg = g.RT < g.Ho ? g.RT : g.Ho;
+    g.nseg = g.RT / g.rows_seg;
+    g.rows_in = (g.rows_seg - 1) * stride + 3;
+    g.RS = Wi + 2;
+    g.Q = g.nseg * g.rows_in * g.RS;
+    g.total_rows = NI * g.Ho;
+    g.ntiles = (g.total_rows + g.RT - 1) / g.RT;
+    return true;
+}
+
+// largest tile (<= 80 output pixels) whose double-buffered images and staging items fit the block
+bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
+    for (int cap = TP; cap >= 2; cap /= 2) {
+        if (!wg_geom_cap(g, NI, Cin, Cout, Hi, Wi, stride, cap)) continue;
+        const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
+        const int vec = (Wi % 4 == 0 && g.Wo % 4 == 0) ? 4 : 2;
+        const size_t lds = (size_t)2 * (3 * p.pm * A_PLANE + (size_t)x_terms * p.pn * g.Q * ROWB);
+        const int nitems = (TP / vec) * 4 * p.pm + g.nseg * g.rows_in * (Wi / vec) * 4 * p.pn;
+        if (lds <= 160 * 1024 && nitems <= (p.pm * p.pn == 4 ? 1 : 2) * 192 * p.pm * p.pn) return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
+    WgGeom g{};
+    if (ksize != 3 || !wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
+    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
+    return (int64_t)p.kslices * Cout * Cin * 9;
+}
+
+// grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and grad_y[NI][Cout][Ho][Wo].
+// x_terms as in eas_conv_fwd.  workspace: eas_conv_wgrad_workspace_floats(...) floats.
+int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                   int stride, int x_terms, eas_stream_t stream) {
+    if (!x || !grad_y || !grad_w || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+    if (ksize != 3 || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || Cout % 8 != 0 || Wi % 2 != 0)
+        return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    WgGeom g{};
+    if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;
+    if (g.Wo % 2 != 0 || (g.Ho * g.Wo) % 4 != 0) return EAS_ERR_UNSUPPORTED;
+    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
+    g.kslices = p.kslices;
+    hipStream_t st = eas_s(stream);
+    const bool v4 = Wi % 4 == 0 && g.Wo % 4 == 0;
+    int rc = EAS_ERR_UNSUPPORTED;
+#define EAS_WG(S_, XT_, PM_, PN_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4>(x, grad_y, workspace, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2>(x, grad_y, workspace, g, st))
+#define EAS_WG_SHAPE(S_, XT_)                                                  \
+    do {                                                                       \
+        if (p.pm == 2 && p.pn == 2) rc = EAS_WG(S_, XT_, 2, 2);                \
+        else if (p.pm == 2) rc = EAS_WG(S_, XT_, 2, 1);                        \
+        else if (p.pn == 2) rc = EAS_WG(S_, XT_, 1, 2);                        \
+        else rc = EAS_WG(S_, XT_, 1, 1);                                       \
+    } while (0)
+    if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1);
+    else if (stride == 1) EAS_WG_SHAPE(1, 3);
+    else if (x_terms == 1) EAS_WG_SHAPE(2, 1);
+    else EAS_WG_SHAPE(2, 3);
+#undef EAS_WG_SHAPE
+#undef EAS_WG
+    if (rc != EAS_OK) return rc;
+    EAS_CHECK_LAUNCH();
+    const int n = Cout * Cin * 9;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, grad_w, n, g.kslices);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+}  // extern "C"

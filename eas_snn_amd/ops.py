@@ -514,3 +514,57 @@ def arsnn_forward(ev_rev, input_params, gate_params, kernel_size, Ts, readout, s
     cfg = (int(kernel_size), depth, int(Ts), READOUT_IDS[readout], bool(spike_attach), bool(write_zero), bool(use_abs),
            float(thresh), 0.0 if soft else float(v_reset), soft, bool(record))
     return _ARSNNFn.apply(ev_rev, cfg, *input_params, *gate_params)
+
+
+# ------------------------------------------------------------------------------------------------ K4 conv (MFMA)
+_INEXACT = {}
+
+
+def conv_inexact_flag(device):
+    """Device int32 that eas_conv_fwd ORs with 1 if an input promised to hold small integers (x_terms=1) does not."""
+    key = str(device)
+    if key not in _INEXACT:
+        _INEXACT[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _INEXACT[key]
+
+
+def conv_pack_weights(w, mode=0):
+    """w [Cout,Cin,k,k] fp32 -> MFMA A-fragment order, three exact bf16 terms (mode 1: transposed+flipped for dgrad)."""
+    _dev(w)
+    w = _f32c(w)
+    Cout, Cin, k = w.shape[0], w.shape[1], w.shape[-1]
+    L = _lib.lib()
+    packed = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, mode), dtype=torch.uint8, device=w.device)
+    check(L.eas_conv_pack_weights(ptr(w), ptr(packed), Cout, Cin, k, mode, stream()), 'eas_conv_pack_weights')
+    return packed
+
+
+def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms):
+    """conv2d(x [NI,Cin,H,W], packed weights), padding ksize//2, on the matrix cores."""
+    _dev(x, packed, bias)
+    x = _f32c(x)
+    NI, Cin, Hi, Wi = x.shape
+    pad = ksize // 2
+    Ho, Wo = (Hi + 2 * pad - ksize) // stride + 1, (Wi + 2 * pad - ksize) // stride + 1
+    y = torch.empty((NI, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    flops_bytes = 4 * (x.numel() + y.numel())
+    _call('eas_conv_fwd', flops_bytes, _lib.lib().eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi, ksize, stride,
+          x_terms, ptr(conv_inexact_flag(x.device)) if x_terms == 1 else None, stream())
+    return y
+
+
+def conv_wgrad(x, gy, ksize, stride, x_terms):
+    """grad_w [Cout,Cin,3,3] of conv2d(x, w, stride, padding 1) given grad_y, on the matrix cores (deterministic)."""
+    _dev(x, gy)
+    x, gy = _f32c(x), _f32c(gy)
+    NI, Cin, Hi, Wi = x.shape
+    Cout = gy.shape[1]
+    L = _lib.lib()
+    nws = L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms)
+    if nws <= 0:
+        raise _lib.EasHipError('eas_conv_wgrad: unsupported configuration')
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    gw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    _call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad, ptr(x), ptr(gy), ptr(gw), ptr(ws), NI, Cin, Cout, Hi, Wi, ksize,
+          stride, x_terms, stream())
+    return gw

@@ -189,6 +189,35 @@ int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w,
                              int N, int Cin, int Cout, int H, int W, int k, eas_stream_t stream);
 int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k);
 
+/* ---------------------------------------------------------------------------------------------
+ * K4 (conv half)  dense 1x1 / 3x3 convolutions of the conv -> BN -> LIF step on the matrix cores.
+ *     Replaces SeqToANNContainer(nn.Conv2d) / nn.Conv2d inside BaseConv (yolox/models/network_blocks.py:31-56
+ *     after yolox/utils/utils_snn.py:25-27; ATen/MIOpen convolution forward and backward).
+ * fp32 NCHW tensors; padding = ksize/2; ksize in {1,3}; stride in {1,2}; no groups/dilation.  Every fp32 operand
+ * is split into exact bf16 terms and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (csrc/conv_mfma.hip), i.e. an fp32-accumulated sum of the same products an fp32 convolution forms.
+ *
+ * eas_conv_pack_weights: w[Cout][Cin][k][k] -> MFMA A-fragment order, 3 bf16 terms; mode 0 for the forward conv,
+ *     mode 1 (transposed + flipped) for the input gradient of a stride-1 conv.  `packed` holds
+ *     eas_conv_packed_weight_bytes(Cout,Cin,k,mode) bytes.
+ * eas_conv_fwd: y[NI][Cout][Ho][Wo] (+bias[Cout] if not NULL).  x_terms = 1: x holds small integers (spikes and
+ *     their SEW sums; *inexact_flag, if not NULL, is OR-ed with 1 when an element is not exact in bf16);
+ *     x_terms = 3: general fp32 x.  Input gradient of a stride-1 conv: call with x = grad_y, Cin/Cout swapped,
+ *     weights packed in mode 1, x_terms = 3. */
+int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode);
+int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int ksize, int mode, eas_stream_t stream);
+int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
+                 int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
+
+/* grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and
+ * grad_y[NI][Cout][Ho][Wo] (ATen convolution_backward, weight part).  Reduction over output pixels on the matrix
+ * cores (csrc/conv_wgrad_mfma.hip): grad_y as three exact bf16 terms, x as one (x_terms = 1, spikes / small integers)
+ * or three; per-block partial sums are reduced in fixed order through `workspace`
+ * (eas_conv_wgrad_workspace_floats(...) floats) -- deterministic. */
+int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
+int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi,
+                   int Wi, int ksize, int stride, int x_terms, eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
