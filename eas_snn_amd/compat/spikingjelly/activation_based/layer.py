@@ -19,17 +19,31 @@ class SeqToANNContainer(nn.Sequential, base.StepModule):
     def supported_step_mode(self):
         return ('m',)
 
+    def _run_inner(self_, x):
+        """The wrapped stateless module(s) on a [N,C,H,W] batch; a lone Conv2d goes to the matrix-core kernels."""
+        if len(self_) == 1 and type(self_[0]) is nn.Conv2d and x.is_cuda:
+            return ops.conv2d(x, self_[0])
+        return nn.Sequential.forward(self_, x)
+
     def forward(self, x_seq):
         base = getattr(x_seq, '_eas_base', None)
         if base is not None:
             # x_seq is T identical frames (stride-0 broadcast of ``base``, spiking_yolox.py:52-57): a stateless module
             # gives T identical results, so it runs once and the result is broadcast again (bit-identical, 1/T the work)
             with ops.replicated(x_seq.shape[0]):      # BN inside sees N samples that stand for T*N
-                y0 = super().forward(base)
+                y0 = self._run_inner(base)
             y = y0.unsqueeze(0).expand(x_seq.shape[0], *y0.shape)
             y._eas_base = y0
             return y
-        return functional.seq_to_ann_forward(x_seq, super().forward)
+        small = ops.is_small_int(x_seq)
+        x = x_seq.flatten(0, 1)
+        if small:
+            ops.mark_small_int(x)
+        y = self._run_inner(x)
+        y = y.view(x_seq.shape[0], x_seq.shape[1], *y.shape[1:])
+        if small and len(self) == 1 and isinstance(self[0], (nn.MaxPool2d, nn.Upsample)):
+            ops.mark_small_int(y)           # pooling / nearest upsampling of spikes are spikes
+        return y
 
 
 class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
@@ -73,6 +87,7 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
             want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0])
         if v_out is not None:
             node.v = v_out
+        ops.mark_small_int(spikes)          # the neuron's output is 0/1 by construction
         return (spikes, mean) if want_mean else spikes
 
 

@@ -86,6 +86,7 @@ class BaseNode(base.MemoryModule):
                                                 a['flags'], a['surrogate'], a['alpha'], want_mean=want_mean)
         if v_out is not None:
             self.v = v_out
+        ops.mark_small_int(spikes)          # 0/1 by construction (convolutions reading it use one exact bf16 term)
         return (spikes, mean) if want_mean else spikes
 
     def single_step_forward(self, x):

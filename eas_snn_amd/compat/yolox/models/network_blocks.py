@@ -20,6 +20,14 @@ def get_activation(name='silu', inplace=True):
     return table[name]()
 
 
+def _cat(parts):
+    """Channel concatenation; a concatenation of spike tensors is still a spike tensor."""
+    out = torch.cat(list(parts), dim=-3)
+    if all(ops.is_small_int(p) for p in parts):
+        ops.mark_small_int(out)
+    return out
+
+
 class BaseConv(nn.Module):
     """Conv2d -> BatchNorm -> activation (spiking: SeqToANNContainer(Conv2d) -> BN('m') -> PLIF)."""
 
@@ -34,7 +42,7 @@ class BaseConv(nn.Module):
     def forward(self, x):
         if isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d):
             return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate)
-        y = self.conv(x)
+        y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
                 and (self.bn.momentum is not None or not self.bn.training)):
             return ops.bn_silu(y, self.bn)          # one statistics pass + one fused normalise/SiLU pass (HIP)
@@ -64,7 +72,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         y = self.conv2(self.conv1(x))
-        return y + x if self.use_add else y      # SEW residual: spike sums 0/1/2 when spiking
+        if not self.use_add:
+            return y
+        out = y + x                              # SEW residual: spike sums 0/1/2.. when spiking
+        if ops.is_small_int(y) and ops.is_small_int(x):
+            ops.mark_small_int(out)
+        return out
 
 
 class SPPBottleneck(nn.Module):
@@ -77,7 +90,7 @@ class SPPBottleneck(nn.Module):
 
     def forward(self, x):
         x = self.conv1(x)
-        return self.conv2(torch.cat([x] + [m(x) for m in self.m], dim=-3))
+        return self.conv2(_cat([x] + [m(x) for m in self.m]))
 
 
 class CSPLayer(nn.Module):
@@ -90,7 +103,7 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
     def forward(self, x):
-        return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), dim=-3))
+        return self.conv3(_cat((self.m(self.conv1(x)), self.conv2(x))))
 
 
 class Focus(nn.Module):

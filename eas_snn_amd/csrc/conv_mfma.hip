@@ -353,8 +353,11 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         {1, 8, 160, 512, N8, launch_fwd<KS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, launch_fwd<KS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
         {1, 1, 640, 256, N4, launch_fwd<KS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, launch_fwd<KS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
         {1, 4, 160, 256, N4, launch_fwd<KS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>}};
+    // cost model (measured on MI355X, scripts/dev_conv.py): every block of one shape takes about the same time whatever part
+    // of its pixel tile is valid; one block per CU; a round of 8-wave blocks costs ~1.27x a round of 4-wave blocks
     int best = -1;
-    long best_blocks = -1;
+    double best_cost = 0.0;
+    int best_valid = 0;
     ConvGeom best_g = g;
     static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
     for (int i = 0; i < 7; ++i) {
@@ -375,8 +378,11 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         }
         if (!fits) continue;
         const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm));
-        if (blocks * c.threads >= 2 * 224 * 256) { best = i; best_g = t; break; }   // fills 256 CUs twice over: take the widest such tile
-        if (blocks * c.threads > best_blocks) { best = i; best_blocks = blocks * c.threads; best_g = t; }
+        const double cost = (double)((blocks + 255) / 256) * (c.threads == 512 ? 1.27 : 1.0);
+        const int valid = t.RT * g.Wo;
+        if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && valid > best_valid)) {
+            best = i; best_cost = cost; best_valid = valid; best_g = t;
+        }
     }
     if (best < 0) return EAS_ERR_UNSUPPORTED;
     return cands[best].fn(x, wp, bias, y, inexact, best_g, st);

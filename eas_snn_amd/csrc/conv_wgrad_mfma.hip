@@ -278,12 +278,28 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     }
 }
 
+// dW[i] = sum over slabs, fixed order: 64 outputs x 4 slice lanes per block, each lane sums every 4th slab in order, then
+// the four partial sums are added in lane order (deterministic)
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int n, int kslices) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ double part[4][64];
+    const int o = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
     double s = 0.0;
-    for (int k = 0; k < kslices; ++k) s += (double)slabs[(size_t)k * n + i];
-    gw[i] = (float)s;
+    if (i < n) {
+        int k = kl;
+        for (; k + 12 < kslices; k += 16) {
+            const float a = slabs[(size_t)k * n + i], b = slabs[(size_t)(k + 4) * n + i], c = slabs[(size_t)(k + 8) * n + i],
+                        d = slabs[(size_t)(k + 12) * n + i];
+            s += (double)a;
+            s += (double)b;
+            s += (double)c;
+            s += (double)d;
+        }
+        for (; k < kslices; k += 4) s += (double)slabs[(size_t)k * n + i];
+    }
+    part[kl][o] = s;
+    __syncthreads();
+    if (kl == 0 && i < n) gw[i] = (float)(((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
 }
 
 int pick_rows(int Ho, int Wo, int cap) {
@@ -404,7 +420,7 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
     if (rc != EAS_OK) return rc;
     EAS_CHECK_LAUNCH();
     const int n = Cout * Cin * 9;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, grad_w, n, g.kslices);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grad_w, n, g.kslices);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

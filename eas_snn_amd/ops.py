@@ -568,3 +568,78 @@ def conv_wgrad(x, gy, ksize, stride, x_terms):
     _call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad, ptr(x), ptr(gy), ptr(gw), ptr(ws), NI, Cin, Cout, Hi, Wi, ksize,
           stride, x_terms, stream())
     return gw
+
+
+# Which convolutions run on the hand-written MFMA kernels ('mfma') and which stay on ATen/MIOpen ('miopen').
+# Per role so that a slower kernel of ours never displaces a faster library one (measured: scripts/dev_conv.py).
+CONV_POLICY = {'fwd3': 'mfma', 'fwd1': 'miopen', 'dgrad3': 'mfma', 'dgrad1': 'miopen', 'wgrad3': 'mfma'}
+
+
+VERIFY_SMALL_INT = False     # tests switch this on: every tagged tensor is checked (host sync) before it is used
+
+
+def mark_small_int(t):
+    """Tag a tensor whose values are spikes or sums of a few spikes (exact in bf16): convolutions reading it use one
+    bf16 term instead of three.  Untagged tensors always take the general three-term path."""
+    t._eas_small_int = True
+    return t
+
+
+def is_small_int(t):
+    return getattr(t, '_eas_small_int', False)
+
+
+def conv_eligible(x, conv):
+    k = conv.kernel_size[0]
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.kernel_size in ((1, 1), (3, 3)) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (k // 2, k // 2)
+            and conv.padding_mode == 'zeros' and x.shape[1] % 8 == 0 and x.shape[-1] % 2 == 0
+            and CONV_POLICY['fwd%d' % k] == 'mfma' and not (k == 1 and conv.stride != (1, 1)))
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, x_terms):
+        _dev(x, w, bias)
+        k, Cout = w.shape[-1], w.shape[0]
+        y = conv_fwd_packed(x, conv_pack_weights(w, 0), bias, Cout, k, stride, x_terms)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (k, stride, x_terms, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        k, stride, x_terms, has_bias = ctx.cfg
+        gy = _f32c(gy)
+        gx = gw = gb = None
+        Cin = w.shape[1]
+        own_d = ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
+        own_w = ctx.needs_input_grad[1] and k == 3 and CONV_POLICY['wgrad3'] == 'mfma' and w.shape[0] % 8 == 0 and (
+            gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0) and _lib.lib().eas_conv_wgrad_workspace_floats(
+                x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0
+        if own_d:
+            gx = conv_fwd_packed(gy, conv_pack_weights(w, 1), None, Cin, k, 1, 3)
+        if own_w:
+            gw = conv_wgrad(x, gy, k, stride, x_terms)
+        need_d = ctx.needs_input_grad[0] and not own_d
+        need_w = ctx.needs_input_grad[1] and not own_w
+        if need_d or need_w:
+            rx, rw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1,
+                                                            (need_d, need_w, False))
+            gx = rx if need_d else gx
+            gw = rw if need_w else gw
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None, None
+
+
+def conv2d(x, conv, small_int=None):
+    """``conv(x)`` for an ``nn.Conv2d`` on the matrix-core kernels where eligible (else ATen/MIOpen)."""
+    if not conv_eligible(x, conv):
+        return conv._conv_forward(x, conv.weight, conv.bias)
+    if small_int is None:
+        small_int = is_small_int(x)
+    if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
+        raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
+    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3)

@@ -32,3 +32,13 @@ def split_cases(npz):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _verify_spike_tags():
+    """Every tensor the model code tags as 'spikes / small integers' is checked for bf16 exactness before a convolution
+    uses the one-term path (eas_snn_amd.ops.VERIFY_SMALL_INT)."""
+    from eas_snn_amd import ops
+    ops.VERIFY_SMALL_INT = True
+    yield
+    ops.VERIFY_SMALL_INT = False
