@@ -111,7 +111,7 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // steps of the current chunk and written to the other LDS buffer during its last steps, so each load has several thousand
 // cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
 template <int KS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
-__global__ __launch_bounds__(64 * WVM * WVN) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+__global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
                                                             ConvGeom g) {
     typedef float vecf __attribute__((ext_vector_type(VEC)));
@@ -347,7 +347,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
     // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
     // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
     struct Cand { int wm, wvm, bn, threads, nit; launch_fn fn; };
-    constexpr int N8 = XT == 1 ? 2 : 1, N4 = XT == 1 ? 4 : 2;   // staging items per thread (register budget)
+    constexpr int N8 = XT == 1 ? 2 : 1, N4 = 2;   // staging items per thread (register budget: 2 waves per SIMD either way)
     const Cand cands[7] = {
         {1, 2, 640, 512, N8, launch_fwd<KS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, launch_fwd<KS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
         {1, 8, 160, 512, N8, launch_fwd<KS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, launch_fwd<KS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
@@ -378,7 +378,12 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         }
         if (!fits) continue;
         const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm));
-        const double cost = (double)((blocks + 255) / 256) * (c.threads == 512 ? 1.27 : 1.0);
+        // resident blocks per CU: one 8-wave block, or two 4-wave blocks when their LDS fits twice (independent barriers
+        // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
+        const size_t lds_bytes = (size_t)2 * t.Q * CCH * 2 * XT;
+        const int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
+        const double round_cost = c.threads == 512 ? 1.27 : (bpc == 2 ? 1.2 : 1.0);
+        const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
         const int valid = t.RT * g.Wo;
         if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && valid > best_valid)) {
             best = i; best_cost = cost; best_valid = valid; best_g = t;
