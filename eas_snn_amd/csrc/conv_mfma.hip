@@ -395,6 +395,9 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
 
 }  // namespace
 
+int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
+                         hipStream_t st);
+
 extern "C" {
 
 int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode) {
@@ -419,7 +422,7 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                  int stride, int x_terms, int* inexact_flag, eas_stream_t stream) {
     if (!x || !packed_w || !y || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || Wi % 2 != 0) return EAS_ERR_UNSUPPORTED;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || (ksize == 3 && Wi % 2 != 0)) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     ConvGeom g{};
     const int pad = ksize / 2;
@@ -443,7 +446,10 @@ int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float*
                             : dispatch_tile<KS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
     if (ksize == 3 && stride == 1) { EAS_CONV_DISPATCH(3, 1, 16); }
     else if (ksize == 3 && stride == 2) { EAS_CONV_DISPATCH(3, 2, 16); }
-    else if (ksize == 1 && stride == 1) { EAS_CONV_DISPATCH(1, 1, 32); }
+    else if (ksize == 1 && stride == 1) {
+        rc = (g.dbg & 32) ? EAS_ERR_UNSUPPORTED : eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
+        if (rc != EAS_OK) { EAS_CONV_DISPATCH(1, 1, 32); }
+    }
 #undef EAS_CONV_DISPATCH
     if (rc != EAS_OK) return rc;
     EAS_CHECK_LAUNCH();

@@ -378,9 +378,13 @@ bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, i
 
 }  // namespace
 
+int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW);
+int eas_conv1x1_wgrad_dispatch(const float* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st);
+
 extern "C" {
 
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
+    if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi) * Cout * Cin : 0;
     WgGeom g{};
     if (ksize != 3 || !wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
     const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
@@ -392,8 +396,21 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
 int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                    int stride, int x_terms, eas_stream_t stream) {
     if (!x || !grad_y || !grad_w || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if (ksize != 3 || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || Cout % 8 != 0 || Wi % 2 != 0)
-        return EAS_ERR_UNSUPPORTED;
+    if ((x_terms != 1 && x_terms != 3)) return EAS_ERR_UNSUPPORTED;
+    if (ksize == 1) {
+        if (stride != 1) return EAS_ERR_UNSUPPORTED;
+        EAS_CLEAR_ERR();
+        const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi);
+        if (slices <= 0) return EAS_ERR_UNSUPPORTED;
+        const int rc1 = eas_conv1x1_wgrad_dispatch(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, x_terms, eas_s(stream));
+        if (rc1 != EAS_OK) return rc1;
+        EAS_CHECK_LAUNCH();
+        const int n1 = Cout * Cin;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n1 + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n1, slices);
+        EAS_CHECK_LAUNCH();
+        return EAS_OK;
+    }
+    if (ksize != 3 || (stride != 1 && stride != 2) || Cin % 8 != 0 || Cout % 8 != 0 || Wi % 2 != 0) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;

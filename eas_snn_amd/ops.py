@@ -572,7 +572,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms):
 
 # Which convolutions run on the hand-written MFMA kernels ('mfma') and which stay on ATen/MIOpen ('miopen').
 # Per role so that a slower kernel of ours never displaces a faster library one (measured: scripts/dev_conv.py).
-CONV_POLICY = {'fwd3': 'mfma', 'fwd1': 'miopen', 'dgrad3': 'mfma', 'dgrad1': 'miopen', 'wgrad3': 'mfma'}
+CONV_POLICY = {'fwd3': 'mfma', 'fwd1': 'mfma', 'dgrad3': 'mfma', 'dgrad1': 'mfma', 'wgrad3': 'mfma', 'wgrad1': 'mfma'}
 
 
 VERIFY_SMALL_INT = False     # tests switch this on: every tagged tensor is checked (host sync) before it is used
@@ -593,7 +593,7 @@ def conv_eligible(x, conv):
     k = conv.kernel_size[0]
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1)
             and conv.kernel_size in ((1, 1), (3, 3)) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (k // 2, k // 2)
-            and conv.padding_mode == 'zeros' and x.shape[1] % 8 == 0 and x.shape[-1] % 2 == 0
+            and conv.padding_mode == 'zeros' and x.shape[1] % 8 == 0 and (k == 1 or x.shape[-1] % 2 == 0)
             and CONV_POLICY['fwd%d' % k] == 'mfma' and not (k == 1 and conv.stride != (1, 1)))
 
 
@@ -615,9 +615,9 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         Cin = w.shape[1]
         own_d = ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
-        own_w = ctx.needs_input_grad[1] and k == 3 and CONV_POLICY['wgrad3'] == 'mfma' and w.shape[0] % 8 == 0 and (
-            gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0) and _lib.lib().eas_conv_wgrad_workspace_floats(
-                x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0
+        own_w = ctx.needs_input_grad[1] and CONV_POLICY['wgrad%d' % k] == 'mfma' and _lib.lib().eas_conv_wgrad_workspace_floats(
+            x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
+                k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
         if own_d:
             gx = conv_fwd_packed(gy, conv_pack_weights(w, 1), None, Cin, k, 1, 3)
         if own_w:

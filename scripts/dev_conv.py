@@ -59,28 +59,28 @@ def acc():
 def wacc():
     cases = [(2, 16, 32, 8, 10, 1, True), (2, 32, 32, 16, 20, 1, False), (3, 64, 64, 32, 40, 1, True), (2, 64, 128, 16, 20, 1, True),
              (2, 32, 64, 64, 80, 1, True), (4, 128, 128, 8, 10, 1, True), (2, 64, 128, 32, 40, 2, True), (2, 32, 64, 16, 20, 2, False),
-             (5, 24, 40, 12, 16, 1, False), (3, 128, 64, 16, 20, 1, False)]
-    for (NI, Cin, Cout, H, W, s, sp) in cases:
-        x, w = make(NI, Cin, Cout, H, W, 3, sp)
+             (5, 24, 40, 12, 16, 1, False), (3, 128, 64, 16, 20, 1, False), (3, 128, 64, 16, 20, 1, False, 1), (2, 64, 32, 64, 80, 1, True, 1),
+             (4, 1024, 512, 8, 10, 1, True, 1), (2, 40, 24, 8, 12, 1, False, 1)]
+    for case in cases:
+        (NI, Cin, Cout, H, W, s, sp), kk = case[:7], (case[7] if len(case) > 7 else 3)
+        x, w = make(NI, Cin, Cout, H, W, kk, sp)
         Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
         gy = torch.randn(NI, Cout, Ho, Wo, device=dev)
-        ref = torch.nn.grad.conv2d_weight(x.double().cpu(), w.shape, gy.double().cpu(), stride=s, padding=1)
-        gw = ops.conv_wgrad(x, gy, 3, s, 1 if sp else 3)
-        g32 = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=s, padding=1)
+        ref = torch.nn.grad.conv2d_weight(x.double().cpu(), w.shape, gy.double().cpu(), stride=s, padding=kk // 2)
+        gw = ops.conv_wgrad(x, gy, kk, s, 1 if sp else 3)
+        g32 = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=s, padding=kk // 2)
         scale = ref.abs().max().item()
-        print(f'wgrad NI={NI} {Cin:3d}->{Cout:3d} {H}x{W} s{s} {"spk" if sp else "f32"}: max err / max|gw|  own '
+        print(f'wgrad k{kk} NI={NI} {Cin:3d}->{Cout:3d} {H}x{W} s{s} {"spk" if sp else "f32"}: max err / max|gw|  own '
               f'{(gw.double().cpu() - ref).abs().max().item() / scale:.2e}   miopen-fp32 {(g32.double().cpu() - ref).abs().max().item() / scale:.2e}', flush=True)
 
 
 def wtime():
     for (name, NI, Cin, Cout, H, W, k, s, sp) in bench_shapes():
-        if k != 3:
-            continue
         x, w = make(NI, Cin, Cout, H, W, k, sp)
         Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
         gy = torch.randn(NI, Cout, Ho, Wo, device=dev)
-        t_own = timeit(lambda: ops.conv_wgrad(x, gy, 3, s, 1 if sp else 3))
-        t_mio = timeit(lambda: torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=s, padding=1))
+        t_own = timeit(lambda: ops.conv_wgrad(x, gy, k, s, 1 if sp else 3))
+        t_mio = timeit(lambda: torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=s, padding=k // 2))
         fl = 2.0 * NI * Cout * Ho * Wo * Cin * k * k
         print(f'wgrad {name:22s} own {t_own:7.3f} ms ({fl / t_own / 1e9:7.1f} TF fp32-equiv) | miopen {t_mio:7.3f} ms ({fl / t_mio / 1e9:6.1f} TF)', flush=True)
 
