@@ -27,6 +27,8 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+F32_MFMA_PEAK_TF = 157.3    # dense f32-input MFMA peak (MI355X_MICROARCH.md, Matrix cores)
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same
 # command, scripts/gpu_profile.sh; gfx950 corrections applied by scripts/pmc_summary.py).  C-ABI entry -> device kernels.
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
@@ -147,21 +149,54 @@ def main():
         functional.reset_net(model)
         return out['total_loss']
 
-    for _ in range(args.warmup):
-        step()
+    # Single GPU: the whole step (histogram .. Adam .. reset) is captured once into a HIP graph and replayed, which removes
+    # the host's per-launch cost (~2000 launches per step); the step has no host synchronisation.  Multi-GPU runs stay
+    # eager (DDP's reducer + RCCL inside a captured graph is not something this repository can test on one GPU).
+    use_graph = world == 1 and os.environ.get('EAS_BENCH_GRAPH', '1') != '0'
+    graph = None
+    if use_graph:
+        for gr in opt.param_groups:
+            gr['capturable'] = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup - 1, 2)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step()
+        graph.replay()                       # last warm-up step
+        run = graph.replay
+    else:
+        for _ in range(args.warmup):
+            loss = step()
+        run = step
     timer = ops.KernelTimer() if rank == 0 else None
-    ops.set_timer(timer)
+    if graph is None:
+        ops.set_timer(timer)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        r = run()
+        loss = r if r is not None else loss
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.set_timer(None)
+    timed_steps = args.steps
+    if graph is not None and rank == 0:
+        # HIP events cannot be recorded inside a captured graph: the per-kernel durations behind `roofline` come from eager
+        # steps of the same process right after the timed region (same kernels, same stream, same data)
+        timed_steps = 3
+        ops.set_timer(timer)
+        for _ in range(timed_steps):
+            step()
+        torch.cuda.synchronize()
+        ops.set_timer(None)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -171,23 +206,50 @@ def main():
     if rank == 0:
         frames_total = args.batch * world * args.steps
         summ = timer.summary()
-        fam = {k: dict(calls=v['calls'], ms_per_step=round(v['ms'] / args.steps, 4),
-                       GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None) for k, v in summ.items()}
+        fam = {k: dict(calls=v['calls'], ms_per_step=round(v['ms'] / timed_steps, 4),
+                       GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
+                       **({'TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} if v['flops'] > 0 else {})) for k, v in summ.items()}
         dom = max(summ, key=lambda k: summ[k]['ms'])
         d = summ[dom]
-        achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, 2 if dom.endswith('_bwd') and 'bn_' in dom else 1),
-                    'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'kernel': dom,
-                    'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'hip_kernel_ms_per_step': fam,
-                    'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / (elapsed * 1e3), 4)}
+        sec = d['ms'] * 1e-3
+        common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1),
+                  'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
+                  'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
+                  'kernel_timing': 'HIP events, eager steps after the graph-replayed timed region' if graph is not None
+                  else 'HIP events inside the timed region'}
+        if d['flops'] > 0:
+            # dense convolutions: bounded by the matrix cores.  achieved = algorithmic flops (2 x MAC of the fp32 convolution) per
+            # second against the dense f32 MFMA peak (the arithmetic the path reproduces); every fp32 product is formed from
+            # 3 (spike inputs) or 6 (general inputs) exact bf16 term products on v_mfma_f32_32x32x16_bf16, so the bf16 flops
+            # actually issued and their share of the dense bf16 peak are reported next to it.
+            achieved = d['flops'] / sec / 1e12
+            roofline = {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / F32_MFMA_PEAK_TF, 4),
+                        'mfma_bf16_issued_tflops': round(d['issue_flops'] / sec / 1e12, 1), 'mfma_bf16_peak_tflops': BF16_MFMA_PEAK_TF,
+                        'mfma_bf16_util': round(d['issue_flops'] / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                        'algorithmic_GBps': round(d['bytes'] / sec / 1e9, 1)}
+        else:
+            achieved = d['bytes'] / sec / 1e9
+            roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(achieved / HBM_PEAK_GBS, 4)}
+        roofline.update(common)
+        # the dominant HBM-bound family as well (the elementwise/BN/LIF kernels of the step)
+        hbm_fams = {k: v for k, v in summ.items() if v['flops'] == 0}
+        if hbm_fams:
+            hk = max(hbm_fams, key=lambda k: hbm_fams[k]['ms'])
+            hv = hbm_fams[hk]
+            roofline['hbm_dominant'] = {'kernel': hk, 'achieved': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                                        'unit': 'GB/s', 'frac': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        'traffic': pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1),
+                                        'algorithmic_bytes_per_call': round(hv['bytes'] / hv['calls'])}
         line = {'metric': 'event-frames/sec (T=3) SYOLOX-S Gen1 304x240', 'value': round(frames_total / elapsed, 2),
                 'unit': 'event-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, batch 64/GPU, '
                                        'raw events -> histogram -> fwd + bwd + Adam + reset_net',
-                           'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}'},
+                           'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}',
+                           'launch': 'hip-graph replay of the whole step' if graph is not None else 'eager'},
                 'roofline': roofline}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.events)

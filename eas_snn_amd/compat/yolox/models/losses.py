@@ -3,6 +3,13 @@ import torch
 import torch.nn as nn
 
 
+def _prod2(t):
+    """Product over a last axis of length 2 (box width x height).  ``torch.prod``'s backward inspects the input for zeros
+    on the host, which stalls the stream and cannot be captured in a HIP graph; the explicit product has neither problem."""
+    return t[..., 0] * t[..., 1]
+
+
+
 class IOUloss(nn.Module):
     def __init__(self, reduction='none', loss_type='iou'):
         super().__init__()
@@ -15,16 +22,16 @@ class IOUloss(nn.Module):
         p_lo, p_hi = pred[:, :2] - pred[:, 2:] / 2, pred[:, :2] + pred[:, 2:] / 2
         t_lo, t_hi = target[:, :2] - target[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2
         tl, br = torch.max(p_lo, t_lo), torch.min(p_hi, t_hi)
-        area_p, area_g = torch.prod(pred[:, 2:], 1), torch.prod(target[:, 2:], 1)
-        en = (tl < br).type(tl.type()).prod(dim=1)
-        area_i = torch.prod(br - tl, 1) * en
+        area_p, area_g = _prod2(pred[:, 2:]), _prod2(target[:, 2:])
+        en = _prod2((tl < br).type(tl.type()))
+        area_i = _prod2(br - tl) * en
         area_u = area_p + area_g - area_i
         iou = area_i / (area_u + 1e-16)
         if self.loss_type == 'iou':
             loss = 1 - iou ** 2
         elif self.loss_type == 'giou':
             c_tl, c_br = torch.min(p_lo, t_lo), torch.max(p_hi, t_hi)
-            area_c = torch.prod(c_br - c_tl, 1)
+            area_c = _prod2(c_br - c_tl)
             giou = iou - (area_c - area_u) / area_c.clamp(1e-16)
             loss = 1 - giou.clamp(min=-1.0, max=1.0)
         else:

@@ -17,6 +17,13 @@ from .losses import IOUloss
 from .network_blocks import BaseConv, DWConv
 
 
+def _prod2(t):
+    """Product over a last axis of length 2 (box width x height).  ``torch.prod``'s backward inspects the input for zeros
+    on the host, which stalls the stream and cannot be captured in a HIP graph; the explicit product has neither problem."""
+    return t[..., 0] * t[..., 1]
+
+
+
 def _grid(h, w, device, dtype):
     yv, xv = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
     return torch.stack((xv, yv), 2).view(1, -1, 2).to(dtype)
@@ -120,9 +127,9 @@ class YOLOXHead(nn.Module):
         a, b = gt_boxes[:, :, None, :], bbox_preds[:, None, :, :]
         tl = torch.max(a[..., :2] - a[..., 2:] / 2, b[..., :2] - b[..., 2:] / 2)
         br = torch.min(a[..., :2] + a[..., 2:] / 2, b[..., :2] + b[..., 2:] / 2)
-        en = (tl < br).to(tl.dtype).prod(dim=-1)
-        area_i = torch.prod(br - tl, -1) * en
-        ious = area_i / (torch.prod(a[..., 2:], -1) + torch.prod(b[..., 2:], -1) - area_i)
+        en = _prod2((tl < br).to(tl.dtype))
+        area_i = _prod2(br - tl) * en
+        ious = area_i / (_prod2(a[..., 2:]) + _prod2(b[..., 2:]) - area_i)
         ious = torch.where(cand[:, None, :] & gt_valid[..., None], ious, torch.zeros_like(ious))
         iou_cost = -torch.log(ious + 1e-8)
 

@@ -36,14 +36,17 @@ class KernelTimer:
     def __init__(self):
         self.rec = {}
 
-    def add(self, name, start, end, nbytes):
-        self.rec.setdefault(name, []).append((start, end, nbytes))
+    def add(self, name, start, end, nbytes, flops=0.0, issue_flops=0.0):
+        self.rec.setdefault(name, []).append((start, end, nbytes, flops, issue_flops))
 
     def summary(self):
+        """per entry point: calls, total ms, algorithmic bytes, algorithmic flops (2 x MAC) and matrix-core flops issued
+        (algorithmic x number of bf16 term products)."""
         out = {}
         for name, items in self.rec.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in items)
-            out[name] = dict(calls=len(items), ms=ms, bytes=sum(b for _, _, b in items))
+            ms = sum(it[0].elapsed_time(it[1]) for it in items)
+            out[name] = dict(calls=len(items), ms=ms, bytes=sum(it[2] for it in items), flops=sum(it[3] for it in items),
+                             issue_flops=sum(it[4] for it in items))
         return out
 
 
@@ -55,7 +58,7 @@ def set_timer(timer):
     _TIMER = timer
 
 
-def _call(name, nbytes, fn, *args):
+def _call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     """Invoke one C-ABI entry point (optionally bracketed by HIP events) and check its status."""
     if _TIMER is None:
         check(fn(*args), name)
@@ -64,7 +67,7 @@ def _call(name, nbytes, fn, *args):
     s.record()
     check(fn(*args), name)
     e.record()
-    _TIMER.add(name, s, e, nbytes)
+    _TIMER.add(name, s, e, nbytes, flops, issue_flops)
 
 
 def _dev(*tensors):
@@ -547,9 +550,9 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms):
     pad = ksize // 2
     Ho, Wo = (Hi + 2 * pad - ksize) // stride + 1, (Wi + 2 * pad - ksize) // stride + 1
     y = torch.empty((NI, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    flops_bytes = 4 * (x.numel() + y.numel())
-    _call('eas_conv_fwd', flops_bytes, _lib.lib().eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi, ksize, stride,
-          x_terms, ptr(conv_inexact_flag(x.device)) if x_terms == 1 else None, stream())
+    fl = 2.0 * y.numel() * Cin * ksize * ksize
+    _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
+          ksize, stride, x_terms, None, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
     return y
 
 
@@ -565,8 +568,9 @@ def conv_wgrad(x, gy, ksize, stride, x_terms):
         raise _lib.EasHipError('eas_conv_wgrad: unsupported configuration')
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     gw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    fl = 2.0 * gy.numel() * Cin * ksize * ksize
     _call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad, ptr(x), ptr(gy), ptr(gw), ptr(ws), NI, Cin, Cout, Hi, Wi, ksize,
-          stride, x_terms, stream())
+          stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
     return gw
 
 
