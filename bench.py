@@ -36,17 +36,22 @@ PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_l
                'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
                'eas_event_histogram': ['event_hist_kernel'], 'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel'],
                'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel'],
-               'eas_conv_fwd': ['conv_fwd_mfma_kernel'], 'eas_conv_wgrad': ['conv_wgrad_mfma_kernel']}
+               'eas_conv_fwd': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel'], 'eas_conv_wgrad': ['conv_wgrad_mfma_kernel', 'conv1x1_wgrad_kernel']}
 
 
 def pmc_traffic(entry, launches_per_call):
-    """Average HBM bytes one call of ``entry`` moves (sum over its device launches), from the committed PMC summary."""
+    """Average HBM bytes one call of ``entry`` moves, from the committed PMC summary: launch-weighted mean over the device
+    kernels that implement it, times the launches one call makes."""
     try:
         with open(PMC_FILE) as fh:
             pmc = json.load(fh)
-        return round(sum(pmc[k]['hbm_bytes_per_launch'] for k in PMC_KERNELS[entry]) * launches_per_call)
-    except (OSError, KeyError, ValueError):
+        ks = [pmc[k] for k in PMC_KERNELS[entry] if k in pmc]
+        n = sum(k['launches'] for k in ks)
+        return round(sum(k['hbm_bytes_per_launch'] * k['launches'] for k in ks) / n * launches_per_call)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
+
+
 SENSOR = (240, 304)
 CANVAS = (256, 320)
 OPTS = ['T', '3', 'Tm', '4', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
