@@ -51,6 +51,8 @@ PROTOTYPES = {
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
     'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
+    'eas_spp_pool_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
+    'eas_spp_pool_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
 }
 
 

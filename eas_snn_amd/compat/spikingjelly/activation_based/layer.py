@@ -76,7 +76,7 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
             return (out, ops.time_mean(out)) if want_mean else out
         batch = self._use_batch_stats()
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            ops.bump_counter(self.num_batches_tracked)
         a = node.lif_args()
         update = batch and self.training and self.track_running_stats
         base = getattr(y_seq, '_eas_base', None)       # conv output shared by all T steps (identical input frames)

@@ -28,6 +28,18 @@ def _cat(parts):
     return out
 
 
+def _pool_ksize(m):
+    """kernel size of a (possibly SeqToANNContainer-wrapped) stride-1 'same' MaxPool2d, else None."""
+    if isinstance(m, sj_layer.SeqToANNContainer) and len(m) == 1:
+        m = m[0]
+    if type(m) is nn.MaxPool2d and m.stride in (1, (1, 1)) and m.dilation in (1, (1, 1)) and not m.ceil_mode:
+        k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+        p = m.padding if isinstance(m.padding, int) else m.padding[0]
+        if p == k // 2:
+            return k
+    return None
+
+
 class BaseConv(nn.Module):
     """Conv2d -> BatchNorm -> activation (spiking: SeqToANNContainer(Conv2d) -> BN('m') -> PLIF)."""
 
@@ -90,6 +102,9 @@ class SPPBottleneck(nn.Module):
 
     def forward(self, x):
         x = self.conv1(x)
+        ks = [_pool_ksize(m) for m in self.m]
+        if all(k is not None for k in ks) and ops.spp_pool_supported(x, ks):
+            return self.conv2(ops.spp_pool_cat(x, ks))      # three poolings + concatenation in one kernel
         return self.conv2(_cat([x] + [m(x) for m in self.m]))
 
 

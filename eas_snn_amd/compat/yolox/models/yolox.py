@@ -3,6 +3,8 @@ spiking_yolox.py:16-76)."""
 import torch
 import torch.nn as nn
 
+from eas_snn_amd import ops
+
 from .yolo_head import SpikingYOLOXHead, YOLOXHead
 from .yolo_pafpn import YOLOPAFPN
 from .spiking_yolo_pafpn import SpikingYOLOPAFPN
@@ -41,8 +43,9 @@ class YOLOX(nn.Module):
         self.head = YOLOXHead(80) if head is None else head
 
     def forward(self, x, targets=None):
-        x = _run_embedding(self.embedding, x, 4)
-        return _head_outputs(self, self.backbone(x), targets, x)
+        with ops.deferred_counters():
+            x = _run_embedding(self.embedding, x, 4)
+            return _head_outputs(self, self.backbone(x), targets, x)
 
 
 class SpikingYOLOX(nn.Module):
@@ -54,6 +57,10 @@ class SpikingYOLOX(nn.Module):
         self.head = SpikingYOLOXHead(80) if head is None else head
 
     def forward(self, x, targets=None):
+        with ops.deferred_counters():
+            return self._forward(x, targets)
+
+    def _forward(self, x, targets=None):
         x = _run_embedding(self.embedding, x, 5)
         # one adaptive frame is repeated for all T steps; Ts > 1 must equal T (spiking_yolox.py:52-57)
         if x.dim() == 4 or x.shape[0] == 1:

@@ -303,7 +303,7 @@ def bn_silu(y, bn):
     batch = bn.training or (bn.running_mean is None and bn.running_var is None)
     update = batch and bn.training and bn.track_running_stats
     if update and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn.num_batches_tracked)
     state = (bn.running_mean if (update or not batch) else None, bn.running_var if (update or not batch) else None, bool(batch),
              float(bn.momentum) if update else None, float(bn.eps), _REPLICAS)
     return _BNSiLUFn.apply(y, bn.weight, bn.bias, state)
@@ -647,3 +647,69 @@ def conv2d(x, conv, small_int=None):
     if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
         raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
     return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3)
+
+
+# ------------------------------------------------------------------------------------------------ SPP pooling block
+class _SPPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ks):
+        _dev(x)
+        x = _f32c(x)
+        lead, (Cc, H, W) = x.shape[:-3], x.shape[-3:]
+        N = x.numel() // (Cc * H * W)
+        out = torch.empty(lead + (4 * Cc, H, W), dtype=torch.float32, device=x.device)
+        _call('eas_spp_pool_fwd', 4 * 5 * x.numel(), _lib.lib().eas_spp_pool_fwd, ptr(x), ptr(out), N, Cc, H, W, ks[0], ks[1], ks[2], stream())
+        ctx.save_for_backward(x)
+        ctx.ks = ks
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _f32c(g)
+        Cc, H, W = x.shape[-3:]
+        N = x.numel() // (Cc * H * W)
+        gx = torch.empty_like(x)
+        ks = ctx.ks
+        _call('eas_spp_pool_bwd', 4 * 6 * x.numel(), _lib.lib().eas_spp_pool_bwd, ptr(x), ptr(g), ptr(gx), N, Cc, H, W, ks[0], ks[1], ks[2],
+              stream())
+        return gx, None
+
+
+def spp_pool_supported(x, ks):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() in (4, 5) and len(ks) == 3 and all(k % 2 == 1 for k in ks) and (
+        x.shape[-1] * x.shape[-2] <= 1024)
+
+
+def spp_pool_cat(x, ks):
+    """cat[x, maxpool_k(x) for k in ks] along the channel axis of x [..., C, H, W] in one kernel (and one for the backward)."""
+    out = _SPPFn.apply(x, tuple(int(k) for k in ks))
+    if is_small_int(x):
+        mark_small_int(out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ BN step counters
+_DEFERRED = None
+
+
+class deferred_counters:
+    """Inside this context ``bump_counter`` only records the ``num_batches_tracked`` tensors; they are all incremented by ONE
+    foreach kernel on exit instead of one tiny launch per BatchNorm layer (74 per forward of SYOLOX-S)."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.prev, _DEFERRED = _DEFERRED, []
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        pending, _DEFERRED = _DEFERRED, self.prev
+        if pending:
+            torch._foreach_add_(pending, 1)
+
+
+def bump_counter(t):
+    if _DEFERRED is None:
+        t.add_(1)
+    else:
+        _DEFERRED.append(t)

@@ -218,6 +218,13 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
 int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi,
                    int Wi, int ksize, int stride, int x_terms, eas_stream_t stream);
 
+/* SPP pooling block fused: out[N][4C][H][W] = cat[x, maxpool_k0(x), maxpool_k1(x), maxpool_k2(x)] (stride 1, padding k/2,
+ * odd k; ATen tie rule: first maximum in row-major order) and its backward (arg-max recomputed from x; deterministic gather).
+ * Replaces SPPBottleneck.forward's three MaxPool2d + torch.cat (yolox/models/network_blocks.py:143-147).  H*W <= 1024. */
+int eas_spp_pool_fwd(const float* x, float* out, int64_t N, int C, int H, int W, int k0, int k1, int k2, eas_stream_t stream);
+int eas_spp_pool_bwd(const float* x, const float* grad_out, float* grad_x, int64_t N, int C, int H, int W, int k0, int k1, int k2,
+                     eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

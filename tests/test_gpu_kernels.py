@@ -462,3 +462,24 @@ def test_conv_mfma_is_deterministic_and_checks_spike_tags(dev):
     bad = (x + 0.3).to(dev)
     with pytest.raises(_lib.EasHipError):              # a tensor tagged as spikes that is not exact in bf16 is refused (test switch)
         ops.conv2d(ops.mark_small_int(bad), conv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,spikes', [((3, 2, 16, 8, 10), True), ((4, 8, 8, 10), False), ((2, 3, 5, 7), True), ((1, 2, 4, 20, 20), False)])
+def test_spp_pool_cat_matches_maxpool(dev, shape, spikes):
+    """Fused SPP pooling (+concat) against three nn.MaxPool2d + cat, forward and backward; 0/1 inputs exercise the tie rule."""
+    import torch.nn.functional as F
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(shape, generator=g) < 0.3).float() if spikes else torch.randn(shape, generator=g)
+    ks = (5, 9, 13)
+    xd = x.to(dev).requires_grad_(True)
+    out = ops.spp_pool_cat(xd, ks)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(dev))
+    xr = x.clone().requires_grad_(True)
+    flat = xr.flatten(0, -4) if xr.dim() > 4 else xr
+    ref = torch.cat([flat] + [F.max_pool2d(flat, k, 1, k // 2) for k in ks], dim=1).view(out.shape)
+    ref.backward(go)
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
