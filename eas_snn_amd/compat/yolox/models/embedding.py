@@ -96,3 +96,88 @@ class AdaptiveRSNNEmbedding(nn.Module):
                                      self.Ts, self.readout, self.spike_attach, self.write_zero, self.abs,
                                      float(self.thresh), None if self.vreset is None else float(self.vreset), record=record)
         return (agg, rec.long()) if record else agg
+
+
+class _TimeFlat(nn.Module):
+    """``tdLayer`` of the reference (yolox/models/layer.py:122-132): the wrapped module is applied with [T, N] folded into
+    the batch axis; child name ``layer`` so the keys read ``input_conv.layer.0.weight`` like the reference's."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, x):
+        T = x.shape[0]
+        y = ops.small_conv_stack(x.contiguous().view(-1, *x.shape[2:]), _stack_params(self.layer))
+        return y.view(T, -1, *y.shape[1:])
+
+
+class _DecayCell(nn.Module):
+    """Holder of LIFCell's learnable decay logit (yolox/models/cell.py:26-35): key ``cell.decay``."""
+
+    def __init__(self, decay):
+        super().__init__()
+        self.decay = decay if isinstance(decay, nn.Parameter) else nn.Parameter(torch.as_tensor(float(decay)))
+
+
+def _steps_newest_first(events, nb_steps):
+    """[B,Tl,Tm,2,H,W] | [B,Tm,2,H,W] -> ([Tm,N,2,H,W] newest first, lead dims); a 4-D batch is repeated for every step."""
+    if events.dim() < 5:
+        return events.unsqueeze(0).expand(nb_steps, *events.shape).contiguous(), None
+    return _time_major(events)
+
+
+class SpikingEmbedding(nn.Module):
+    """ "rsnn" (yolox/models/embedding.py:229-316): the sampler's gated recurrence without segments; readout = sum of the
+    pre-reset potentials, or the last potential.  One autograd node over the HIP kernels (ops.gated_recurrence)."""
+
+    def __init__(self, kernel_size, in_channel=2, out_channel=2, readout='sum', relu=False, depth=1, **kwargs_spikes):
+        super().__init__()
+        _check_spike_fn(kwargs_spikes)
+        self.kernel_size, self.readout, self.relu, self.depth = kernel_size, readout, relu, int(depth)
+        self.kwargs_spikes = kwargs_spikes
+        self.nb_steps = kwargs_spikes['Tm'] if 'Tm' in kwargs_spikes else kwargs_spikes['nb_steps']
+        self.thresh = kwargs_spikes['thresh']
+        self.vreset = copy.deepcopy(kwargs_spikes['vreset'])
+        self.input_conv = _TimeFlat(_conv_stack(in_channel, out_channel * 2, kernel_size, self.depth))
+        self.gate_conv = _conv_stack(out_channel, out_channel * 2, kernel_size, self.depth)
+        for m in self.input_conv.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.orthogonal_(m.weight, gain=nn.init.calculate_gain('relu'))
+        for m in self.gate_conv.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, nonlinearity='sigmoid')
+
+    def forward(self, events):
+        ev, lead = _steps_newest_first(events, self.nb_steps)
+        out = ops.gated_recurrence(ev, _stack_params(self.input_conv.layer), _stack_params(self.gate_conv), self.kernel_size,
+                                   self.readout, self.relu, float(self.thresh), None if self.vreset is None else float(self.vreset))
+        if self.readout == 'last' and lead is not None:          # embedding.py:304-306: 'last' is un-flattened
+            out = out.view(tuple(lead) + tuple(out.shape[1:])).transpose(0, 1)
+        return out
+
+
+class LIFEmbedding(nn.Module):
+    """ "snn" (yolox/models/embedding.py:28-76 + LIFCell.forward, cell.py:37-65): psp = conv stack per micro-slice;
+    v = sigmoid(decay)*v + psp, fire (> thresh), reset; readout = sum of the pre-reset potentials or the last potential.
+    The recurrence runs on the sampler's step kernels with a constant gate plane and no recurrent convolution."""
+
+    def __init__(self, kernel_size, in_channel=2, out_channel=2, readout='sum', depth=1, **kwargs_spikes):
+        super().__init__()
+        _check_spike_fn(kwargs_spikes)
+        self.kernel_size, self.readout, self.depth = kernel_size, readout, int(depth)
+        self.nb_steps = kwargs_spikes['Tm'] if 'Tm' in kwargs_spikes else kwargs_spikes['nb_steps']
+        self.thresh = kwargs_spikes['thresh']
+        self.vreset = copy.deepcopy(kwargs_spikes['vreset'])
+        self.embedding_conv = _TimeFlat(_conv_stack(in_channel, out_channel, kernel_size, self.depth))
+        self.cell = _DecayCell(kwargs_spikes['decay'])
+        for m in self.embedding_conv.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.orthogonal_(m.weight, gain=nn.init.calculate_gain('relu'))
+
+    def forward(self, events):
+        ev, _ = _steps_newest_first(events, self.nb_steps)
+        psp = self.embedding_conv(ev)                                        # [Tm, N, C2, H, W]
+        x = torch.cat([self.cell.decay.expand_as(psp), psp], dim=2)          # gate pre-activation | current
+        return ops.gated_recurrence(x, [], [], self.kernel_size, self.readout, False, float(self.thresh),
+                                    None if self.vreset is None else float(self.vreset))

@@ -28,7 +28,7 @@ __device__ __forceinline__ void step_elem(float g_in, float c_in, float g_rec, f
     v_out = c.soft_reset ? vn - c.thresh * spike : vn * (1.0f - spike) + c.v_reset * spike;
     const float vs1 = vsum + vn;                          // :179
     if (spike != 0.0f) {
-        if (seg < c.Ts) {
+        if (c.readout != 3 && seg < c.Ts) {
             float val = c.readout == 0 ? vs1 : (c.readout == 1 ? v_out : vs1 / (float)(c.t - tl));
             if (c.spike_attach) val = val * spike;
             agg[(int64_t)seg * c.total + i] += val;       // :194
@@ -37,7 +37,7 @@ __device__ __forceinline__ void step_elem(float g_in, float c_in, float g_rec, f
             seg += 1;
             tl = c.t;
         }
-        vsum_out = 0.0f;                                  // :197 (every fired element)
+        vsum_out = c.readout == 3 ? vs1 : 0.0f;           // :197 (every fired element); readout 3 = running sum ("rsnn"/"snn")
     } else {
         vsum_out = vs1;
     }
@@ -88,10 +88,10 @@ __device__ __forceinline__ void step_elem_bwd(float gv_out, float gvs_out, float
     const float spike = (vn - c.thresh) > 0.0f ? 1.0f : 0.0f;
     const bool fired = spike != 0.0f;
     const float vs1 = vsum_prev + vn;
-    float d_vs1 = fired ? 0.0f : gvs_out;   // vsum_out = fired ? 0 : vs1
+    float d_vs1 = (fired && c.readout != 3) ? 0.0f : gvs_out;   // vsum_out = fired ? 0 : vs1   (running sum: always vs1)
     float d_vout = gv_out;
     float d_s = gsp;
-    if (fired && seg_b < c.Ts) {
+    if (fired && c.readout != 3 && seg_b < c.Ts) {
         const float ga = g_agg[(int64_t)seg_b * c.total + i];
         float d_pre = ga;
         if (c.spike_attach) {
@@ -185,7 +185,7 @@ int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float*
                        int C2, int HW, eas_stream_t stream) {
     if (!conv_in || !conv_rec || !v || !vsum || !seg || !t_last || !agg || !v_out || !vsum_out || !spike_out)
         return EAS_ERR_INVALID_ARG;
-    if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 2) return EAS_ERR_INVALID_ARG;
+    if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 3) return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)conv_in | (uintptr_t)conv_rec | (uintptr_t)v | (uintptr_t)vsum | (uintptr_t)seg | (uintptr_t)t_last |
          (uintptr_t)v_out | (uintptr_t)vsum_out | (uintptr_t)spike_out | (uintptr_t)gate_save | (uintptr_t)vn_save |
@@ -208,7 +208,7 @@ int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const floa
     if (!g_agg || !v_prev || !vsum_prev || !gate_save || !vn_save || !seg_before || !t_last_before || !g_conv ||
         !g_v_prev || !g_vsum_prev)
         return EAS_ERR_INVALID_ARG;
-    if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 2 || !(sg_alpha > 0.f))
+    if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 3 || !(sg_alpha > 0.f))
         return EAS_ERR_INVALID_ARG;
     StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, sg_alpha, (int64_t)C2 * HW,
               (int64_t)N * C2 * HW};

@@ -392,36 +392,48 @@ def _conv_stack_fwd(x, params, k):
 
 class _ARSNNFn(torch.autograd.Function):
     """Whole adaptive-sampler loop as ONE autograd node (embedding.py:141-226): conv stacks via eas_smallconv_*,
-    the per-step integrate / fire / reset / segment-write via eas_arsnn_step_*."""
+    the per-step integrate / fire / reset / segment-write via eas_arsnn_step_*.
+
+    ``running`` in the configuration selects the plain gated recurrence of the simpler embeddings instead
+    (SpikingEmbedding "rsnn" embedding.py:229-316, LIFEmbedding "snn" :28-76): no segments, the output is the running sum
+    of the pre-reset potentials ('sum') or the last potential ('last').  With an empty input stack ``ev`` already holds
+    the [Tm,N,2*C2,H,W] gate|current planes; with an empty gate stack there is no recurrent convolution."""
 
     @staticmethod
     def forward(ctx, ev, cfg, *params):
         _dev(ev, *params)
         L = _lib.lib()
-        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record = cfg
+        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = cfg
         ev = _f32c(ev)
         Tm, N, Cin, H, W = ev.shape
-        pin, pg = params[:2 * depth], params[2 * depth:]
-        C2 = pg[0].shape[1]
+        pin, pg = params[:2 * d_in], params[2 * d_in:]
         HW = H * W
         if HW % 4 != 0:
             raise _lib.EasHipError('sampler needs H*W divisible by 4')
         dev = ev.device
-        need_grad = any(ctx.needs_input_grad[2:])
+        need_grad = any(ctx.needs_input_grad[2:]) or ctx.needs_input_grad[0]
         st = stream()
-        X, in_ins = _conv_stack_fwd(ev.view(Tm * N, Cin, H, W), pin, k)
-        X = X.view(Tm, N, 2 * C2, H, W)
+        if d_in:
+            X, in_ins = _conv_stack_fwd(ev.view(Tm * N, Cin, H, W), pin, k)
+            X = X.view(Tm, N, X.shape[1], H, W)
+        else:
+            X, in_ins = ev, []
+        C2 = X.shape[2] // 2
         shape = (N, C2, H, W)
         v = torch.zeros(shape, device=dev)
         vsum = torch.zeros(shape, device=dev)
         spike = torch.zeros(shape, device=dev)
         seg = torch.zeros(shape, dtype=torch.int32, device=dev)
         tl = torch.full(shape, -1, dtype=torch.int32, device=dev)
-        agg = torch.zeros((Ts,) + shape, device=dev)
+        agg = torch.zeros((1 if running else Ts,) + shape, device=dev)
+        zero_rec = None if d_gate else torch.zeros((N, 2 * C2, H, W), device=dev)
         saved = []
         t_rec = []
         for t in range(Tm):
-            R, g_ins = _conv_stack_fwd(spike, pg, k)
+            if d_gate:
+                R, g_ins = _conv_stack_fwd(spike, pg, k)
+            else:
+                R, g_ins = zero_rec, []
             v_n, vs_n, sp_n = torch.empty_like(v), torch.empty_like(v), torch.empty_like(v)
             if need_grad:
                 gate, vn = torch.empty_like(v), torch.empty_like(v)
@@ -429,77 +441,86 @@ class _ARSNNFn(torch.autograd.Function):
             else:
                 gate = vn = seg_b = tl_b = None
             _call('eas_arsnn_step_fwd', 38 * v.numel(), L.eas_arsnn_step_fwd, ptr(X[t]), ptr(R), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
-                  ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, readout, int(sat),
-                  thresh, v_reset, int(soft), N, C2, HW, st)
+                  ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, 3 if running else readout,
+                  int(sat), thresh, v_reset, int(soft), N, C2, HW, st)
             if need_grad:
                 saved.append((g_ins, v, vsum, gate, vn, seg_b, tl_b))
             v, vsum, spike = v_n, vs_n, sp_n
             if record:
                 t_rec.append(tl.clone())
-        check(L.eas_arsnn_tail_fwd(ptr(v), ptr(vsum), ptr(spike), ptr(seg), ptr(tl), ptr(agg), Tm, Ts, readout, int(wz), N, C2,
-                                   HW, st), 'eas_arsnn_tail_fwd')
         pre_relu = None
+        if running:
+            out = vsum if running == 'sum' else v
+        else:
+            check(L.eas_arsnn_tail_fwd(ptr(v), ptr(vsum), ptr(spike), ptr(seg), ptr(tl), ptr(agg), Tm, Ts, readout, int(wz), N, C2,
+                                       HW, st), 'eas_arsnn_tail_fwd')
+            out = agg
         if ab:
-            pre_relu = agg
-            agg = torch.relu(agg)
+            pre_relu = out
+            out = torch.relu(out)
         ctx.cfg = cfg
         ctx.dims = (Tm, N, Cin, C2, H, W)
-        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu)
+        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu, agg)
         ctx.params = params
         ctx.ev_needs_grad = ctx.needs_input_grad[0]
         rec = torch.stack(t_rec) if record else None
         if rec is not None:
             ctx.mark_non_differentiable(rec)
-        return agg, rec
+        return out, rec
 
     @staticmethod
-    def backward(ctx, g_agg, _g_rec):
+    def backward(ctx, g_out, _g_rec):
         L = _lib.lib()
-        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record = ctx.cfg
+        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = ctx.cfg
         Tm, N, Cin, C2, H, W = ctx.dims
-        saved, in_ins, spike_last, seg, tl, pre_relu = ctx.saved
+        saved, in_ins, spike_last, seg, tl, pre_relu, agg = ctx.saved
         params = ctx.params
-        pin, pg = params[:2 * depth], params[2 * depth:]
-        pad = k // 2
+        pin, pg = params[:2 * d_in], params[2 * d_in:]
         HW = H * W
         st = stream()
-        g_agg = _f32c(g_agg)
+        g_out = _f32c(g_out)
         if ab:
-            g_agg = g_agg * (pre_relu > 0)
-        dev = g_agg.device
+            g_out = g_out * (pre_relu > 0)
+        dev = g_out.device
         shape = (N, C2, H, W)
-        g_v = torch.empty(shape, device=dev)
-        g_vs = torch.empty(shape, device=dev)
-        check(L.eas_arsnn_tail_bwd(ptr(g_agg), ptr(spike_last), ptr(seg), ptr(tl), ptr(g_v), ptr(g_vs), Tm, Ts, readout, int(wz),
-                                   N, C2, HW, st), 'eas_arsnn_tail_bwd')
+        if running:
+            g_agg = agg                                  # never read in running mode (no segment writes); a valid pointer
+            zeros = torch.zeros(shape, device=dev)
+            g_v, g_vs = (zeros, g_out.contiguous()) if running == 'sum' else (g_out.contiguous(), zeros)
+        else:
+            g_agg = g_out
+            g_v = torch.empty(shape, device=dev)
+            g_vs = torch.empty(shape, device=dev)
+            check(L.eas_arsnn_tail_bwd(ptr(g_agg), ptr(spike_last), ptr(seg), ptr(tl), ptr(g_v), ptr(g_vs), Tm, Ts, readout, int(wz),
+                                       N, C2, HW, st), 'eas_arsnn_tail_bwd')
         g_spike = None
         gX = torch.empty((Tm, N, 2 * C2, H, W), device=dev)
         # gradient reaching each conv of the gate stack at every step (batched weight-grad at the end)
-        g_stage = [[None] * Tm for _ in range(depth)]
+        g_stage = [[None] * Tm for _ in range(d_gate)]
         for t in range(Tm - 1, -1, -1):
             g_ins, v_prev, vs_prev, gate, vn, seg_b, tl_b = saved[t]
             g_vp, g_vsp = torch.empty_like(g_v), torch.empty_like(g_v)
             check(L.eas_arsnn_step_bwd(ptr(g_v), ptr(g_vs), ptr(g_spike), ptr(g_agg), ptr(v_prev), ptr(vs_prev), ptr(gate), ptr(vn),
-                                       ptr(seg_b), ptr(tl_b), ptr(gX[t]), ptr(g_vp), ptr(g_vsp), t, Ts, readout, int(sat), thresh,
-                                       v_reset, int(soft), 1.0, N, C2, HW, st), 'eas_arsnn_step_bwd')
+                                       ptr(seg_b), ptr(tl_b), ptr(gX[t]), ptr(g_vp), ptr(g_vsp), t, Ts, 3 if running else readout,
+                                       int(sat), thresh, v_reset, int(soft), 1.0, N, C2, HW, st), 'eas_arsnn_step_bwd')
             g_v, g_vs = g_vp, g_vsp
             g = gX[t]
-            for i in range(depth - 1, -1, -1):
+            for i in range(d_gate - 1, -1, -1):
                 g_stage[i][t] = g
                 if i == 0 and t == 0:
                     break                      # spike input of step 0 is the constant 0
                 g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None)   # ReLU in front of conv i fused as a mask
-            g_spike = g if t > 0 else None
+            g_spike = g if (t > 0 and d_gate) else None
         grads_g = []
-        for i in range(depth):
+        for i in range(d_gate):
             gs = torch.cat(g_stage[i], 0)
             xs = torch.cat([saved[t][0][i] for t in range(Tm)], 0)
             gw, gb = smallconv_bwd_weight(gs, xs, pg[2 * i])
             grads_g += [gw, gb]
         # input conv stack, all Tm steps at once
-        grads_in = [None] * (2 * depth)
+        grads_in = [None] * (2 * d_in)
         g = gX.view(Tm * N, 2 * C2, H, W)
-        for i in range(depth - 1, -1, -1):
+        for i in range(d_in - 1, -1, -1):
             grads_in[2 * i], grads_in[2 * i + 1] = smallconv_bwd_weight(g, in_ins[i], pin[2 * i])
             if i > 0 or ctx.ev_needs_grad:
                 g = smallconv_bwd_input(g, pin[2 * i], in_ins[i] if i > 0 else None)
@@ -515,9 +536,50 @@ def arsnn_forward(ev_rev, input_params, gate_params, kernel_size, Ts, readout, s
     depth = len(input_params) // 2
     soft = v_reset is None
     cfg = (int(kernel_size), depth, int(Ts), READOUT_IDS[readout], bool(spike_attach), bool(write_zero), bool(use_abs),
-           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record))
+           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record), None, depth, len(gate_params) // 2)
     return _ARSNNFn.apply(ev_rev, cfg, *input_params, *gate_params)
 
+
+def gated_recurrence(ev_or_x, input_params, gate_params, kernel_size, readout, relu, thresh, v_reset):
+    """The plain gated spiking recurrence of SpikingEmbedding / LIFEmbedding: vn = sigmoid(g)*v + c, fire (> thresh), reset;
+    returns sum_t vn ('sum') or the last potential ('last').  ``input_params`` empty: ``ev_or_x`` is [Tm,N,2*C2,H,W]
+    (gate pre-activations | currents); ``gate_params`` empty: no recurrent convolution."""
+    if readout not in ('sum', 'last'):
+        raise NotImplementedError(readout)
+    soft = v_reset is None
+    d_in, d_gate = len(input_params) // 2, len(gate_params) // 2
+    cfg = (int(kernel_size), max(d_in, d_gate), 1, 0, False, False, bool(relu), float(thresh), 0.0 if soft else float(v_reset), soft,
+           False, readout, d_in, d_gate)
+    return _ARSNNFn.apply(ev_or_x, cfg, *input_params, *gate_params)[0]
+
+
+class _SmallConvFn(torch.autograd.Function):
+    """One tiny-channel convolution (+ fused ReLU) of the embeddings on the LDS-tiled direct kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        _dev(x, w, b)
+        y = smallconv_fwd(x, w, b, relu=relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = _f32c(g)
+        if y is not None:
+            g = g * (y > 0)
+        gx = smallconv_bwd_input(g, w) if ctx.needs_input_grad[0] else None
+        gw, gb = smallconv_bwd_weight(g, x, w)
+        return gx, gw, gb, None
+
+
+def small_conv_stack(x, params):
+    """Conv [+ ReLU + Conv]* with [w0, b0, w1, b1, ...] on x [N,C,H,W]."""
+    n = len(params) // 2
+    for i in range(n):
+        x = _SmallConvFn.apply(x, params[2 * i], params[2 * i + 1], i < n - 1)
+    return x
 
 # ------------------------------------------------------------------------------------------------ K4 conv (MFMA)
 _INEXACT = {}

@@ -145,7 +145,9 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
  *     yolox/models/embedding.py:170-201 + update :132-139; tail :203-217), dense masked form.
  * conv_in / conv_rec: [N][2*C2][HW] outputs of input_conv(ev[t]) / gate_conv(spike): channels
  * [0,C2) gate pre-activation, [C2,2*C2) current.  State per (n,c,hw): v, vsum (fp32), seg, t_last
- * (int32).  agg: [Ts][N][C2][HW].  readout: 0 sum, 1 last, 2 avg.  v_reset_mode: 0 hard reset to
+ * (int32).  agg: [Ts][N][C2][HW].  readout: 0 sum, 1 last, 2 avg; 3 (step kernels only) = plain gated recurrence of
+ * SpikingEmbedding / LIFEmbedding (embedding.py:229-316, 28-76): vsum is a running sum that is never reset and no
+ * segment is written.  v_reset_mode: 0 hard reset to
  * v_reset, 1 soft (v - thresh*spike).  Saved for backward: gate, vn (pre-reset), seg_before,
  * t_last_before (all nullable in inference). */
 int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float* v, const float* vsum,

@@ -483,3 +483,29 @@ def test_spp_pool_cat_matches_maxpool(dev, shape, spikes):
     ref.backward(go)
     assert torch.equal(out.detach().cpu(), ref.detach())
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['rsnn', 'snn'])
+@pytest.mark.parametrize('ro', ['sum', 'last'])
+def test_simple_embeddings_golden(dev, kind, ro):
+    """SpikingEmbedding ("rsnn") / LIFEmbedding ("snn") on the HIP kernels against golden vectors produced by the reference
+    classes (oracle/gen_golden.py): output, input gradient and every parameter gradient."""
+    import torch.nn as nn
+    from oracle import fill
+    from yolox.models import embedding as E
+    from yolox.models.activation import Rectangle
+    from yolox.utils.util import warp_decay
+    g = load_golden(f'emb_{kind}_{ro}')
+    kw = dict(nb_steps=4, vreset=0.0, thresh=1.0, spike_fn=Rectangle, decay=nn.Parameter(warp_decay(0.5)))
+    m = (E.SpikingEmbedding(5, 2, 2, readout=ro, relu=(ro == 'last'), depth=2, **kw) if kind == 'rsnn'
+         else E.LIFEmbedding(5, 2, 2, readout=ro, depth=2, **kw))
+    assert fill.procedural_fill_(m, conv_gain=2.0) == int(g['crc'])
+    m.to(dev)
+    x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
+    out = m(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g['out'], rtol=1e-5, atol=1e-5)
+    out.backward(torch.from_numpy(g['gout']).to(dev))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=1e-3, atol=1e-4)
+    for n, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=2e-3, atol=2e-3, err_msg=n)
