@@ -120,8 +120,14 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    force_ddp = os.environ.get('EAS_BENCH_FORCE_DDP') == '1'     # development: exercise the DDP/RCCL path with one rank
+    if world > 1 or force_ddp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if force_ddp and world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
     assert world == args.gpus or world == 1, f'launched {world} ranks for --gpus {args.gpus}'
 
@@ -139,7 +145,7 @@ def main():
     model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
     opt = exp.get_optimizer(args.batch * world)
     net = model
-    if world > 1:
+    if world > 1 or force_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
 
     ev = data.events_to_device(data.synth_event_batch(args.batch, args.events, *SENSOR, seed=rank), dev)
@@ -157,7 +163,7 @@ def main():
     # Single GPU: the whole step (histogram .. Adam .. reset) is captured once into a HIP graph and replayed, which removes
     # the host's per-launch cost (~2000 launches per step); the step has no host synchronisation.  Multi-GPU runs stay
     # eager (DDP's reducer + RCCL inside a captured graph is not something this repository can test on one GPU).
-    use_graph = world == 1 and os.environ.get('EAS_BENCH_GRAPH', '1') != '0'
+    use_graph = world == 1 and not force_ddp and os.environ.get('EAS_BENCH_GRAPH', '1') != '0'
     graph = None
     if use_graph:
         for gr in opt.param_groups:
@@ -259,7 +265,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.events)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 
