@@ -184,8 +184,6 @@ def main():
             loss = step()
         run = step
     timer = ops.KernelTimer() if rank == 0 else None
-    if graph is None:
-        ops.set_timer(timer)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -197,17 +195,16 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # Per-kernel durations behind `roofline`: HIP events around every C-ABI call, on the stream the kernels are launched on, in
+    # eager steps of this same process right after the timed region (same kernels, same data).  Not inside it: events cannot be
+    # recorded into a captured graph, and ~1400 event records per eager step would slow the timed region itself by ~10 %.
+    # With more than one rank every rank runs these steps (the DDP all-reduce needs all of them); rank 0 records.
+    timed_steps = 3
+    ops.set_timer(timer)
+    for _ in range(timed_steps):
+        step()
+    torch.cuda.synchronize()
     ops.set_timer(None)
-    timed_steps = args.steps
-    if graph is not None and rank == 0:
-        # HIP events cannot be recorded inside a captured graph: the per-kernel durations behind `roofline` come from eager
-        # steps of the same process right after the timed region (same kernels, same stream, same data)
-        timed_steps = 3
-        ops.set_timer(timer)
-        for _ in range(timed_steps):
-            step()
-        torch.cuda.synchronize()
-        ops.set_timer(None)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -226,8 +223,7 @@ def main():
         common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1),
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
-                  'kernel_timing': 'HIP events, eager steps after the graph-replayed timed region' if graph is not None
-                  else 'HIP events inside the timed region'}
+                  'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'}
         if d['flops'] > 0:
             # dense convolutions: bounded by the matrix cores.  achieved = algorithmic flops (2 x MAC of the fp32 convolution) per
             # second against the dense f32 MFMA peak (the arithmetic the path reproduces); every fp32 product is formed from

@@ -30,12 +30,16 @@ struct ConvGeom {
     int RT;        // output rows (flattened over images) per block tile
     int rows_seg;  // output rows per image segment inside a tile = min(RT, Ho)
     int nseg;      // image segments per tile = RT / rows_seg
-    int rows_in;   // input rows staged per segment = (rows_seg-1)*S + KS
+    int rows_in;   // input rows staged per segment = (rows_seg-1)*S + ext_h
     int RS;        // staged row stride in pixels = Wi + 2*pad
     int Q;         // staged input pixels per tile = nseg*rows_in*RS
     int MT;        // ceil(Cout/32)
     int KSTEPS;    // ceil(Cin/16)
     int total_rows;
+    int pad_t, pad_l;   // rows above / columns left of the image in the staged patch (zero halo)
+    int ext_h;          // rows spanned by the taps (3 for a 3x3 kernel)
+    int tap_off[9];     // staged-pixel offset (dh*RS + dw) of every tap
+    int oH, oW, os, oph, opw;   // output tensor height/width, output stride and phase: y[.., orow*os+oph, ocol*os+opw]
     int dbg;       // development ablation switches (EAS_CONV_DBG): 1 no output stores, 2 no staging after chunk 0, 4 weights from one address
 };
 
@@ -81,6 +85,48 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16x8* __
     }
 }
 
+// Input gradient of a stride-2 3x3 convolution (padding 1), by output-pixel parity class (ph, pw): grad_x[2a+ph][2b+pw]
+// only receives taps with kh = ph+1 (mod 2): a stride-1 "convolution" of grad_y with 1, 2, 2 or 4 taps per class
+//   ph = 0: kh = 1 reads grad_y row a ;  ph = 1: kh = 2 reads row a (dh = 0), kh = 0 reads row a+1 (dh = 1); same for columns.
+// Packed: class c = 2*ph+pw at bf16x8 offset 3*MT*KSTEPS*64*{0,1,3,5}[c], inside [term][mt][kstep][local tap = ih*(pw+1)+iw][lane];
+// A[m = ci][k = co][tap] = w[co][ci][kh][kw].
+__global__ void conv_pack_weights_s2dgrad_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
+    const int M = Cin, K = Cout;
+    const int MT = (M + 31) / 32, KSTEPS = (K + 15) / 16;
+    const int total = MT * KSTEPS * 9 * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63;
+        int rest = idx >> 6;
+        const int tap9 = rest % 9;
+        rest /= 9;
+        const int ks = rest % KSTEPS;
+        const int mt = rest / KSTEPS;
+        const int kh = tap9 / 3, kw = tap9 - kh * 3;
+        const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
+        const int ih = kh == 0 ? 1 : 0, iw = kw == 0 ? 1 : 0;
+        const int cls = 2 * ph + pw, ntap = (ph + 1) * (pw + 1), lt = ih * (pw + 1) + iw;
+        const int cum = cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5));
+        const size_t base = (size_t)3 * MT * KSTEPS * 64 * cum;
+        const size_t term = (size_t)MT * KSTEPS * ntap * 64;
+        const size_t pos = (((size_t)mt * KSTEPS + ks) * ntap + lt) * 64 + lane;
+        const int m = mt * 32 + (lane & 31);
+        bf16x8 t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * (lane >> 5) + j;
+            const float v = (m < M && k < K) ? w[((size_t)k * Cin + m) * 9 + tap9] : 0.0f;
+            __bf16 a, b, c;
+            split3(v, a, b, c);
+            t0[j] = a;
+            t1[j] = b;
+            t2[j] = c;
+        }
+        wp[base + pos] = t0;
+        wp[base + term + pos] = t1;
+        wp[base + 2 * term + pos] = t2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 8 consecutive input channels of one staged pixel -> bf16 term(s) -> one 16-byte LDS store per term
 template <int XT>
@@ -110,12 +156,11 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // lane for VEC = 4) and VEC 16-byte LDS stores per term.  The next chunk's items are all requested during the first MFMA
 // steps of the current chunk and written to the other LDS buffer during its last steps, so each load has several thousand
 // cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
-template <int KS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
 __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
                                                             ConvGeom g) {
     typedef float vecf __attribute__((ext_vector_type(VEC)));
-    constexpr int PAD = KS / 2, TAPS = KS * KS;
     constexpr int PIXB = CCH * 2;  // bytes per staged pixel and term
     constexpr int NSTEPS = (CCH / 16) * TAPS;
     constexpr int NT = 64 * WVM * WVN;   // threads; NIT = staging items per thread per chunk (upper bound, surplus skipped block-uniformly)
@@ -133,15 +178,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     const int buf_bytes = term_stride * XT;
     const int npix = g.RT * g.Wo;
 
-    // zero the halo columns of both buffers (never written again)
-    if (PAD > 0) {
+    // zero the halo columns of both buffers (never written again): pad_l columns left of the image, the rest right of it
+    {
         const int rows = g.nseg * g.rows_in;
-        const int per_row = 2 * PAD * (PIXB / 16);
+        const int hcols = g.RS - g.Wi;
+        const int per_row = hcols * (PIXB / 16);
         for (int i = tid; i < rows * per_row * XT * 2; i += NT) {
             const int row = i / per_row, k = i - row * per_row;
             const int bt = row / rows, rw = row - bt * rows;   // bt = buffer*XT + term
-            const int side = k / (PAD * (PIXB / 16)), kk = k - side * (PAD * (PIXB / 16));
-            const int col = side ? g.RS - PAD : 0;
+            const int hc = k / (PIXB / 16), kk = k - hc * (PIXB / 16);
+            const int col = hc < g.pad_l ? hc : g.Wi + hc;
             *(uint4*)(smem + (size_t)bt * term_stride + ((size_t)rw * g.RS + col) * PIXB + kk * 16) = make_uint4(0, 0, 0, 0);
         }
     }
@@ -158,7 +204,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S) * PIXB + h * 16;
         const int rho = rho0 + rl;
         const int img = rho / g.Ho, orow = rho - img * g.Ho;
-        ybase[j] = (p < npix && rho < g.total_rows) ? (((long)img * g.Cout * g.Ho + orow) * g.Wo + c) : -1;
+        const int yr = orow * g.os + g.oph, yc = c * g.os + g.opw;
+        ybase[j] = (p < npix && rho < g.total_rows && yr < g.oH && yc < g.oW) ? (((long)img * g.Cout * g.oH + yr) * g.oW + yc) : -1;
     }
 
     // per-thread staging items (the same for every channel chunk)
@@ -173,10 +220,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int gi = item / units, u = item - gi * units;
         const int seg = u / units_seg, rem = u - seg * units_seg;
         const int rl = rem / units_row, cu = rem - rl * units_row;
-        const int ir = r0 * S - PAD + rl, img = img0 + seg;
+        const int ir = r0 * S - g.pad_t + rl, img = img0 + seg;
         const bool ok = ir >= 0 && ir < g.Hi && img < g.NI;
         gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + cu * VEC) : -1;
-        lofs[it] = ((seg * g.rows_in + rl) * g.RS + PAD + cu * VEC) * PIXB + gi * 16;
+        lofs[it] = ((seg * g.rows_in + rl) * g.RS + g.pad_l + cu * VEC) * PIXB + gi * 16;
         gch[it] = gi * 8;
     }
 
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
             // keep the prefetch loads (next step's weights, the next patch) ahead of this step's MFMAs: without the fence
             // the scheduler sinks them behind the last use of the registers they would share
             __builtin_amdgcn_sched_barrier(0);
-            const int toff = ((tap / KS) * g.RS + (tap % KS)) * PIXB + kk * 32;
+            const int toff = g.tap_off[tap] * PIXB + kk * 32;
             bf16x8 b[WN][XT];
 #pragma unroll
             for (int j = 0; j < WN; ++j)
@@ -300,7 +347,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     }
 
     // ---- epilogue: D tile (col = pixel = lane&31, row = (e&3) + 8*(e>>2) + 4*h) -> y NCHW
-    const long cstride = (long)g.Ho * g.Wo;
+    const long cstride = (long)g.oH * g.oW;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         if (mt0 + i >= g.MT) continue;
@@ -316,9 +363,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     }
 }
 
-template <int KS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
 int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
-    auto kern = conv_fwd_mfma_kernel<KS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
+    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
     const size_t lds = (size_t)2 * g.Q * CCH * 2 * XT;
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
     static bool attr_set = false;
@@ -342,17 +389,17 @@ int pick_rows(int Ho, int Wo, int BN) {
 
 typedef int (*launch_fn)(const float*, const bf16x8*, const float*, float*, int*, ConvGeom, hipStream_t);
 
-template <int KS, int S, int XT, int CCH, int VEC>
+template <int TAPS, int S, int XT, int CCH, int VEC>
 int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
     // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
     // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
     struct Cand { int wm, wvm, bn, threads, nit; launch_fn fn; };
     constexpr int N8 = XT == 1 ? 2 : 1, N4 = 2;   // staging items per thread (register budget: 2 waves per SIMD either way)
     const Cand cands[7] = {
-        {1, 2, 640, 512, N8, launch_fwd<KS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, launch_fwd<KS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
-        {1, 8, 160, 512, N8, launch_fwd<KS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, launch_fwd<KS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
-        {1, 1, 640, 256, N4, launch_fwd<KS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, launch_fwd<KS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
-        {1, 4, 160, 256, N4, launch_fwd<KS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>}};
+        {1, 2, 640, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
+        {1, 8, 160, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
+        {1, 1, 640, 256, N4, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
+        {1, 4, 160, 256, N4, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>}};
     // cost model (measured on MI355X, scripts/dev_conv.py): every block of one shape takes about the same time whatever part
     // of its pixel tile is valid; one block per CU; a round of 8-wave blocks costs ~1.27x a round of 4-wave blocks
     int best = -1;
@@ -371,7 +418,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
             if (t.RT == 0) break;
             t.rows_seg = t.RT < g.Ho ? t.RT : g.Ho;
             t.nseg = t.RT / t.rows_seg;
-            t.rows_in = (t.rows_seg - 1) * S + KS;
+            t.rows_in = (t.rows_seg - 1) * S + g.ext_h;
             t.Q = t.nseg * t.rows_in * t.RS;
             fits = (size_t)2 * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wi / VEC) * (CCH / 8) <= c.nit * c.threads;
             cap = t.RT * g.Wo;
@@ -406,12 +453,16 @@ int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode) {
 }
 
 int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int ksize, int mode, eas_stream_t stream) {
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || (mode != 0 && mode != 1)) return EAS_ERR_INVALID_ARG;
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || mode < 0 || mode > 2 || (mode == 2 && ksize != 3))
+        return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
     const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
     const int total = ((M + 31) / 32) * ((K + 15) / 16) * ksize * ksize * 64;
-    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin,
-                       ksize * ksize, mode);
+    if (mode == 2)
+        hipLaunchKernelGGL(conv_pack_weights_s2dgrad_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin);
+    else
+        hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin,
+                           ksize * ksize, mode);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -430,6 +481,10 @@ int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float*
     g.Ho = (Hi + 2 * pad - ksize) / stride + 1;
     g.Wo = (Wi + 2 * pad - ksize) / stride + 1;
     g.RS = Wi + 2 * pad;
+    g.pad_t = g.pad_l = pad;
+    g.ext_h = ksize;
+    for (int t = 0; t < ksize * ksize; ++t) g.tap_off[t] = (t / ksize) * g.RS + (t % ksize);
+    g.oH = g.Ho; g.oW = g.Wo; g.os = 1; g.oph = g.opw = 0;
     g.MT = (Cout + 31) / 32;
     g.KSTEPS = (Cin + 15) / 16;
     g.total_rows = NI * g.Ho;
@@ -439,20 +494,54 @@ int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float*
     hipStream_t st = eas_s(stream);
     int rc = EAS_ERR_UNSUPPORTED;
     const bool v4 = Wi % 4 == 0;
-#define EAS_CONV_DISPATCH(KS_, S_, CCH_)                                                                                          \
-    rc = x_terms == 1 ? (v4 ? dispatch_tile<KS_, S_, 1, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                             \
-                            : dispatch_tile<KS_, S_, 1, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))                            \
-                      : (v4 ? dispatch_tile<KS_, S_, 3, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                             \
-                            : dispatch_tile<KS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
-    if (ksize == 3 && stride == 1) { EAS_CONV_DISPATCH(3, 1, 16); }
-    else if (ksize == 3 && stride == 2) { EAS_CONV_DISPATCH(3, 2, 16); }
-    else if (ksize == 1 && stride == 1) {
-        rc = (g.dbg & 32) ? EAS_ERR_UNSUPPORTED : eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
-        if (rc != EAS_OK) { EAS_CONV_DISPATCH(1, 1, 32); }
-    }
+#define EAS_CONV_DISPATCH(TAPS_, S_, CCH_)                                                                                        \
+    rc = x_terms == 1 ? (v4 ? dispatch_tile<TAPS_, S_, 1, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
+                            : dispatch_tile<TAPS_, S_, 1, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))                          \
+                      : (v4 ? dispatch_tile<TAPS_, S_, 3, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
+                            : dispatch_tile<TAPS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
+    if (ksize == 3 && stride == 1) { EAS_CONV_DISPATCH(9, 1, 16); }
+    else if (ksize == 3 && stride == 2) { EAS_CONV_DISPATCH(9, 2, 16); }
+    else if (ksize == 1 && stride == 1) rc = eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
 #undef EAS_CONV_DISPATCH
     if (rc != EAS_OK) return rc;
     EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// grad_x[NI,Cin,Hi,Wi] of a stride-2 3x3 convolution (padding 1) from grad_y[NI,Cout,Ho,Wo] and the weights packed with
+// mode 2: four launches, one per parity class of the input pixel (1, 2, 2 and 4 taps), each a stride-1 tap-list
+// convolution over grad_y (general fp32, three bf16 terms) that writes every second row/column of grad_x.
+int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, int NI, int Cin, int Cout, int Hi, int Wi, eas_stream_t stream) {
+    if (!grad_y || !packed_w || !grad_x || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    if (Cout % 8 != 0 || Wo % 2 != 0) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    hipStream_t st = eas_s(stream);
+    static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
+    const int MT = (Cin + 31) / 32, KSTEPS = (Cout + 15) / 16;
+    const int cum[4] = {0, 1, 3, 5};
+    const bool v4 = Wo % 4 == 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        ConvGeom g{};
+        g.NI = NI; g.Cin = Cout; g.Cout = Cin; g.Hi = Ho; g.Wi = Wo; g.Ho = Ho; g.Wo = Wo;
+        g.RS = Wo + pw;
+        g.pad_t = g.pad_l = 0;
+        g.ext_h = ph + 1;
+        for (int ih = 0; ih <= ph; ++ih)
+            for (int iw = 0; iw <= pw; ++iw) g.tap_off[ih * (pw + 1) + iw] = ih * g.RS + iw;
+        g.oH = Hi; g.oW = Wi; g.os = 2; g.oph = ph; g.opw = pw;
+        g.MT = MT; g.KSTEPS = KSTEPS;
+        g.total_rows = NI * Ho;
+        g.dbg = dbg;
+        const bf16x8* wp = (const bf16x8*)packed_w + (size_t)3 * MT * KSTEPS * 64 * cum[cls];
+        int rc;
+        if (cls == 0) rc = v4 ? dispatch_tile<1, 1, 3, 64, 4>(grad_y, wp, nullptr, grad_x, nullptr, g, st) : dispatch_tile<1, 1, 3, 64, 2>(grad_y, wp, nullptr, grad_x, nullptr, g, st);
+        else if (cls == 3) rc = v4 ? dispatch_tile<4, 1, 3, 16, 4>(grad_y, wp, nullptr, grad_x, nullptr, g, st) : dispatch_tile<4, 1, 3, 16, 2>(grad_y, wp, nullptr, grad_x, nullptr, g, st);
+        else rc = v4 ? dispatch_tile<2, 1, 3, 32, 4>(grad_y, wp, nullptr, grad_x, nullptr, g, st) : dispatch_tile<2, 1, 3, 32, 2>(grad_y, wp, nullptr, grad_x, nullptr, g, st);
+        if (rc != EAS_OK) return rc;
+        EAS_CHECK_LAUNCH();
+    }
     return EAS_OK;
 }
 

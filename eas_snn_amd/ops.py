@@ -684,8 +684,16 @@ class _ConvFn(torch.autograd.Function):
         own_w = ctx.needs_input_grad[1] and CONV_POLICY['wgrad%d' % k] == 'mfma' and _lib.lib().eas_conv_wgrad_workspace_floats(
             x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
+        own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and CONV_POLICY['dgrad3'] == 'mfma' and w.shape[0] % 8 == 0
+                  and gy.shape[-1] % 2 == 0)
         if own_d:
             gx = conv_fwd_packed(gy, conv_pack_weights(w, 1), None, Cin, k, 1, 3)
+        elif own_d2:
+            gx = torch.empty_like(x)
+            fl = 2.0 * gy.numel() * Cin * 9
+            _call('eas_conv_fwd', 4 * (x.numel() + gy.numel()), _lib.lib().eas_conv_dgrad_s2, ptr(gy), ptr(conv_pack_weights(w, 2)), ptr(gx),
+                  x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stream(), flops=fl, issue_flops=6 * fl)
+            own_d = True
         if own_w:
             gw = conv_wgrad(x, gy, k, stride, x_terms)
         need_d = ctx.needs_input_grad[0] and not own_d

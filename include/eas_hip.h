@@ -200,7 +200,8 @@ int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k);
  * (csrc/conv_mfma.hip), i.e. an fp32-accumulated sum of the same products an fp32 convolution forms.
  *
  * eas_conv_pack_weights: w[Cout][Cin][k][k] -> MFMA A-fragment order, 3 bf16 terms; mode 0 for the forward conv,
- *     mode 1 (transposed + flipped) for the input gradient of a stride-1 conv.  `packed` holds
+ *     mode 1 (transposed + flipped) for the input gradient of a stride-1 conv, mode 2 (transposed, grouped by input-pixel
+ *     parity class) for the input gradient of a stride-2 3x3 conv.  `packed` holds
  *     eas_conv_packed_weight_bytes(Cout,Cin,k,mode) bytes.
  * eas_conv_fwd: y[NI][Cout][Ho][Wo] (+bias[Cout] if not NULL).  x_terms = 1: x holds small integers (spikes and
  *     their SEW sums; *inexact_flag, if not NULL, is OR-ed with 1 when an element is not exact in bf16);
@@ -210,6 +211,10 @@ int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode);
 int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int ksize, int mode, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
+/* Input gradient of a stride-2 3x3 convolution: grad_x[NI][Cin][Hi][Wi] from grad_y[NI][Cout][Ho][Wo] and the weights
+ * packed with mode 2 (eas_conv_pack_weights), by parity class of the input pixel (1/2/2/4 taps per class). */
+int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, int NI, int Cin, int Cout, int Hi, int Wi,
+                      eas_stream_t stream);
 
 /* grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and
  * grad_y[NI][Cout][Ho][Wo] (ATen convolution_backward, weight part).  Reduction over output pixels on the matrix

@@ -93,7 +93,9 @@ def bench_shapes():
         ('dark3.0 s2', 192, 64, 128, 64, 80, 3, 2, True), ('dark4.0 s2', 192, 128, 256, 32, 40, 3, 2, True),
         ('dark5.0 s2', 192, 256, 512, 16, 20, 3, 2, True),
         ('dark3.conv3 1x1', 192, 128, 128, 32, 40, 1, 1, True), ('dark2.conv1 1x1', 192, 64, 32, 64, 80, 1, 1, True),
-        ('dark5.spp.conv2 1x1', 192, 1024, 512, 8, 10, 1, 1, True)]
+        ('dark5.spp.conv2 1x1', 192, 1024, 512, 8, 10, 1, 1, True),
+        ('dgrad dark2.m', 192, 32, 32, 64, 80, 3, 1, False), ('dgrad dark3.m', 192, 64, 64, 32, 40, 3, 1, False),
+        ('dgrad dark4.m', 192, 128, 128, 16, 20, 3, 1, False), ('dgrad dark5.m', 192, 256, 256, 8, 10, 3, 1, False)]
 
 
 def time_():
@@ -136,7 +138,10 @@ def ablate():
         name, NI, Cin, Cout, H, W, k, s, sp = bench_shapes()[idx]
         x, w = make(NI, Cin, Cout, H, W, k, sp)
         pk = ops.conv_pack_weights(w, 0)
-        t = timeit(lambda: ops.conv_fwd_packed(x, pk, None, Cout, k, s, 1 if sp else 3), reps=20)
+        try:
+            t = timeit(lambda: ops.conv_fwd_packed(x, pk, None, Cout, k, s, 1 if sp else 3), reps=20)
+        except Exception:
+            t = float('nan')
         print(f'dbg={os.environ.get("EAS_CONV_DBG", "0")} {name:20s} {t * 1e3:8.1f} us', flush=True)
 
 

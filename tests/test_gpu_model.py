@@ -223,3 +223,52 @@ def test_state_dict_roundtrip_and_writeback_switch(dev):
             ops.set_state_writeback(True)
         functional.reset_net(model)
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)     # MIOpen may pick another conv algorithm on the second call
+
+
+CONFIG_CASES = {
+    # BASELINE.json configs[3]: 1Mpx stacked histogram summed to 2 channels, 3 classes, T=3, Tm=Tl micro-steps (canvas 384x640 scaled /4)
+    'cfg4_1mpx': (dict(depth=0.33, width=0.5, T=3, Tm=2, Ts=1, num_classes=3, use_spike='full_spike_v2'), (1, 1, 2, 2, 96, 160)),
+    # configs[4]: N-Caltech101, 100 classes, T=7, Tm=8 long-sequence adaptive sampling with Ts=T (canvas 192x256 scaled /2)
+    'cfg5_ncaltech_ts7': (dict(depth=0.33, width=0.5, T=7, Tm=8, Ts=7, num_classes=100, use_spike='True', alpha=1.5), (1, 1, 8, 2, 96, 128)),
+    'cfg5_ncaltech_ts1': (dict(depth=0.33, width=0.5, T=7, Tm=8, Ts=1, num_classes=100, use_spike='True'), (2, 1, 8, 2, 64, 64)),
+    # the simpler embeddings in front of the whole model
+    'emb_rsnn': (dict(depth=0.33, width=0.5, T=3, Tm=4, embedding='rsnn', use_spike='True'), (2, 1, 4, 2, 64, 96)),
+    'emb_snn': (dict(depth=0.33, width=0.5, T=3, Tm=4, embedding='snn', use_spike='True'), (2, 1, 4, 2, 64, 96)),
+    'emb_count': (dict(depth=0.33, width=0.5, T=3, Tm=4, embedding='count', use_spike='True'), (2, 1, 4, 2, 64, 96)),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(CONFIG_CASES))
+def test_config_shaped_cases_vs_cpu_oracle(dev, name):
+    """Parity cases shaped like BASELINE.json configs[3], configs[4] (canvases scaled down so the CPU oracle finishes in
+    seconds) and the alternative embeddings: same procedural weights, fresh seeded Poisson event volumes, eval logits of
+    the HIP model against the torch-CPU oracle model within 1e-4 (relative + absolute) for the bulk of the anchors --
+    single rounding-level spike flips are amplified by the spiking backbone, see DESIGN.md section 5."""
+    from oracle import fill, model_ref, sj_ref
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    cfg, shape = CONFIG_CASES[name]
+    H, W = shape[-2:]
+    exp = get_exp(None, 'e-yolox-s')
+    opts = list(BASE_OPTS) + ['input_size', f'({H},{W})', 'test_size', f'({H},{W})']
+    for k, v in cfg.items():
+        if k in ('depth', 'width'):
+            continue
+        if k in [o for o in opts[::2]]:
+            opts[opts.index(k) + 1] = str(v)
+        else:
+            opts += [k, str(v)]
+    exp.merge(opts)
+    hip = exp.get_model()
+    ref = model_ref.build_model(**cfg)
+    rx = fill.ANN_KEYS[cfg['use_spike']]
+    assert fill.procedural_fill_(hip, 2.0, ann_regex=rx) == fill.procedural_fill_(ref, 2.0, ann_regex=rx)
+    x = torch.from_numpy(fill.poisson_events(shape, 0.5, seed=123))
+    ref.eval(); hip.to(dev).eval()
+    with torch.no_grad():
+        lr = ref(x).numpy()
+        lh = hip(x.to(dev)).cpu().numpy()
+    sj_ref.reset_net(ref); functional.reset_net(hip)
+    assert lh.shape == lr.shape
+    assert _frac_close(lh, lr, RTOL, 1e-4) > 0.95, _frac_close(lh, lr, RTOL, 1e-4)
