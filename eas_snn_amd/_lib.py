@@ -21,6 +21,7 @@ PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
     'eas_status_string': (C.c_char_p, [C.c_int]),
     'eas_event_histogram': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    'eas_event_histogram_dat': (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_counts_to_canvas': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_event_voxel_grid': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_lif_fwd': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P, _P, C.c_int, C.c_int64, _P]),

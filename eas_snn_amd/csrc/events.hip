@@ -93,6 +93,54 @@ __global__ __launch_bounds__(EAS_BLOCK) void event_hist_kernel(const uint32_t* _
     }
 }
 
+// Same binning straight from Prophesee .dat records (8 bytes: u32 t, u32 packed with x = bits 0..13, y = bits 14..27,
+// p = bit 28; yolox/utils/psee_loader/io/dat_events_tools.py:24-54): decode + window + histogram in one pass, so the raw
+// file bytes are the only thing that crosses PCIe.  Two records per thread (one 16-byte load) when the buffer is aligned.
+__device__ __forceinline__ SampleWin sample_window_dat(const uint2* __restrict__ rec, const int64_t* __restrict__ offsets, int b, int Tm) {
+    const int64_t a = offsets[b], e = offsets[b + 1];
+    SampleWin w;
+    w.t0 = rec[a].x;
+    w.win = (rec[e - 1].x - w.t0) / (uint32_t)Tm;
+    return w;
+}
+
+__device__ __forceinline__ void bin_dat(uint32_t tt, uint32_t packed, const SampleWin& w, int b, int Tm, int H, int W,
+                                        int32_t* __restrict__ out, uint32_t* __restrict__ oob) {
+    bin_one(tt, packed & 16383u, (packed >> 14) & 16383u, (packed >> 28) & 1u, w, b, Tm, H, W, out, oob);
+}
+
+template <bool VEC2>
+__global__ __launch_bounds__(EAS_BLOCK) void event_hist_dat_kernel(const uint2* __restrict__ rec, int64_t nev,
+                                                                   const int64_t* __restrict__ offsets, int B, int Tm, int H, int W,
+                                                                   int32_t* __restrict__ out, uint32_t* __restrict__ oob) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC2) {
+        const int64_t npairs = nev / 2;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < npairs; g += stride) {
+            const uint4 v = reinterpret_cast<const uint4*>(rec)[g];
+            const int64_t i0 = g * 2;
+            int b = find_sample(offsets, B, i0);
+            SampleWin w = sample_window_dat(rec, offsets, b, Tm);
+            bin_dat(v.x, v.y, w, b, Tm, H, W, out, oob);
+            if (i0 + 1 >= offsets[b + 1]) {           // the pair straddles a sample boundary (also skips empty samples)
+                b = find_sample(offsets, B, i0 + 1);
+                w = sample_window_dat(rec, offsets, b, Tm);
+            }
+            bin_dat(v.z, v.w, w, b, Tm, H, W, out, oob);
+        }
+        if ((nev & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t i = nev - 1;
+            const int b = find_sample(offsets, B, i);
+            bin_dat(rec[i].x, rec[i].y, sample_window_dat(rec, offsets, b, Tm), b, Tm, H, W, out, oob);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += stride) {
+            const int b = find_sample(offsets, B, i);
+            bin_dat(rec[i].x, rec[i].y, sample_window_dat(rec, offsets, b, Tm), b, Tm, H, W, out, oob);
+        }
+    }
+}
+
 __global__ __launch_bounds__(EAS_BLOCK) void counts_to_canvas_kernel(const int32_t* __restrict__ counts, int64_t F, int H,
                                                                      int W, int Hc, int Wc, float* __restrict__ out) {
     const int64_t total = F * Hc * Wc;
@@ -151,6 +199,27 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
         hipLaunchKernelGGL(event_hist_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev,
                            sample_offsets, B, Tm, H, W, out, oob_count);
     }
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_event_histogram_dat(const void* records, int64_t nev, const int64_t* sample_offsets, int B, int Tm, int H, int W,
+                            int32_t* out, uint32_t* oob_count, eas_stream_t stream) {
+    if (!out || !sample_offsets || B < 1 || Tm < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
+    if (nev > 0 && (!records || ((uintptr_t)records & 7))) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    const size_t bytes = (size_t)B * Tm * 2 * H * W * sizeof(int32_t);
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (oob_count && hipMemsetAsync(oob_count, 0, sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (nev == 0) return EAS_OK;
+    const uint2* rec = (const uint2*)records;
+    if (((uintptr_t)records & 15) == 0)
+        hipLaunchKernelGGL(event_hist_dat_kernel<true>, dim3(eas_grid_1d((nev + 1) / 2)), dim3(EAS_BLOCK), 0, st, rec, nev, sample_offsets, B,
+                           Tm, H, W, out, oob_count);
+    else
+        hipLaunchKernelGGL(event_hist_dat_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, rec, nev, sample_offsets, B, Tm, H,
+                           W, out, oob_count);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

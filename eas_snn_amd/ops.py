@@ -324,6 +324,22 @@ def event_histogram(t, x, y, p, sample_offsets, Tm, H, W, return_oob=False):
     return (out, oob) if return_oob else out
 
 
+def event_histogram_dat(records, sample_offsets, Tm, H, W, return_oob=False):
+    """Count frames int32 [B, Tm, 2, H, W] straight from .dat records: ``records`` is the raw byte image of the events
+    (uint8 [8*nev], or any 8-byte-record view) already on the device; decode + binning happen in one kernel."""
+    _dev(records, sample_offsets)
+    assert sample_offsets.dtype == torch.int64
+    rec = records.contiguous().view(torch.uint8)
+    assert rec.numel() % 8 == 0, '.dat event records are 8 bytes'
+    nev = rec.numel() // 8
+    B = sample_offsets.numel() - 1
+    out = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=rec.device)
+    oob = torch.empty(1, dtype=torch.int32, device=rec.device) if return_oob else None
+    _call('eas_event_histogram_dat', 8 * nev + 4 * out.numel(), _lib.lib().eas_event_histogram_dat, ptr(rec), nev, ptr(sample_offsets), B, Tm,
+          H, W, ptr(out), ptr(oob), stream())
+    return (out, oob) if return_oob else out
+
+
 def counts_to_canvas(counts, Hc, Wc):
     """int32 [..., H, W] -> float32 [..., Hc, Wc], zero padded bottom/right."""
     _dev(counts)

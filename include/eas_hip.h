@@ -57,6 +57,12 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
                         const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
                         uint32_t* oob_count, eas_stream_t stream);
 
+/* The same count frames straight from Prophesee .dat event records (8 bytes each: u32 t, u32 packed with x = bits 0..13,
+ * y = bits 14..27, p = bit 28; load_td_data, yolox/utils/psee_loader/io/dat_events_tools.py:29-54): decode, micro-slice
+ * window and histogram in one pass over the raw file bytes after the header.  `records` is 8-byte aligned. */
+int eas_event_histogram_dat(const void* records, int64_t nev, const int64_t* sample_offsets, int B, int Tm, int H, int W,
+                            int32_t* out, uint32_t* oob_count, eas_stream_t stream);
+
 /* int32 counts [F][H][W] -> fp32 canvas [F][Hc][Wc], zero padded bottom/right (top-left placement,
  * as gen1.py:447-455 does with scale 1).  Replaces np.stack + astype + pad + trainer.py:99 cast. */
 int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out,

@@ -118,3 +118,42 @@ def synth_events(n_events, height=240, width=304, t0=1_000_000, span_us=200_000,
     y = rng.integers(0, height, size=n_events, dtype=np.int64).astype(np.uint16)
     p = (rng.random(n_events) < 0.5).astype(np.uint8)
     return t, x, y, p
+
+
+# ----------------------------------------------------------------------------------------- .dat records
+def parse_dat_header(buf):
+    """Offset of the first event record, event type and event size of a Prophesee ``.dat`` file image (bytes).
+    Follows parse_header (yolox/utils/psee_loader/io/dat_events_tools.py:121-175): comment lines start with '% ';
+    if there was at least one, two bytes follow (event type, event size); else type 0 / size 8."""
+    pos, ncomment = 0, 0
+    while True:
+        end = buf.find(b'\n', pos)
+        line = buf[pos:] if end < 0 else buf[pos:end + 1]
+        if line[:2] != b'% ':
+            break
+        ncomment += 1
+        pos = end + 1
+    if ncomment > 0:
+        return pos + 2, int(buf[pos]), int(buf[pos + 1])
+    return pos, 0, 8
+
+
+def decode_dat_records(rec):
+    """rec: uint32 [nev, 2] little-endian (t, packed) -> (t u4, x u2, y u2, p u1).
+    Follows load_td_data (dat_events_tools.py:44-54): x = bits 0..13, y = bits 14..27, p = bit 28 of the second word."""
+    rec = np.asarray(rec, dtype=np.uint32).reshape(-1, 2)
+    packed = rec[:, 1].astype(np.int64)
+    x = np.bitwise_and(packed, 16383)
+    y = np.right_shift(np.bitwise_and(packed, 268419072), 14)
+    pp = np.right_shift(np.bitwise_and(packed, 268435456), 28)
+    return rec[:, 0].copy(), x.astype(np.uint16), y.astype(np.uint16), pp.astype(np.uint8)
+
+
+def encode_dat_file(t, x, y, p, height=240, width=304):
+    """A ``.dat`` file image (header + 8-byte records) for synthetic events -- test input only."""
+    head = ('% Data file containing Event2D events.\n% Version 2\n% Date 2024-1-1 0:0:0\n'
+            f'% Height {height}\n% Width {width}\n').encode('latin-1')
+    rec = np.empty((len(t), 2), dtype='<u4')
+    rec[:, 0] = t
+    rec[:, 1] = (np.asarray(x, np.uint32) & 16383) | ((np.asarray(y, np.uint32) & 16383) << 14) | ((np.asarray(p, np.uint32) & 1) << 28)
+    return head + bytes([0, 8]) + rec.tobytes()

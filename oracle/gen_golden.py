@@ -161,6 +161,28 @@ def gen_events():
             flat[f'{name}/{k}'] = np.asarray(v)
     save('events_voxel_grid', names=np.array(sorted(vox)), **flat)
 
+    # .dat records decoded by the reference's own reader (psee_loader/io/dat_events_tools.py), then binned by GEN1Dataset
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_dat_tools', os.path.join(REF, 'yolox/utils/psee_loader/io/dat_events_tools.py'))
+    dat_tools = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dat_tools)
+    from oracle.events_ref import encode_dat_file
+    t, x, y, p = synth_events(6000, 240, 304, seed=31)
+    x[100:107] = 16383                 # 14-bit extremes in mid-stream (first/last event define the slicing window); bits above bit 28 are ignored
+    image = bytearray(encode_dat_file(t, x, y, p))
+    body = len(image) - 8 * len(t)
+    for i in (3, 11, 200):
+        image[body + 8 * i + 7] |= 0xE0
+    with tempfile.NamedTemporaryFile(suffix='.dat', delete=False) as fh:
+        fh.write(bytes(image))
+        path = fh.name
+    ev = dat_tools.load_td_data(path)
+    os.unlink(path)
+    inside = (ev['x'] < 304) & (ev['y'] < 240)
+    ms = ref_micro_sum(ev['t'][inside], ev['x'][inside], ev['y'][inside], ev['p'][inside].astype('u1'), 4, 240, 304)
+    save('events_dat', file_image=np.frombuffer(bytes(image), dtype=np.uint8), t=ev['t'], x=ev['x'], y=ev['y'], p=ev['p'],
+         micro_sum=ms.astype(np.int32), oob=np.int64((~inside).sum()))
+
 
 # ----------------------------------------------------------------------------- a5/a7 embeddings
 def gen_embeddings():

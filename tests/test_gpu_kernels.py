@@ -509,3 +509,34 @@ def test_simple_embeddings_golden(dev, kind, ro):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=1e-3, atol=1e-4)
     for n, p in m.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=2e-3, atol=2e-3, err_msg=n)
+
+
+@pytest.mark.gpu
+def test_event_histogram_from_dat_records(dev):
+    """.dat records -> count frames in one kernel: bit-exact against the reference's reader + binning (golden), against
+    the struct-of-arrays kernel on a ragged batch (empty sample, odd counts, unaligned record buffer), and the
+    out-of-sensor counter."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    g = load_golden('events_dat')
+    image = g['file_image'].tobytes()
+    start, _, _ = events_ref.parse_dat_header(image)
+    body = np.frombuffer(image[start:], dtype=np.uint8).copy()
+    rec = torch.from_numpy(body).to(dev)
+    offs = torch.tensor([0, len(g['t'])], dtype=torch.int64, device=dev)
+    out, oob = ops.event_histogram_dat(rec, offs, 4, 240, 304, return_oob=True)
+    assert np.array_equal(out[0].cpu().numpy(), g['micro_sum']) and int(oob) == int(g['oob'])
+    # ragged batch vs the SoA kernel (which is itself pinned to the reference)
+    streams = [events_ref.synth_events(n, 60, 76, seed=40 + i) for i, n in enumerate((1001, 0, 3, 2500, 1))]
+    t = np.concatenate([s[0] for s in streams]); x = np.concatenate([s[1] for s in streams])
+    y = np.concatenate([s[2] for s in streams]); p = np.concatenate([s[3] for s in streams])
+    offsets = np.cumsum([0] + [len(s[0]) for s in streams]).astype(np.int64)
+    want = ops.event_histogram(torch.from_numpy(t).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev),
+                               torch.from_numpy(p).to(dev), torch.from_numpy(offsets).to(dev), 4, 60, 76)
+    raw = events_ref.encode_dat_file(t, x, y, p, 60, 76)
+    raw = np.frombuffer(raw[events_ref.parse_dat_header(raw)[0]:], dtype=np.uint8)
+    for shift in (0, 8):                               # 16-byte aligned and only 8-byte aligned record buffers
+        buf = torch.zeros(len(raw) + shift, dtype=torch.uint8, device=dev)
+        buf[shift:] = torch.from_numpy(raw.copy()).to(dev)
+        got = ops.event_histogram_dat(buf[shift:], torch.from_numpy(offsets).to(dev), 4, 60, 76)
+        assert torch.equal(got, want)
