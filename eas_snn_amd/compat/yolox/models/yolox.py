@@ -43,6 +43,8 @@ class YOLOX(nn.Module):
         self.head = YOLOXHead(80) if head is None else head
 
     def forward(self, x, targets=None):
+        if x.is_cuda:
+            ops.prepack_conv_weights(self)        # one launch for all conv weights (no-op while they are unchanged)
         with ops.deferred_counters():
             x = _run_embedding(self.embedding, x, 4)
             return _head_outputs(self, self.backbone(x), targets, x)
@@ -57,6 +59,8 @@ class SpikingYOLOX(nn.Module):
         self.head = SpikingYOLOXHead(80) if head is None else head
 
     def forward(self, x, targets=None):
+        if x.is_cuda:
+            ops.prepack_conv_weights(self)        # one launch for all conv weights (no-op while they are unchanged)
         with ops.deferred_counters():
             return self._forward(x, targets)
 

@@ -55,34 +55,32 @@ __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16&
 // weights [Cout][Cin][KS][KS] fp32 -> A fragments: wp[term][mt][kstep][tap][lane] (8 bf16 each)
 //   mode 0 (forward):        M = Cout, K = Cin :  A[m][k][tap] = w[m][k][tap]
 //   mode 1 (input gradient): M = Cin,  K = Cout:  A[m][k][tap] = w[k][m][TAPS-1-tap]      (transposed + flipped)
-__global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, int TAPS, int mode) {
+__device__ __forceinline__ void pack_fragment(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, int TAPS, int mode,
+                                              int idx, int total) {
     const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
-    const int MT = (M + 31) / 32, KSTEPS = (K + 15) / 16;
-    const int total = MT * KSTEPS * TAPS * 64;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63;
-        int rest = idx >> 6;
-        const int tap = rest % TAPS;
-        rest /= TAPS;
-        const int ks = rest % KSTEPS;
-        const int mt = rest / KSTEPS;
-        const int m = mt * 32 + (lane & 31);
-        bf16x8 t0, t1, t2;
+    const int KSTEPS = (K + 15) / 16;
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int tap = rest % TAPS;
+    rest /= TAPS;
+    const int ks = rest % KSTEPS;
+    const int mt = rest / KSTEPS;
+    const int m = mt * 32 + (lane & 31);
+    bf16x8 t0, t1, t2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = ks * 16 + 8 * (lane >> 5) + j;
-            float v = 0.0f;
-            if (m < M && k < K) v = mode ? w[((size_t)k * Cin + m) * TAPS + (TAPS - 1 - tap)] : w[((size_t)m * Cin + k) * TAPS + tap];
-            __bf16 a, b, c;
-            split3(v, a, b, c);
-            t0[j] = a;
-            t1[j] = b;
-            t2[j] = c;
-        }
-        wp[idx] = t0;
-        wp[(size_t)total + idx] = t1;
-        wp[(size_t)2 * total + idx] = t2;
+    for (int j = 0; j < 8; ++j) {
+        const int k = ks * 16 + 8 * (lane >> 5) + j;
+        float v = 0.0f;
+        if (m < M && k < K) v = mode ? w[((size_t)k * Cin + m) * TAPS + (TAPS - 1 - tap)] : w[((size_t)m * Cin + k) * TAPS + tap];
+        __bf16 a, b, c;
+        split3(v, a, b, c);
+        t0[j] = a;
+        t1[j] = b;
+        t2[j] = c;
     }
+    wp[idx] = t0;
+    wp[(size_t)total + idx] = t1;
+    wp[(size_t)2 * total + idx] = t2;
 }
 
 // Input gradient of a stride-2 3x3 convolution (padding 1), by output-pixel parity class (ph, pw): grad_x[2a+ph][2b+pw]
@@ -90,40 +88,63 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16x8* __
 //   ph = 0: kh = 1 reads grad_y row a ;  ph = 1: kh = 2 reads row a (dh = 0), kh = 0 reads row a+1 (dh = 1); same for columns.
 // Packed: class c = 2*ph+pw at bf16x8 offset 3*MT*KSTEPS*64*{0,1,3,5}[c], inside [term][mt][kstep][local tap = ih*(pw+1)+iw][lane];
 // A[m = ci][k = co][tap] = w[co][ci][kh][kw].
-__global__ void conv_pack_weights_s2dgrad_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin) {
+__device__ __forceinline__ void pack_fragment_s2dgrad(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, int idx) {
     const int M = Cin, K = Cout;
     const int MT = (M + 31) / 32, KSTEPS = (K + 15) / 16;
-    const int total = MT * KSTEPS * 9 * 64;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63;
-        int rest = idx >> 6;
-        const int tap9 = rest % 9;
-        rest /= 9;
-        const int ks = rest % KSTEPS;
-        const int mt = rest / KSTEPS;
-        const int kh = tap9 / 3, kw = tap9 - kh * 3;
-        const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
-        const int ih = kh == 0 ? 1 : 0, iw = kw == 0 ? 1 : 0;
-        const int cls = 2 * ph + pw, ntap = (ph + 1) * (pw + 1), lt = ih * (pw + 1) + iw;
-        const int cum = cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5));
-        const size_t base = (size_t)3 * MT * KSTEPS * 64 * cum;
-        const size_t term = (size_t)MT * KSTEPS * ntap * 64;
-        const size_t pos = (((size_t)mt * KSTEPS + ks) * ntap + lt) * 64 + lane;
-        const int m = mt * 32 + (lane & 31);
-        bf16x8 t0, t1, t2;
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int tap9 = rest % 9;
+    rest /= 9;
+    const int ks = rest % KSTEPS;
+    const int mt = rest / KSTEPS;
+    const int kh = tap9 / 3, kw = tap9 - kh * 3;
+    const int ph = kh == 1 ? 0 : 1, pw = kw == 1 ? 0 : 1;
+    const int ih = kh == 0 ? 1 : 0, iw = kw == 0 ? 1 : 0;
+    const int cls = 2 * ph + pw, ntap = (ph + 1) * (pw + 1), lt = ih * (pw + 1) + iw;
+    const int cum = cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5));
+    const size_t base = (size_t)3 * MT * KSTEPS * 64 * cum;
+    const size_t term = (size_t)MT * KSTEPS * ntap * 64;
+    const size_t pos = (((size_t)mt * KSTEPS + ks) * ntap + lt) * 64 + lane;
+    const int m = mt * 32 + (lane & 31);
+    bf16x8 t0, t1, t2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = ks * 16 + 8 * (lane >> 5) + j;
-            const float v = (m < M && k < K) ? w[((size_t)k * Cin + m) * 9 + tap9] : 0.0f;
-            __bf16 a, b, c;
-            split3(v, a, b, c);
-            t0[j] = a;
-            t1[j] = b;
-            t2[j] = c;
-        }
-        wp[base + pos] = t0;
-        wp[base + term + pos] = t1;
-        wp[base + 2 * term + pos] = t2;
+    for (int j = 0; j < 8; ++j) {
+        const int k = ks * 16 + 8 * (lane >> 5) + j;
+        const float v = (m < M && k < K) ? w[((size_t)k * Cin + m) * 9 + tap9] : 0.0f;
+        __bf16 a, b, c;
+        split3(v, a, b, c);
+        t0[j] = a;
+        t1[j] = b;
+        t2[j] = c;
+    }
+    wp[base + pos] = t0;
+    wp[base + term + pos] = t1;
+    wp[base + 2 * term + pos] = t2;
+}
+
+__device__ __forceinline__ int pack_total(int Cout, int Cin, int ksize, int mode) {
+    const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    return ((M + 31) / 32) * ((K + 15) / 16) * ksize * ksize * 64;
+}
+
+__global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, int ksize, int mode) {
+    const int total = pack_total(Cout, Cin, ksize, mode);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        if (mode == 2) pack_fragment_s2dgrad(w, wp, Cout, Cin, idx);
+        else pack_fragment(w, wp, Cout, Cin, ksize * ksize, mode, idx, total);
+    }
+}
+
+// every weight tensor of a model in ONE launch (blockIdx.y = job): a job is six int64 {w, packed, Cout, Cin, ksize, mode}
+__global__ void conv_pack_weights_many_kernel(const long long* __restrict__ jobs) {
+    const long long* j = jobs + (size_t)blockIdx.y * 6;
+    const float* w = (const float*)j[0];
+    bf16x8* wp = (bf16x8*)j[1];
+    const int Cout = (int)j[2], Cin = (int)j[3], ksize = (int)j[4], mode = (int)j[5];
+    const int total = pack_total(Cout, Cin, ksize, mode);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        if (mode == 2) pack_fragment_s2dgrad(w, wp, Cout, Cin, idx);
+        else pack_fragment(w, wp, Cout, Cin, ksize * ksize, mode, idx, total);
     }
 }
 
@@ -458,11 +479,18 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
     EAS_CLEAR_ERR();
     const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
     const int total = ((M + 31) / 32) * ((K + 15) / 16) * ksize * ksize * 64;
-    if (mode == 2)
-        hipLaunchKernelGGL(conv_pack_weights_s2dgrad_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin);
-    else
-        hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin,
-                           ksize * ksize, mode);
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin, ksize,
+                       mode);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// jobs: device array of njobs x 6 int64 {weight pointer, packed pointer, Cout, Cin, ksize, mode}; one launch packs them all
+// (the weights of a model only change at the optimizer step, so a training step needs this once)
+int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream) {
+    if (!jobs || njobs < 1) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(conv_pack_weights_many_kernel, dim3(24, njobs), dim3(EAS_BLOCK), 0, eas_s(stream), (const long long*)jobs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

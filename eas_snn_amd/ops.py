@@ -681,18 +681,22 @@ def conv_eligible(x, conv):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, x_terms):
+    def forward(ctx, x, w, bias, stride, x_terms, packs):
+        """packs: {mode: packed weights} valid for the current version of ``w`` (prepack_conv_weights), or None."""
         _dev(x, w, bias)
         k, Cout = w.shape[-1], w.shape[0]
-        y = conv_fwd_packed(x, conv_pack_weights(w, 0), bias, Cout, k, stride, x_terms)
+        pk = packs[0] if packs and 0 in packs else conv_pack_weights(w, 0)
+        y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms)
         ctx.save_for_backward(x, w)
         ctx.cfg = (k, stride, x_terms, bias is not None)
+        ctx.packs = packs if packs and getattr(w, '_version', None) == packs.get('version') else None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         k, stride, x_terms, has_bias = ctx.cfg
+        packs = ctx.packs if ctx.packs and w._version == ctx.packs.get('version') else None
         gy = _f32c(gy)
         gx = gw = gb = None
         Cin = w.shape[1]
@@ -703,11 +707,13 @@ class _ConvFn(torch.autograd.Function):
         own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and CONV_POLICY['dgrad3'] == 'mfma' and w.shape[0] % 8 == 0
                   and gy.shape[-1] % 2 == 0)
         if own_d:
-            gx = conv_fwd_packed(gy, conv_pack_weights(w, 1), None, Cin, k, 1, 3)
+            pk = packs[1] if packs and 1 in packs else conv_pack_weights(w, 1)
+            gx = conv_fwd_packed(gy, pk, None, Cin, k, 1, 3)
         elif own_d2:
             gx = torch.empty_like(x)
             fl = 2.0 * gy.numel() * Cin * 9
-            _call('eas_conv_fwd', 4 * (x.numel() + gy.numel()), _lib.lib().eas_conv_dgrad_s2, ptr(gy), ptr(conv_pack_weights(w, 2)), ptr(gx),
+            pk = packs[2] if packs and 2 in packs else conv_pack_weights(w, 2)
+            _call('eas_conv_fwd', 4 * (x.numel() + gy.numel()), _lib.lib().eas_conv_dgrad_s2, ptr(gy), ptr(pk), ptr(gx),
                   x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stream(), flops=fl, issue_flops=6 * fl)
             own_d = True
         if own_w:
@@ -721,7 +727,51 @@ class _ConvFn(torch.autograd.Function):
             gw = rw if need_w else gw
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
+
+
+def _static_conv_ok(conv):
+    if type(conv) is not torch.nn.Conv2d:
+        return False
+    k = conv.kernel_size[0]
+    return (conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size in ((1, 1), (3, 3))
+            and conv.stride in ((1, 1), (2, 2)) and conv.padding == (k // 2, k // 2) and conv.padding_mode == 'zeros'
+            and conv.in_channels % 8 == 0 and not (k == 1 and conv.stride != (1, 1)))
+
+
+def prepack_conv_weights(model):
+    """Pack the weights of every eligible nn.Conv2d of ``model`` for the matrix-core kernels in ONE launch
+    (eas_conv_pack_weights_many): forward order, plus the transposed orders the input gradients need.  Cheap to call at
+    the start of every forward: it returns at once while no weight has changed since the last packing (tensor version
+    counters), and repacks everything after an optimizer step.  Convolutions then find their packed weights in
+    ``conv._eas_packs`` instead of launching one tiny packing kernel each (111 launches per training step)."""
+    plan = getattr(model, '_eas_pack_plan', None)
+    convs = plan['convs'] if plan else [m for m in model.modules() if _static_conv_ok(m) and m.weight.is_cuda]
+    if not convs:
+        return
+    sig = tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
+    if plan and plan['sig'] == sig:
+        return
+    L = _lib.lib()
+    if not plan or plan['ptrs'] != tuple(p for p, _ in sig):
+        jobs, packs = [], []
+        dev = convs[0].weight.device
+        for c in convs:
+            k, Cout, Cin = c.kernel_size[0], c.out_channels, c.in_channels
+            modes = [0] + ([1] if c.stride == (1, 1) and Cout % 8 == 0 else []) + ([2] if c.stride == (2, 2) and k == 3 and Cout % 8 == 0 else [])
+            d = {}
+            for m in modes:
+                d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)
+                jobs.append([c.weight.data_ptr(), d[m].data_ptr(), Cout, Cin, k, m])
+            packs.append(d)
+        plan = {'convs': convs, 'packs': packs, 'ptrs': tuple(p for p, _ in sig), 'njobs': len(jobs),
+                'jobs': torch.tensor(jobs, dtype=torch.int64).to(dev)}
+        object.__setattr__(model, '_eas_pack_plan', plan)
+    check(L.eas_conv_pack_weights_many(ptr(plan['jobs']), plan['njobs'], stream()), 'eas_conv_pack_weights_many')
+    plan['sig'] = sig
+    for c, d in zip(convs, plan['packs']):
+        d['version'] = c.weight._version
+        object.__setattr__(c, '_eas_packs', d)
 
 
 def conv2d(x, conv, small_int=None):
@@ -732,7 +782,10 @@ def conv2d(x, conv, small_int=None):
         small_int = is_small_int(x)
     if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
         raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
-    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3)
+    packs = getattr(conv, '_eas_packs', None)
+    if packs is not None and packs.get('version') != conv.weight._version:
+        packs = None
+    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs)
 
 
 # ------------------------------------------------------------------------------------------------ SPP pooling block

@@ -215,6 +215,9 @@ int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k);
  *     weights packed in mode 1, x_terms = 3. */
 int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode);
 int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int ksize, int mode, eas_stream_t stream);
+/* the same for many weight tensors in one launch: `jobs` is a device array of njobs x 6 int64
+ * {weight pointer, packed pointer, Cout, Cin, ksize, mode} */
+int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
 /* Input gradient of a stride-2 3x3 convolution: grad_x[NI][Cin][Hi][Wi] from grad_y[NI][Cout][Ho][Wo] and the weights
