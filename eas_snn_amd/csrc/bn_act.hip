@@ -37,9 +37,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
     const float shift = beta[c] - mean[c] * scale;
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = g / hw4;
-        const int q = (int)(g - n * hw4);
+    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        const int64_t n = gw.n;
+        const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         const float4 v = *reinterpret_cast<const float4*>(y + base);
         float4 o;
@@ -88,9 +89,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
         if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
     }
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = g / hw4;
-        const int q = (int)(g - n * hw4);
+    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        const int64_t n = gw.n;
+        const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         const float4 yv = *reinterpret_cast<const float4*>(y + base);
         const float4 gv = *reinterpret_cast<const float4*>(grad_out + base);

@@ -36,9 +36,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial(const float* __res
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)TN * hw4;
     double s = 0.0, ss = 0.0;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = g / hw4;
-        const int q = (int)(g - n * hw4);
+    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        const int64_t n = gw.n;
+        const int q = gw.q;
         const float4 v = reinterpret_cast<const float4*>(y + ((n * C + c) * (int64_t)HW))[q];
         s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
         ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -117,9 +118,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
     const int64_t groups = (int64_t)N * hw4;
     const int64_t M = (int64_t)N * C * HW;
     const int64_t yts = bcast ? 0 : M;       // T identical input frames: one plane stands for all steps
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = g / hw4;
-        const int q = (int)(g - n * hw4);
+    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        const int64_t n = gw.n;
+        const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         float4 ys[T_];
 #pragma unroll
@@ -217,9 +219,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
     }
     float s1 = 0.f, s2 = 0.f, dk = 0.f;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = g / hw4;
-        const int q = (int)(g - n * hw4);
+    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        const int64_t n = gw.n;
+        const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         float4 ys[T_], gsv[T_];
 #pragma unroll

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     constexpr int NSTEPS = (CCH / 16) * TAPS;
     constexpr int NT = 64 * WVM * WVN;   // threads; NIT = staging items per thread per chunk (upper bound, surplus skipped block-uniformly)
     constexpr bool SPREAD = NSTEPS >= 2 * NIT;   // commit item i after step NSTEPS-NIT+i, else after the last step
+    constexpr bool BPF = XT == 1 && NSTEPS > 1;   // B-fragment prefetch one step ahead
     static_assert(WVM * WVN == 4 || WVM * WVN == 8, "4 or 8 waves per block");
     static_assert(CCH % 16 == 0, "ci chunk is a multiple of the MFMA k");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
 
     const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
     int st = 0;
+    bf16x8 b_nxt[WN];
     for (int c = 0; c < nchunks; ++c) {
         const unsigned char* cur = smem + (c & 1) * buf_bytes;
         unsigned char* nxt = smem + ((c + 1) & 1) * buf_bytes;
@@ -325,12 +327,30 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
             // keep the prefetch loads (next step's weights, the next patch) ahead of this step's MFMAs: without the fence
             // the scheduler sinks them behind the last use of the registers they would share
             __builtin_amdgcn_sched_barrier(0);
-            const int toff = g.tap_off[tap] * PIXB + kk * 32;
+            // B fragments of this step; with spike inputs (one term, 20 registers) the NEXT step's fragments are requested
+            // before this step's MFMAs so that the LDS latency is off the critical path (first step of a chunk excepted)
             bf16x8 b[WN][XT];
+            if constexpr (BPF) {
+                if (s == 0) {
+                    const int toff0 = g.tap_off[0] * PIXB;
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+                    for (int j = 0; j < WN; ++j) b_nxt[j] = *(const bf16x8*)(cur + qoff[j] + toff0);
+                }
 #pragma unroll
-                for (int t = 0; t < XT; ++t) b[j][t] = *(const bf16x8*)(cur + t * term_stride + ((g.dbg & 8) ? (lane * 16) : (qoff[j] + toff)));
+                for (int j = 0; j < WN; ++j) b[j][0] = b_nxt[j];
+                if (s + 1 < NSTEPS) {
+                    const int kk1 = (s + 1) / TAPS, tap1 = (s + 1) - kk1 * TAPS;
+                    const int toff1 = g.tap_off[tap1] * PIXB + kk1 * 32;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) b_nxt[j] = *(const bf16x8*)(cur + qoff[j] + toff1);
+                }
+            } else {
+                const int toff = g.tap_off[tap] * PIXB + kk * 32;
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int t = 0; t < XT; ++t) b[j][t] = *(const bf16x8*)(cur + t * term_stride + qoff[j] + toff);
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll

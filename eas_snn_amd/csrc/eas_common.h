@@ -66,6 +66,25 @@ __device__ __forceinline__ T eas_block_sum(T v, T* smem) {
     return r;
 }
 
+// (image, float4-group-in-plane) of group index g0 and its advance by `stride` groups, without a 64-bit division per group
+struct GroupWalk {
+    int n, q, dn, dq, hw4;
+    __device__ __forceinline__ GroupWalk(int64_t g0, int64_t stride, int hw4_) : hw4(hw4_) {
+        n = (int)(g0 / hw4_);
+        q = (int)(g0 - (int64_t)n * hw4_);
+        dn = (int)(stride / hw4_);
+        dq = (int)(stride - (int64_t)dn * hw4_);
+    }
+    __device__ __forceinline__ void next() {
+        n += dn;
+        q += dq;
+        if (q >= hw4) {
+            q -= hw4;
+            ++n;
+        }
+    }
+};
+
 struct EasLifParams {
     const float* w_logit;  // PLIF: k = sigmoid(*w_logit); else k_const
     float k_const;
