@@ -62,8 +62,8 @@ OPTS = ['T', '3', 'Tm', '4', 'embedding', 'arsnn', 'num_classes', '2', 'spike_at
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='samples per GPU')
     ap.add_argument('--events', type=int, default=200_000, help='events per sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -131,6 +131,10 @@ def main():
         dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
     assert world == args.gpus or world == 1, f'launched {world} ranks for --gpus {args.gpus}'
 
+    # everything runs on one non-default stream: autograd's AccumulateGrad nodes remember the stream they were created on,
+    # and a later graph capture breaks if that was the default stream
+    torch.cuda.set_stream(torch.cuda.Stream())
+
     import eas_snn_amd
     from eas_snn_amd import data, ops
     from spikingjelly.activation_based import functional
@@ -160,30 +164,38 @@ def main():
         functional.reset_net(model)
         return out['total_loss']
 
-    # The step has no host synchronisation, so it can be captured once into a HIP graph and replayed (EAS_BENCH_GRAPH=1,
-    # single GPU).  Measured on MI355X the eager launches are as fast or faster (36.9 vs 38.1 ms/step: the host enqueues a
-    # step in 21-27 ms, well ahead of the GPU, and graph nodes add a little per-kernel cost), so eager is the default for
-    # every N and the graph path stays as an option for slower hosts.
-    use_graph = world == 1 and not force_ddp and os.environ.get('EAS_BENCH_GRAPH', '0') == '1'
+    # Launch mode.  The step has no host synchronisation, so on a single GPU it can be captured once into a HIP graph and
+    # replayed.  Eager launches are a little faster while the host stays ahead of the GPU (quiet host: a step is enqueued in
+    # 21-27 ms against the ~37 ms the GPU needs; graph nodes add ~1 ms of per-kernel cost) and slower once it does not.  So the
+    # last two warm-up steps measure how long the host needs to enqueue a step; if that is more than 85 % of the step time the
+    # timed region replays the graph, otherwise it launches eagerly (EAS_BENCH_GRAPH=0/1 forces eager/graph).  Multi-GPU
+    # runs stay eager (DDP's reducer + RCCL inside a captured graph cannot be tested on the one-GPU box).
+    mode = os.environ.get('EAS_BENCH_GRAPH', 'auto')
+    for _ in range(max(args.warmup - 2, 1)):
+        loss = step()
+    torch.cuda.synchronize()
+    t_a = time.perf_counter()
+    step()
+    loss = step()
+    t_enq = time.perf_counter() - t_a
+    torch.cuda.synchronize()
+    t_tot = time.perf_counter() - t_a
+    host_bound = t_enq > 0.85 * t_tot
     graph = None
-    if use_graph:
+    if world == 1 and not force_ddp and (mode == '1' or (mode == 'auto' and host_bound)):
         for gr in opt.param_groups:
             gr['capturable'] = True
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(args.warmup - 1, 2)):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
+        for st_ in opt.state.values():         # Adam's step counters live on the host in eager mode; a captured step needs them on the device
+            if torch.is_tensor(st_.get('step')):
+                st_['step'] = st_['step'].to(dev)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = step()
-        graph.replay()                       # last warm-up step
-        run = graph.replay
-    else:
-        for _ in range(args.warmup):
-            loss = step()
-        run = step
+        graph.replay()                       # warm-up replay
+    run = graph.replay if graph is not None else step
     timer = ops.KernelTimer() if rank == 0 else None
     torch.cuda.synchronize()
     if world > 1:
@@ -257,7 +269,8 @@ def main():
                 'config': {'workload': 'SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, batch 64/GPU, '
                                        'raw events -> histogram -> fwd + bwd + Adam + reset_net',
                            'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}',
-                           'launch': 'hip-graph replay of the whole step' if graph is not None else 'eager'},
+                           'launch': 'hip-graph replay of the whole step' if graph is not None else 'eager launches',
+                           'host_enqueue_share_of_step': round(t_enq / t_tot, 3)},
                 'roofline': roofline}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.events)
