@@ -775,7 +775,11 @@ def prepack_conv_weights(model):
 
 
 def conv2d(x, conv, small_int=None):
-    """``conv(x)`` for an ``nn.Conv2d`` on the matrix-core kernels where eligible (else ATen/MIOpen)."""
+    """``conv(x)`` for an ``nn.Conv2d`` on the matrix-core kernels where eligible (else ATen/MIOpen).
+    A module that carries forward hooks (RecordHook in energy_estimation, event_evaluator.py:519-523; thop in
+    get_model_info) is called the ordinary way so that the hooks fire."""
+    if conv._forward_hooks or conv._forward_pre_hooks or torch.nn.modules.module._global_forward_hooks:
+        return conv(x)
     if not conv_eligible(x, conv):
         return conv._conv_forward(x, conv.weight, conv.bias)
     if small_int is None:

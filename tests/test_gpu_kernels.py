@@ -540,3 +540,20 @@ def test_event_histogram_from_dat_records(dev):
         buf[shift:] = torch.from_numpy(raw.copy()).to(dev)
         got = ops.event_histogram_dat(buf[shift:], torch.from_numpy(offsets).to(dev), 4, 60, 76)
         assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_conv_forward_hooks_still_fire(dev):
+    """energy_estimation (event_evaluator.py:519-523) records conv inputs with forward hooks: a hooked nn.Conv2d is called
+    the ordinary way, an un-hooked one goes to the matrix-core kernel; both give the same result."""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    conv = nn.Conv2d(16, 32, 3, 1, 1, bias=False).to(dev)
+    x = torch.randint(0, 2, (2, 16, 8, 10)).float().to(dev)
+    y0 = ops.conv2d(x, conv, small_int=True)
+    seen = []
+    h = conv.register_forward_hook(lambda m, i, o: seen.append(i[0].shape))
+    y1 = ops.conv2d(x, conv, small_int=True)
+    h.remove()
+    assert seen == [x.shape]
+    np.testing.assert_allclose(y0.detach().cpu().numpy(), y1.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
