@@ -12,6 +12,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// loads of lanes without a pixel / channel groups past Cin read these zeros (stride 0) instead of being masked
+__device__ __attribute__((aligned(32))) float eas_c1_zero_page[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 struct C1Geom {
     int NI, Cin, Cout, HW;
     int tiles_per_img, total_tiles;   // 32-pixel tiles
@@ -74,13 +77,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         ap[m] = wp + (size_t)mt * g.KSTEPS * 64 + lane;
     }
 
-    // raw x of k-step ks: 8 channels (ks*16 + 8h + j) of this lane's pixel per N-tile; unconditional clamped loads
+    // raw x of k-step ks: 8 channels (ks*16 + 8h + j) of this lane's pixel per N-tile.  Lanes without a pixel and channel
+    // groups past Cin (Cin % 8 == 0) read the zero page with stride 0: unconditional loads, no per-element masking
     auto fetch = [&](float (&raw)[WN][8], int ks) {
+        const bool ch_ok = ks * 16 + 8 * h < g.Cin;
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
-            const float* src = x + (xoff[n] >= 0 ? xoff[n] : 8L * h * g.HW) + (long)ks * 16 * g.HW;
+            const bool ok = ch_ok && xoff[n] >= 0;
+            const float* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : eas_c1_zero_page;
+            const long cs = ok ? (long)g.HW : 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) raw[n][j] = src[(long)j * g.HW];
+            for (int j = 0; j < 8; ++j) raw[n][j] = src[j * cs];
         }
     };
     auto step = [&](float (&raw)[WN][8], int ks) {
@@ -91,12 +98,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
             for (int t = 0; t < 3; ++t) a[m][t] = ap[m][t * a_term + (size_t)ks * 64];
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
-            const bool ok = xoff[n] >= 0;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (ok && ks * 16 + 8 * h + j < g.Cin) ? raw[n][j] : 0.0f;
             bf16x8 b[XT];
-            to_terms<XT>(v, b);
+            to_terms<XT>(raw[n], b);
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
                 if constexpr (XT == 1) {
@@ -129,16 +132,34 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     }
     if (ks < g.KSTEPS) step(r0, ks);
 
+    // lean epilogue: one pointer per (M-tile, pixel tile), rows by multiples of the channel stride, bias once per M-tile,
+    // per-element channel check only for a ragged last M-tile
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         if (mt0 + m >= g.MT) continue;
+        const int co0 = (mt0 + m) * 32 + 4 * h;
+        const bool full = (mt0 + m) * 32 + 32 <= g.Cout;
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (e & 3) + 8 * (e >> 2);
+                bv[e] = co < g.Cout ? bias[co] : 0.0f;
+            }
+        }
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             if (yoff[n] < 0) continue;
+            float* yp = y + yoff[n] + (long)co0 * g.HW;
+            if (full) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = (mt0 + m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < g.Cout) y[yoff[n] + (long)co * g.HW] = acc[m][n][e] + (bias ? bias[co] : 0.0f);
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
             }
         }
     }
@@ -219,29 +240,31 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(const float* __re
     const int ks_begin = blockIdx.x * g.per_slice;
     const int ks_end = ks_begin + g.per_slice < g.total_ksteps ? ks_begin + g.per_slice : g.total_ksteps;
 
+    // rows past Cout / Cin read the zero page (no offsets added): unconditional loads, no masking of the values
     auto fetch = [&](f32x4 (&ra)[2], f32x4 (&rb)[WN][2], int ks) {
         const int img = ks / g.ksteps_img, p0 = (ks - img * g.ksteps_img) * 16;
-        const float* pa = gy + (long)img * g.Cout * g.HW + a_row + p0;
+        const float* pa = co_ok ? gy + (long)img * g.Cout * g.HW + a_row + p0 : eas_c1_zero_page;
         ra[0] = *(const f32x4*)pa;
         ra[1] = *(const f32x4*)(pa + 4);
         const float* pb = x + (long)img * g.Cin * g.HW + p0;
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
-            rb[n][0] = *(const f32x4*)(pb + b_row[n]);
-            rb[n][1] = *(const f32x4*)(pb + b_row[n] + 4);
+            const float* q = ci_ok[n] ? pb + b_row[n] : eas_c1_zero_page;
+            rb[n][0] = *(const f32x4*)q;
+            rb[n][1] = *(const f32x4*)(q + 4);
         }
     };
     auto step = [&](f32x4 (&ra)[2], f32x4 (&rb)[WN][2]) {
         float va[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) va[j] = co_ok ? ra[j >> 2][j & 3] : 0.0f;
+        for (int j = 0; j < 8; ++j) va[j] = ra[j >> 2][j & 3];
         bf16x8 a[3];
         to_terms<3>(va, a);
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             float vb[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vb[j] = ci_ok[n] ? rb[n][j >> 2][j & 3] : 0.0f;
+            for (int j = 0; j < 8; ++j) vb[j] = rb[n][j >> 2][j & 3];
             bf16x8 b[XT];
             to_terms<XT>(vb, b);
             if constexpr (XT == 1) {
@@ -277,10 +300,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(const float* __re
     for (int n = 0; n < WN; ++n) {
         const int ci = ci0 + 32 * n + r;
         if (ci >= g.Cin) continue;
+        const int row0 = (cog * 4 + wave) * 32 + 4 * h;
+        float* sp = slab + (size_t)row0 * g.Cin + ci;
+        if (row0 - 4 * h + 32 <= g.Cout) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (cog * 4 + wave) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row < g.Cout) slab[(size_t)row * g.Cin + ci] = acc[n][e];
+            for (int e = 0; e < 16; ++e) sp[(size_t)((e & 3) + 8 * (e >> 2)) * g.Cin] = acc[n][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (row0 + (e & 3) + 8 * (e >> 2) < g.Cout) sp[(size_t)((e & 3) + 8 * (e >> 2)) * g.Cin] = acc[n][e];
         }
     }
 }

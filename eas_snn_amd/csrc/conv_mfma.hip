@@ -24,6 +24,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// staging loads of rows outside the image / channels past Cin read these zeros (channel stride 0) instead of being masked
+__device__ __attribute__((aligned(16))) float eas_conv_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct ConvGeom {
     int NI, Cin, Cout, Hi, Wi, Ho, Wo;
@@ -40,7 +44,7 @@ struct ConvGeom {
     int ext_h;          // rows spanned by the taps (3 for a 3x3 kernel)
     int tap_off[9];     // staged-pixel offset (dh*RS + dw) of every tap
     int oH, oW, os, oph, opw;   // output tensor height/width, output stride and phase: y[.., orow*os+oph, ocol*os+opw]
-    int dbg;       // development ablation switches (EAS_CONV_DBG): 1 no output stores, 2 no staging after chunk 0, 4 weights from one address
+    int dbg;       // development ablation switches (EAS_CONV_DBG): 2 no staging after chunk 0, 4 weights from one address, 16 no barrier
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -257,38 +261,48 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // A fragments: linear in the step index st = kstep*TAPS + tap
+    // A fragments: linear in the step index st = kstep*TAPS + tap.  Read with buffer loads: per-lane offset lane*16 in a VGPR,
+    // everything else (term, M-tile, step) in a scalar offset -> no vector ALU work per load.  Register sets rotate (the
+    // step count of a chunk is a multiple of NSETS), so "current" and "prefetched" fragments never need copying.
+    constexpr int NSETS = (NSTEPS % 2 == 0) ? 2 : 3;
+    static_assert(NSTEPS % NSETS == 0, "fragment register sets rotate back at the end of a chunk");
     const int steps_total = g.KSTEPS * TAPS;
-    const size_t a_term = (size_t)g.MT * steps_total * 64;
-    const bf16x8* ap[WM];
+    const unsigned a_term_bytes = (unsigned)g.MT * steps_total * 1024u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 3 * a_term_bytes, 0x00020000);
+    const int a_voff = lane * 16;
+    unsigned a_soff[WM];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int mt = (mt0 + i) < g.MT ? (mt0 + i) : (g.MT - 1);
-        ap[i] = wp + (size_t)mt * steps_total * 64 + lane;
+        a_soff[i] = __builtin_amdgcn_readfirstlane((unsigned)mt * steps_total * 1024u);
     }
-    bf16x8 a_cur[WM][3], a_nxt[WM][3];
+    bf16x8 a[NSETS][WM][3];
+    auto load_a = [&](int set, int step) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) a_cur[i][t] = ap[i][t * a_term];
+            for (int t = 0; t < 3; ++t)
+                a[set][i][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              a_rsrc, a_voff, a_soff[i] + t * a_term_bytes + (unsigned)step * 1024u, 0));
+    };
+    load_a(0, 0);
 
-    // loads are unconditional (clamped to a valid address) so that nothing branches or waits around them; rows outside the
-    // image and channel groups past Cin are zeroed when the values are consumed (Cin % 8 == 0: a group is valid or not as a whole)
+    // loads are unconditional: a row outside the image or a channel group past Cin (Cin % 8 == 0: a group is valid or not as
+    // a whole) reads the zero page with channel stride 0, so nothing branches, waits or needs masking around them
     vecf L[NIT][8];
     auto fetch = [&](int it, int c0) {
-        int cb = c0 + gch[it];
-        cb = cb < g.Cin - 8 ? cb : g.Cin - 8;
-        const float* src = x + (size_t)(gofs[it] >= 0 ? gofs[it] : 0) + (size_t)cb * plane;
+        const bool ok = gofs[it] >= 0 && c0 + gch[it] < g.Cin;
+        const float* src = ok ? x + (size_t)gofs[it] + (size_t)(c0 + gch[it]) * plane : eas_conv_zero_page;
+        const size_t cs = ok ? plane : 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * plane);
+        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * cs);
     };
     auto commit = [&](unsigned char* buf, int it, int c0) {
-        const bool ok = gofs[it] >= 0 && c0 + gch[it] < g.Cin;
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ok ? L[it][j][p] : 0.0f;
+            for (int j = 0; j < 8; ++j) v[j] = L[it][j][p];
             stage_store<XT>(buf + lofs[it] + p * PIXB, term_stride, v, inexact);
         }
     };
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
 
     const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
     int st = 0;
-    bf16x8 b_nxt[WN];
+    bf16x8 bq[NSETS][WN];
     for (int c = 0; c < nchunks; ++c) {
         const unsigned char* cur = smem + (c & 1) * buf_bytes;
         unsigned char* nxt = smem + ((c + 1) & 1) * buf_bytes;
@@ -315,10 +329,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
             const int kk = s / TAPS, tap = s - kk * TAPS;
             ++st;
             const int stn = (g.dbg & 4) ? 0 : (st < steps_total ? st : steps_total - 1);   // prefetch next step's weights (clamped at the end)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) a_nxt[i][t] = ap[i][t * a_term + (size_t)stn * 64];
+            load_a((s + 1) % NSETS, stn);
             if (more) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
@@ -334,16 +345,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
                 if (s == 0) {
                     const int toff0 = g.tap_off[0] * PIXB;
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) b_nxt[j] = *(const bf16x8*)(cur + qoff[j] + toff0);
+                    for (int j = 0; j < WN; ++j) bq[0][j] = *(const bf16x8*)(cur + qoff[j] + toff0);
                 }
-#pragma unroll
-                for (int j = 0; j < WN; ++j) b[j][0] = b_nxt[j];
                 if (s + 1 < NSTEPS) {
                     const int kk1 = (s + 1) / TAPS, tap1 = (s + 1) - kk1 * TAPS;
                     const int toff1 = g.tap_off[tap1] * PIXB + kk1 * 32;
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) b_nxt[j] = *(const bf16x8*)(cur + qoff[j] + toff1);
+                    for (int j = 0; j < WN; ++j) bq[(s + 1) % NSETS][j] = *(const bf16x8*)(cur + qoff[j] + toff1);
                 }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[j][0] = bq[s % NSETS][j];
             } else {
                 const int toff = g.tap_off[tap] * PIXB + kk * 32;
 #pragma unroll
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
 #pragma unroll
                     for (int t = 0; t < XT; ++t) b[j][t] = *(const bf16x8*)(cur + t * term_stride + qoff[j] + toff);
             }
+            bf16x8 (&a_cur)[WM][3] = a[s % NSETS];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -369,10 +381,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][0], acc[i][j], 0, 0, 0);
                     }
                 }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) a_cur[i][t] = a_nxt[i][t];
             if (SPREAD && more) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
@@ -387,18 +395,36 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         if (!(g.dbg & 16)) __syncthreads();
     }
 
-    // ---- epilogue: D tile (col = pixel = lane&31, row = (e&3) + 8*(e>>2) + 4*h) -> y NCHW
+    // ---- epilogue: D tile (col = pixel = lane&31, row = (e&3) + 8*(e>>2) + 4*h) -> y NCHW.  Lean on purpose: one pointer per
+    // (M-tile, pixel tile), rows reached by adding multiples of the channel stride; bias values loaded once per M-tile;
+    // the per-element channel bound check only for a ragged last M-tile (the epilogue used to be as long as the main loop).
     const long cstride = (long)g.oH * g.oW;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         if (mt0 + i >= g.MT) continue;
+        const int co0 = (mt0 + i) * 32 + 4 * h;
+        const bool full = (mt0 + i) * 32 + 32 <= g.Cout;          // block-uniform
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (e & 3) + 8 * (e >> 2);
+                bv[e] = co < g.Cout ? bias[co] : 0.0f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             if (ybase[j] < 0) continue;
+            float* yp = y + ybase[j] + (long)co0 * cstride;
+            if (full) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = (mt0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < g.Cout && (!(g.dbg & 1) || acc[i][j][e] == 12345.f)) y[ybase[j] + co * cstride] = acc[i][j][e] + (bias ? bias[co] : 0.0f);
+                for (int e = 0; e < 16; ++e) yp[((e & 3) + 8 * (e >> 2)) * cstride] = acc[i][j][e] + bv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[((e & 3) + 8 * (e >> 2)) * cstride] = acc[i][j][e] + bv[e];
             }
         }
     }

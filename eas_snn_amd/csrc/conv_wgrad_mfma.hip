@@ -31,6 +31,9 @@ constexpr int KST = TP / 16;
 constexpr int ROWB = 64;     // bytes per staged pixel row of one 32-channel plane
 constexpr int A_PLANE = TP * ROWB;
 
+// staging loads of rows outside the image / channels past the tensor read these zeros (channel stride 0)
+__device__ __attribute__((aligned(16))) float eas_wg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct WgGeom {
     int NI, Cin, Cout, Hi, Wi, Ho, Wo;
     int RT, rows_seg, nseg, rows_in, RS, Q;
@@ -161,7 +164,6 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     }
 
     vecf L[NIT][8];
-    bool Lok[NIT];
     auto fetch = [&](int it, int tile) {
         const int rho0 = tile * g.RT;
         const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
@@ -181,16 +183,17 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.Wo + (ok ? it_col[it] : 0);
             plane = planeY;
         }
-        Lok[it] = ok;
+        const float* sp = ok ? src : eas_wg_zero_page;
+        const size_t cs = ok ? plane : 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * plane);
+        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(sp + j * cs);
     };
     auto commit = [&](unsigned char* buf, int it) {
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = Lok[it] ? L[it][j][p] : 0.0f;
+            for (int j = 0; j < 8; ++j) v[j] = L[it][j][p];
             unsigned char* dst = buf + it_lofs[it] + p * ROWB;
             if (it_kind[it] == 1) stage_terms<XT>(dst, b_term, v);
             else stage_terms<3>(dst, A_TERM, v);
@@ -265,11 +268,14 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     const int ci = ci0 + pn * 32 + (lane & 31);
     float* slab = slabs + (size_t)blockIdx.x * g.Cout * g.Cin * 9;
     if (ci < g.Cin) {
+        const int cob = co0 + pm * 32 + 4 * (lane >> 5);
+        float* d0 = slab + ((size_t)cob * g.Cin + ci) * 9 + kh * 3;
+        const size_t rs = (size_t)g.Cin * 9;
+        const bool full = co0 + pm * 32 + 32 <= g.Cout;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int co = co0 + pm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (co < g.Cout) {
-                float* d = slab + ((size_t)co * g.Cin + ci) * 9 + kh * 3;
+            if (full || cob + (e & 3) + 8 * (e >> 2) < g.Cout) {
+                float* d = d0 + ((e & 3) + 8 * (e >> 2)) * rs;
                 d[0] = acc[0][e];
                 d[1] = acc[1][e];
                 d[2] = acc[2][e];
