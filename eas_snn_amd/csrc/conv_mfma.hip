@@ -44,8 +44,14 @@ struct ConvGeom {
     int ext_h;          // rows spanned by the taps (3 for a 3x3 kernel)
     int tap_off[9];     // staged-pixel offset (dh*RS + dw) of every tap
     int oH, oW, os, oph, opw;   // output tensor height/width, output stride and phase: y[.., orow*os+oph, ocol*os+opw]
+    // ceil(2^40 / d) for the divisors of the per-thread geometry set-up: n / d == (n * m) >> 40 for n, d < 2^20
+    unsigned long long m_Wo, m_rows_seg, m_Ho, m_units, m_units_seg, m_units_row, m_hrow, m_rows;
     int dbg;       // development ablation switches (EAS_CONV_DBG): 2 no staging after chunk 0, 4 weights from one address, 16 no barrier
 };
+
+// exact n / d for n, d < 2^20 with m = ceil(2^40 / d): a multiply-shift instead of the ~25-instruction integer division
+__device__ __forceinline__ int fdiv(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
+static inline unsigned long long fdiv_magic(int d) { return ((1ULL << 40) + (unsigned long long)d - 1) / (unsigned long long)(d > 0 ? d : 1); }
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
     hi = (__bf16)v;
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     const int wm = wave / WVN, wn = wave % WVN;
     const int r = lane & 31, h = lane >> 5;
     const int rho0 = blockIdx.x * g.RT;
-    const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
+    const int img0 = fdiv(rho0, g.m_Ho), r0 = rho0 - img0 * g.Ho;
     const int mt0 = (blockIdx.y * WVM + wm) * WM;
     const int term_stride = g.Q * PIXB;
     const int buf_bytes = term_stride * XT;
@@ -210,8 +216,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int hcols = g.RS - g.Wi;
         const int per_row = hcols * (PIXB / 16);
         for (int i = tid; i < rows * per_row * XT * 2; i += NT) {
-            const int row = i / per_row, k = i - row * per_row;
-            const int bt = row / rows, rw = row - bt * rows;   // bt = buffer*XT + term
+            const int row = fdiv(i, g.m_hrow), k = i - row * per_row;
+            const int bt = fdiv(row, g.m_rows), rw = row - bt * rows;   // bt = buffer*XT + term
             const int hc = k / (PIXB / 16), kk = k - hc * (PIXB / 16);
             const int col = hc < g.pad_l ? hc : g.Wi + hc;
             *(uint4*)(smem + (size_t)bt * term_stride + ((size_t)rw * g.RS + col) * PIXB + kk * 16) = make_uint4(0, 0, 0, 0);
@@ -225,11 +231,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     for (int j = 0; j < WN; ++j) {
         const int p = (wn * WN + j) * 32 + r;
         const int pc = p < npix ? p : 0;
-        const int rl = pc / g.Wo, c = pc - rl * g.Wo;
-        const int seg = rl / g.rows_seg, rr = rl - seg * g.rows_seg;
+        const int rl = fdiv(pc, g.m_Wo), c = pc - rl * g.Wo;
+        const int seg = fdiv(rl, g.m_rows_seg), rr = rl - seg * g.rows_seg;
         qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S) * PIXB + h * 16;
         const int rho = rho0 + rl;
-        const int img = rho / g.Ho, orow = rho - img * g.Ho;
+        const int img = fdiv(rho, g.m_Ho), orow = rho - img * g.Ho;
         const int yr = orow * g.os + g.oph, yc = c * g.os + g.opw;
         ybase[j] = (p < npix && rho < g.total_rows && yr < g.oH && yc < g.oW) ? (((long)img * g.Cout * g.oH + yr) * g.oW + yc) : -1;
     }
@@ -243,9 +249,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     for (int it = 0; it < NIT; ++it) {
         int item = it * NT + tid;
         item = item < nitems ? item : nitems - 1;   // surplus threads of the last slice redo its last item (same bytes)
-        const int gi = item / units, u = item - gi * units;
-        const int seg = u / units_seg, rem = u - seg * units_seg;
-        const int rl = rem / units_row, cu = rem - rl * units_row;
+        const int gi = fdiv(item, g.m_units), u = item - gi * units;
+        const int seg = fdiv(u, g.m_units_seg), rem = u - seg * units_seg;
+        const int rl = fdiv(rem, g.m_units_row), cu = rem - rl * units_row;
         const int ir = r0 * S - g.pad_t + rl, img = img0 + seg;
         const bool ok = ir >= 0 && ir < g.Hi && img < g.NI;
         gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + cu * VEC) : -1;
@@ -439,6 +445,14 @@ int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, in
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
         attr_set = true;
+    }
+    {
+        const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
+        const int rows = g.nseg * g.rows_in, per_row = (g.RS - g.Wi) * (CCH * 2 / 16);
+        if (g.total_rows >= (1 << 20) || units >= (1 << 20)) return EAS_ERR_UNSUPPORTED;     // fdiv range
+        g.m_Wo = fdiv_magic(g.Wo); g.m_rows_seg = fdiv_magic(g.rows_seg); g.m_Ho = fdiv_magic(g.Ho);
+        g.m_units = fdiv_magic(units); g.m_units_seg = fdiv_magic(units_seg); g.m_units_row = fdiv_magic(units_row);
+        g.m_hrow = fdiv_magic(per_row); g.m_rows = fdiv_magic(rows);
     }
     dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
