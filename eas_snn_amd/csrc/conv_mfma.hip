@@ -14,8 +14,14 @@
 //     ds_read_b128 and the KS*KS taps are plain address offsets into the same image.
 //   input gradient of a stride-1 conv is the same kernel on grad_y with the weights packed transposed + flipped.
 //
-// Block = 4 waves (one per SIMD, up to 512 registers each); wave tile = WM x WN MFMA tiles of 32x32, block tile =
-// (WVM*WM*32) output channels x (WVN*WN*32) output pixels = RT whole output rows (possibly several whole images).
+//   input gradient of a stride-2 3x3 conv: per parity class of the input pixel a stride-1 tap-list convolution (eas_conv_dgrad_s2).
+//
+// Wave tile = one 32-channel M-tile x five 32-pixel N-tiles (80 accumulator registers); block = 4 or 8 waves arranged
+// (waves along M) x (waves along N), block tile = RT whole output rows (possibly several whole images); two 4-wave blocks or
+// one 8-wave block per CU (two waves per SIMD hide each other's staging and LDS latency).  The kernel is written for a
+// low vector-ALU count per MFMA (PMC: a wave can hide about five VALU instructions per MFMA slot): fragment register sets
+// rotate instead of being copied, weights come by buffer loads with scalar offsets, staging loads that fall outside the
+// image read a zero page with stride 0 instead of being masked, and the epilogue walks one pointer per tile.
 #include <stdlib.h>
 
 #include "eas_common.h"
