@@ -1,82 +1,152 @@
 // SPP pooling block fused: out = cat[x, maxpool_k0(x), maxpool_k1(x), maxpool_k2(x)] along channels (stride 1, padding k/2)
 // and its backward (reference: SPPBottleneck.forward, yolox/models/network_blocks.py:143-147, on the spike tensors of
 // dark5; ATen max_pool2d semantics: the first maximum in row-major scan order wins ties, which matters for 0/1 inputs).
-// One block per (image, channel) plane held in LDS; the backward recomputes the arg-max from x (nothing is saved) and
-// gathers in a fixed order (deterministic, no atomics).
+//
+// A block holds PPB (image, channel) planes in LDS (dark5 planes are 8x10: three of them fill a 256-thread block).
+// The arg-max is separable under the first-maximum rule: the leftmost maximum of each row window (one scan over the
+// widest window serves all three pool sizes), then the first row whose row-maximum is strictly greater.  The three
+// arg-max indices of a pixel are packed into one word (10 bits each, planes <= 1024 pixels).  The backward recomputes
+// the arg-max from x (nothing is saved) and gathers over the widest window in a fixed order (deterministic, no atomics),
+// with the pooled gradients staged in LDS.
 #include "eas_common.h"
 
 namespace {
 
-constexpr int kMaxPlane = 1024;
+constexpr int kMaxPlane = 1024;   // pixels per plane (10-bit indices) and LDS floats per block
 
-__device__ __forceinline__ int argmax_window(const float* plane, int H, int W, int h, int w, int r) {
-    const int h0 = h - r < 0 ? 0 : h - r, h1 = h + r >= H ? H - 1 : h + r;
-    const int w0 = w - r < 0 ? 0 : w - r, w1 = w + r >= W ? W - 1 : w + r;
-    int best = h0 * W + w0;
-    float bv = plane[best];
-    for (int a = h0; a <= h1; ++a)
-        for (int b = w0; b <= w1; ++b) {
-            const float v = plane[a * W + b];
-            if (v > bv || v != v) {   // strictly greater (first maximum wins), NaN propagates like ATen
-                bv = v;
-                best = a * W + b;
-            }
+struct SppGeom {
+    int C, H, W, HW, ppb, r0, r1, r2;
+    long long planes;
+};
+
+__device__ __forceinline__ bool better(float v, float bv) { return v > bv || v != v; }   // NaN propagates like ATen
+
+// plane[ppb*HW] loaded; fills amax[ppb*HW] with the packed plane-local arg-max indices of the three windows.
+__device__ __forceinline__ void spp_argmax(const float* plane, unsigned* rowarg, unsigned* amax, const SppGeom& g, int work) {
+    const int rs[3] = {g.r0, g.r1, g.r2};
+    const int rmax = max(g.r0, max(g.r1, g.r2));
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        const int lp = idx / g.HW, i = idx - lp * g.HW, h = i / g.W, w = i - h * g.W;
+        const float* row = plane + lp * g.HW + h * g.W;
+        int best[3];
+        float bv[3];
+        bool have[3] = {false, false, false};
+        const int b0 = w - rmax < 0 ? 0 : w - rmax, b1 = w + rmax >= g.W ? g.W - 1 : w + rmax;
+        for (int b = b0; b <= b1; ++b) {
+            const float v = row[b];
+            const int d = b > w ? b - w : w - b;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (d <= rs[j] && (!have[j] || better(v, bv[j]))) {
+                    have[j] = true;
+                    bv[j] = v;
+                    best[j] = b;
+                }
         }
-    return best;
+        rowarg[idx] = (unsigned)best[0] | ((unsigned)best[1] << 10) | ((unsigned)best[2] << 20);   // column of the row-window maximum
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        const int lp = idx / g.HW, i = idx - lp * g.HW, h = i / g.W, w = i - h * g.W;
+        const float* pl = plane + lp * g.HW;
+        const unsigned* ra = rowarg + lp * g.HW;
+        unsigned packed = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = rs[j];
+            const int a0 = h - r < 0 ? 0 : h - r, a1 = h + r >= g.H ? g.H - 1 : h + r;
+            int best = a0 * g.W + (int)((ra[a0 * g.W + w] >> (10 * j)) & 1023u);
+            float bv = pl[best];
+            for (int a = a0 + 1; a <= a1; ++a) {
+                const int q = a * g.W + (int)((ra[a * g.W + w] >> (10 * j)) & 1023u);
+                const float v = pl[q];
+                if (better(v, bv)) {
+                    bv = v;
+                    best = q;
+                }
+            }
+            packed |= (unsigned)best << (10 * j);
+        }
+        amax[idx] = packed;
+    }
 }
 
-__global__ __launch_bounds__(EAS_BLOCK) void spp_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int k0,
-                                                            int k1, int k2) {
+__global__ __launch_bounds__(EAS_BLOCK) void spp_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, SppGeom g) {
     __shared__ float plane[kMaxPlane];
-    const int HW = H * W;
-    const int64_t pc = blockIdx.x;          // n*C + c
-    const int64_t n = pc / C, c = pc - n * C;
-    const float* src = x + pc * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) plane[i] = src[i];
+    __shared__ unsigned rowarg[kMaxPlane];
+    __shared__ unsigned amax[kMaxPlane];
+    const long long p0 = (long long)blockIdx.x * g.ppb;
+    const int np = (int)(g.planes - p0 < g.ppb ? g.planes - p0 : g.ppb);
+    const int work = np * g.HW;
+    const float* src = x + p0 * g.HW;
+    for (int i = threadIdx.x; i < work; i += blockDim.x) plane[i] = src[i];
     __syncthreads();
-    float* dst = out + (n * 4 * C + c) * HW;
-    const int ks[3] = {k0, k1, k2};
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const int h = i / W, w = i - h * W;
-        dst[i] = plane[i];
+    spp_argmax(plane, rowarg, amax, g, work);
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        const int lp = idx / g.HW, i = idx - lp * g.HW;
+        const long long pc = p0 + lp, n = pc / g.C, c = pc - n * g.C;
+        float* dst = out + (n * 4 * g.C + c) * g.HW + i;
+        const float* pl = plane + lp * g.HW;
+        const unsigned pk = amax[idx];
+        dst[0] = pl[i];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dst[(int64_t)(j + 1) * C * HW + i] = plane[argmax_window(plane, H, W, h, w, ks[j] / 2)];
+        for (int j = 0; j < 3; ++j) dst[(long long)(j + 1) * g.C * g.HW] = pl[(pk >> (10 * j)) & 1023u];
     }
 }
 
 __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout, float* __restrict__ gx,
-                                                            int C, int H, int W, int k0, int k1, int k2) {
+                                                            SppGeom g) {
     __shared__ float plane[kMaxPlane];
-    __shared__ short amax[3][kMaxPlane];
-    const int HW = H * W;
-    const int64_t pc = blockIdx.x;
-    const int64_t n = pc / C, c = pc - n * C;
-    const float* src = x + pc * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) plane[i] = src[i];
-    __syncthreads();
-    const int ks[3] = {k0, k1, k2};
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const int h = i / W, w = i - h * W;
+    __shared__ unsigned rowarg[kMaxPlane];
+    __shared__ unsigned amax[kMaxPlane];
+    __shared__ float gp[3][kMaxPlane];
+    const long long p0 = (long long)blockIdx.x * g.ppb;
+    const int np = (int)(g.planes - p0 < g.ppb ? g.planes - p0 : g.ppb);
+    const int work = np * g.HW;
+    const float* src = x + p0 * g.HW;
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        plane[idx] = src[idx];
+        const int lp = idx / g.HW, i = idx - lp * g.HW;
+        const long long pc = p0 + lp, n = pc / g.C, c = pc - n * g.C;
+        const float* gsrc = gout + (n * 4 * g.C + c) * g.HW + i;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) amax[j][i] = (short)argmax_window(plane, H, W, h, w, ks[j] / 2);
+        for (int j = 0; j < 3; ++j) gp[j][idx] = gsrc[(long long)(j + 1) * g.C * g.HW];
     }
     __syncthreads();
-    const float* g = gout + (n * 4 * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const int h = i / W, w = i - h * W;
-        float s = g[i];
+    spp_argmax(plane, rowarg, amax, g, work);
+    __syncthreads();
+    const int rs[3] = {g.r0, g.r1, g.r2};
+    const int rmax = max(g.r0, max(g.r1, g.r2));
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        const int lp = idx / g.HW, i = idx - lp * g.HW, h = i / g.W, w = i - h * g.W;
+        const long long pc = p0 + lp, n = pc / g.C, c = pc - n * g.C;
+        float s = gout[(n * 4 * g.C + c) * g.HW + i];
+        const int h0 = h - rmax < 0 ? 0 : h - rmax, h1 = h + rmax >= g.H ? g.H - 1 : h + rmax;
+        const int w0 = w - rmax < 0 ? 0 : w - rmax, w1 = w + rmax >= g.W ? g.W - 1 : w + rmax;
+        for (int a = h0; a <= h1; ++a) {
+            const int da = a > h ? a - h : h - a;
+            for (int b = w0; b <= w1; ++b) {
+                const int db = b > w ? b - w : w - b;
+                const int d = da > db ? da : db;
+                const int q = lp * g.HW + a * g.W + b;
+                const unsigned pk = amax[q];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int r = ks[j] / 2;
-            const float* gj = g + (int64_t)(j + 1) * C * HW;
-            const int h0 = h - r < 0 ? 0 : h - r, h1 = h + r >= H ? H - 1 : h + r;
-            const int w0 = w - r < 0 ? 0 : w - r, w1 = w + r >= W ? W - 1 : w + r;
-            for (int a = h0; a <= h1; ++a)
-                for (int b = w0; b <= w1; ++b)
-                    if (amax[j][a * W + b] == i) s += gj[a * W + b];
+                for (int j = 0; j < 3; ++j)
+                    if (d <= rs[j] && (int)((pk >> (10 * j)) & 1023u) == i) s += gp[j][q];
+            }
         }
-        gx[pc * HW + i] = s;
+        gx[pc * g.HW + i] = s;
     }
+}
+
+int make_geom(SppGeom& g, int64_t N, int C, int H, int W, int k0, int k1, int k2) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return EAS_ERR_INVALID_ARG;
+    if (H * W > kMaxPlane || !(k0 & 1) || !(k1 & 1) || !(k2 & 1) || k0 < 1 || k1 < 1 || k2 < 1 || N * C > 0x7fffffff) return EAS_ERR_UNSUPPORTED;
+    g.C = C; g.H = H; g.W = W; g.HW = H * W;
+    g.r0 = k0 / 2; g.r1 = k1 / 2; g.r2 = k2 / 2;
+    g.planes = N * C;
+    g.ppb = EAS_BLOCK / g.HW < 1 ? 1 : EAS_BLOCK / g.HW;
+    return EAS_OK;
 }
 
 }  // namespace
@@ -84,20 +154,22 @@ __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restr
 extern "C" {
 
 int eas_spp_pool_fwd(const float* x, float* out, int64_t N, int C, int H, int W, int k0, int k1, int k2, eas_stream_t stream) {
-    if (!x || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return EAS_ERR_INVALID_ARG;
-    if (H * W > kMaxPlane || !(k0 & 1) || !(k1 & 1) || !(k2 & 1) || N * C > 0x7fffffff) return EAS_ERR_UNSUPPORTED;
+    if (!x || !out) return EAS_ERR_INVALID_ARG;
+    SppGeom g;
+    if (int rc = make_geom(g, N, C, H, W, k0, k1, k2)) return rc;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(spp_fwd_kernel, dim3((unsigned)(N * C)), dim3(H * W >= 192 ? EAS_BLOCK : 128), 0, eas_s(stream), x, out, C, H, W, k0, k1, k2);
+    hipLaunchKernelGGL(spp_fwd_kernel, dim3((unsigned)((g.planes + g.ppb - 1) / g.ppb)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
 
 int eas_spp_pool_bwd(const float* x, const float* grad_out, float* grad_x, int64_t N, int C, int H, int W, int k0, int k1, int k2,
                      eas_stream_t stream) {
-    if (!x || !grad_out || !grad_x || N <= 0 || C <= 0 || H <= 0 || W <= 0) return EAS_ERR_INVALID_ARG;
-    if (H * W > kMaxPlane || !(k0 & 1) || !(k1 & 1) || !(k2 & 1) || N * C > 0x7fffffff) return EAS_ERR_UNSUPPORTED;
+    if (!x || !grad_out || !grad_x) return EAS_ERR_INVALID_ARG;
+    SppGeom g;
+    if (int rc = make_geom(g, N, C, H, W, k0, k1, k2)) return rc;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(spp_bwd_kernel, dim3((unsigned)(N * C)), dim3(H * W >= 192 ? EAS_BLOCK : 128), 0, eas_s(stream), x, grad_out, grad_x, C, H, W, k0, k1, k2);
+    hipLaunchKernelGGL(spp_bwd_kernel, dim3((unsigned)((g.planes + g.ppb - 1) / g.ppb)), dim3(EAS_BLOCK), 0, eas_s(stream), x, grad_out, grad_x, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -47,7 +47,8 @@ def main():
     for _ in range(4):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+    by_ops = bool(os.environ.get('EAS_PROFILE_OPS'))
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=by_ops) as prof:
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
@@ -76,6 +77,12 @@ def main():
     print('--- top kernels (calls/step, ms/step, name)')
     for name, (n, us) in rows[:70]:
         print(f'{n / steps:8.1f} {us / steps / 1e3:9.3f}  {name[:150]}')
+
+    if by_ops:   # ATen glue by operator and input shapes (which tensors the remaining non-HIP time is spent on)
+        print('--- aten ops by input shape (calls/step, self device ms/step, op, shapes)')
+        ka = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::') and e.self_device_time_total > 0]
+        for e in sorted(ka, key=lambda e: -e.self_device_time_total)[:60]:
+            print(f'{e.count / steps:8.1f} {e.self_device_time_total / steps / 1e3:9.3f}  {e.key:28s} {str(e.input_shapes)[:150]}')
 
 
 if __name__ == '__main__':
