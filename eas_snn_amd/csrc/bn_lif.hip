@@ -179,7 +179,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
     int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-    float* __restrict__ grad_beta, int N, int C, int HW, int bcast) {
+    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast) {
     __shared__ double red[NW];
     __shared__ float bc[2];
     const int c = blockIdx.y;
@@ -279,6 +279,16 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
             }
         }
     }
+    if (APPLY && grad_w && blockIdx.x == 0 && blockIdx.y == 0) {
+        // dL/dw of the (scalar) PLIF decay: fixed-order sum of every (channel, chunk) partial of pass 1, by one block
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
+            const int cc = i / nchunks, j = i - cc * nchunks;
+            acc += part[((int64_t)cc * kMaxChunks + j) * 4 + 2];
+        }
+        const double tot = eas_block_sum<double, NW>(acc, red);
+        if (threadIdx.x == 0) *grad_w = (float)tot * (k * (1.0f - k));
+    }
     if (!APPLY) {
         const double t1 = eas_block_sum<double, NW>((double)s1, red);
         const double t2 = eas_block_sum<double, NW>((double)s2, red);
@@ -287,22 +297,6 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
             double* o = part + ((int64_t)c * kMaxChunks + blockIdx.x) * 4;
             o[0] = t1; o[1] = t2; o[2] = t3;
         }
-    }
-}
-
-__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_gradw_finalize(const double* __restrict__ part, int C, int nchunks,
-                                                                   const float* __restrict__ w_logit,
-                                                                   float* __restrict__ grad_w) {
-    __shared__ double red[NW];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
-        const int c = i / nchunks, j = i - c * nchunks;
-        acc += part[((int64_t)c * kMaxChunks + j) * 4 + 2];
-    }
-    const double tot = eas_block_sum<double, NW>(acc, red);
-    if (threadIdx.x == 0) {
-        const float k = eas_sigmoidf(*w_logit);
-        *grad_w = (float)tot * (k * (1.0f - k));
     }
 }
 
@@ -338,16 +332,12 @@ int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, co
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, N, C, HW, bcast);
+                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast);
     EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, N, C, HW, bcast);
+                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast);
     EAS_CHECK_LAUNCH();
-    if (grad_w) {
-        hipLaunchKernelGGL(bn_lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, ws, C, chunks, p.w_logit, grad_w);
-        EAS_CHECK_LAUNCH();
-    }
     return EAS_OK;
 }
 

@@ -363,22 +363,25 @@ def event_voxel_grid(t, x, y, p, sample_offsets, n_bins, H, W):
 
 
 # ------------------------------------------------------------------------------------------------ K3
-def smallconv_fwd(x, w, b, relu=False):
-    """Direct LDS-tiled conv (stride 1, 'same' padding) for the sampler's tiny-channel stacks."""
+def smallconv_fwd(x, w, b, relu=False, out=None):
+    """Direct LDS-tiled conv (stride 1, 'same' padding) for the sampler's tiny-channel stacks.  ``out``: a contiguous
+    [N,Cout,H,W] destination (e.g. one step's slice of a time-batched buffer) instead of a fresh tensor."""
     x, w = _f32c(x), _f32c(w)
     N, Cin, H, W = x.shape
     Cout, k = w.shape[0], w.shape[-1]
-    y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device) if out is None else out
+    assert y.is_contiguous() and y.shape == (N, Cout, H, W)
     _call('eas_smallconv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_smallconv_fwd, ptr(x), ptr(w), ptr(b), ptr(y), N, Cin, Cout,
           H, W, k, int(relu), stream())
     return y
 
 
-def smallconv_bwd_input(gy, w, relu_mask=None):
+def smallconv_bwd_input(gy, w, relu_mask=None, out=None):
     gy, w = _f32c(gy), _f32c(w)
     N, Cout, H, W = gy.shape
     Cin, k = w.shape[1], w.shape[-1]
-    gx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=gy.device)
+    gx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=gy.device) if out is None else out
+    assert gx.is_contiguous() and gx.shape == (N, Cin, H, W)
     _call('eas_smallconv_bwd_input', 4 * (gy.numel() + gx.numel()), _lib.lib().eas_smallconv_bwd_input, ptr(gy), ptr(w),
           ptr(relu_mask), ptr(gx), N, Cin, Cout, H, W, k, stream())
     return gx
@@ -396,13 +399,14 @@ def smallconv_bwd_weight(gy, x, w):
     return gw, gb
 
 
-def _conv_stack_fwd(x, params, k):
-    """Conv(k, pad k//2) [+ ReLU + Conv]*: returns (out, inputs of every conv).  ReLU is fused into the producing conv."""
+def _conv_stack_fwd(x, params, k, mids=None):
+    """Conv(k, pad k//2) [+ ReLU + Conv]*: returns (out, inputs of every conv).  ReLU is fused into the producing conv.
+    ``mids[i]``: destination of conv i's output for i < n-1 (the input of conv i+1)."""
     ins = []
     n = len(params) // 2
     for i in range(n):
         ins.append(x)
-        x = smallconv_fwd(x, params[2 * i], params[2 * i + 1], relu=(i < n - 1))
+        x = smallconv_fwd(x, params[2 * i], params[2 * i + 1], relu=(i < n - 1), out=mids[i] if mids is not None and i < n - 1 else None)
     return x, ins
 
 
@@ -438,7 +442,16 @@ class _ARSNNFn(torch.autograd.Function):
         shape = (N, C2, H, W)
         v = torch.zeros(shape, device=dev)
         vsum = torch.zeros(shape, device=dev)
-        spike = torch.zeros(shape, device=dev)
+        # inputs of every gate conv for all Tm steps, written in place by the producing kernels: the batched weight
+        # gradient reads them as one [Tm*N,...] tensor (no concatenation).  gate_in[0][t] = spike entering step t.
+        keep = need_grad and d_gate
+        if keep:
+            gate_in = [torch.empty((Tm, N, pg[2 * i].shape[1], H, W), device=dev) for i in range(d_gate)]
+            gate_in[0][0].zero_()
+            spike = gate_in[0][0]
+        else:
+            gate_in = None
+            spike = torch.zeros(shape, device=dev)
         seg = torch.zeros(shape, dtype=torch.int32, device=dev)
         tl = torch.full(shape, -1, dtype=torch.int32, device=dev)
         agg = torch.zeros((1 if running else Ts,) + shape, device=dev)
@@ -447,10 +460,11 @@ class _ARSNNFn(torch.autograd.Function):
         t_rec = []
         for t in range(Tm):
             if d_gate:
-                R, g_ins = _conv_stack_fwd(spike, pg, k)
+                R, g_ins = _conv_stack_fwd(spike, pg, k, [gate_in[i + 1][t] for i in range(d_gate - 1)] if keep else None)
             else:
                 R, g_ins = zero_rec, []
-            v_n, vs_n, sp_n = torch.empty_like(v), torch.empty_like(v), torch.empty_like(v)
+            v_n, vs_n = torch.empty_like(v), torch.empty_like(v)
+            sp_n = gate_in[0][t + 1] if keep and t + 1 < Tm else torch.empty_like(v)
             if need_grad:
                 gate, vn = torch.empty_like(v), torch.empty_like(v)
                 seg_b, tl_b = torch.empty_like(seg), torch.empty_like(tl)
@@ -476,7 +490,7 @@ class _ARSNNFn(torch.autograd.Function):
             out = torch.relu(out)
         ctx.cfg = cfg
         ctx.dims = (Tm, N, Cin, C2, H, W)
-        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu, agg)
+        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu, agg, gate_in)
         ctx.params = params
         ctx.ev_needs_grad = ctx.needs_input_grad[0]
         rec = torch.stack(t_rec) if record else None
@@ -489,7 +503,7 @@ class _ARSNNFn(torch.autograd.Function):
         L = _lib.lib()
         k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = ctx.cfg
         Tm, N, Cin, C2, H, W = ctx.dims
-        saved, in_ins, spike_last, seg, tl, pre_relu, agg = ctx.saved
+        saved, in_ins, spike_last, seg, tl, pre_relu, agg, gate_in = ctx.saved
         params = ctx.params
         pin, pg = params[:2 * d_in], params[2 * d_in:]
         HW = H * W
@@ -511,8 +525,9 @@ class _ARSNNFn(torch.autograd.Function):
                                        N, C2, HW, st), 'eas_arsnn_tail_bwd')
         g_spike = None
         gX = torch.empty((Tm, N, 2 * C2, H, W), device=dev)
-        # gradient reaching each conv of the gate stack at every step (batched weight-grad at the end)
-        g_stage = [[None] * Tm for _ in range(d_gate)]
+        # gradient reaching each conv of the gate stack at every step, written into time-batched buffers by the producing
+        # kernels (batched weight-grad at the end); the last conv's is gX itself
+        g_stage = [torch.empty((Tm, N, pg[2 * i].shape[0], H, W), device=dev) for i in range(d_gate - 1)] + ([gX] if d_gate else [])
         for t in range(Tm - 1, -1, -1):
             g_ins, v_prev, vs_prev, gate, vn, seg_b, tl_b = saved[t]
             g_vp, g_vsp = torch.empty_like(g_v), torch.empty_like(g_v)
@@ -521,17 +536,15 @@ class _ARSNNFn(torch.autograd.Function):
                                        int(sat), thresh, v_reset, int(soft), 1.0, N, C2, HW, st), 'eas_arsnn_step_bwd')
             g_v, g_vs = g_vp, g_vsp
             g = gX[t]
-            for i in range(d_gate - 1, -1, -1):
-                g_stage[i][t] = g
+            for i in range(d_gate - 1, -1, -1):           # g = gradient at the output of gate conv i = g_stage[i][t]
                 if i == 0 and t == 0:
                     break                      # spike input of step 0 is the constant 0
-                g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None)   # ReLU in front of conv i fused as a mask
+                # ReLU in front of conv i fused as a mask
+                g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None, out=g_stage[i - 1][t] if i > 0 else None)
             g_spike = g if (t > 0 and d_gate) else None
         grads_g = []
         for i in range(d_gate):
-            gs = torch.cat(g_stage[i], 0)
-            xs = torch.cat([saved[t][0][i] for t in range(Tm)], 0)
-            gw, gb = smallconv_bwd_weight(gs, xs, pg[2 * i])
+            gw, gb = smallconv_bwd_weight(g_stage[i].flatten(0, 1), gate_in[i].flatten(0, 1), pg[2 * i])
             grads_g += [gw, gb]
         # input conv stack, all Tm steps at once
         grads_in = [None] * (2 * d_in)

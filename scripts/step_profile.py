@@ -75,7 +75,7 @@ def main():
     for k, us in sorted(fam.items(), key=lambda kv: -kv[1]):
         print(f'{us / steps / 1e3:9.3f}  {k}')
     print('--- top kernels (calls/step, ms/step, name)')
-    for name, (n, us) in rows[:70]:
+    for name, (n, us) in rows[:int(os.environ.get("EAS_PROFILE_ROWS", "70"))]:
         print(f'{n / steps:8.1f} {us / steps / 1e3:9.3f}  {name[:150]}')
 
     if by_ops:   # ATen glue by operator and input shapes (which tensors the remaining non-HIP time is spent on)
