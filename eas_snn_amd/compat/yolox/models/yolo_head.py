@@ -17,6 +17,11 @@ from .losses import IOUloss
 from .network_blocks import BaseConv, DWConv
 
 
+def _pred(conv, x):
+    """prediction conv through ops.conv2d (own kernels where eligible, and visible to the statistics tap of eas_snn_amd.stats)"""
+    return ops.conv2d(x, conv) if type(conv) is nn.Conv2d and x.is_cuda else conv(x)
+
+
 def _prod2(t):
     """Product over a last axis of length 2 (box width x height).  ``torch.prod``'s backward inspects the input for zeros
     on the host, which stalls the stream and cannot be captured in a HIP graph; the explicit product has neither problem."""
@@ -67,7 +72,7 @@ class YOLOXHead(nn.Module):
         x = self.stems[k](x)
         cls_feat = self.cls_convs[k](x)
         reg_feat = self.reg_convs[k](x)
-        cls_out, reg_out, obj_out = self.cls_preds[k](cls_feat), self.reg_preds[k](reg_feat), self.obj_preds[k](reg_feat)
+        cls_out, reg_out, obj_out = _pred(self.cls_preds[k], cls_feat), _pred(self.reg_preds[k], reg_feat), _pred(self.obj_preds[k], reg_feat)
         if self.full_spike:        # mean input current over T (spiking_yolo_head.py:175-178)
             cls_out, reg_out, obj_out = ops.time_mean(cls_out), ops.time_mean(reg_out), ops.time_mean(obj_out)
         return reg_out, obj_out, cls_out

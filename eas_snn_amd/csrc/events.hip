@@ -176,6 +176,77 @@ __global__ __launch_bounds__(EAS_BLOCK) void voxel_grid_kernel(const uint32_t* _
     }
 }
 
+// Voxel cube (to_voxel_cube_numpy, yolox/utils/event_reps.py:92-138): counts per (slice, channel, y, x) with
+// slice = floor(float32(t_rel) / float32(window)) and channel = (p + 1) * (tbin + 1) - 1, tbin = floor((t_rel % window) /
+// (window / tbins)) in float64 -- the reference's own arithmetic, quirks included (channel collisions for tbins >= 2).
+__global__ __launch_bounds__(EAS_BLOCK) void voxel_cube_kernel(const uint32_t* __restrict__ t, const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
+                                                               int64_t nev, const int64_t* __restrict__ offsets, int B, int ns,
+                                                               int tbins, int H, int W, int32_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = find_sample(offsets, B, i);
+        const int64_t a = offsets[b], e = offsets[b + 1];
+        const uint32_t t0 = t[a];
+        const uint32_t win = (t[e - 1] - t0) / (uint32_t)ns;
+        if (win == 0) continue;
+        const uint32_t tr = t[i] - t0;
+        if ((uint64_t)tr >= (uint64_t)win * (uint64_t)ns) continue;        // tail beyond ns whole windows is dropped
+        const uint32_t xx = x[i], yy = y[i];
+        if (xx >= (uint32_t)W || yy >= (uint32_t)H) continue;
+        const int sl = (int)floorf((float)(int32_t)tr / (float)win);
+        const int tb = (int)floor((double)(tr % win) / ((double)win / (double)tbins));
+        const int ch = ((int)p[i] + 1) * (tb + 1) - 1;
+        if (sl >= ns || ch >= 2 * tbins) continue;                         // the reference raises on these; never for p in {0,1}
+        atomicAdd(out + ((((int64_t)b * ns + sl) * (2 * tbins) + ch) * H + yy) * W + xx, 1);
+    }
+}
+
+// Time surface (GEN1Dataset.agrregate 'timesurface', gen1.py:362-369 + to_timesurface_numpy, event_reps.py:141-160).
+// Pass 1: latest timestamp per (sample, slice, polarity, pixel) by integer atomic max (timestamps ascend, so the
+// maximum is the reference's "last write wins").  Pass 2: running maximum over the slices, then
+// exp(-((i + 1) * window + t0 - latest) / tau) in float64; untouched pixels keep latest = 0 exactly like the reference.
+__global__ __launch_bounds__(EAS_BLOCK) void time_surface_scatter_kernel(const uint32_t* __restrict__ t, const uint16_t* __restrict__ x,
+                                                                         const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
+                                                                         int64_t nev, const int64_t* __restrict__ offsets, int B,
+                                                                         int ns, int H, int W, uint32_t* __restrict__ latest) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = find_sample(offsets, B, i);
+        const SampleWin w = sample_window(t, offsets, b, ns);
+        if (w.win == 0) continue;
+        const uint32_t k = (t[i] - w.t0) / w.win;
+        if (k >= (uint32_t)ns) continue;
+        const uint32_t xx = x[i], yy = y[i], pp = p[i];
+        if (xx >= (uint32_t)W || yy >= (uint32_t)H || pp > 1u) continue;
+        atomicMax(latest + ((((int64_t)b * ns + k) * 2 + pp) * H + yy) * W + xx, t[i]);
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void time_surface_exp_kernel(const uint32_t* __restrict__ t, const int64_t* __restrict__ offsets,
+                                                                     int B, int ns, int H, int W, double tau,
+                                                                     const uint32_t* __restrict__ latest, double* __restrict__ out) {
+    const int64_t plane = (int64_t)2 * H * W, total = (int64_t)B * plane;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / plane);
+        const int64_t q = i - (int64_t)b * plane;
+        const int64_t a = offsets[b], e = offsets[b + 1];
+        SampleWin w{0u, 0u};
+        if (e > a) w = sample_window(t, offsets, b, ns);
+        uint32_t m = 0;
+        for (int k = 0; k < ns; ++k) {
+            const int64_t idx = ((int64_t)b * ns + k) * plane + q;
+            if (w.win == 0) {                       // no events, or a window of zero length (invalid input): zeros
+                out[idx] = 0.0;
+                continue;
+            }
+            const uint32_t l = latest[idx];
+            m = l > m ? l : m;
+            const uint32_t end = (uint32_t)(k + 1) * w.win + w.t0;       // uint32 arithmetic as numpy's
+            const int64_t diff = -((int64_t)end - (int64_t)m);
+            out[idx] = exp((double)diff / tau);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -246,6 +317,41 @@ int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y
     if (nev == 0) return EAS_OK;
     hipLaunchKernelGGL(voxel_grid_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets,
                        B, n_bins, H, W, out);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_event_voxel_cube(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                         const int64_t* sample_offsets, int B, int num_slices, int tbins, int H, int W, int32_t* out,
+                         eas_stream_t stream) {
+    if (!out || !sample_offsets || B < 1 || num_slices < 1 || tbins < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
+    if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    if (hipMemsetAsync(out, 0, (size_t)B * num_slices * 2 * tbins * H * W * sizeof(int32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (nev == 0) return EAS_OK;
+    hipLaunchKernelGGL(voxel_cube_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets, B, num_slices,
+                       tbins, H, W, out);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_event_time_surface(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                           const int64_t* sample_offsets, int B, int num_slices, int H, int W, double tau, uint32_t* workspace,
+                           double* out, eas_stream_t stream) {
+    if (!out || !workspace || !sample_offsets || B < 1 || num_slices < 1 || H < 1 || W < 1 || nev < 0 || !(tau > 0.0)) return EAS_ERR_INVALID_ARG;
+    if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    const int64_t total = (int64_t)B * num_slices * 2 * H * W;
+    if (hipMemsetAsync(workspace, 0, (size_t)total * sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (nev > 0) {
+        hipLaunchKernelGGL(time_surface_scatter_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets, B,
+                           num_slices, H, W, workspace);
+        EAS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(time_surface_exp_kernel, dim3(eas_grid_1d((int64_t)B * 2 * H * W)), dim3(EAS_BLOCK), 0, st, t, sample_offsets, B,
+                       num_slices, H, W, tau, workspace, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -362,6 +362,27 @@ def event_voxel_grid(t, x, y, p, sample_offsets, n_bins, H, W):
     return out
 
 
+def event_voxel_cube(t, x, y, p, sample_offsets, num_slices, H, W, tbins=2):
+    """int32 [B, num_slices, 2*tbins, H, W] voxel-cube counts (the reference returns them as float64)."""
+    _dev(t, x, y, p, sample_offsets)
+    B = sample_offsets.numel() - 1
+    out = torch.empty((B, num_slices, 2 * tbins, H, W), dtype=torch.int32, device=t.device)
+    check(_lib.lib().eas_event_voxel_cube(ptr(t), ptr(x), ptr(y), ptr(p), t.numel(), ptr(sample_offsets), B, num_slices, tbins, H, W,
+                                          ptr(out), stream()), 'eas_event_voxel_cube')
+    return out
+
+
+def event_time_surface(t, x, y, p, sample_offsets, num_slices, H, W, tau=50e3):
+    """float64 [B, num_slices, 2, H, W] exponential time surfaces at the end of every micro-slice."""
+    _dev(t, x, y, p, sample_offsets)
+    B = sample_offsets.numel() - 1
+    ws = torch.empty((B, num_slices, 2, H, W), dtype=torch.int32, device=t.device)
+    out = torch.empty((B, num_slices, 2, H, W), dtype=torch.float64, device=t.device)
+    check(_lib.lib().eas_event_time_surface(ptr(t), ptr(x), ptr(y), ptr(p), t.numel(), ptr(sample_offsets), B, num_slices, H, W,
+                                            float(tau), ptr(ws), ptr(out), stream()), 'eas_event_time_surface')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ K3
 def smallconv_fwd(x, w, b, relu=False, out=None):
     """Direct LDS-tiled conv (stride 1, 'same' padding) for the sampler's tiny-channel stacks.  ``out``: a contiguous
@@ -459,6 +480,8 @@ class _ARSNNFn(torch.autograd.Function):
         saved = []
         t_rec = []
         for t in range(Tm):
+            if _CONV_SINK is not None and d_gate:
+                _CONV_SINK.sampler_spikes.append(spike)
             if d_gate:
                 R, g_ins = _conv_stack_fwd(spike, pg, k, [gate_in[i + 1][t] for i in range(d_gate - 1)] if keep else None)
             else:
@@ -787,10 +810,41 @@ def prepack_conv_weights(model):
         object.__setattr__(c, '_eas_packs', d)
 
 
+# Statistics tap (eas_snn_amd/stats.py): when set, every convolution input of the model is shown to it before the
+# convolution runs -- ``sink(conv_module, x, replicas)`` for the dense convolutions, and the sampler appends the spike
+# tensor entering each micro-step to ``sink.sampler_spikes``.  The kernels that run are the same with or without it.
+_CONV_SINK = None
+
+
+def set_conv_sink(sink):
+    global _CONV_SINK
+    prev, _CONV_SINK = _CONV_SINK, sink
+    return prev
+
+
+def conv_sink():
+    return _CONV_SINK
+
+
+def spike_sop(x, ksize, stride, cout):
+    """(sum x, conv(x, ones).sum()) of a convolution input x [NI,Cin,H,W] as a device float64 tensor of 2 (eas_spike_sop)."""
+    _dev(x)
+    x = _f32c(x)
+    NI, Cin, H, W = x.shape
+    L = _lib.lib()
+    out = torch.empty(2, dtype=torch.float64, device=x.device)
+    ws = torch.empty(L.eas_spike_sop_workspace_doubles(), dtype=torch.float64, device=x.device)
+    _call('eas_spike_sop', 4 * x.numel(), L.eas_spike_sop, ptr(x), NI, Cin, H, W, int(ksize), int(stride), int(cout), ptr(out), ptr(ws),
+          stream())
+    return out
+
+
 def conv2d(x, conv, small_int=None):
     """``conv(x)`` for an ``nn.Conv2d`` on the matrix-core kernels where eligible (else ATen/MIOpen).
     A module that carries forward hooks (RecordHook in energy_estimation, event_evaluator.py:519-523; thop in
     get_model_info) is called the ordinary way so that the hooks fire."""
+    if _CONV_SINK is not None:
+        _CONV_SINK(conv, x, _REPLICAS)
     if conv._forward_hooks or conv._forward_pre_hooks or torch.nn.modules.module._global_forward_hooks:
         return conv(x)
     if not conv_eligible(x, conv):

@@ -74,6 +74,20 @@ int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y
                          const int64_t* sample_offsets, int B, int n_bins, int H, int W, double* out,
                          eas_stream_t stream);
 
+/* Voxel cube, to_voxel_cube_numpy (yolox/utils/event_reps.py:92-138; call sites gen1.py:371-372, ncaltech.py:259):
+ * out[b][slice][channel][y][x] int32 counts (zeroed by the call), 2*tbins channels, channel = (p+1)*(tbin+1)-1 as the
+ * reference computes it.  The reference returns these counts as float64. */
+int eas_event_voxel_cube(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                         const int64_t* sample_offsets, int B, int num_slices, int tbins, int H, int W, int32_t* out,
+                         eas_stream_t stream);
+
+/* Time surfaces at the end of each micro-slice, GEN1Dataset.agrregate(method='timesurface') (gen1.py:362-369) =
+ * slice_events + to_timesurface_numpy (yolox/utils/event_reps.py:141-160): out[b][slice][p][y][x] float64 =
+ * exp(-((slice+1)*window + t0 - latest_timestamp) / tau).  workspace: B*num_slices*2*H*W uint32 (latest timestamps). */
+int eas_event_time_surface(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                           const int64_t* sample_offsets, int B, int num_slices, int H, int W, double tau,
+                           uint32_t* workspace, double* out, eas_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  multi-step (P)LIF neuron.  Replaces spikingjelly ParametricLIFNode / LIFNode
  *     multi_step_forward (call site yolox/utils/utils_snn.py:44-53): per step
@@ -240,6 +254,17 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
 int eas_spp_pool_fwd(const float* x, float* out, int64_t N, int C, int H, int W, int k0, int k1, int k2, eas_stream_t stream);
 int eas_spp_pool_bwd(const float* x, const float* grad_out, float* grad_x, int64_t N, int C, int H, int W, int k0, int k1, int k2,
                      eas_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spike-count / synaptic-operation statistics.  Replaces calc_layer_sop of
+ * energy_estimation (yolox/evaluators/event_evaluator.py:473-487, inputs gathered by RecordHook
+ * yolox/utils/hooks.py:31-44): for the input x [NI][Cin][H][W] of a ksize x ksize convolution
+ * (padding (ksize-1)/2, stride, Cout outputs, groups 1)
+ *     out[0] = sum x   (spike count)      out[1] = conv(x, all-ones weights).sum()   (accumulate operations)
+ * workspace: eas_spike_sop_workspace_doubles() doubles.  Deterministic (fixed-order reduction). */
+int64_t eas_spike_sop_workspace_doubles(void);
+int eas_spike_sop(const float* x, int64_t NI, int Cin, int H, int W, int ksize, int stride, int Cout, double* out,
+                  double* workspace, eas_stream_t stream);
 
 #ifdef __cplusplus
 }

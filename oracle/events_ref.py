@@ -110,6 +110,67 @@ def voxel_grid(t, x, y, p_signed, n_time_bins, height, width):
     return grid.reshape(n_time_bins, 1, height, width)
 
 
+def voxel_cube(t, x, y, p, num_slices, tbins, height, width):
+    """Voxel cube [num_slices, 2*tbins, H, W] float64 (event counts).
+
+    Follows to_voxel_cube_numpy (yolox/utils/event_reps.py:92-138):
+        t -= t[0]; window = (t[-1] - t[0]) // num_slices; keep t < window * num_slices
+        slice   = floor(float32(t) / float32(window))         (torch int32 / int64 tensor division is float32)
+        tbin    = (t % window) // (window / tbins)             (float64 floor division)
+        channel = (p + 1) * (tbin + 1) - 1                     (p in {0, 1}: p=0 -> tbin, p=1 -> 2*tbin + 1;
+                                                                 so (p=0, tbin=1) and (p=1, tbin=0) share channel 1 and
+                                                                 channel 2 stays empty for tbins = 2 -- kept as is)
+        counts accumulated by sparse_coo(...).coalesce()
+    The reference needs a SIGNED timestamp dtype here (torch cannot promote a uint32 window); ``t`` is taken as int64.
+    Empty input -> zeros (the reference returns the transposed shape [n, 2*tbins, W, H] for it; here always [.., H, W]).
+    window == 0 keeps no event -> zeros.
+    """
+    out = np.zeros((num_slices, 2 * tbins, height, width), dtype=np.float64)
+    if len(t) == 0:
+        return out
+    t = np.asarray(t).astype(np.int64)
+    t = t - t[0]
+    window = (t[-1] - t[0]) // num_slices
+    keep = t < window * num_slices
+    if window == 0 or not keep.any():
+        return out
+    t, xs, ys, ps = t[keep], np.asarray(x)[keep].astype(np.int64), np.asarray(y)[keep].astype(np.int64), np.asarray(p)[keep].astype(np.int64)
+    sl = np.floor(t.astype(np.int32).astype(np.float32) / np.float32(window)).astype(np.int64)
+    tbin = (t % window) // (window / tbins)
+    ch = ((ps + 1) * (tbin + 1) - 1).astype(np.int64)
+    np.add.at(out, (sl, ch, ys, xs), 1.0)
+    return out
+
+
+def time_surface(t, x, y, p, num_slices, height, width, tau):
+    """Exponential time surfaces [num_slices, 2, H, W] float64 at the end of each micro-slice.
+
+    Follows GEN1Dataset.agrregate(method='timesurface') (gen1.py:362-369) = slice_events (gen1.py:313-328) +
+    to_timesurface_numpy (yolox/utils/event_reps.py:141-160):
+        memory[p, y, x] = timestamp of the latest event so far (slices are applied in order, later writes win)
+        surface_i = exp(-((i + 1) * window + t[0] - memory) / tau)        (memory starts at 0: untouched pixels give
+                                                                          exp(-end_i / tau), tiny but not zero)
+    Empty input -> zeros.  window == 0 makes the reference index an empty first slice (IndexError): declared invalid
+    input here and returns zeros.
+    """
+    out = np.zeros((num_slices, 2, height, width), dtype=np.float64)
+    bounds = slice_bounds(t, num_slices)
+    if bounds is None:
+        return out
+    t = np.asarray(t).astype(np.int64)
+    window = (t[-1] - t[0]) // num_slices
+    if window == 0:
+        return out
+    memory = np.zeros((2, height, width), dtype=np.int64)
+    xs, ys, ps = np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64), np.asarray(p).astype(np.int64)
+    for i, (a, b) in enumerate(bounds):
+        # later events win: timestamps ascend, so the maximum is the last write
+        np.maximum.at(memory, (ps[a:b], ys[a:b], xs[a:b]), t[a:b])
+        diff = -((i + 1) * window + t[0] - memory)
+        out[i] = np.exp(diff / tau)
+    return out
+
+
 def synth_events(n_events, height=240, width=304, t0=1_000_000, span_us=200_000, seed=0):
     """Synthetic stream of BASELINE.md section 2 / SURVEY 8d config 1."""
     rng = np.random.default_rng(seed)

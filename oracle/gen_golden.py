@@ -85,6 +85,59 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+# ----------------------------------------------------------------------------- other event representations
+def gen_event_reps():
+    """voxel cube / time surface of the reference (yolox/utils/event_reps.py:92-160) on seeded synthetic streams."""
+    from types import SimpleNamespace
+    from yolox.data.datasets.gen1 import GEN1Dataset
+    from yolox.utils.event_reps import to_timesurface_numpy, to_voxel_cube_numpy
+    from oracle.events_ref import synth_events
+    dts = np.dtype([('t', 'i8'), ('x', 'i2'), ('y', 'i2'), ('p', 'i1')])   # signed fields: torch cannot promote a uint32 window
+    dtu = np.dtype([('t', 'u4'), ('x', 'u2'), ('y', 'u2'), ('p', 'u1')])
+
+    def struct(t, x, y, p, dt):
+        ev = np.zeros(len(t), dtype=dt)
+        ev['t'], ev['x'], ev['y'], ev['p'] = t, x, y, p
+        return ev
+
+    cases = {}
+    for name, (n, ns, tb, H, W, seed) in {'vc_small_n4_tb2': (3000, 4, 2, 24, 32, 21), 'vc_small_n3_tb3': (3000, 3, 3, 24, 32, 22),
+                                          'vc_tiny_n4_tb2': (9, 4, 2, 8, 8, 23), 'vc_gen1_n4_tb2': (20000, 4, 2, 240, 304, 24),
+                                          'vc_small_n5_tb1': (2000, 5, 1, 24, 32, 25)}.items():
+        t, x, y, p = synth_events(n, H, W, seed=seed)
+        out = to_voxel_cube_numpy(struct(t, x, y, p, dts), [W, H, 2], ns, tbins=tb)
+        assert out.shape == (ns, 2 * tb, H, W) and (out == np.round(out)).all()
+        cases[name] = dict(t=t, x=x, y=y, p=p, ns=ns, tbins=tb, H=H, W=W, out=out.astype(np.int32))
+    t, x, y, p = synth_events(50, 8, 8, seed=26)
+    one = np.full(50, 777, np.uint32)                                       # window == 0: nothing kept
+    cases['vc_same_timestamp'] = dict(t=one, x=x, y=y, p=p, ns=4, tbins=2, H=8, W=8,
+                                      out=to_voxel_cube_numpy(struct(one, x, y, p, dts), [8, 8, 2], 4, tbins=2).astype(np.int32))
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f'{name}/{k}'] = np.asarray(v)
+    save('events_voxel_cube', names=np.array(sorted(cases)), **flat)
+
+    cases = {}
+    for name, (n, ns, H, W, tau, seed, dt) in {'ts_small_n4': (3000, 4, 24, 32, 50e3, 31, dtu), 'ts_small_n8': (3000, 8, 24, 32, 10e3, 32, dtu),
+                                               'ts_tiny_n4': (9, 4, 8, 8, 50e3, 33, dtu), 'ts_gen1_n4': (20000, 4, 240, 304, 50e3, 34, dtu),
+                                               'ts_small_n3_signed': (3000, 3, 24, 32, 50e3, 35, dts)}.items():
+        t, x, y, p = synth_events(n, H, W, seed=seed)
+        me = SimpleNamespace(img_size=(H, W), slice_args={'micro_slice': ns})
+        me.slice_events = lambda e, k, overlap=0: GEN1Dataset.slice_events(me, e, k, overlap)
+        out = GEN1Dataset.agrregate(me, struct(t, x, y, p, dt), 'timesurface')       # tau = 50e3 hard-coded at gen1.py:369
+        if tau != 50e3:
+            slices, d = me.slice_events(struct(t, x, y, p, dt), ns)
+            out = to_timesurface_numpy(slices, [W, H, 2], dt=d, tau=tau)
+        assert out.shape == (ns, 2, H, W)
+        cases[name] = dict(t=t, x=x, y=y, p=p, ns=ns, H=H, W=W, tau=tau, out=out)
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f'{name}/{k}'] = np.asarray(v)
+    save('events_time_surface', names=np.array(sorted(cases)), **flat)
+
+
 # ----------------------------------------------------------------------------- K1 events
 def gen_events():
     from types import SimpleNamespace
@@ -381,11 +434,11 @@ def gen_models():
 def main():
     torch.set_num_threads(8)
     setup_reference_imports()
-    which = sys.argv[1:] or ['events', 'embeddings', 'lif', 'blocks', 'models']
+    which = sys.argv[1:] or ['events', 'reps', 'embeddings', 'lif', 'blocks', 'models']
     for w in which:
         print(f'[{w}]')
         {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
-         'models': gen_models}[w]()
+         'models': gen_models, 'reps': gen_event_reps}[w]()
     assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
 
 

@@ -114,6 +114,70 @@ def test_voxel_grid_golden(dev):
         np.testing.assert_allclose(got, c['out'], rtol=1e-9, atol=1e-12, err_msg=name)
 
 
+def _ev_dev(c, dev):
+    return (_t(c['t'].view(np.int32), dev).view(torch.uint32), _t(c['x'].view(np.int16), dev).view(torch.uint16),
+            _t(c['y'].view(np.int16), dev).view(torch.uint16), _t(c['p'], dev))
+
+
+def test_voxel_cube_golden_and_batch(dev):
+    """eas_event_voxel_cube against the reference's to_voxel_cube_numpy outputs (bit-exact counts) and, batched with an empty
+    sample in the middle, against the oracle."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    cases = split_cases(load_golden('events_voxel_cube'))
+    for name, c in cases.items():
+        off = torch.tensor([0, len(c['t'])], dtype=torch.int64, device=dev)
+        out = ops.event_voxel_cube(*_ev_dev(c, dev), off, int(c['ns']), int(c['H']), int(c['W']), tbins=int(c['tbins']))
+        assert out.dtype == torch.int32 and np.array_equal(out[0].cpu().numpy(), c['out']), name
+    names = ['vc_small_n4_tb2', None, 'vc_small_n5_tb1', 'vc_small_n3_tb3']          # same sensor, ragged, one empty sample
+    parts = [cases[n] if n else None for n in names]
+    cat = {k: np.concatenate([q[k] for q in parts if q is not None]) for k in ('t', 'x', 'y', 'p')}
+    off = np.cumsum([0] + [len(q['t']) if q is not None else 0 for q in parts])
+    out = ops.event_voxel_cube(*_ev_dev(cat, dev), _t(off, dev), 4, 24, 32, tbins=2).cpu().numpy()
+    for b, q in enumerate(parts):
+        ref = np.zeros((4, 4, 24, 32)) if q is None else events_ref.voxel_cube(q['t'], q['x'], q['y'], q['p'], 4, 2, 24, 32)
+        assert np.array_equal(out[b], ref.astype(np.int32)), b
+    assert out.sum() > 0 and out[1].sum() == 0
+
+
+def test_time_surface_golden_and_batch(dev):
+    """eas_event_time_surface against the reference's agrregate('timesurface') outputs (float64 exp: 1e-13 relative) and batched
+    against the oracle; the 'latest timestamp' indices are integer work and must agree exactly (checked through log)."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    cases = split_cases(load_golden('events_time_surface'))
+    for name, c in cases.items():
+        off = torch.tensor([0, len(c['t'])], dtype=torch.int64, device=dev)
+        out = ops.event_time_surface(*_ev_dev(c, dev), off, int(c['ns']), int(c['H']), int(c['W']), tau=float(c['tau']))
+        got = out[0].cpu().numpy()
+        np.testing.assert_allclose(got, c['out'], rtol=1e-13, atol=0, err_msg=name)
+        # integer part: tau * log(surface) recovers latest - end exactly (|.| < 2^31, rounding error << 0.5)
+        assert np.array_equal(np.rint(np.log(got) * float(c['tau'])), np.rint(np.log(c['out']) * float(c['tau']))), name
+    parts = [cases['ts_small_n4'], None, cases['ts_small_n8']]
+    cat = {k: np.concatenate([q[k] for q in parts if q is not None]) for k in ('t', 'x', 'y', 'p')}
+    off = np.cumsum([0] + [len(q['t']) if q is not None else 0 for q in parts])
+    out = ops.event_time_surface(*_ev_dev(cat, dev), _t(off, dev), 4, 24, 32, tau=50e3).cpu().numpy()
+    for b, q in enumerate(parts):
+        ref = np.zeros((4, 2, 24, 32)) if q is None else events_ref.time_surface(q['t'], q['x'], q['y'], q['p'], 4, 24, 32, 50e3)
+        np.testing.assert_allclose(out[b], ref, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize('shape,k,s,cout', [((6, 8, 16, 20), 3, 1, 16), ((4, 4, 17, 23), 3, 2, 8), ((3, 2, 32, 40), 5, 1, 4), ((5, 16, 8, 10), 1, 1, 32),
+                                           ((2, 3, 64, 80), 3, 2, 24)])
+def test_spike_sop_matches_all_ones_convolution(dev, shape, k, s, cout):
+    """eas_spike_sop against calc_layer_sop's arithmetic (event_evaluator.py:473-487): a convolution with all-ones weights over the
+    input, summed -- exact for spike data (every term is a small integer), float64 on both sides."""
+    import torch.nn.functional as F
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(shape, generator=g) < 0.2).float() * torch.randint(1, 4, shape, generator=g).float()      # SEW sums 0..3
+    ref = F.conv2d(x.double(), torch.ones(cout, shape[1], k, k, dtype=torch.float64), stride=s, padding=(k - 1) // 2).sum()
+    out = ops.spike_sop(x.to(dev), k, s, cout).cpu()
+    assert float(out[0]) == float(x.double().sum()) and float(out[1]) == float(ref)
+    out2 = ops.spike_sop(x.to(dev), k, s, cout).cpu()
+    assert torch.equal(out, out2)
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def _oracle_node(kind, sg, alpha, v_reset, decay_input, detach):
     from oracle import sj_ref

@@ -204,6 +204,33 @@ def test_model_matches_cpu_oracle_on_fresh_input(dev):
     assert _frac_close(lh, lr, RTOL, 1e-4) > 0.97
 
 
+def test_energy_estimation_matches_reference_restatement(dev):
+    """eas_snn_amd.stats.energy_estimation (device taps + eas_spike_sop) against the statement-by-statement restatement of
+    EventEvaluator.energy_estimation (event_evaluator.py:466-565) on the torch-CPU oracle model with the same weights: MAC
+    counts are exact; accumulate counts depend on the spikes, which may differ by a few rounding-level flips between a GPU and a
+    CPU run of a spiking net, hence 2 %."""
+    from eas_snn_amd import stats
+    from oracle import fill, model_ref, sj_ref, stats_ref
+    from yolox.exp import get_exp
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(BASE_OPTS + ['use_spike', 'True'])
+    hip = exp.get_model()
+    ref = model_ref.build_model(use_spike='True')
+    assert fill.procedural_fill_(hip, 2.0, ann_regex=fill.ANN_KEYS['True']) == fill.procedural_fill_(ref, 2.0, ann_regex=fill.ANN_KEYS['True'])
+    batches = [torch.from_numpy(fill.poisson_events((3, 1, 4, 2, 64, 96), 0.5, seed=s)) for s in (5, 6)]
+    want = stats_ref.energy_estimation(ref, batches, T=3, reset_fn=sj_ref.reset_net)
+    got = stats.energy_estimation(hip.to(dev), [b.to(dev) for b in batches], T=3)
+    assert got['num_samples'] == want['num_samples'] == 6
+    for k in stats.GROUPS:
+        assert got['module_mac'][k] == want['module_mac'][k], k
+        np.testing.assert_allclose(got['module_ac'][k], want['module_ac'][k], rtol=2e-2, err_msg=k)
+    assert got['module_ac']['embedding'] > 0 and got['module_ac']['backbone'] > 0
+    np.testing.assert_allclose(got['ann_energy'], want['ann_energy'], rtol=1e-12)
+    np.testing.assert_allclose(got['snn_energy'], want['snn_energy'], rtol=2e-2)
+    with pytest.raises(ValueError):                                    # the reference reshapes by T: batch 2 with T = 3 is an error
+        stats.energy_estimation(hip, [batches[0][:2].to(dev)], T=3)
+
+
 def test_state_dict_roundtrip_and_writeback_switch(dev):
     from eas_snn_amd import ops
     from spikingjelly.activation_based import functional
