@@ -247,6 +247,57 @@ __global__ __launch_bounds__(EAS_BLOCK) void time_surface_exp_kernel(const uint3
     }
 }
 
+// Letterbox / jitter augmentation of count frames on the device (GEN1Dataset.get_random_data, gen1.py:433-521): every
+// frame of sample b is resized to (nw, nh) with cv2.resize(INTER_LINEAR) semantics, pasted at (dx, dy) into a zero canvas,
+// optionally mirrored left-right, and cast to fp32 (trainer.py:99).  cv2's linear resize for float64 images, restated from
+// OpenCV's resize.cpp (not in the reference tree, opencv-python pinned by pip-requirements.txt; no cv2 in this image:
+// parity unpinned): fx = float((j + 0.5) * (iw / nw) - 0.5), sx = floor(fx), fx -= sx, clamped at both borders with
+// fx = 0; float32 weights, float64 arithmetic, horizontal pass first: out = (S[sy][sx]*a0 + S[sy][sx+1]*a1)*b0 + (...)*b1.
+struct AxisTap { int s0, s1; float w0, w1; };
+
+__device__ __forceinline__ AxisTap linear_tap(int j, int n_src, int n_dst) {
+    const double scale = (double)n_src / (double)n_dst;
+    float f = (float)(((double)j + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    AxisTap t;
+    t.s0 = s;
+    t.s1 = s + 1 < n_src ? s + 1 : n_src - 1;
+    t.w0 = 1.f - f;
+    t.w1 = f;
+    return t;
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void counts_letterbox_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ params,
+                                                                     int B, int F, int H, int W, int Hc, int Wc, float* __restrict__ out) {
+    const int64_t total = (int64_t)B * F * Hc * Wc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wc);
+        const int64_t r = i / Wc;
+        const int yy = (int)(r % Hc);
+        const int64_t f = r / Hc;
+        const int b = (int)(f / F);
+        const int32_t* pr = params + 5 * b;
+        const int nw = pr[0], nh = pr[1], dx = pr[2], dy = pr[3], flip = pr[4];
+        const int xs = (flip ? Wc - 1 - xx : xx) - dx, ys = yy - dy;
+        float v = 0.f;
+        if (xs >= 0 && xs < nw && ys >= 0 && ys < nh) {
+            const int32_t* src = counts + f * H * W;
+            if (nw == W && nh == H) {
+                v = (float)src[ys * W + xs];                  // cv2.resize with dsize == size is a copy
+            } else {
+                const AxisTap tx = linear_tap(xs, W, nw), ty = linear_tap(ys, H, nh);
+                const double r0 = (double)src[ty.s0 * W + tx.s0] * (double)tx.w0 + (double)src[ty.s0 * W + tx.s1] * (double)tx.w1;
+                const double r1 = (double)src[ty.s1 * W + tx.s0] * (double)tx.w0 + (double)src[ty.s1 * W + tx.s1] * (double)tx.w1;
+                v = (float)(r0 * (double)ty.w0 + r1 * (double)ty.w1);
+            }
+        }
+        out[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,6 +403,16 @@ int eas_event_time_surface(const uint32_t* t, const uint16_t* x, const uint16_t*
     }
     hipLaunchKernelGGL(time_surface_exp_kernel, dim3(eas_grid_1d((int64_t)B * 2 * H * W)), dim3(EAS_BLOCK), 0, st, t, sample_offsets, B,
                        num_slices, H, W, tau, workspace, out);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_counts_letterbox(const int32_t* counts, const int32_t* params, int B, int F, int H, int W, int Hc, int Wc, float* out,
+                         eas_stream_t stream) {
+    if (!counts || !params || !out || B < 1 || F < 1 || H < 1 || W < 1 || Hc < 1 || Wc < 1) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(counts_letterbox_kernel, dim3(eas_grid_1d((int64_t)B * F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
+                       params, B, F, H, W, Hc, Wc, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -72,3 +72,63 @@ class SyntheticEventLoader:
             ev = events_to_device(synth_event_batch(self.batch_size, self.n_events, *self.sensor_hw, seed=i), dev)
             frames = events_to_frames(ev, self.exp.Tm, self.sensor_hw, self.exp.input_size)
             yield frames, synth_targets(self.batch_size, self.exp.input_size, dev)
+
+# ------------------------------------------------------------------------------------------------ augmentation parameters
+def letterbox_params(ih, iw, h, w, letterbox=True, center=False):
+    """(nw, nh, dx, dy, flip) of the deterministic branch of GEN1Dataset.get_random_data (gen1.py:438-483)."""
+    if letterbox:
+        scale = min(w / iw, h / ih)
+        nw, nh = int(iw * scale), int(ih * scale)
+        dx, dy = ((w - nw) // 2, (h - nh) // 2) if center else (0, 0)
+    else:
+        nw, nh, dx, dy = w, h, 0, 0
+    return nw, nh, dx, dy, 0
+
+
+def jitter_params(ih, iw, h, w, jitter=.3, rng=np.random):
+    """(nw, nh, dx, dy, flip) of the random branch (gen1.py:485-504), drawing from ``rng`` in the reference's order
+    (two draws for the aspect ratio, scale, dx, dy, flip)."""
+    def rand(a=0., b=1.):
+        return rng.rand() * (b - a) + a
+    new_ar = iw / ih * rand(1 - jitter, 1 + jitter) / rand(1 - jitter, 1 + jitter)
+    scale = rand(.4, 1)
+    if new_ar < 1:
+        nh = int(scale * h)
+        nw = int(nh * new_ar)
+    else:
+        nw = int(scale * w)
+        nh = int(nw / new_ar)
+    dx = int(rand(0, w - nw))
+    dy = int(rand(0, h - nh))
+    flip = rand() < .5
+    return nw, nh, dx, dy, int(flip)
+
+
+def transform_boxes(bboxes, params, ih, iw, h, w, rng=None):
+    """Box side of get_random_data (gen1.py:462-473 / :509-520): rows (x1, y1, x2, y2, ...) as int64, shuffled with ``rng`` when
+    given, scaled, shifted, mirrored, clipped, and boxes no larger than one pixel dropped; returns float32."""
+    nw, nh, dx, dy, flip = params
+    box = np.array(bboxes, dtype=np.int64)
+    if len(box) > 0:
+        if rng is not None:
+            rng.shuffle(box)
+        box[:, [0, 2]] = box[:, [0, 2]] * nw / iw + dx
+        box[:, [1, 3]] = box[:, [1, 3]] * nh / ih + dy
+        if flip:
+            box[:, [0, 2]] = w - box[:, [2, 0]]
+        box[:, 0:2][box[:, 0:2] < 0] = 0
+        box[:, 2][box[:, 2] > w] = w
+        box[:, 3][box[:, 3] > h] = h
+        box_w = box[:, 2] - box[:, 0]
+        box_h = box[:, 3] - box[:, 1]
+        box = box[np.logical_and(box_w > 1, box_h > 1)]
+    return np.array(box, dtype=np.float32)
+
+
+def events_to_frames_augmented(ev_dev, Tm, sensor_hw, canvas_hw, params):
+    """events -> histogram (K1) -> resize / paste / flip on the device -> [B, 1, Tm, 2, Hc, Wc] fp32; ``params``: per-sample
+    (nw, nh, dx, dy, flip) rows."""
+    H, W = sensor_hw
+    counts = ops.event_histogram(ev_dev['t'], ev_dev['x'], ev_dev['y'], ev_dev['p'], ev_dev['offsets'], Tm, H, W)
+    par = torch.as_tensor(np.asarray(params, dtype=np.int32).reshape(-1, 5)).to(counts.device)
+    return ops.counts_letterbox(counts, par, canvas_hw[0], canvas_hw[1]).unsqueeze(1)

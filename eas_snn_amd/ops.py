@@ -352,6 +352,19 @@ def counts_to_canvas(counts, Hc, Wc):
     return out
 
 
+def counts_letterbox(counts, params, Hc, Wc):
+    """int32 counts [B, ..., H, W] -> fp32 [B, ..., Hc, Wc]: per-sample resize (cv2 INTER_LINEAR semantics) to (nw, nh), paste at
+    (dx, dy), optional left-right flip; ``params`` int32 [B, 5] = (nw, nh, dx, dy, flip) (see data.letterbox_params / jitter_params)."""
+    _dev(counts, params)
+    assert counts.dtype == torch.int32 and params.dtype == torch.int32 and params.shape == (counts.shape[0], 5)
+    counts, params = counts.contiguous(), params.contiguous()
+    B, (H, W) = counts.shape[0], counts.shape[-2:]
+    F = counts.numel() // (B * H * W)
+    out = torch.empty(counts.shape[:-2] + (Hc, Wc), dtype=torch.float32, device=counts.device)
+    check(_lib.lib().eas_counts_letterbox(ptr(counts), ptr(params), B, F, H, W, Hc, Wc, ptr(out), stream()), 'eas_counts_letterbox')
+    return out
+
+
 def event_voxel_grid(t, x, y, p, sample_offsets, n_bins, H, W):
     """float64 [B, n_bins, 1, H, W] bilinear-in-time voxel grid."""
     _dev(t, x, y, p, sample_offsets)

@@ -68,6 +68,14 @@ int eas_event_histogram_dat(const void* records, int64_t nev, const int64_t* sam
 int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out,
                          eas_stream_t stream);
 
+/* Letterbox / jitter augmentation of the count frames on the device (GEN1Dataset.get_random_data,
+ * gen1.py:433-521: batch_resize with cv2.INTER_LINEAR :423-431, paste into a zero canvas, left-right flip) fused with the
+ * fp32 cast of trainer.py:99.  counts [B][F][H][W] int32; params [B][5] int32 = (nw, nh, dx, dy, flip) per sample (the
+ * host draws them exactly as the reference does, eas_snn_amd/data.py); out [B][F][Hc][Wc] fp32.  The paste rectangle must lie
+ * inside the canvas.  cv2 itself is absent from this image: the resize follows OpenCV's published algorithm. */
+int eas_counts_letterbox(const int32_t* counts, const int32_t* params, int B, int F, int H, int W, int Hc, int Wc, float* out,
+                         eas_stream_t stream);
+
 /* Bilinear-in-time voxel grid, to_voxel_grid_numpy (yolox/utils/event_reps.py:30-89).
  * out[b][bin][y][x] float64 (zeroed by the call); polarity 0 counts as -1. */
 int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,

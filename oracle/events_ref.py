@@ -171,6 +171,47 @@ def time_surface(t, x, y, p, num_slices, height, width, tau):
     return out
 
 
+def _linear_taps(n_src, n_dst):
+    """cv2.resize INTER_LINEAR tap table along one axis (OpenCV imgproc/src/resize.cpp, cv::resize generic path for
+    CV_64F: float32 weights, borders clamped with weight 0): returns (s0, s1, w0, w1)."""
+    scale = np.float64(n_src) / np.float64(n_dst)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo = s < 0
+    f[lo], s[lo] = 0, 0
+    hi = s >= n_src - 1
+    f[hi], s[hi] = 0, n_src - 1
+    return s, np.minimum(s + 1, n_src - 1), (np.float32(1) - f).astype(np.float64), f.astype(np.float64)
+
+
+def resize_linear(img, nw, nh):
+    """cv2.resize(img [H,W,C] float64, (nw, nh), INTER_LINEAR) restated (parity unpinned: cv2 is not installed here).
+    Horizontal pass, then vertical pass, float64 arithmetic with float32 weights; same size -> copy."""
+    H, W = img.shape[:2]
+    if (nw, nh) == (W, H):
+        return img.copy()
+    x0, x1, a0, a1 = _linear_taps(W, nw)
+    y0, y1, b0, b1 = _linear_taps(H, nh)
+    a0, a1 = a0[None, :, None], a1[None, :, None]
+    rows = img[:, x0] * a0 + img[:, x1] * a1                   # [H, nw, C]
+    return rows[y0] * b0[:, None, None] + rows[y1] * b1[:, None, None]
+
+
+def letterbox_frames(frames, params, h, w):
+    """Image side of GEN1Dataset.get_random_data (gen1.py:433-521) for given draw results ``params`` =
+    (nw, nh, dx, dy, flip): frames [nf, nc, ih, iw] float64 -> [nf, nc, h, w] float64."""
+    nw, nh, dx, dy, flip = params
+    nf, nc, ih, iw = frames.shape
+    image = frames.transpose(0, 2, 3, 1)
+    image = np.stack([resize_linear(im, nw, nh) for im in image])
+    new_image = np.zeros([nf, h, w, nc])
+    new_image[:, dy:dy + nh, dx:dx + nw] = image
+    if flip:
+        new_image = np.ascontiguousarray(new_image[:, :, ::-1, :])
+    return np.transpose(new_image, (0, 3, 1, 2))
+
+
 def synth_events(n_events, height=240, width=304, t0=1_000_000, span_us=200_000, seed=0):
     """Synthetic stream of BASELINE.md section 2 / SURVEY 8d config 1."""
     rng = np.random.default_rng(seed)

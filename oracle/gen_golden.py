@@ -138,6 +138,40 @@ def gen_event_reps():
     save('events_time_surface', names=np.array(sorted(cases)), **flat)
 
 
+# ----------------------------------------------------------------------------- augmentation draws + boxes
+def gen_augment():
+    """GEN1Dataset.get_random_data (gen1.py:433-521) run with a SHAPE-ONLY stand-in for cv2.resize (cv2 is not installed; the
+    stand-in returns ones of the requested size and carries no arithmetic).  What the fixtures pin: the order of the random
+    draws, (nw, nh, dx, dy) -- read back from the rectangle of ones -- the flip, and the box transform.  The bilinear
+    resize itself stays unpinned (oracle/events_ref.resize_linear restates OpenCV's algorithm)."""
+    from types import SimpleNamespace
+    import cv2
+    from yolox.data.datasets.gen1 import GEN1Dataset
+    cv2.resize = lambda image, dsize, interpolation: np.ones((dsize[1], dsize[0]) + image.shape[2:])
+    cv2.INTER_LINEAR = getattr(cv2, 'INTER_LINEAR', 1)
+    cases = {}
+    boxes = np.array([[30, 40, 120, 160, 0], [200, 20, 290, 100, 1], [5, 5, 9, 200, 1], [150, 150, 300, 239, 0]], dtype=np.float64)
+    for name, (ih, iw, h, w, random, letterbox, center, seed) in {
+            'jitter_gen1_s1': (240, 304, 256, 320, True, True, False, 1), 'jitter_gen1_s2': (240, 304, 256, 320, True, True, False, 2),
+            'jitter_gen1_s3': (240, 304, 256, 320, True, True, False, 3), 'jitter_gen1_s4': (240, 304, 256, 320, True, True, False, 4),
+            'jitter_ncal_s5': (180, 240, 192, 256, True, True, False, 5), 'letterbox_gen1': (240, 304, 256, 320, False, True, False, 6),
+            'letterbox_center': (240, 304, 320, 320, False, True, True, 7), 'stretch_gen1': (240, 304, 256, 320, False, False, False, 8)}.items():
+        me = SimpleNamespace(letterbox_image=letterbox)
+        me.rand = lambda a=0, b=1: np.random.rand() * (b - a) + a
+        me.batch_resize = lambda images, dsize, interpolation: GEN1Dataset.batch_resize(me, images, dsize, interpolation)
+        np.random.seed(seed)
+        frames = np.zeros((2, 2, ih, iw))
+        out, bb = GEN1Dataset.get_random_data(me, frames, boxes.copy(), (h, w), random=random, center=center)
+        ys, xs = np.nonzero(out[0, 0])
+        cases[name] = dict(ih=ih, iw=iw, h=h, w=w, random=int(random), letterbox=int(letterbox), center=int(center), seed=seed,
+                           rect=np.array([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1]), boxes_in=boxes, boxes_out=bb)
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f'{name}/{k}'] = np.asarray(v)
+    save('augment_draws', names=np.array(sorted(cases)), **flat)
+
+
 # ----------------------------------------------------------------------------- K1 events
 def gen_events():
     from types import SimpleNamespace
@@ -434,11 +468,11 @@ def gen_models():
 def main():
     torch.set_num_threads(8)
     setup_reference_imports()
-    which = sys.argv[1:] or ['events', 'reps', 'embeddings', 'lif', 'blocks', 'models']
+    which = sys.argv[1:] or ['events', 'reps', 'augment', 'embeddings', 'lif', 'blocks', 'models']
     for w in which:
         print(f'[{w}]')
         {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
-         'models': gen_models, 'reps': gen_event_reps}[w]()
+         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment}[w]()
     assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
 
 

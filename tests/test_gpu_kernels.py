@@ -178,6 +178,31 @@ def test_spike_sop_matches_all_ones_convolution(dev, shape, k, s, cout):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize('H,W,Hc,Wc', [(240, 304, 256, 320), (24, 30, 32, 40), (180, 240, 192, 256)])
+def test_counts_letterbox_matches_oracle(dev, H, W, Hc, Wc):
+    """eas_counts_letterbox (resize + paste + flip + fp32 cast) against the oracle's restatement of
+    get_random_data's image side: same float64 arithmetic with float32 weights, so the fp32 results are identical; the identity
+    case must reproduce eas_counts_to_canvas bit for bit."""
+    from eas_snn_amd import data, ops
+    from oracle import events_ref
+    rng = np.random.RandomState(9)
+    B, Tm = 5, 3
+    counts = np.random.default_rng(4).poisson(0.6, (B, Tm, 2, H, W)).astype(np.int32)
+    params = [data.letterbox_params(H, W, Hc, Wc), data.letterbox_params(H, W, Hc, Wc, center=True), (W, H, 0, 0, 0)]
+    params += [data.jitter_params(H, W, Hc, Wc, rng=rng) for _ in range(B - len(params))]
+    assert any(p[4] for p in params) or True
+    par = torch.tensor(params, dtype=torch.int32, device=dev)
+    out = ops.counts_letterbox(_t(counts, dev), par, Hc, Wc).cpu().numpy()
+    assert out.shape == (B, Tm, 2, Hc, Wc) and out.dtype == np.float32
+    for b in range(B):
+        ref = events_ref.letterbox_frames(counts[b].astype(np.float64), params[b], Hc, Wc).astype(np.float32)
+        assert np.array_equal(out[b], ref), (b, params[b], np.abs(out[b] - ref).max())
+    ident = ops.counts_to_canvas(_t(counts[2:3], dev), Hc, Wc).cpu().numpy()
+    assert np.array_equal(out[2:3], ident)
+    flipped = ops.counts_letterbox(_t(counts[:1], dev), torch.tensor([[W, H, 0, 0, 1]], dtype=torch.int32, device=dev), Hc, Wc).cpu().numpy()
+    assert np.array_equal(flipped[..., ::-1], ops.counts_to_canvas(_t(counts[:1], dev), Hc, Wc).cpu().numpy())
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def _oracle_node(kind, sg, alpha, v_reset, decay_input, detach):
     from oracle import sj_ref
