@@ -912,6 +912,30 @@ def spp_pool_cat(x, ks):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ detections
+def postprocess_device(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    """(rows [B, A, 7], counts int32 [B]) on the device, no host synchronisation (eas_postprocess)."""
+    _dev(prediction)
+    pred = _f32c(prediction)
+    B, A, row = pred.shape
+    if row != 5 + num_classes:
+        raise ValueError(f'prediction rows have {row} columns, expected 5 + {num_classes}')
+    L = _lib.lib()
+    out = torch.empty((B, A, 7), dtype=torch.float32, device=pred.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=pred.device)
+    ws = torch.empty(L.eas_postprocess_workspace_bytes(B, A), dtype=torch.uint8, device=pred.device)
+    check(L.eas_postprocess(ptr(pred), B, A, int(num_classes), float(conf_thre), float(nms_thre), int(bool(class_agnostic)), ptr(out),
+                            ptr(cnt), ptr(ws), stream()), 'eas_postprocess')
+    return out, cnt
+
+
+def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    """``yolox.utils.postprocess`` (boxes.py:33-77): list with one [n, 7] tensor per image (None where nothing is kept)."""
+    out, cnt = postprocess_device(prediction, num_classes, conf_thre, nms_thre, class_agnostic)
+    counts = cnt.tolist()                                   # the one host synchronisation: the result is a ragged python list
+    return [out[i, :n] if n else None for i, n in enumerate(counts)]
+
+
 # ------------------------------------------------------------------------------------------------ BN step counters
 _DEFERRED = None
 

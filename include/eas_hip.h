@@ -274,6 +274,17 @@ int64_t eas_spike_sop_workspace_doubles(void);
 int eas_spike_sop(const float* x, int64_t NI, int Cin, int H, int W, int ksize, int stride, int Cout, double* out,
                   double* workspace, eas_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Detection post-processing.  Replaces ``postprocess`` (yolox/utils/boxes.py:33-77; called by the
+ * evaluators, e.g. psee_evaluator.py:212) including torchvision.ops.nms / batched_nms (torchvision 0.16.1, restated).
+ * pred [B][A][5+ncls] = decoded head output (cx, cy, w, h, obj, class scores), NOT modified (the reference overwrites the
+ * first four columns with the corners in place).  out [B][A][7]: rows (x1, y1, x2, y2, obj_conf, class_conf, class_pred) of
+ * the kept detections of image b in descending score order, out_count[b] of them.  A <= 16384.
+ * workspace: eas_postprocess_workspace_bytes(B, A) bytes. */
+int64_t eas_postprocess_workspace_bytes(int B, int A);
+int eas_postprocess(const float* pred, int B, int A, int ncls, float conf_thre, float nms_thre, int class_agnostic, float* out,
+                    int* out_count, void* workspace, eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,6 +203,44 @@ def test_counts_letterbox_matches_oracle(dev, H, W, Hc, Wc):
     assert np.array_equal(flipped[..., ::-1], ops.counts_to_canvas(_t(counts[:1], dev), Hc, Wc).cpu().numpy())
 
 
+def _synth_predictions(B, A, ncls, seed, clusters=12):
+    """decoded head output with heavily overlapping boxes around a few centres (so that the NMS has work) and a spread of scores"""
+    rng = np.random.default_rng(seed)
+    cen = rng.uniform(20, 300, (B, clusters, 2))
+    pick = rng.integers(0, clusters, (B, A))
+    cxy = np.take_along_axis(cen, pick[..., None].repeat(2, -1), 1) + rng.normal(0, 6, (B, A, 2))
+    wh = rng.uniform(15, 80, (B, A, 2))
+    obj = rng.uniform(0, 1, (B, A, 1)) ** 2
+    cls = rng.uniform(0, 1, (B, A, ncls))
+    return np.concatenate([cxy, wh, obj, cls], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize('B,A,ncls,conf,thr,agnostic', [(3, 1680, 2, 0.01, 0.65, False), (2, 1680, 2, 0.3, 0.45, True), (2, 700, 100, 0.001, 0.65, False),
+                                                        (1, 5600, 3, 0.0005, 0.65, False), (2, 90, 1, 0.9999, 0.5, False)])
+def test_postprocess_matches_restated_reference(dev, B, A, ncls, conf, thr, agnostic):
+    """eas_postprocess (confidence mask + class-aware NMS for the whole batch) against the numpy restatement of
+    yolox/utils/boxes.py:33-77 + torchvision's nms / batched_nms: identical kept sets, order and rows.  (1, 5600, 3) keeps more than
+    5000 candidates and takes the per-class branch; the last case keeps nothing for some image (None)."""
+    from eas_snn_amd import ops
+    from oracle import postprocess_ref
+    from yolox.utils import postprocess
+    pred = _synth_predictions(B, A, ncls, seed=A + ncls)
+    before = pred.copy()
+    got = postprocess(_t(pred, dev), ncls, conf, thr, class_agnostic=agnostic)
+    want = postprocess_ref.postprocess(pred, ncls, conf, thr, class_agnostic=agnostic)
+    assert np.array_equal(pred, before) and len(got) == len(want) == B
+    for g, w in zip(got, want):
+        if w is None:
+            assert g is None
+            continue
+        assert g is not None and g.shape == w.shape, (None if g is None else g.shape, w.shape)
+        assert np.array_equal(g.cpu().numpy(), w)
+    rows, cnt = ops.postprocess_device(_t(pred, dev), ncls, conf, thr, agnostic)
+    assert rows.shape == (B, A, 7) and cnt.tolist() == [0 if w is None else len(w) for w in want]
+    if A == 5600:
+        assert max(int((p[:, 4] * p[:, 5:].max(1) >= conf).sum()) for p in pred) > 5000
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def _oracle_node(kind, sg, alpha, v_reset, decay_input, detach):
     from oracle import sj_ref
