@@ -39,6 +39,8 @@ struct WgGeom {
     int RT, rows_seg, nseg, rows_in, RS, Q;
     int total_rows, ntiles, kslices;
     int ci_blocks;
+    int pitchX, pitchY;      // row strides of x / grad_y in floats (a column part of a wider image keeps the image's pitch)
+    int own_lo, own_hi;      // grad_y columns of this (sub-)image that count; the others are read as zeros
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     const int unitsA = TP / VEC, nA = unitsA * 4 * PM;
     const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, unitsB = g.nseg * units_seg, nB = unitsB * 4 * PN;
     const int nitems = nA + nB;
-    const size_t planeY = (size_t)g.Ho * g.Wo, planeX = (size_t)g.Hi * g.Wi;
+    const size_t planeY = (size_t)g.Ho * g.pitchY, planeX = (size_t)g.Hi * g.pitchX;
     int it_kind[NIT], it_seg[NIT], it_row[NIT], it_col[NIT], it_ch[NIT], it_lofs[NIT];   // kind: 0 grad_y, 1 x, 2 padding (zeros)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -175,12 +177,12 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             const int ir = r0 * S - 1 + it_row[it];
             ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin;
             const int ch = ci0 + it_ch[it] < g.Cin ? ci0 + it_ch[it] : g.Cin - 8;
-            src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.Wi + it_col[it];
+            src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.pitchX + it_col[it];
             plane = planeX;
         } else {
-            ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout;
+            ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout && it_col[it] >= g.own_lo && it_col[it] < g.own_hi;
             const int ch = co0 + it_ch[it] < g.Cout ? co0 + it_ch[it] : g.Cout - 8;
-            src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.Wo + (ok ? it_col[it] : 0);
+            src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.pitchY + (ok ? it_col[it] : 0);
             plane = planeY;
         }
         const float* sp = ok ? src : eas_wg_zero_page;
@@ -366,6 +368,7 @@ bool wg_geom_cap(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int strid
     g.Q = g.nseg * g.rows_in * g.RS;
     g.total_rows = NI * g.Ho;
     g.ntiles = (g.total_rows + g.RT - 1) / g.RT;
+    g.pitchX = Wi; g.pitchY = g.Wo; g.own_lo = 0; g.own_hi = g.Wo;
     return true;
 }
 
@@ -382,6 +385,52 @@ bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, i
     return false;
 }
 
+// A layer whose output rows do not fit the 80-pixel reduction tile (or whose staged input rows do not fit LDS) is cut into
+// column parts: part p owns TW output columns and runs as a convolution over the sub-image made of its own columns plus
+// kExt more on each inner side (so every staged vector stays 16-byte aligned); grad_y columns outside the owned range are
+// read as zeros, which makes the sub-image's artificial zero halo irrelevant.  Row pitch stays the full image's.
+constexpr int kExt = 4;
+constexpr int kMaxParts = 16;
+struct WgPart { WgGeom g; WgPlan p; int xoff, yoff, slab0; };
+
+// returns the number of parts (0 = unsupported); total slab count in *slabs
+int wg_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms, WgPart* parts, int* slabs) {
+    WgGeom g{};
+    *slabs = 0;
+    if (wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) {
+        parts[0].g = g;
+        parts[0].p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
+        parts[0].xoff = parts[0].yoff = parts[0].slab0 = 0;
+        *slabs = parts[0].p.kslices;
+        return 1;
+    }
+    const int Wo = (Wi + 2 - 3) / stride + 1;
+    if (Wi % 4 != 0 || Wo % 4 != 0 || Wo * stride != Wi) return 0;
+    for (int TW = 40; TW >= 8; TW -= 4) {
+        if (Wo % TW != 0 || Wo / TW > kMaxParts || Wo / TW < 2) continue;
+        const int np = Wo / TW;
+        bool ok = true;
+        int total = 0;
+        for (int p = 0; p < np && ok; ++p) {
+            const int c0 = p * TW;
+            const int lo = c0 - kExt < 0 ? 0 : c0 - kExt, hi = c0 + TW + kExt > Wo ? Wo : c0 + TW + kExt;
+            WgGeom gp{};
+            ok = wg_geom(gp, NI, Cin, Cout, Hi, (hi - lo) * stride, stride, x_terms) && gp.Wo == hi - lo;
+            if (!ok) break;
+            gp.pitchX = Wi; gp.pitchY = Wo; gp.own_lo = c0 - lo; gp.own_hi = c0 - lo + TW;
+            parts[p].g = gp;
+            parts[p].p = wg_plan(Cin, Cout, stride, x_terms, gp.ntiles);
+            parts[p].xoff = lo * stride; parts[p].yoff = lo; parts[p].slab0 = total;
+            total += parts[p].p.kslices;
+        }
+        if (ok) {
+            *slabs = total;
+            return np;
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW);
@@ -391,10 +440,11 @@ extern "C" {
 
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
     if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi) * Cout * Cin : 0;
-    WgGeom g{};
-    if (ksize != 3 || !wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
-    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
-    return (int64_t)p.kslices * Cout * Cin * 9;
+    if (ksize != 3) return 0;
+    WgPart parts[kMaxParts];
+    int slabs = 0;
+    if (!wg_parts(NI, Cin, Cout, Hi, Wi, stride, x_terms, parts, &slabs)) return 0;
+    return (int64_t)slabs * Cout * Cin * 9;
 }
 
 // grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and grad_y[NI][Cout][Ho][Wo].
@@ -418,15 +468,23 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
     }
     if (ksize != 3 || (stride != 1 && stride != 2) || Cin % 8 != 0 || Cout % 8 != 0 || Wi % 2 != 0) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
-    WgGeom g{};
-    if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;
-    if (g.Wo % 2 != 0 || (g.Ho * g.Wo) % 4 != 0) return EAS_ERR_UNSUPPORTED;
-    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
-    g.kslices = p.kslices;
+    WgPart parts[kMaxParts];
+    int slabs = 0;
+    const int np = wg_parts(NI, Cin, Cout, Hi, Wi, stride, x_terms, parts, &slabs);
+    if (np == 0) return EAS_ERR_UNSUPPORTED;
     hipStream_t st = eas_s(stream);
-    const bool v4 = Wi % 4 == 0 && g.Wo % 4 == 0;
+    const int n = Cout * Cin * 9;
     int rc = EAS_ERR_UNSUPPORTED;
-#define EAS_WG(S_, XT_, PM_, PN_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4>(x, grad_y, workspace, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2>(x, grad_y, workspace, g, st))
+    for (int ip = 0; ip < np; ++ip) {
+        WgGeom g = parts[ip].g;
+        const WgPlan p = parts[ip].p;
+        if (g.Wo % 2 != 0 || (g.Ho * g.Wo) % 4 != 0) return EAS_ERR_UNSUPPORTED;
+        g.kslices = p.kslices;
+        const float* xp = x + parts[ip].xoff;
+        const float* gyp = grad_y + parts[ip].yoff;
+        float* wsp = workspace + (size_t)parts[ip].slab0 * n;
+        const bool v4 = g.Wi % 4 == 0 && g.Wo % 4 == 0 && parts[ip].xoff % 4 == 0 && parts[ip].yoff % 4 == 0;
+#define EAS_WG(S_, XT_, PM_, PN_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4>(xp, gyp, wsp, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2>(xp, gyp, wsp, g, st))
 #define EAS_WG_SHAPE(S_, XT_)                                                  \
     do {                                                                       \
         if (p.pm == 2 && p.pn == 2) rc = EAS_WG(S_, XT_, 2, 2);                \
@@ -434,16 +492,16 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
         else if (p.pn == 2) rc = EAS_WG(S_, XT_, 1, 2);                        \
         else rc = EAS_WG(S_, XT_, 1, 1);                                       \
     } while (0)
-    if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1);
-    else if (stride == 1) EAS_WG_SHAPE(1, 3);
-    else if (x_terms == 1) EAS_WG_SHAPE(2, 1);
-    else EAS_WG_SHAPE(2, 3);
+        if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1);
+        else if (stride == 1) EAS_WG_SHAPE(1, 3);
+        else if (x_terms == 1) EAS_WG_SHAPE(2, 1);
+        else EAS_WG_SHAPE(2, 3);
 #undef EAS_WG_SHAPE
 #undef EAS_WG
-    if (rc != EAS_OK) return rc;
-    EAS_CHECK_LAUNCH();
-    const int n = Cout * Cin * 9;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grad_w, n, g.kslices);
+        if (rc != EAS_OK) return rc;
+        EAS_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grad_w, n, slabs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -539,7 +539,10 @@ CONV_CASES = [  # NI, Cin, Cout, H, W, k, stride, spikes
     (2, 24, 40, 12, 16, 3, 1, False), (2, 8, 32, 16, 16, 3, 1, False), (2, 64, 128, 16, 20, 3, 2, True), (2, 32, 64, 16, 20, 3, 2, False),
     (3, 64, 32, 8, 10, 1, 1, True), (2, 128, 64, 16, 20, 1, 1, False), (2, 32, 32, 64, 80, 3, 1, True), (5, 128, 128, 16, 20, 3, 1, True),
     (4, 256, 256, 8, 10, 3, 1, True), (1, 8, 5, 7, 10, 3, 1, False), (2, 128, 2, 8, 10, 1, 1, False), (3, 40, 72, 10, 12, 3, 2, False),
-    (2, 1024, 512, 8, 10, 1, 1, True), (1, 16, 16, 6, 4, 3, 1, True)]
+    (2, 1024, 512, 8, 10, 1, 1, True), (1, 16, 16, 6, 4, 3, 1, True),
+    # output rows wider than the 80-pixel reduction tile: the weight gradient runs in column parts (stem / dark2.0 shapes at 128x160)
+    (2, 8, 32, 16, 160, 3, 1, False), (2, 32, 64, 16, 160, 3, 2, False), (2, 32, 32, 8, 96, 3, 1, True), (1, 16, 16, 8, 240, 3, 1, True),
+    (2, 64, 64, 8, 320, 3, 2, True)]
 
 
 @pytest.mark.gpu
@@ -556,9 +559,17 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         conv.weight.copy_(w)
     xd = x.to(dev).requires_grad_(True)
     assert ops.conv_eligible(xd, conv)
+    if k == 3 and Cout % 8 == 0:          # the weight gradient of these runs on the own kernel too (no library fallback)
+        from eas_snn_amd import _lib
+        assert _lib.lib().eas_conv_wgrad_workspace_floats(NI, Cin, Cout, H, W, k, s, 1 if spikes else 3) > 0
     y = ops.conv2d(xd, conv, small_int=spikes)
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
-    y.backward(gy.to(dev))
+    wide = ops.CONV_POLICY['wgrad3_wide']
+    ops.CONV_POLICY['wgrad3_wide'] = 'mfma'          # column-part weight gradient for rows wider than the reduction tile
+    try:
+        y.backward(gy.to(dev))
+    finally:
+        ops.CONV_POLICY['wgrad3_wide'] = wide
     x64 = x.double().requires_grad_(True)
     w64 = w.double().requires_grad_(True)
     b64 = conv.bias.detach().double().cpu() if conv.bias is not None else None
