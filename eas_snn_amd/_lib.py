@@ -16,6 +16,12 @@ _lib = None
 _f32p, _i32p, _u32p, _u16p, _u8p, _i64p, _f64p = (C.c_void_p,) * 7   # raw device addresses
 _P = C.c_void_p
 
+class EasBnPending(C.Structure):
+    """include/eas_hip.h EasBnPending: statistics whose finalize happens inside the consuming kernel."""
+    _fields_ = [('partial', C.c_void_p), ('chunks', C.c_int), ('replicas', C.c_int), ('count', C.c_double), ('eps', C.c_float),
+                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p)]
+
+
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
 PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
@@ -43,6 +49,12 @@ PROTOTYPES = {
     'eas_bn_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                  C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_silu_fwd': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
+    'eas_bn_silu_fwd_ex': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.POINTER(EasBnPending), _P]),
+    'eas_bn_stats_partial': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'eas_bn_lif_fwd_ex': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P]),
+    'eas_bn_lif_bwd_ex': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                    C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 3 + [_P]),
     'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, _P]),

@@ -67,12 +67,21 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
     def _use_batch_stats(self):
         return self.training or (self.running_mean is None and self.running_var is None)
 
-    def fused_with(self, node, y_seq, want_mean=False):
-        """spikes = node(self(y_seq)) for y_seq [T,N,C,H,W] without materialising the BN output."""
-        if not (self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
-                and (self.momentum is not None or not self.training)):
+    def can_fuse(self, y_seq):
+        return bool(self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
+                    and (self.momentum is not None or not self.training))
+
+    def fused_with(self, node, y_seq, want_mean=False, residual=None, cat=None):
+        """spikes = node(self(y_seq)) for y_seq [T,N,C,H,W] without materialising the BN output.
+        residual: the result is spikes + residual (SEW shortcut) from the same kernel; cat = (buffer [T,N,Ctot,H,W], first
+        channel): the result is written into that channel range of the buffer and returned as a view of it."""
+        if not self.can_fuse(y_seq):
+            if cat is not None:
+                raise RuntimeError('in-place concatenation needs the fused BN+LIF path (callers check network_blocks._fusable)')
             y_seq = y_seq.contiguous()
             out = node(self(y_seq))
+            if residual is not None:
+                out = out + residual
             return (out, ops.time_mean(out)) if want_mean else out
         batch = self._use_batch_stats()
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
@@ -84,10 +93,11 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
             y_seq if base is None else base, self.weight, self.bias, self.running_mean if (update or not batch) else None,
             self.running_var if (update or not batch) else None, batch, self.momentum if update else None, self.eps,
             node._v_in(y_seq[0]), a['w'], a['k_const'], a['v_th'], a['v_reset'], a['flags'], a['surrogate'], a['alpha'],
-            want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0])
+            want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0], residual=residual, cat=cat)
         if v_out is not None:
             node.v = v_out
-        ops.mark_small_int(spikes)          # the neuron's output is 0/1 by construction
+        if residual is None or ops.is_small_int(residual):
+            ops.mark_small_int(spikes)      # the neuron's output is 0/1 by construction (plus a spike-count residual)
         return (spikes, mean) if want_mean else spikes
 
 

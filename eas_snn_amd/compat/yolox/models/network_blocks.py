@@ -40,6 +40,18 @@ def _pool_ksize(m):
     return None
 
 
+def _fusable(block, x):
+    """a converted BaseConv (1x1 or 3x3, stride 1) whose BN+LIF runs on the fused HIP kernels for a 5-D CUDA spike tensor"""
+    return (isinstance(block, BaseConv) and block.spiking() and x.dim() == 5 and x.is_cuda and not block.emit_rate
+            and block.bn.affine and block.bn.step_mode == 'm' and (block.bn.momentum is not None or not block.bn.training)
+            and (x.shape[-1] * x.shape[-2]) % 4 == 0 and x.shape[0] <= 8 and _stride1(block.conv))
+
+
+def _stride1(conv):
+    c = conv[0] if isinstance(conv, nn.Sequential) and len(conv) == 1 else conv
+    return isinstance(c, nn.Conv2d) and c.stride in (1, (1, 1))
+
+
 class BaseConv(nn.Module):
     """Conv2d -> BatchNorm -> activation (spiking: SeqToANNContainer(Conv2d) -> BN('m') -> PLIF)."""
 
@@ -51,9 +63,15 @@ class BaseConv(nn.Module):
         self.act = get_activation(act, inplace=True)
         self.emit_rate = False     # spiking only: also return the firing rate (mean over T) from the fused kernel
 
-    def forward(self, x):
-        if isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d):
-            return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate)
+    def spiking(self):
+        return isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d)
+
+    def forward(self, x, residual=None, cat=None):
+        """residual / cat: only for converted (spiking) blocks on the fused BN+LIF path -- the SEW shortcut addition and the
+        channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer)."""
+        if self.spiking():
+            return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate, residual=residual, cat=cat)
+        assert residual is None and cat is None
         y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
                 and (self.bn.momentum is not None or not self.bn.training)):
@@ -82,8 +100,14 @@ class Bottleneck(nn.Module):
         self.conv2 = (DWConv if depthwise else BaseConv)(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
-    def forward(self, x):
-        y = self.conv2(self.conv1(x))
+    def forward(self, x, cat=None):
+        """cat = (buffer, first channel): write the block's output into that channel range of a concatenation buffer."""
+        h = self.conv1(x)
+        if _fusable(self.conv2, x):
+            # SEW residual (spike sums 0/1/2..) and the caller's concatenation from the BN+LIF kernel of conv2
+            return self.conv2(h, residual=x if self.use_add else None, cat=cat)
+        assert cat is None
+        y = self.conv2(h)
         if not self.use_add:
             return y
         out = y + x                              # SEW residual: spike sums 0/1/2.. when spiking
@@ -118,6 +142,24 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
     def forward(self, x):
+        last = self.m[-1] if len(self.m) else self.conv1
+        tail = last.conv2 if isinstance(last, Bottleneck) else last
+        if _fusable(tail, x) and _fusable(self.conv2, x) and not (isinstance(last, Bottleneck) and isinstance(last.conv2, DWConv)):
+            # both branches write their spikes straight into the two halves of the concatenation (no torch.cat, and the
+            # backward hands each branch its half of the gradient as a view)
+            T, N = x.shape[:2]
+            h = self.conv2.conv[0].out_channels if isinstance(self.conv2.conv, nn.Sequential) else self.conv2.conv.out_channels
+            Ho, Wo = x.shape[-2:]
+            buf = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.float32, device=x.device)
+            if len(self.m):
+                a = self.conv1(x)
+                for blk in self.m[:-1]:
+                    a = blk(a)
+                a = self.m[-1](a, cat=(buf, 0))
+            else:
+                a = self.conv1(x, cat=(buf, 0))
+            b = self.conv2(x, cat=(buf, h))
+            return self.conv3(ops.join_channels(buf, a, b))
         return self.conv3(_cat((self.m(self.conv1(x)), self.conv2(x))))
 
 

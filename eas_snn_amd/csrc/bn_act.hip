@@ -31,10 +31,18 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ out, int N,
-                                                                int C, int HW) {
+                                                                int C, int HW, BnFin fin) {
+    __shared__ float st[2];
     const int c = blockIdx.y;
-    const float scale = gamma[c] * invstd[c];
-    const float shift = beta[c] - mean[c] * scale;
+    float mu, istd;
+    if (fin.part) {
+        bn_finalize_in_block(fin, c, st, mu, istd);
+    } else {
+        mu = mean[c];
+        istd = invstd[c];
+    }
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
     GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
@@ -126,17 +134,30 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
 
 extern "C" {
 
-int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                    float* out, int N, int C, int HW, eas_stream_t stream) {
+int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+                       float* out, int N, int C, int HW, const EasBnPending* pend, eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !out || N < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
+    BnFin fin{};
+    if (pend && pend->partial) {
+        if (pend->chunks < 1 || pend->chunks > kMaxChunks || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
+        if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
+        fin.part = pend->partial; fin.nchunks = pend->chunks; fin.replicas = pend->replicas; fin.count = pend->count;
+        fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
+        fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
+    }
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW);
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
+}
+
+int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    float* out, int N, int C, int HW, eas_stream_t stream) {
+    return eas_bn_silu_fwd_ex(y, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, out, N, C, HW, nullptr, stream);
 }
 
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,

@@ -101,6 +101,11 @@ __global__ __launch_bounds__(EAS_WAVE) void bn_stats_finalize(const double* __re
     }
 }
 
+struct BnLifOut {
+    const float* residual;   // nullable [T][N][C][HW]: spikes_out = spikes + residual (SEW shortcut, network_blocks.py:99-104)
+    int out_ctot;            // 0: dense; else spikes are channels of a [T][N][out_ctot][HW] tensor (pointer already at channel 0 of the slice)
+};
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int T_, bool HARD, bool DI, bool STRICT>
 __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
@@ -108,10 +113,20 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* v_in, float* v_out,
                                                                EasLifParams p, float* __restrict__ spikes,
-                                                               float* __restrict__ mean_out, int N, int C, int HW, int bcast) {
+                                                               float* __restrict__ mean_out, int N, int C, int HW, int bcast,
+                                                               BnFin fin, BnLifOut ox) {
+    __shared__ float st[2];
     const int c = blockIdx.y;
-    const float scale = gamma[c] * invstd[c];
-    const float shift = beta[c] - mean[c] * scale;
+    float mu, istd;
+    if (fin.part) {
+        bn_finalize_in_block(fin, c, st, mu, istd);
+    } else {
+        mu = mean[c];
+        istd = invstd[c];
+    }
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
+    const int64_t Mo = ox.out_ctot ? (int64_t)N * ox.out_ctot * HW : (int64_t)N * C * HW;
     const float k = eas_lif_k(p);
     const float omk = 1.0f - k;
     const int hw4 = HW / VEC;
@@ -136,8 +151,13 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
             eas_lif_step<HARD, DI, STRICT>(v.y, fmaf(ys[t].y, scale, shift), k, omk, p.v_th, p.v_reset, h.y, s.y);
             eas_lif_step<HARD, DI, STRICT>(v.z, fmaf(ys[t].z, scale, shift), k, omk, p.v_th, p.v_reset, h.z, s.z);
             eas_lif_step<HARD, DI, STRICT>(v.w, fmaf(ys[t].w, scale, shift), k, omk, p.v_th, p.v_reset, h.w, s.w);
-            *reinterpret_cast<float4*>(spikes + (int64_t)t * M + base) = s;
             acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+            if (ox.residual) {
+                const float4 r = *reinterpret_cast<const float4*>(ox.residual + (int64_t)t * M + base);
+                s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+            }
+            const int64_t obase = ox.out_ctot ? (n * ox.out_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
+            *reinterpret_cast<float4*>(spikes + (int64_t)t * Mo + obase) = s;
         }
         if (v_out) *reinterpret_cast<float4*>(v_out + base) = v;
         if (mean_out) {
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
     int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast) {
+    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot) {
     __shared__ double red[NW];
     __shared__ float bc[2];
     const int c = blockIdx.y;
@@ -194,6 +214,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const int64_t M = (int64_t)N * C * HW;
     const float invT = 1.0f / (float)T_;
     const int64_t yts = bcast ? 0 : M;
+    const int64_t Mg = gs_ctot ? (int64_t)N * gs_ctot * HW : M;      // grad_s may be a channel slice of a wider tensor
     float m1 = 0.f, m2 = 0.f;
     if (APPLY) {
         // fixed-order reduction of this channel's chunk partials (every block computes the same value)
@@ -236,7 +257,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         for (int t = 0; t < T_; ++t) {
             gsv[t] = gm;
             if (grad_s) {
-                const float4 g4 = *reinterpret_cast<const float4*>(grad_s + (int64_t)t * M + base);
+                const int64_t gbase = gs_ctot ? (n * gs_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
+                const float4 g4 = *reinterpret_cast<const float4*>(grad_s + (int64_t)t * Mg + gbase);
                 gsv[t].x += g4.x; gsv[t].y += g4.y; gsv[t].z += g4.z; gsv[t].w += g4.w;
             }
         }
@@ -303,10 +325,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
 template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_fwd_t(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                  const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-                 int bcast, hipStream_t st) {
+                 int bcast, const BnFin& fin, const BnLifOut& ox, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
-                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast);
+                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -314,9 +336,9 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
 template <bool HARD, bool DI, bool STRICT>
 int launch_fwd(int T, const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-               int bcast, hipStream_t st) {
+               int bcast, const BnFin& fin, const BnLifOut& ox, hipStream_t st) {
 #define EAS_CASE(TT) \
-    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, st);
+    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -328,15 +350,15 @@ template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
-                 int C, int HW, int bcast, hipStream_t st) {
+                 int C, int HW, int bcast, int gs_ctot, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast);
+                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot);
     EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast);
+                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -345,11 +367,11 @@ template <bool HARD, bool DI, bool STRICT>
 int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* y, const float* mean,
                const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
                float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
-               double* ws, int N, int C, int HW, int bcast, hipStream_t st) {
+               double* ws, int N, int C, int HW, int bcast, int gs_ctot, hipStream_t st) {
 #define EAS_CASE(TT)                                                                                               \
     case TT:                                                                                                       \
         return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
-                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, st);
+                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -363,13 +385,8 @@ extern "C" {
 
 int64_t eas_bn_workspace_doubles(int C) { return (int64_t)C * kMaxChunks * 4; }
 
-int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps, float momentum, float* mean,
-                 float* invstd, float* running_mean, float* running_var, double* workspace, eas_stream_t stream) {
-    if (!y || !mean || !invstd || !workspace || TN < 1 || C < 1 || HW < 1 || replicas < 1) return EAS_ERR_INVALID_ARG;
-    if ((running_mean == nullptr) != (running_var == nullptr)) return EAS_ERR_INVALID_ARG;
-    if (C > 65535) return EAS_ERR_UNSUPPORTED;
-    hipStream_t st = eas_s(stream);
-    EAS_CLEAR_ERR();
+// launches the partial-sum kernel; returns the number of chunks per channel (> 0) or a negative status
+static int stats_partial(const float* y, int TN, int C, int HW, double* workspace, hipStream_t st) {
     int chunks;
     if (HW % VEC == 0 && (((uintptr_t)y) & 15) == 0) {
         chunks = pick_chunks((int64_t)TN * (HW / VEC), C);
@@ -378,27 +395,61 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps,
         chunks = pick_chunks((int64_t)TN * HW, C);
         hipLaunchKernelGGL(bn_stats_partial_scalar, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
     }
-    EAS_CHECK_LAUNCH();
+    if (hipGetLastError() != hipSuccess) return EAS_ERR_LAUNCH;
+    return chunks;
+}
+
+int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps, float momentum, float* mean,
+                 float* invstd, float* running_mean, float* running_var, double* workspace, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !workspace || TN < 1 || C < 1 || HW < 1 || replicas < 1) return EAS_ERR_INVALID_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return EAS_ERR_INVALID_ARG;
+    if (C > 65535) return EAS_ERR_UNSUPPORTED;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    const int chunks = stats_partial(y, TN, C, HW, workspace, st);
+    if (chunks < 0) return chunks;
     hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, replicas, eps,
                        momentum, mean, invstd, running_mean, running_var);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
 
-int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                   const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
-                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
-                   eas_stream_t stream) {
+int eas_bn_stats_partial(const float* y, int TN, int C, int HW, double* workspace, eas_stream_t stream) {
+    if (!y || !workspace || TN < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
+    if (C > 65535) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    return stats_partial(y, TN, C, HW, workspace, eas_s(stream));
+}
+
+static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin& fin) {
+    fin = BnFin{};
+    if (!pend || !pend->partial) return EAS_OK;
+    if (pend->chunks < 1 || pend->chunks > kMaxChunks || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
+    if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
+    fin.part = pend->partial; fin.nchunks = pend->chunks; fin.replicas = pend->replicas; fin.count = pend->count;
+    fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
+    fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
+    return EAS_OK;
+}
+
+int eas_bn_lif_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+                      const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
+                      int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
+                      const EasBnPending* pending, const float* residual, int out_ctot, eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !spikes || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
-    if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out) & 15) return EAS_ERR_INVALID_ARG;
+    if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out | (uintptr_t)residual) & 15) return EAS_ERR_INVALID_ARG;
+    if (out_ctot != 0 && out_ctot < C) return EAS_ERR_INVALID_ARG;
+    BnFin fin;
+    if (int rc = fin_from(pending, mean, invstd, fin)) return rc;
+    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot};
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) \
-    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, st)
+    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, fin, ox, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -407,11 +458,19 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
 #undef EAS_DISPATCH
 }
 
-int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,
-                   const float* invstd, const float* gamma, const float* beta, const float* v_init,
-                   const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
-                   float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                   float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
+                   int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
+                   eas_stream_t stream) {
+    return eas_bn_lif_fwd_ex(y, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, v_in, v_out, w_logit, k_const, v_th,
+                             v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, stream);
+}
+
+int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                      const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                      float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
         (!grad_s && !grad_mean) || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
@@ -420,19 +479,30 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)grad_s | (uintptr_t)grad_mean | (uintptr_t)v_init | (uintptr_t)grad_y) & 15)
         return EAS_ERR_INVALID_ARG;
+    if (grad_s_ctot != 0 && grad_s_ctot < C) return EAS_ERR_INVALID_ARG;
+    const int gs_ctot = grad_s_ctot == C ? 0 : grad_s_ctot;
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
-                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, st)
+                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
     if (hard && di && !strict) EAS_DISPATCH(true, true, false);
     return EAS_ERR_UNSUPPORTED;
 #undef EAS_DISPATCH
+}
+
+int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                   const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                   float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                   float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+    return eas_bn_lif_bwd_ex(grad_s, 0, grad_mean, y, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset, flags,
+                             surrogate, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C, HW, y_bcast, stream);
 }
 
 }  // extern "C"

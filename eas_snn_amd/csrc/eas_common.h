@@ -66,6 +66,55 @@ __device__ __forceinline__ T eas_block_sum(T v, T* smem) {
     return r;
 }
 
+#define EAS_BN_MAX_CHUNKS 64   // chunk partials per channel in the BN workspaces (kMaxChunks of bn_lif.hip / bn_act.hip)
+
+// ------------------------------------------------------------------------------------------------ fused finalize
+// Statistics finalize folded into the consumer: every block of channel c reduces that channel's chunk partials in the
+// same fixed order (identical result in every block), block 0 of the channel publishes mean / invstd for the backward
+// and updates the running statistics.  Saves one launch per layer (74 per SYOLOX-S step).
+struct BnFin {
+    const double* part;     // NULL: mean / invstd are inputs
+    int nchunks, replicas;
+    double count;
+    float eps, momentum;
+    float* mean_out;
+    float* invstd_out;
+    float* rmean;           // nullable
+    float* rvar;
+};
+
+__device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, float* st, float& mu, float& istd) {
+    if (threadIdx.x < EAS_WAVE) {
+        double s = 0.0, ss = 0.0;
+        if ((int)threadIdx.x < f.nchunks) {
+            s = f.part[((int64_t)c * EAS_BN_MAX_CHUNKS + threadIdx.x) * 2 + 0];
+            ss = f.part[((int64_t)c * EAS_BN_MAX_CHUNKS + threadIdx.x) * 2 + 1];
+        }
+        s = eas_wave_sum(s);
+        ss = eas_wave_sum(ss);
+        if (threadIdx.x == 0) {
+            const double m = s / f.count;
+            double var = ss / f.count - m * m;
+            if (var < 0.0) var = 0.0;
+            st[0] = (float)m;
+            st[1] = (float)(1.0 / sqrt(var + (double)f.eps));
+            if (blockIdx.x == 0) {
+                f.mean_out[c] = st[0];
+                f.invstd_out[c] = st[1];
+                if (f.rmean) {
+                    const double full = f.count * f.replicas;
+                    const double unbiased = full > 1.0 ? var * full / (full - 1.0) : var;
+                    f.rmean[c] = (float)((1.0 - f.momentum) * f.rmean[c] + f.momentum * m);
+                    f.rvar[c] = (float)((1.0 - f.momentum) * f.rvar[c] + f.momentum * unbiased);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    mu = st[0];
+    istd = st[1];
+}
+
 // (image, float4-group-in-plane) of group index g0 and its advance by `stride` groups, without a 64-bit division per group
 struct GroupWalk {
     int n, q, dn, dq, hw4;

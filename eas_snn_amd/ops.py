@@ -4,6 +4,8 @@ streams, autograd bookkeeping); all arithmetic of the hot path runs in the HIP k
 
 No CPU path: CPU tensors raise.
 """
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -68,6 +70,22 @@ def _call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     check(fn(*args), name)
     e.record()
     _TIMER.add(name, s, e, nbytes, flops, issue_flops)
+
+
+def _timer_mark():
+    """start event of a timed region that is not a single _call (None when no timer is installed)"""
+    if _TIMER is None:
+        return None
+    s = torch.cuda.Event(enable_timing=True)
+    s.record()
+    return s
+
+
+def _timer_add(name, start, nbytes):
+    if start is not None and _TIMER is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _TIMER.add(name, start, e, nbytes)
 
 
 def _dev(*tensors):
@@ -155,10 +173,37 @@ class _TimeMeanFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ K4 (BN + LIF)
+def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev):
+    """launch the partial-sum pass of the batch statistics; the consumer kernel finalizes (EasBnPending)."""
+    ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
+    chunks = L.eas_bn_stats_partial(ptr(y), TN, Cc, HW, ptr(ws), stream())
+    if chunks <= 0:
+        check(chunks if chunks < 0 else -1, 'eas_bn_stats_partial')
+    pend = _lib.EasBnPending(ptr(ws), chunks, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
+                             ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None)
+    return pend, ws
+
+
+def _channel_slice_of(g, Cc):
+    """total channel count if ``g`` [T,N,C,H,W] is a channel slice of a contiguous wider tensor (what the backward of an
+    in-place concatenation hands out), else 0."""
+    if g.is_contiguous():
+        return Cc
+    T, N, C_, H, W = g.shape
+    st = g.stride()
+    if st[4] == 1 and st[3] == W and st[2] == H * W and st[1] % (H * W) == 0 and st[1] // (H * W) > C_ and st[0] == N * st[1] \
+            and (g.data_ptr() % 16) == 0:
+        return st[1] // (H * W)
+    return 0
+
+
 class _BNLIFFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v, t_bcast):
-        """y: [T,N,C,H,W], or [N,C,H,W] standing for ``t_bcast`` identical time steps."""
+    def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v, t_bcast,
+                residual, cat_buf, cat_c0):
+        """y: [T,N,C,H,W], or [N,C,H,W] standing for ``t_bcast`` identical time steps.  residual [T,N,C,H,W]: the output is
+        spikes + residual (SEW shortcut).  cat_buf [T,N,Ctot,H,W]: the output is written as channels cat_c0.. of it and
+        returned as a view (concatenation in place)."""
         running_mean, running_var, use_batch_stats, momentum, eps = bn_state
         _dev(y, gamma, beta, v_in, w)
         L = _lib.lib()
@@ -172,25 +217,36 @@ class _BNLIFFn(torch.autograd.Function):
             plane = y.shape[1:]
         HW = plane[-1] * plane[-2]
         dev = y.device
+        pend = keep = None
         if use_batch_stats:
             mean = torch.empty(Cc, dtype=torch.float32, device=dev)
             invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
-            ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
-            _call('eas_bn_stats', 4 * y.numel(), L.eas_bn_stats, ptr(y), N if t_bcast else T * N, Cc, HW, T if t_bcast else 1, eps,
-                  momentum if momentum is not None else 0.0, ptr(mean), ptr(invstd),
-                  ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None,
-                  ptr(ws), stream())
+            t0 = _timer_mark()
+            pend, keep = _pending_stats(L, y, N if t_bcast else T * N, Cc, HW, T if t_bcast else 1, eps, momentum, running_mean,
+                                        running_var, dev)
+            _timer_add('eas_bn_stats', t0, 4 * y.numel())
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-        spikes = torch.empty((T,) + tuple(plane), dtype=torch.float32, device=dev)
+        if residual is not None:
+            residual = _f32c(residual)
+            assert not want_mean and residual.shape == (T,) + tuple(plane)
+        if cat_buf is not None:
+            assert cat_buf.is_contiguous() and cat_buf.shape[:2] == (T, N) and cat_buf.shape[3:] == tuple(plane[2:])
+            spikes = cat_buf.narrow(2, cat_c0, Cc)
+            ctot = cat_buf.shape[2]
+        else:
+            spikes = torch.empty((T,) + tuple(plane), dtype=torch.float32, device=dev)
+            ctot = 0
         v_out = torch.empty(plane, dtype=torch.float32, device=dev) if write_v else None
         mo = torch.empty(plane, dtype=torch.float32, device=dev) if want_mean else None
-        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()), L.eas_bn_lif_fwd, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()), L.eas_bn_lif_fwd_ex, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
               ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, int(bool(t_bcast)),
-              stream())
+              C.byref(pend) if pend is not None else None, ptr(residual), ctot, stream())
+        del keep
         ctx.save_for_backward(y, mean, invstd, gamma, beta, v_in, w)
         ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), T, N, Cc, HW, bool(t_bcast))
+        ctx.has_residual = residual is not None
         if v_out is not None:
             ctx.mark_non_differentiable(v_out)
         return spikes, v_out, mo
@@ -200,10 +256,15 @@ class _BNLIFFn(torch.autograd.Function):
         y, mean, invstd, gamma, beta, v_in, w = ctx.saved_tensors
         k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW, bcast = ctx.cfg
         L = _lib.lib()
-        nout = 15
+        nout = 18
         if g_s is None and g_mean is None:
             return (torch.zeros_like(y),) + (None,) * (nout - 1)
-        g_s = _f32c(g_s)
+        g_res = g_s if ctx.has_residual else None          # d(spikes + residual)/d residual = identity: the same tensor, no copy
+        ctot = 0
+        if g_s is not None:
+            ctot = _channel_slice_of(g_s, Cc) if g_s.dim() == 5 and g_s.dtype == torch.float32 else 0
+            if ctot == 0:
+                g_s = _f32c(g_s)
         g_mean = _f32c(g_mean)
         gy = torch.empty_like(y)
         ggamma = torch.empty_like(gamma)
@@ -212,11 +273,36 @@ class _BNLIFFn(torch.autograd.Function):
         gw = torch.empty_like(w) if want_w else None
         ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
         nsteps = T * N * Cc * HW
-        _call('eas_bn_lif_bwd', 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel()), L.eas_bn_lif_bwd,
-              ptr(g_s), ptr(g_mean), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th,
+        _call('eas_bn_lif_bwd', 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel()), L.eas_bn_lif_bwd_ex,
+              ptr(g_s), ctot, ptr(g_mean), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th,
               v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW,
               int(bcast), stream())
-        return (gy, ggamma, gbeta, None, None, gw) + (None,) * (nout - 6)
+        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 9 + (g_res, None, None)
+
+
+class _JoinFn(torch.autograd.Function):
+    """The tensor whose channel slices were written in place by the producers of ``parts`` (concatenation without a copy):
+    forward hands out ``buf`` itself, backward hands each producer its channel slice of the gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.sizes = [p.shape[-3] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c = [], 0
+        for n in ctx.sizes:
+            outs.append(g.narrow(-3, c, n))
+            c += n
+        return (None,) + tuple(outs)
+
+
+def join_channels(buf, *parts):
+    out = _JoinFn.apply(buf, *parts)
+    if all(is_small_int(p) for p in parts):
+        mark_small_int(out)
+    return out
 
 
 def bn_lif_supported(y_seq, T):
@@ -224,7 +310,7 @@ def bn_lif_supported(y_seq, T):
 
 
 def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_stats, momentum, eps, v_in, w, k_const,
-                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None, t_bcast=0):
+                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None, t_bcast=0, residual=None, cat=None):
     """Fused BatchNorm(step_mode='m') + multi-step LIF on the conv output y_seq [T,N,C,H,W]
     (or one plane [N,C,H,W] shared by ``t_bcast`` identical steps)."""
     if write_v is None:
@@ -232,7 +318,8 @@ def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_st
     state = (running_mean, running_var, bool(use_batch_stats), None if momentum is None else float(momentum), float(eps))
     return _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags),
                           SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate), float(alpha),
-                          bool(want_mean), bool(write_v), int(t_bcast))
+                          bool(want_mean), bool(write_v), int(t_bcast), residual, cat[0] if cat is not None else None,
+                          int(cat[1]) if cat is not None else 0)
 
 
 # Number of identical copies the current batch stands for (set by SeqToANNContainer while it runs a stateless block
@@ -267,16 +354,17 @@ class _BNSiLUFn(torch.autograd.Function):
         if use_batch_stats:
             mean = torch.empty(Cc, dtype=torch.float32, device=dev)
             invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
-            ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
-            _call('eas_bn_stats', 4 * y.numel(), L.eas_bn_stats, ptr(y), N, Cc, HW, replicas, eps, momentum if momentum is not None else 0.0,
-                  ptr(mean), ptr(invstd), ptr(running_mean) if momentum is not None else None,
-                  ptr(running_var) if momentum is not None else None, ptr(ws), stream())
+            t0 = _timer_mark()
+            pend, keep = _pending_stats(L, y, N, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev)
+            _timer_add('eas_bn_stats', t0, 4 * y.numel())
         else:
+            pend = keep = None
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
         out = torch.empty_like(y)
-        _call('eas_bn_silu_fwd', 8 * y.numel(), L.eas_bn_silu_fwd, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), N, Cc,
-              HW, stream())
+        _call('eas_bn_silu_fwd', 8 * y.numel(), L.eas_bn_silu_fwd_ex, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), N, Cc,
+              HW, C.byref(pend) if pend is not None else None, stream())
+        del keep
         ctx.save_for_backward(y, mean, invstd, gamma, beta)
         ctx.cfg = (bool(use_batch_stats), N, Cc, HW)
         return out

@@ -158,12 +158,46 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
                    float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
                    float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
 
+/* ---- variants that save launches and copies inside a network (same arithmetic as the calls above) ----
+ * eas_bn_stats_partial: only the per-chunk partial sums of eas_bn_stats; returns the number of chunks per channel (> 0)
+ *   or a negative status.  The finalize (mean, invstd, running statistics) then happens inside the consuming kernel:
+ *   pass an EasBnPending to eas_bn_lif_fwd_ex / eas_bn_silu_fwd_ex, whose mean / invstd arguments become OUTPUTS
+ *   (needed by the backward calls).
+ * eas_bn_lif_fwd_ex: residual (nullable, [T][N][C][HW]): spikes_out = spikes + residual, the SEW shortcut of Bottleneck
+ *   (network_blocks.py:99-104) without a separate addition; out_ctot (0 or >= C): the spikes are written as C consecutive
+ *   channels of a [T][N][out_ctot][HW] tensor, `spikes` pointing at the first of them -- the concatenations of CSPLayer
+ *   (network_blocks.py:183-188) happen in place.  mean_out is the rate of the spikes themselves (without residual).
+ * eas_bn_lif_bwd_ex: grad_s_ctot (0 or >= C): grad_s is such a channel slice of a wider gradient tensor. */
+typedef struct {
+    const double* partial;   /* workspace filled by eas_bn_stats_partial; NULL = statistics already final */
+    int chunks;              /* its return value */
+    int replicas;            /* as eas_bn_stats */
+    double count;            /* TN * HW */
+    float eps, momentum;
+    float* running_mean;     /* nullable pair */
+    float* running_var;
+} EasBnPending;
+int eas_bn_stats_partial(const float* y, int TN, int C, int HW, double* workspace, eas_stream_t stream);
+int eas_bn_lif_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+                      const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
+                      int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
+                      const EasBnPending* pending, const float* residual, int out_ctot, eas_stream_t stream);
+int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                      const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                      float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
+
+
 /* BatchNorm2d + SiLU fused for the real-valued BaseConv blocks (stem, PAFPN neck, head:
  * yolox/models/network_blocks.py:52-53 with nn.SiLU); y: conv output [N][C][HW]; mean/invstd from eas_bn_stats
  * (training) or the running statistics (eval).  Backward = two passes like eas_bn_lif_bwd; only y is kept.
  * workspace: eas_bn_workspace_doubles(C) doubles. */
 int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                     float* out, int N, int C, int HW, eas_stream_t stream);
+/* eas_bn_silu_fwd with the statistics finalize folded in (see EasBnPending above): mean / invstd become outputs. */
+int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+                       float* out, int N, int C, int HW, const EasBnPending* pending, eas_stream_t stream);
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
                     double* workspace, int N, int C, int HW, eas_stream_t stream);
