@@ -3,6 +3,8 @@
 // (u32 t + u16 x + u16 y + u8 p) + 4*Tm*2*H*W B for the frames (zero-fill + result).
 // One thread handles 4 consecutive events (16-B / 8-B / 8-B / 4-B vector loads); the atomics are
 // int32 `global_atomic_add` without return, so results are bit-exact and order independent.
+#include <stdlib.h>
+
 #include "eas_common.h"
 
 namespace {
@@ -137,6 +139,97 @@ __global__ __launch_bounds__(EAS_BLOCK) void event_hist_dat_kernel(const uint2* 
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nev; i += stride) {
             const int b = find_sample(offsets, B, i);
             bin_dat(rec[i].x, rec[i].y, sample_window_dat(rec, offsets, b, Tm), b, Tm, H, W, out, oob);
+        }
+    }
+}
+
+// LDS-privatised form of the histogram for streams with many events per frame: one block owns one (sample, micro-slice,
+// band of rows) and keeps that band's two polarity planes in LDS (<= 150 KB).  The events of a micro-slice are a
+// contiguous run of the time-sorted stream (two binary searches = the reference's np.searchsorted, gen1.py:324-325), so the
+// block streams through that run with coalesced loads, counts the events that fall into its rows with LDS atomics, and
+// writes its band once with coalesced stores: no global atomics, no zero-fill pass, every output element written
+// exactly once.  Each event is read by every band of its slice (L2-resident re-reads); bit-exact like the scatter form.
+constexpr int kBandThreads = 1024;
+constexpr int kBandLdsBytes = 150 * 1024;
+constexpr int kMaxBands = 8;
+
+__device__ __forceinline__ int64_t lower_bound_t(const uint32_t* __restrict__ t, int64_t lo, int64_t hi, uint32_t key) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (t[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBandThreads) void event_hist_banded_kernel(const uint32_t* __restrict__ t, const uint16_t* __restrict__ x,
+                                                                         const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
+                                                                         const int64_t* __restrict__ offsets, int B, int Tm, int H, int W,
+                                                                         int rows, int nbands, int32_t* __restrict__ out,
+                                                                         uint32_t* __restrict__ oob) {
+    extern __shared__ int cnt[];            // [2][rows][W]
+    __shared__ int64_t range[2];
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so the bands of one (sample, slice) get ids
+    // 8 apart -- same XCD, one L2: the slice's events come from HBM once and from that L2 for the other bands
+    const int L = blockIdx.x, tid = threadIdx.x;
+    const int sl = (L & 7) + 8 * (L / (8 * nbands)), band = (L >> 3) % nbands;
+    if (sl >= B * Tm) return;
+    const int b = sl / Tm, k = sl - b * Tm;
+    const int y0 = band * rows, y1 = y0 + rows < H ? y0 + rows : H;
+    const int plane = rows * W;
+    if ((plane & 3) == 0) {
+        for (int i = tid; i < plane / 2; i += kBandThreads) reinterpret_cast<int4*>(cnt)[i] = make_int4(0, 0, 0, 0);
+    } else {
+        for (int i = tid; i < 2 * plane; i += kBandThreads) cnt[i] = 0;
+    }
+    if (tid == 0) {
+        const int64_t a = offsets[b], e = offsets[b + 1];
+        int64_t lo = 0, hi = 0;
+        if (e > a) {
+            const uint32_t t0 = t[a];
+            const uint32_t win = (t[e - 1] - t0) / (uint32_t)Tm;
+            if (win != 0) {
+                lo = lower_bound_t(t, a, e, t0 + (uint32_t)k * win);
+                hi = lower_bound_t(t, lo, e, t0 + (uint32_t)(k + 1) * win);
+            }
+        }
+        range[0] = lo;
+        range[1] = hi;
+    }
+    __syncthreads();
+    const int64_t lo = range[0], hi = range[1];
+    unsigned bad = 0;
+    constexpr int UN = 4;                   // events in flight per thread (all loads issued before the first LDS atomic)
+    for (int64_t i0 = lo + tid; i0 < hi; i0 += (int64_t)UN * kBandThreads) {
+        unsigned xs[UN], ys[UN], ps[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t i = i0 + (int64_t)u * kBandThreads;
+            const bool in = i < hi;
+            xs[u] = in ? x[i] : 0u;
+            ys[u] = in ? y[i] : 0xffffffffu;          // sentinel: neither counted nor out-of-range
+            ps[u] = in ? p[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (ys[u] == 0xffffffffu) continue;
+            if (xs[u] >= (unsigned)W || ys[u] >= (unsigned)H) {
+                ++bad;
+                continue;
+            }
+            if (ys[u] < (unsigned)y0 || ys[u] >= (unsigned)y1) continue;
+            atomicAdd(&cnt[(ps[u] != 0 ? plane : 0) + (int)(ys[u] - y0) * W + (int)xs[u]], 1);
+        }
+    }
+    if (band == 0 && oob && bad) atomicAdd(oob, bad);
+    __syncthreads();
+    const int n = (y1 - y0) * W;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int32_t* dst = out + ((((int64_t)b * Tm + k) * 2 + c) * H + y0) * W;
+        if ((n & 3) == 0 && (plane & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+            for (int i = tid; i < n / 4; i += kBandThreads) reinterpret_cast<int4*>(dst)[i] = reinterpret_cast<const int4*>(cnt + c * plane)[i];
+        } else {
+            for (int i = tid; i < n; i += kBandThreads) dst[i] = cnt[c * plane + i];
         }
     }
 }
@@ -310,8 +403,29 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     const size_t bytes = (size_t)B * Tm * 2 * H * W * sizeof(int32_t);
-    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (oob_count && hipMemsetAsync(oob_count, 0, sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    // dense streams (>= 2048 events per frame on average) whose frame splits into at most 8 LDS-sized row bands: LDS form
+    int rows = kBandLdsBytes / (8 * W);
+    if (rows > H) rows = H;
+    const int nbands = rows > 0 ? (H + rows - 1) / rows : kMaxBands + 1;
+    const char* force = getenv("EAS_HIST_FORM");      // development switch: "scatter" / "banded"
+    const bool dense = nev >= (int64_t)B * Tm * 2048;
+    if (nbands <= kMaxBands && (int64_t)B * Tm < (1 << 24) && (force ? force[0] == 'b' : dense)) {
+        rows = (H + nbands - 1) / nbands;              // even bands
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)event_hist_banded_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBandLdsBytes) != hipSuccess)
+                return EAS_ERR_LAUNCH;
+            attr_set = true;
+        }
+        const int nb = (H + rows - 1) / rows;
+        const int64_t groups = ((int64_t)B * Tm + 7) / 8;
+        hipLaunchKernelGGL(event_hist_banded_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), (size_t)2 * rows * W * 4, st, t, x, y,
+                           p, sample_offsets, B, Tm, H, W, rows, nb, out, oob_count);
+        EAS_CHECK_LAUNCH();
+        return EAS_OK;
+    }
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (nev == 0) return EAS_OK;
     const bool vec = (((uintptr_t)t & 15) | ((uintptr_t)x & 7) | ((uintptr_t)y & 7) | ((uintptr_t)p & 3)) == 0;
     if (vec) {

@@ -72,6 +72,53 @@ def test_event_histogram_batched_ragged_vs_oracle(dev):
     assert np.array_equal(canvas[..., :H, :W], ref.astype(np.float32)) and canvas[..., H:, :].sum() == 0 and canvas[..., :, W:].sum() == 0
 
 
+@pytest.mark.parametrize('form', ['scatter', 'banded'])
+def test_event_histogram_both_forms_golden_and_ragged(dev, form, monkeypatch):
+    """The global-atomic scatter form and the LDS-privatised banded form of eas_event_histogram (chosen by event density;
+    EAS_HIST_FORM forces one) on every golden case, on a ragged batch with empty samples and out-of-range events, and on a
+    sensor that needs several row bands: bit-exact against the reference's outputs / the oracle in both forms."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    monkeypatch.setenv('EAS_HIST_FORM', form)
+    cases = split_cases(load_golden('events_micro_sum'))
+    for name, c in cases.items():
+        out, oob = _run_hist(c, dev, ops)
+        assert int(oob) == 0 and np.array_equal(out[0].cpu().numpy(), c['out']), name
+    H, W, Tm = 240, 304, 4
+    sizes = [0, 1, 7, 20000, 3, 0, 50001, 1234, 2]
+    parts = [events_ref.synth_events(n, H, W, seed=10 + i) if n else tuple(np.zeros(0, d) for d in (np.uint32, np.uint16, np.uint16, np.uint8))
+             for i, n in enumerate(sizes)]
+    t, x, y, p = (np.concatenate([q[j] for q in parts]) for j in range(4))
+    off = np.cumsum([0] + sizes).astype(np.int64)
+    ref = events_ref.micro_sum_batch(t, x, y, p, off, Tm, H, W)
+    x2 = x.copy(); x2[30000:30040] = 400                      # 40 events right of the sensor, inside sample 6
+    keep = np.ones(len(t), bool); keep[30000:30040] = False
+    a6, e6 = off[6], off[7]
+    k6 = keep[a6:e6]
+    ref6 = events_ref.micro_sum(t[a6:e6], np.where(k6, x[a6:e6], 0), y[a6:e6], p[a6:e6], Tm, H, W)      # reference binning, then remove the outsiders
+    dev_args = lambda xs: (_t(t.view(np.int32), dev).view(torch.uint32), _t(xs.view(np.int16), dev).view(torch.uint16),
+                           _t(y.view(np.int16), dev).view(torch.uint16), _t(p, dev), _t(off, dev), Tm, H, W)
+    out = ops.event_histogram(*dev_args(x))
+    assert np.array_equal(out.cpu().numpy(), ref)
+    out2, oob = ops.event_histogram(*dev_args(x2), return_oob=True)
+    got = out2.cpu().numpy()
+    assert np.array_equal(np.delete(got, 6, 0), np.delete(ref, 6, 0))
+    bounds = events_ref.slice_bounds(t[a6:e6], Tm)
+    inside = sum(int(k6[lo:hi].sum()) for lo, hi in bounds)
+    total = sum(hi - lo for lo, hi in bounds)
+    assert int(got[6].sum()) == inside and int(oob) == total - inside
+    # 720 x 1280 needs more row bands than the LDS form takes: it must still give the right answer (falls back to scatter)
+    tb, xb, yb, pb = events_ref.synth_events(30000, 720, 1280, seed=77)
+    big = ops.event_histogram(_t(tb.view(np.int32), dev).view(torch.uint32), _t(xb.view(np.int16), dev).view(torch.uint16),
+                              _t(yb.view(np.int16), dev).view(torch.uint16), _t(pb, dev), torch.tensor([0, 30000], device=dev), 2, 720, 1280)
+    assert np.array_equal(big[0].cpu().numpy(), events_ref.micro_sum(tb, xb, yb, pb, 2, 720, 1280).astype(np.int32))
+    # 480 x 640 (VGA) takes 4 bands of 120 rows
+    tv, xv, yv, pv = events_ref.synth_events(40000, 480, 640, seed=78)
+    vga = ops.event_histogram(_t(tv.view(np.int32), dev).view(torch.uint32), _t(xv.view(np.int16), dev).view(torch.uint16),
+                              _t(yv.view(np.int16), dev).view(torch.uint16), _t(pv, dev), torch.tensor([0, 40000], device=dev), 3, 480, 640)
+    assert np.array_equal(vga[0].cpu().numpy(), events_ref.micro_sum(tv, xv, yv, pv, 3, 480, 640).astype(np.int32))
+
+
 def test_event_histogram_full_size_properties(dev):
     """BASELINE config size (64 x 200k events): checksum-style properties, oracle on a subsample."""
     from eas_snn_amd import data, ops
@@ -384,6 +431,51 @@ def test_bn_lif_fused_vs_oracle(dev, T, N, C, H, W, train):
     np.testing.assert_allclose(hbn.running_mean.cpu().numpy(), rbn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(hbn.running_var.cpu().numpy(), rbn.running_var.numpy(), rtol=1e-5, atol=1e-6)
     assert int(hbn.num_batches_tracked) == int(rbn.num_batches_tracked)
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_bn_lif_residual_and_inplace_concatenation(dev, train):
+    """The SEW shortcut addition and the channel concatenation done inside the BN+LIF kernel (eas_bn_lif_fwd_ex residual /
+    out_ctot, eas_bn_lif_bwd_ex grad_s_ctot, statistics finalized in the kernel) against the same layers composed with
+    ``+`` and ``torch.cat`` on the plain path: forward, every gradient and the running statistics must be bit-identical."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import layer, neuron, surrogate
+    T, N, Ca, Cb, H, W = 3, 2, 8, 5, 12, 16
+    rng = np.random.default_rng(17)
+    ya = (rng.standard_normal((T, N, Ca, H, W)) * 1.5 + 0.3).astype(np.float32)
+    yb = (rng.standard_normal((T, N, Cb, H, W)) * 1.5 + 0.3).astype(np.float32)
+    res = (rng.random((T, N, Ca, H, W)) < 0.3).astype(np.float32)
+    gout = rng.standard_normal((T, N, Ca + Cb, H, W)).astype(np.float32)
+
+    def build():
+        torch.manual_seed(3)
+        mods = []
+        for C_ in (Ca, Cb):
+            bn = layer.BatchNorm2d(C_, eps=1e-3, momentum=0.03, step_mode='m')
+            with torch.no_grad():
+                bn.weight.uniform_(0.8, 1.6); bn.bias.uniform_(-0.1, 0.6); bn.running_mean.uniform_(-0.2, 0.4); bn.running_var.uniform_(0.5, 2.5)
+            node = neuron.ParametricLIFNode(init_tau=2.0, decay_input=False, v_reset=None, surrogate_function=surrogate.ATan(2.0), step_mode='m')
+            mods += [bn.to(dev).train(train), node.to(dev)]
+        return mods
+
+    outs = []
+    for fused in (False, True):
+        bna, na, bnb, nb = build()
+        a_in, b_in, r_in = (_t(v, dev).requires_grad_(True) for v in (ya, yb, res))
+        if fused:
+            buf = torch.empty((T, N, Ca + Cb, H, W), device=dev)
+            a = bna.fused_with(na, a_in, residual=r_in, cat=(buf, 0))
+            b = bnb.fused_with(nb, b_in, cat=(buf, Ca))
+            assert a.data_ptr() == buf.data_ptr() and not b.is_contiguous()
+            out = ops.join_channels(buf, a, b)
+        else:
+            out = torch.cat([bna.fused_with(na, a_in) + r_in, bnb.fused_with(nb, b_in)], dim=2)
+        (out * _t(gout, dev)).sum().backward()
+        outs.append([out.detach(), a_in.grad, b_in.grad, r_in.grad, bna.weight.grad, bna.bias.grad, bnb.weight.grad, na.w.grad, nb.w.grad,
+                     bna.running_mean, bna.running_var, bnb.running_mean])
+    for i, (u, v) in enumerate(zip(*outs)):
+        assert torch.equal(u, v), i
+    assert outs[0][0].max() == 2.0          # a spike on top of a residual spike
 
 
 # ------------------------------------------------------------------------------------------------ K3 sampler
