@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kBandThreads) void event_hist_banded_kernel(const u
                                                                          const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
                                                                          const int64_t* __restrict__ offsets, int B, int Tm, int H, int W,
                                                                          int rows, int nbands, int32_t* __restrict__ out,
-                                                                         uint32_t* __restrict__ oob) {
+                                                                         uint32_t* __restrict__ oob, float* __restrict__ canvas, int Hc,
+                                                                         int Wc) {
     extern __shared__ int cnt[];            // [2][rows][W]
     __shared__ int64_t range[2];
     // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so the bands of one (sample, slice) get ids
@@ -223,6 +224,21 @@ __global__ __launch_bounds__(kBandThreads) void event_hist_banded_kernel(const u
     if (band == 0 && oob && bad) atomicAdd(oob, bad);
     __syncthreads();
     const int n = (y1 - y0) * W;
+    if (canvas) {
+        // fp32 frames straight into the zero-padded model canvas [B][Tm][2][Hc][Wc] (gen1.py:447-455 + trainer.py:99 cast):
+        // this band's rows with their right padding; the last band also writes the bottom padding rows
+        const int yend = band == nbands - 1 ? Hc : y1;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float* dst = canvas + ((((int64_t)b * Tm + k) * 2 + c) * Hc + y0) * Wc;
+            const int total = (yend - y0) * Wc;
+            for (int i = tid; i < total; i += kBandThreads) {
+                const int r = i / Wc, col = i - r * Wc;
+                dst[i] = (r < y1 - y0 && col < W) ? (float)cnt[c * plane + r * W + col] : 0.0f;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         int32_t* dst = out + ((((int64_t)b * Tm + k) * 2 + c) * H + y0) * W;
@@ -395,9 +411,12 @@ __global__ __launch_bounds__(EAS_BLOCK) void counts_letterbox_kernel(const int32
 
 extern "C" {
 
-int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
-                        const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
-                        uint32_t* oob_count, eas_stream_t stream) {
+// counts into ``out``; or, when ``canvas`` is given and the banded form applies, fp32 frames straight into the canvas
+// (*wrote_canvas = 1) without touching ``out``
+static int histogram_impl(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                          const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
+                          uint32_t* oob_count, float* canvas, int Hc, int Wc, int* wrote_canvas, eas_stream_t stream) {
+    if (wrote_canvas) *wrote_canvas = 0;
     if (!out || !sample_offsets || B < 1 || Tm < 1 || H < 1 || W < 1 || nev < 0) return EAS_ERR_INVALID_ARG;
     if (nev > 0 && (!t || !x || !y || !p)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
@@ -421,8 +440,9 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
         const int nb = (H + rows - 1) / rows;
         const int64_t groups = ((int64_t)B * Tm + 7) / 8;
         hipLaunchKernelGGL(event_hist_banded_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), (size_t)2 * rows * W * 4, st, t, x, y,
-                           p, sample_offsets, B, Tm, H, W, rows, nb, out, oob_count);
+                           p, sample_offsets, B, Tm, H, W, rows, nb, out, oob_count, canvas, Hc, Wc);
         EAS_CHECK_LAUNCH();
+        if (canvas && wrote_canvas) *wrote_canvas = 1;
         return EAS_OK;
     }
     if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return EAS_ERR_LAUNCH;
@@ -437,6 +457,24 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
     }
     EAS_CHECK_LAUNCH();
     return EAS_OK;
+}
+
+int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                        const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
+                        uint32_t* oob_count, eas_stream_t stream) {
+    return histogram_impl(t, x, y, p, nev, sample_offsets, B, Tm, H, W, out, oob_count, nullptr, 0, 0, nullptr, stream);
+}
+
+int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out, eas_stream_t stream);
+
+int eas_event_frames(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                     const int64_t* sample_offsets, int B, int Tm, int H, int W, int Hc, int Wc, float* frames,
+                     int32_t* scratch_counts, uint32_t* oob_count, eas_stream_t stream) {
+    if (!frames || !scratch_counts || Hc < H || Wc < W) return EAS_ERR_INVALID_ARG;
+    int wrote = 0;
+    const int rc = histogram_impl(t, x, y, p, nev, sample_offsets, B, Tm, H, W, scratch_counts, oob_count, frames, Hc, Wc, &wrote, stream);
+    if (rc != EAS_OK || wrote) return rc;
+    return eas_counts_to_canvas(scratch_counts, (int64_t)B * Tm * 2, H, W, Hc, Wc, frames, stream);
 }
 
 int eas_event_histogram_dat(const void* records, int64_t nev, const int64_t* sample_offsets, int B, int Tm, int H, int W,

@@ -29,8 +29,7 @@ def events_to_device(ev, device):
 def events_to_frames(ev_dev, Tm, sensor_hw, canvas_hw):
     """Device events -> model input [B, Tl=1, Tm, 2, Hc, Wc] fp32 via the HIP histogram (K1)."""
     H, W = sensor_hw
-    counts = ops.event_histogram(ev_dev['t'], ev_dev['x'], ev_dev['y'], ev_dev['p'], ev_dev['offsets'], Tm, H, W)
-    frames = ops.counts_to_canvas(counts, canvas_hw[0], canvas_hw[1])
+    frames = ops.event_frames(ev_dev['t'], ev_dev['x'], ev_dev['y'], ev_dev['p'], ev_dev['offsets'], Tm, H, W, canvas_hw[0], canvas_hw[1])
     return frames.unsqueeze(1)
 
 

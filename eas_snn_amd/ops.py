@@ -428,6 +428,17 @@ def event_histogram_dat(records, sample_offsets, Tm, H, W, return_oob=False):
     return (out, oob) if return_oob else out
 
 
+def event_frames(t, x, y, p, sample_offsets, Tm, H, W, Hc, Wc):
+    """raw events -> fp32 count frames on the zero-padded model canvas [B, Tm, 2, Hc, Wc] in one call (K1 + canvas)."""
+    _dev(t, x, y, p, sample_offsets)
+    B = sample_offsets.numel() - 1
+    out = torch.empty((B, Tm, 2, Hc, Wc), dtype=torch.float32, device=t.device)
+    scratch = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=t.device)
+    _call('eas_event_histogram', 9 * t.numel() + 4 * out.numel(), _lib.lib().eas_event_frames, ptr(t), ptr(x), ptr(y), ptr(p), t.numel(),
+          ptr(sample_offsets), B, Tm, H, W, Hc, Wc, ptr(out), ptr(scratch), None, stream())
+    return out
+
+
 def counts_to_canvas(counts, Hc, Wc):
     """int32 [..., H, W] -> float32 [..., Hc, Wc], zero padded bottom/right."""
     _dev(counts)

@@ -68,6 +68,13 @@ int eas_event_histogram_dat(const void* records, int64_t nev, const int64_t* sam
 int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out,
                          eas_stream_t stream);
 
+/* eas_event_histogram + eas_counts_to_canvas in one call: fp32 frames [B][Tm][2][Hc][Wc] (zero padded bottom/right).  Dense
+ * streams are binned in LDS and written to the canvas directly (the int32 counts never reach HBM); otherwise the counts go
+ * through scratch_counts [B][Tm][2][H][W].  Values are identical either way. */
+int eas_event_frames(const uint32_t* t, const uint16_t* x, const uint16_t* y, const uint8_t* p, int64_t nev,
+                     const int64_t* sample_offsets, int B, int Tm, int H, int W, int Hc, int Wc, float* frames,
+                     int32_t* scratch_counts, uint32_t* oob_count, eas_stream_t stream);
+
 /* Letterbox / jitter augmentation of the count frames on the device (GEN1Dataset.get_random_data,
  * gen1.py:433-521: batch_resize with cv2.INTER_LINEAR :423-431, paste into a zero canvas, left-right flip) fused with the
  * fp32 cast of trainer.py:99.  counts [B][F][H][W] int32; params [B][5] int32 = (nw, nh, dx, dy, flip) per sample (the

@@ -119,6 +119,28 @@ def test_event_histogram_both_forms_golden_and_ragged(dev, form, monkeypatch):
     assert np.array_equal(vga[0].cpu().numpy(), events_ref.micro_sum(tv, xv, yv, pv, 3, 480, 640).astype(np.int32))
 
 
+@pytest.mark.parametrize('form', ['scatter', 'banded'])
+def test_event_frames_equals_histogram_plus_canvas(dev, form, monkeypatch):
+    """eas_event_frames (events -> padded fp32 frames in one call; dense streams never write the int32 counts) equals
+    eas_event_histogram followed by eas_counts_to_canvas, in both forms, incl. a sample without events."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    monkeypatch.setenv('EAS_HIST_FORM', form)
+    H, W, Tm = 240, 304, 4
+    sizes = [30000, 0, 12345]
+    parts = [events_ref.synth_events(n, H, W, seed=40 + i) if n else tuple(np.zeros(0, d) for d in (np.uint32, np.uint16, np.uint16, np.uint8))
+             for i, n in enumerate(sizes)]
+    t, x, y, p = (np.concatenate([q[j] for q in parts]) for j in range(4))
+    off = np.cumsum([0] + sizes).astype(np.int64)
+    args = (_t(t.view(np.int32), dev).view(torch.uint32), _t(x.view(np.int16), dev).view(torch.uint16),
+            _t(y.view(np.int16), dev).view(torch.uint16), _t(p, dev), _t(off, dev), Tm, H, W)
+    frames = ops.event_frames(*args, 256, 320)
+    ref = ops.counts_to_canvas(ops.event_histogram(*args), 256, 320)
+    assert frames.shape == (3, Tm, 2, 256, 320) and torch.equal(frames, ref)
+    want = events_ref.micro_sum_batch(t, x, y, p, off, Tm, H, W)
+    assert np.array_equal(frames[..., :H, :W].cpu().numpy(), want.astype(np.float32)) and float(frames[1].abs().sum()) == 0
+
+
 def test_event_histogram_full_size_properties(dev):
     """BASELINE config size (64 x 200k events): checksum-style properties, oracle on a subsample."""
     from eas_snn_amd import data, ops
