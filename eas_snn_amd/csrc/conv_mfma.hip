@@ -524,6 +524,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         }
     }
     if (best < 0) return EAS_ERR_UNSUPPORTED;
+    if (!y) return EAS_OK;                       // geometry query (eas_conv_fwd_supported): a tile exists, nothing is launched
     return cands[best].fn(x, wp, bias, y, inexact, best_g, st);
 }
 
@@ -564,9 +565,10 @@ int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream)
 // y[NI,Cout,Ho,Wo] = conv2d(x[NI,Cin,Hi,Wi], weights packed with mode 0 (or mode 1 for the stride-1 input gradient, called
 // with grad_y as x and Cin/Cout swapped), padding ksize/2.  x_terms = 1: x holds small integers (spikes and their SEW sums,
 // exact in bf16; `inexact_flag`, if given, is set to 1 should any element not be); x_terms = 3: general fp32 input.
-int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                 int stride, int x_terms, int* inexact_flag, eas_stream_t stream) {
-    if (!x || !packed_w || !y || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                         int stride, int x_terms, int* inexact_flag, eas_stream_t stream, bool query) {
+    if (!query && (!x || !packed_w || !y)) return EAS_ERR_INVALID_ARG;
+    if (NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || (ksize == 3 && Wi % 2 != 0)) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     ConvGeom g{};
@@ -595,11 +597,22 @@ int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float*
                             : dispatch_tile<TAPS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
     if (ksize == 3 && stride == 1) { EAS_CONV_DISPATCH(9, 1, 16); }
     else if (ksize == 3 && stride == 2) { EAS_CONV_DISPATCH(9, 2, 16); }
-    else if (ksize == 1 && stride == 1) rc = eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
+    else if (ksize == 1 && stride == 1) rc = query ? EAS_OK : eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
 #undef EAS_CONV_DISPATCH
-    if (rc != EAS_OK) return rc;
+    if (rc != EAS_OK || query) return rc;
     EAS_CHECK_LAUNCH();
     return EAS_OK;
+}
+
+int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                 int stride, int x_terms, int* inexact_flag, eas_stream_t stream) {
+    return conv_fwd_impl(x, packed_w, bias, y, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, inexact_flag, stream, false);
+}
+
+// 1 when eas_conv_fwd has a tile for this geometry (the staged input rows of one tile must fit LDS: general fp32 inputs of
+// 3x3 convolutions wider than ~280 pixels do not), else 0: callers keep the library convolution for those layers.
+int eas_conv_fwd_supported(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
+    return conv_fwd_impl(nullptr, nullptr, nullptr, nullptr, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, nullptr, nullptr, true) == EAS_OK ? 1 : 0;
 }
 
 // grad_x[NI,Cin,Hi,Wi] of a stride-2 3x3 convolution (padding 1) from grad_y[NI,Cout,Ho,Wo] and the weights packed with

@@ -832,14 +832,29 @@ def conv_eligible(x, conv):
             and CONV_POLICY['fwd%d' % k] == 'mfma' and not (k == 1 and conv.stride != (1, 1)))
 
 
+_FWD_SUPPORT = {}
+
+
+def conv_fwd_supported(NI, Cin, Cout, Hi, Wi, k, stride, x_terms):
+    """geometry query of eas_conv_fwd (cached): False -> the layer keeps the library convolution"""
+    key = (NI, Cin, Cout, Hi, Wi, k, stride, x_terms)
+    r = _FWD_SUPPORT.get(key)
+    if r is None:
+        r = _FWD_SUPPORT[key] = bool(_lib.lib().eas_conv_fwd_supported(*key))
+    return r
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, x_terms, packs):
         """packs: {mode: packed weights} valid for the current version of ``w`` (prepack_conv_weights), or None."""
         _dev(x, w, bias)
         k, Cout = w.shape[-1], w.shape[0]
-        pk = packs[0] if packs and 0 in packs else conv_pack_weights(w, 0)
-        y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms)
+        if conv_fwd_supported(x.shape[0], x.shape[1], Cout, x.shape[2], x.shape[3], k, stride, x_terms):
+            pk = packs[0] if packs and 0 in packs else conv_pack_weights(w, 0)
+            y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms)
+        else:       # no tile fits (very wide rows of real-valued inputs): library forward, own backward where that fits
+            y = torch.ops.aten.convolution(x, w, bias, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1)
         ctx.save_for_backward(x, w)
         ctx.cfg = (k, stride, x_terms, bias is not None)
         ctx.packs = packs if packs and getattr(w, '_version', None) == packs.get('version') else None
@@ -853,13 +868,14 @@ class _ConvFn(torch.autograd.Function):
         gy = _f32c(gy)
         gx = gw = gb = None
         Cin = w.shape[1]
-        own_d = ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
+        own_d = (ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
+                 and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3], k, 1, 3))
         own_w = ctx.needs_input_grad[1] and CONV_POLICY['wgrad%d' % k] == 'mfma' and (
             k == 1 or gy.shape[-1] <= 80 or CONV_POLICY['wgrad3_wide'] == 'mfma') and _lib.lib().eas_conv_wgrad_workspace_floats(
             x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
         own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and CONV_POLICY['dgrad3'] == 'mfma' and w.shape[0] % 8 == 0
-                  and gy.shape[-1] % 2 == 0)
+                  and gy.shape[-1] % 2 == 0 and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3] + 2, k, 1, 3))
         if own_d:
             pk = packs[1] if packs and 1 in packs else conv_pack_weights(w, 1)
             gx = conv_fwd_packed(gy, pk, None, Cin, k, 1, 3)
@@ -867,9 +883,12 @@ class _ConvFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             fl = 2.0 * gy.numel() * Cin * 9
             pk = packs[2] if packs and 2 in packs else conv_pack_weights(w, 2)
-            _call('eas_conv_fwd', 4 * (x.numel() + gy.numel()), _lib.lib().eas_conv_dgrad_s2, ptr(gy), ptr(pk), ptr(gx),
-                  x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stream(), flops=fl, issue_flops=6 * fl)
-            own_d = True
+            try:
+                _call('eas_conv_fwd', 4 * (x.numel() + gy.numel()), _lib.lib().eas_conv_dgrad_s2, ptr(gy), ptr(pk), ptr(gx),
+                      x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stream(), flops=fl, issue_flops=6 * fl)
+                own_d = True
+            except _lib.EasHipError:        # no tile for this width (checked before anything is launched): library input gradient
+                gx = None
         if own_w:
             gw = conv_wgrad(x, gy, k, stride, x_terms)
         need_d = ctx.needs_input_grad[0] and not own_d

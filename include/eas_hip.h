@@ -283,6 +283,9 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
+/* 1 when eas_conv_fwd has a tile for this geometry, else 0 (it would return EAS_ERR_UNSUPPORTED): one tile's staged input
+ * rows must fit LDS, which general fp32 inputs of 3x3 convolutions on rows wider than ~280 pixels do not. */
+int eas_conv_fwd_supported(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
 /* Input gradient of a stride-2 3x3 convolution: grad_x[NI][Cin][Hi][Wi] from grad_y[NI][Cout][Ho][Wo] and the weights
  * packed with mode 2 (eas_conv_pack_weights), by parity class of the input pixel (1/2/2/4 taps per class). */
 int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, int NI, int Cin, int Cout, int Hi, int Wi,

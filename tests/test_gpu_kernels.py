@@ -695,6 +695,32 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('NI,Cin,Cout,H,W,s', [(1, 8, 16, 6, 320, 1), (1, 16, 32, 8, 640, 2), (1, 16, 16, 4, 1280, 1)])
+def test_conv_without_a_tile_keeps_the_library_path(dev, NI, Cin, Cout, H, W, s):
+    """Real-valued 3x3 inputs on rows too wide for one LDS tile (the stem / dark2.0 of the 1 Mpx configuration, 192x320):
+    eas_conv_fwd_supported says so and ops.conv2d keeps the library convolution for that layer instead of failing; results
+    still match fp64."""
+    import torch.nn as nn
+    from eas_snn_amd import _lib, ops
+    assert _lib.lib().eas_conv_fwd_supported(NI, Cin, Cout, H, W, 3, s, 3) == 0
+    assert _lib.lib().eas_conv_fwd_supported(NI, Cin, Cout, H, 80, 3, s, 3) == 1
+    x, w = _conv_case(NI, Cin, Cout, H, W, 3, False, seed=W)
+    conv = nn.Conv2d(Cin, Cout, 3, s, 1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, conv)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+    y.backward(gy.to(dev))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, None, stride=s, padding=1)
+    y64.backward(gy.double())
+    for name, got, ref in (('y', y, y64), ('grad_x', xd.grad, x64.grad), ('grad_w', conv.weight.grad, w64.grad)):
+        err = (got.detach().double().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+        assert err < 1e-5, f'{name}: {err:.2e}'
+
+
+@pytest.mark.gpu
 def test_conv_mfma_is_deterministic_and_checks_spike_tags(dev):
     import torch.nn as nn
     from eas_snn_amd import _lib, ops
