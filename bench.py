@@ -165,11 +165,11 @@ def main():
         return out['total_loss']
 
     # Launch mode.  The step has no host synchronisation, so on a single GPU it can be captured once into a HIP graph and
-    # replayed.  Eager launches are a little faster while the host stays ahead of the GPU (quiet host: a step is enqueued in
-    # 21-27 ms against the ~37 ms the GPU needs; graph nodes add ~1 ms of per-kernel cost) and slower once it does not.  So the
-    # last two warm-up steps measure how long the host needs to enqueue a step; if that is more than 75 % of the step time the
-    # timed region replays the graph, otherwise it launches eagerly (EAS_BENCH_GRAPH=0/1 forces eager/graph).  Multi-GPU
-    # runs stay eager (DDP's reducer + RCCL inside a captured graph cannot be tested on the one-GPU box).
+    # replayed.  Eager launches are ~3 % faster while the host stays ahead of the GPU (quiet host: a step is enqueued in
+    # ~20 ms against the ~32 ms the GPU needs; graph nodes add ~1 ms of per-kernel cost) and much slower once it does not (a
+    # busy host: 51 ms measured for the same kernels).  So on one GPU the warm-up captures the graph and then times a few eager
+    # steps and a few replays; the timed region uses whichever was faster (EAS_BENCH_GRAPH=0/1 forces eager/graph).
+    # Multi-GPU runs stay eager (DDP's reducer + RCCL inside a captured graph cannot be tested on the one-GPU box).
     mode = os.environ.get('EAS_BENCH_GRAPH', 'auto')
     for _ in range(max(args.warmup - 2, 1)):
         loss = step()
@@ -180,9 +180,9 @@ def main():
     t_enq = time.perf_counter() - t_a
     torch.cuda.synchronize()
     t_tot = time.perf_counter() - t_a
-    host_bound = t_enq > 0.75 * t_tot
     graph = None
-    if world == 1 and not force_ddp and (mode == '1' or (mode == 'auto' and host_bound)):
+    probe = {}
+    if world == 1 and not force_ddp and mode in ('1', 'auto'):
         for gr in opt.param_groups:
             gr['capturable'] = True
         for st_ in opt.state.values():         # Adam's step counters live on the host in eager mode; a captured step needs them on the device
@@ -195,6 +195,17 @@ def main():
         with torch.cuda.graph(graph):
             loss = step()
         graph.replay()                       # warm-up replay
+        if mode == 'auto':
+            def clock(fn, n=4):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3
+            probe = {'eager_ms': round(clock(step), 3), 'graph_ms': round(clock(graph.replay), 3)}
+            if probe['eager_ms'] < probe['graph_ms']:
+                graph_keep, graph = graph, None          # eager is faster on this host right now
     run = graph.replay if graph is not None else step
     timer = ops.KernelTimer() if rank == 0 else None
     torch.cuda.synchronize()
@@ -270,7 +281,7 @@ def main():
                                        'raw events -> histogram -> fwd + bwd + Adam + reset_net',
                            'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}',
                            'launch': 'hip-graph replay of the whole step' if graph is not None else 'eager launches',
-                           'host_enqueue_share_of_step': round(t_enq / t_tot, 3)},
+                           'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3)},
                 'roofline': roofline}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.events)
