@@ -71,6 +71,7 @@ PROTOTYPES = {
     'eas_conv_pack_weights': (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),
     'eas_conv_pack_weights_many': (C.c_int, [_P, C.c_int, _P]),
     'eas_conv_fwd_supported': (C.c_int, [C.c_int] * 8),
+    'eas_conv_wgrad_parts': (C.c_int, [C.c_int] * 7),
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
     'eas_conv_dgrad_s2': (C.c_int, [_P] * 3 + [C.c_int] * 5 + [_P]),
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),

@@ -36,7 +36,9 @@ def _time_major(events):
     if events.dim() > 5:
         lead = events.shape[:-4]
         events = events.flatten(end_dim=-5)
-    return torch.flip(events.transpose(0, 1), dims=[0]).contiguous(), lead
+    # one pass: gather the micro-slices newest first into a contiguous time-major tensor (flip + contiguous would be two)
+    Tm = events.shape[1]
+    return torch.stack([events[:, Tm - 1 - t] for t in range(Tm)]), lead
 
 
 def _check_spike_fn(kwargs_spikes):

@@ -447,6 +447,14 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
     return (int64_t)slabs * Cout * Cin * 9;
 }
 
+// number of column parts eas_conv_wgrad uses for a 3x3 layer: 1 = the whole image rows fit one reduction tile, > 1 = column
+// parts (slower per flop: narrower tiles, re-staged halos), 0 = unsupported
+int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
+    WgPart parts[kMaxParts];
+    int slabs = 0;
+    return wg_parts(NI, Cin, Cout, Hi, Wi, stride, x_terms, parts, &slabs);
+}
+
 // grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and grad_y[NI][Cout][Ho][Wo].
 // x_terms as in eas_conv_fwd.  workspace: eas_conv_wgrad_workspace_floats(...) floats.
 int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,

@@ -804,7 +804,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms):
 # Per role so that a slower kernel of ours never displaces a faster library one (measured: scripts/dev_conv.py).
 CONV_POLICY = {'fwd3': 'mfma', 'fwd1': 'mfma', 'dgrad3': 'mfma', 'dgrad1': 'mfma', 'wgrad3': 'mfma', 'wgrad1': 'mfma',
                # 3x3 weight gradient of layers whose output rows are wider than the 80-pixel reduction tile (stem and dark2.0 at
-               # 128x160): eas_conv_wgrad handles them in column parts, but measured 0.92 ms against MIOpen's 0.49 ms for the two
+               # 128x160, eas_conv_wgrad_parts > 1): eas_conv_wgrad handles them in column parts, but measured 0.92 ms against MIOpen's 0.49 ms for the two
                # layers of the step (Cin = 8 fills a quarter of the MFMA tile; LDS limits dark2.0 to 28-pixel parts), so the
                # library keeps them unless this is set to 'mfma'
                'wgrad3_wide': 'aten'}
@@ -833,6 +833,16 @@ def conv_eligible(x, conv):
 
 
 _FWD_SUPPORT = {}
+_WG_PARTS = {}
+
+
+def _wgrad_single_part(NI, Cin, Cout, Hi, Wi, stride, x_terms):
+    key = (NI, Cin, Cout, Hi, Wi, stride, x_terms)
+    r = _WG_PARTS.get(key)
+    if r is None:
+        r = _WG_PARTS[key] = _lib.lib().eas_conv_wgrad_parts(*key)
+    return r == 1
+
 
 
 def conv_fwd_supported(NI, Cin, Cout, Hi, Wi, k, stride, x_terms):
@@ -871,7 +881,7 @@ class _ConvFn(torch.autograd.Function):
         own_d = (ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
                  and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3], k, 1, 3))
         own_w = ctx.needs_input_grad[1] and CONV_POLICY['wgrad%d' % k] == 'mfma' and (
-            k == 1 or gy.shape[-1] <= 80 or CONV_POLICY['wgrad3_wide'] == 'mfma') and _lib.lib().eas_conv_wgrad_workspace_floats(
+            k == 1 or CONV_POLICY['wgrad3_wide'] == 'mfma' or _wgrad_single_part(x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stride, x_terms)) and _lib.lib().eas_conv_wgrad_workspace_floats(
             x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
         own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and CONV_POLICY['dgrad3'] == 'mfma' and w.shape[0] % 8 == 0

@@ -297,6 +297,9 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
  * or three; per-block partial sums are reduced in fixed order through `workspace`
  * (eas_conv_wgrad_workspace_floats(...) floats) -- deterministic. */
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
+/* number of column parts eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, > 1 = column parts
+ * (correct but slower per flop), 0 = unsupported. */
+int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms);
 int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi,
                    int Wi, int ksize, int stride, int x_terms, eas_stream_t stream);
 
