@@ -11,7 +11,9 @@
 //     GEMM view: D[co][pixel] = A[co][(tap,ci)] * B[(tap,ci)][pixel];  A = weights, packed once per call into MFMA
 //     fragment order (conv_pack_weights_kernel), read straight from L2 into registers; B = the input patch, staged
 //     through LDS as [term][input pixel incl. zero halo][ci chunk] bf16, so each lane's 8 consecutive ci are one 16-byte
-//     ds_read_b128 and the KS*KS taps are plain address offsets into the same image.
+//     ds_read_b128 and the KS*KS taps are plain address offsets into the same image; the two 8-channel halves of a k-step
+//     live in separate planes ([term][8-channel group][pixel][16 B]) so that the 32 lanes of a half-wave read 512 contiguous
+//     bytes (pixel-major 32-byte rows cost a 2-way bank conflict on every fragment read).
 //   input gradient of a stride-1 conv is the same kernel on grad_y with the weights packed transposed + flipped.
 //
 //   input gradient of a stride-2 3x3 conv: per parity class of the input pixel a stride-1 tap-list convolution (eas_conv_dgrad_s2).
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     const int img0 = fdiv(rho0, g.m_Ho), r0 = rho0 - img0 * g.Ho;
     const int mt0 = (blockIdx.y * WVM + wm) * WM;
     const int term_stride = g.Q * PIXB;
+    const int grp = g.Q * 16;      // bytes of one 8-channel group plane: LDS layout [term][8-channel group][pixel][8 ch = 16 B]
     const int buf_bytes = term_stride * XT;
     const int npix = g.RT * g.Wo;
 
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
             const int bt = fdiv(row, g.m_rows), rw = row - bt * rows;   // bt = buffer*XT + term
             const int hc = k / (PIXB / 16), kk = k - hc * (PIXB / 16);
             const int col = hc < g.pad_l ? hc : g.Wi + hc;
-            *(uint4*)(smem + (size_t)bt * term_stride + ((size_t)rw * g.RS + col) * PIXB + kk * 16) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(smem + (size_t)bt * term_stride + (size_t)kk * grp + ((size_t)rw * g.RS + col) * 16) = make_uint4(0, 0, 0, 0);
         }
     }
 
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int pc = p < npix ? p : 0;
         const int rl = fdiv(pc, g.m_Wo), c = pc - rl * g.Wo;
         const int seg = fdiv(rl, g.m_rows_seg), rr = rl - seg * g.rows_seg;
-        qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S) * PIXB + h * 16;
+        qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S) * 16 + h * grp;
         const int rho = rho0 + rl;
         const int img = fdiv(rho, g.m_Ho), orow = rho - img * g.Ho;
         const int yr = orow * g.os + g.oph, yc = c * g.os + g.opw;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int ir = r0 * S - g.pad_t + rl, img = img0 + seg;
         const bool ok = ir >= 0 && ir < g.Hi && img < g.NI;
         gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + cu * VEC) : -1;
-        lofs[it] = ((seg * g.rows_in + rl) * g.RS + g.pad_l + cu * VEC) * PIXB + gi * 16;
+        lofs[it] = ((seg * g.rows_in + rl) * g.RS + g.pad_l + cu * VEC) * 16 + gi * grp;
         gch[it] = gi * 8;
     }
 
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = L[it][j][p];
-            stage_store<XT>(buf + lofs[it] + p * PIXB, term_stride, v, inexact);
+            stage_store<XT>(buf + lofs[it] + p * 16, term_stride, v, inexact);
         }
     };
 
@@ -355,20 +358,20 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
             bf16x8 b[WN][XT];
             if constexpr (BPF) {
                 if (s == 0) {
-                    const int toff0 = g.tap_off[0] * PIXB;
+                    const int toff0 = g.tap_off[0] * 16;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bq[0][j] = *(const bf16x8*)(cur + qoff[j] + toff0);
                 }
                 if (s + 1 < NSTEPS) {
                     const int kk1 = (s + 1) / TAPS, tap1 = (s + 1) - kk1 * TAPS;
-                    const int toff1 = g.tap_off[tap1] * PIXB + kk1 * 32;
+                    const int toff1 = g.tap_off[tap1] * 16 + kk1 * 2 * grp;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bq[(s + 1) % NSETS][j] = *(const bf16x8*)(cur + qoff[j] + toff1);
                 }
 #pragma unroll
                 for (int j = 0; j < WN; ++j) b[j][0] = bq[s % NSETS][j];
             } else {
-                const int toff = g.tap_off[tap] * PIXB + kk * 32;
+                const int toff = g.tap_off[tap] * 16 + kk * 2 * grp;
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
