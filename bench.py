@@ -107,9 +107,30 @@ def cpu_baseline(cpu_batch, n_events):
         el = time.time() - t0
         if el > 12.0 or n >= 5 or warm > 20.0:   # bounded sample: ~10-30 s of CPU work
             break
+    # SURVEY 8(d) side figures: K1's numpy restatement single-threaded (how a DataLoader worker runs it) and the eval
+    # forward of one sample (BASELINE configs[0]), both bounded to a few seconds
+    t1 = time.time()
+    k1_n = 0
+    while time.time() - t1 < 1.5:
+        events_ref.micro_sum(*streams[k1_n % cpu_batch], 4, *SENSOR)
+        k1_n += 1
+    k1_rate = k1_n * n_events / (time.time() - t1)
+    model.eval()
+    one = torch.from_numpy(np.zeros((1, 1, 4, 2) + CANVAS, np.float32))
+    one[0, 0, :, :, :SENSOR[0], :SENSOR[1]] = torch.from_numpy(events_ref.micro_sum(*streams[0], 4, *SENSOR).astype(np.float32))
+    with torch.no_grad():
+        model(one)
+        sj_ref.reset_net(model)
+        t2, ev_n = time.time(), 0
+        while time.time() - t2 < 2.0:
+            model(one)
+            sj_ref.reset_net(model)
+            ev_n += 1
+    ev_rate = ev_n / (time.time() - t2)
     return {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port',
             'sample': f'oracle (torch-CPU fp32) SYOLOX-S T=3 256x320 fwd+bwd+Adam, batch {cpu_batch}, {n} iterations, '
-                      f'{n_events} events/sample binned with numpy'}
+                      f'{n_events} events/sample binned with numpy',
+            'k1_numpy_events_per_s_1thread': round(k1_rate), 'eval_forward_1_sample_frames_per_s': round(ev_rate, 2)}
 
 
 def main():
