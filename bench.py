@@ -170,8 +170,19 @@ def main():
     model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
     opt = exp.get_optimizer(args.batch * world)
     net = model
+    flat_sync = None
+    # gradient exchange at N > 1: one flat RCCL all-reduce after backward (eas_snn_amd/parallel.py; ~7 ms less host work per step
+    # than DistributedDataParallel, which hides a 0.6 ms all-reduce but pushes the host to 0.83 of the step) -- EAS_BENCH_DP=ddp
+    # selects DistributedDataParallel (bucketed, overlapped with backward) instead
+    dp_mode = os.environ.get('EAS_BENCH_DP', 'flat')
     if world > 1 or force_ddp:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
+        if dp_mode == 'ddp':
+            # gradients live inside the all-reduce buckets (no per-parameter copy kernels)
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
+                                                            gradient_as_bucket_view=True)
+        else:
+            from eas_snn_amd.parallel import FlatGradAllReduce
+            flat_sync = FlatGradAllReduce(model)
 
     ev = data.events_to_device(data.synth_event_batch(args.batch, args.events, *SENSOR, seed=rank), dev)
     targets = data.synth_targets(args.batch, CANVAS, dev)
@@ -181,6 +192,8 @@ def main():
         out = net(frames, targets)
         opt.zero_grad(set_to_none=True)
         out['total_loss'].backward()
+        if flat_sync is not None:
+            flat_sync.sync()
         opt.step()
         functional.reset_net(model)
         return out['total_loss']
@@ -300,7 +313,7 @@ def main():
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, batch 64/GPU, '
                                        'raw events -> histogram -> fwd + bwd + Adam + reset_net',
-                           'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}',
+                           'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}', 'gradient_exchange': (dp_mode if (world > 1 or force_ddp) else None),
                            'launch': 'hip-graph replay of the whole step' if graph is not None else 'eager launches',
                            'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3)},
                 'roofline': roofline}

@@ -158,6 +158,24 @@ def _worker_main(tag, out_dir):
         ddp.module.weight.fill_(1.0)
     ddp(torch.full((1, 3), float(rank + 1))).sum().backward()
     assert torch.allclose(ddp.module.weight.grad, torch.full((1, 3), 1.5))
+    # the flat gradient all-reduce bench.py uses at N > 1 (eas_snn_amd/parallel.py): parameters broadcast from rank 0, gradients
+    # averaged with one collective, identical to DDP's result
+    from eas_snn_amd.parallel import FlatGradAllReduce
+    torch.manual_seed(100 + rank)                       # different initial weights per rank: the constructor must equalise them
+    mlp = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2))
+    sync = FlatGradAllReduce(mlp)
+    w0 = [p.detach().clone() for p in mlp.parameters()]
+    gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
+    dist.all_gather(gathered, w0[0])
+    assert torch.equal(gathered[0], gathered[1])
+    x = torch.arange(6, dtype=torch.float32).view(2, 3) * (rank + 1)
+    mlp(x).square().sum().backward()
+    local = [p.grad.clone() for p in mlp.parameters()]
+    sync.sync()
+    for p, g in zip(mlp.parameters(), local):
+        both = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(both, g)
+        assert torch.allclose(p.grad, (both[0] + both[1]) / 2, rtol=1e-6, atol=1e-7)
     open(os.path.join(out_dir, f'ok_{tag}_{rank}'), 'w').write('ok')
 
 
