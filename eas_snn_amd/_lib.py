@@ -138,6 +138,18 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = None
+
+
 def stream():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream on the current device (called once per kernel launch: the raw getter avoids
+    building a torch.cuda.Stream object every time)"""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        if raw is not None:
+            _RAW_STREAM = lambda: raw(torch.cuda.current_device())
+        else:
+            _RAW_STREAM = lambda: torch.cuda.current_stream().cuda_stream
+    return _RAW_STREAM()
