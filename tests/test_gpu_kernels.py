@@ -141,6 +141,40 @@ def test_event_frames_equals_histogram_plus_canvas(dev, form, monkeypatch):
     assert np.array_equal(frames[..., :H, :W].cpu().numpy(), want.astype(np.float32)) and float(frames[1].abs().sum()) == 0
 
 
+@pytest.mark.parametrize('form', ['scatter', 'banded'])
+@pytest.mark.parametrize('H,W,Tm,B', [(101, 300, 3, 3), (61, 1000, 2, 5), (7, 5, 5, 2)])
+def test_event_histogram_odd_geometries(dev, form, H, W, Tm, B, monkeypatch):
+    """band heights that do not divide the sensor height, widths that are not multiples of 4, B*Tm not a multiple of 8"""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    monkeypatch.setenv('EAS_HIST_FORM', form)
+    parts = [events_ref.synth_events(5000 + 777 * i, H, W, seed=60 + i) for i in range(B)]
+    t, x, y, p = (np.concatenate([q[j] for q in parts]) for j in range(4))
+    off = np.cumsum([0] + [len(q[0]) for q in parts]).astype(np.int64)
+    args = (_t(t.view(np.int32), dev).view(torch.uint32), _t(x.view(np.int16), dev).view(torch.uint16),
+            _t(y.view(np.int16), dev).view(torch.uint16), _t(p, dev), _t(off, dev), Tm, H, W)
+    ref = events_ref.micro_sum_batch(t, x, y, p, off, Tm, H, W)
+    assert np.array_equal(ops.event_histogram(*args).cpu().numpy(), ref)
+    Hc, Wc = H + 3, W + 5
+    fr = ops.event_frames(*args, Hc, Wc).cpu().numpy()
+    assert np.array_equal(fr[..., :H, :W], ref.astype(np.float32)) and fr[..., H:, :].sum() == 0 and fr[..., :, W:].sum() == 0
+
+
+def test_postprocess_score_ties_keep_anchor_order(dev):
+    """identical boxes and scores: the stable descending sort keeps the lowest anchor index (torchvision's nms sorts stably)"""
+    from eas_snn_amd import ops
+    from oracle import postprocess_ref
+    pred = np.zeros((1, 64, 7), np.float32)
+    pred[0, :, :4] = [50, 50, 20, 20]
+    pred[0, :, 4] = 0.5
+    pred[0, :, 5] = 0.8
+    pred[0, 10:20, 0] += 100          # a second cluster, same scores
+    pred[0, 30:, 6] = 0.8             # third group: both classes tie -> class 0 (first maximum)
+    got = ops.postprocess(_t(pred, dev), 2, 0.1, 0.5)
+    want = postprocess_ref.postprocess(pred, 2, 0.1, 0.5)
+    assert np.array_equal(got[0].cpu().numpy(), want[0]) and len(want[0]) == 2
+
+
 def test_event_histogram_full_size_properties(dev):
     """BASELINE config size (64 x 200k events): checksum-style properties, oracle on a subsample."""
     from eas_snn_amd import data, ops
