@@ -6,8 +6,8 @@
 // The arg-max is separable under the first-maximum rule: the leftmost maximum of each row window (one scan over the
 // widest window serves all three pool sizes), then the first row whose row-maximum is strictly greater.  The three
 // arg-max indices of a pixel are packed into one word (10 bits each, planes <= 1024 pixels).  The backward recomputes
-// the arg-max from x (nothing is saved) and gathers over the widest window in a fixed order (deterministic, no atomics),
-// with the pooled gradients staged in LDS.
+// the arg-max from x (nothing is saved) and gathers separably (column pass, then row pass) in a fixed order (deterministic,
+// no atomics), with the pooled gradients staged in LDS.
 #include "eas_common.h"
 
 namespace {
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restr
     __shared__ unsigned rowarg[kMaxPlane];
     __shared__ unsigned amax[kMaxPlane];
     __shared__ float gp[3][kMaxPlane];
+    __shared__ float tcol[3][kMaxPlane];
     const long long p0 = (long long)blockIdx.x * g.ppb;
     const int np = (int)(g.planes - p0 < g.ppb ? g.planes - p0 : g.ppb);
     const int work = np * g.HW;
@@ -115,25 +116,39 @@ __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restr
     __syncthreads();
     spp_argmax(plane, rowarg, amax, g, work);
     __syncthreads();
+    // Separable gather.  Output (a, b) of pool j sends its gradient to (row, col) = (bestrow_j(a, b), rowarg_j(bestrow, b)):
+    //   tcol_j(h, b) = sum over a in [h - r, h + r] of g_j(a, b) where bestrow_j(a, b) == h          (column pass)
+    //   gx(h, w)    += sum over b in [w - r, w + r] of tcol_j(h, b) where rowarg_j(h, b) == w         (row pass)
+    // 2 * (2r + 1) reads per pixel and pool instead of (2r + 1)^2, fixed order (deterministic, no atomics).
     const int rs[3] = {g.r0, g.r1, g.r2};
-    const int rmax = max(g.r0, max(g.r1, g.r2));
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        const int lp = idx / g.HW, i = idx - lp * g.HW, h = i / g.W, b = i - h * g.W;
+        const int base = lp * g.HW;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = rs[j];
+            const int a0 = h - r < 0 ? 0 : h - r, a1 = h + r >= g.H ? g.H - 1 : h + r;
+            float t = 0.f;
+            for (int a = a0; a <= a1; ++a) {
+                const int q = base + a * g.W + b;
+                const int bestrow = (int)((amax[q] >> (10 * j)) & 1023u) / g.W;
+                if (bestrow == h) t += gp[j][q];
+            }
+            tcol[j][idx] = t;
+        }
+    }
+    __syncthreads();
     for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
         const int lp = idx / g.HW, i = idx - lp * g.HW, h = i / g.W, w = i - h * g.W;
         const long long pc = p0 + lp, n = pc / g.C, c = pc - n * g.C;
+        const int rowbase = lp * g.HW + h * g.W;
         float s = gout[(n * 4 * g.C + c) * g.HW + i];
-        const int h0 = h - rmax < 0 ? 0 : h - rmax, h1 = h + rmax >= g.H ? g.H - 1 : h + rmax;
-        const int w0 = w - rmax < 0 ? 0 : w - rmax, w1 = w + rmax >= g.W ? g.W - 1 : w + rmax;
-        for (int a = h0; a <= h1; ++a) {
-            const int da = a > h ? a - h : h - a;
-            for (int b = w0; b <= w1; ++b) {
-                const int db = b > w ? b - w : w - b;
-                const int d = da > db ? da : db;
-                const int q = lp * g.HW + a * g.W + b;
-                const unsigned pk = amax[q];
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (d <= rs[j] && (int)((pk >> (10 * j)) & 1023u) == i) s += gp[j][q];
-            }
+        for (int j = 0; j < 3; ++j) {
+            const int r = rs[j];
+            const int b0 = w - r < 0 ? 0 : w - r, b1 = w + r >= g.W ? g.W - 1 : w + r;
+            for (int b = b0; b <= b1; ++b)
+                if ((int)((rowarg[rowbase + b] >> (10 * j)) & 1023u) == w) s += tcol[j][rowbase + b];
         }
         gx[pc * g.HW + i] = s;
     }
