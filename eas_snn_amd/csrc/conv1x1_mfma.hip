@@ -5,6 +5,8 @@
 // registers to exact bf16 term(s).  A = weights pre-packed in fragment order (conv_pack_weights_kernel, taps = 1), read
 // from L1/L2.  HBM-bound (<= 64 flop/byte): x is read once per 32*WM output channels, y written once.
 // (reference: nn.Conv2d(k=1) inside BaseConv, yolox/models/network_blocks.py:31-56.)
+#include <stdlib.h>
+
 #include "eas_common.h"
 
 namespace {
@@ -313,6 +315,192 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(const float* __re
     }
 }
 
+// LDS-staged form.  The direct form above hands the texture unit 64 different cache lines per load instruction (lanes =
+// channels, 32 bytes each), which bounds it near 2 TB/s.  Here the block stages a [channels] x [KC pixels] slab of grad_y
+// and x with coalesced 16-byte loads (consecutive lanes = consecutive pixels of one channel row), converts every element ONCE
+// to its exact bf16 term(s) (the direct form converts x in each of its four waves) and the waves read MFMA fragments from
+// LDS: lane (channel r, half h) reads 16 bytes at row r, pixels 8h..8h+7 of a k-step.  Row pitch = KC*2 + 16 bytes (an odd
+// multiple of 16: the 16 lanes of a b128 pass cover all banks).  Block tile = (32*WVM) co x (32*WVN*NT) ci, 4 waves;
+// double-buffered: the next chunk's global loads are issued before the current chunk's MFMAs and written to the other
+// buffer after them (one barrier per chunk).
+template <int XT, int WVM, int WVN, int NT, int KS>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                float* __restrict__ slabs, W1Geom g) {
+    constexpr int KC = 16 * KS;                 // pixels per chunk
+    constexpr int PITCH = KC * 2 + 16;          // bytes per channel row and term
+    constexpr int RA = 32 * WVM, RB = 32 * WVN * NT;
+    constexpr int A_TERM = RA * PITCH, B_TERM = RB * PITCH;
+    constexpr int BUF = 3 * A_TERM + XT * B_TERM;
+    constexpr int V4R = KC / 4;                 // float4 loads per channel row and chunk
+    constexpr int ITEMS = (RA + RB) * V4R;      // float4 staging items per chunk
+    constexpr int NIT = (ITEMS + 255) / 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int cob = blockIdx.y / g.ci_blocks, cib = blockIdx.y - cob * g.ci_blocks;
+    const int co0 = cob * RA, ci0 = cib * RB;
+
+    // staging items: item -> (row, float4 index in the row); rows [0, RA) grad_y channels, [RA, RA+RB) x channels
+    int it_goff[NIT];        // element offset inside the image's tensor (channel * HW + 4 * v), -1: zero row
+    int it_lofs[NIT];        // LDS byte offset of the first term
+    bool it_isa[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int item = it * 256 + tid;
+        item = item < ITEMS ? item : ITEMS - 1;
+        const int row = item / V4R, v = item - row * V4R;
+        const bool isa = row < RA;
+        const int ch = isa ? co0 + row : ci0 + row - RA;
+        const bool ok = isa ? ch < g.Cout : ch < g.Cin;
+        it_isa[it] = isa;
+        it_goff[it] = ok ? ch * g.HW + 4 * v : -1;
+        it_lofs[it] = isa ? row * PITCH + 8 * v : 3 * A_TERM + (row - RA) * PITCH + 8 * v;
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+
+    const int chunks_img = g.HW / KC;
+    const int total_chunks = g.NI * chunks_img;
+    const int c_begin = blockIdx.x * g.per_slice;
+    const int c_end = c_begin + g.per_slice < total_chunks ? c_begin + g.per_slice : total_chunks;
+
+    f32x4 L[NIT];
+    auto fetch = [&](int c) {
+        const int img = c / chunks_img, p0 = (c - img * chunks_img) * KC;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it * 256 >= ITEMS) continue;
+            const float* base = it_isa[it] ? gy + (long)img * g.Cout * g.HW : x + (long)img * g.Cin * g.HW;
+            const float* src = it_goff[it] >= 0 ? base + it_goff[it] + p0 : eas_c1_zero_page;
+            L[it] = *(const f32x4*)src;
+        }
+    };
+    auto commit = [&](unsigned char* buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it * 256 >= ITEMS || it * 256 + tid >= ITEMS) continue;
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 t0, t1, t2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = L[it][j];
+                const __bf16 hi = (__bf16)v;
+                const float r1 = v - (float)hi;
+                const __bf16 mid = (__bf16)r1;
+                t0[j] = hi;
+                t1[j] = mid;
+                t2[j] = (__bf16)(r1 - (float)mid);
+            }
+            unsigned char* dst = buf + it_lofs[it];
+            *(bf16x4*)dst = t0;
+            if (it_isa[it]) {
+                *(bf16x4*)(dst + A_TERM) = t1;
+                *(bf16x4*)(dst + 2 * A_TERM) = t2;
+            } else if (XT == 3) {
+                *(bf16x4*)(dst + B_TERM) = t1;
+                *(bf16x4*)(dst + 2 * B_TERM) = t2;
+            }
+        }
+    };
+
+    const int a_frag = (wm * 32 + r) * PITCH + 16 * h;                        // + term * A_TERM + ks * 32
+    const int b_frag = 3 * A_TERM + (wn * NT * 32 + r) * PITCH + 16 * h;      // + n * 32 * PITCH + term * B_TERM + ks * 32
+
+    int c = c_begin;
+    if (c < c_end) {
+        fetch(c);
+        commit(smem);
+    }
+    __syncthreads();
+    int par = 0;
+    for (; c < c_end; ++c, par ^= 1) {
+        const unsigned char* cur = smem + par * BUF;
+        const bool more = c + 1 < c_end;
+        if (more) fetch(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[t] = *(const bf16x8*)(cur + a_frag + t * A_TERM + ks * 32);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bf16x8 b[XT];
+#pragma unroll
+                for (int t = 0; t < XT; ++t) b[t] = *(const bf16x8*)(cur + b_frag + n * 32 * PITCH + t * B_TERM + ks * 32);
+                if constexpr (XT == 1) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[n], 0, 0, 0);
+                } else {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[n], 0, 0, 0);
+                }
+            }
+        }
+        if (more) commit(smem + (par ^ 1) * BUF);
+        __syncthreads();
+    }
+
+    // partial sums of this block -> slab [slice][co][ci]; D: col = ci = lane&31, row = co = (e&3) + 8*(e>>2) + 4*h
+    float* slab = slabs + (size_t)blockIdx.x * g.Cout * g.Cin;
+    const int row0 = co0 + wm * 32 + 4 * h;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ci = ci0 + (wn * NT + n) * 32 + r;
+        if (ci >= g.Cin) continue;
+        float* sp = slab + (size_t)row0 * g.Cin + ci;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (row0 + (e & 3) + 8 * (e >> 2) < g.Cout) sp[(size_t)((e & 3) + 8 * (e >> 2)) * g.Cin] = acc[n][e];
+    }
+}
+
+struct W1Plan { int wvm, wvn, nt, ks, slices; };
+
+// block shape for the LDS form: all four waves busy whatever Cout is
+W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW) {
+    W1Plan p;
+    if (Cout > 64) { p.wvm = 4; p.wvn = 1; p.nt = 4; }
+    else if (Cout > 32) { p.wvm = 2; p.wvn = 2; p.nt = 2; }
+    else { p.wvm = 1; p.wvn = 4; p.nt = 1; }
+    p.ks = HW % 32 == 0 ? 2 : 1;
+    g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
+    const int RA = 32 * p.wvm, RB = 32 * p.wvn * p.nt;
+    g.ci_blocks = (Cin + RB - 1) / RB;
+    const int yz = ((Cout + RA - 1) / RA) * g.ci_blocks;
+    const int total_chunks = NI * (HW / (16 * p.ks));
+    int slices = (512 + yz - 1) / yz;
+    if (slices > total_chunks) slices = total_chunks;
+    g.per_slice = (total_chunks + slices - 1) / slices;
+    p.slices = (total_chunks + g.per_slice - 1) / g.per_slice;
+    return p;
+}
+
+template <int XT, int WVM, int WVN, int NT, int KS>
+int launch_w1_lds(const float* x, const float* gy, float* slabs, W1Geom g, int slices, hipStream_t st) {
+    auto kern = conv1x1_wgrad_lds_kernel<XT, WVM, WVN, NT, KS>;
+    constexpr int PITCH = 16 * KS * 2 + 16;
+    const size_t lds = (size_t)2 * (3 * 32 * WVM + XT * 32 * WVN * NT) * PITCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(slices, ((g.Cout + 32 * WVM - 1) / (32 * WVM)) * g.ci_blocks);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, gy, slabs, g);
+    return EAS_OK;
+}
+
 bool w1_geom(W1Geom& g, int NI, int Cin, int Cout, int HW) {
     if (HW % 16 != 0) return false;
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
@@ -328,8 +516,15 @@ bool w1_geom(W1Geom& g, int NI, int Cin, int Cout, int HW) {
 
 }  // namespace
 
+static bool w1_use_lds() {
+    static const int v = getenv("EAS_W1_FORM") ? (getenv("EAS_W1_FORM")[0] == 'd' ? 0 : 1) : 1;   // development switch: "direct" / "lds"
+    return v != 0;
+}
+
 int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW) {
     W1Geom g{};
+    if (HW % 16 != 0) return 0;
+    if (w1_use_lds()) return w1_plan(g, NI, Cin, Cout, HW).slices;
     if (!w1_geom(g, NI, Cin, Cout, HW)) return 0;
     return (g.total_ksteps + g.per_slice - 1) / g.per_slice;
 }
@@ -337,6 +532,15 @@ int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW) {
 // slabs: eas_conv1x1_wgrad_slices(...) * Cout * Cin floats; the caller reduces them (conv_wgrad_reduce_kernel)
 int eas_conv1x1_wgrad_dispatch(const float* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st) {
     W1Geom g{};
+    if (HW % 16 != 0) return EAS_ERR_UNSUPPORTED;
+    if (w1_use_lds()) {
+        const W1Plan p = w1_plan(g, NI, Cin, Cout, HW);
+#define EAS_W1(XT_, M_, N_, T_) (p.ks == 2 ? launch_w1_lds<XT_, M_, N_, T_, 2>(x, gy, slabs, g, p.slices, st) : launch_w1_lds<XT_, M_, N_, T_, 1>(x, gy, slabs, g, p.slices, st))
+#define EAS_W1_SHAPE(XT_) (p.wvm == 4 ? EAS_W1(XT_, 4, 1, 4) : (p.wvm == 2 ? EAS_W1(XT_, 2, 2, 2) : EAS_W1(XT_, 1, 4, 1)))
+        return x_terms == 1 ? EAS_W1_SHAPE(1) : EAS_W1_SHAPE(3);
+#undef EAS_W1_SHAPE
+#undef EAS_W1
+    }
     if (!w1_geom(g, NI, Cin, Cout, HW)) return EAS_ERR_UNSUPPORTED;
     const int slices = (g.total_ksteps + g.per_slice - 1) / g.per_slice;
     dim3 grid(slices, ((Cout + 127) / 128) * g.ci_blocks);
