@@ -479,7 +479,8 @@ W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW) {
     g.ci_blocks = (Cin + RB - 1) / RB;
     const int yz = ((Cout + RA - 1) / RA) * g.ci_blocks;
     const int total_chunks = NI * (HW / (16 * p.ks));
-    int slices = (512 + yz - 1) / yz;
+    static const int target = getenv("EAS_W1_BLOCKS") ? atoi(getenv("EAS_W1_BLOCKS")) : 512;
+    int slices = (target + yz - 1) / yz;
     if (slices > total_chunks) slices = total_chunks;
     g.per_slice = (total_chunks + slices - 1) / slices;
     p.slices = (total_chunks + g.per_slice - 1) / g.per_slice;
