@@ -167,6 +167,162 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     }
 }
 
+// Variant for layers with many input channels and few pixels (dark5: 256..1024 channels on 15 360 pixels).  There the direct
+// kernel is bound by the texture path, not by HBM or the matrix cores: every wave fetches its own copy of the weight fragments
+// (WM x 3 KB per k-step) -- 64 KB per k-step and CU against 768 cycles of MFMA work.  Here the four waves of a block (same
+// output channels, different pixels) share them: the block loads each k-step's WM x 3 fragments once (coalesced 16-byte
+// loads), double-buffers them in LDS and every wave reads its operands with conflict-free ds_read_b128.  One barrier per k-step.
+template <int XT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+                                                                      const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
+    constexpr int NFRAG = WM * 3;                        // 1 KB fragments per k-step
+    constexpr int NLD = (NFRAG * 64 + 255) / 256;        // 16-byte staging loads per thread and k-step
+    __shared__ bf16x8 As[2][NFRAG][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int mt0 = blockIdx.y * WM;
+    const int tile0 = (blockIdx.x * 4 + wave) * WN;
+
+    long xoff[WN], yoff[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int t = tile0 + n;
+        const int img = t / g.tiles_per_img, p = (t - img * g.tiles_per_img) * 32 + r;
+        const bool ok = t < g.total_tiles && p < g.HW;
+        xoff[n] = ok ? ((long)img * g.Cin + 8 * h) * g.HW + p : -1;
+        yoff[n] = ok ? (long)img * g.Cout * g.HW + p : -1;
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+    // staging piece q = it*256 + tid -> fragment f = q / 64 (= term * WM + m), lane q % 64
+    const size_t a_term = (size_t)g.MT * g.KSTEPS * 64;
+    const bf16x8* asrc[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        int q = it * 256 + tid;
+        q = q < NFRAG * 64 ? q : NFRAG * 64 - 1;
+        const int f = q >> 6, t = f / WM, m = f - t * WM;
+        const int mt = (mt0 + m) < g.MT ? (mt0 + m) : g.MT - 1;
+        asrc[it] = wp + t * a_term + (size_t)mt * g.KSTEPS * 64 + (q & 63);
+    }
+    bf16x8 areg[NLD];
+    auto a_fetch = [&](int ks) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) areg[it] = asrc[it][(size_t)ks * 64];
+    };
+    auto a_commit = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int q = it * 256 + tid;
+            if (q < NFRAG * 64) (&As[buf][0][0])[q] = areg[it];
+        }
+    };
+    auto x_fetch = [&](float (&raw)[WN][8], int ks) {
+        const bool ch_ok = ks * 16 + 8 * h < g.Cin;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const bool ok = ch_ok && xoff[n] >= 0;
+            const float* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : eas_c1_zero_page;
+            const long cs = ok ? (long)g.HW : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[n][j] = src[j * cs];
+        }
+    };
+    auto step = [&](float (&raw)[WN][8], int buf) {
+        bf16x8 a[WM][3];
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[m][t] = As[buf][t * WM + m][lane];
+        bf16x8 b[WN][XT];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) to_terms<XT>(raw[n], b[n]);
+        if constexpr (XT == 1) {
+#pragma unroll
+            for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][ta], b[n][0], acc[m][n], 0, 0, 0);
+        } else {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA[q]], b[n][PB[q]], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    float r0[WN][8], r1[WN][8];
+    a_fetch(0);
+    x_fetch(r0, 0);
+    a_commit(0);
+    __syncthreads();
+    int ks = 0;
+    for (; ks + 1 < g.KSTEPS; ks += 2) {
+        a_fetch(ks + 1);
+        x_fetch(r1, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(r0, 0);
+        a_commit(1);
+        __syncthreads();
+        const int kn = ks + 2 < g.KSTEPS ? ks + 2 : ks + 1;
+        a_fetch(kn);
+        x_fetch(r0, kn);
+        __builtin_amdgcn_sched_barrier(0);
+        step(r1, 1);
+        a_commit(0);
+        __syncthreads();
+    }
+    if (ks < g.KSTEPS) step(r0, 0);
+
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        if (mt0 + m >= g.MT) continue;
+        const int co0 = (mt0 + m) * 32 + 4 * h;
+        const bool full = (mt0 + m) * 32 + 32 <= g.Cout;
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (e & 3) + 8 * (e >> 2);
+                bv[e] = co < g.Cout ? bias[co] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            if (yoff[n] < 0) continue;
+            float* yp = y + yoff[n] + (long)co0 * g.HW;
+            if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+            }
+        }
+    }
+}
+
+template <int XT, int WM, int WN>
+int launch_c1_shared(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
+    dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
+    hipLaunchKernelGGL((conv1x1_mfma_sharedA_kernel<XT, WM, WN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    return EAS_OK;
+}
+
 template <int XT, int WM, int WN>
 int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
@@ -186,15 +342,50 @@ int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias
     g.MT = (Cout + 31) / 32;
     g.KSTEPS = (Cin + 15) / 16;
     const bf16x8* wp = (const bf16x8*)packed_w;
-    // all output channels in one wave when they fit (x is then read exactly once); 2 pixel tiles per wave
-    if (x_terms == 1) {
-        if (g.MT >= 4) return launch_c1<1, 4, 2>(x, wp, bias, y, g, st);
-        if (g.MT >= 2) return launch_c1<1, 2, 2>(x, wp, bias, y, g, st);
-        return launch_c1<1, 1, 2>(x, wp, bias, y, g, st);
+    // wave tile = WM channel tiles x WN pixel tiles.  Large layers: all output channels in one wave when they fit (x is then read
+    // once per 128 output channels), 2 pixel tiles per wave.  Layers with few pixels and many channels (dark5: 15 360 pixels, up
+    // to 1024 -> 512 channels) would leave most CUs with one 4-wave block or none: shrink the wave tile until the grid has at
+    // least ~2 blocks per CU (x is re-read from L2 by more channel groups, which these small layers can afford).
+    int wm = g.MT >= 4 ? 4 : (g.MT >= 2 ? 2 : 1), wn = 2;
+    auto blocks = [&](int m, int n) { return (long)((g.total_tiles + 4 * n - 1) / (4 * n)) * ((g.MT + m - 1) / m); };
+    static const long want = getenv("EAS_C1_BLOCKS") ? atol(getenv("EAS_C1_BLOCKS")) : 512;
+    if (blocks(wm, wn) < want) wn = 1;
+    while (blocks(wm, wn) < want && wm > 1) wm >>= 1;
+    // many input channels (>= 256): weight-fragment traffic, not HBM, bounds the direct kernel -> block-shared fragments
+    static const int shared_min = getenv("EAS_C1_SHARED_MIN_CIN") ? atoi(getenv("EAS_C1_SHARED_MIN_CIN")) : 256;
+    if (Cin >= shared_min && g.MT >= 4) {
+        // wave tile of the shared form: shrink it while the grid has fewer than ~2 blocks per CU
+        int sm = 4, sn = 2;
+        static const char* force = getenv("EAS_C1_SHARED_SHAPE");     // development: "42", "41", "22", "21"
+        if (force) { sm = force[0] - '0'; sn = force[1] - '0'; }
+        else {
+            constexpr long want_s = 384;       // swept on the dark4 / dark5 shapes (scripts/dev_conv.py c1time)
+            if (blocks(sm, sn) < want_s) sn = 1;
+            if (blocks(sm, sn) < want_s) sm = 2;
+        }
+#define EAS_C1S(XT_)                                                                            \
+    do {                                                                                        \
+        if (sm == 4 && sn == 2) return launch_c1_shared<XT_, 4, 2>(x, wp, bias, y, g, st);      \
+        if (sm == 4) return launch_c1_shared<XT_, 4, 1>(x, wp, bias, y, g, st);                 \
+        if (sn == 2) return launch_c1_shared<XT_, 2, 2>(x, wp, bias, y, g, st);                 \
+        return launch_c1_shared<XT_, 2, 1>(x, wp, bias, y, g, st);                              \
+    } while (0)
+        if (x_terms == 1) EAS_C1S(1);
+        EAS_C1S(3);
+#undef EAS_C1S
     }
-    if (g.MT >= 4) return launch_c1<3, 4, 2>(x, wp, bias, y, g, st);
-    if (g.MT >= 2) return launch_c1<3, 2, 2>(x, wp, bias, y, g, st);
-    return launch_c1<3, 1, 2>(x, wp, bias, y, g, st);
+#define EAS_C1(XT_)                                                                     \
+    do {                                                                                \
+        if (wm == 4 && wn == 2) return launch_c1<XT_, 4, 2>(x, wp, bias, y, g, st);     \
+        if (wm == 2 && wn == 2) return launch_c1<XT_, 2, 2>(x, wp, bias, y, g, st);     \
+        if (wm == 1 && wn == 2) return launch_c1<XT_, 1, 2>(x, wp, bias, y, g, st);     \
+        if (wm == 4) return launch_c1<XT_, 4, 1>(x, wp, bias, y, g, st);                \
+        if (wm == 2) return launch_c1<XT_, 2, 1>(x, wp, bias, y, g, st);                \
+        return launch_c1<XT_, 1, 1>(x, wp, bias, y, g, st);                             \
+    } while (0)
+    if (x_terms == 1) EAS_C1(1);
+    EAS_C1(3);
+#undef EAS_C1
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -378,24 +378,26 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
                     for (int t = 0; t < XT; ++t) b[j][t] = *(const bf16x8*)(cur + t * term_stride + qoff[j] + toff);
             }
             bf16x8 (&a_cur)[WM][3] = a[s % NSETS];
+            // smallest products first; pairs (weight term, input term) with ta + tb <= 2.  Term-major order: consecutive MFMAs go
+            // to different accumulators (a dependent MFMA right behind its producer waits for the result), the order per
+            // accumulator is unchanged
+            if constexpr (XT == 1) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int ta = 2; ta >= 0; --ta)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    // smallest products first; pairs (weight term, input term) with ta + tb <= 2
-                    if constexpr (XT == 1) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                    }
-                }
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][ta], b[j][0], acc[i][j], 0, 0, 0);
+            } else {
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+            }
             if (SPREAD && more) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)

@@ -149,3 +149,22 @@ if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[1] == 'one':
     one(int(sys.argv[2]))
 if __name__ == '__main__' and sys.argv[1:] == ['ablate']:
     ablate()
+
+
+def c1time():
+    """1x1 forward / input-gradient shapes with many channels (dark4 / dark5)"""
+    shapes = [('dark5.spp.conv2 fwd', 192, 1024, 512, 8, 10, True), ('dark5.conv3 fwd', 192, 512, 512, 8, 10, True),
+              ('dark5.conv1 fwd', 192, 512, 256, 8, 10, True), ('dark5.m.conv1 fwd', 192, 256, 256, 8, 10, True),
+              ('dark5.spp.conv2 dgrad', 192, 512, 1024, 8, 10, False), ('dark5.conv3 dgrad', 192, 512, 512, 8, 10, False),
+              ('dark4.conv3 fwd', 192, 256, 256, 16, 20, True), ('dark4.conv3 dgrad', 192, 256, 256, 16, 20, False),
+              ('dark4.conv1 fwd', 192, 256, 128, 16, 20, True)]
+    for name, NI, Cin, Cout, H, W, sp in shapes:
+        x, w = make(NI, Cin, Cout, H, W, 1, sp)
+        pk = ops.conv_pack_weights(w, 0)
+        t = timeit(lambda: ops.conv_fwd_packed(x, pk, None, Cout, 1, 1, 1 if sp else 3))
+        mb = 4 * NI * H * W * (Cin + Cout) / 1e6
+        print(f'{name:24s} {t * 1e3:7.1f} us   {mb / t / 1e3:6.2f} TB/s algorithmic ({mb:.0f} MB)', flush=True)
+
+
+if __name__ == '__main__' and sys.argv[1:] == ['c1time']:
+    c1time()
