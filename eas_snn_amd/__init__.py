@@ -5,7 +5,9 @@ Layout:
   _lib.py, ops.py  ctypes binding and autograd operators over the C ABI
   compat/          host-side mirror of the reference's operator interface:
                    ``spikingjelly.activation_based`` and the ``yolox`` names the EAS-SNN tools import
-  data.py          synthetic event streams -> GPU event histogram (K1) -> model input
+  data.py          synthetic event streams -> GPU event histogram (K1) -> model input; augmentation draws + box transform
+  stats.py         spike-count / SOP statistics and the reference's energy estimate on the device
+  parallel.py      flat gradient all-reduce over RCCL for one process per GPU
 
 Importing this package puts ``compat/`` at the front of ``sys.path`` so that ``import spikingjelly`` /
 ``import yolox`` resolve to the HIP-backed implementations (set EAS_SNN_NO_COMPAT=1 to skip).
