@@ -168,6 +168,7 @@ def main():
     torch.manual_seed(80)
     model = exp.get_model().to(dev)
     model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
+    model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'    # development switch: 0 = tensor-op SimOTA
     opt = exp.get_optimizer(args.batch * world)
     net = model
     flat_sync = None

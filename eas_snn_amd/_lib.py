@@ -37,6 +37,7 @@ PROTOTYPES = {
     'eas_postprocess_workspace_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'eas_postprocess': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P, _P]),
     'eas_event_frames': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    'eas_simota_assign': (C.c_int, [_P] * 8 + [C.c_int] * 4 + [_P] * 4),
     'eas_event_voxel_grid': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_lif_fwd': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P, _P, C.c_int, C.c_int64, _P]),
     'eas_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,

@@ -53,6 +53,7 @@ class YOLOXHead(nn.Module):
             self.reg_preds.append(nn.Conv2d(hid, 4, 1, 1, 0))
             self.obj_preds.append(nn.Conv2d(hid, 1, 1, 1, 0))
         self.use_l1 = False
+        self.fused_assign = True       # SimOTA assignment in one HIP launch (ops.simota_assign); False = the tensor-op form (_assign)
         self.l1_loss = nn.L1Loss(reduction='none')
         self.bcewithlog_loss = nn.BCEWithLogitsLoss(reduction='none')
         self.iou_loss = IOUloss(reduction='none')
@@ -173,8 +174,13 @@ class YOLOXHead(nn.Module):
             G = max(int(nlabel.max()), 1)
         gt_valid = torch.arange(G, device=labels.device)[None] < nlabel[:, None]
         gt_cls, gt_boxes = labels[:, :G, 0], labels[:, :G, 1:5]
-        fg, matched, matched_iou = self._assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds.detach(),
-                                                obj_preds.detach(), cls_preds.detach())
+        if self.fused_assign and ops.simota_supported(gt_valid, bbox_preds):
+            # one HIP launch over the valid label rows instead of ~100 tensor ops over all G padded rows
+            fg, matched, matched_iou = ops.simota_assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds.detach(),
+                                                         obj_preds.detach(), cls_preds.detach())
+        else:
+            fg, matched, matched_iou = self._assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds.detach(),
+                                                    obj_preds.detach(), cls_preds.detach())
         num_fg = fg.sum().to(outputs.dtype).clamp(min=1)
         num_gts = nlabel.sum().to(outputs.dtype).clamp(min=1)
         fgf = fg.to(outputs.dtype)

@@ -1070,6 +1070,30 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
     return [out[i, :n] if n else None for i, n in enumerate(counts)]
 
 
+def simota_supported(gt_valid, bbox_preds):
+    return bbox_preds.is_cuda and bbox_preds.dtype == torch.float32 and gt_valid.shape[1] <= 255 and bbox_preds.shape[1] <= 4096
+
+
+@torch.no_grad()
+def simota_assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds, obj_preds, cls_preds):
+    """SimOTA assignment for the whole batch in one launch (eas_simota_assign): (fg bool [B,A], matched int64 [B,A],
+    matched_iou float [B,A]) -- the outputs of YOLOXHead._assign."""
+    _dev(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds, obj_preds, cls_preds)
+    B, A = bbox_preds.shape[:2]
+    G, nc = gt_valid.shape[1], cls_preds.shape[-1]
+    gr = _f32c(grids.reshape(-1, 2)[:A].float())
+    st = _f32c(strides.reshape(-1)[:A].float())
+    gb, gc = _f32c(gt_boxes.float()), _f32c(gt_cls.float())
+    gv = gt_valid.to(torch.uint8).contiguous()
+    bx, ob, cl = _f32c(bbox_preds.float()), _f32c(obj_preds.float().reshape(B, A)), _f32c(cls_preds.float())
+    fg = torch.empty((B, A), dtype=torch.uint8, device=bx.device)
+    matched = torch.empty((B, A), dtype=torch.int64, device=bx.device)
+    miou = torch.empty((B, A), dtype=torch.float32, device=bx.device)
+    check(_lib.lib().eas_simota_assign(ptr(gr), ptr(st), ptr(gb), ptr(gc), ptr(gv), ptr(bx), ptr(ob), ptr(cl), B, G, A, nc, ptr(fg),
+                                       ptr(matched), ptr(miou), stream()), 'eas_simota_assign')
+    return fg.bool(), matched, miou
+
+
 # ------------------------------------------------------------------------------------------------ BN step counters
 _DEFERRED = None
 

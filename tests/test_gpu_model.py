@@ -231,6 +231,49 @@ def test_energy_estimation_matches_reference_restatement(dev):
         stats.energy_estimation(hip, [batches[0][:2].to(dev)], T=3)
 
 
+@pytest.mark.parametrize('B,G,nc,hw,seed', [(4, 50, 2, (64, 96), 1), (3, 12, 100, (64, 64), 2), (2, 50, 3, (256, 320), 3)])
+def test_fused_simota_assignment_equals_tensor_form(dev, B, G, nc, hw, seed):
+    """eas_simota_assign (one launch over the valid label rows) against YOLOXHead._assign (the batch-wide tensor formulation
+    that the golden train-loss fixtures pin): foreground mask, matched rows and matched IoUs.  Inputs: random decoded
+    predictions around a few ground-truth boxes, images with 0, 1 and many labels, clustered so that anchors are claimed by
+    several boxes (the least-cost rule) and dynamic k varies."""
+    from eas_snn_amd import ops
+    from yolox.models.yolo_head import YOLOXHead
+    g = torch.Generator().manual_seed(seed)
+    H, W = hw
+    head = YOLOXHead(nc, width=0.5)
+    grids, strides = [], []
+    for s_ in (8, 16, 32):
+        hs, ws = H // s_, W // s_
+        yv, xv = torch.meshgrid(torch.arange(hs), torch.arange(ws), indexing='ij')
+        grids.append(torch.stack((xv, yv), 2).view(1, -1, 2).float())
+        strides.append(torch.full((1, hs * ws), float(s_)))
+    grids, strides = torch.cat(grids, 1), torch.cat(strides, 1)
+    A = grids.shape[1]
+    n_valid = torch.randint(0, min(G, 9), (B,), generator=g)
+    n_valid[0] = 0
+    if B > 1:
+        n_valid[1] = min(G, 8)
+    gt_valid = torch.arange(G)[None] < n_valid[:, None]
+    centres = torch.rand(B, G, 2, generator=g) * torch.tensor([W * 0.6, H * 0.6]) + torch.tensor([W * 0.2, H * 0.2])
+    centres[:, 1::2] = centres[:, 0::2][:, :centres[:, 1::2].shape[1]] + 6.0          # overlapping pairs -> anchors with several claimants
+    gt_boxes = torch.cat([centres, torch.rand(B, G, 2, generator=g) * 60 + 12], -1)
+    gt_cls = torch.randint(0, nc, (B, G), generator=g).float()
+    ctr = (grids[0] + 0.5) * strides[0][:, None]
+    bbox = torch.cat([ctr[None].expand(B, -1, -1) + torch.randn(B, A, 2, generator=g) * 4, torch.rand(B, A, 2, generator=g) * 70 + 8], -1)
+    obj, cls = torch.randn(B, A, 1, generator=g) * 2, torch.randn(B, A, nc, generator=g) * 2
+    args = [t.to(dev) for t in (grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls)]
+    fg_r, m_r, iou_r = head._assign(*args)
+    fg_h, m_h, iou_h = ops.simota_assign(*args)
+    assert fg_h.dtype == torch.bool and m_h.dtype == torch.int64
+    agree = (fg_r == fg_h).float().mean().item()
+    assert agree == 1.0, f'foreground masks differ on {(1 - agree) * B * A:.0f} anchors'
+    assert torch.equal(m_r[fg_r], m_h[fg_h]) and int(fg_r.sum()) > 0 and int(fg_r[0].sum()) == 0
+    torch.testing.assert_close(iou_h, iou_r, rtol=1e-6, atol=1e-7)
+    multi = int((fg_r & (iou_r > 0)).sum())
+    assert multi > 0
+
+
 def test_state_dict_roundtrip_and_writeback_switch(dev):
     from eas_snn_amd import ops
     from spikingjelly.activation_based import functional
