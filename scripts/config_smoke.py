@@ -38,6 +38,9 @@ def main():
         torch.manual_seed(80)
         model = exp.get_model().to(dev)
         model.head.use_l1 = True
+        model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'
+        if os.environ.get('EAS_SMOKE_ONLY') and os.environ['EAS_SMOKE_ONLY'] not in name:
+            continue
         opt = exp.get_optimizer(batch)
         g = torch.Generator().manual_seed(1)
         frames = torch.poisson(torch.full((batch, 1, Tm, 2) + canvas, 0.3), generator=g).to(dev)
