@@ -169,6 +169,7 @@ def main():
     model = exp.get_model().to(dev)
     model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
     model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'    # development switch: 0 = tensor-op SimOTA
+    model.head.fused_loss = os.environ.get('EAS_FUSED_LOSS', '1') == '1'        # development switch: 0 = tensor-op loss terms
     opt = exp.get_optimizer(args.batch * world)
     net = model
     flat_sync = None

@@ -54,6 +54,7 @@ class YOLOXHead(nn.Module):
             self.obj_preds.append(nn.Conv2d(hid, 1, 1, 1, 0))
         self.use_l1 = False
         self.fused_assign = True       # SimOTA assignment in one HIP launch (ops.simota_assign); False = the tensor-op form (_assign)
+        self.fused_loss = True         # decode + assignment + loss terms + gradient on the HIP kernels (ops.det_loss)
         self.l1_loss = nn.L1Loss(reduction='none')
         self.bcewithlog_loss = nn.BCEWithLogitsLoss(reduction='none')
         self.iou_loss = IOUloss(reduction='none')
@@ -83,8 +84,16 @@ class YOLOXHead(nn.Module):
 
     def forward(self, xin, labels=None, imgs=None):
         outputs, origin_preds, grids, strides = [], [], [], []
+        if self.training and self.fused_loss and self.fused_assign:
+            raws = [self._level(k, self._prepare(x)) for k, x in enumerate(xin)]
+            regs, objs, clss = [r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws]
+            if ops.det_loss_supported(regs, labels, self.iou_loss.loss_type):
+                # decode + assignment + loss terms + their gradient in five launches (ops.det_loss)
+                return ops.det_loss(regs, objs, clss, labels, self.strides, self.num_classes, self.use_l1)
+        else:
+            raws = None
         for k, (stride, x) in enumerate(zip(self.strides, xin)):
-            reg_out, obj_out, cls_out = self._level(k, self._prepare(x))
+            reg_out, obj_out, cls_out = raws[k] if raws is not None else self._level(k, self._prepare(x))
             if self.training:
                 out = torch.cat([reg_out, obj_out, cls_out], 1)
                 B, Cn, H, W = out.shape

@@ -16,7 +16,7 @@ namespace {
 constexpr int SB = 256;
 constexpr int NWV = SB / EAS_WAVE;
 
-struct SimGeom { int B, G, A, nc, kk; };
+struct SimGeom { int B, G, A, nc, kk; int sb, so, sc; };   // sb / so / sc: floats per anchor in the bbox / obj / cls arrays
 
 __device__ __forceinline__ unsigned ord_bits(float f) {
     const unsigned u = __float_as_uint(f);
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ gr
     const float* GB = gt_boxes + (size_t)b * g.G * 4;
     const float* GC = gt_cls + (size_t)b * g.G;
     const unsigned char* GV = gt_valid + (size_t)b * g.G;
-    const float* BX = bbox + (size_t)b * g.A * 4;
-    const float* OB = obj + (size_t)b * g.A;
-    const float* CL = cls + (size_t)b * g.A * g.nc;
+    const float* BX = bbox + (size_t)b * g.A * g.sb;
+    const float* OB = obj + (size_t)b * g.A * g.so;
+    const float* CL = cls + (size_t)b * g.A * g.sc;
 
     for (int a = tid; a < g.A; a += SB) {
         const float s = strides[a];
@@ -106,16 +106,17 @@ __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ gr
             const bool inc = fminf(fminf(d0, d1), fminf(d2, d3)) > 0.0f;
             float io = 0.0f, co = 1e12f;
             if (cand[a]) {
-                const float px = BX[4 * a], py = BX[4 * a + 1], pw = BX[4 * a + 2], ph = BX[4 * a + 3];
+                const float* bp = BX + (size_t)a * g.sb;
+                const float px = bp[0], py = bp[1], pw = bp[2], ph = bp[3];
                 const float tlx = fmaxf(gx - gw / 2, px - pw / 2), tly = fmaxf(gy - gh / 2, py - ph / 2);
                 const float brx = fminf(gx + gw / 2, px + pw / 2), bry = fminf(gy + gh / 2, py + ph / 2);
                 const float en = ((tlx < brx) ? 1.0f : 0.0f) * ((tly < bry) ? 1.0f : 0.0f);
                 const float area_i = ((brx - tlx) * (bry - tly)) * en;
                 io = area_i / (gw * gh + pw * ph - area_i);
                 const float iou_cost = -logf(io + 1e-8f);
-                const float so = sigm(OB[a]);
+                const float so = sigm(OB[(size_t)a * g.so]);
                 float cc = 0.0f;
-                for (int c = 0; c < g.nc; ++c) cc += bce01(sqrtf(sigm(CL[(size_t)a * g.nc + c]) * so), c == tc);
+                for (int c = 0; c < g.nc; ++c) cc += bce01(sqrtf(sigm(CL[(size_t)a * g.sc + c]) * so), c == tc);
                 co = cc + 3.0f * iou_cost + 1e6f * (inc ? 0.0f : 1.0f);
             }
             iou[a] = io;
@@ -184,14 +185,14 @@ extern "C" {
 // grids [A][2], strides [A], gt_boxes [B][G][4] (cx, cy, w, h), gt_cls [B][G] (float class ids), gt_valid [B][G] (0/1),
 // bbox [B][A][4] decoded (cx, cy, w, h), obj [B][A], cls [B][A][nc] raw logits.
 // Out: fg [B][A] (0/1), matched [B][A] int64 (gt row, 0 where none), matched_iou [B][A].  G <= 255, A <= 4096.
-int eas_simota_assign(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls,
-                      const unsigned char* gt_valid, const float* bbox, const float* obj, const float* cls, int B, int G, int A,
-                      int nc, unsigned char* fg, long long* matched, float* matched_iou, eas_stream_t stream) {
+static int simota_launch(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls, const unsigned char* gt_valid,
+                         const float* bbox, const float* obj, const float* cls, int sb, int so, int sc, int B, int G, int A, int nc,
+                         unsigned char* fg, long long* matched, float* matched_iou, eas_stream_t stream) {
     if (!grids || !strides || !gt_boxes || !gt_cls || !gt_valid || !bbox || !obj || !cls || !fg || !matched || !matched_iou) return EAS_ERR_INVALID_ARG;
     if (B < 1 || G < 1 || A < 1 || nc < 1) return EAS_ERR_INVALID_ARG;
     if (G > 255 || A > 4096) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
-    SimGeom g{B, G, A, nc, A < 10 ? A : 10};
+    SimGeom g{B, G, A, nc, A < 10 ? A : 10, sb, so, sc};
     const size_t lds = (size_t)A * (5 * 4 + 5);
     static bool attr_set = false;
     if (!attr_set) {
@@ -202,6 +203,22 @@ int eas_simota_assign(const float* grids, const float* strides, const float* gt_
                        matched, matched_iou, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
+}
+
+int eas_simota_assign(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls,
+                      const unsigned char* gt_valid, const float* bbox, const float* obj, const float* cls, int B, int G, int A,
+                      int nc, unsigned char* fg, long long* matched, float* matched_iou, eas_stream_t stream) {
+    return simota_launch(grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls, 4, 1, nc, B, G, A, nc, fg, matched, matched_iou, stream);
+}
+
+// the same on decoded rows [B][A][5+nc] (cx, cy, w, h, obj logit, class logits) as eas_det_decode writes them
+int eas_simota_assign_rows(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls,
+                           const unsigned char* gt_valid, const float* dec, int B, int G, int A, int nc, unsigned char* fg,
+                           long long* matched, float* matched_iou, eas_stream_t stream) {
+    if (!dec) return EAS_ERR_INVALID_ARG;
+    const int row = 5 + nc;
+    return simota_launch(grids, strides, gt_boxes, gt_cls, gt_valid, dec, dec + 4, dec + 5, row, row, row, B, G, A, nc, fg, matched, matched_iou,
+                         stream);
 }
 
 }  // extern "C"

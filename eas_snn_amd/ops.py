@@ -1094,6 +1094,89 @@ def simota_assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds, obj_pr
     return fg.bool(), matched, miou
 
 
+_ANCHOR_CACHE = {}
+
+
+def _anchor_tables(hws, strides, device):
+    """grids [A,2] and strides [A] of the head levels (cached per geometry and device)"""
+    key = (tuple(hws), tuple(float(s_) for s_ in strides), str(device))
+    t = _ANCHOR_CACHE.get(key)
+    if t is None:
+        gs, ss = [], []
+        for (h, w), s_ in zip(hws, strides):
+            yv, xv = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+            gs.append(torch.stack((xv, yv), 2).reshape(-1, 2).float())
+            ss.append(torch.full((h * w,), float(s_)))
+        t = _ANCHOR_CACHE[key] = (torch.cat(gs).to(device), torch.cat(ss).to(device))
+    return t
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _DetLossFn(torch.autograd.Function):
+    """Decode + SimOTA assignment + loss terms + their gradient for the raw head maps of all levels: five launches forward
+    (eas_det_decode, eas_simota_assign_rows, eas_det_loss x2) plus a few tiny label ops, one multiply backward."""
+
+    @staticmethod
+    def forward(ctx, labels, strides, nc, use_l1, *raw):
+        L = len(raw) // 3
+        regs, objs, clss = [_f32c(t) for t in raw[0::3]], [_f32c(t) for t in raw[1::3]], [_f32c(t) for t in raw[2::3]]
+        _dev(labels, *regs)
+        lib = _lib.lib()
+        dev = regs[0].device
+        B = regs[0].shape[0]
+        hws = [tuple(r.shape[-2:]) for r in regs]
+        A = sum(h * w for h, w in hws)
+        hw_arr = (C.c_int * (2 * L))(*[v for hw in hws for v in hw])
+        st_arr = (C.c_float * L)(*[float(s_) for s_ in strides])
+        dec = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=dev)
+        check(lib.eas_det_decode(L, _ptr_array(regs), _ptr_array(objs), _ptr_array(clss), hw_arr, st_arr, B, nc, ptr(dec), stream()),
+              'eas_det_decode')
+        labels = labels.float()
+        G = labels.shape[1]
+        nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
+        gt_valid = (torch.arange(G, device=dev)[None] < nlabel[:, None]).to(torch.uint8)
+        gt_cls, gt_boxes = labels[:, :, 0].contiguous(), labels[:, :, 1:5].contiguous()
+        num_gts = nlabel.sum().float()
+        grids, svec = _anchor_tables(hws, strides, dev)
+        fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+        matched = torch.empty((B, A), dtype=torch.int64, device=dev)
+        miou = torch.empty((B, A), dtype=torch.float32, device=dev)
+        check(lib.eas_simota_assign_rows(ptr(grids), ptr(svec), ptr(gt_boxes), ptr(gt_cls), ptr(gt_valid), ptr(dec), B, G, A, nc, ptr(fg),
+                                         ptr(matched), ptr(miou), stream()), 'eas_simota_assign_rows')
+        g_regs, g_objs, g_clss = [torch.empty_like(t) for t in regs], [torch.empty_like(t) for t in objs], [torch.empty_like(t) for t in clss]
+        out = torch.empty(7, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.eas_det_loss_workspace_doubles(), dtype=torch.float64, device=dev)
+        check(lib.eas_det_loss(L, _ptr_array(regs), _ptr_array(objs), _ptr_array(clss), _ptr_array(g_regs), _ptr_array(g_objs),
+                               _ptr_array(g_clss), hw_arr, st_arr, B, nc, ptr(dec), ptr(gt_boxes), ptr(gt_cls), G, ptr(fg), ptr(matched),
+                               ptr(miou), ptr(num_gts), int(bool(use_l1)), ptr(out), ptr(ws), stream()), 'eas_det_loss')
+        ctx.grads = [g for trip in zip(g_regs, g_objs, g_clss) for g in trip]
+        ctx.scale = out[6]
+        outs = tuple(out[i] for i in range(6))
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        grads = ctx.grads
+        torch._foreach_mul_(grads, g_total * ctx.scale)
+        return (None, None, None, None) + tuple(grads)
+
+
+def det_loss_supported(raw_regs, labels, loss_type):
+    A = sum(r.shape[-1] * r.shape[-2] for r in raw_regs)
+    return (raw_regs[0].is_cuda and raw_regs[0].dtype == torch.float32 and len(raw_regs) <= 4 and A <= 4096 and labels.shape[1] <= 255
+            and loss_type == 'iou' and all(r.dim() == 4 for r in raw_regs))
+
+
+def det_loss(regs, objs, clss, labels, strides, num_classes, use_l1):
+    """(total, 5*iou, obj, cls, l1, num_fg/num_gts) of YOLOXHead.get_losses from the raw head maps of every level."""
+    raw = [t for trip in zip(regs, objs, clss) for t in trip]
+    return _DetLossFn.apply(labels, tuple(float(s_) for s_ in strides), int(num_classes), bool(use_l1), *raw)
+
+
 # ------------------------------------------------------------------------------------------------ BN step counters
 _DEFERRED = None
 

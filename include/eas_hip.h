@@ -342,6 +342,29 @@ int eas_simota_assign(const float* grids, const float* strides, const float* gt_
                       const unsigned char* gt_valid, const float* bbox, const float* obj, const float* cls, int B, int G, int A,
                       int nc, unsigned char* fg, long long* matched, float* matched_iou, eas_stream_t stream);
 
+/* eas_simota_assign on decoded rows [B][A][5+nc] (cx, cy, w, h, obj logit, class logits) as eas_det_decode writes them. */
+int eas_simota_assign_rows(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls,
+                           const unsigned char* gt_valid, const float* dec, int B, int G, int A, int nc, unsigned char* fg,
+                           long long* matched, float* matched_iou, eas_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Detection loss after the assignment, forward and gradient in one pass: the loss terms of YOLOXHead.get_losses
+ * (yolox/models/yolo_head.py:296-420 as inherited by spiking_yolo_head.py; IOUloss yolox/models/losses.py:10-53 with
+ * loss_type 'iou').  reg / obj / cls: HOST arrays of L <= 4 device pointers to the raw head maps [B][4|1|nc][H_l][W_l];
+ * hw: host array [L][2]; strides: host array [L].
+ * eas_det_decode: decoded rows dec [B][A][5+nc], A = sum H_l*W_l (the cat / permute / (o+grid)*stride / exp(o)*stride chain).
+ * eas_det_loss: out[0..5] = total, 5*iou, obj, cls, l1, num_fg/num_gts and out[6] = 1/num_fg; g_reg / g_obj / g_cls (host
+ *   arrays of device pointers, shapes of the raw maps, every element written) receive d(total * num_fg)/d(raw map): the caller
+ *   multiplies them by grad_total * out[6].  num_gts: device float scalar.  workspace: eas_det_loss_workspace_doubles(). */
+int eas_det_decode(int L, const float* const* reg, const float* const* obj, const float* const* cls, const int* hw,
+                   const float* strides, int B, int nc, float* dec, eas_stream_t stream);
+int64_t eas_det_loss_workspace_doubles(void);
+int eas_det_loss(int L, const float* const* reg, const float* const* obj, const float* const* cls, float* const* g_reg,
+                 float* const* g_obj, float* const* g_cls, const int* hw, const float* strides, int B, int nc, const float* dec,
+                 const float* gt_boxes, const float* gt_cls, int G, const unsigned char* fg, const long long* matched,
+                 const float* matched_iou, const float* num_gts, int use_l1, float* out, double* workspace,
+                 eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,6 +274,42 @@ def test_fused_simota_assignment_equals_tensor_form(dev, B, G, nc, hw, seed):
     assert multi > 0
 
 
+@pytest.mark.parametrize('nc,use_l1,hw,seed', [(2, True, (64, 96), 1), (2, False, (64, 96), 2), (100, True, (64, 64), 3), (3, True, (256, 320), 4)])
+def test_fused_detection_loss_equals_tensor_form(dev, nc, use_l1, hw, seed):
+    """ops.det_loss (eas_det_decode + eas_simota_assign_rows + eas_det_loss: decode, assignment, loss terms and their
+    gradient in five launches) against the tensor-op get_losses of the same head on the same features and labels: the six
+    returned numbers and the gradient of the total loss w.r.t. every head parameter and the input features."""
+    import copy
+    from yolox.models.yolo_head import YOLOXHead
+    torch.manual_seed(seed)
+    H, W = hw
+    head = YOLOXHead(nc, width=0.25).to(dev).train()
+    head.use_l1 = use_l1
+    B = 4
+    feats = [torch.randn(B, c, H // s_, W // s_, device=dev) * 0.5 for c, s_ in zip((64, 128, 256), (8, 16, 32))]
+    labels = torch.zeros(B, 50, 5, device=dev)
+    g = torch.Generator().manual_seed(seed)
+    for b in range(1, B):                                   # image 0 has no label
+        n = int(torch.randint(1, 7, (1,), generator=g))
+        cxy = torch.rand(n, 2, generator=g) * torch.tensor([W * 0.6, H * 0.6]) + torch.tensor([W * 0.2, H * 0.2])
+        labels[b, :n] = torch.cat([torch.randint(0, nc, (n, 1), generator=g).float(), cxy, torch.rand(n, 2, generator=g) * 40 + 10], 1).to(dev)
+    res = []
+    for fused in (False, True):
+        h = copy.deepcopy(head)
+        h.fused_loss = h.fused_assign = fused
+        xs = [f.clone().requires_grad_(True) for f in feats]
+        out = h(xs, labels)
+        out[0].backward()
+        res.append(([float(v) for v in out], [x.grad.clone() for x in xs], {n_: p.grad.clone() for n_, p in h.named_parameters() if p.grad is not None}))
+    (v0, gx0, gp0), (v1, gx1, gp1) = res
+    np.testing.assert_allclose(v1, v0, rtol=2e-5, atol=1e-6)
+    assert v0[5] > 0 and set(gp0) == set(gp1)
+    for a, b_ in zip(gx0, gx1):
+        torch.testing.assert_close(b_, a, rtol=1e-4, atol=1e-6 * float(a.abs().max()) + 1e-9)
+    for k in gp0:
+        torch.testing.assert_close(gp1[k], gp0[k], rtol=1e-4, atol=2e-6 * float(gp0[k].abs().max()) + 1e-9, msg=k)
+
+
 def test_state_dict_roundtrip_and_writeback_switch(dev):
     from eas_snn_amd import ops
     from spikingjelly.activation_based import functional
