@@ -8,6 +8,13 @@ from .darknet import CSPDarknet
 from .network_blocks import BaseConv, CSPLayer, DWConv
 
 
+def _cat2(a, b):
+    """torch.cat([a, b], channel axis) with a one-kernel backward (two contiguous gradients instead of two slice copies)"""
+    if ops.upcat_supported(a, b, 1):
+        return ops.upsample_cat(a, b, 1)
+    return torch.cat([a, b], -3)
+
+
 class YOLOPAFPN(nn.Module):
     def __init__(self, depth=1.0, width=1.0, in_features=('dark3', 'dark4', 'dark5'), in_channels=[256, 512, 1024],
                  depthwise=False, in_dim=3, act='silu'):
@@ -35,12 +42,20 @@ class YOLOPAFPN(nn.Module):
         feats = self.backbone(x)
         return [feats[f] for f in self.in_features]
 
+    def _up_cat(self, low, skip):
+        """torch.cat([self.upsample(low), skip], channel axis): one kernel (and one for its backward) for a plain nearest x2"""
+        up = self.upsample[0] if isinstance(self.upsample, nn.Sequential) and len(self.upsample) == 1 else self.upsample
+        if (type(up) is nn.Upsample and up.mode == 'nearest' and up.scale_factor in (2, 2.0, (2, 2), (2.0, 2.0)) and up.size is None
+                and ops.upcat_supported(low, skip, 2)):
+            return ops.upsample_cat(low, skip, 2)
+        return torch.cat([self.upsample(low), skip], -3)
+
     def forward(self, x):
         x2, x1, x0 = self._features(x)
         fpn_out0 = self.lateral_conv0(x0)
-        f_out0 = self.C3_p4(torch.cat([self.upsample(fpn_out0), x1], -3))
+        f_out0 = self.C3_p4(self._up_cat(fpn_out0, x1))
         fpn_out1 = self.reduce_conv1(f_out0)
-        pan_out2 = self.C3_p3(torch.cat([self.upsample(fpn_out1), x2], -3))
-        pan_out1 = self.C3_n3(torch.cat([self.bu_conv2(pan_out2), fpn_out1], -3))
-        pan_out0 = self.C3_n4(torch.cat([self.bu_conv1(pan_out1), fpn_out0], -3))
+        pan_out2 = self.C3_p3(self._up_cat(fpn_out1, x2))
+        pan_out1 = self.C3_n3(_cat2(self.bu_conv2(pan_out2), fpn_out1))
+        pan_out0 = self.C3_n4(_cat2(self.bu_conv1(pan_out1), fpn_out0))
         return pan_out2, pan_out1, pan_out0

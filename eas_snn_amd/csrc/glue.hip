@@ -1,0 +1,109 @@
+// Layout glue of the PAFPN neck: out = cat[upsample_nearest(a, x up), b] along channels in one kernel, and its backward
+// (grad_a = sum over each up x up cell, grad_b = contiguous copy) in one kernel.  Replaces nn.Upsample + torch.cat
+// (yolox/models/yolo_pafpn.py:101-113: `torch.cat([self.upsample(fpn_out0), x1], 1)`) and, with up = 1, the plain
+// two-tensor concatenations of the bottom-up path (:115-121); backward replaces upsample_nearest2d_backward + two
+// slice copies.  HBM-bound: every element read / written once, 16-byte accesses along W.
+#include "eas_common.h"
+
+namespace {
+
+struct UpcatGeom { long long M; int Ca, Cb, H, W, up; };   // a [M][Ca][H][W]; b [M][Cb][H*up][W*up]; out [M][Ca+Cb][H*up][W*up]
+
+__global__ __launch_bounds__(EAS_BLOCK) void upcat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                              UpcatGeom g) {
+    const int Ho = g.H * g.up, Wo = g.W * g.up, C = g.Ca + g.Cb, w4 = Wo / 4;
+    const long long total = g.M * C * Ho * w4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % w4);
+        long long r = i / w4;
+        const int y = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C);
+        const long long m = r / C;
+        float4 v;
+        if (c < g.Ca) {
+            const float* src = a + ((m * g.Ca + c) * g.H + y / g.up) * (long long)g.W;
+            if (g.up == 2) {
+                const float2 s = *reinterpret_cast<const float2*>(src + 2 * x4);
+                v = make_float4(s.x, s.x, s.y, s.y);
+            } else {
+                v = *reinterpret_cast<const float4*>(src + 4 * x4);
+            }
+        } else {
+            v = *reinterpret_cast<const float4*>(b + ((m * g.Cb + (c - g.Ca)) * Ho + y) * (long long)Wo + 4 * x4);
+        }
+        *reinterpret_cast<float4*>(out + ((m * C + c) * Ho + y) * (long long)Wo + 4 * x4) = v;
+    }
+}
+
+__global__ __launch_bounds__(EAS_BLOCK) void upcat_bwd_kernel(const float* __restrict__ go, float* __restrict__ ga, float* __restrict__ gb,
+                                                              UpcatGeom g) {
+    const int Ho = g.H * g.up, Wo = g.W * g.up, C = g.Ca + g.Cb;
+    const int wa2 = g.W / 2, wb4 = Wo / 4;
+    const long long na = g.M * g.Ca * g.H * wa2, nb = g.M * g.Cb * Ho * wb4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (long long)gridDim.x * blockDim.x) {
+        if (i < na) {                                   // two grad_a elements: a 2 x 4 (up = 2) or 1 x 2 (up = 1) patch of grad_out
+            const int x2 = (int)(i % wa2);
+            long long r = i / wa2;
+            const int h = (int)(r % g.H);
+            r /= g.H;
+            const int c = (int)(r % g.Ca);
+            const long long m = r / g.Ca;
+            const float* src = go + ((m * C + c) * Ho + h * g.up) * (long long)Wo;
+            float2 o;
+            if (g.up == 2) {
+                const float4 t = *reinterpret_cast<const float4*>(src + 4 * x2), u = *reinterpret_cast<const float4*>(src + Wo + 4 * x2);
+                o.x = ((t.x + t.y) + u.x) + u.y;        // row-major accumulation like upsample_nearest2d_backward
+                o.y = ((t.z + t.w) + u.z) + u.w;
+            } else {
+                o = *reinterpret_cast<const float2*>(src + 2 * x2);
+            }
+            *reinterpret_cast<float2*>(ga + ((m * g.Ca + c) * g.H + h) * (long long)g.W + 2 * x2) = o;
+        } else {
+            const long long k = i - na;
+            const int x4 = (int)(k % wb4);
+            long long r = k / wb4;
+            const int y = (int)(r % Ho);
+            r /= Ho;
+            const int c = (int)(r % g.Cb);
+            const long long m = r / g.Cb;
+            *reinterpret_cast<float4*>(gb + ((m * g.Cb + c) * Ho + y) * (long long)Wo + 4 * x4) =
+                *reinterpret_cast<const float4*>(go + ((m * C + g.Ca + c) * Ho + y) * (long long)Wo + 4 * x4);
+        }
+    }
+}
+
+int check_geom(const UpcatGeom& g) {
+    if (g.M < 1 || g.Ca < 1 || g.Cb < 1 || g.H < 1 || g.W < 1) return EAS_ERR_INVALID_ARG;
+    if ((g.up != 1 && g.up != 2) || (g.W * g.up) % 4 != 0 || g.W % 2 != 0) return EAS_ERR_UNSUPPORTED;
+    return EAS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eas_upcat_fwd(const float* a, const float* b, float* out, int64_t M, int Ca, int Cb, int H, int W, int up, eas_stream_t stream) {
+    if (!a || !b || !out) return EAS_ERR_INVALID_ARG;
+    const UpcatGeom g{M, Ca, Cb, H, W, up};
+    if (int rc = check_geom(g)) return rc;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(eas_grid_1d(M * (Ca + Cb) * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), a, b, out, g);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_upcat_bwd(const float* grad_out, float* grad_a, float* grad_b, int64_t M, int Ca, int Cb, int H, int W, int up, eas_stream_t stream) {
+    if (!grad_out || !grad_a || !grad_b) return EAS_ERR_INVALID_ARG;
+    const UpcatGeom g{M, Ca, Cb, H, W, up};
+    if (int rc = check_geom(g)) return rc;
+    if (((uintptr_t)grad_out | (uintptr_t)grad_a | (uintptr_t)grad_b) & 15) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(upcat_bwd_kernel, dim3(eas_grid_1d(M * Ca * H * (W / 2) + M * Cb * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0,
+                       eas_s(stream), grad_out, grad_a, grad_b, g);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+}  // extern "C"

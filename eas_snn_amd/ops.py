@@ -1177,6 +1177,44 @@ def det_loss(regs, objs, clss, labels, strides, num_classes, use_l1):
     return _DetLossFn.apply(labels, tuple(float(s_) for s_ in strides), int(num_classes), bool(use_l1), *raw)
 
 
+# ------------------------------------------------------------------------------------------------ neck glue
+class _UpcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, up):
+        _dev(a, b)
+        a, b = _f32c(a), _f32c(b)
+        lead, (Ca, H, W) = a.shape[:-3], a.shape[-3:]
+        Cb = b.shape[-3]
+        M = a.numel() // (Ca * H * W)
+        out = torch.empty(lead + (Ca + Cb, H * up, W * up), dtype=torch.float32, device=a.device)
+        check(_lib.lib().eas_upcat_fwd(ptr(a), ptr(b), ptr(out), M, Ca, Cb, H, W, up, stream()), 'eas_upcat_fwd')
+        ctx.cfg = (a.shape, b.shape, M, Ca, Cb, H, W, up)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ashape, bshape, M, Ca, Cb, H, W, up = ctx.cfg
+        g = _f32c(g)
+        ga = torch.empty(ashape, dtype=torch.float32, device=g.device)
+        gb = torch.empty(bshape, dtype=torch.float32, device=g.device)
+        check(_lib.lib().eas_upcat_bwd(ptr(g), ptr(ga), ptr(gb), M, Ca, Cb, H, W, up, stream()), 'eas_upcat_bwd')
+        return ga, gb, None
+
+
+def upcat_supported(a, b, up):
+    return (a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.dim() == b.dim() and a.dim() >= 4
+            and a.shape[:-3] == b.shape[:-3] and b.shape[-2] == a.shape[-2] * up and b.shape[-1] == a.shape[-1] * up
+            and (a.shape[-1] * up) % 4 == 0 and a.shape[-1] % 2 == 0)
+
+
+def upsample_cat(a, b, up=2):
+    """cat[nearest-upsample(a, x up), b] along channels in one kernel (one more for the backward); up = 1: plain concatenation"""
+    out = _UpcatFn.apply(a, b, int(up))
+    if up == 1 and is_small_int(a) and is_small_int(b):
+        mark_small_int(out)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ BN step counters
 _DEFERRED = None
 

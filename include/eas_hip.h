@@ -365,6 +365,15 @@ int eas_det_loss(int L, const float* const* reg, const float* const* obj, const 
                  const float* matched_iou, const float* num_gts, int use_l1, float* out, double* workspace,
                  eas_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Neck glue: out [M][Ca+Cb][H*up][W*up] = cat[upsample_nearest(a [M][Ca][H][W], x up), b [M][Cb][H*up][W*up]] along channels,
+ * up = 2 (nn.Upsample(scale_factor=2) + torch.cat, yolox/models/yolo_pafpn.py:101-113) or up = 1 (the plain two-tensor
+ * concatenations of the bottom-up path, :115-121).  Backward: grad_a = sum over each up x up cell (row-major order, as
+ * upsample_nearest2d_backward), grad_b = contiguous copy, one kernel.  (W * up) % 4 == 0, W % 2 == 0. */
+int eas_upcat_fwd(const float* a, const float* b, float* out, int64_t M, int Ca, int Cb, int H, int W, int up, eas_stream_t stream);
+int eas_upcat_bwd(const float* grad_out, float* grad_a, float* grad_b, int64_t M, int Ca, int Cb, int H, int W, int up,
+                  eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

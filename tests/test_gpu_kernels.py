@@ -344,6 +344,28 @@ def test_postprocess_matches_restated_reference(dev, B, A, ncls, conf, thr, agno
         assert max(int((p[:, 4] * p[:, 5:].max(1) >= conf).sum()) for p in pred) > 5000
 
 
+@pytest.mark.parametrize('lead,Ca,Cb,H,W,up', [((3,), 8, 5, 6, 10, 2), ((2, 2), 4, 4, 4, 6, 2), ((3,), 6, 3, 8, 12, 1), ((1,), 128, 256, 16, 20, 2)])
+def test_upsample_cat_matches_torch(dev, lead, Ca, Cb, H, W, up):
+    """eas_upcat_fwd / eas_upcat_bwd against nn.Upsample(nearest) + torch.cat and their autograd: bit-identical"""
+    import torch.nn.functional as F
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(Ca * 10 + up)
+    a = torch.randn(lead + (Ca, H, W), generator=g)
+    b = torch.randn(lead + (Cb, H * up, W * up), generator=g)
+    go = torch.randn(lead + (Ca + Cb, H * up, W * up), generator=g)
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    assert ops.upcat_supported(ad, bd, up)
+    out = ops.upsample_cat(ad, bd, up)
+    out.backward(go.to(dev))
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    au = F.interpolate(ar.flatten(0, -4), scale_factor=up, mode='nearest').view(lead + (Ca, H * up, W * up)) if up > 1 else ar
+    ref = torch.cat([au, br], -3)
+    ref.backward(go)
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert torch.equal(bd.grad.cpu(), br.grad)
+    torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-6, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def _oracle_node(kind, sg, alpha, v_reset, decay_input, detach):
     from oracle import sj_ref
