@@ -73,6 +73,39 @@ __global__ __launch_bounds__(EAS_BLOCK) void upcat_bwd_kernel(const float* __res
     }
 }
 
+// Focus (space to depth, yolox/models/network_blocks.py:198-213): out[m][k*C + c][h][w] = x[m][c][2h + dy_k][2w + dx_k] with
+// (dy, dx) = (0,0), (1,0), (0,1), (1,1) for k = 0..3 -- four strided slices + torch.cat in the reference; a permutation, so
+// the backward is the inverse permutation.  One thread handles a 2 x 4 input patch (two float4 loads, four float2 stores).
+__global__ __launch_bounds__(EAS_BLOCK) void focus_kernel(const float* __restrict__ src, float* __restrict__ dst, long long M, int C, int Ho,
+                                                          int Wo, int inverse) {
+    const int w2 = Wo / 2;
+    const long long total = M * C * Ho * w2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x2 = (int)(i % w2);
+        long long r = i / w2;
+        const int h = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C);
+        const long long m = r / C;
+        // full-resolution patch rows 2h, 2h+1, columns 4*x2 .. 4*x2+3 ; packed outputs (k, h, 2*x2 .. 2*x2+1)
+        const long long full = ((m * C + c) * (2LL * Ho) + 2 * h) * (2LL * Wo) + 4 * x2;
+        const long long packed = ((m * 4 * C + c) * Ho + h) * (long long)Wo + 2 * x2;
+        const long long kstride = (long long)C * Ho * Wo;
+        if (!inverse) {
+            const float4 t = *reinterpret_cast<const float4*>(src + full), u = *reinterpret_cast<const float4*>(src + full + 2 * Wo);
+            *reinterpret_cast<float2*>(dst + packed) = make_float2(t.x, t.z);                  // k = 0: (0, 0)
+            *reinterpret_cast<float2*>(dst + packed + kstride) = make_float2(u.x, u.z);        // k = 1: (1, 0)
+            *reinterpret_cast<float2*>(dst + packed + 2 * kstride) = make_float2(t.y, t.w);    // k = 2: (0, 1)
+            *reinterpret_cast<float2*>(dst + packed + 3 * kstride) = make_float2(u.y, u.w);    // k = 3: (1, 1)
+        } else {
+            const float2 k0 = *reinterpret_cast<const float2*>(src + packed), k1 = *reinterpret_cast<const float2*>(src + packed + kstride);
+            const float2 k2 = *reinterpret_cast<const float2*>(src + packed + 2 * kstride), k3 = *reinterpret_cast<const float2*>(src + packed + 3 * kstride);
+            *reinterpret_cast<float4*>(dst + full) = make_float4(k0.x, k2.x, k0.y, k2.y);
+            *reinterpret_cast<float4*>(dst + full + 2 * Wo) = make_float4(k1.x, k3.x, k1.y, k3.y);
+        }
+    }
+}
+
 int check_geom(const UpcatGeom& g) {
     if (g.M < 1 || g.Ca < 1 || g.Cb < 1 || g.H < 1 || g.W < 1) return EAS_ERR_INVALID_ARG;
     if ((g.up != 1 && g.up != 2) || (g.W * g.up) % 4 != 0 || g.W % 2 != 0) return EAS_ERR_UNSUPPORTED;
@@ -102,6 +135,18 @@ int eas_upcat_bwd(const float* grad_out, float* grad_a, float* grad_b, int64_t M
     EAS_CLEAR_ERR();
     hipLaunchKernelGGL(upcat_bwd_kernel, dim3(eas_grid_1d(M * Ca * H * (W / 2) + M * Cb * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0,
                        eas_s(stream), grad_out, grad_a, grad_b, g);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// x [M][C][2*Ho][2*Wo] -> out [M][4*C][Ho][Wo] (inverse = 0), or the inverse permutation (inverse = 1: the backward).  Wo % 2 == 0.
+int eas_focus(const float* src, float* dst, int64_t M, int C, int Ho, int Wo, int inverse, eas_stream_t stream) {
+    if (!src || !dst || M < 1 || C < 1 || Ho < 1 || Wo < 1) return EAS_ERR_INVALID_ARG;
+    if (Wo % 2 != 0) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(focus_kernel, dim3(eas_grid_1d(M * C * Ho * (Wo / 2))), dim3(EAS_BLOCK), 0, eas_s(stream), src, dst, (long long)M, C, Ho, Wo,
+                       inverse);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

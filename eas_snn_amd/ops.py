@@ -5,6 +5,7 @@ streams, autograd bookkeeping); all arithmetic of the hot path runs in the HIP k
 No CPU path: CPU tensors raise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -1202,6 +1203,8 @@ class _UpcatFn(torch.autograd.Function):
 
 
 def upcat_supported(a, b, up):
+    if os.environ.get('EAS_NO_UPCAT'):         # development switch
+        return False
     return (a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.dim() == b.dim() and a.dim() >= 4
             and a.shape[:-3] == b.shape[:-3] and b.shape[-2] == a.shape[-2] * up and b.shape[-1] == a.shape[-1] * up
             and (a.shape[-1] * up) % 4 == 0 and a.shape[-1] % 2 == 0)
@@ -1213,6 +1216,36 @@ def upsample_cat(a, b, up=2):
     if up == 1 and is_small_int(a) and is_small_int(b):
         mark_small_int(out)
     return out
+
+
+class _FocusFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = _f32c(x)
+        M, Cc, H, W = x.shape
+        out = torch.empty((M, 4 * Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(_lib.lib().eas_focus(ptr(x), ptr(out), M, Cc, H // 2, W // 2, 0, stream()), 'eas_focus')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        M, C4, Ho, Wo = g.shape
+        gx = torch.empty((M, C4 // 4, 2 * Ho, 2 * Wo), dtype=torch.float32, device=g.device)
+        check(_lib.lib().eas_focus(ptr(g), ptr(gx), M, C4 // 4, Ho, Wo, 1, stream()), 'eas_focus')
+        return gx
+
+
+def focus_supported(x):
+    if os.environ.get('EAS_NO_FOCUS'):         # development switch
+        return False
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-2] % 2 == 0 and x.shape[-1] % 4 == 0
+
+
+def focus(x):
+    """space to depth of Focus.forward: cat(x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]) in one kernel"""
+    return _FocusFn.apply(x)
 
 
 # ------------------------------------------------------------------------------------------------ BN step counters

@@ -374,6 +374,11 @@ int eas_upcat_fwd(const float* a, const float* b, float* out, int64_t M, int Ca,
 int eas_upcat_bwd(const float* grad_out, float* grad_a, float* grad_b, int64_t M, int Ca, int Cb, int H, int W, int up,
                   eas_stream_t stream);
 
+/* Focus, space to depth (yolox/models/network_blocks.py:198-213: four strided slices + torch.cat): x [M][C][2*Ho][2*Wo] ->
+ * out [M][4*C][Ho][Wo], out[m][k*C+c][h][w] = x[m][c][2h+dy_k][2w+dx_k], (dy,dx) = (0,0),(1,0),(0,1),(1,1); inverse = 1 is the
+ * inverse permutation (the backward).  Wo % 2 == 0. */
+int eas_focus(const float* src, float* dst, int64_t M, int C, int Ho, int Wo, int inverse, eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -366,6 +366,21 @@ def test_upsample_cat_matches_torch(dev, lead, Ca, Cb, H, W, up):
     torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('shape', [(3, 2, 8, 12), (2, 3, 16, 20), (1, 2, 256, 320)])
+def test_focus_matches_slices(dev, shape):
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(shape[-1])
+    x = torch.randn(shape, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    out = ops.focus(xd)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(dev))
+    xr = x.clone().requires_grad_(True)
+    ref = torch.cat((xr[..., ::2, ::2], xr[..., 1::2, ::2], xr[..., ::2, 1::2], xr[..., 1::2, 1::2]), dim=1)
+    ref.backward(go)
+    assert torch.equal(out.detach().cpu(), ref.detach()) and torch.equal(xd.grad.cpu(), xr.grad)
+
+
 # ------------------------------------------------------------------------------------------------ K2
 def _oracle_node(kind, sg, alpha, v_reset, decay_input, detach):
     from oracle import sj_ref
