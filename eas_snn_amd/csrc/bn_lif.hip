@@ -36,11 +36,23 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial(const float* __res
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)TN * hw4;
     double s = 0.0, ss = 0.0;
-    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
-        const int64_t n = gw.n;
-        const int q = gw.q;
-        const float4 v = reinterpret_cast<const float4*>(y + ((n * C + c) * (int64_t)HW))[q];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride, hw4);
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // two groups in flight per thread (both loads issued before the double-precision accumulation of either); the order in
+    // which a thread adds its groups is unchanged
+    for (; g + stride < groups; g += 2 * stride) {
+        const float4 v0 = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * C + c) * (int64_t)HW))[gw.q];
+        gw.next();
+        const float4 v1 = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * C + c) * (int64_t)HW))[gw.q];
+        gw.next();
+        s += (double)v0.x + (double)v0.y + (double)v0.z + (double)v0.w;
+        ss += (double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w;
+        s += (double)v1.x + (double)v1.y + (double)v1.z + (double)v1.w;
+        ss += (double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w;
+    }
+    if (g < groups) {
+        const float4 v = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * C + c) * (int64_t)HW))[gw.q];
         s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
         ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
