@@ -85,43 +85,41 @@ def letterbox_params(ih, iw, h, w, letterbox=True, center=False):
 
 
 def jitter_params(ih, iw, h, w, jitter=.3, rng=np.random):
-    """(nw, nh, dx, dy, flip) of the random branch (gen1.py:485-504), drawing from ``rng`` in the reference's order
-    (two draws for the aspect ratio, scale, dx, dy, flip)."""
-    def rand(a=0., b=1.):
-        return rng.rand() * (b - a) + a
-    new_ar = iw / ih * rand(1 - jitter, 1 + jitter) / rand(1 - jitter, 1 + jitter)
-    scale = rand(.4, 1)
-    if new_ar < 1:
-        nh = int(scale * h)
-        nw = int(nh * new_ar)
-    else:
+    """(nw, nh, dx, dy, flip) of the random branch of get_random_data (gen1.py:485-504).  Six uniform draws from ``rng`` in the
+    reference's order: two for the aspect-ratio distortion (numerator, denominator, each in [1-jitter, 1+jitter)), the scale in
+    [0.4, 1), the horizontal and vertical paste offsets, the flip coin."""
+    u = lambda lo, hi: lo + (hi - lo) * rng.rand()
+    aspect = (iw / ih) * u(1 - jitter, 1 + jitter) / u(1 - jitter, 1 + jitter)
+    scale = u(.4, 1)
+    if aspect >= 1:                      # wide result: the width is scaled, the height follows the aspect ratio
         nw = int(scale * w)
-        nh = int(nw / new_ar)
-    dx = int(rand(0, w - nw))
-    dy = int(rand(0, h - nh))
-    flip = rand() < .5
-    return nw, nh, dx, dy, int(flip)
+        nh = int(nw / aspect)
+    else:
+        nh = int(scale * h)
+        nw = int(nh * aspect)
+    dx, dy = int(u(0, w - nw)), int(u(0, h - nh))
+    return nw, nh, dx, dy, int(u(0, 1) < .5)
 
 
 def transform_boxes(bboxes, params, ih, iw, h, w, rng=None):
-    """Box side of get_random_data (gen1.py:462-473 / :509-520): rows (x1, y1, x2, y2, ...) as int64, shuffled with ``rng`` when
-    given, scaled, shifted, mirrored, clipped, and boxes no larger than one pixel dropped; returns float32."""
+    """Box side of get_random_data (gen1.py:462-473 / :509-520) for given draw results: rows (x1, y1, x2, y2, ...) are
+    truncated to int64, optionally shuffled with ``rng``, mapped through the resize / paste / flip (every intermediate result
+    truncated to int64 again, as the reference's in-place integer array does), clipped to the canvas, and boxes that are not
+    wider and higher than one pixel are dropped.  Returns float32."""
     nw, nh, dx, dy, flip = params
     box = np.array(bboxes, dtype=np.int64)
-    if len(box) > 0:
-        if rng is not None:
-            rng.shuffle(box)
-        box[:, [0, 2]] = box[:, [0, 2]] * nw / iw + dx
-        box[:, [1, 3]] = box[:, [1, 3]] * nh / ih + dy
-        if flip:
-            box[:, [0, 2]] = w - box[:, [2, 0]]
-        box[:, 0:2][box[:, 0:2] < 0] = 0
-        box[:, 2][box[:, 2] > w] = w
-        box[:, 3][box[:, 3] > h] = h
-        box_w = box[:, 2] - box[:, 0]
-        box_h = box[:, 3] - box[:, 1]
-        box = box[np.logical_and(box_w > 1, box_h > 1)]
-    return np.array(box, dtype=np.float32)
+    if len(box) == 0:
+        return box.astype(np.float32)
+    if rng is not None:
+        rng.shuffle(box)
+    xs = (box[:, [0, 2]] * nw / iw + dx).astype(np.int64)        # float64 arithmetic, truncation toward zero
+    ys = (box[:, [1, 3]] * nh / ih + dy).astype(np.int64)
+    if flip:
+        xs = w - xs[:, ::-1]
+    box[:, 0], box[:, 2] = np.maximum(xs[:, 0], 0), np.minimum(xs[:, 1], w)
+    box[:, 1], box[:, 3] = np.maximum(ys[:, 0], 0), np.minimum(ys[:, 1], h)
+    keep = ((box[:, 2] - box[:, 0]) > 1) & ((box[:, 3] - box[:, 1]) > 1)
+    return box[keep].astype(np.float32)
 
 
 def events_to_frames_augmented(ev_dev, Tm, sensor_hw, canvas_hw, params):

@@ -1,98 +1,89 @@
 """TEST INFRASTRUCTURE -- CPU restatement of the reference's SOP / energy estimate.
 
-Follows EventEvaluator.energy_estimation (yolox/evaluators/event_evaluator.py:466-565) and RecordHook
-(yolox/utils/hooks.py:31-44) statement by statement, with the ``.cuda()`` / ``torch.cuda.FloatTensor`` moves dropped
-(the reference method cannot run without a CUDA device, so it cannot be executed in the build container: this file is
-its restatement, and its arithmetic is exactly the reference's -- a deep copy of each layer with all-ones weights applied
-by PyTorch itself).  Only tests/ may import this module.
-"""
-import copy
+What the reference does (EventEvaluator.energy_estimation, yolox/evaluators/event_evaluator.py:466-565, with the
+input-recording hook of yolox/utils/hooks.py:31-44), restated here without its CUDA-only tensor moves (the method cannot
+run without a CUDA device, so it cannot be executed in the build container):
 
+* the layers that count are the nn.Conv2d modules found by walking ``model.named_children()``: the children of
+  ``model.backbone`` are filed under 'backbone' (the child called 'backbone') or 'fpn' (every other child), the
+  remaining top-level children under their own name; inside a group a layer is keyed by its name RELATIVE to the child it
+  was found in, so later layers replace earlier ones of the same relative name (:492-510);
+* per batch, every counted layer's input is recorded during one forward; a non-embedding layer's single recorded input
+  [M, C, H, W] is viewed as [T, M/T, C, H, W], an embedding layer's inputs (one per call) are stacked (:519-531);
+* accumulate operations of a layer = sum of ``conv(all-ones weights, zero bias)`` applied to the inputs summed over their
+  first axis, except for five named layers with real-valued inputs; multiply-accumulates = the same convolution applied to
+  a tensor of ones of that summed shape (:473-487, :533-539);
+* energies: 0.9 pJ per accumulate, 4.6 pJ per multiply-accumulate, reported per sample in units of 1e9 (:556-565).
+
+The arithmetic is PyTorch's own convolution, so this file only fixes the bookkeeping.  Only tests/ may import it.
+"""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 NO_AC_LAYERS = ('input_conv.0', 'input_conv.2', 'gate_conv.2', 'stem.0.conv.conv', 'dark2.0.conv.0')   # :533
+GROUPS = ('embedding', 'backbone', 'fpn', 'head')
 
 
-class RecordHook:
-    """hooks.py:31-44: keeps a clone of the first positional input of every call."""
+def counted_layers(model):
+    """{group: {relative name: conv module}} with the reference's replacement of equal relative names."""
+    table = {g: {} for g in GROUPS}
+    for top_name, top in model.named_children():
+        if top_name == 'backbone':
+            for part_name, part in top.named_children():
+                group = 'backbone' if part_name == 'backbone' else 'fpn'
+                table[group].update({n: m for n, m in part.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))})
+        else:
+            table[top_name].update({n: m for n, m in top.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))})
+    return table
 
-    def __init__(self):
-        self.inputs = []
 
-    def __call__(self, module, input, output):
-        self.inputs.append(input[0].data.clone())
+def ones_conv_sum(conv, x):
+    """sum of the layer's convolution with every weight set to one and no bias, applied to x [N, C, H, W]"""
+    w = torch.ones_like(conv.weight, dtype=x.dtype)
+    return F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups).sum()
 
 
-def calc_layer_sop(layer, inputs, ac=True):
-    """event_evaluator.py:473-487."""
-    sop_ac = 0
-    spike_counts = inputs.sum(0)
-    analog_counts = torch.ones_like(spike_counts)
-    aux_layer = copy.deepcopy(layer)
-    aux_layer.weight = torch.nn.Parameter(torch.ones_like(aux_layer.weight))
-    if aux_layer.bias is not None:
-        aux_layer.bias = torch.nn.Parameter(torch.zeros_like(aux_layer.bias))
-    if ac:
-        sop_ac = aux_layer(spike_counts).sum()
-    sop_mac = aux_layer(analog_counts).sum()
-    return sop_ac, sop_mac
+def layer_sop(conv, inputs, count_accumulates, dtype=torch.float64):
+    """(accumulate operations, multiply-accumulates) of one layer for its recorded ``inputs`` [K, N, C, H, W]"""
+    summed = inputs.to(dtype).sum(0)
+    mac = ones_conv_sum(conv, torch.ones_like(summed))
+    ac = ones_conv_sum(conv, summed) if count_accumulates else torch.zeros((), dtype=dtype)
+    return float(ac), float(mac)
 
 
 @torch.no_grad()
-def energy_estimation(model, batches, T, reset_fn=None, exact=True):
-    """Returns the dictionary eas_snn_amd.stats.energy_estimation returns.  ``exact``: run the all-ones layers in float64
-    (the reference sums ~1e8 float32 terms per layer; float64 gives the value those sums approximate)."""
-    hook_cls = (nn.Conv2d, nn.Linear)
+def energy_estimation(model, batches, T, reset_fn=None):
+    """Returns the dictionary eas_snn_amd.stats.energy_estimation returns (float64 sums: the value the reference's float32
+    sums over ~1e8 terms approximate)."""
     model.eval()
-    groups = ('embedding', 'backbone', 'fpn', 'head')
-    module_ac = {k: 0.0 for k in groups}
-    module_mac = {k: 0.0 for k in groups}
-    cali_layers = {k: {} for k in groups}
-    for m in model.named_children():                                                   # :492-510
-        module_name = m[0]
-        if m[0] == 'backbone':
-            for m_bb in m[1].named_children():
-                module_name = 'backbone' if m_bb[0] == 'backbone' else 'fpn'
-                for l in m_bb[1].named_modules():
-                    if isinstance(l[1], hook_cls):
-                        cali_layers[module_name][l[0]] = l[1]
-        else:
-            for l in m[1].named_modules():
-                if isinstance(l[1], hook_cls):
-                    cali_layers[module_name][l[0]] = l[1]
+    table = counted_layers(model)
+    module_ac = {g: 0.0 for g in GROUPS}
+    module_mac = {g: 0.0 for g in GROUPS}
     num_samples = 0
-    tot_ac = tot_mac = 0.0
-    for batch in batches:                                                              # :513-541
+    for batch in batches:
         imgs = batch[0] if isinstance(batch, (tuple, list)) else batch
         num_samples += len(imgs)
-        hooks = {k: {} for k in groups}
-        for key, module_layers in cali_layers.items():
-            for name, layer in module_layers.items():
-                hooker = RecordHook()
-                hooks[key][name] = (layer.register_forward_hook(hooker), hooker)
+        seen = {(g, n): [] for g in GROUPS for n in table[g]}
+        handles = [m.register_forward_hook(lambda mod, inp, out, key=(g, n): seen[key].append(inp[0].detach().clone()))
+                   for g in GROUPS for n, m in table[g].items()]
         model(imgs)
-        for key, module_layers in cali_layers.items():
-            for name, layer in module_layers.items():
-                handler, hooker = hooks[key][name]
-                if key != 'embedding':
-                    assert len(hooker.inputs) == 1
-                    inputs = hooker.inputs[0].reshape([T, -1] + list(hooker.inputs[0].shape[1:]))
+        for h in handles:
+            h.remove()
+        for g in GROUPS:
+            for name, conv in table[g].items():
+                rec = seen[(g, name)]
+                if g == 'embedding':
+                    inputs = torch.stack(rec)
                 else:
-                    inputs = torch.stack(hooker.inputs)
-                if_ac = name not in NO_AC_LAYERS
-                handler.remove()
-                lay = layer
-                if exact:
-                    lay = copy.deepcopy(layer).double()
-                    inputs = inputs.double()
-                sop_ac, sop_mac = calc_layer_sop(lay, inputs, ac=if_ac)
-                module_ac[key] += float(sop_ac)
-                tot_ac += float(sop_ac)
-                module_mac[key] += float(sop_mac)
-                tot_mac += float(sop_mac)
+                    assert len(rec) == 1, f'{g}.{name} ran {len(rec)} times'
+                    inputs = rec[0].reshape([T, -1] + list(rec[0].shape[1:]))
+                ac, mac = layer_sop(conv, inputs, name not in NO_AC_LAYERS)
+                module_ac[g] += ac
+                module_mac[g] += mac
         if reset_fn is not None:
             reset_fn(model)
+    tot_ac, tot_mac = sum(module_ac.values()), sum(module_mac.values())
     return {'module_ac': module_ac, 'module_mac': module_mac, 'tot_ac': tot_ac, 'tot_mac': tot_mac, 'num_samples': num_samples,
             'sop_snn_G': tot_ac / num_samples / 1e9, 'sop_ann_G': tot_mac / num_samples / 1e9,
             'snn_energy': 0.9 * tot_ac / num_samples / 1e9, 'ann_energy': 4.6 * tot_mac / num_samples / 1e9}
