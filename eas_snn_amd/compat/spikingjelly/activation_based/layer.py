@@ -110,3 +110,29 @@ class Conv2d(nn.Conv2d, base.StepModule):
         if self.step_mode == 's':
             return super().forward(x)
         return functional.seq_to_ann_forward(x, super().forward)
+
+
+def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None):
+    """spikes of node_a(bn_a(y12[:, :, :Ca])) and node_b(bn_b(y12[:, :, Ca:])) from ONE convolution output y12 [T,N,Ca+Cb,H,W]
+    (ops.bn_lif_pair): the two 1x1 branches of a CSPLayer.  cat_a / cat_b = (buffer, first channel) as in ``fused_with``."""
+    packs = []
+    for bn, node, cat in ((bn_a, node_a, cat_a), (bn_b, node_b, cat_b)):
+        batch = bn._use_batch_stats()
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            ops.bump_counter(bn.num_batches_tracked)
+        update = batch and bn.training and bn.track_running_stats
+        a = node.lif_args()
+        state = (bn.running_mean if (update or not batch) else None, bn.running_var if (update or not batch) else None, bool(batch),
+                 None if not update or bn.momentum is None else float(bn.momentum), float(bn.eps))
+        cfg = (state, node._v_in(y12[0, :, :bn.num_features]), float(a['k_const']), float(a['v_th']), float(a['v_reset']), int(a['flags']),
+               ops.SURROGATE_IDS[a['surrogate']] if isinstance(a['surrogate'], str) else int(a['surrogate']), float(a['alpha']),
+               bool(ops.state_writeback()), cat, int(bn.num_features))
+        packs.append((bn.weight, bn.bias, a['w'], cfg))
+    sa, va, sb, vb = ops.bn_lif_pair(y12, packs[0], packs[1])
+    if va is not None:
+        node_a.v = va
+    if vb is not None:
+        node_b.v = vb
+    ops.mark_small_int(sa)
+    ops.mark_small_int(sb)
+    return sa, sb

@@ -141,6 +141,18 @@ class CSPLayer(nn.Module):
         self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
+    def _dual_ok(self):
+        """conv1 / conv2 as one convolution: both plain bias-free 1x1 convolutions without hooks (EAS_NO_DUAL: development switch)"""
+        import os
+        if os.environ.get('EAS_NO_DUAL'):
+            return False
+        for blk in (self.conv1, self.conv2):
+            c = blk.conv[0] if isinstance(blk.conv, nn.Sequential) and len(blk.conv) == 1 else None
+            if (type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.bias is not None or c.groups != 1
+                    or c._forward_hooks or c._forward_pre_hooks or c.in_channels % 8 != 0 or blk.emit_rate):
+                return False
+        return not torch.nn.modules.module._global_forward_hooks
+
     def forward(self, x):
         last = self.m[-1] if len(self.m) else self.conv1
         tail = last.conv2 if isinstance(last, Bottleneck) else last
@@ -151,14 +163,27 @@ class CSPLayer(nn.Module):
             h = self.conv2.conv[0].out_channels if isinstance(self.conv2.conv, nn.Sequential) else self.conv2.conv.out_channels
             Ho, Wo = x.shape[-2:]
             buf = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.float32, device=x.device)
+            if self._dual_ok():
+                # conv1 and conv2 read the same x: ONE 1x1 convolution with the concatenated weights, then the two BN+LIF layers on
+                # the two channel halves of its output (x read once; the input gradient is one convolution, no branch addition)
+                c1, c2 = self.conv1.conv[0], self.conv2.conv[0]
+                x4 = x.flatten(0, 1)
+                if ops.is_small_int(x):
+                    ops.mark_small_int(x4)
+                sink = ops.conv_sink()
+                if sink is not None:
+                    sink(c1, x4, 1)
+                    sink(c2, x4, 1)
+                y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
+                a, b = sj_layer.fused_pair(self.conv1.bn, self.conv1.act, self.conv2.bn, self.conv2.act, y12,
+                                           cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
+            else:
+                a = self.conv1(x, cat=None if len(self.m) else (buf, 0))
+                b = self.conv2(x, cat=(buf, h))
             if len(self.m):
-                a = self.conv1(x)
                 for blk in self.m[:-1]:
                     a = blk(a)
                 a = self.m[-1](a, cat=(buf, 0))
-            else:
-                a = self.conv1(x, cat=(buf, 0))
-            b = self.conv2(x, cat=(buf, h))
             return self.conv3(ops.join_channels(buf, a, b))
         return self.conv3(_cat((self.m(self.conv1(x)), self.conv2(x))))
 

@@ -30,7 +30,7 @@ static inline int pick_chunks(int64_t groups_per_channel, int C) {
 
 // ------------------------------------------------------------------------------------------------ stats
 __global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial(const float* __restrict__ y, int TN, int C, int HW,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, int Cy) {
     __shared__ double red[NW];
     const int c = blockIdx.y;
     const int hw4 = HW / VEC;
@@ -42,9 +42,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial(const float* __res
     // two groups in flight per thread (both loads issued before the double-precision accumulation of either); the order in
     // which a thread adds its groups is unchanged
     for (; g + stride < groups; g += 2 * stride) {
-        const float4 v0 = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * C + c) * (int64_t)HW))[gw.q];
+        const float4 v0 = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * Cy + c) * (int64_t)HW))[gw.q];
         gw.next();
-        const float4 v1 = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * C + c) * (int64_t)HW))[gw.q];
+        const float4 v1 = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * Cy + c) * (int64_t)HW))[gw.q];
         gw.next();
         s += (double)v0.x + (double)v0.y + (double)v0.z + (double)v0.w;
         ss += (double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_stats_partial(const float* __res
         ss += (double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w;
     }
     if (g < groups) {
-        const float4 v = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * C + c) * (int64_t)HW))[gw.q];
+        const float4 v = reinterpret_cast<const float4*>(y + (((int64_t)gw.n * Cy + c) * (int64_t)HW))[gw.q];
         s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
         ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(EAS_WAVE) void bn_stats_finalize(const double* __re
 struct BnLifOut {
     const float* residual;   // nullable [T][N][C][HW]: spikes_out = spikes + residual (SEW shortcut, network_blocks.py:99-104)
     int out_ctot;            // 0: dense; else spikes are channels of a [T][N][out_ctot][HW] tensor (pointer already at channel 0 of the slice)
+    int y_ctot;              // 0: dense; else y is such a channel slice of a [T][N][y_ctot][HW] tensor (one convolution feeding two BN+LIF layers)
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -144,15 +145,17 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
     const int64_t M = (int64_t)N * C * HW;
-    const int64_t yts = bcast ? 0 : M;       // T identical input frames: one plane stands for all steps
+    const int Cy = ox.y_ctot ? ox.y_ctot : C;
+    const int64_t yts = bcast ? 0 : (int64_t)N * Cy * HW;       // T identical input frames: one plane stands for all steps
     GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         float4 ys[T_];
+        const int64_t ybase = (n * Cy + c) * (int64_t)HW + (int64_t)q * VEC;
 #pragma unroll
-        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + base);
+        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + ybase);
         const float vr0 = HARD ? p.v_reset : 0.0f;
         float4 v = v_in ? *reinterpret_cast<const float4*>(v_in + base) : make_float4(vr0, vr0, vr0, vr0);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
     int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot) {
+    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot) {
     __shared__ double red[NW];
     __shared__ float bc[2];
     const int c = blockIdx.y;
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const int64_t groups = (int64_t)N * hw4;
     const int64_t M = (int64_t)N * C * HW;
     const float invT = 1.0f / (float)T_;
-    const int64_t yts = bcast ? 0 : M;
+    const int Cy = y_ctot ? y_ctot : C;                               // y / grad_y may be channel slices of a wider tensor
+    const int64_t My = (int64_t)N * Cy * HW;
+    const int64_t yts = bcast ? 0 : My;
     const int64_t Mg = gs_ctot ? (int64_t)N * gs_ctot * HW : M;      // grad_s may be a channel slice of a wider tensor
     float m1 = 0.f, m2 = 0.f;
     if (APPLY) {
@@ -258,8 +263,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
         float4 ys[T_], gsv[T_];
+        const int64_t ybase = (n * Cy + c) * (int64_t)HW + (int64_t)q * VEC;
 #pragma unroll
-        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + base);
+        for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + ybase);
         float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
         if (grad_mean) {
             gm = *reinterpret_cast<const float4*>(grad_mean + base);
@@ -306,10 +312,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
                 float4 a = outv[0];
 #pragma unroll
                 for (int t = 1; t < T_; ++t) { a.x += outv[t].x; a.y += outv[t].y; a.z += outv[t].z; a.w += outv[t].w; }
-                *reinterpret_cast<float4*>(grad_y + base) = a;
+                *reinterpret_cast<float4*>(grad_y + ybase) = a;
             } else {
 #pragma unroll
-                for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * M + base) = outv[t];
+                for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * My + ybase) = outv[t];
             }
         }
     }
@@ -362,15 +368,15 @@ template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
-                 int C, int HW, int bcast, int gs_ctot, hipStream_t st) {
+                 int C, int HW, int bcast, int gs_ctot, int y_ctot, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot);
+                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot);
+                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -379,11 +385,11 @@ template <bool HARD, bool DI, bool STRICT>
 int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* y, const float* mean,
                const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
                float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
-               double* ws, int N, int C, int HW, int bcast, int gs_ctot, hipStream_t st) {
+               double* ws, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot, hipStream_t st) {
 #define EAS_CASE(TT)                                                                                               \
     case TT:                                                                                                       \
         return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
-                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, st);
+                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, y_ctot, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -398,12 +404,14 @@ extern "C" {
 int64_t eas_bn_workspace_doubles(int C) { return (int64_t)C * kMaxChunks * 4; }
 
 // launches the partial-sum kernel; returns the number of chunks per channel (> 0) or a negative status
-static int stats_partial(const float* y, int TN, int C, int HW, double* workspace, hipStream_t st) {
+static int stats_partial(const float* y, int TN, int C, int HW, double* workspace, int y_ctot, hipStream_t st) {
+    const int Cy = y_ctot ? y_ctot : C;
     int chunks;
     if (HW % VEC == 0 && (((uintptr_t)y) & 15) == 0) {
         chunks = pick_chunks((int64_t)TN * (HW / VEC), C);
-        hipLaunchKernelGGL(bn_stats_partial, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
+        hipLaunchKernelGGL(bn_stats_partial, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace, Cy);
     } else {
+        if (Cy != C) return EAS_ERR_UNSUPPORTED;
         chunks = pick_chunks((int64_t)TN * HW, C);
         hipLaunchKernelGGL(bn_stats_partial_scalar, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
     }
@@ -418,7 +426,7 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps,
     if (C > 65535) return EAS_ERR_UNSUPPORTED;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
-    const int chunks = stats_partial(y, TN, C, HW, workspace, st);
+    const int chunks = stats_partial(y, TN, C, HW, workspace, 0, st);
     if (chunks < 0) return chunks;
     hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, replicas, eps,
                        momentum, mean, invstd, running_mean, running_var);
@@ -426,11 +434,11 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps,
     return EAS_OK;
 }
 
-int eas_bn_stats_partial(const float* y, int TN, int C, int HW, double* workspace, eas_stream_t stream) {
-    if (!y || !workspace || TN < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
+int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, double* workspace, eas_stream_t stream) {
+    if (!y || !workspace || TN < 1 || C < 1 || HW < 1 || (y_ctot != 0 && y_ctot < C)) return EAS_ERR_INVALID_ARG;
     if (C > 65535) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
-    return stats_partial(y, TN, C, HW, workspace, eas_s(stream));
+    return stats_partial(y, TN, C, HW, workspace, y_ctot == C ? 0 : y_ctot, eas_s(stream));
 }
 
 static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin& fin) {
@@ -444,7 +452,7 @@ static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin&
     return EAS_OK;
 }
 
-int eas_bn_lif_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
                       const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                       int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
                       const EasBnPending* pending, const float* residual, int out_ctot, eas_stream_t stream) {
@@ -452,10 +460,10 @@ int eas_bn_lif_fwd_ex(const float* y, float* mean, float* invstd, const float* g
         return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out | (uintptr_t)residual) & 15) return EAS_ERR_INVALID_ARG;
-    if (out_ctot != 0 && out_ctot < C) return EAS_ERR_INVALID_ARG;
+    if ((out_ctot != 0 && out_ctot < C) || (y_ctot != 0 && (y_ctot < C || y_bcast))) return EAS_ERR_INVALID_ARG;
     BnFin fin;
     if (int rc = fin_from(pending, mean, invstd, fin)) return rc;
-    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot};
+    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot, y_ctot == C ? 0 : y_ctot};
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
@@ -474,11 +482,11 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
                    const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                    int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
                    eas_stream_t stream) {
-    return eas_bn_lif_fwd_ex(y, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, v_in, v_out, w_logit, k_const, v_th,
+    return eas_bn_lif_fwd_ex(y, 0, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, v_in, v_out, w_logit, k_const, v_th,
                              v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, stream);
 }
 
-int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, const float* mean,
+int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
@@ -491,15 +499,16 @@ int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_me
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)grad_s | (uintptr_t)grad_mean | (uintptr_t)v_init | (uintptr_t)grad_y) & 15)
         return EAS_ERR_INVALID_ARG;
-    if (grad_s_ctot != 0 && grad_s_ctot < C) return EAS_ERR_INVALID_ARG;
+    if ((grad_s_ctot != 0 && grad_s_ctot < C) || (y_ctot != 0 && (y_ctot < C || y_bcast))) return EAS_ERR_INVALID_ARG;
     const int gs_ctot = grad_s_ctot == C ? 0 : grad_s_ctot;
+    const int yc = y_ctot == C ? 0 : y_ctot;
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
-                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, st)
+                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, yc, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -513,7 +522,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
                    const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                    float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
                    float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
-    return eas_bn_lif_bwd_ex(grad_s, 0, grad_mean, y, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset, flags,
+    return eas_bn_lif_bwd_ex(grad_s, 0, grad_mean, y, 0, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset, flags,
                              surrogate, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C, HW, y_bcast, stream);
 }
 

@@ -174,10 +174,10 @@ class _TimeMeanFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ K4 (BN + LIF)
-def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev):
+def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=None, y_ctot=0):
     """launch the partial-sum pass of the batch statistics; the consumer kernel finalizes (EasBnPending)."""
     ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
-    chunks = L.eas_bn_stats_partial(ptr(y), TN, Cc, HW, ptr(ws), stream())
+    chunks = L.eas_bn_stats_partial(ptr(y) if y_ptr is None else y_ptr, y_ctot, TN, Cc, HW, ptr(ws), stream())
     if chunks <= 0:
         check(chunks if chunks < 0 else -1, 'eas_bn_stats_partial')
     pend = _lib.EasBnPending(ptr(ws), chunks, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
@@ -241,7 +241,7 @@ class _BNLIFFn(torch.autograd.Function):
             ctot = 0
         v_out = torch.empty(plane, dtype=torch.float32, device=dev) if write_v else None
         mo = torch.empty(plane, dtype=torch.float32, device=dev) if want_mean else None
-        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()), L.eas_bn_lif_fwd_ex, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()), L.eas_bn_lif_fwd_ex, ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
               ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, int(bool(t_bcast)),
               C.byref(pend) if pend is not None else None, ptr(residual), ctot, stream())
         del keep
@@ -275,7 +275,7 @@ class _BNLIFFn(torch.autograd.Function):
         ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
         nsteps = T * N * Cc * HW
         _call('eas_bn_lif_bwd', 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel()), L.eas_bn_lif_bwd_ex,
-              ptr(g_s), ctot, ptr(g_mean), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th,
+              ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th,
               v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW,
               int(bcast), stream())
         return (gy, ggamma, gbeta, None, None, gw) + (None,) * 9 + (g_res, None, None)
@@ -304,6 +304,104 @@ def join_channels(buf, *parts):
     if all(is_small_int(p) for p in parts):
         mark_small_int(out)
     return out
+
+
+class _BNLIF2Fn(torch.autograd.Function):
+    """Two BN+LIF layers on the two channel ranges of ONE convolution output y12 [T,N,Ca+Cb,H,W] (the 1x1 branches conv1 /
+    conv2 of a CSPLayer computed by one convolution with concatenated weights): each reads its channel slice in place and
+    the backward writes both slices of ONE gradient tensor, so the convolution's input gradient needs no addition of two
+    branch gradients and its input is read once."""
+
+    @staticmethod
+    def forward(ctx, y12, gamma_a, beta_a, w_a, gamma_b, beta_b, w_b, cfg_a, cfg_b):
+        L = _lib.lib()
+        y12 = _f32c(y12)
+        T, N, Ct, H, W = y12.shape
+        HW = H * W
+        dev = y12.device
+        outs, saved, cfgs = [], [], []
+        c0 = 0
+        for gamma, beta, w, cfg in ((gamma_a, beta_a, w_a, cfg_a), (gamma_b, beta_b, w_b, cfg_b)):
+            (running_mean, running_var, use_batch_stats, momentum, eps), v_in, k_const, v_th, v_reset, flags, sg_id, alpha, write_v, cat, Cc = cfg
+            _dev(gamma, beta, v_in, w)
+            v_in = _f32c(v_in)
+            yp = y12.data_ptr() + 4 * c0 * HW
+            pend = keep = None
+            if use_batch_stats:
+                mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+                invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+                t0 = _timer_mark()
+                pend, keep = _pending_stats(L, y12, T * N, Cc, HW, 1, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct)
+                _timer_add('eas_bn_stats', t0, 4 * T * N * Cc * HW)
+            else:
+                mean = running_mean
+                invstd = torch.rsqrt(running_var + eps)
+            if cat is not None:
+                spikes = cat[0].narrow(2, cat[1], Cc)
+                ctot = cat[0].shape[2]
+            else:
+                spikes = torch.empty((T, N, Cc, H, W), dtype=torch.float32, device=dev)
+                ctot = 0
+            v_out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev) if write_v else None
+            _call('eas_bn_lif_fwd', 8 * T * N * Cc * HW, L.eas_bn_lif_fwd_ex, yp, Ct, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                  ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), None, T, N, Cc, HW, 0,
+                  C.byref(pend) if pend is not None else None, None, ctot, stream())
+            del keep
+            outs += [spikes, v_out]
+            saved += [mean, invstd, gamma, beta, v_in, w]
+            cfgs.append((k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), Cc, c0))
+            c0 += Cc
+        ctx.save_for_backward(y12, *saved)
+        ctx.cfgs = cfgs
+        ctx.dims = (T, N, Ct, HW)
+        for v in (outs[1], outs[3]):
+            if v is not None:
+                ctx.mark_non_differentiable(v)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_sa, g_va, g_sb, g_vb):
+        y12, *saved = ctx.saved_tensors
+        T, N, Ct, HW = ctx.dims
+        L = _lib.lib()
+        gy12 = torch.empty_like(y12)
+        res = []
+        for i, g_s in enumerate((g_sa, g_sb)):
+            mean, invstd, gamma, beta, v_in, w = saved[6 * i:6 * i + 6]
+            k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, Cc, c0 = ctx.cfgs[i]
+            ggamma, gbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            gw = torch.empty_like(w) if w is not None else None
+            if g_s is None:
+                gy12.narrow(2, c0, Cc).zero_()
+                ggamma.zero_(); gbeta.zero_()
+                if gw is not None:
+                    gw.zero_()
+            else:
+                ctot = _channel_slice_of(g_s, Cc) if g_s.dtype == torch.float32 else 0
+                if ctot == 0:
+                    g_s = _f32c(g_s)
+                ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device)
+                off = 4 * c0 * HW
+                _call('eas_bn_lif_bwd', 12 * T * N * Cc * HW, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, None, y12.data_ptr() + off, Ct, ptr(mean),
+                      ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats),
+                      gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, 0, stream())
+            res += [ggamma, gbeta, gw]
+        return (gy12,) + tuple(res) + (None, None)
+
+
+def bn_lif_pair(y12, a, b):
+    """a / b: (gamma, beta, w, cfg) of the two layers, cfg = (bn_state, v_in, k_const, v_th, v_reset, flags, surrogate id, alpha,
+    write_v, cat or None, channels).  Returns (spikes_a, v_a, spikes_b, v_b)."""
+    return _BNLIF2Fn.apply(y12, a[0], a[1], a[2], b[0], b[1], b[2], a[3], b[3])
+
+
+def conv2d_weight(x, weight, stride=1, small_int=None):
+    """functional form of ``conv2d`` for a weight tensor that is not a module parameter (e.g. two concatenated 1x1 weights)"""
+    if small_int is None:
+        small_int = is_small_int(x)
+    if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
+        raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
+    return _ConvFn.apply(x, weight, None, stride, 1 if small_int else 3, None)
 
 
 def bn_lif_supported(y_seq, T):

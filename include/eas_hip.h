@@ -174,7 +174,10 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
  *   (network_blocks.py:99-104) without a separate addition; out_ctot (0 or >= C): the spikes are written as C consecutive
  *   channels of a [T][N][out_ctot][HW] tensor, `spikes` pointing at the first of them -- the concatenations of CSPLayer
  *   (network_blocks.py:183-188) happen in place.  mean_out is the rate of the spikes themselves (without residual).
- * eas_bn_lif_bwd_ex: grad_s_ctot (0 or >= C): grad_s is such a channel slice of a wider gradient tensor. */
+ * eas_bn_lif_bwd_ex: grad_s_ctot (0 or >= C): grad_s is such a channel slice of a wider gradient tensor.
+ * y_ctot (0 or >= C) in all three: y -- and grad_y in the backward -- are C consecutive channels of a [T][N][y_ctot][HW]
+ *   tensor, the pointers at the first of them: ONE convolution (concatenated weights) feeds the two 1x1 branches of a CSPLayer
+ *   (network_blocks.py:175-188), its input is read once and its input gradient needs no addition of two branch gradients. */
 typedef struct {
     const double* partial;   /* workspace filled by eas_bn_stats_partial; NULL = statistics already final */
     int chunks;              /* its return value */
@@ -184,12 +187,12 @@ typedef struct {
     float* running_mean;     /* nullable pair */
     float* running_var;
 } EasBnPending;
-int eas_bn_stats_partial(const float* y, int TN, int C, int HW, double* workspace, eas_stream_t stream);
-int eas_bn_lif_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, double* workspace, eas_stream_t stream);
+int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
                       const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                       int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
                       const EasBnPending* pending, const float* residual, int out_ctot, eas_stream_t stream);
-int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, const float* mean,
+int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,

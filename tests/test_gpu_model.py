@@ -310,6 +310,50 @@ def test_fused_detection_loss_equals_tensor_form(dev, nc, use_l1, hw, seed):
         torch.testing.assert_close(gp1[k], gp0[k], rtol=1e-4, atol=2e-6 * float(gp0[k].abs().max()) + 1e-9, msg=k)
 
 
+@pytest.mark.parametrize('train', [True, False])
+def test_csp_single_convolution_for_both_branches_is_identical(dev, train, monkeypatch):
+    """CSPLayer with conv1 / conv2 computed by ONE 1x1 convolution (concatenated weights, the two BN+LIF layers on channel slices of
+    its output, one gradient tensor) against the two-convolution path: spikes and BN running statistics bit-identical (the same
+    products are summed in the same order per output channel), gradients equal to rounding."""
+    import copy
+    from yolox.models.network_blocks import CSPLayer
+    from yolox.utils.utils_snn import convert_to_spiking
+    from spikingjelly.activation_based import functional, surrogate
+    torch.manual_seed(5)
+    base = CSPLayer(32, 32, n=2)
+    convert_to_spiking(base, spike_fn=surrogate.ATan(2.0))
+    for m in base.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+            with torch.no_grad():
+                m.running_mean.fill_(-0.8)          # eval mode: neurons must fire for the comparison to mean something
+    x = (torch.rand(3, 2, 32, 16, 20) < 0.3).float()
+    go = torch.randn(3, 2, 32, 16, 20)
+    res = []
+    for nodual in ('1', ''):
+        if nodual:
+            monkeypatch.setenv('EAS_NO_DUAL', '1')
+        else:
+            monkeypatch.delenv('EAS_NO_DUAL', raising=False)
+        net = copy.deepcopy(base).to(dev).train(train)
+        assert net._dual_ok() == (not nodual)
+        from eas_snn_amd import ops
+        xd = ops.mark_small_int(x.to(dev)).requires_grad_(True)
+        out = net(xd)
+        out.backward(go.to(dev))
+        functional.reset_net(net)
+        res.append((out.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                    {k: b.clone() for k, b in net.named_buffers()}))
+    (o0, g0, p0, b0), (o1, g1, p1, b1) = res
+    assert torch.equal(o0, o1) and float(o0.sum()) > 0
+    # the input gradient sums the two branches' products in one accumulation instead of two sums and an addition: rounding-level
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
+    for k in p0:
+        torch.testing.assert_close(p1[k], p0[k], rtol=1e-5, atol=1e-6 * float(p0[k].abs().max()) + 1e-12, msg=k)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+
+
 def test_state_dict_roundtrip_and_writeback_switch(dev):
     from eas_snn_amd import ops
     from spikingjelly.activation_based import functional
