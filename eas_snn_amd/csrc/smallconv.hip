@@ -34,34 +34,43 @@ struct Stager {
     using G = Geo<K>;
     static constexpr int NE = CIN * G::LH * G::LW;
     static constexpr int PER = (NE + NT - 1) / NT;
+    // Which window element a thread stages does not depend on the tile: (channel, row, column) -> image-relative offset, packed
+    // (row, column) and LDS offset are worked out ONCE per thread (the divisions by the window width / height per element and
+    // tile were as many vector-ALU instructions as the convolution's FMAs); per tile only the bounds test and one add remain.
+    int rel[PER];        // (c * H + r) * W + col, relative to the window origin
+    int rc[PER];         // r | col << 8, or -1 for the surplus elements of the last slice
+    int lofs[PER];       // c * PLANE + r * LWS + col
 
-    __device__ __forceinline__ static void load(const float* __restrict__ x, float (&pre)[PER], int n, int H, int W, int y0,
-                                                int x0) {
-        const int64_t img = (int64_t)n * CIN * H * W;
+    __device__ __forceinline__ void init(int H, int W) {
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
             const int idx = threadIdx.x + it * NT;
             const int col = idx % G::LW;
             const int r = (idx / G::LW) % G::LH;
             const int c = idx / (G::LW * G::LH);
-            const int gy = y0 - G::PAD + r, gx = x0 - G::PAD + col;
-            const bool ok = idx < NE && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float v = x[ok ? img + ((int64_t)c * H + gy) * W + gx : 0];
+            rel[it] = (c * H + r) * W + col;
+            rc[it] = idx < NE ? (r | (col << 8)) : -1;
+            lofs[it] = c * PLANE + r * LWS + col;
+        }
+    }
+
+    __device__ __forceinline__ void load(const float* __restrict__ x, float (&pre)[PER], int n, int H, int W, int y0, int x0) const {
+        const int oy = y0 - G::PAD, ox = x0 - G::PAD;
+        const float* win = x + ((int64_t)n * CIN * H + oy) * W + ox;       // window origin (may lie outside the image)
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int r = rc[it] & 255, col = rc[it] >> 8;
+            const unsigned gy = (unsigned)(oy + r), gx = (unsigned)(ox + col);
+            const bool ok = rc[it] >= 0 && gy < (unsigned)H && gx < (unsigned)W;
+            const float v = *(ok ? win + rel[it] : x);
             pre[it] = ok ? v : 0.f;
         }
     }
 
-    __device__ __forceinline__ static void store(float* __restrict__ lds, const float (&pre)[PER]) {
+    __device__ __forceinline__ void store(float* __restrict__ lds, const float (&pre)[PER]) const {
 #pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int idx = threadIdx.x + it * NT;
-            if (idx < NE) {
-                const int col = idx % G::LW;
-                const int r = (idx / G::LW) % G::LH;
-                const int c = idx / (G::LW * G::LH);
-                lds[c * PLANE + r * LWS + col] = pre[it];
-            }
-        }
+        for (int it = 0; it < PER; ++it)
+            if (rc[it] >= 0) lds[lofs[it]] = pre[it];
     }
 };
 
@@ -74,6 +83,8 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
     using G = Geo<K>;
     constexpr int PLANE = G::LH * LWS;
     using St = Stager<CIN, K, PLANE>;
+    St st;
+    st.init(H, W);
     __shared__ __attribute__((aligned(16))) float lds[CIN * PLANE];
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = N * tiles_x * tiles_y;
@@ -81,16 +92,16 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
     float pre[St::PER];
     int tile = blockIdx.x;
     if (tile < ntiles)
-        St::load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
+        st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
     for (; tile < ntiles; tile += gridDim.x) {
         const int n = tile / (tiles_x * tiles_y);
         const int ty0 = ((tile / tiles_x) % tiles_y) * TH, tx0 = (tile % tiles_x) * TW;
         __syncthreads();                               // readers of the previous tile are done
-        St::store(lds, pre);
+        st.store(lds, pre);
         __syncthreads();
         const int nxt = tile + gridDim.x;              // next tile's loads fly during this tile's FMAs
         if (nxt < ntiles)
-            St::load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
+            st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
         float acc[COUT][4];
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
@@ -182,6 +193,8 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
             for (int kx = 0; kx < K; ++kx) acc[o][ky][kx] = 0.f;
     }
     using St = Stager<CIN, K, PLANE>;
+    St st;
+    st.init(H, W);
     constexpr int GPER = (LG / 4 + NT - 1) / NT;
     float pre[St::PER];
     float4 preg[GPER];
@@ -210,12 +223,12 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
     };
     int tile = blockIdx.x;
     if (tile < ntiles) {
-        St::load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
+        st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
         load_gy(tile);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                           // previous tile's readers are done
-        St::store(lx, pre);
+        st.store(lx, pre);
 #pragma unroll
         for (int it = 0; it < GPER; ++it) {
             const int idx = threadIdx.x + it * NT;
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
         __syncthreads();
         const int nxt = tile + gridDim.x;          // next tile's loads fly during this tile's FMAs
         if (nxt < ntiles) {
-            St::load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
+            st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
             load_gy(nxt);
         }
         for (int u = grp; u < UNITS; u += GROUPS) {
