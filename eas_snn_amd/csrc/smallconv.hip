@@ -29,7 +29,7 @@ struct Geo {
 // global loads back to back (out-of-range lanes read element 0 and are zeroed by a select, so there are no
 // branches and the loads stay in flight across the compute phase of the previous tile); `store` writes them to
 // LDS (channel planes PLANE floats apart, rows LWS floats apart).
-template <int CIN, int K, int PLANE>
+template <int CIN, int K, int PLANE, int PITCH = LWS>
 struct Stager {
     using G = Geo<K>;
     static constexpr int NE = CIN * G::LH * G::LW;
@@ -39,7 +39,7 @@ struct Stager {
     // tile were as many vector-ALU instructions as the convolution's FMAs); per tile only the bounds test and one add remain.
     int rel[PER];        // (c * H + r) * W + col, relative to the window origin
     int rc[PER];         // r | col << 8, or -1 for the surplus elements of the last slice
-    int lofs[PER];       // c * PLANE + r * LWS + col
+    int lofs[PER];       // c * PLANE + r * PITCH + col
 
     __device__ __forceinline__ void init(int H, int W) {
 #pragma unroll
@@ -50,7 +50,7 @@ struct Stager {
             const int c = idx / (G::LW * G::LH);
             rel[it] = (c * H + r) * W + col;
             rc[it] = idx < NE ? (r | (col << 8)) : -1;
-            lofs[it] = c * PLANE + r * LWS + col;
+            lofs[it] = c * PLANE + r * PITCH + col;
         }
     }
 
@@ -81,8 +81,13 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
                                                           const float* __restrict__ b, const float* __restrict__ mask,
                                                           float* __restrict__ y, int N, int H, int W, int relu) {
     using G = Geo<K>;
-    constexpr int PLANE = G::LH * LWS;
-    using St = Stager<CIN, K, PLANE>;
+    // Row pitch 128 floats (a multiple of the 64-bank row): ds_read_b128 serves the lanes in the groups {0-3,12-15,20-27},
+    // {4-11,16-19,28-31}, ...; with lane = (row << 4) | column-quad a group then touches column quads 0-3 and 12-15 of one row and
+    // 4-11 of the next -- every bank once.  (The earlier pitch of 80 floats shifted the second row by 16 banks onto the first
+    // row's quads 12-15: PMC showed 62 % of the LDS cycles as bank conflicts; the kernel gained 3 %, it is not LDS-bound.)
+    constexpr int LWF = 128;
+    constexpr int PLANE = G::LH * LWF;
+    using St = Stager<CIN, K, PLANE, LWF>;
     St st;
     st.init(H, W);
     __shared__ __attribute__((aligned(16))) float lds[CIN * PLANE];
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 float v[G::NV4 * 4];
-                const float4* row = reinterpret_cast<const float4*>(lds + i * PLANE + (ty + ky) * LWS + 4 * tx);
+                const float4* row = reinterpret_cast<const float4*>(lds + i * PLANE + (ty + ky) * LWF + 4 * tx);
 #pragma unroll
                 for (int q = 0; q < G::NV4; ++q) {
                     const float4 t = row[q];
