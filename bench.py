@@ -3,7 +3,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic raw events already resident in HBM:
   K1 event histogram (4 micro-slices) -> canvas -> adaptive sampler (arsnn) -> spiking backbone (T=3) -> PAFPN ->
-  head -> SimOTA loss -> backward -> (DDP gradient all-reduce over RCCL) -> Adam step -> reset_net.
+  head -> SimOTA loss -> backward -> (N>1: one packed gradient all-reduce over RCCL, eas_snn_amd/parallel.py) -> Adam step ->
+  reset_net.  The warm-up also times eager launches against HIP-graph replay of the same step and the timed region uses the faster.
 Workload = BASELINE.json configs[1]: SYOLOX-S, Gen1 304x240 sensor (256x320 canvas), T=3, Tm=4, batch 64 per GPU.
 Multi-GPU: data parallel, weak scaling (64 samples per rank), launched by torch.distributed.run.
 
