@@ -195,3 +195,41 @@ def test_launch_two_ranks_gloo(tmp_path):
     r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     assert (tmp_path / 'ok_t_0').exists() and (tmp_path / 'ok_t_1').exists()
+
+
+def test_model_ema_and_exp_lookup(tmp_path):
+    """ModelEMA: floating entries follow keep*avg + (1-keep)*live with keep = decay*(1-exp(-n/2000)), integer buffers are left
+    alone, DDP-style wrappers are looked through; get_exp: file wins over name, a broken file raises ImportError."""
+    import math
+    from yolox.exp import get_exp
+    from yolox.utils import ModelEMA, is_parallel
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 1), torch.nn.BatchNorm2d(3))
+    ema = ModelEMA(net, 0.9998)
+    assert not is_parallel(net) and not ema.ema.training and not any(p.requires_grad for p in ema.ema.parameters())
+    before = {k: v.clone() for k, v in ema.ema.state_dict().items()}
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(1.0)
+        net[1].running_mean.add_(0.5)
+        net[1].num_batches_tracked.add_(7)
+    ema.update(net)
+    keep = 0.9998 * (1.0 - math.exp(-1 / 2000))
+    assert ema.updates == 1 and abs(ema.decay(1) - keep) < 1e-15
+    live = net.state_dict()
+    for k, v in ema.ema.state_dict().items():
+        if v.is_floating_point():
+            torch.testing.assert_close(v, keep * before[k] + (1.0 - keep) * live[k], rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(v, before[k])
+
+    good = tmp_path / 'my_exp_file.py'
+    good.write_text('class Exp:\n    tag = "from-file"\n')
+    assert get_exp(str(good), 'e-yolox-s').tag == 'from-file'
+    bad = tmp_path / 'my_bad_exp_file.py'
+    bad.write_text('x = 1\n')
+    with pytest.raises(ImportError):
+        get_exp(str(bad), None)
+    with pytest.raises(AssertionError):
+        get_exp(None, None)
+    assert type(get_exp(None, 'e-yolox-s')).__name__ == 'Exp'
