@@ -9,6 +9,8 @@
 // The same kernel computes the data gradient (weights flipped + channel-transposed, optional ReLU mask epilogue).
 // The weight gradient kernel keeps x (with halo) and grad_y tiles in LDS, gives each thread one (ci, ky) row of
 // the filter for all (co, kx) and a share of the tile's pixels, and reduces block partials in fixed order.
+#include <stdlib.h>
+
 #include "eas_common.h"
 
 namespace {
@@ -361,7 +363,17 @@ int launch_wgrad_k(int k, const float* gy, const float* x, float* partial, int n
 
 bool bad_ptr(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
+// EAS_SW_FORM=fma|mfma (development switch): which weight-gradient kernel eas_smallconv_bwd_weight launches
+bool wgrad_on_mfma() {
+    const char* e = getenv("EAS_SW_FORM");      // read per call, so a test can compare the two forms in one process
+    return e && e[0] == 'm';
+}
+
 }  // namespace
+
+// smallconv_wgrad_mfma.hip
+int eas_sw_mfma_partials(const float* gy, const float* x, float* partial, int max_blocks, int N, int Cin, int Cout, int H, int W,
+                         int k, hipStream_t st);
 
 extern "C" {
 
@@ -399,14 +411,20 @@ int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w,
     if (!grad_y || !x || !grad_w || !workspace || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
-    const int tiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const int nblocks = tiles < kWgradBlocks ? tiles : kWgradBlocks;
-    int rc;
-    if (Cin == 2 && Cout == 4) rc = launch_wgrad_k<2, 4>(k, grad_y, x, workspace, nblocks, N, H, W, st);
-    else if (Cin == 4 && Cout == 4) rc = launch_wgrad_k<4, 4>(k, grad_y, x, workspace, nblocks, N, H, W, st);
-    else if (Cin == 2 && Cout == 2) rc = launch_wgrad_k<2, 2>(k, grad_y, x, workspace, nblocks, N, H, W, st);
-    else return EAS_ERR_UNSUPPORTED;
-    if (rc != EAS_OK) return rc;
+    int nblocks;
+    if (wgrad_on_mfma()) {
+        nblocks = eas_sw_mfma_partials(grad_y, x, workspace, kWgradBlocks, N, Cin, Cout, H, W, k, st);
+        if (nblocks < 0) return nblocks;
+    } else {
+        const int tiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+        nblocks = tiles < kWgradBlocks ? tiles : kWgradBlocks;
+        int rc;
+        if (Cin == 2 && Cout == 4) rc = launch_wgrad_k<2, 4>(k, grad_y, x, workspace, nblocks, N, H, W, st);
+        else if (Cin == 4 && Cout == 4) rc = launch_wgrad_k<4, 4>(k, grad_y, x, workspace, nblocks, N, H, W, st);
+        else if (Cin == 2 && Cout == 2) rc = launch_wgrad_k<2, 2>(k, grad_y, x, workspace, nblocks, N, H, W, st);
+        else return EAS_ERR_UNSUPPORTED;
+        if (rc != EAS_OK) return rc;
+    }
     const int nw = Cout * Cin * k * k, nout = nw + Cout;
     hipLaunchKernelGGL(smallconv_wgrad_finalize, dim3(nout), dim3(EAS_WAVE), 0, st, workspace, nblocks, nout, nw,
                        grad_w, grad_b);

@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage (on the GPU box): pmc_kernel.sh <kernel regex> <tag> -- SQ counters of one kernel family under scripts/bench_kernels.py
-RX=${1:-smallconv}; TAG=${2:-pmc_k}
+# usage (on the GPU box): pmc_kernel.sh <kernel regex> <tag> [script] -- SQ counters of one kernel family under scripts/bench_kernels.py
+# (or another driver script, path relative to the repo root)
+RX=${1:-smallconv}; TAG=${2:-pmc_k}; SCRIPT=${3:-scripts/bench_kernels.py}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -9,7 +10,7 @@ for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
             "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_IFETCH SQ_INSTS_WAVE32_LDS SQ_WAVE_READY"; do
   N=$(echo $PASS | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "$RX" --output-format csv -d $OUT/$N -- python3 $ROOT/scripts/bench_kernels.py > $OUT/$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "$RX" --output-format csv -d $OUT/$N -- python3 $ROOT/$SCRIPT > $OUT/$N.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -633,6 +633,36 @@ def test_smallconv_vs_fp64_reference(dev, cin, cout, k, N, H, W):
     np.testing.assert_allclose(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3)), rtol=1e-4, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize('cin,cout,k,N,H,W', [(2, 4, 5, 3, 32, 64), (4, 4, 5, 2, 48, 80), (2, 4, 7, 2, 20, 36), (4, 4, 3, 1, 16, 64),
+                                               (2, 2, 5, 2, 17, 30), (4, 4, 7, 1, 256, 320), (2, 4, 3, 5, 33, 130), (4, 4, 5, 2, 7, 5),
+                                               (4, 4, 5, 1, 9, 67)])
+def test_smallconv_weight_gradient_forms(dev, monkeypatch, cin, cout, k, N, H, W):
+    """the two weight-gradient kernels behind eas_smallconv_bwd_weight (EAS_SW_FORM=fma: VALU kernel, mfma: (channel, kernel row) x
+    (channel, kernel column) tiles on the matrix cores with exact bf16 terms) against fp64, incl. images smaller than one tile,
+    ragged bands / chunks, W % 4 != 0, spike-valued x, and run-to-run determinism of the MFMA form."""
+    from eas_snn_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout * 100 + k * 10 + H)
+    x = rng.standard_normal((N, cin, H, W)).astype(np.float32)
+    if (H + W) % 2:
+        x = (x > 0.3).astype(np.float32) * rng.integers(1, 4, x.shape).astype(np.float32)     # event counts
+    w = np.zeros((cout, cin, k, k), np.float32)
+    gy = (rng.standard_normal((N, cout, H, W)) * np.exp(rng.uniform(-3, 3, (N, cout, 1, 1)))).astype(np.float32)
+    xd, gyd = torch.from_numpy(x).double(), torch.from_numpy(gy).double()
+    want_w = torch.nn.grad.conv2d_weight(xd, w.shape, gyd, padding=k // 2).numpy()
+    want_b = gy.astype(np.float64).sum((0, 2, 3))
+    mag_w = torch.nn.grad.conv2d_weight(xd.abs(), w.shape, gyd.abs(), padding=k // 2).numpy()    # sum of |products|
+    mag_b = np.abs(gy).astype(np.float64).sum((0, 2, 3))
+    got = {}
+    for form in ('fma', 'mfma'):
+        monkeypatch.setenv('EAS_SW_FORM', form)
+        gw, gb = ops.smallconv_bwd_weight(_t(gy, dev), _t(x, dev), _t(w, dev))
+        got[form] = (gw.cpu().numpy(), gb.cpu().numpy())
+        assert np.all(np.abs(got[form][0] - want_w) <= 2e-6 * mag_w + 1e-30), form
+        assert np.all(np.abs(got[form][1] - want_b) <= 2e-6 * mag_b + 1e-30), form
+    gw2, gb2 = ops.smallconv_bwd_weight(_t(gy, dev), _t(x, dev), _t(w, dev))
+    assert np.array_equal(gw2.cpu().numpy(), got['mfma'][0]) and np.array_equal(gb2.cpu().numpy(), got['mfma'][1])
+
+
 # ------------------------------------------------------------------------------------------------ BN + SiLU (ANN blocks)
 @pytest.mark.parametrize('N,C,H,W,train', [(4, 16, 12, 20, True), (4, 16, 12, 20, False), (1, 3, 2, 2, True), (64, 128, 32, 40, True)])
 def test_bn_silu_fused_vs_torch(dev, N, C, H, W, train):
