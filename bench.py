@@ -36,7 +36,7 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
 PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
                'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
                'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel'], 'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel'],
-               'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel'],
+               'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel', 'smallconv_wgrad_mfma_kernel'],
                'eas_conv_fwd': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel'], 'eas_conv_wgrad': ['conv_wgrad_mfma_kernel', 'conv1x1_wgrad_kernel']}
 
 

@@ -8,7 +8,8 @@
 // channel from registers (16..  accumulators), weights come from scalar loads (uniform addresses -> SGPRs).
 // The same kernel computes the data gradient (weights flipped + channel-transposed, optional ReLU mask epilogue).
 // The weight gradient kernel keeps x (with halo) and grad_y tiles in LDS, gives each thread one (ci, ky) row of
-// the filter for all (co, kx) and a share of the tile's pixels, and reduces block partials in fixed order.
+// the filter for all (co, kx) and a share of the tile's pixels, and reduces block partials in fixed order; for k >= 5 the
+// matrix-core form of smallconv_wgrad_mfma.hip produces the block partials instead.
 #include <stdlib.h>
 
 #include "eas_common.h"
@@ -363,10 +364,13 @@ int launch_wgrad_k(int k, const float* gy, const float* x, float* partial, int n
 
 bool bad_ptr(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
-// EAS_SW_FORM=fma|mfma (development switch): which weight-gradient kernel eas_smallconv_bwd_weight launches
-bool wgrad_on_mfma() {
-    const char* e = getenv("EAS_SW_FORM");      // read per call, so a test can compare the two forms in one process
-    return e && e[0] == 'm';
+// Which weight-gradient kernel eas_smallconv_bwd_weight launches: the matrix-core form for k >= 5 (measured on MI355X, 256 images of
+// 256x320: 4->4 k5 345 us against 580 us, k7 91 against 417 us), the vector-ALU form for k = 3 (95 against 145 us).
+// EAS_SW_FORM=fma|mfma (development switch) forces one; read per call, so a test can compare the two forms in one process.
+bool wgrad_on_mfma(int k) {
+    const char* e = getenv("EAS_SW_FORM");
+    if (e && e[0]) return e[0] == 'm';
+    return k >= 5;
 }
 
 }  // namespace
@@ -412,7 +416,7 @@ int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w,
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     int nblocks;
-    if (wgrad_on_mfma()) {
+    if (wgrad_on_mfma(k)) {
         nblocks = eas_sw_mfma_partials(grad_y, x, workspace, kWgradBlocks, N, Cin, Cout, H, W, k, st);
         if (nblocks < 0) return nblocks;
     } else {

@@ -15,11 +15,12 @@
 // start at column w + kw - P: x is staged twice, as is ("even") and shifted by one column ("odd"), so that every fragment
 // starts on a 4-byte boundary of one of the two copies and is read as four dwords.
 //
-// Block = 4 waves, persistent over (image, 8-row band, 64-column chunk) tiles; wave v takes rows v, v+4 of the band.  The
-// 32x32 accumulator tile stays in registers over all tiles; per block one fixed-order reduction over the waves, block partials in
-// the layout of smallconv.hip's VALU kernel (its finalize kernel sums them in fixed order: deterministic, no float atomics).
-#include <stdlib.h>
-
+// Persistent blocks over (image, 8-row band, 64-column chunk) tiles, one block per CU: 8 staging waves convert tile t+1 to bf16
+// terms (global loads issued two tiles ahead) into one LDS buffer while 8 multiplying waves, one x row each, run the MFMAs of tile t
+// from the other; one barrier per tile.  The 32x32 accumulator tiles stay in registers over all tiles; per block one fixed-order
+// reduction over the waves, block partials in the layout of smallconv.hip's VALU kernel (its finalize kernel sums them in fixed
+// order: deterministic, no float atomics).  Measured (MI355X, 256 images of 256x320, 4->4 k5): 345 us against 580 us for the VALU
+// kernel; the LDS array is the limiter (78 % busy: six operand fragments per six MFMAs), not the matrix cores.
 #include "eas_common.h"
 
 namespace {
@@ -54,18 +55,16 @@ struct Sw {
     static constexpr int G_BYTES = 3 * G_TERM;
     static constexpr int X_BYTES = 3 * X_TERM;
     static constexpr int STAGE_BYTES = G_BYTES + X_BYTES;
-    static constexpr int RED_BYTES = NWV * 32 * 33 * 4;
+    static constexpr int RED_BYTES = 2 * NWV * 32 * 33 * 4;
     static constexpr int LDS_BYTES = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
     static constexpr int NWT = COUT * CIN * K * K;
     static constexpr int NOUT = NWT + COUT;
     static constexpr int G_ITEMS = GR * COUT * (WC / 8);
     static constexpr int X_ITEMS = RB * CIN * (XC / 8);
-    static constexpr int NG = (G_ITEMS + NTH - 1) / NTH;   // staging items per thread
-    static constexpr int NX = (X_ITEMS + NTH - 1) / NTH;
     static_assert(COUT * K <= 32 && CIN * K + 1 <= 32, "does not fit one 32x32 tile");
     static_assert(PAD + 1 <= HALO && XC <= XP && (X_COPY / 4) % 64 == 8, "x staging geometry");
-    static_assert(LDS_BYTES <= 65536, "LDS");
-    static_assert(RB == 2 * NWV, "two rows per wave");
+    static_assert(2 * STAGE_BYTES <= 160 * 1024 && STAGE_BYTES % 16 == 0, "LDS");
+    static_assert(RB == 2 * NWV, "two rows per wave (4 waves) / one row per wave (8 waves)");
 };
 
 __device__ __forceinline__ void sw_split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -103,41 +102,49 @@ __device__ __forceinline__ void sw_load_row(const float* __restrict__ row, bool 
     }
 }
 
+// VEC (W % 4 == 0, aligned tensors): 16 waves, two LDS buffers -- waves 0-7 convert and stage tile t+1 (vector ALU, LDS stores) while
+// waves 8-15 multiply tile t, one row of the band each (matrix cores, LDS reads); each SIMD hosts two waves of either kind, one
+// barrier per tile.
+// !VEC (any W / alignment): 4 waves do both in turn on one buffer.
 template <int CIN, int COUT, int K, bool VEC>
-__global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                                   float* __restrict__ partial, int N, int H, int W, int dbg) {
+__global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                                   float* __restrict__ partial, int N, int H, int W) {
     using S = Sw<CIN, COUT, K>;
     constexpr int PAD = S::PAD;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[S::LDS_BYTES];
-    unsigned char* const sg = smem;
-    unsigned char* const sx = smem + S::G_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NBUF = VEC ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // NBUF x STAGE_BYTES
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int NTS = VEC ? 2 * NTH : NTH;                                    // staging threads
+    constexpr int NCW = VEC ? 2 * NWV : NWV;                                    // multiplying waves
+    constexpr int RPW = RB / NCW;                                               // rows of the band per multiplying wave
+    const int wave = VEC ? (tid >> 6) - NTS / 64 : (tid >> 6);                  // index among the multiplying waves (< 0: staging wave)
     const int r = lane & 31, hh = lane >> 5;
 
     // this lane's A row (co, kh) and B column (ci, kw).  Lanes outside the (co,kh) x (ci,kw) ranges read constant LDS rows (zeros;
     // ones for the bias column) with zero strides: the compute phase has no branches and no selects.
     const bool a_ok = r < COUT * K;
     const int a_co = a_ok ? r / K : 0, a_kh = a_ok ? r % K : 0;
-    int a_off = a_ok ? (((2 * PAD - a_kh) * COUT + a_co) * S::GP + 8 * hh) * 2 : S::G_ROWS * S::GP * 2;
-    int a_rs = a_ok ? COUT * S::GP * 2 : 0, a_kss = a_ok ? 32 : 0;         // + row*a_rs + ks*a_kss + term*G_TERM
+    const int a_off = a_ok ? (((2 * PAD - a_kh) * COUT + a_co) * S::GP + 8 * hh) * 2 : S::G_ROWS * S::GP * 2;
+    const int a_rs = a_ok ? COUT * S::GP * 2 : 0, a_kss = a_ok ? 32 : 0;         // + row*a_rs + ks*a_kss + term*G_TERM
     const int b_kind = r < CIN * K ? 1 : (r == CIN * K ? 2 : 0);                 // 1 data, 2 ones (bias column), 0 unused
     const int b_ci = b_kind == 1 ? r / K : 0, b_kw = b_kind == 1 ? r % K : PAD;
     const int sft = b_kw - PAD;                                                   // column shift of this lane's fragment
     const int odd = sft & 1;
-    int b_off = b_kind == 1 ? odd * S::X_COPY + (b_ci * S::XP + HALO + 8 * hh + (sft - odd)) * 2
+    const int b_off = b_kind == 1 ? odd * S::X_COPY + (b_ci * S::XP + HALO + 8 * hh + (sft - odd)) * 2
                                   : (b_kind == 2 ? S::X_ONES : S::X_ZERO);
-    int b_rs = b_kind == 1 ? CIN * S::XP * 2 : 0, b_kss = b_kind == 1 ? 32 : 0;   // + row*b_rs + ks*b_kss + term*X_TERM
-    if (dbg & 4) { a_off = S::G_ROWS * S::GP * 2; a_rs = 0; a_kss = 0; }      // timing experiments: broadcast reads
-    if (dbg & 8) { b_off = S::X_ZERO; b_rs = 0; b_kss = 0; }
+    const int b_rs = b_kind == 1 ? CIN * S::XP * 2 : 0, b_kss = b_kind == 1 ? 32 : 0;   // + row*b_rs + ks*b_kss + term*X_TERM
 
     // constant rows (never overwritten by the staging)
-    for (int i = tid; i < 3 * S::GP / 2; i += NTH) {
-        const int tm = i / (S::GP / 2), d = i % (S::GP / 2);
-        *(unsigned int*)(sg + tm * S::G_TERM + S::G_ROWS * S::GP * 2 + 4 * d) = 0u;
+    for (int i = tid; i < NBUF * 3 * (S::GP / 2); i += blockDim.x) {
+        const int buf = i / (3 * (S::GP / 2)), rest = i % (3 * (S::GP / 2));
+        const int tm = rest / (S::GP / 2), d = rest % (S::GP / 2);
+        *(unsigned int*)(smem + buf * S::STAGE_BYTES + tm * S::G_TERM + S::G_ROWS * S::GP * 2 + 4 * d) = 0u;
     }
-    for (int i = tid; i < 3 * 2 * 4; i += NTH) {
-        const int tm = i / 8, which = (i >> 2) & 1, d = i & 3;
-        *(unsigned int*)(sx + tm * S::X_TERM + (which ? S::X_ZERO : S::X_ONES) + 4 * d) = (which == 0 && tm == 0) ? 0x3f803f80u : 0u;
+    for (int i = tid; i < NBUF * 3 * 2 * 4; i += blockDim.x) {
+        const int buf = i / 24, rest = i % 24;
+        const int tm = rest / 8, which = (rest >> 2) & 1, d = rest & 3;
+        *(unsigned int*)(smem + buf * S::STAGE_BYTES + S::G_BYTES + tm * S::X_TERM + (which ? S::X_ZERO : S::X_ONES) + 4 * d) =
+            (which == 0 && tm == 0) ? 0x3f803f80u : 0u;
     }
 
     f32x16 acc0, acc1;
@@ -162,12 +169,12 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
     // ---- this wave's two rows of the staged band: 8 (k-step, row) steps, fragments of step s+1 read while step s multiplies;
     //      one accumulator per row (independent MFMA chains)
     struct Frag { bf16x8 a[3], b[3]; };
-    const unsigned char* const pa0 = sg + a_off + wave * a_rs;
-    const unsigned char* const pb0 = sx + b_off + wave * b_rs;
+    const unsigned char* pa0 = smem + a_off + wave * a_rs;
+    const unsigned char* pb0 = smem + S::G_BYTES + b_off + wave * b_rs;
     auto read_frag = [&](Frag& f, int step) {
-        const int ks = step >> 1, i = step & 1;
-        const unsigned char* pa = pa0 + i * (NWV * a_rs) + ks * a_kss;
-        const unsigned char* pb = pb0 + i * (NWV * b_rs) + ks * b_kss;
+        const int ks = step / RPW, i = step % RPW;
+        const unsigned char* pa = pa0 + i * (NCW * a_rs) + ks * a_kss;
+        const unsigned char* pb = pb0 + i * (NCW * b_rs) + ks * b_kss;
 #pragma unroll
         for (int tm = 0; tm < 3; ++tm) {
             f.a[tm] = *(const bf16x8*)(pa + tm * S::G_TERM);
@@ -185,8 +192,10 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[0], acc, 0, 0, 0);
     };
-    auto compute = [&]() {
-        constexpr int STEPS = 2 * (WC / 16);
+    auto compute = [&](int buf) {
+        constexpr int STEPS = RPW * (WC / 16);
+        pa0 = smem + buf * S::STAGE_BYTES + a_off + wave * a_rs;
+        pb0 = smem + buf * S::STAGE_BYTES + S::G_BYTES + b_off + wave * b_rs;
         Frag f0, f1;
         read_frag(f0, 0);
 #pragma unroll
@@ -198,18 +207,28 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
         }
     };
 
+    // accumulators of a multiplying wave -> LDS (after the last barrier of the tile loop: every buffer has been consumed)
+    auto write_red = [&]() {
+        float* red = (float*)smem;                       // [wave][m][33]
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = 4 * hh + (e & 3) + 8 * (e >> 2);
+            red[(wave * 32 + m) * 33 + r] = acc0[e] + acc1[e];
+        }
+    };
+
     if constexpr (VEC) {
         // W % 4 == 0 and 16-byte aligned tensors: every float4 of a staged row lies entirely inside or outside the image.  Each thread
         // owns NG + NX fixed items (8 columns of one staged row); the global loads of the NEXT tile are issued (unconditionally, from a
         // clamped address) before the MFMA phase of the current one and converted / written to LDS after it.
-        constexpr int NG = S::NG, NX = S::NX;
+        constexpr int NG = (S::G_ITEMS + NTS - 1) / NTS, NX = (S::X_ITEMS + NTS - 1) / NTS;
         int g_dr[NG], g_dc[NG], g_ch[NG], g_lds[NG];
         int x_dr[NX], x_dc[NX], x_ch[NX], x_lds[NX];
         bool g_valid[NG], x_valid[NX];
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int id = j * NTH + tid;
-            g_valid[j] = id < S::G_ITEMS;
+            const int id = j * NTS + tid;
+            g_valid[j] = tid < NTS && id < S::G_ITEMS;
             const int idc = g_valid[j] ? id : 0;
             const int c8 = idc % (WC / 8), rc = idc / (WC / 8);
             const int co = rc % COUT, jrow = rc / COUT;
@@ -218,8 +237,8 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
         }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int id = j * NTH + ((j & 1) ? NTH - 1 - tid : tid);      // odd rounds from the top: spreads the ragged last rounds over the waves
-            x_valid[j] = id < S::X_ITEMS;
+            const int id = j * NTS + (((j + NG) & 1) ? NTS - 1 - tid : tid);   // alternate rounds from the top: spreads the ragged rounds over the waves
+            x_valid[j] = tid < NTS && id >= 0 && id < S::X_ITEMS;
             const int idc = x_valid[j] ? id : 0;
             const int c8 = idc % (XC / 8), rc = idc / (XC / 8);
             const int ci = rc % CIN, row_l = rc / CIN;
@@ -259,7 +278,8 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
                 p.xm[j] = (ok0 ? 1 : 0) | (ok1 ? 2 : 0) | (ok2 ? 4 : 0);
             }
         };
-        auto commit = [&](const Pre& p) {
+        auto commit = [&](const Pre& p, int buf) {
+            unsigned char* const base = smem + buf * S::STAGE_BYTES;
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 if (!g_valid[j]) continue;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
                 float v[8];
                 v[0] = ok0 ? p.ga[j].x : 0.f; v[1] = ok0 ? p.ga[j].y : 0.f; v[2] = ok0 ? p.ga[j].z : 0.f; v[3] = ok0 ? p.ga[j].w : 0.f;
                 v[4] = ok1 ? p.gb[j].x : 0.f; v[5] = ok1 ? p.gb[j].y : 0.f; v[6] = ok1 ? p.gb[j].z : 0.f; v[7] = ok1 ? p.gb[j].w : 0.f;
-                sw_store_terms<0, 8>(smem + g_lds[j], S::G_TERM, v);
+                sw_store_terms<0, 8>(base + g_lds[j], S::G_TERM, v);
             }
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
@@ -277,28 +297,52 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
                 v[0] = ok0 ? p.xa[j].x : 0.f; v[1] = ok0 ? p.xa[j].y : 0.f; v[2] = ok0 ? p.xa[j].z : 0.f; v[3] = ok0 ? p.xa[j].w : 0.f;
                 v[4] = ok1 ? p.xb[j].x : 0.f; v[5] = ok1 ? p.xb[j].y : 0.f; v[6] = ok1 ? p.xb[j].z : 0.f; v[7] = ok1 ? p.xb[j].w : 0.f;
                 v[8] = ok2 ? p.xc[j] : 0.f;
-                unsigned char* dst = smem + x_lds[j];
+                unsigned char* dst = base + x_lds[j];
                 sw_store_terms<0, 9>(dst, S::X_TERM, v);
                 sw_store_terms<1, 9>(dst + S::X_COPY, S::X_TERM, v);
             }
         };
+        // The two kinds of waves run separate loops (wave-uniform branch on a scalar wave index: the register allocator sees the
+        // staging registers and the accumulators / fragments on different paths) with the same number of barriers.
         const int G = gridDim.x;
+        const bool stager = __builtin_amdgcn_readfirstlane(tid >> 6) < NTS / 64;
         int t = blockIdx.x;
-        Pre pa, pb;
-        if (t < ntiles) issue(pa, t);
-        if (t + G < ntiles) issue(pb, t + G);
-        for (; t < ntiles; t += 2 * G) {
-            if (!(dbg & 1)) commit(pa);
-            __syncthreads();
+        if (stager) {
+            Pre pa, pb;                                // tiles t, t+2G, .. in pa; t+G, t+3G, .. in pb
+            issue(pa, t);
+            if (t + G < ntiles) issue(pb, t + G);
+            commit(pa, 0);
             if (t + 2 * G < ntiles) issue(pa, t + 2 * G);
-            if (!(dbg & 2)) compute();
             __syncthreads();
-            if (t + G >= ntiles) break;
-            if (!(dbg & 1)) commit(pb);
+            for (;;) {
+                if (t + G < ntiles) {
+                    commit(pb, 1);
+                    if (t + 3 * G < ntiles) issue(pb, t + 3 * G);
+                }
+                __syncthreads();
+                t += G;
+                if (t >= ntiles) break;
+                if (t + G < ntiles) {
+                    commit(pa, 0);
+                    if (t + 3 * G < ntiles) issue(pa, t + 3 * G);
+                }
+                __syncthreads();
+                t += G;
+                if (t >= ntiles) break;
+            }
+        } else {
             __syncthreads();
-            if (t + 3 * G < ntiles) issue(pb, t + 3 * G);
-            if (!(dbg & 2)) compute();
-            __syncthreads();
+            for (;;) {
+                compute(0);
+                __syncthreads();
+                t += G;
+                if (t >= ntiles) break;
+                compute(1);
+                __syncthreads();
+                t += G;
+                if (t >= ntiles) break;
+            }
+            write_red();
         }
     } else {
         __syncthreads();
@@ -314,7 +358,7 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
                 const float* row = gy + ((size_t)n * COUT + co) * plane + (size_t)(row_ok ? ho : 0) * W;
                 float v[8];
                 sw_load_row<8>(row, row_ok, w0 + 8 * c8, W, v);
-                sw_store_terms<0, 8>(sg + ((jrow * COUT + co) * S::GP + 8 * c8) * 2, S::G_TERM, v);
+                sw_store_terms<0, 8>(smem + ((jrow * COUT + co) * S::GP + 8 * c8) * 2, S::G_TERM, v);
             }
             // ---- stage x rows h0 .. h0+RB-1, columns w0-HALO .. w0+WC+HALO-1, as is and shifted by one column
             for (int id = tid; id < S::X_ITEMS; id += NTH) {
@@ -325,25 +369,21 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
                 const float* row = x + ((size_t)n * CIN + ci) * plane + (size_t)(row_ok ? h : 0) * W;
                 float v[9];
                 sw_load_row<9>(row, row_ok, w0 - HALO + 8 * c8, W, v);
-                unsigned char* dst = sx + ((row_l * CIN + ci) * S::XP + 8 * c8) * 2;
+                unsigned char* dst = smem + S::G_BYTES + ((row_l * CIN + ci) * S::XP + 8 * c8) * 2;
                 sw_store_terms<0, 9>(dst, S::X_TERM, v);
                 sw_store_terms<1, 9>(dst + S::X_COPY, S::X_TERM, v);
             }
             __syncthreads();
-            compute();
+            compute(0);
             __syncthreads();
         }
+        write_red();
     }
 
     // ---- block partial: waves summed in fixed order
-    float* red = (float*)smem;                       // [wave][m][33]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int m = 4 * hh + (e & 3) + 8 * (e >> 2);
-        red[(wave * 32 + m) * 33 + r] = acc0[e] + acc1[e];
-    }
+    const float* red = (const float*)smem;
     __syncthreads();
-    for (int e = tid; e < S::NOUT; e += NTH) {
+    for (int e = tid; e < S::NOUT; e += blockDim.x) {
         int m, nn;
         if (e < S::NWT) {                            // e indexes [co][ci][kh][kw]
             const int co = e / (CIN * K * K), rem = e % (CIN * K * K);
@@ -356,29 +396,42 @@ __global__ __launch_bounds__(NTH) void smallconv_wgrad_mfma_kernel(const float* 
         }
         float s = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < NWV; ++wv) s += red[(wv * 32 + m) * 33 + nn];
+        for (int wv = 0; wv < NCW; ++wv) s += red[(wv * 32 + m) * 33 + nn];
         partial[(int64_t)blockIdx.x * S::NOUT + e] = s;
     }
 }
 
 template <int CIN, int COUT, int K>
-void sw_launch_k(bool vec, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
-    static const int dbg = getenv("EAS_SW_DBG") ? atoi(getenv("EAS_SW_DBG")) : 0;   // development: 1 skips the LDS staging stores, 2 the MFMA phase (timing only)
-    if (vec) hipLaunchKernelGGL((smallconv_wgrad_mfma_kernel<CIN, COUT, K, true>), dim3(nblocks), dim3(NTH), 0, st, gy, x, partial, N, H, W, dbg);
-    else hipLaunchKernelGGL((smallconv_wgrad_mfma_kernel<CIN, COUT, K, false>), dim3(nblocks), dim3(NTH), 0, st, gy, x, partial, N, H, W, dbg);
+int sw_launch_k(bool vec, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
+    using S = Sw<CIN, COUT, K>;
+    if (vec) {
+        auto kern = smallconv_wgrad_mfma_kernel<CIN, COUT, K, true>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(4 * NTH), 2 * S::STAGE_BYTES, st, gy, x, partial, N, H, W);
+    } else {
+        hipLaunchKernelGGL((smallconv_wgrad_mfma_kernel<CIN, COUT, K, false>), dim3(nblocks), dim3(NTH), S::LDS_BYTES, st, gy, x, partial, N, H, W);
+    }
+    return EAS_OK;
 }
 
 template <int CIN, int COUT>
 int sw_launch(int k, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
     const bool vec = (W & 3) == 0 && ((((uintptr_t)gy) | ((uintptr_t)x)) & 15) == 0;   // float4 staging loads with register prefetch
+    int rc;
+    if (vec && nblocks > 256) nblocks = 256;             // 8-wave blocks with two LDS buffers: one per CU
     switch (k) {
-        case 3: sw_launch_k<CIN, COUT, 3>(vec, gy, x, partial, nblocks, N, H, W, st); break;
-        case 5: sw_launch_k<CIN, COUT, 5>(vec, gy, x, partial, nblocks, N, H, W, st); break;
-        case 7: sw_launch_k<CIN, COUT, 7>(vec, gy, x, partial, nblocks, N, H, W, st); break;
+        case 3: rc = sw_launch_k<CIN, COUT, 3>(vec, gy, x, partial, nblocks, N, H, W, st); break;
+        case 5: rc = sw_launch_k<CIN, COUT, 5>(vec, gy, x, partial, nblocks, N, H, W, st); break;
+        case 7: rc = sw_launch_k<CIN, COUT, 7>(vec, gy, x, partial, nblocks, N, H, W, st); break;
         default: return EAS_ERR_UNSUPPORTED;
     }
+    if (rc != EAS_OK) return rc;
     EAS_CHECK_LAUNCH();
-    return EAS_OK;
+    return nblocks;
 }
 
 }  // namespace
@@ -395,5 +448,5 @@ int eas_sw_mfma_partials(const float* gy, const float* x, float* partial, int ma
     else if (Cin == 4 && Cout == 4) rc = sw_launch<4, 4>(k, gy, x, partial, nblocks, N, H, W, st);
     else if (Cin == 2 && Cout == 2) rc = sw_launch<2, 2>(k, gy, x, partial, nblocks, N, H, W, st);
     else return EAS_ERR_UNSUPPORTED;
-    return rc == EAS_OK ? nblocks : rc;
+    return rc;
 }
