@@ -6,7 +6,7 @@
 // Two to four channels cannot fill an MFMA tile by themselves, but (channel, kernel row) x (channel, kernel column) can: for one
 // row h of x and 16 consecutive columns w (the reduction index),
 //
-//   A[m = co*K + kh][w] = gy[co][h - kh + P][w]         (<= 28 rows of 32)
+//   A[m = kh*COUT + co][w] = gy[co][h - kh + P][w]      (<= 28 rows of 32)
 //   B[w][n = ci*K + kw] = x[ci][h][w + kw - P]          (<= 28 columns of 32; column CIN*K holds ones -> row sums = db)
 //   D[m][n] += A * B                                    = dW[co][ci][kh][kw]
 //
@@ -41,16 +41,16 @@ struct Sw {
     static constexpr int PAD = K / 2;
     static constexpr int GR = RB + K - 1;                  // staged grad_y rows
     static constexpr int GP = WC + 8;                      // grad_y row pitch (elements): 144 bytes
-    static constexpr int G_ROWS = GR * COUT;               // + one constant row of zeros (unused A rows of the 32x32 tile)
-    static constexpr int G_TERM = (G_ROWS + 1) * GP * 2;   // bytes per term
-    // x rows: one per (row, channel), pitch 48 dwords -> the channels of a row start on banks 0 / 48 / 32 / 16; the odd copy starts 8
-    // banks after the even one: the dword reads of the <= 28 B columns (4 channels x {even, odd} x 2 k-halves) hit distinct banks
-    static constexpr int XP = 96;                          // x row pitch (elements): 192 bytes
-    static constexpr int X_ROWS = RB * CIN;                // + two constant rows: ones (bias column), zeros (unused B columns)
-    static constexpr int X_RAW = (X_ROWS + 2) * XP * 2;
-    static constexpr int X_COPY = X_RAW + ((8 + 64 - (X_RAW / 4) % 64) % 64) * 4;   // bytes per (term, copy)
-    static constexpr int X_ONES = X_ROWS * XP * 2 + 4;     // constant rows inside the even copy: banks 1.. and 2.. (free of data columns)
-    static constexpr int X_ZERO = X_ROWS * XP * 2 + 66 * 4;
+    static constexpr int G_ROWS = GR * COUT;
+    static constexpr int G_TERM = G_ROWS * GP * 2;         // bytes per term
+    // x rows: one per (row, channel), pitch 40 dwords; the odd copy starts 4 banks after the even one.  ds_read_b32 / ds_read2_b32
+    // bank 32 lanes over 32 banks: channel c's <= 5 distinct dwords sit on banks 3..8 + 8c (+4 for the second k-half, which is the
+    // other lane group), the bias column's constant row on bank 2: conflict-free for k <= 5 (k = 7 with 4 channels: 2-way on half)
+    static constexpr int XP = XC;                          // x row pitch (elements): 160 bytes
+    static constexpr int X_ROWS = RB * CIN;                // + one constant row: ones (bias column)
+    static constexpr int X_RAW = (X_ROWS + 1) * XP * 2;
+    static constexpr int X_COPY = X_RAW + ((4 + 32 - (X_RAW / 4) % 32) % 32) * 4;   // bytes per (term, copy)
+    static constexpr int X_ONES = X_ROWS * XP * 2 + 8;     // constant row inside the even copy, from bank 2
     static constexpr int X_TERM = 2 * X_COPY;
     static constexpr int G_BYTES = 3 * G_TERM;
     static constexpr int X_BYTES = 3 * X_TERM;
@@ -62,7 +62,7 @@ struct Sw {
     static constexpr int G_ITEMS = GR * COUT * (WC / 8);
     static constexpr int X_ITEMS = RB * CIN * (XC / 8);
     static_assert(COUT * K <= 32 && CIN * K + 1 <= 32, "does not fit one 32x32 tile");
-    static_assert(PAD + 1 <= HALO && XC <= XP && (X_COPY / 4) % 64 == 8, "x staging geometry");
+    static_assert(PAD + 1 <= HALO && XC <= XP && (X_COPY / 4) % 32 == 4 && X_COPY % 16 == 0, "x staging geometry");
     static_assert(2 * STAGE_BYTES <= 160 * 1024 && STAGE_BYTES % 16 == 0, "LDS");
     static_assert(RB == 2 * NWV, "two rows per wave (4 waves) / one row per wave (8 waves)");
 };
@@ -120,31 +120,27 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
     const int wave = VEC ? (tid >> 6) - NTS / 64 : (tid >> 6);                  // index among the multiplying waves (< 0: staging wave)
     const int r = lane & 31, hh = lane >> 5;
 
-    // this lane's A row (co, kh) and B column (ci, kw).  Lanes outside the (co,kh) x (ci,kw) ranges read constant LDS rows (zeros;
-    // ones for the bias column) with zero strides: the compute phase has no branches and no selects.
-    const bool a_ok = r < COUT * K;
-    const int a_co = a_ok ? r / K : 0, a_kh = a_ok ? r % K : 0;
-    const int a_off = a_ok ? (((2 * PAD - a_kh) * COUT + a_co) * S::GP + 8 * hh) * 2 : S::G_ROWS * S::GP * 2;
-    const int a_rs = a_ok ? COUT * S::GP * 2 : 0, a_kss = a_ok ? 32 : 0;         // + row*a_rs + ks*a_kss + term*G_TERM
-    const int b_kind = r < CIN * K ? 1 : (r == CIN * K ? 2 : 0);                 // 1 data, 2 ones (bias column), 0 unused
-    const int b_ci = b_kind == 1 ? r / K : 0, b_kw = b_kind == 1 ? r % K : PAD;
+    // this lane's A row m = kh*COUT + co and B column n = ci*K + kw.  Rows / columns of the 32x32 tile past those ranges are never read
+    // back, so their lanes repeat the address of a used lane of the same LDS lane group (a broadcast, no extra bank cycle); the bias
+    // column reads a constant row of ones.  The kernel-row-major order of m puts the <= 16 rows one ds_read_b128 lane group touches
+    // on distinct 16-byte bank groups (row pitch 9 x 16 bytes): no branches, no selects and no bank conflicts in the compute phase.
+    const bool g0 = (r & 3) == r || (r >= 12 && r < 16) || (r >= 20 && r < 28);   // ds_read_b128 lane groups {0-3,12-15,20-27} / the rest
+    const int ra = r < COUT * K ? r : (g0 ? 0 : 4);
+    const int a_kh = ra / COUT, a_co = ra % COUT;
+    const int a_off = (((2 * PAD - a_kh) * COUT + a_co) * S::GP + 8 * hh) * 2;
+    const int a_rs = COUT * S::GP * 2, a_kss = 32;                               // + row*a_rs + ks*a_kss + term*G_TERM
+    const bool b_ones = r == CIN * K;                                            // bias column
+    const int rb = r < CIN * K ? r : 0;
+    const int b_ci = rb / K, b_kw = rb % K;
     const int sft = b_kw - PAD;                                                   // column shift of this lane's fragment
     const int odd = sft & 1;
-    const int b_off = b_kind == 1 ? odd * S::X_COPY + (b_ci * S::XP + HALO + 8 * hh + (sft - odd)) * 2
-                                  : (b_kind == 2 ? S::X_ONES : S::X_ZERO);
-    const int b_rs = b_kind == 1 ? CIN * S::XP * 2 : 0, b_kss = b_kind == 1 ? 32 : 0;   // + row*b_rs + ks*b_kss + term*X_TERM
+    const int b_off = b_ones ? S::X_ONES : odd * S::X_COPY + (b_ci * S::XP + HALO + 8 * hh + (sft - odd)) * 2;
+    const int b_rs = b_ones ? 0 : CIN * S::XP * 2, b_kss = b_ones ? 0 : 32;       // + row*b_rs + ks*b_kss + term*X_TERM
 
-    // constant rows (never overwritten by the staging)
-    for (int i = tid; i < NBUF * 3 * (S::GP / 2); i += blockDim.x) {
-        const int buf = i / (3 * (S::GP / 2)), rest = i % (3 * (S::GP / 2));
-        const int tm = rest / (S::GP / 2), d = rest % (S::GP / 2);
-        *(unsigned int*)(smem + buf * S::STAGE_BYTES + tm * S::G_TERM + S::G_ROWS * S::GP * 2 + 4 * d) = 0u;
-    }
-    for (int i = tid; i < NBUF * 3 * 2 * 4; i += blockDim.x) {
-        const int buf = i / 24, rest = i % 24;
-        const int tm = rest / 8, which = (rest >> 2) & 1, d = rest & 3;
-        *(unsigned int*)(smem + buf * S::STAGE_BYTES + S::G_BYTES + tm * S::X_TERM + (which ? S::X_ZERO : S::X_ONES) + 4 * d) =
-            (which == 0 && tm == 0) ? 0x3f803f80u : 0u;
+    // constant row of ones (first term; zeros in the other two), never overwritten by the staging
+    for (int i = tid; i < NBUF * 3 * 4; i += blockDim.x) {
+        const int buf = i / 12, tm = (i % 12) / 4, d = i & 3;
+        *(unsigned int*)(smem + buf * S::STAGE_BYTES + S::G_BYTES + tm * S::X_TERM + S::X_ONES + 4 * d) = tm == 0 ? 0x3f803f80u : 0u;
     }
 
     f32x16 acc0, acc1;
@@ -388,10 +384,10 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
         if (e < S::NWT) {                            // e indexes [co][ci][kh][kw]
             const int co = e / (CIN * K * K), rem = e % (CIN * K * K);
             const int ci = rem / (K * K), kk = rem % (K * K);
-            m = co * K + kk / K;
+            m = (kk / K) * COUT + co;
             nn = ci * K + kk % K;
         } else {
-            m = (e - S::NWT) * K + PAD;
+            m = PAD * COUT + (e - S::NWT);
             nn = CIN * K;
         }
         float s = 0.f;
