@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage (on the GPU box): pmc_kernel.sh <kernel regex> <tag> [script] -- SQ counters of one kernel family under scripts/bench_kernels.py
-# (or another driver script, path relative to the repo root)
-RX=${1:-smallconv}; TAG=${2:-pmc_k}; SCRIPT=${3:-scripts/bench_kernels.py}
+# usage (on the GPU box): pmc_kernel.sh <kernel regex> <tag> ["script args.."] -- SQ counters of one kernel family under one eager
+# bench.py step (or another driver script with its arguments, path relative to the repo root)
+export EAS_BENCH_GRAPH=0
+RX=${1:-smallconv}; TAG=${2:-pmc_k}; SCRIPT=${3:-bench.py --steps 1 --warmup 1 --no-cpu-baseline}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
