@@ -365,7 +365,7 @@ int launch_wgrad_k(int k, const float* gy, const float* x, float* partial, int n
 bool bad_ptr(const void* p) { return ((uintptr_t)p & 15) != 0; }
 
 // Which weight-gradient kernel eas_smallconv_bwd_weight launches: the matrix-core form for k >= 5 (measured on MI355X, 256 images of
-// 256x320: 4->4 k5 345 us against 580 us, k7 91 against 417 us), the vector-ALU form for k = 3 (95 against 145 us).
+// 256x320: 4->4 k5 324 us against 580 us, k7 79 against 417 us), the vector-ALU form for k = 3 (95 against 165 us).
 // EAS_SW_FORM=fma|mfma (development switch) forces one; read per call, so a test can compare the two forms in one process.
 bool wgrad_on_mfma(int k) {
     const char* e = getenv("EAS_SW_FORM");
