@@ -905,8 +905,15 @@ CONV_POLICY = {'fwd3': 'mfma', 'fwd1': 'mfma', 'dgrad3': 'mfma', 'dgrad1': 'mfma
                # 3x3 weight gradient of layers whose output rows are wider than the 80-pixel reduction tile (stem and dark2.0 at
                # 128x160, eas_conv_wgrad_parts > 1): eas_conv_wgrad handles them in column parts, but measured 0.92 ms against MIOpen's 0.49 ms for the two
                # layers of the step (Cin = 8 fills a quarter of the MFMA tile; LDS limits dark2.0 to 28-pixel parts), so the
-               # library keeps them unless this is set to 'mfma'
+               # library keeps them unless this is set to 'mfma'.  MIOpen's kernel for them splits the reduction with float atomics:
+               # these two gradients are the only values of the training step that are not bit-reproducible from run to run
+               # (tests/test_gpu_model.py::test_train_step_is_bit_reproducible), so torch.use_deterministic_algorithms(True)
+               # also routes them to eas_conv_wgrad (fixed-order slab reduction; +0.4 ms per step).
                'wgrad3_wide': 'aten'}
+
+
+def _wide_wgrad_on_mfma():
+    return CONV_POLICY['wgrad3_wide'] == 'mfma' or torch.are_deterministic_algorithms_enabled()
 
 
 VERIFY_SMALL_INT = False     # tests switch this on: every tagged tensor is checked (host sync) before it is used
@@ -980,7 +987,7 @@ class _ConvFn(torch.autograd.Function):
         own_d = (ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
                  and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3], k, 1, 3))
         own_w = ctx.needs_input_grad[1] and CONV_POLICY['wgrad%d' % k] == 'mfma' and (
-            k == 1 or CONV_POLICY['wgrad3_wide'] == 'mfma' or _wgrad_single_part(x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stride, x_terms)) and _lib.lib().eas_conv_wgrad_workspace_floats(
+            k == 1 or _wide_wgrad_on_mfma() or _wgrad_single_part(x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stride, x_terms)) and _lib.lib().eas_conv_wgrad_workspace_floats(
             x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
         own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and CONV_POLICY['dgrad3'] == 'mfma' and w.shape[0] % 8 == 0
