@@ -163,8 +163,8 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
         w0 = (rest - band * chunks) * WC;
     };
 
-    // ---- this wave's two rows of the staged band: 8 (k-step, row) steps, fragments of step s+1 read while step s multiplies;
-    //      one accumulator per row (independent MFMA chains)
+    // ---- this wave's RPW rows of the staged band: RPW * 4 (k-step, row) steps, the fragments of step s+1 read while step s
+    //      multiplies; two accumulators used in turn (independent MFMA chains)
     struct Frag { bf16x8 a[3], b[3]; };
     const unsigned char* pa0 = smem + a_off + wave * a_rs;
     const unsigned char* pb0 = smem + S::G_BYTES + b_off + wave * b_rs;
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
 
     if constexpr (VEC) {
         // W % 4 == 0 and 16-byte aligned tensors: every float4 of a staged row lies entirely inside or outside the image.  Each thread
-        // owns NG + NX fixed items (8 columns of one staged row); the global loads of the NEXT tile are issued (unconditionally, from a
-        // clamped address) before the MFMA phase of the current one and converted / written to LDS after it.
+        // of the staging waves owns NG + NX fixed items (8 columns of one staged row); its global loads are issued unconditionally (from
+        // a clamped address, masked when they are converted) two tiles before the tile is written to LDS.
         constexpr int NG = (S::G_ITEMS + NTS - 1) / NTS, NX = (S::X_ITEMS + NTS - 1) / NTS;
         int g_dr[NG], g_dc[NG], g_ch[NG], g_lds[NG];
         int x_dr[NX], x_dc[NX], x_ch[NX], x_lds[NX];
