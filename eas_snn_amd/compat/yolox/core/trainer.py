@@ -2,6 +2,7 @@
 model -> device, optimizer, DDP(broadcast_buffers=False) over RCCL, EMA, per-iteration
 forward / backward / step / reset_net, LR schedule, 'latest' checkpoint.  Evaluation, TensorBoard/W&B
 logging and dataset prefetching are out of scope (synthetic loader yields GPU tensors)."""
+import contextlib
 import os
 import time
 
@@ -50,8 +51,6 @@ class Trainer:
             self.ema_model = ModelEMA(model, 0.9998)
             self.ema_model.updates = self.max_iter * self.start_epoch
         self.model = model
-        # every iteration ends with reset_net, so the final membrane potentials never need to reach HBM
-        ops.set_state_writeback(False)
 
     def resume_train(self, model):
         ckpt_file = getattr(self.args, 'ckpt', None)
@@ -67,6 +66,11 @@ class Trainer:
 
     def train(self):
         self.before_train()
+        # every iteration ends with reset_net, so the final membrane potentials never need to reach HBM (scoped: restored on exit)
+        with ops.no_state_writeback() if self.exp.use_spike else contextlib.nullcontext():
+            self._train_epochs()
+
+    def _train_epochs(self):
         for self.epoch in range(self.start_epoch, self.max_epoch):
             (self.model.module if is_parallel(self.model) else self.model).head.use_l1 = True   # no_aug from epoch 0
             for self.iter, (inps, targets) in enumerate(self.train_loader):

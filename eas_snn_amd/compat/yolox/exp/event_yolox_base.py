@@ -115,9 +115,10 @@ class EventExp(BaseExp):
             return self.optimizer
         lr = self.warmup_lr if self.warmup_epochs > 0 else self.basic_lr_per_img * batch_size
         bn_w, conv_w, biases, neuron_p = [], [], [], []
+        adam = self.optimizer == 'ADAM'
         for k, v in self.model.named_modules():
-            if 'embedding' in k:
-                continue
+            if adam and 'embedding' in k:       # own group below; the SGD branch of the reference (:361-377) keeps the
+                continue                        # sampler's convolutions in the weight / bias groups and has no neuron group
             if hasattr(v, 'bias') and isinstance(v.bias, nn.Parameter):
                 biases.append(v.bias)
             if isinstance(v, nn.BatchNorm2d) or 'bn' in k:
@@ -127,7 +128,7 @@ class EventExp(BaseExp):
             if is_spiking_neuron(v):
                 neuron_p.extend(p for _, p in v.named_parameters())
         emb_p = [p for _, p in self.model.embedding.named_parameters() if p.requires_grad]
-        if self.optimizer == 'ADAM':
+        if adam:
             # same update rule as the reference's torch.optim.Adam; on the GPU the single-kernel-per-group implementation
             # (40 small foreach kernels per step become 5)
             on_gpu = all(p.is_cuda for p in bn_w + conv_w + biases + neuron_p + emb_p)
@@ -136,7 +137,7 @@ class EventExp(BaseExp):
             opt = torch.optim.SGD(bn_w, lr=lr, momentum=self.momentum, nesterov=True)
         opt.add_param_group({'params': conv_w, 'weight_decay': self.weight_decay})
         opt.add_param_group({'params': biases})
-        if self.optimizer == 'ADAM':
+        if adam:
             opt.add_param_group({'params': neuron_p})
             opt.add_param_group({'params': emb_p, 'lr': lr if self.emb_lr < 0 else self.emb_lr})
         self.optimizer = opt

@@ -1,5 +1,7 @@
 """Model wrappers: sampler -> (T-broadcast) -> backbone -> head (reference: yolox/models/yolox.py:10-60,
 spiking_yolox.py:16-76)."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -35,6 +37,11 @@ def _head_outputs(model, fpn_outs, targets, x):
             'num_fg': num_fg}
 
 
+def _scope(model, x):
+    """all convolution weights packed for the matrix-core kernels by one launch, valid for this forward only"""
+    return ops.packed_weights(model) if x.is_cuda else contextlib.nullcontext()
+
+
 class YOLOX(nn.Module):
     def __init__(self, backbone=None, head=None, embedding=None):
         super().__init__()
@@ -43,9 +50,7 @@ class YOLOX(nn.Module):
         self.head = YOLOXHead(80) if head is None else head
 
     def forward(self, x, targets=None):
-        if x.is_cuda:
-            ops.prepack_conv_weights(self)        # one launch for all conv weights (no-op while they are unchanged)
-        with ops.deferred_counters():
+        with _scope(self, x), ops.deferred_counters():
             x = _run_embedding(self.embedding, x, 4)
             return _head_outputs(self, self.backbone(x), targets, x)
 
@@ -59,9 +64,7 @@ class SpikingYOLOX(nn.Module):
         self.head = SpikingYOLOXHead(80) if head is None else head
 
     def forward(self, x, targets=None):
-        if x.is_cuda:
-            ops.prepack_conv_weights(self)        # one launch for all conv weights (no-op while they are unchanged)
-        with ops.deferred_counters():
+        with _scope(self, x), ops.deferred_counters():
             return self._forward(x, targets)
 
     def _forward(self, x, targets=None):

@@ -1,6 +1,4 @@
-"""Box utilities used by the head and the evaluators (reference: yolox/utils/boxes.py:33-104)."""
-import torch
-
+"""Box utilities used by the head and the evaluators (reference: yolox/utils/boxes.py:33-77; pairwise IoU lives in the SimOTA kernel, csrc/simota.hip)."""
 from eas_snn_amd import ops
 
 
@@ -8,21 +6,3 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
     """reference: yolox/utils/boxes.py:33-77 (torchvision NMS inside) -> one HIP call for the whole batch.  Unlike the reference
     the ``prediction`` tensor is left untouched (the reference rewrites its first four columns to corners in place)."""
     return ops.postprocess(prediction, num_classes, conf_thre, nms_thre, class_agnostic)
-
-
-def bboxes_iou(bboxes_a, bboxes_b, xyxy=True):
-    if bboxes_a.shape[1] != 4 or bboxes_b.shape[1] != 4:
-        raise IndexError
-    if xyxy:
-        tl = torch.max(bboxes_a[:, None, :2], bboxes_b[:, :2])
-        br = torch.min(bboxes_a[:, None, 2:], bboxes_b[:, 2:])
-        area_a = torch.prod(bboxes_a[:, 2:] - bboxes_a[:, :2], 1)
-        area_b = torch.prod(bboxes_b[:, 2:] - bboxes_b[:, :2], 1)
-    else:
-        tl = torch.max(bboxes_a[:, None, :2] - bboxes_a[:, None, 2:] / 2, bboxes_b[:, :2] - bboxes_b[:, 2:] / 2)
-        br = torch.min(bboxes_a[:, None, :2] + bboxes_a[:, None, 2:] / 2, bboxes_b[:, :2] + bboxes_b[:, 2:] / 2)
-        area_a = torch.prod(bboxes_a[:, 2:], 1)
-        area_b = torch.prod(bboxes_b[:, 2:], 1)
-    en = (tl < br).type(tl.type()).prod(dim=2)
-    area_i = torch.prod(br - tl, 2) * en
-    return area_i / (area_a[:, None] + area_b - area_i)

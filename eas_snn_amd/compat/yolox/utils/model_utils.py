@@ -9,15 +9,17 @@ def get_model_info(model: nn.Module, tsize=None) -> str:
 
 
 def fuse_conv_and_bn(conv, bn):
+    """conv followed by eval-mode BatchNorm as one biased convolution: every output channel is scaled by
+    gamma / sqrt(var + eps) and shifted (reference: yolox/utils/model_utils.py fuse_conv_and_bn)."""
     import torch
-    fused = nn.Conv2d(conv.in_channels, conv.out_channels, kernel_size=conv.kernel_size, stride=conv.stride,
-                      padding=conv.padding, groups=conv.groups, bias=True).requires_grad_(False).to(conv.weight.device)
-    w_bn = torch.diag(bn.weight.div(torch.sqrt(bn.eps + bn.running_var)))
-    fused.weight.copy_(torch.mm(w_bn, conv.weight.clone().view(conv.out_channels, -1)).view(fused.weight.shape))
-    b_conv = torch.zeros(conv.weight.size(0), device=conv.weight.device) if conv.bias is None else conv.bias
-    b_bn = bn.bias - bn.weight.mul(bn.running_mean).div(torch.sqrt(bn.running_var + bn.eps))
-    fused.bias.copy_(torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn)
-    return fused
+    with torch.no_grad():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        bias = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, groups=conv.groups,
+                        bias=True).to(conv.weight.device)
+        out.weight.copy_(conv.weight * scale.view(-1, 1, 1, 1))
+        out.bias.copy_((bias - bn.running_mean) * scale + bn.bias)
+    return out.requires_grad_(False)
 
 
 def fuse_model(model: nn.Module) -> nn.Module:

@@ -32,6 +32,21 @@ def state_writeback():
     return _STATE_WRITEBACK
 
 
+class no_state_writeback:
+    """``with ops.no_state_writeback():`` around a loop whose every iteration ends with ``reset_net`` (the reference's
+    train / eval loops): the final membrane potentials are not written to HBM.  The previous setting is restored on exit,
+    so stateful use (streaming inference, ``node.v`` inspection) elsewhere in the process is unaffected."""
+
+    def __enter__(self):
+        global _STATE_WRITEBACK
+        self.prev, _STATE_WRITEBACK = _STATE_WRITEBACK, False
+        return self
+
+    def __exit__(self, *exc):
+        global _STATE_WRITEBACK
+        _STATE_WRITEBACK = self.prev
+
+
 class KernelTimer:
     """Per-call HIP-event timing of the C-ABI entry points (bench.py roofline accounting).  Events are recorded on
     the stream the kernels are launched on (torch's current stream)."""
@@ -724,7 +739,10 @@ class _ARSNNFn(torch.autograd.Function):
             out = torch.relu(out)
         ctx.cfg = cfg
         ctx.dims = (Tm, N, Cin, C2, H, W)
-        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu, agg, gate_in)
+        # ``agg`` is this node's own output unless ``running``: keeping it on ctx would tie output -> grad_fn -> ctx -> output
+        # into a reference cycle (Ts*N*C2*H*W floats held until the cyclic GC runs); the backward reads it in running mode only
+        # (as a valid dummy pointer).  ``pre_relu`` likewise is ``out`` before the ReLU, a distinct tensor.
+        ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu, agg if running else None, gate_in)
         ctx.params = params
         ctx.ev_needs_grad = ctx.needs_input_grad[0]
         rec = torch.stack(t_rec) if record else None
@@ -963,7 +981,7 @@ def conv_fwd_supported(NI, Cin, Cout, Hi, Wi, k, stride, x_terms):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, x_terms, packs):
-        """packs: {mode: packed weights} valid for the current version of ``w`` (prepack_conv_weights), or None."""
+        """packs: {mode: packed weights} made from the current values of ``w`` (packed_weights scope), or None."""
         _dev(x, w, bias)
         k, Cout = w.shape[-1], w.shape[0]
         if conv_fwd_supported(x.shape[0], x.shape[1], Cout, x.shape[2], x.shape[3], k, stride, x_terms):
@@ -973,14 +991,14 @@ class _ConvFn(torch.autograd.Function):
             y = torch.ops.aten.convolution(x, w, bias, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1)
         ctx.save_for_backward(x, w)
         ctx.cfg = (k, stride, x_terms, bias is not None)
-        ctx.packs = packs if packs and getattr(w, '_version', None) == packs.get('version') else None
+        ctx.packs = packs        # valid for the backward of this forward (same weights; autograd forbids changing them in between)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         k, stride, x_terms, has_bias = ctx.cfg
-        packs = ctx.packs if ctx.packs and w._version == ctx.packs.get('version') else None
+        packs = ctx.packs
         gy = _f32c(gy)
         gx = gw = gb = None
         Cin = w.shape[1]
@@ -1028,21 +1046,28 @@ def _static_conv_ok(conv):
             and conv.in_channels % 8 == 0 and not (k == 1 and conv.stride != (1, 1)))
 
 
+_PACK_SCOPE = None       # the pack dictionaries' generation that is valid right now (inside ``packed_weights``), else None
+_PACK_GEN = 0
+
+
 def prepack_conv_weights(model):
     """Pack the weights of every eligible nn.Conv2d of ``model`` for the matrix-core kernels in ONE launch
-    (eas_conv_pack_weights_many): forward order, plus the transposed orders the input gradients need.  Cheap to call at
-    the start of every forward: it returns at once while no weight has changed since the last packing (tensor version
-    counters), and repacks everything after an optimizer step.  Convolutions then find their packed weights in
-    ``conv._eas_packs`` instead of launching one tiny packing kernel each (111 launches per training step)."""
+    (eas_conv_pack_weights_many): forward order, plus the transposed orders the input gradients need.  Returns the
+    generation number of the packing.
+
+    Called at the start of EVERY forward (``packed_weights``): there is no cheap, reliable way to learn that a weight has
+    changed -- ``torch.optim.Adam(fused=True)`` (event_yolox_base.py get_optimizer) and ``p.data`` writes change the values
+    without touching ``Tensor._version`` -- so nothing is cached across forwards.  One launch over all weights (~150 MB of
+    traffic for SYOLOX-S, < 0.1 ms) instead of 111 tiny packing kernels; inside a captured HIP graph the launch is part of the
+    graph, so every replay packs the weights the optimizer has just written."""
+    global _PACK_GEN
     plan = getattr(model, '_eas_pack_plan', None)
     convs = plan['convs'] if plan else [m for m in model.modules() if _static_conv_ok(m) and m.weight.is_cuda]
     if not convs:
-        return
-    sig = tuple((c.weight.data_ptr(), c.weight._version) for c in convs)
-    if plan and plan['sig'] == sig:
-        return
+        return None
     L = _lib.lib()
-    if not plan or plan['ptrs'] != tuple(p for p, _ in sig):
+    ptrs = tuple(c.weight.data_ptr() for c in convs)
+    if not plan or plan['ptrs'] != ptrs:
         jobs, packs = [], []
         dev = convs[0].weight.device
         for c in convs:
@@ -1053,14 +1078,34 @@ def prepack_conv_weights(model):
                 d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)
                 jobs.append([c.weight.data_ptr(), d[m].data_ptr(), Cout, Cin, k, m])
             packs.append(d)
-        plan = {'convs': convs, 'packs': packs, 'ptrs': tuple(p for p, _ in sig), 'njobs': len(jobs),
+        plan = {'convs': convs, 'packs': packs, 'ptrs': ptrs, 'njobs': len(jobs),
                 'jobs': torch.tensor(jobs, dtype=torch.int64).to(dev)}
         object.__setattr__(model, '_eas_pack_plan', plan)
     check(L.eas_conv_pack_weights_many(ptr(plan['jobs']), plan['njobs'], stream()), 'eas_conv_pack_weights_many')
-    plan['sig'] = sig
+    _PACK_GEN += 1
     for c, d in zip(convs, plan['packs']):
-        d['version'] = c.weight._version
+        d['gen'] = _PACK_GEN
         object.__setattr__(c, '_eas_packs', d)
+    return _PACK_GEN
+
+
+class packed_weights:
+    """``with ops.packed_weights(model):`` around a model forward: packs all convolution weights once (see
+    prepack_conv_weights) and makes exactly that packing visible to ``conv2d`` for the duration of the block.  Outside the
+    block (a sub-module called on its own, a later call after the weights changed) ``conv2d`` packs the weight it is given,
+    so a stale packing can never be used."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        global _PACK_SCOPE
+        self.prev = _PACK_SCOPE
+        _PACK_SCOPE = prepack_conv_weights(self.model)
+
+    def __exit__(self, *exc):
+        global _PACK_SCOPE
+        _PACK_SCOPE = self.prev
 
 
 # Statistics tap (eas_snn_amd/stats.py): when set, every convolution input of the model is shown to it before the
@@ -1107,8 +1152,8 @@ def conv2d(x, conv, small_int=None):
     if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
         raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
     packs = getattr(conv, '_eas_packs', None)
-    if packs is not None and packs.get('version') != conv.weight._version:
-        packs = None
+    if packs is not None and (_PACK_SCOPE is None or packs.get('gen') != _PACK_SCOPE):
+        packs = None            # not inside the forward that made this packing: pack the weight as it is now
     return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs)
 
 

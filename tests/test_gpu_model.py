@@ -221,6 +221,69 @@ def test_train_step_is_bit_reproducible(dev, monkeypatch, name, wide):
     assert set(diff) <= allowed, f'run-to-run gradient differences in {diff}'
 
 
+def test_forward_after_fused_adam_step_uses_updated_weights(dev):
+    """The packed MFMA weights must follow the optimizer: ``torch.optim.Adam(fused=True)`` (what EventExp.get_optimizer builds on
+    the GPU) rewrites parameters without touching ``Tensor._version``.  Forward -> backward -> fused Adam steps -> forward again
+    must equal (a) the same forward with every convolution packing its weight on the spot, bit for bit, and (b) the torch-CPU
+    oracle model holding the updated state, and must differ from the logits before the update."""
+    from eas_snn_amd import ops
+    from oracle import fill, model_ref, sj_ref
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    from eas_snn_amd import data
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(BASE_OPTS + ['use_spike', 'True'])
+    exp.optimizer = 'ADAM'
+    hip = exp.get_model()
+    fill.procedural_fill_(hip, 2.0, ann_regex=fill.ANN_KEYS['True'])
+    hip.to(dev)
+    opt = exp.get_optimizer(2)
+    assert all(gr.get('fused') for gr in opt.param_groups), 'the GPU optimizer of the exp is the fused Adam'
+    for gr in opt.param_groups:
+        gr['lr'] = 3e-3                      # large enough that every weight visibly moves
+    x = torch.from_numpy(fill.poisson_events((2, 1, 4, 2, 64, 96), 0.5, seed=11)).to(dev)
+    tg = data.synth_targets(2, (64, 96), dev)
+    hip.eval()
+    with torch.no_grad():
+        before = hip(x).clone()
+    functional.reset_net(hip)
+    hip.train()
+    hip.head.use_l1 = True
+    w0 = hip.backbone.backbone.dark3[0].conv[0].weight.detach().clone()
+    for _ in range(2):
+        out = hip(x, tg)
+        opt.zero_grad(set_to_none=True)
+        out['total_loss'].backward()
+        opt.step()
+        functional.reset_net(hip)
+    assert not torch.equal(w0, hip.backbone.backbone.dark3[0].conv[0].weight)
+    hip.eval()
+    with torch.no_grad():
+        after = hip(x).clone()
+        functional.reset_net(hip)
+        # (a) no packing scope: every convolution packs the weight tensor it is handed
+        real_scope = ops.packed_weights
+        try:
+            import contextlib
+            ops.packed_weights = lambda model: contextlib.nullcontext()
+            unpacked = hip(x).clone()
+        finally:
+            ops.packed_weights = real_scope
+        functional.reset_net(hip)
+    assert torch.equal(after, unpacked), 'forward after the optimizer step used stale packed weights'
+    assert not torch.equal(after, before)
+    # (b) the oracle with the updated state
+    ref = model_ref.build_model(use_spike='True')
+    ref.load_state_dict({k: v.detach().cpu() for k, v in hip.state_dict().items()})
+    ref.eval()
+    with torch.no_grad():
+        lr = ref(x.cpu()).numpy()
+    sj_ref.reset_net(ref)
+    frac = _frac_close(after.cpu().numpy(), lr, RTOL, 1e-4)
+    print(f'after 2 fused-Adam steps: {frac * 100:.2f}% of logits within 1e-4 of the oracle on the updated weights')
+    assert frac > 0.97
+
+
 def test_model_matches_cpu_oracle_on_fresh_input(dev):
     """Same weights, fresh seeded input: HIP model vs the torch-CPU oracle model (not only the stored fixtures)."""
     from oracle import fill, model_ref, sj_ref
