@@ -6,7 +6,12 @@ One "step" = one pass of the hot path over one batch of synthetic raw events alr
   head -> SimOTA loss -> backward -> (N>1: one packed gradient all-reduce over RCCL, eas_snn_amd/parallel.py) -> Adam step ->
   reset_net.  The warm-up also times eager launches against HIP-graph replay of the same step and the timed region uses the faster.
 Workload = BASELINE.json configs[1]: SYOLOX-S, Gen1 304x240 sensor (256x320 canvas), T=3, Tm=4, batch 64 per GPU.
-Multi-GPU: data parallel, weak scaling (64 samples per rank), launched by torch.distributed.run.
+Multi-GPU: data parallel, weak scaling (64 samples per rank), one process per GPU over RCCL.  ``python bench.py --gpus N`` with
+no WORLD_SIZE in the environment starts the N ranks itself (children are started before the parent touches the GPU, like the
+reference's yolox/core/launch.py:59-98 spawns its workers; the parent only waits and passes rank 0's line through); under
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` the ranks are already there.  A rank count different
+from --gpus is an error.  At N > 1 every rank replays TWO HIP graphs per step -- (histogram, forward, backward, gradient
+packing) and (Adam, reset) -- with the one flat RCCL all-reduce launched eagerly between them: three host calls per step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      achieved algorithmic GB/s of the dominant hand-written HIP kernel family, timed with HIP events
@@ -69,7 +74,22 @@ def parse():
     ap.add_argument('--events', type=int, default=200_000, help='events per sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--selftest-cpu', action='store_true',
+                    help='no GPU: run the launcher, rendezvous (gloo), barrier / max-over-ranks timing and the flat gradient '
+                         'exchange on a stand-in CPU module (tests/test_cpu_host.py)')
     return ap.parse_args()
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for ln in fh:
+                if ln.lower().startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(cpu_batch, n_events):
@@ -128,17 +148,114 @@ def cpu_baseline(cpu_batch, n_events):
             sj_ref.reset_net(model)
             ev_n += 1
     ev_rate = ev_n / (time.time() - t2)
-    return {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port',
+    return {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port', 'cpu_model': _cpu_model(),
+            'host_logical_cpus': os.cpu_count(),
             'sample': f'oracle (torch-CPU fp32) SYOLOX-S T=3 256x320 fwd+bwd+Adam, batch {cpu_batch}, {n} iterations, '
                       f'{n_events} events/sample binned with numpy',
             'k1_numpy_events_per_s_1thread': round(k1_rate), 'eval_forward_1_sample_frames_per_s': round(ev_rate, 2)}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """Start one child process per GPU and wait for them.  Runs BEFORE anything in this process touches the GPU (counting devices
+    does not initialise it); the children are fresh interpreters, never an exec of a process that holds the GPU.  Rank 0's JSON
+    line reaches stdout through the inherited descriptor.  Returns the exit code (non-zero when any rank failed)."""
+    import subprocess
+    n = args.gpus
+    if not args.selftest_cpu:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f'bench.py: --gpus {n} but only {have} GPU(s) visible', file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r), EAS_BENCH_SPAWNED='1')))
+    rc = 0
+    try:
+        while procs:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in procs:              # one rank failed: the others would wait in a collective forever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            pr.kill()
+    return rc
+
+
+def selftest_cpu(args, world, rank):
+    """The N-rank protocol of this file without a GPU: gloo rendezvous from the launcher's environment, flat gradient exchange on a
+    stand-in module, barrier-bracketed timed region, max over ranks, one JSON line from rank 0."""
+    from eas_snn_amd.parallel import FlatGradAllReduce
+    if os.environ.get('EAS_BENCH_SELFTEST_FAIL_RANK') == str(rank):     # test hook: this rank dies before the rendezvous
+        sys.exit(7)
+    if world > 1:
+        dist.init_process_group('gloo')
+    torch.manual_seed(rank)
+    net = torch.nn.Linear(16, 4)
+    sync = FlatGradAllReduce(net) if world > 1 else None
+    x = torch.full((8, 16), float(rank + 1))
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        net(x).sum().backward()
+        if sync is not None:
+            sync.sync()
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    g = net.weight.grad.clone()
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        lo, hi = g.clone(), g.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), 'ranks hold different averaged gradients'
+    if rank == 0:
+        # d(sum)/dW = 8 * x per output row; averaged over ranks r = 1..world
+        want = 8.0 * sum(range(1, world + 1)) / world
+        assert torch.allclose(g, torch.full_like(g, want)), (g[0, 0].item(), want)
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(float(el) / args.steps * 1e3, 4), 'backend': 'gloo',
+                          'gradient_exchange': 'flat' if world > 1 else None,
+                          'spawned_by_bench': os.environ.get('EAS_BENCH_SPAWNED') == '1'}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        print(f'bench.py: launched with {world} rank(s) for --gpus {args.gpus}', file=sys.stderr)
+        sys.exit(3)
+    if args.selftest_cpu:
+        return selftest_cpu(args, world, rank)
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -151,7 +268,6 @@ def main():
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
-    assert world == args.gpus or world == 1, f'launched {world} ranks for --gpus {args.gpus}'
 
     # everything runs on one non-default stream: autograd's AccumulateGrad nodes remember the stream they were created on,
     # and a later graph capture breaks if that was the default stream
@@ -190,23 +306,35 @@ def main():
     ev = data.events_to_device(data.synth_event_batch(args.batch, args.events, *SENSOR, seed=rank), dev)
     targets = data.synth_targets(args.batch, CANVAS, dev)
 
-    def step():
+    def fwd_bwd():
         frames = data.events_to_frames(ev, exp.Tm, SENSOR, CANVAS)
         out = net(frames, targets)
         opt.zero_grad(set_to_none=True)
         out['total_loss'].backward()
         if flat_sync is not None:
-            flat_sync.sync()
-        opt.step()
-        functional.reset_net(model)
+            flat_sync.pack()
         return out['total_loss']
 
-    # Launch mode.  The step has no host synchronisation, so on a single GPU it can be captured once into a HIP graph and
-    # replayed.  Eager launches are ~3 % faster while the host stays ahead of the GPU (quiet host: a step is enqueued in
-    # ~20 ms against the ~32 ms the GPU needs; graph nodes add ~1 ms of per-kernel cost) and much slower once it does not (a
-    # busy host: 51 ms measured for the same kernels).  So on one GPU the warm-up captures the graph and then times a few eager
-    # steps and a few replays; the timed region uses whichever was faster (EAS_BENCH_GRAPH=0/1 forces eager/graph).
-    # Multi-GPU runs stay eager (DDP's reducer + RCCL inside a captured graph cannot be tested on the one-GPU box).
+    def update():
+        if flat_sync is not None:
+            flat_sync.attach()
+        opt.step()
+        functional.reset_net(model)
+
+    def step():
+        loss_ = fwd_bwd()
+        if flat_sync is not None:
+            flat_sync.reduce()               # the one collective of the step: RCCL all-reduce of the flat gradient buffer
+        update()
+        return loss_
+
+    # Launch mode.  The step has no host synchronisation, so it can be captured into HIP graphs and replayed.  One GPU: ONE
+    # graph for the whole step; the warm-up times a few eager steps and a few replays and the timed region uses whichever was
+    # faster (eager wins by ~3 % while the host stays ahead of the GPU, loses by 2x on a busy host).  N > 1 (flat exchange):
+    # TWO graphs -- forward + backward + gradient packing | Adam + reset -- with the RCCL all-reduce launched eagerly between
+    # them, so a rank costs the host three calls per step instead of ~1100 kernel launches (eight ranks share one host).
+    # DistributedDataParallel (EAS_BENCH_DP=ddp) stays eager: its reducer hooks cannot be captured.
+    # EAS_BENCH_GRAPH=0/1 forces eager/graph.
     mode = os.environ.get('EAS_BENCH_GRAPH', 'auto')
     for _ in range(max(args.warmup - 2, 1)):
         loss = step()
@@ -219,7 +347,10 @@ def main():
     t_tot = time.perf_counter() - t_a
     graph = None
     probe = {}
-    if world == 1 and not force_ddp and mode in ('1', 'auto'):
+    launch = 'eager launches'
+    multi = world > 1 or force_ddp
+    run = step
+    if mode in ('1', 'auto') and not (multi and dp_mode == 'ddp'):
         for gr in opt.param_groups:
             gr['capturable'] = True
         for st_ in opt.state.values():         # Adam's step counters live on the host in eager mode; a captured step needs them on the device
@@ -228,22 +359,40 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss = step()
-        graph.replay()                       # warm-up replay
-        if mode == 'auto':
-            def clock(fn, n=4):
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t) / n * 1e3
-            probe = {'eager_ms': round(clock(step), 3), 'graph_ms': round(clock(graph.replay), 3)}
-            if probe['eager_ms'] < probe['graph_ms']:
-                graph_keep, graph = graph, None          # eager is faster on this host right now
-    run = graph.replay if graph is not None else step
+        if not multi:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = step()
+            graph.replay()                       # warm-up replay
+            run = graph.replay
+            launch = 'hip-graph replay of the whole step'
+            if mode == 'auto':
+                def clock(fn, n=4):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / n * 1e3
+                probe = {'eager_ms': round(clock(step), 3), 'graph_ms': round(clock(graph.replay), 3)}
+                if probe['eager_ms'] < probe['graph_ms']:
+                    run, launch = step, 'eager launches'         # eager is faster on this host right now
+        else:
+            pool = torch.cuda.graph_pool_handle()
+            g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_a, pool=pool):
+                loss = fwd_bwd()
+            flat_sync.reduce()
+            with torch.cuda.graph(g_b, pool=pool):
+                update()
+            graph = (g_a, g_b)
+
+            def run():
+                g_a.replay()
+                flat_sync.reduce()
+                g_b.replay()
+            run()                                # warm-up replay
+            launch = 'two hip-graph replays per step (fwd+bwd+pack | adam+reset) with the eager RCCL all-reduce between them'
     timer = ops.KernelTimer() if rank == 0 else None
     torch.cuda.synchronize()
     if world > 1:
@@ -282,6 +431,8 @@ def main():
         d = summ[dom]
         sec = d['ms'] * 1e-3
         common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1),
+                  'traffic_source': 'committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes over this command (profiles/pmc_traffic_latest.json, '
+                                    'scripts/gpu_profile.sh), not re-measured in this run',
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
                   'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'}
@@ -291,8 +442,12 @@ def main():
             # 3 (spike inputs) or 6 (general inputs) exact bf16 term products on v_mfma_f32_32x32x16_bf16, so the bf16 flops
             # actually issued and their share of the dense bf16 peak are reported next to it.
             achieved = d['flops'] / sec / 1e12
+            # ceiling of the exact-bf16-term scheme itself: the bf16 pipe divided by the term products per fp32 product
+            # (3 for spike inputs -> 833 TF, 6 for real-valued inputs -> 417 TF), weighted by this step's mix of the two
+            scheme_ceiling = BF16_MFMA_PEAK_TF * d['flops'] / d['issue_flops']
             roofline = {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
                         'frac': round(achieved / F32_MFMA_PEAK_TF, 4),
+                        'scheme_ceiling_tflops': round(scheme_ceiling, 1), 'frac_of_scheme_ceiling': round(achieved / scheme_ceiling, 4),
                         'mfma_bf16_issued_tflops': round(d['issue_flops'] / sec / 1e12, 1), 'mfma_bf16_peak_tflops': BF16_MFMA_PEAK_TF,
                         'mfma_bf16_util': round(d['issue_flops'] / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
                         'algorithmic_GBps': round(d['bytes'] / sec / 1e9, 1)}
@@ -317,7 +472,7 @@ def main():
                 'config': {'workload': 'SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, batch 64/GPU, '
                                        'raw events -> histogram -> fwd + bwd + Adam + reset_net',
                            'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}', 'gradient_exchange': (dp_mode if (world > 1 or force_ddp) else None),
-                           'launch': 'hip-graph replay of the whole step' if graph is not None else 'eager launches',
+                           'launch': launch, 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                            'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3)},
                 'roofline': roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -46,9 +46,12 @@ PROTOTYPES = {
     'eas_upcat_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 5 + [_P]),
     'eas_focus': (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_event_voxel_grid': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'eas_stacked_hist_event_sum': (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P, _P]),
     'eas_lif_fwd': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P, _P, C.c_int, C.c_int64, _P]),
     'eas_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                               _P, _P, _P, C.c_int, C.c_int64, _P]),
+    'eas_lif_bwd_patan': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
+                                    _P, _P, _P, C.c_int, C.c_int64, _P]),
     'eas_reduce_workspace_floats': (C.c_int64, [C.c_int64]),
     'eas_time_mean': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
@@ -64,6 +67,8 @@ PROTOTYPES = {
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P]),
     'eas_bn_lif_bwd_ex': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                     C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_bn_lif_bwd_patan': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P,
+                                       _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 3 + [_P]),
     'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, _P]),

@@ -58,6 +58,8 @@ class BaseNode(base.MemoryModule):
         sid = getattr(sf, 'hip_id', None)
         if sid is None:
             raise NotImplementedError(f'surrogate {type(sf).__name__} has no HIP backward; use surrogate.ATan / Sigmoid / Rect')
+        if sid == 'patan':
+            return sid, sf.alpha              # learnable device scalar: handed to the kernels as a pointer, gradient comes back
         return sid, float(sf.alpha)
 
     def _v_in(self, x0):

@@ -46,7 +46,10 @@ class EventExp(BaseExp):
             return surrogate.ATan(self.alpha)
         if self.spike_fn == 'sigmoid':
             return surrogate.Sigmoid(self.alpha)
-        raise NotImplementedError(f"spike_fn '{self.spike_fn}' has no HIP backward (available: rect, atan, sigmoid)")
+        if self.spike_fn == 'patan':
+            from yolox.models.activation import EfficientNoisySpikeII, InvArcTanh
+            return EfficientNoisySpikeII(InvArcTanh(self.alpha), p=0)
+        raise KeyError(self.spike_fn)            # the reference indexes a dict of these four names
 
     def get_kwargs_spikes(self):
         from yolox.models.activation import Rectangle

@@ -149,7 +149,8 @@ class CSPLayer(nn.Module):
         for blk in (self.conv1, self.conv2):
             c = blk.conv[0] if isinstance(blk.conv, nn.Sequential) and len(blk.conv) == 1 else None
             if (type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.bias is not None or c.groups != 1
-                    or c._forward_hooks or c._forward_pre_hooks or c.in_channels % 8 != 0 or blk.emit_rate):
+                    or c._forward_hooks or c._forward_pre_hooks or c.in_channels % 8 != 0 or blk.emit_rate
+                    or getattr(blk.act.surrogate_function, 'hip_id', None) == 'patan'):     # learnable slope: per-layer BN+LIF calls
                 return False
         return not torch.nn.modules.module._global_forward_hooks
 

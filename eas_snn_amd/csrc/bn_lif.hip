@@ -187,7 +187,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
 template <int T_, bool HARD, bool DI, bool STRICT>
 __device__ __forceinline__ void recompute_dz(const float (&yv)[T_], const float (&gs)[T_], float v0, float scale,
                                              float shift, float k, float omk, const EasLifParams& p, bool detach,
-                                             int sg_id, float alpha, float (&dz)[T_], float& dk) {
+                                             int sg_id, float alpha, float (&dz)[T_], float& dk, float& da) {
     float h[T_], vprev[T_], z[T_];
     float v = v0;
 #pragma unroll
@@ -202,7 +202,7 @@ __device__ __forceinline__ void recompute_dz(const float (&yv)[T_], const float 
     for (int t = T_ - 1; t >= 0; --t) {
         float dkt, gx;
         eas_lif_step_bwd<HARD, DI, STRICT>(gs[t], gv, h[t], vprev[t], z[t], k, omk, p.v_th, p.v_reset, detach, sg_id,
-                                           alpha, dkt, gx);
+                                           alpha, dkt, gx, da);
         dz[t] = gx;
         dk += dkt;
     }
@@ -214,9 +214,11 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
     int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot) {
+    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot,
+    const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha) {
     __shared__ double red[NW];
     __shared__ float bc[2];
+    if (alpha_dev) alpha = fabsf(*alpha_dev);    // learnable slope (EAS_SG_PATAN)
     const int c = blockIdx.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         __syncthreads();
         if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
     }
-    float s1 = 0.f, s2 = 0.f, dk = 0.f;
+    float s1 = 0.f, s2 = 0.f, dk = 0.f, da = 0.f;
     GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
         const int64_t n = gw.n;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
             }
             const float v0e = reinterpret_cast<const float*>(&v0)[e];
             float dke = 0.f;
-            recompute_dz<T_, HARD, DI, STRICT>(yv, gs, v0e, scale, shift, k, omk, p, detach, sg_id, alpha, dz, dke);
+            recompute_dz<T_, HARD, DI, STRICT>(yv, gs, v0e, scale, shift, k, omk, p, detach, sg_id, alpha, dz, dke, da);
 #pragma unroll
             for (int t = 0; t < T_; ++t) {
                 const float xhat = (yv[t] - mu) * istd;
@@ -329,13 +331,28 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         const double tot = eas_block_sum<double, NW>(acc, red);
         if (threadIdx.x == 0) *grad_w = (float)tot * (k * (1.0f - k));
     }
+    if (APPLY && grad_alpha && blockIdx.x == 0 && blockIdx.y == 0) {
+        // dL/dalpha of the learnable surrogate slope: same fixed-order sum over slot 3 of the partials
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
+            const int cc = i / nchunks, j = i - cc * nchunks;
+            acc += part[((int64_t)cc * kMaxChunks + j) * 4 + 3];
+        }
+        const double tot = eas_block_sum<double, NW>(acc, red);
+        if (threadIdx.x == 0) {
+            const float a = *alpha_dev;
+            *grad_alpha = (float)tot * (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f));
+        }
+    }
     if (!APPLY) {
         const double t1 = eas_block_sum<double, NW>((double)s1, red);
         const double t2 = eas_block_sum<double, NW>((double)s2, red);
         const double t3 = eas_block_sum<double, NW>((double)dk, red);
+        double t4 = 0.0;
+        if (sg_id == EAS_SG_PATAN) t4 = eas_block_sum<double, NW>((double)da, red);
         if (threadIdx.x == 0) {
             double* o = part + ((int64_t)c * kMaxChunks + blockIdx.x) * 4;
-            o[0] = t1; o[1] = t2; o[2] = t3;
+            o[0] = t1; o[1] = t2; o[2] = t3; o[3] = t4;
         }
     }
 }
@@ -368,15 +385,15 @@ template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
-                 int C, int HW, int bcast, int gs_ctot, int y_ctot, hipStream_t st) {
+                 int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot);
+                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
     EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot);
+                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, grad_alpha);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -385,11 +402,13 @@ template <bool HARD, bool DI, bool STRICT>
 int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* y, const float* mean,
                const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
                float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
-               double* ws, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot, hipStream_t st) {
+               double* ws, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha,
+               hipStream_t st) {
 #define EAS_CASE(TT)                                                                                               \
     case TT:                                                                                                       \
         return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
-                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, y_ctot, st);
+                                                  batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, y_ctot,         \
+                                                  alpha_dev, grad_alpha, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -486,15 +505,17 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
                              v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, stream);
 }
 
-int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
-                      const float* invstd, const float* gamma, const float* beta, const float* v_init,
-                      const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
-                      float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                           const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                           float alpha, const float* alpha_dev, float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma,
+                           float* grad_beta, float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast,
+                           eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
         (!grad_s && !grad_mean) || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
-    if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_RECT || !(alpha > 0.f)) return EAS_ERR_INVALID_ARG;
+    if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;
+    if (surrogate == EAS_SG_PATAN ? !alpha_dev : !(alpha > 0.f)) return EAS_ERR_INVALID_ARG;
     if (grad_w && !w_logit) return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)grad_s | (uintptr_t)grad_mean | (uintptr_t)v_init | (uintptr_t)grad_y) & 15)
@@ -508,13 +529,35 @@ int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_me
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
-                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, yc, st)
+                               batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, yc,    \
+                               alpha_dev, grad_alpha, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
     if (hard && di && !strict) EAS_DISPATCH(true, true, false);
     return EAS_ERR_UNSUPPORTED;
 #undef EAS_DISPATCH
+}
+
+int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                      const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
+                      float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+    if (surrogate == EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;      // learnable slope: eas_bn_lif_bwd_patan
+    return bn_lif_bwd_impl(grad_s, grad_s_ctot, grad_mean, y, y_ctot, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset,
+                           flags, surrogate, alpha, nullptr, nullptr, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C,
+                           HW, y_bcast, stream);
+}
+
+int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                         const float* w_logit, float k_const, float v_th, float v_reset, int flags, const float* alpha,
+                         float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+    return bn_lif_bwd_impl(grad_s, grad_s_ctot, grad_mean, y, y_ctot, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset,
+                           flags, EAS_SG_PATAN, 0.f, alpha, grad_alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C,
+                           HW, y_bcast, stream);
 }
 
 int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,

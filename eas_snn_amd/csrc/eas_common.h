@@ -30,7 +30,7 @@ __device__ __forceinline__ float eas_sigmoidf(float x) { return 1.0f / (1.0f + _
 
 // surrogate gradient g'(u), u = h - v_th
 __device__ __forceinline__ float eas_surrogate_grad(int id, float alpha, float u) {
-    if (id == EAS_SG_ATAN) {
+    if (id == EAS_SG_ATAN || id == EAS_SG_PATAN) {   // PATAN: the same slope with alpha = |learnable alpha| (resolved by the caller)
         // alpha/2 / (1 + q^2) with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (~10 instructions): the BN+LIF
         // backward is vector-ALU bound (two recomputing passes), and 1 ulp on a surrogate slope is far inside the 1e-4 parity bar
         const float q = 1.57079632679489661923f * alpha * u;
@@ -166,13 +166,21 @@ __device__ __forceinline__ void eas_lif_step(float& v, float x, float k, float o
 // dL/dh of one step and the pieces the caller needs.
 //   gs: dL/ds_t from the output, gv: dL/dv_t from the future (updated to dL/dv_{t-1} on return)
 //   returns dh = dL/dh_t;  dk_term = dh * dh/dk (for grad of the decay)
+//   da (accumulated, EAS_SG_PATAN only): dL/d|alpha| of the learnable arctan surrogate sigma(u) = atan(pi/2 |alpha| u)/pi + 1/2
+//   (yolox/models/activation.py:121-130): every use of s_t -- the output and, unless detached, the reset term -- carries
+//   d sigma/d|alpha| = u/2 / (1 + (pi/2 |alpha| u)^2); the sign of alpha is applied by the finalize.
 template <bool HARD, bool DI, bool STRICT>
 __device__ __forceinline__ float eas_lif_step_bwd(float gs, float& gv, float h, float v_prev, float x, float k,
                                                   float omk, float v_th, float v_reset, bool detach, int sg_id,
-                                                  float alpha, float& dk_term, float& gx) {
+                                                  float alpha, float& dk_term, float& gx, float& da) {
     const float u = h - v_th;
     const float s = STRICT ? (u > 0.0f ? 1.0f : 0.0f) : (u >= 0.0f ? 1.0f : 0.0f);
     const float sg = eas_surrogate_grad(sg_id, alpha, u);
+    if (sg_id == EAS_SG_PATAN) {     // block-uniform branch
+        const float q = 1.57079632679489661923f * alpha * u;
+        const float gs_all = detach ? gs : (HARD ? gs + gv * (v_reset - h) : gs - gv * v_th);
+        da += gs_all * (0.5f * u * __builtin_amdgcn_rcpf(1.0f + q * q));
+    }
     float dvdh;
     if (HARD) {
         dvdh = detach ? (1.0f - s) : (1.0f - s) + (v_reset - h) * sg;

@@ -88,9 +88,12 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_bwd_kernel(const float* __restr
                                                             const float* __restrict__ h_save,
                                                             const float* __restrict__ v_init,
                                                             const float* __restrict__ x, EasLifParams p, int sg_id,
-                                                            float alpha, float* __restrict__ grad_x,
-                                                            float* __restrict__ partial, int T_rt, int64_t M) {
+                                                            float alpha, const float* __restrict__ alpha_dev,
+                                                            float* __restrict__ grad_x, float* __restrict__ partial,
+                                                            float* __restrict__ partial_a, int T_rt, int64_t M) {
     __shared__ float red[EAS_BLOCK / EAS_WAVE];
+    if (alpha_dev) alpha = fabsf(*alpha_dev);    // learnable slope (EAS_SG_PATAN)
+    float da = 0.f;
     const float k = eas_lif_k(p);
     const float omk = 1.0f - k;
     const bool detach = (p.flags & EAS_LIF_DETACH_RESET) != 0;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_bwd_kernel(const float* __restr
             for (int e = 0; e < VEC; ++e) {
                 float dkt;
                 eas_lif_step_bwd<HARD, DI, STRICT>(gs[e], gv[e], hh[e], vp[e], xv[e], k, omk, p.v_th, p.v_reset,
-                                                   detach, sg_id, alpha, dkt, gx[e]);
+                                                   detach, sg_id, alpha, dkt, gx[e], da);
                 dk += dkt;
             }
             reinterpret_cast<float4*>(grad_x + (int64_t)t * M)[i] = make_float4(gx[0], gx[1], gx[2], gx[3]);
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_bwd_kernel(const float* __restr
                 const float xv = (DI && x) ? x[(int64_t)t * M + j] : 0.f;
                 float dkt, gx;
                 eas_lif_step_bwd<HARD, DI, STRICT>(gs, gv, h, vp, xv, k, omk, p.v_th, p.v_reset, detach, sg_id,
-                                                   alpha, dkt, gx);
+                                                   alpha, dkt, gx, da);
                 dk += dkt;
                 grad_x[(int64_t)t * M + j] = gx;
             }
@@ -166,20 +169,39 @@ __global__ __launch_bounds__(EAS_BLOCK) void lif_bwd_kernel(const float* __restr
         const float tot = eas_block_sum<float, EAS_BLOCK / EAS_WAVE>(dk, red);
         if (threadIdx.x == 0) partial[blockIdx.x] = tot;
     }
+    if (partial_a) {
+        const float tot = eas_block_sum<float, EAS_BLOCK / EAS_WAVE>(da, red);
+        if (threadIdx.x == 0) partial_a[blockIdx.x] = tot;
+    }
 }
 
 // final stage of the grad_w reduction: sum the per-block partials in a fixed order (deterministic)
 // and apply dk/dw = k (1 - k).
+// and, for the learnable surrogate slope, d|alpha|/dalpha = sign(alpha) (0 at 0, like torch.abs).
 __global__ __launch_bounds__(EAS_BLOCK) void lif_gradw_finalize(const float* __restrict__ partial, int n,
                                                                 const float* __restrict__ w_logit,
-                                                                float* __restrict__ grad_w) {
+                                                                float* __restrict__ grad_w,
+                                                                const float* __restrict__ partial_a,
+                                                                const float* __restrict__ alpha_dev,
+                                                                float* __restrict__ grad_alpha) {
     __shared__ double red[EAS_BLOCK / EAS_WAVE];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)partial[i];
-    const double tot = eas_block_sum<double, EAS_BLOCK / EAS_WAVE>(acc, red);
-    if (threadIdx.x == 0) {
-        const float k = eas_sigmoidf(*w_logit);
-        *grad_w = (float)tot * (k * (1.0f - k));
+    if (grad_w) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)partial[i];
+        const double tot = eas_block_sum<double, EAS_BLOCK / EAS_WAVE>(acc, red);
+        if (threadIdx.x == 0) {
+            const float k = eas_sigmoidf(*w_logit);
+            *grad_w = (float)tot * (k * (1.0f - k));
+        }
+    }
+    if (grad_alpha) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)partial_a[i];
+        const double tot = eas_block_sum<double, EAS_BLOCK / EAS_WAVE>(acc, red);
+        if (threadIdx.x == 0) {
+            const float a = *alpha_dev;
+            *grad_alpha = (float)tot * (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f));
+        }
     }
 }
 
@@ -229,16 +251,18 @@ int launch_fwd(const float* x, const float* v_in, float* v_out, EasLifParams p, 
 
 template <bool HARD, bool DI, bool STRICT>
 int launch_bwd(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init, const float* x,
-               EasLifParams p, int sg, float alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
-               hipStream_t st) {
+               EasLifParams p, int sg, float alpha, const float* alpha_dev, float* grad_alpha, float* grad_x, float* grad_w,
+               float* workspace, int T, int64_t M, hipStream_t st) {
     int grid = eas_grid_1d(M % VEC == 0 ? M / VEC : M);
     if (grid > kReduceBlocks) grid = kReduceBlocks;
     float* partial = grad_w ? workspace : nullptr;
+    float* partial_a = grad_alpha ? workspace + kReduceBlocks : nullptr;
     hipLaunchKernelGGL((lif_bwd_kernel<0, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean,
-                       h_save, v_init, x, p, sg, alpha, grad_x, partial, T, M);
+                       h_save, v_init, x, p, sg, alpha, alpha_dev, grad_x, partial, partial_a, T, M);
     EAS_CHECK_LAUNCH();
-    if (grad_w) {
-        hipLaunchKernelGGL(lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, partial, grid, p.w_logit, grad_w);
+    if (grad_w || grad_alpha) {
+        hipLaunchKernelGGL(lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, partial, grid, p.w_logit, grad_w, partial_a, alpha_dev,
+                           grad_alpha);
         EAS_CHECK_LAUNCH();
     }
     return EAS_OK;
@@ -248,7 +272,7 @@ int launch_bwd(const float* grad_s, const float* grad_mean, const float* h_save,
 
 extern "C" {
 
-int64_t eas_reduce_workspace_floats(int64_t) { return kReduceBlocks; }
+int64_t eas_reduce_workspace_floats(int64_t) { return 2 * kReduceBlocks; }   // grad_w partials | grad_alpha partials
 
 int eas_lif_fwd(const float* x, const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th,
                 float v_reset, int flags, float* spikes, float* h_save, float* mean_out, int T, int64_t M, eas_stream_t stream) {
@@ -272,13 +296,14 @@ int eas_lif_fwd(const float* x, const float* v_in, float* v_out, const float* w_
 #undef EAS_DISPATCH
 }
 
-int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init,
-                const float* x, const float* w_logit, float k_const, float v_th, float v_reset, int flags,
-                int surrogate, float alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
-                eas_stream_t stream) {
+static int lif_bwd_impl(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init,
+                        const float* x, const float* w_logit, float k_const, float v_th, float v_reset, int flags,
+                        int surrogate, float alpha, const float* alpha_dev, float* grad_alpha, float* grad_x, float* grad_w,
+                        float* workspace, int T, int64_t M, eas_stream_t stream) {
     if (!h_save || !grad_x || T < 1 || M < 0 || (!grad_s && !grad_mean)) return EAS_ERR_INVALID_ARG;
-    if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_RECT || !(alpha > 0.f)) return EAS_ERR_INVALID_ARG;
-    if (grad_w && (!workspace || !w_logit)) return EAS_ERR_INVALID_ARG;
+    if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;
+    if (surrogate == EAS_SG_PATAN ? !alpha_dev : !(alpha > 0.f)) return EAS_ERR_INVALID_ARG;
+    if ((grad_w && (!workspace || !w_logit)) || (grad_alpha && (!workspace || !alpha_dev))) return EAS_ERR_INVALID_ARG;
     if (M == 0) return EAS_OK;
     if (((uintptr_t)grad_s | (uintptr_t)grad_mean | (uintptr_t)h_save | (uintptr_t)v_init | (uintptr_t)x |
          (uintptr_t)grad_x) & 15)
@@ -289,7 +314,7 @@ int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) \
-    return launch_bwd<H, D, S>(grad_s, grad_mean, h_save, v_init, x, p, surrogate, alpha, grad_x, grad_w, workspace, T, M, st)
+    return launch_bwd<H, D, S>(grad_s, grad_mean, h_save, v_init, x, p, surrogate, alpha, alpha_dev, grad_alpha, grad_x, grad_w, workspace, T, M, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (!hard && !di && strict) EAS_DISPATCH(false, false, true);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -299,6 +324,23 @@ int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save
     if (hard && di && !strict) EAS_DISPATCH(true, true, false);
     EAS_DISPATCH(true, true, true);
 #undef EAS_DISPATCH
+}
+
+int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init,
+                const float* x, const float* w_logit, float k_const, float v_th, float v_reset, int flags,
+                int surrogate, float alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
+                eas_stream_t stream) {
+    if (surrogate == EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;      // learnable slope: eas_lif_bwd_patan
+    return lif_bwd_impl(grad_s, grad_mean, h_save, v_init, x, w_logit, k_const, v_th, v_reset, flags, surrogate, alpha, nullptr, nullptr,
+                        grad_x, grad_w, workspace, T, M, stream);
+}
+
+int eas_lif_bwd_patan(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init,
+                      const float* x, const float* w_logit, float k_const, float v_th, float v_reset, int flags,
+                      const float* alpha, float* grad_alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
+                      eas_stream_t stream) {
+    return lif_bwd_impl(grad_s, grad_mean, h_save, v_init, x, w_logit, k_const, v_th, v_reset, flags, EAS_SG_PATAN, 0.f, alpha, grad_alpha,
+                        grad_x, grad_w, workspace, T, M, stream);
 }
 
 int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t stream) {

@@ -12,7 +12,8 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream
 
-SURROGATE_IDS = {'atan': 0, 'sigmoid': 1, 'rect': 2}
+SURROGATE_IDS = {'atan': 0, 'sigmoid': 1, 'rect': 2, 'patan': 3}
+SG_PATAN = 3      # learnable slope: ``alpha`` is a device tensor of one element and receives a gradient
 FLAG_HARD_RESET, FLAG_DECAY_INPUT, FLAG_DETACH_RESET, FLAG_FIRE_STRICT = 1, 2, 4, 8
 READOUT_IDS = {'sum': 0, 'last': 1, 'avg': 2}
 
@@ -32,19 +33,27 @@ def state_writeback():
     return _STATE_WRITEBACK
 
 
-class no_state_writeback:
-    """``with ops.no_state_writeback():`` around a loop whose every iteration ends with ``reset_net`` (the reference's
-    train / eval loops): the final membrane potentials are not written to HBM.  The previous setting is restored on exit,
-    so stateful use (streaming inference, ``node.v`` inspection) elsewhere in the process is unaffected."""
+class state_writeback_scope:
+    """``with ops.state_writeback_scope(flag):`` -- the setting for the duration of the block, the previous one restored on exit."""
+
+    def __init__(self, flag):
+        self.flag = bool(flag)
 
     def __enter__(self):
         global _STATE_WRITEBACK
-        self.prev, _STATE_WRITEBACK = _STATE_WRITEBACK, False
+        self.prev, _STATE_WRITEBACK = _STATE_WRITEBACK, self.flag
         return self
 
     def __exit__(self, *exc):
         global _STATE_WRITEBACK
         _STATE_WRITEBACK = self.prev
+
+
+def no_state_writeback():
+    """``with ops.no_state_writeback():`` around a loop whose every iteration ends with ``reset_net`` (the reference's
+    train / eval loops): the final membrane potentials are not written to HBM.  The previous setting is restored on exit,
+    so stateful use (streaming inference, ``node.v`` inspection) elsewhere in the process is unaffected."""
+    return state_writeback_scope(False)
 
 
 class KernelTimer:
@@ -110,6 +119,15 @@ def _dev(*tensors):
             raise _lib.EasHipError('eas_snn_amd operators run on the GPU only (got a CPU tensor); there is no CPU fallback')
 
 
+def _alpha_arg(sg_id, alpha):
+    """float for the fixed-slope surrogates; the learnable [1] device tensor itself for 'patan' (never read on the host)"""
+    if sg_id == SG_PATAN:
+        if not torch.is_tensor(alpha) or alpha.numel() != 1 or alpha.dtype != torch.float32:
+            raise _lib.EasHipError("surrogate 'patan' needs its learnable alpha as a float32 tensor of one element")
+        return alpha
+    return float(alpha)
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -135,15 +153,18 @@ class _LIFFn(torch.autograd.Function):
         _call('eas_lif_fwd', (8 + (4 if h is not None else 0)) * T * M, L.eas_lif_fwd, ptr(x), ptr(v_in), ptr(v_out), ptr(w),
               k_const, v_th, v_reset, flags, ptr(spikes), ptr(h), ptr(mean), T, M, stream())
         keep_x = x if (flags & FLAG_DECAY_INPUT) and w is not None else None
-        ctx.save_for_backward(h, v_in, w, keep_x)
-        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, T, M)
+        learn = sg_id == SG_PATAN
+        if learn:
+            _dev(alpha)
+        ctx.save_for_backward(h, v_in, w, keep_x, alpha if learn else None)
+        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, None if learn else alpha, T, M)
         if v_out is not None:
             ctx.mark_non_differentiable(v_out)
         return spikes, v_out, mean
 
     @staticmethod
     def backward(ctx, g_s, g_v, g_mean):
-        h, v_in, w, x = ctx.saved_tensors
+        h, v_in, w, x, alpha_t = ctx.saved_tensors
         k_const, v_th, v_reset, flags, sg_id, alpha, T, M = ctx.cfg
         L = _lib.lib()
         if g_s is None and g_mean is None:
@@ -153,18 +174,24 @@ class _LIFFn(torch.autograd.Function):
         gx = torch.empty_like(h)
         want_w = w is not None and ctx.needs_input_grad[2]
         gw = torch.empty_like(w) if want_w else None
-        ws = torch.empty(L.eas_reduce_workspace_floats(M), dtype=torch.float32, device=h.device) if want_w else None
-        _call('eas_lif_bwd', 12 * T * M, L.eas_lif_bwd, ptr(g_s), ptr(g_mean), ptr(h), ptr(v_in), ptr(x), ptr(w), k_const,
-              v_th, v_reset, flags, sg_id, alpha, ptr(gx), ptr(gw), ptr(ws), T, M, stream())
-        return gx, None, gw, None, None, None, None, None, None, None, None
+        want_a = alpha_t is not None and ctx.needs_input_grad[8]
+        ga = torch.empty_like(alpha_t) if want_a else None
+        ws = torch.empty(L.eas_reduce_workspace_floats(M), dtype=torch.float32, device=h.device) if (want_w or want_a) else None
+        if alpha_t is not None:
+            _call('eas_lif_bwd', 12 * T * M, L.eas_lif_bwd_patan, ptr(g_s), ptr(g_mean), ptr(h), ptr(v_in), ptr(x), ptr(w), k_const,
+                  v_th, v_reset, flags, ptr(alpha_t), ptr(ga), ptr(gx), ptr(gw), ptr(ws), T, M, stream())
+        else:
+            _call('eas_lif_bwd', 12 * T * M, L.eas_lif_bwd, ptr(g_s), ptr(g_mean), ptr(h), ptr(v_in), ptr(x), ptr(w), k_const,
+                  v_th, v_reset, flags, sg_id, alpha, ptr(gx), ptr(gw), ptr(ws), T, M, stream())
+        return gx, None, gw, None, None, None, None, None, ga, None, None
 
 
 def lif_multistep(x_seq, v_in, w, k_const, v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None):
     """Multi-step (P)LIF over x_seq [T, ...].  Returns (spikes, v_final|None, mean_over_T|None)."""
     if write_v is None:
         write_v = _STATE_WRITEBACK
-    return _LIFFn.apply(x_seq, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags),
-                        SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate), float(alpha),
+    sg_id = SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate)
+    return _LIFFn.apply(x_seq, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags), sg_id, _alpha_arg(sg_id, alpha),
                         bool(want_mean), bool(write_v))
 
 
@@ -260,8 +287,11 @@ class _BNLIFFn(torch.autograd.Function):
               ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, int(bool(t_bcast)),
               C.byref(pend) if pend is not None else None, ptr(residual), ctot, stream())
         del keep
-        ctx.save_for_backward(y, mean, invstd, gamma, beta, v_in, w)
-        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), T, N, Cc, HW, bool(t_bcast))
+        learn = sg_id == SG_PATAN
+        if learn:
+            _dev(alpha)
+        ctx.save_for_backward(y, mean, invstd, gamma, beta, v_in, w, alpha if learn else None)
+        ctx.cfg = (k_const, v_th, v_reset, flags, sg_id, None if learn else alpha, bool(use_batch_stats), T, N, Cc, HW, bool(t_bcast))
         ctx.has_residual = residual is not None
         if v_out is not None:
             ctx.mark_non_differentiable(v_out)
@@ -269,7 +299,7 @@ class _BNLIFFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_s, g_v, g_mean):
-        y, mean, invstd, gamma, beta, v_in, w = ctx.saved_tensors
+        y, mean, invstd, gamma, beta, v_in, w, alpha_t = ctx.saved_tensors
         k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW, bcast = ctx.cfg
         L = _lib.lib()
         nout = 18
@@ -289,11 +319,18 @@ class _BNLIFFn(torch.autograd.Function):
         gw = torch.empty_like(w) if want_w else None
         ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
         nsteps = T * N * Cc * HW
-        _call('eas_bn_lif_bwd', 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel()), L.eas_bn_lif_bwd_ex,
-              ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th,
-              v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW,
-              int(bcast), stream())
-        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 9 + (g_res, None, None)
+        nbytes = 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel())
+        ga = None
+        if alpha_t is not None:
+            ga = torch.empty_like(alpha_t) if ctx.needs_input_grad[11] else None
+            _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_patan, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
+                  ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, ptr(alpha_t), ptr(ga), int(batch_stats), ptr(gy), ptr(ggamma),
+                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
+        else:
+            _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
+                  ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma),
+                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
+        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 5 + (ga,) + (None,) * 3 + (g_res, None, None)
 
 
 class _JoinFn(torch.autograd.Function):
@@ -430,10 +467,10 @@ def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_st
     if write_v is None:
         write_v = _STATE_WRITEBACK
     state = (running_mean, running_var, bool(use_batch_stats), None if momentum is None else float(momentum), float(eps))
-    return _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags),
-                          SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate), float(alpha),
-                          bool(want_mean), bool(write_v), int(t_bcast), residual, cat[0] if cat is not None else None,
-                          int(cat[1]) if cat is not None else 0)
+    sg_id = SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate)
+    return _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags), sg_id,
+                          _alpha_arg(sg_id, alpha), bool(want_mean), bool(write_v), int(t_bcast), residual,
+                          cat[0] if cat is not None else None, int(cat[1]) if cat is not None else 0)
 
 
 # Number of identical copies the current batch stands for (set by SeqToANNContainer while it runs a stateless block
@@ -550,6 +587,23 @@ def event_frames(t, x, y, p, sample_offsets, Tm, H, W, Hc, Wc):
     scratch = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=t.device)
     _call('eas_event_histogram', 9 * t.numel() + 4 * out.numel(), _lib.lib().eas_event_frames, ptr(t), ptr(x), ptr(y), ptr(p), t.numel(),
           ptr(sample_offsets), B, Tm, H, W, Hc, Wc, ptr(out), ptr(scratch), None, stream())
+    return out
+
+
+def stacked_hist_event_sum(hist, Hc, Wc, nbins=10, n_valid=None):
+    """RVT stacked histogram u8 [B, Tm, 2*nbins, H, W] -> fp32 model input [B, 1, Tm, 2, Hc, Wc]: sum over the time bins of each
+    polarity, zero padded to the canvas (RVTGEN4Dataset.generate_slices 'event_sum' + validation letterbox, rvt_gen4.py:109-125,
+    516-533).  n_valid int32 [B]: samples that supply only their first n_valid[b] slices (zero slices in front)."""
+    _dev(hist, n_valid)
+    assert hist.dtype == torch.uint8 and hist.dim() == 5 and hist.shape[2] == 2 * nbins
+    hist = hist.contiguous()
+    B, Tm, _, H, W = hist.shape
+    if n_valid is not None:
+        assert n_valid.dtype == torch.int32 and n_valid.shape == (B,)
+        n_valid = n_valid.contiguous()
+    out = torch.empty((B, 1, Tm, 2, Hc, Wc), dtype=torch.float32, device=hist.device)
+    _call('eas_stacked_hist_event_sum', hist.numel() + 4 * out.numel(), _lib.lib().eas_stacked_hist_event_sum, ptr(hist), ptr(n_valid), B, Tm,
+          int(nbins), H, W, Hc, Wc, ptr(out), stream())
     return out
 
 

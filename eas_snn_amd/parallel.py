@@ -14,24 +14,54 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
+    """``pack()`` -> ``reduce()`` -> ``attach()`` between backward and the optimizer step (``sync()`` does all three).
+
+    The flat buffer is allocated once, so the three phases can live in different HIP graphs: ``pack`` at the end of a captured
+    forward+backward, ``reduce`` (the RCCL call) launched eagerly between two graph replays, ``attach`` at the start of a captured
+    optimizer step.  ``attach`` launches nothing: it makes every ``p.grad`` a view of the reduced buffer, which the optimizer
+    reads in place (no unpack copy)."""
+
     def __init__(self, module, process_group=None, broadcast_parameters=True):
         self.group = process_group
         self.params = [p for p in module.parameters() if p.requires_grad]
+        self.sizes = [p.numel() for p in self.params]
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.flat = None
+        self.views = None
         if broadcast_parameters and dist.is_initialized():
             with torch.no_grad():
                 flat = torch.cat([p.detach().reshape(-1) for p in self.params])
                 dist.broadcast(flat, src=0, group=process_group)
-                torch._foreach_copy_([p.detach() for p in self.params], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in self.params]), self.params)])
+                torch._foreach_copy_([p.detach() for p in self.params], [c.view_as(p) for c, p in zip(flat.split(self.sizes), self.params)])
+
+    def pack(self):
+        """all gradients -> the flat buffer (one concatenation kernel family)"""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError('FlatGradAllReduce: a parameter has no gradient (unused parameters need DistributedDataParallel)')
+        if self.flat is None:
+            self.flat = torch.empty(sum(self.sizes), dtype=grads[0].dtype, device=grads[0].device)
+            self.views = [c.view_as(p) for c, p in zip(self.flat.split(self.sizes), self.params)]
+        if grads[0].data_ptr() == self.views[0].data_ptr():
+            return                                   # gradients were accumulated into the attached views: already packed
+        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+
+    def reduce(self):
+        """ONE all-reduce of the flat buffer, then the 1/world scale (SUM + scale: every backend has it, gloo has no AVG)"""
+        if dist.is_initialized():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                self.flat.mul_(1.0 / self.world)
+
+    def attach(self):
+        """``p.grad`` := the parameter's slice of the reduced buffer (host-side pointer assignment, no launch)"""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def sync(self):
         """average the gradients over the ranks (call between backward and the optimizer step)"""
         if self.world == 1 and not dist.is_initialized():
             return
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):
-            raise RuntimeError('FlatGradAllReduce: a parameter has no gradient (unused parameters need DistributedDataParallel)')
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)      # SUM + scale: every backend has it (gloo has no AVG)
-        flat.mul_(1.0 / self.world)
-        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        self.pack()
+        self.reduce()
+        self.attach()

@@ -145,15 +145,21 @@ class SopMeter:
 
 
 @torch.no_grad()
-def energy_estimation(model, batches, T):
+def energy_estimation(model, batches, T, reset_between_batches=False):
     """``EventEvaluator.energy_estimation`` (event_evaluator.py:466-565) over an iterable of input batches
-    [B,Tl,Tm,2,H,W] (or (imgs, ...) tuples as the reference's loader yields).  Returns the numbers the reference prints."""
+    [B,Tl,Tm,2,H,W] (or (imgs, ...) tuples as the reference's loader yields).  Returns the numbers the reference prints.
+
+    Like the reference, the neurons are NOT reset between batches by default (its loop at :515-541 only calls ``model(imgs)``):
+    the membrane potentials left by one batch are the initial state of the next, so all batches must have the same shape.
+    ``reset_between_batches=True`` makes every batch start from rest.  The network is reset once at the end."""
     from spikingjelly.activation_based import functional
     was_training = model.training
     model.eval()
     meter = SopMeter(model, T)
     prev = ops.set_conv_sink(meter)
     num = 0
+    keep_state = ops.state_writeback_scope(True)          # the carried state must reach HBM whatever the caller's setting
+    keep_state.__enter__()
     try:
         for batch in batches:
             imgs = batch[0] if isinstance(batch, (tuple, list)) else batch
@@ -162,8 +168,11 @@ def energy_estimation(model, batches, T):
             emb = getattr(model, 'embedding', None)
             if emb is not None and imgs.dim() >= 5:
                 meter.embedding_layers(emb, imgs.shape[0] * (imgs.shape[1] if imgs.dim() > 5 else 1), imgs.shape[-2], imgs.shape[-1])
-            functional.reset_net(model)
+            if reset_between_batches:
+                functional.reset_net(model)
     finally:
+        keep_state.__exit__(None, None, None)
+        functional.reset_net(model)
         ops.set_conv_sink(prev)
         model.train(was_training)
     return meter.result(num)

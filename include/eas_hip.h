@@ -33,6 +33,11 @@ typedef void* eas_stream_t; /* hipStream_t */
 #define EAS_SG_ATAN 0
 #define EAS_SG_SIGMOID 1
 #define EAS_SG_RECT 2
+/* 'patan' = EfficientNoisySpikeII(InvArcTanh(alpha), p=0) (yolox/exp/event_yolox_base.py:145-150,
+ * yolox/models/activation.py:121-130,181-205): Heaviside forward, backward through
+ * sigma(u) = atan(pi/2 |alpha| u)/pi + 1/2 with a LEARNABLE alpha that lives on the device.  Only through
+ * eas_lif_bwd_patan / eas_bn_lif_bwd_patan (alpha pointer + grad_alpha output). */
+#define EAS_SG_PATAN 3
 
 /* neuron flags */
 #define EAS_LIF_HARD_RESET 1   /* v = (1-s)*h + s*v_reset ; else soft: v = h - s*v_th        */
@@ -103,6 +108,16 @@ int eas_event_time_surface(const uint32_t* t, const uint16_t* x, const uint16_t*
                            const int64_t* sample_offsets, int B, int num_slices, int H, int W, double tau,
                            uint32_t* workspace, double* out, eas_stream_t stream);
 
+/* Config-4 input (BASELINE configs[3]): RVT stacked histogram -> per-polarity counts on the model canvas.  Replaces
+ * RVTGEN4Dataset.generate_slices(..., method='event_sum') (yolox/data/datasets/rvt_gen4.py:109-125: reshape
+ * [n][2*nbins][H][W] -> [n][2][nbins][H][W], sum over the bins, zero slices in FRONT when fewer than num_slice
+ * representations exist) followed by the validation letterbox at scale 1 = zero padding to the canvas (rvt_gen4.py:516-533).
+ * hist: u8 [B][Tm][2*nbins][H][W] (channel = polarity*nbins + bin); n_valid (nullable, int32 [B]): sample b supplies
+ * only its first n_valid[b] slices, which become the LAST n_valid[b] output slices.  out: fp32 [B][Tm][2][Hc][Wc]
+ * (the model input [B][Tl=1][Tm][2][Hc][Wc]), Hc >= H, Wc >= W, Wc % 16 == 0.  Integer sums (<= 255*nbins): bit-exact. */
+int eas_stacked_hist_event_sum(const uint8_t* hist, const int32_t* n_valid, int B, int Tm, int nbins, int H, int W, int Hc,
+                               int Wc, float* out, eas_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  multi-step (P)LIF neuron.  Replaces spikingjelly ParametricLIFNode / LIFNode
  *     multi_step_forward (call site yolox/utils/utils_snn.py:44-53): per step
@@ -127,6 +142,14 @@ int eas_lif_bwd(const float* grad_s, const float* grad_mean, const float* h_save
                 eas_stream_t stream);
 
 int64_t eas_reduce_workspace_floats(int64_t M);
+
+/* eas_lif_bwd for the learnable arctan surrogate (EAS_SG_PATAN): alpha is a DEVICE scalar (no host read), the slope uses
+ * |*alpha|; grad_alpha (nullable) receives dL/dalpha = sign(alpha) * sum over neuron-steps of dL/ds_t * u/2 / (1 + (pi/2 |alpha| u)^2),
+ * u = h_t - v_th, where dL/ds_t includes the path through the reset unless EAS_LIF_DETACH_RESET (fixed-order reduction). */
+int eas_lif_bwd_patan(const float* grad_s, const float* grad_mean, const float* h_save, const float* v_init,
+                      const float* x, const float* w_logit, float k_const, float v_th, float v_reset, int flags,
+                      const float* alpha, float* grad_alpha, float* grad_x, float* grad_w, float* workspace, int T, int64_t M,
+                      eas_stream_t stream);
 
 /* mean over the leading T axis: [T][M] -> [M] (out_features[f].mean(axis=0)). */
 int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t stream);
@@ -197,7 +220,12 @@ int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_me
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
                       float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
-
+/* eas_bn_lif_bwd_ex for the learnable arctan surrogate (see eas_lif_bwd_patan). */
+int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, const float* v_init,
+                         const float* w_logit, float k_const, float v_th, float v_reset, int flags, const float* alpha,
+                         float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
+                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
 
 /* BatchNorm2d + SiLU fused for the real-valued BaseConv blocks (stem, PAFPN neck, head:
  * yolox/models/network_blocks.py:52-53 with nn.SiLU); y: conv output [N][C][HW]; mean/invstd from eas_bn_stats

@@ -62,6 +62,27 @@ def micro_sum(t, x, y, p, num_micro, height, width):
     return np.stack([aggregate_sum(x[a:b], y[a:b], p[a:b], height, width) for a, b in bounds])
 
 
+def stacked_hist_event_sum(ev_repr, num_slice, height, width):
+    """RVT stacked-histogram slices -> per-polarity counts, restating RVTGEN4Dataset.generate_slices(method='event_sum')
+    (yolox/data/datasets/rvt_gen4.py:118-125) from the point where ``ev_repr`` [n <= num_slice, 2*nbins, H, W] (u8) has been
+    read: reshape to [n, 2, nbins, H, W], sum over the bins (numpy promotes u8 sums to 64-bit: no wrap-around), zero slices
+    in FRONT up to num_slice, leading macro axis of 1.  Returns float64 [1, num_slice, 2, H, W] like the reference.
+    Pinned by tests/golden/stacked_hist.npz (generated from the reference method, oracle/gen_golden.py)."""
+    ev_repr = np.asarray(ev_repr)
+    n = ev_repr.shape[0]
+    summed = ev_repr.reshape(n, 2, -1, height, width).sum(axis=2)
+    pad = np.zeros([num_slice - n] + list(summed.shape[1:]))
+    return np.expand_dims(np.concatenate([pad, summed], axis=0), axis=0)
+
+
+def pad_to_canvas(frames, canvas_h, canvas_w):
+    """zero padding bottom/right of the trailing two axes: the validation letterbox of get_random_data at scale 1, dx = dy = 0
+    (gen1.py:447-455, rvt_gen4.py:516-533)"""
+    out = np.zeros(frames.shape[:-2] + (canvas_h, canvas_w), dtype=frames.dtype)
+    out[..., :frames.shape[-2], :frames.shape[-1]] = frames
+    return out
+
+
 def micro_sum_batch(t, x, y, p, sample_offsets, num_micro, height, width):
     """Batched form used to check the HIP kernel: events of sample b are
     ``[sample_offsets[b], sample_offsets[b+1])``.  Returns int32 [B, Tm, 2, H, W]."""

@@ -55,7 +55,17 @@ _SHIMS = {
     'pycocotools/coco.py': 'class COCO: pass\n',
     'pycocotools/cocoeval.py': 'class COCOeval: pass\n',
     'pycocotools/mask.py': '',
-    'h5py/__init__.py': 'class File: pass\n',
+    # container stand-in for the HDF5 reader: `File(path)['data']` is the array stored next to it as <path>.npy (no arithmetic)
+    'h5py/__init__.py': '''
+        import numpy as _np
+        class File:
+            def __init__(self, path, mode='r'):
+                self._d = {'data': _np.load(path + '.npy', mmap_mode='r')}
+            def __enter__(self):
+                return self._d
+            def __exit__(self, *a):
+                return False
+    ''',
     'thop/__init__.py': 'def profile(*a, **k): raise NotImplementedError\n',
 }
 
@@ -353,6 +363,183 @@ def gen_lif_layer():
          gdecay=_np(lay.cell.decay.grad))
 
 
+# ----------------------------------------------------------------------------- 8f rank 3: SOP / energy estimate
+def gen_energy():
+    """EventEvaluator.energy_estimation (yolox/evaluators/event_evaluator.py:466-565) itself, run on the CPU: its CUDA-only tensor
+    moves are patched to the identity for the duration of the call (Tensor.cuda, torch.cuda.FloatTensor -> the CPU type; no
+    arithmetic in them) and the figures it prints are captured at full precision (Tensor.__format__ -> repr of the float).  The model
+    is the reference's own SYOLOX-S from EventExp.get_model with the procedural fill; two batches, NO reset between them (the
+    method does not reset the neurons between batches)."""
+    import re
+    import types
+    import yolox.evaluators.event_evaluator as ee
+    from yolox.exp import get_exp
+    from spikingjelly.activation_based import functional
+    from oracle.fill import ANN_KEYS, poisson_events, procedural_fill_
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(['T', '3', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
+               'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True', 'spike_fn', 'atan', 'use_spike', 'True'])
+    torch.manual_seed(80)
+    model = exp.get_model()
+    crc = procedural_fill_(model, 2.0, ann_regex=ANN_KEYS['True'])
+    seeds = (5, 6)
+    batches = [(torch.from_numpy(poisson_events((3, 1, 4, 2, 64, 96), 0.5, seed=s_)), None, None, None) for s_ in seeds]
+    lines = []
+    saved = (torch.Tensor.cuda, torch.cuda.FloatTensor, torch.Tensor.__format__, getattr(ee, 'print', None))
+    try:
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.cuda.FloatTensor = torch.FloatTensor
+        torch.Tensor.__format__ = lambda self, spec: repr(float(self)) if self.dim() == 0 else object.__format__(self, spec)
+        ee.print = lambda *a, **k: lines.append(' '.join(str(v) for v in a))
+        ee.EventEvaluator.energy_estimation(types.SimpleNamespace(dataloader=batches), model, exp)
+    finally:
+        torch.Tensor.cuda, torch.cuda.FloatTensor, torch.Tensor.__format__ = saved[:3]
+        if saved[3] is None:
+            del ee.print
+        else:
+            ee.print = saved[3]
+    functional.reset_net(model)
+    text = '\n'.join(lines)
+    num = r'([-+0-9.eE]+|inf|nan)'
+    tot = re.search(r'SOP in SNN: ' + num + r', SOP in ANN ' + num, text)
+    arrays = {'sop_snn_G': np.float64(tot.group(1)), 'sop_ann_G': np.float64(tot.group(2)),
+              'snn_energy': np.float64(re.search(r'SNN Energy:' + num, text).group(1)),
+              'ann_energy': np.float64(re.search(r'ANN Energy:' + num, text).group(1))}
+    for key in ('embedding', 'backbone', 'fpn', 'head'):
+        m = re.search(key + r': SOP in SNN: ' + num + r', SOP in ANN ' + num, text)
+        arrays[f'ac_G/{key}'] = np.float64(m.group(1))
+        arrays[f'mac_G/{key}'] = np.float64(m.group(2))
+    save('energy_estimation', seeds=np.array(seeds), shape=np.array((3, 1, 4, 2, 64, 96)), crc=np.uint32(crc), T=np.int64(exp.T),
+         printed=np.array(text), **arrays)
+    print(text)
+
+
+# ----------------------------------------------------------------------------- config-4 input: RVT stacked histogram
+def gen_stacked_hist():
+    """RVTGEN4Dataset.generate_slices(file, time, num_slice, 'event_sum') (rvt_gen4.py:109-125) called unbound on a synthetic
+    representation directory: the index arrays are real .npy files, the HDF5 container is stood in for by an .npy next to it."""
+    import types
+    from yolox.data.datasets.rvt_gen4 import RVTGEN4Dataset
+    rng = np.random.default_rng(44)
+    rep_name = 'stacked_histogram_dt=50_nbins=10'
+    arrays = {}
+    names = []
+    for name, (H, W, n_repr, nbins, hi) in {'small': (12, 16, 9, 10, 4), 'saturated': (6, 32, 6, 10, 256), 'ragged_w': (5, 21, 5, 10, 7),
+                                            'bins3': (4, 16, 5, 3, 50)}.items():
+        root = tempfile.mkdtemp(prefix='eas_rvt_')
+        rep_dir = os.path.join(root, 'event_representations_v2', rep_name)
+        os.makedirs(rep_dir)
+        data = rng.integers(0, hi, (n_repr, 2 * nbins, H, W)).astype(np.uint8)
+        if name == 'saturated':
+            data[2:] = 255                                       # sums of 2550 must not wrap around in 8 bits
+        obj2repr = np.arange(n_repr, dtype=np.int64)
+        np.save(os.path.join(rep_dir, 'objframe_idx_2_repr_idx.npy'), obj2repr)
+        np.save(os.path.join(rep_dir, 'timestamps_us.npy'), (np.arange(n_repr) + 1) * 50000)
+        np.save(os.path.join(rep_dir, 'event_representations_ds2_nearest.h5.npy'), data)
+        me = types.SimpleNamespace(files=[root], rep_name=rep_name, img_size=(H, W))
+        arrays[f'{name}/data'] = data
+        for time, num_slice in ((n_repr - 1, 4), (1, 4), (0, 3), (3, 1), (2, 3)):
+            out = RVTGEN4Dataset.generate_slices(me, 0, time, num_slice, 'event_sum')
+            key = f'{name}/t{time}_n{num_slice}'
+            arrays[key] = out
+            names.append(key)
+            assert out.shape == (1, num_slice, 2, H, W) and out.dtype == np.float64
+    arrays['cases'] = np.array(names)
+    save('stacked_hist', **arrays)
+
+
+# ----------------------------------------------------------------------------- a10 'patan'
+def gen_patan():
+    """The reference's own EfficientNoisySpikeII(InvArcTanh(alpha), p=0) (activation.py:121-130,181-205; what 'patan' selects at
+    event_yolox_base.py:145-150) as the surrogate of a ParametricLIFNode configured as utils_snn.py:44-53: spikes, input gradient,
+    dL/dw and dL/dalpha for train mode (positive and negative alpha), spikes for eval mode; then one converted BaseConv and a
+    whole SYOLOX-S built by the reference's EventExp with spike_fn='patan'."""
+    from yolox.models.activation import EfficientNoisySpikeII, InvArcTanh
+    from yolox.models.network_blocks import BaseConv
+    from yolox.utils.utils_snn import convert_to_spiking
+    from spikingjelly.activation_based import functional, neuron
+    from oracle.fill import procedural_fill_
+    rng = np.random.default_rng(21)
+    T, M = 4, 4096
+    xn = (rng.standard_normal((T, M)) * 0.9 + 0.45).astype(np.float32)
+    xn[0, :64] = 1.0                      # exact-threshold inputs (v = 0 * 0.5 + 1.0 -> u = 0 -> fires under '>=')
+    xn[1, 64:128] = 0.5
+    g = rng.standard_normal((T, M)).astype(np.float32)
+    for tag, alpha, detach in (('pos', 2.0, False), ('neg', -1.5, False), ('detach', 2.0, True)):
+        sf = EfficientNoisySpikeII(InvArcTanh(alpha), p=0)
+        node = neuron.ParametricLIFNode(init_tau=2.0, decay_input=False, v_threshold=1.0, v_reset=None, surrogate_function=sf,
+                                        detach_reset=detach, step_mode='m', backend='torch')
+        node.train()
+        x = torch.from_numpy(xn).requires_grad_(True)
+        s = node(x)
+        s.backward(torch.from_numpy(g))
+        arrays = dict(x=xn, gout=g, spikes=_np(s), gx=_np(x.grad), gw=_np(node.w.grad), galpha=_np(sf.inv_sg.alpha.grad),
+                      alpha=np.float32(alpha), detach=np.bool_(detach), v_final=_np(node.v))
+        functional.reset_net(node)
+        node.eval()
+        with torch.no_grad():
+            arrays['spikes_eval'] = _np(node(torch.from_numpy(xn)))
+        assert np.array_equal(arrays['spikes_eval'], arrays['spikes']), 'train-mode forward of patan is not the exact Heaviside step'
+        save(f'lif_patan_{tag}', **arrays)
+
+    # one converted block, train mode
+    mod = convert_to_spiking(BaseConv(8, 16, 1, 1), EfficientNoisySpikeII(InvArcTanh(2.0), p=0))
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    crc = procedural_fill_(mod, conv_gain=2.5)
+    mod.train()
+    xb = (rng.random((3, 2, 8, 12, 16)) < 0.3).astype(np.float32)
+    xx = torch.from_numpy(xb).requires_grad_(True)
+    out = mod(xx)
+    gb = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(torch.from_numpy(gb))
+    extra = {f'grad/{n}': _np(p.grad) for n, p in mod.named_parameters()}
+    extra.update({f'buf/{n}': _np(b) for n, b in mod.named_buffers()})
+    save('block_baseconv1x1_patan_train', x=xb, out=_np(out), gout=gb, gx=_np(xx.grad), crc=np.uint32(crc),
+         keys=np.array(list(mod.state_dict().keys())), **extra)
+
+    # whole model through the reference's EventExp
+    from yolox.exp import get_exp
+    from oracle.fill import ANN_KEYS, poisson_events
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(['T', '3', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
+               'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True', 'spike_fn', 'patan', 'use_spike', 'True'])
+    torch.manual_seed(80)
+    model = exp.get_model()
+    crc = procedural_fill_(model, conv_gain=2.0, ann_regex=ANN_KEYS['True'])
+    x = torch.from_numpy(poisson_events((2, 1, exp.Tm, 2, 64, 64), 0.5, seed=17))
+    model.eval()
+    with torch.no_grad():
+        logits = model(x)
+    functional.reset_net(model)
+    arrays = dict(x=_np(x), logits=_np(logits), crc=np.uint32(crc), keys=np.array(list(model.state_dict().keys())), gain=np.float32(2.0),
+                  nparam=np.int64(sum(p.numel() for p in model.parameters())))
+    model.train()
+    model.head.use_l1 = True
+    tg = torch.zeros(2, 50, 5)
+    for b in range(2):
+        tg[b, 0] = torch.tensor([0, 64 * 0.3, 64 * 0.4, 64 * 0.25, 64 * 0.3])
+        tg[b, 1] = torch.tensor([1, 64 * 0.7, 64 * 0.6, 64 * 0.2, 64 * 0.35])
+    out = model(x, tg)
+    out['total_loss'].backward()
+    functional.reset_net(model)
+    for k in ('total_loss', 'iou_loss', 'l1_loss', 'conf_loss', 'cls_loss'):
+        arrays[f'loss/{k}'] = np.float32(float(out[k]))
+    arrays['loss/num_fg'] = np.float32(out['num_fg'])
+    arrays['targets'] = _np(tg)
+    gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.grad is not None}
+    arrays['gradnorm_keys'] = np.array(list(gn))
+    arrays['gradnorm_vals'] = np.array(list(gn.values()), np.float32)
+    for n, p in model.named_parameters():
+        if n.endswith('inv_sg.alpha') or n.endswith('act.w'):
+            arrays[f'grad/{n}'] = _np(p.grad)
+    opt_groups = [len(gr['params']) for gr in exp.get_optimizer(2).param_groups]
+    arrays['optimizer_group_sizes'] = np.array(opt_groups)
+    save('model_s_true_patan_64', **arrays)
+    print('    optimizer groups', opt_groups, ' alpha grads', sum(1 for k in arrays if k.startswith('grad/') and k.endswith('alpha')))
+
+
 # ----------------------------------------------------------------------------- a12 blocks
 def gen_blocks():
     from yolox.models.network_blocks import BaseConv, CSPLayer, SPPBottleneck
@@ -468,11 +655,11 @@ def gen_models():
 def main():
     torch.set_num_threads(8)
     setup_reference_imports()
-    which = sys.argv[1:] or ['events', 'reps', 'augment', 'embeddings', 'lif', 'blocks', 'models']
+    which = sys.argv[1:] or ['events', 'reps', 'augment', 'embeddings', 'lif', 'patan', 'stacked_hist', 'energy', 'blocks', 'models']
     for w in which:
         print(f'[{w}]')
         {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
-         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment}[w]()
+         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy}[w]()
     assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
 
 

@@ -427,6 +427,8 @@ def build_model(**overrides):
         fn = sj.ATan(c['alpha'])
     elif c['spike_fn'] == 'sigmoid':
         fn = sj.Sigmoid(c['alpha'])
+    elif c['spike_fn'] == 'patan':
+        fn = sj.PATan(c['alpha'])
     else:
         raise NotImplementedError(c['spike_fn'])
     if c['embedding'] == 'arsnn':

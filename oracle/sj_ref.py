@@ -100,6 +100,44 @@ class Sigmoid(_SurrogateBase):
         return (x * self.alpha).sigmoid()
 
 
+class InvArcTanh(nn.Module):
+    """sigma(x) = atan(pi/2 * |alpha| * x) / pi + 1/2 with a learnable alpha of shape [1]
+    (restates yolox/models/activation.py:121-130; pinned by tests/golden/lif_patan*.npz generated from the reference class)."""
+
+    def __init__(self, alpha=1.0, learnable=True):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.tensor([float(alpha)])) if learnable else alpha
+
+    def forward(self, x, gates=None):
+        return 1.0 / math.pi * torch.atan(math.pi / 2.0 * torch.abs(self.alpha) * x) + 0.5
+
+
+class EfficientNoisySpikeII(nn.Module):
+    """'patan' = EfficientNoisySpikeII(InvArcTanh(alpha), p=0) (event_yolox_base.py:145-150; activation.py:181-205).
+    Training: sigma(x) + ((x >= 0) - sigma(x)) * mask, detached second term, mask ~ Bernoulli(1 - p) drawn once;
+    eval: Heaviside.  With p = 0 the mask is all ones: the forward value is exactly the Heaviside step (for x >= 0
+    sigma >= 1/2, so 1 - sigma and sigma + (1 - sigma) are exact in fp32) and the gradient is sigma's."""
+
+    def __init__(self, inv_sg, p=0.5, spike=True):
+        super().__init__()
+        self.inv_sg = inv_sg
+        self.p = p
+        self.spike = spike
+        self.mask = None
+
+    def forward(self, x, gates=None):
+        sigx = self.inv_sg(x, gates)
+        if self.training:
+            if self.mask is None:
+                self.mask = torch.bernoulli(torch.ones_like(x) * (1 - self.p))
+            return sigx + (((x >= 0).float() - sigx) * self.mask).detach()
+        return (x >= 0).float() if self.spike else sigx
+
+
+def PATan(alpha=2.0):
+    return EfficientNoisySpikeII(InvArcTanh(alpha), p=0)
+
+
 # ----------------------------------------------------------------------------- base
 class MemoryModule(nn.Module):
     """Stateful module: memories live outside ``state_dict`` and are restored by ``reset()``."""

@@ -1,8 +1,11 @@
 """TEST INFRASTRUCTURE -- CPU restatement of the reference's SOP / energy estimate.
 
 What the reference does (EventEvaluator.energy_estimation, yolox/evaluators/event_evaluator.py:466-565, with the
-input-recording hook of yolox/utils/hooks.py:31-44), restated here without its CUDA-only tensor moves (the method cannot
-run without a CUDA device, so it cannot be executed in the build container):
+input-recording hook of yolox/utils/hooks.py:31-44), restated here without its CUDA-only tensor moves.  PINNED: oracle/gen_golden.py
+runs the reference method itself on the CPU (its ``.cuda()`` moves patched to the identity) and
+tests/test_oracle_golden.py::test_energy_estimation_restatement_matches_the_reference_function holds this file to the figures it
+printed (tests/golden/energy_estimation.npz).  The reference does not reset the neurons between batches: ``reset_fn=None``
+reproduces that.
 
 * the layers that count are the nn.Conv2d modules found by walking ``model.named_children()``: the children of
   ``model.backbone`` are filed under 'backbone' (the child called 'backbone') or 'fpn' (every other child), the

@@ -95,7 +95,8 @@ def test_exp_merge_type_coercion_quirks():
 
 @pytest.mark.parametrize('name,use_spike,extra', [('model_s_true_64', 'True', []), ('model_s_full_64', 'full_spike', []),
                                                   ('model_s_fullv2_64', 'full_spike_v2', []), ('model_s_false_64', 'False', []),
-                                                  ('model_m_fullv2_t5_64x96', 'full_spike_v2', ['T', '5'])])
+                                                  ('model_m_fullv2_t5_64x96', 'full_spike_v2', ['T', '5']),
+                                                  ('model_s_true_patan_64', 'True', ['spike_fn', 'patan'])])
 def test_model_tree_and_checkpoint_keys_match_reference(name, use_spike, extra):
     from spikingjelly.activation_based import layer, neuron
     from yolox.exp import get_exp
@@ -116,7 +117,11 @@ def test_model_tree_and_checkpoint_keys_match_reference(name, use_spike, extra):
         assert type(model.backbone.backbone.stem).__name__ == 'SeqToANNContainer'
         assert isinstance(model.backbone.backbone.stem[0].conv.act, torch.nn.SiLU)          # stem stays ANN
         opt = exp.get_optimizer(64)
-        assert [len(g_['params']) for g_ in opt.param_groups] == [74, 83, 83, 34, 8]
+        if 'patan' in name:     # every neuron also owns the learnable slope ...surrogate_function.inv_sg.alpha (activation.py:121-124)
+            assert [len(g_['params']) for g_ in opt.param_groups] == list(g['optimizer_group_sizes']) == [74, 83, 83, 68, 8]
+            assert sum(k.endswith('act.surrogate_function.inv_sg.alpha') for k in model.state_dict()) == 34
+        else:
+            assert [len(g_['params']) for g_ in opt.param_groups] == [74, 83, 83, 34, 8]
 
 
 def test_neuron_state_and_reset_semantics():
@@ -270,3 +275,35 @@ def test_no_file_is_a_token_level_copy_of_its_reference_namesake():
                 worst.append((share, os.path.relpath(os.path.join(d, f), ROOT), os.path.relpath(r, ref_root)))
     worst.sort(reverse=True)
     assert worst and worst[0][0] < 0.72, f'token-level similarity to the reference too high: {worst[:3]}'
+
+
+def _run_bench(argv, env_extra=None, drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK')):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=300)
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` (no WORLD_SIZE): the parent starts two children, they rendezvous (gloo here, RCCL on the GPU box),
+    exchange gradients through FlatGradAllReduce and rank 0 prints ONE line reporting two ranks (reference: the tools spawn
+    their workers, yolox/core/launch.py:59-98)."""
+    import json
+    r = _run_bench(['--gpus', '2', '--selftest-cpu', '--steps', '3', '--warmup', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['spawned_by_bench'] and rec['gradient_exchange'] == 'flat'
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    r = _run_bench(['--gpus', '2', '--selftest-cpu'], env_extra={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'}, drop=())
+    assert r.returncode != 0 and 'rank' in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """a rank that dies takes the launch down with a non-zero code instead of leaving the others in a collective"""
+    r = _run_bench(['--gpus', '2', '--selftest-cpu', '--steps', '1', '--warmup', '0'], env_extra={'EAS_BENCH_SELFTEST_FAIL_RANK': '1'})
+    assert r.returncode != 0

@@ -193,6 +193,61 @@ def test_event_histogram_full_size_properties(dev):
         assert np.array_equal(out[b].cpu().numpy(), ref.astype(np.int32))
 
 
+def test_stacked_hist_event_sum_golden_bit_exact(dev):
+    """eas_stacked_hist_event_sum (config-4 input) against outputs of the reference's RVTGEN4Dataset.generate_slices('event_sum')
+    (rvt_gen4.py:109-125): every fixture case as one ragged batch per representation geometry (young sequences = zero slices in
+    front via n_valid), canvas padding included, bit for bit."""
+    from eas_snn_amd import ops
+    from test_oracle_golden import _stacked_hist_cases
+    groups = {}
+    for key, sl, num_slice, want in _stacked_hist_cases():
+        groups.setdefault((key.split('/')[0], num_slice), []).append((key, sl, want))
+    assert len(groups) >= 8
+    for (name, Tm), items in groups.items():
+        H, W = items[0][2].shape[-2:]
+        nb2 = items[0][1].shape[1]
+        Hc, Wc = ((H + 31) // 32) * 32, ((W + 31) // 32) * 32
+        hist = np.zeros((len(items), Tm, nb2, H, W), np.uint8)
+        nv = np.zeros(len(items), np.int32)
+        for b, (_, sl, _) in enumerate(items):
+            hist[b, :len(sl)] = sl
+            hist[b, len(sl):] = 201                      # slots beyond n_valid must never be read into the result
+            nv[b] = len(sl)
+        out = ops.stacked_hist_event_sum(_t(hist, dev), Hc, Wc, nbins=nb2 // 2, n_valid=_t(nv, dev)).cpu().numpy()
+        assert out.shape == (len(items), 1, Tm, 2, Hc, Wc) and out.dtype == np.float32
+        for b, (key, _, want) in enumerate(items):
+            assert np.array_equal(out[b, 0, :, :, :H, :W].astype(np.float64), want[0]), key
+            assert not out[b, 0, :, :, H:, :].any() and not out[b, 0, :, :, :, W:].any(), key
+
+
+def test_stacked_hist_event_sum_full_size_vs_oracle(dev):
+    """BASELINE configs[3] shape: [B, Tm, 20, 360, 640] u8 -> [B, 1, Tm, 2, 384, 640]; the oracle on two samples, and for the whole
+    batch the size-independent properties: total count preserved (sum of checksums), linearity in the input, zero padding."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    B, Tm, H, W, Hc, Wc = 16, 4, 360, 640, 384, 640
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    hist = torch.poisson(torch.full((B, Tm, 20, H, W), 0.3), generator=gen).clamp_(max=255).to(torch.uint8)
+    d = hist.to(dev)
+    out = ops.stacked_hist_event_sum(d, Hc, Wc)
+    assert out.shape == (B, 1, Tm, 2, Hc, Wc)
+    for b in (0, B - 1):
+        want = events_ref.pad_to_canvas(events_ref.stacked_hist_event_sum(hist[b].numpy(), Tm, H, W), Hc, Wc)
+        assert np.array_equal(out[b].cpu().numpy().astype(np.float64), want)
+    assert float(out.double().sum()) == float(hist.double().sum())
+    assert not out[..., H:, :].any()
+    twice = ops.stacked_hist_event_sum((d * 2).to(torch.uint8), Hc, Wc)
+    assert torch.equal(twice, out * 2)
+    nv = torch.tensor([Tm - (b % (Tm + 1)) for b in range(B)], dtype=torch.int32, device=dev)   # 0..Tm valid slices
+    part = ops.stacked_hist_event_sum(d, Hc, Wc, n_valid=nv)
+    for b in range(B):
+        n = int(nv[b])
+        assert not part[b, 0, :Tm - n].any() and torch.equal(part[b, 0, Tm - n:], out[b, 0, :n])
+    import eas_snn_amd
+    with pytest.raises(eas_snn_amd.EasHipError):
+        ops.stacked_hist_event_sum(hist, Hc, Wc)                 # CPU tensor: no fallback
+
+
 def test_event_histogram_out_of_range_is_counted(dev):
     from eas_snn_amd import ops
     t = torch.arange(100, 200, dtype=torch.int32, device=dev).view(torch.uint32)
@@ -459,6 +514,63 @@ def test_lif_golden_inrepo_liflayer(dev):
     np.testing.assert_allclose(-w.grad.item(), g['gdecay'], rtol=1e-4)
 
 
+@pytest.mark.parametrize('tag', ['pos', 'neg', 'detach'])
+def test_lif_patan_golden(dev, tag):
+    """'patan' = EfficientNoisySpikeII(InvArcTanh(alpha), p=0) with a learnable alpha, vectors from the reference's own classes
+    (activation.py:121-130,181-205) inside a PLIF node: spikes bit-exact, grad_x, dL/dw and dL/dalpha (alpha stays on the device:
+    eas_lif_bwd_patan takes the pointer and reduces the gradient in a fixed order)."""
+    from eas_snn_amd import ops
+    g = load_golden(f'lif_patan_{tag}')
+    x = _t(g['x'], dev).requires_grad_(True)
+    w = torch.zeros((), device=dev, requires_grad=True)
+    alpha = torch.tensor([float(g['alpha'])], device=dev, requires_grad=True)
+    flags = ops.FLAG_DETACH_RESET if bool(g['detach']) else 0
+    s, v, _ = ops.lif_multistep(x, None, w, 0.0, 1.0, 0.0, flags, 'patan', alpha, write_v=True)
+    s.backward(_t(g['gout'], dev))
+    assert np.array_equal(s.detach().cpu().numpy(), g['spikes']) and np.array_equal(g['spikes'], g['spikes_eval'])
+    np.testing.assert_allclose(v.cpu().numpy(), g['v_final'], rtol=0, atol=0)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.grad.item(), g['gw'], rtol=1e-4)
+    np.testing.assert_allclose(alpha.grad.cpu().numpy(), g['galpha'], rtol=1e-4)
+    # run-to-run identical (fixed-order reduction)
+    a2 = torch.tensor([float(g['alpha'])], device=dev, requires_grad=True)
+    x2 = _t(g['x'], dev).requires_grad_(True)
+    ops.lif_multistep(x2, None, w.detach().clone().requires_grad_(True), 0.0, 1.0, 0.0, flags, 'patan', a2, write_v=True)[0].backward(_t(g['gout'], dev))
+    assert torch.equal(a2.grad, alpha.grad)
+    with pytest.raises(Exception):
+        ops.lif_multistep(x.detach(), None, w, 0.0, 1.0, 0.0, flags, 'patan', 2.0)      # a python float is not a learnable alpha
+
+
+def test_block_patan_golden(dev):
+    """converted BaseConv with the 'patan' spike function, train mode, against the reference (fused BN+LIF backward with the
+    learnable slope: eas_bn_lif_bwd_patan)."""
+    from oracle import fill
+    from spikingjelly.activation_based import functional
+    from yolox.models.activation import EfficientNoisySpikeII, InvArcTanh
+    from yolox.models.network_blocks import BaseConv
+    from yolox.utils.utils_snn import convert_to_spiking
+    g = load_golden('block_baseconv1x1_patan_train')
+    mod = convert_to_spiking(BaseConv(8, 16, 1, 1), EfficientNoisySpikeII(InvArcTanh(2.0), p=0))
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    assert [str(k) for k in g['keys']] == list(mod.state_dict().keys())
+    assert fill.procedural_fill_(mod, conv_gain=2.5) == int(g['crc'])
+    mod.to(dev).train()
+    x = _t(g['x'], dev).requires_grad_(True)
+    out = mod(x)
+    flips = int((out.detach().cpu().numpy() != g['out']).sum())
+    print(f'block_baseconv1x1_patan_train: {flips} spike flips')
+    assert flips == 0
+    out.backward(_t(g['gout'], dev))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=2e-3, atol=2e-5)
+    for n, p in mod.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=5e-3, atol=5e-4, err_msg=n)
+    for n, b in mod.named_buffers():
+        np.testing.assert_allclose(b.cpu().numpy(), g[f'buf/{n}'], rtol=1e-4, atol=1e-5, err_msg=n)
+    functional.reset_net(mod)
+
+
 def test_time_mean_and_rate_output(dev):
     from eas_snn_amd import ops
     x = torch.randn(3, 2, 4, 8, 8, device=dev, requires_grad=True)
@@ -575,6 +687,11 @@ def test_bn_lif_residual_and_inplace_concatenation(dev, train):
 ARSNN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'arsnn_*.npz')))
 
 
+# output elements allowed to differ from the reference per fixture (rounding-level threshold crossings of the sampler's
+# potential); measured on MI355X: none, except 2 of the 8-step / 7-segment fixture
+ARSNN_MAX_FLIPS = {'arsnn_ts7_tm8': 4}
+
+
 @pytest.mark.parametrize('name', ARSNN)
 def test_arsnn_golden(dev, name):
     from oracle import fill
@@ -597,10 +714,22 @@ def test_arsnn_golden(dev, name):
     ref_rec = g['t_record']                                  # the reference stops recording at its early exit
     assert (t_rec.cpu().numpy()[:len(ref_rec)] != ref_rec).mean() < 2e-3
     out.backward(_t(g['gout'], dev))
-    if not bad.any():
-        np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=2e-3, atol=1e-3)
-        for n, p in m.named_parameters():
-            np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=2e-3, atol=2e-3, err_msg=n)
+    # Gradients are compared UNCONDITIONALLY.  A fixture with no differing output element (all seven today: the assert below
+    # pins that) must match everywhere; were an element to flip, the input gradient may differ only inside the flip's receptive
+    # field and the parameter gradients (sums over all positions) by an amount proportional to the flipped share.
+    nbad = int(bad.sum())
+    print(f'{name}: {nbad} of {bad.size} outputs differ from the reference (flips)')
+    gx, gx_ref = x.grad.cpu().numpy(), g['gx']
+    mism = ~np.isclose(gx, gx_ref, rtol=2e-3, atol=1e-3)
+    reach = (2 * (k // 2) * depth * Tm + 1) ** 2 * 2 * Tm            # elements of x one output element can depend on
+    assert mism.mean() <= min(1.0, bad.mean() * reach), f'{mism.mean():.2e} of the input gradient differs with {nbad} flips'
+    for n, p in m.named_parameters():
+        got_g, ref_g = p.grad.cpu().numpy().astype(np.float64), g[f'grad/{n}'].astype(np.float64)
+        rel = np.linalg.norm(got_g - ref_g) / (np.linalg.norm(ref_g) + 1e-12)
+        assert rel <= 2e-3 + 50.0 * bad.mean(), f'{n}: relative gradient error {rel:.2e} with {nbad} flips'
+        if nbad == 0:
+            np.testing.assert_allclose(got_g, ref_g, rtol=2e-3, atol=2e-3, err_msg=n)
+    assert nbad <= ARSNN_MAX_FLIPS.get(name, 0), f'{name}: {nbad} output elements differ (expected at most {ARSNN_MAX_FLIPS.get(name, 0)})'
 
 
 # ------------------------------------------------------------------------------------------------ sampler convs

@@ -53,10 +53,14 @@ def test_blocks_golden(dev, kind, mode):
         out.backward(torch.from_numpy(g['gout']).to(dev))
         for n, b in mod.named_buffers():
             np.testing.assert_allclose(b.cpu().numpy(), g[f'buf/{n}'], rtol=1e-4, atol=1e-5, err_msg=n)
-        if flips == 0.0:
-            np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=2e-3, atol=2e-5)
-            for n, p in mod.named_parameters():
-                np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=5e-3, atol=5e-4, err_msg=n)
+        # gradients are compared unconditionally: the four train fixtures have no spike flip on MI355X (asserted), so every
+        # element must match
+        nflip = int((got != g['out']).sum())
+        print(f'block_{kind}_{mode}: {nflip} spike flips of {got.size}')
+        assert nflip == 0, f'block_{kind}_train: {nflip} spikes differ from the reference'
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g['gx'], rtol=2e-3, atol=2e-5)
+        for n, p in mod.named_parameters():
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g[f'grad/{n}'], rtol=5e-3, atol=5e-4, err_msg=n)
     functional.reset_net(mod)
 
 
@@ -68,6 +72,7 @@ MODELS = {
     'model_s_true_256x320': ('e-yolox-s', ['use_spike', 'True']),
     'model_m_fullv2_t5_64x96': ('e-yolox-m', ['use_spike', 'full_spike_v2', 'T', '5']),
     'model_s_true_ts3_64': ('e-yolox-s', ['use_spike', 'True', 'Ts', '3']),
+    'model_s_true_patan_64': ('e-yolox-s', ['use_spike', 'True', 'spike_fn', 'patan']),
 }
 
 
@@ -163,7 +168,7 @@ def test_layerwise_teacher_forced_parity_256x320(dev):
           f'worst membrane-potential rel err {worst_v:.2e}')
 
 
-@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64'])
+@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64', 'model_s_true_patan_64'])
 def test_model_train_step_golden(dev, name):
     from spikingjelly.activation_based import functional
     g, model = _build(name, dev)
@@ -241,8 +246,8 @@ def test_forward_after_fused_adam_step_uses_updated_weights(dev):
     assert all(gr.get('fused') for gr in opt.param_groups), 'the GPU optimizer of the exp is the fused Adam'
     for gr in opt.param_groups:
         gr['lr'] = 3e-3                      # large enough that every weight visibly moves
-    x = torch.from_numpy(fill.poisson_events((2, 1, 4, 2, 64, 96), 0.5, seed=11)).to(dev)
-    tg = data.synth_targets(2, (64, 96), dev)
+    x = torch.from_numpy(fill.poisson_events((2, 1, 4, 2, 64, 128), 0.5, seed=11)).to(dev)
+    tg = data.synth_targets(2, (64, 128), dev)
     hip.eval()
     with torch.no_grad():
         before = hip(x).clone()
@@ -270,8 +275,12 @@ def test_forward_after_fused_adam_step_uses_updated_weights(dev):
         finally:
             ops.packed_weights = real_scope
         functional.reset_net(hip)
-    assert torch.equal(after, unpacked), 'forward after the optimizer step used stale packed weights'
-    assert not torch.equal(after, before)
+    # stale weights would reproduce `before` (the update moves the logits by O(1)); the two packing routes agree to rounding (the few
+    # layers the library convolution still runs -- odd widths, 1/2/4-channel outputs -- are not bit-reproducible between calls)
+    moved = float((after - before).abs().max())
+    gap = float((after - unpacked).abs().max())
+    print(f'logits moved by {moved:.3g} with the update; packed-scope vs per-call packing differ by {gap:.3g}')
+    assert moved > 0.05 and gap < 1e-3 * max(1.0, moved), 'forward after the optimizer step used stale packed weights'
     # (b) the oracle with the updated state
     ref = model_ref.build_model(use_spike='True')
     ref.load_state_dict({k: v.detach().cpu() for k, v in hip.state_dict().items()})
@@ -303,29 +312,37 @@ def test_model_matches_cpu_oracle_on_fresh_input(dev):
     assert _frac_close(lh, lr, RTOL, 1e-4) > 0.97
 
 
-def test_energy_estimation_matches_reference_restatement(dev):
-    """eas_snn_amd.stats.energy_estimation (device taps + eas_spike_sop) against the statement-by-statement restatement of
-    EventEvaluator.energy_estimation (event_evaluator.py:466-565) on the torch-CPU oracle model with the same weights: MAC
-    counts are exact; accumulate counts depend on the spikes, which may differ by a few rounding-level flips between a GPU and a
-    CPU run of a spiking net, hence 2 %."""
+def test_energy_estimation_matches_the_reference_function(dev):
+    """eas_snn_amd.stats.energy_estimation (device taps + eas_spike_sop) against (a) the figures the reference's own
+    EventEvaluator.energy_estimation printed for the same weights and batches (tests/golden/energy_estimation.npz, generated by
+    running event_evaluator.py:466-565 on the CPU) and (b) the restated procedure on the torch-CPU oracle model.  MAC counts are
+    exact; accumulate counts depend on the spikes, which may differ by a few rounding-level flips between a GPU and a CPU run of a
+    spiking net: 1 %.  Like the reference, no reset between the batches."""
     from eas_snn_amd import stats
     from oracle import fill, model_ref, sj_ref, stats_ref
     from yolox.exp import get_exp
+    g = load_golden('energy_estimation')
     exp = get_exp(None, 'e-yolox-s')
     exp.merge(BASE_OPTS + ['use_spike', 'True'])
     hip = exp.get_model()
     ref = model_ref.build_model(use_spike='True')
-    assert fill.procedural_fill_(hip, 2.0, ann_regex=fill.ANN_KEYS['True']) == fill.procedural_fill_(ref, 2.0, ann_regex=fill.ANN_KEYS['True'])
-    batches = [torch.from_numpy(fill.poisson_events((3, 1, 4, 2, 64, 96), 0.5, seed=s)) for s in (5, 6)]
-    want = stats_ref.energy_estimation(ref, batches, T=3, reset_fn=sj_ref.reset_net)
+    assert fill.procedural_fill_(hip, 2.0, ann_regex=fill.ANN_KEYS['True']) == fill.procedural_fill_(ref, 2.0, ann_regex=fill.ANN_KEYS['True']) == int(g['crc'])
+    batches = [torch.from_numpy(fill.poisson_events(tuple(int(v) for v in g['shape']), 0.5, seed=int(s_))) for s_ in g['seeds']]
+    want = stats_ref.energy_estimation(ref, batches, T=3, reset_fn=None)
     got = stats.energy_estimation(hip.to(dev), [b.to(dev) for b in batches], T=3)
     assert got['num_samples'] == want['num_samples'] == 6
     for k in stats.GROUPS:
         assert got['module_mac'][k] == want['module_mac'][k], k
-        np.testing.assert_allclose(got['module_ac'][k], want['module_ac'][k], rtol=2e-2, err_msg=k)
+        np.testing.assert_allclose(got['module_mac'][k] / 6 / 1e9, float(g[f'mac_G/{k}']), rtol=1e-6, err_msg=k)     # fp32 sums in the reference
+        np.testing.assert_allclose(got['module_ac'][k], want['module_ac'][k], rtol=1e-2, err_msg=k)
+        np.testing.assert_allclose(got['module_ac'][k] / 6 / 1e9, float(g[f'ac_G/{k}']), rtol=1e-2, err_msg=k)
     assert got['module_ac']['embedding'] > 0 and got['module_ac']['backbone'] > 0
+    np.testing.assert_allclose(got['ann_energy'], float(g['ann_energy']), rtol=1e-6)
+    np.testing.assert_allclose(got['snn_energy'], float(g['snn_energy']), rtol=1e-2)
     np.testing.assert_allclose(got['ann_energy'], want['ann_energy'], rtol=1e-12)
-    np.testing.assert_allclose(got['snn_energy'], want['snn_energy'], rtol=2e-2)
+    # every batch from rest: differs from the carried-state figures (the second batch starts from other potentials)
+    rest = stats.energy_estimation(hip, [b.to(dev) for b in batches], T=3, reset_between_batches=True)
+    assert rest['module_mac'] == got['module_mac'] and rest['module_ac']['backbone'] != got['module_ac']['backbone']
     with pytest.raises(ValueError):                                    # the reference reshapes by T: batch 2 with T = 3 is an error
         stats.energy_estimation(hip, [batches[0][:2].to(dev)], T=3)
 
