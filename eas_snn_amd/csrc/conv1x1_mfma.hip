@@ -42,7 +42,9 @@ __device__ __forceinline__ void to_terms(const float (&v)[8], bf16x8 (&b)[XT]) {
     }
 }
 
-template <int XT, int WM, int WN>
+// RAGK: Cin is not a multiple of 8 (the input gradient of the 1/4/num_classes-channel prediction convolutions, whose "input" is
+// grad_y): channel validity is then tested per channel instead of per 8-channel group.
+template <int XT, int WM, int WN, bool RAGK = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                               const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,14 +84,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     // raw x of k-step ks: 8 channels (ks*16 + 8h + j) of this lane's pixel per N-tile.  Lanes without a pixel and channel
     // groups past Cin (Cin % 8 == 0) read the zero page with stride 0: unconditional loads, no per-element masking
     auto fetch = [&](float (&raw)[WN][8], int ks) {
-        const bool ch_ok = ks * 16 + 8 * h < g.Cin;
+        const int ch0 = ks * 16 + 8 * h;
+        const bool ch_ok = ch0 < g.Cin;
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const bool ok = ch_ok && xoff[n] >= 0;
             const float* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : eas_c1_zero_page;
             const long cs = ok ? (long)g.HW : 0;
+            if constexpr (RAGK) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) raw[n][j] = src[j * cs];
+                for (int j = 0; j < 8; ++j) raw[n][j] = *((ok && ch0 + j < g.Cin) ? src + j * cs : eas_c1_zero_page);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[n][j] = src[j * cs];
+            }
         }
     };
     auto step = [&](float (&raw)[WN][8], int ks) {
@@ -323,10 +331,10 @@ int launch_c1_shared(const float* x, const bf16x8* wp, const float* bias, float*
     return EAS_OK;
 }
 
-template <int XT, int WM, int WN>
+template <int XT, int WM, int WN, bool RAGK = false>
 int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
-    hipLaunchKernelGGL((conv1x1_mfma_kernel<XT, WM, WN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    hipLaunchKernelGGL((conv1x1_mfma_kernel<XT, WM, WN, RAGK>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
@@ -351,6 +359,14 @@ int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias
     static const long want = getenv("EAS_C1_BLOCKS") ? atol(getenv("EAS_C1_BLOCKS")) : 512;
     if (blocks(wm, wn) < want) wn = 1;
     while (blocks(wm, wn) < want && wm > 1) wm >>= 1;
+    if (Cin % 8 != 0) {     // ragged input channels: the direct kernel with per-channel validity (few channels: one pixel tile per wave)
+        if (x_terms == 1) {
+            if (g.MT >= 4) return launch_c1<1, 4, 1, true>(x, wp, bias, y, g, st);
+            return g.MT >= 2 ? launch_c1<1, 2, 1, true>(x, wp, bias, y, g, st) : launch_c1<1, 1, 1, true>(x, wp, bias, y, g, st);
+        }
+        if (g.MT >= 4) return launch_c1<3, 4, 1, true>(x, wp, bias, y, g, st);
+        return g.MT >= 2 ? launch_c1<3, 2, 1, true>(x, wp, bias, y, g, st) : launch_c1<3, 1, 1, true>(x, wp, bias, y, g, st);
+    }
     // many input channels (>= 256): weight-fragment traffic, not HBM, bounds the direct kernel -> block-shared fragments
     static const int shared_min = getenv("EAS_C1_SHARED_MIN_CIN") ? atoi(getenv("EAS_C1_SHARED_MIN_CIN")) : 256;
     if (Cin >= shared_min && g.MT >= 4) {

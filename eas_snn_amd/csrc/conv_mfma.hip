@@ -52,6 +52,11 @@ struct ConvGeom {
     int ext_h;          // rows spanned by the taps (3 for a 3x3 kernel)
     int tap_off[9];     // staged-pixel offset (dh*RS + dw) of every tap
     int oH, oW, os, oph, opw;   // output tensor height/width, output stride and phase: y[.., orow*os+oph, ocol*os+opw]
+    // Column parts (rows too wide for one LDS patch: 3x3 layers on 320-pixel rows with real-valued inputs): blockIdx.z = part, a
+    // tile covers output columns [part*Wo, (part+1)*Wo) of rows that are parts*Wo wide (Wo is the TILE width everywhere in the
+    // kernel).  The staged row then holds input columns gx0 + part*Wo*S .. + Wst, units outside [0, Wi) read the zero page, and
+    // there is no separately zeroed halo (pad_l = 0, qshift = halo units - pad).  One part: Wst = Wi, gx0 = 0, qshift = 0.
+    int Wst, gx0, qshift, parts;
     // ceil(2^40 / d) for the divisors of the per-thread geometry set-up: n / d == (n * m) >> 40 for n, d < 2^20
     unsigned long long m_Wo, m_rows_seg, m_Ho, m_units, m_units_seg, m_units_row, m_hrow, m_rows;
     int dbg;       // development ablation switches (EAS_CONV_DBG): 2 no staging after chunk 0, 4 weights from one address, 16 no barrier
@@ -222,13 +227,13 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     // zero the halo columns of both buffers (never written again): pad_l columns left of the image, the rest right of it
     {
         const int rows = g.nseg * g.rows_in;
-        const int hcols = g.RS - g.Wi;
+        const int hcols = g.RS - g.Wst;
         const int per_row = hcols * (PIXB / 16);
         for (int i = tid; i < rows * per_row * XT * 2; i += NT) {
             const int row = fdiv(i, g.m_hrow), k = i - row * per_row;
             const int bt = fdiv(row, g.m_rows), rw = row - bt * rows;   // bt = buffer*XT + term
             const int hc = k / (PIXB / 16), kk = k - hc * (PIXB / 16);
-            const int col = hc < g.pad_l ? hc : g.Wi + hc;
+            const int col = hc < g.pad_l ? hc : g.Wst + hc;
             *(uint4*)(smem + (size_t)bt * term_stride + (size_t)kk * grp + ((size_t)rw * g.RS + col) * 16) = make_uint4(0, 0, 0, 0);
         }
     }
@@ -242,18 +247,19 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int pc = p < npix ? p : 0;
         const int rl = fdiv(pc, g.m_Wo), c = pc - rl * g.Wo;
         const int seg = fdiv(rl, g.m_rows_seg), rr = rl - seg * g.rows_seg;
-        qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S) * 16 + h * grp;
+        qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S + g.qshift) * 16 + h * grp;
         const int rho = rho0 + rl;
         const int img = fdiv(rho, g.m_Ho), orow = rho - img * g.Ho;
-        const int yr = orow * g.os + g.oph, yc = c * g.os + g.opw;
+        const int yr = orow * g.os + g.oph, yc = ((int)blockIdx.z * g.Wo + c) * g.os + g.opw;
         ybase[j] = (p < npix && rho < g.total_rows && yr < g.oH && yc < g.oW) ? (((long)img * g.Cout * g.oH + yr) * g.oW + yc) : -1;
     }
 
     // per-thread staging items (the same for every channel chunk)
     const size_t plane = (size_t)g.Hi * g.Wi;
-    const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
+    const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
     const int nitems = units * (CCH / 8);
-    int gofs[NIT], lofs[NIT], gch[NIT];   // gofs < 0: row outside the image (zeros)
+    const int gcol0 = g.gx0 + (int)blockIdx.z * g.Wo * S;      // input column of the first staged unit (may be < 0 for part 0)
+    int gofs[NIT], lofs[NIT], gch[NIT];   // gofs < 0: row (or, with column parts, unit) outside the image (zeros)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int item = it * NT + tid;
@@ -262,8 +268,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int seg = fdiv(u, g.m_units_seg), rem = u - seg * units_seg;
         const int rl = fdiv(rem, g.m_units_row), cu = rem - rl * units_row;
         const int ir = r0 * S - g.pad_t + rl, img = img0 + seg;
-        const bool ok = ir >= 0 && ir < g.Hi && img < g.NI;
-        gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + cu * VEC) : -1;
+        const int gc = gcol0 + cu * VEC;
+        const bool ok = ir >= 0 && ir < g.Hi && img < g.NI && gc >= 0 && gc < g.Wi;
+        gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + gc) : -1;
         lofs[it] = ((seg * g.rows_in + rl) * g.RS + g.pad_l + cu * VEC) * 16 + gi * grp;
         gch[it] = gi * 8;
     }
@@ -458,14 +465,14 @@ int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, in
         attr_set = true;
     }
     {
-        const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
-        const int rows = g.nseg * g.rows_in, per_row = (g.RS - g.Wi) * (CCH * 2 / 16);
+        const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
+        const int rows = g.nseg * g.rows_in, per_row = (g.RS - g.Wst) * (CCH * 2 / 16);
         if (g.total_rows >= (1 << 20) || units >= (1 << 20)) return EAS_ERR_UNSUPPORTED;     // fdiv range
         g.m_Wo = fdiv_magic(g.Wo); g.m_rows_seg = fdiv_magic(g.rows_seg); g.m_Ho = fdiv_magic(g.Ho);
         g.m_units = fdiv_magic(units); g.m_units_seg = fdiv_magic(units_seg); g.m_units_row = fdiv_magic(units_row);
         g.m_hrow = fdiv_magic(per_row); g.m_rows = fdiv_magic(rows);
     }
-    dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM));
+    dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM), g.parts);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
     return EAS_OK;
 }
@@ -512,11 +519,11 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
             t.nseg = t.RT / t.rows_seg;
             t.rows_in = (t.rows_seg - 1) * S + g.ext_h;
             t.Q = t.nseg * t.rows_in * t.RS;
-            fits = (size_t)2 * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wi / VEC) * (CCH / 8) <= c.nit * c.threads;
+            fits = (size_t)2 * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wst / VEC) * (CCH / 8) <= c.nit * c.threads;
             cap = t.RT * g.Wo;
         }
         if (!fits) continue;
-        const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm));
+        const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm)) * g.parts;
         // resident blocks per CU: one 8-wave block, or two 4-wave blocks when their LDS fits twice (independent barriers
         // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
         const size_t lds_bytes = (size_t)2 * t.Q * CCH * 2 * XT;
@@ -574,7 +581,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
                          int stride, int x_terms, int* inexact_flag, eas_stream_t stream, bool query) {
     if (!query && (!x || !packed_w || !y)) return EAS_ERR_INVALID_ARG;
     if (NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || Cin % 8 != 0 || (ksize == 3 && Wi % 2 != 0)) return EAS_ERR_UNSUPPORTED;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || (ksize == 3 && (Cin % 8 != 0 || Wi % 2 != 0))) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     ConvGeom g{};
     const int pad = ksize / 2;
@@ -589,6 +596,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     g.MT = (Cout + 31) / 32;
     g.KSTEPS = (Cin + 15) / 16;
     g.total_rows = NI * g.Ho;
+    g.Wst = Wi; g.gx0 = 0; g.qshift = 0; g.parts = 1;
     static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
     g.dbg = dbg;
     const bf16x8* wp = (const bf16x8*)packed_w;
@@ -600,9 +608,29 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
                             : dispatch_tile<TAPS_, S_, 1, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))                          \
                       : (v4 ? dispatch_tile<TAPS_, S_, 3, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
                             : dispatch_tile<TAPS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
-    if (ksize == 3 && stride == 1) { EAS_CONV_DISPATCH(9, 1, 16); }
-    else if (ksize == 3 && stride == 2) { EAS_CONV_DISPATCH(9, 2, 16); }
-    else if (ksize == 1 && stride == 1) rc = query ? EAS_OK : eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
+    const ConvGeom g_full = g;
+    static const int force_parts = getenv("EAS_CONV_PARTS") ? atoi(getenv("EAS_CONV_PARTS")) : 0;   // development: force column parts
+    for (int parts = force_parts > 0 ? force_parts : 1; parts <= 8 && rc == EAS_ERR_UNSUPPORTED && ksize == 3; parts *= 2) {
+        g = g_full;
+        if (parts > 1) {
+            // column parts: the tile is Wo/parts output columns wide; the staged row holds their input columns plus one staging
+            // unit (VEC columns, aligned) of halo on either side, all fetched like interior units (zero page outside the image)
+            const int hv = v4 ? 4 : 2;
+            if (g_full.Wo % parts != 0 || ((g_full.Wo / parts) * stride) % hv != 0) continue;
+            g.parts = parts;
+            g.Wo = g_full.Wo / parts;
+            g.Wst = g.Wo * stride + 2 * hv;
+            g.RS = g.Wst;
+            g.pad_l = 0;
+            g.gx0 = -hv;
+            g.qshift = hv - pad;
+            for (int t = 0; t < ksize * ksize; ++t) g.tap_off[t] = (t / ksize) * g.RS + (t % ksize);
+        }
+        if (stride == 1) { EAS_CONV_DISPATCH(9, 1, 16); }
+        else { EAS_CONV_DISPATCH(9, 2, 16); }
+        if (force_parts > 0) break;
+    }
+    if (ksize == 1 && stride == 1) rc = query ? EAS_OK : eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
 #undef EAS_CONV_DISPATCH
     if (rc != EAS_OK || query) return rc;
     EAS_CHECK_LAUNCH();
@@ -614,8 +642,8 @@ int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float*
     return conv_fwd_impl(x, packed_w, bias, y, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, inexact_flag, stream, false);
 }
 
-// 1 when eas_conv_fwd has a tile for this geometry (the staged input rows of one tile must fit LDS: general fp32 inputs of
-// 3x3 convolutions wider than ~280 pixels do not), else 0: callers keep the library convolution for those layers.
+// 1 when eas_conv_fwd has a tile for this geometry.  Rows whose staged patch does not fit LDS in one piece (3x3 layers with
+// real-valued inputs wider than ~280 pixels: stem / dark2.0 of the 384x640 canvas) run in 2, 4 or 8 column parts.
 int eas_conv_fwd_supported(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
     return conv_fwd_impl(nullptr, nullptr, nullptr, nullptr, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, nullptr, nullptr, true) == EAS_OK ? 1 : 0;
 }
@@ -645,6 +673,7 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
         g.oH = Hi; g.oW = Wi; g.os = 2; g.oph = ph; g.opw = pw;
         g.MT = MT; g.KSTEPS = KSTEPS;
         g.total_rows = NI * Ho;
+        g.Wst = Wo; g.gx0 = 0; g.qshift = 0; g.parts = 1;
         g.dbg = dbg;
         const bf16x8* wp = (const bf16x8*)packed_w + (size_t)3 * MT * KSTEPS * 64 * cum[cls];
         int rc;

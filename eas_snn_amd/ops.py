@@ -971,21 +971,9 @@ def conv_wgrad(x, gy, ksize, stride, x_terms):
     return gw
 
 
-# Which convolutions run on the hand-written MFMA kernels ('mfma') and which stay on ATen/MIOpen ('miopen').
-# Per role so that a slower kernel of ours never displaces a faster library one (measured: scripts/dev_conv.py).
-CONV_POLICY = {'fwd3': 'mfma', 'fwd1': 'mfma', 'dgrad3': 'mfma', 'dgrad1': 'mfma', 'wgrad3': 'mfma', 'wgrad1': 'mfma',
-               # 3x3 weight gradient of layers whose output rows are wider than the 80-pixel reduction tile (stem and dark2.0 at
-               # 128x160, eas_conv_wgrad_parts > 1): eas_conv_wgrad handles them in column parts, but measured 0.92 ms against MIOpen's 0.49 ms for the two
-               # layers of the step (Cin = 8 fills a quarter of the MFMA tile; LDS limits dark2.0 to 28-pixel parts), so the
-               # library keeps them unless this is set to 'mfma'.  MIOpen's kernel for them splits the reduction with float atomics:
-               # these two gradients are the only values of the training step that are not bit-reproducible from run to run
-               # (tests/test_gpu_model.py::test_train_step_is_bit_reproducible), so torch.use_deterministic_algorithms(True)
-               # also routes them to eas_conv_wgrad (fixed-order slab reduction; +0.4 ms per step).
-               'wgrad3_wide': 'aten'}
-
-
-def _wide_wgrad_on_mfma():
-    return CONV_POLICY['wgrad3_wide'] == 'mfma' or torch.are_deterministic_algorithms_enabled()
+# One backend: every dense 1x1 / 3x3 convolution of the step -- forward, input gradient, weight gradient -- runs on the
+# hand-written matrix-core kernels (eas_conv_fwd / eas_conv_dgrad_s2 / eas_conv_wgrad).  The library convolution remains only for
+# geometries those kernels do not cover at all (grouped / dilated / odd-width / other kernel sizes: none in the EAS-SNN models).
 
 
 VERIFY_SMALL_INT = False     # tests switch this on: every tagged tensor is checked (host sync) before it is used
@@ -1007,20 +995,10 @@ def conv_eligible(x, conv):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1)
             and conv.kernel_size in ((1, 1), (3, 3)) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (k // 2, k // 2)
             and conv.padding_mode == 'zeros' and x.shape[1] % 8 == 0 and (k == 1 or x.shape[-1] % 2 == 0)
-            and CONV_POLICY['fwd%d' % k] == 'mfma' and not (k == 1 and conv.stride != (1, 1)))
+            and not (k == 1 and conv.stride != (1, 1)))
 
 
 _FWD_SUPPORT = {}
-_WG_PARTS = {}
-
-
-def _wgrad_single_part(NI, Cin, Cout, Hi, Wi, stride, x_terms):
-    key = (NI, Cin, Cout, Hi, Wi, stride, x_terms)
-    r = _WG_PARTS.get(key)
-    if r is None:
-        r = _WG_PARTS[key] = _lib.lib().eas_conv_wgrad_parts(*key)
-    return r == 1
-
 
 
 def conv_fwd_supported(NI, Cin, Cout, Hi, Wi, k, stride, x_terms):
@@ -1041,7 +1019,7 @@ class _ConvFn(torch.autograd.Function):
         if conv_fwd_supported(x.shape[0], x.shape[1], Cout, x.shape[2], x.shape[3], k, stride, x_terms):
             pk = packs[0] if packs and 0 in packs else conv_pack_weights(w, 0)
             y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms)
-        else:       # no tile fits (very wide rows of real-valued inputs): library forward, own backward where that fits
+        else:       # no tile for this geometry (not reached by the EAS-SNN models): library forward
             y = torch.ops.aten.convolution(x, w, bias, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1)
         ctx.save_for_backward(x, w)
         ctx.cfg = (k, stride, x_terms, bias is not None)
@@ -1056,13 +1034,14 @@ class _ConvFn(torch.autograd.Function):
         gy = _f32c(gy)
         gx = gw = gb = None
         Cin = w.shape[1]
-        own_d = (ctx.needs_input_grad[0] and stride == 1 and CONV_POLICY['dgrad%d' % k] == 'mfma' and w.shape[0] % 8 == 0
+        # the input gradient of a stride-1 convolution is eas_conv_fwd on grad_y with the weights packed transposed + flipped
+        # (1x1: any channel count -- the 1/4/num_classes-channel prediction convolutions included; 3x3: Cout in whole 8-groups)
+        own_d = (ctx.needs_input_grad[0] and stride == 1 and (k == 1 or w.shape[0] % 8 == 0)
                  and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3], k, 1, 3))
-        own_w = ctx.needs_input_grad[1] and CONV_POLICY['wgrad%d' % k] == 'mfma' and (
-            k == 1 or _wide_wgrad_on_mfma() or _wgrad_single_part(x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], stride, x_terms)) and _lib.lib().eas_conv_wgrad_workspace_floats(
+        own_w = ctx.needs_input_grad[1] and _lib.lib().eas_conv_wgrad_workspace_floats(
             x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
-        own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and CONV_POLICY['dgrad3'] == 'mfma' and w.shape[0] % 8 == 0
+        own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and w.shape[0] % 8 == 0
                   and gy.shape[-1] % 2 == 0 and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3] + 2, k, 1, 3))
         if own_d:
             pk = packs[1] if packs and 1 in packs else conv_pack_weights(w, 1)
@@ -1126,7 +1105,7 @@ def prepack_conv_weights(model):
         dev = convs[0].weight.device
         for c in convs:
             k, Cout, Cin = c.kernel_size[0], c.out_channels, c.in_channels
-            modes = [0] + ([1] if c.stride == (1, 1) and Cout % 8 == 0 else []) + ([2] if c.stride == (2, 2) and k == 3 and Cout % 8 == 0 else [])
+            modes = [0] + ([1] if c.stride == (1, 1) and (k == 1 or Cout % 8 == 0) else []) + ([2] if c.stride == (2, 2) and k == 3 and Cout % 8 == 0 else [])
             d = {}
             for m in modes:
                 d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)

@@ -31,7 +31,7 @@ def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     dev = torch.device('cuda:0')
     eas_snn_amd.hip_library()
-    ops.set_state_writeback(False)
+    ops.set_state_writeback(False)           # whole process is a train loop that resets after every step
     for name, (exp_name, opts, canvas, Tm) in CONFIGS.items():
         exp = get_exp(None, exp_name)
         exp.merge(COMMON + opts + ['input_size', str(canvas), 'test_size', str(canvas)])
@@ -43,11 +43,19 @@ def main():
             continue
         opt = exp.get_optimizer(batch)
         g = torch.Generator().manual_seed(1)
-        frames = torch.poisson(torch.full((batch, 1, Tm, 2) + canvas, 0.3), generator=g).to(dev)
+        hist = None
+        if 'cfg4' in name:
+            # configs[3]'s real input: the RVT stacked histogram [B, Tm, 2*10, 360, 640] u8, summed over its 10 time bins and padded
+            # to the canvas on the device inside the step (eas_stacked_hist_event_sum; rvt_gen4.py:118-125)
+            hist = torch.poisson(torch.full((batch, Tm, 20, 360, 640), 0.03), generator=g).clamp_(max=255).to(torch.uint8).to(dev)
+            frames = None
+        else:
+            frames = torch.poisson(torch.full((batch, 1, Tm, 2) + canvas, 0.3), generator=g).to(dev)
         targets = data.synth_targets(batch, canvas, dev)
 
         def step():
-            out = model(frames, targets)
+            x_in = frames if hist is None else ops.stacked_hist_event_sum(hist, *canvas)
+            out = model(x_in, targets)
             opt.zero_grad(set_to_none=True)
             out['total_loss'].backward()
             opt.step()
@@ -77,7 +85,7 @@ def main():
         tot = sum((e.device_time if hasattr(e, 'device_time') else e.cuda_time) for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
         print(f'{name:22s} batch {batch}: {ms:8.1f} ms/step = {batch / ms * 1e3:7.1f} event-frames/s, loss {float(loss):.4f} finite {bool(torch.isfinite(loss))}; '
               f'GPU time: own kernels {own / tot:.0%}, MIOpen/rocBLAS {lib / tot:.1%}, max memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
-        del model, opt, frames
+        del model, opt, frames, hist
         torch.cuda.empty_cache()
 
 

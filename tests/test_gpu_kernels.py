@@ -908,12 +908,7 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         assert _lib.lib().eas_conv_wgrad_workspace_floats(NI, Cin, Cout, H, W, k, s, 1 if spikes else 3) > 0
     y = ops.conv2d(xd, conv, small_int=spikes)
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
-    wide = ops.CONV_POLICY['wgrad3_wide']
-    ops.CONV_POLICY['wgrad3_wide'] = 'mfma'          # column-part weight gradient for rows wider than the reduction tile
-    try:
-        y.backward(gy.to(dev))
-    finally:
-        ops.CONV_POLICY['wgrad3_wide'] = wide
+    y.backward(gy.to(dev))
     x64 = x.double().requires_grad_(True)
     w64 = w.double().requires_grad_(True)
     b64 = conv.bias.detach().double().cpu() if conv.bias is not None else None
@@ -925,15 +920,17 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('NI,Cin,Cout,H,W,s', [(1, 8, 16, 6, 320, 1), (1, 16, 32, 8, 640, 2), (1, 16, 16, 4, 1280, 1)])
-def test_conv_without_a_tile_keeps_the_library_path(dev, NI, Cin, Cout, H, W, s):
-    """Real-valued 3x3 inputs on rows too wide for one LDS tile (the stem / dark2.0 of the 1 Mpx configuration, 192x320):
-    eas_conv_fwd_supported says so and ops.conv2d keeps the library convolution for that layer instead of failing; results
-    still match fp64."""
+@pytest.mark.parametrize('NI,Cin,Cout,H,W,s', [(1, 8, 16, 6, 320, 1), (1, 16, 32, 8, 640, 2), (1, 16, 16, 4, 640, 1), (2, 8, 48, 12, 320, 1),
+                                               (2, 48, 96, 12, 320, 2)])
+def test_conv_on_rows_too_wide_for_one_lds_patch_runs_in_column_parts(dev, NI, Cin, Cout, H, W, s):
+    """Real-valued 3x3 inputs on rows whose staged patch does not fit LDS in one piece (the stem / dark2.0 of the 1 Mpx
+    configuration: 192x320 at SYOLOX-M width): eas_conv_fwd runs them in 2..8 column parts (blockIdx.z), the weight gradient in
+    its own column parts -- no library convolution anywhere; forward, input gradient and weight gradient match fp64, and the
+    column-part forward equals the one-piece forward bit for bit where both exist."""
     import torch.nn as nn
     from eas_snn_amd import _lib, ops
-    assert _lib.lib().eas_conv_fwd_supported(NI, Cin, Cout, H, W, 3, s, 3) == 0
-    assert _lib.lib().eas_conv_fwd_supported(NI, Cin, Cout, H, 80, 3, s, 3) == 1
+    assert _lib.lib().eas_conv_fwd_supported(NI, Cin, Cout, H, W, 3, s, 3) == 1
+    assert _lib.lib().eas_conv_wgrad_workspace_floats(NI, Cin, Cout, H, W, 3, s, 3) > 0
     x, w = _conv_case(NI, Cin, Cout, H, W, 3, False, seed=W)
     conv = nn.Conv2d(Cin, Cout, 3, s, 1, bias=False).to(dev)
     with torch.no_grad():
@@ -941,9 +938,44 @@ def test_conv_without_a_tile_keeps_the_library_path(dev, NI, Cin, Cout, H, W, s)
     xd = x.to(dev).requires_grad_(True)
     y = ops.conv2d(xd, conv)
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
-    y.backward(gy.to(dev))
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        y2 = ops.conv2d(xd, conv)
+        y2.backward(gy.to(dev))
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert not [n for n in names if any(k in n for k in ('igemm', 'Sp3AsmConv', 'miopen', 'naive_conv', 'Cijk', 'gemm'))], names
+    assert torch.equal(y, y2)
     x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
     y64 = torch.nn.functional.conv2d(x64, w64, None, stride=s, padding=1)
+    y64.backward(gy.double())
+    for name, got, ref in (('y', y, y64), ('grad_x', xd.grad, x64.grad), ('grad_w', conv.weight.grad, w64.grad)):
+        err = (got.detach().double().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
+        assert err < 1e-5, f'{name}: {err:.2e}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Cout,H,W', [(1, 8, 10), (4, 16, 20), (2, 32, 40), (100, 8, 8), (3, 48, 80)])
+def test_prediction_conv_input_gradient_on_own_kernel(dev, Cout, H, W):
+    """The 1 / 4 / num_classes-channel 1x1 prediction convolutions of the head: their input gradient is eas_conv_fwd on grad_y with
+    a channel count that is not a multiple of 8 (per-channel validity in the 1x1 kernel) -- no library kernel in forward, input
+    gradient or weight gradient; all three against fp64."""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    Cin, NI = 128, 3
+    x, w = _conv_case(NI, Cin, Cout, H, W, 1, False, seed=Cout)
+    conv = nn.Conv2d(Cin, Cout, 1, 1, 0, bias=True).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xd = x.to(dev).requires_grad_(True)
+    gy = torch.randn(NI, Cout, H, W, generator=torch.Generator().manual_seed(7))
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        y = ops.conv2d(xd, conv)
+        y.backward(gy.to(dev))
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert not [n for n in names if any(k in n for k in ('igemm', 'Sp3AsmConv', 'miopen', 'naive_conv', 'Cijk', 'gemm'))], names
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, conv.bias.detach().double().cpu())
     y64.backward(gy.double())
     for name, got, ref in (('y', y, y64), ('grad_x', xd.grad, x64.grad), ('grad_w', conv.weight.grad, w64.grad)):
         err = (got.detach().double().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
