@@ -64,7 +64,7 @@ PROTOTYPES = {
     'eas_bn_silu_fwd_ex': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.POINTER(EasBnPending), _P]),
     'eas_bn_stats_partial': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_bn_lif_fwd_ex': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
-                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P]),
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P, _P]),
     'eas_bn_lif_bwd_ex': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                     C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_lif_bwd_patan': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P,
@@ -86,9 +86,11 @@ PROTOTYPES = {
     'eas_conv_fwd_supported': (C.c_int, [C.c_int] * 8),
     'eas_conv_wgrad_parts': (C.c_int, [C.c_int] * 7),
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
+    'eas_conv_fwd_u8': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
     'eas_conv_dgrad_s2': (C.c_int, [_P] * 3 + [C.c_int] * 5 + [_P]),
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
     'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
+    'eas_conv_wgrad_u8': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
 }
@@ -134,7 +136,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError = ABI mismatch, also loud
             fn.restype = res
             fn.argtypes = args
-        if handle.eas_abi_version() != 1:
+        if handle.eas_abi_version() != 2:
             raise EasHipError('libeas_hip.so ABI version mismatch; rebuild')
         _lib = handle
     return _lib

@@ -36,9 +36,7 @@ class SeqToANNContainer(nn.Sequential, base.StepModule):
             y._eas_base = y0
             return y
         small = ops.is_small_int(x_seq)
-        x = x_seq.flatten(0, 1)
-        if small:
-            ops.mark_small_int(x)
+        x = ops.fold_time(x_seq)            # [T*N, ...] with the spike tags (small-integer mark, byte copy) carried along
         y = self._run_inner(x)
         y = y.view(x_seq.shape[0], x_seq.shape[1], *y.shape[1:])
         if small and len(self) == 1 and isinstance(self[0], (nn.MaxPool2d, nn.Upsample)):
@@ -71,10 +69,11 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
         return bool(self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
                     and (self.momentum is not None or not self.training))
 
-    def fused_with(self, node, y_seq, want_mean=False, residual=None, cat=None):
+    def fused_with(self, node, y_seq, want_mean=False, residual=None, cat=None, emit_bytes=False):
         """spikes = node(self(y_seq)) for y_seq [T,N,C,H,W] without materialising the BN output.
         residual: the result is spikes + residual (SEW shortcut) from the same kernel; cat = (buffer [T,N,Ctot,H,W], first
-        channel): the result is written into that channel range of the buffer and returned as a view of it."""
+        channel[, uint8 buffer of the same shape]): the result is written into that channel range of the buffer(s) and returned as
+        a view; emit_bytes: the kernel also writes the result as bytes for the 1x1 convolutions that read it next."""
         if not self.can_fuse(y_seq):
             if cat is not None:
                 raise RuntimeError('in-place concatenation needs the fused BN+LIF path (callers check network_blocks._fusable)')
@@ -93,7 +92,8 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
             y_seq if base is None else base, self.weight, self.bias, self.running_mean if (update or not batch) else None,
             self.running_var if (update or not batch) else None, batch, self.momentum if update else None, self.eps,
             node._v_in(y_seq[0]), a['w'], a['k_const'], a['v_th'], a['v_reset'], a['flags'], a['surrogate'], a['alpha'],
-            want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0], residual=residual, cat=cat)
+            want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0], residual=residual, cat=cat,
+            emit_bytes=emit_bytes and (residual is None or ops.is_small_int(residual)))
         if v_out is not None:
             node.v = v_out
         if residual is None or ops.is_small_int(residual):
@@ -112,7 +112,7 @@ class Conv2d(nn.Conv2d, base.StepModule):
         return functional.seq_to_ann_forward(x, super().forward)
 
 
-def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None):
+def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None, emit_bytes=True):
     """spikes of node_a(bn_a(y12[:, :, :Ca])) and node_b(bn_b(y12[:, :, Ca:])) from ONE convolution output y12 [T,N,Ca+Cb,H,W]
     (ops.bn_lif_pair): the two 1x1 branches of a CSPLayer.  cat_a / cat_b = (buffer, first channel) as in ``fused_with``."""
     packs = []
@@ -126,7 +126,7 @@ def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None):
                  None if not update or bn.momentum is None else float(bn.momentum), float(bn.eps))
         cfg = (state, node._v_in(y12[0, :, :bn.num_features]), float(a['k_const']), float(a['v_th']), float(a['v_reset']), int(a['flags']),
                ops.SURROGATE_IDS[a['surrogate']] if isinstance(a['surrogate'], str) else int(a['surrogate']), float(a['alpha']),
-               bool(ops.state_writeback()), cat, int(bn.num_features))
+               bool(ops.state_writeback()), cat, int(bn.num_features), bool(emit_bytes and ops.SPIKE_BYTES))
         packs.append((bn.weight, bn.bias, a['w'], cfg))
     sa, va, sb, vb = ops.bn_lif_pair(y12, packs[0], packs[1])
     if va is not None:

@@ -66,11 +66,13 @@ class BaseConv(nn.Module):
     def spiking(self):
         return isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d)
 
-    def forward(self, x, residual=None, cat=None):
+    def forward(self, x, residual=None, cat=None, emit_bytes=True):
         """residual / cat: only for converted (spiking) blocks on the fused BN+LIF path -- the SEW shortcut addition and the
-        channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer)."""
+        channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer).  emit_bytes: the spikes are
+        also written as bytes for a 1x1 convolution that reads them next (callers whose consumer is a 3x3 convolution pass False)."""
         if self.spiking():
-            return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate, residual=residual, cat=cat)
+            return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate, residual=residual, cat=cat,
+                                      emit_bytes=emit_bytes and x.dim() == 5)
         assert residual is None and cat is None
         y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
@@ -102,7 +104,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, cat=None):
         """cat = (buffer, first channel): write the block's output into that channel range of a concatenation buffer."""
-        h = self.conv1(x)
+        h = self.conv1(x, emit_bytes=False) if self.conv1.spiking() else self.conv1(x)      # read by the 3x3 conv2 only
         if _fusable(self.conv2, x):
             # SEW residual (spike sums 0/1/2..) and the caller's concatenation from the BN+LIF kernel of conv2
             return self.conv2(h, residual=x if self.use_add else None, cat=cat)
@@ -164,28 +166,27 @@ class CSPLayer(nn.Module):
             h = self.conv2.conv[0].out_channels if isinstance(self.conv2.conv, nn.Sequential) else self.conv2.conv.out_channels
             Ho, Wo = x.shape[-2:]
             buf = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.float32, device=x.device)
+            buf8 = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.uint8, device=x.device) if ops.SPIKE_BYTES else None   # byte copy for conv3
             if self._dual_ok():
                 # conv1 and conv2 read the same x: ONE 1x1 convolution with the concatenated weights, then the two BN+LIF layers on
                 # the two channel halves of its output (x read once; the input gradient is one convolution, no branch addition)
                 c1, c2 = self.conv1.conv[0], self.conv2.conv[0]
-                x4 = x.flatten(0, 1)
-                if ops.is_small_int(x):
-                    ops.mark_small_int(x4)
+                x4 = ops.fold_time(x)
                 sink = ops.conv_sink()
                 if sink is not None:
                     sink(c1, x4, 1)
                     sink(c2, x4, 1)
                 y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
                 a, b = sj_layer.fused_pair(self.conv1.bn, self.conv1.act, self.conv2.bn, self.conv2.act, y12,
-                                           cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
+                                           cat_a=None if len(self.m) else (buf, 0, buf8), cat_b=(buf, h, buf8))
             else:
-                a = self.conv1(x, cat=None if len(self.m) else (buf, 0))
-                b = self.conv2(x, cat=(buf, h))
+                a = self.conv1(x, cat=None if len(self.m) else (buf, 0, buf8))
+                b = self.conv2(x, cat=(buf, h, buf8))
             if len(self.m):
                 for blk in self.m[:-1]:
                     a = blk(a)
-                a = self.m[-1](a, cat=(buf, 0))
-            return self.conv3(ops.join_channels(buf, a, b))
+                a = self.m[-1](a, cat=(buf, 0, buf8))
+            return self.conv3(ops.join_channels(buf, a, b, u8_buf=buf8))
         return self.conv3(_cat((self.m(self.conv1(x)), self.conv2(x))))
 
 

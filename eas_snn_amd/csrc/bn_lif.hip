@@ -117,6 +117,8 @@ struct BnLifOut {
     const float* residual;   // nullable [T][N][C][HW]: spikes_out = spikes + residual (SEW shortcut, network_blocks.py:99-104)
     int out_ctot;            // 0: dense; else spikes are channels of a [T][N][out_ctot][HW] tensor (pointer already at channel 0 of the slice)
     int y_ctot;              // 0: dense; else y is such a channel slice of a [T][N][y_ctot][HW] tensor (one convolution feeding two BN+LIF layers)
+    uint8_t* u8;             // nullable: the same output values (0/1 spikes or SEW sums <= 255) once more as bytes, laid out like `spikes`
+                             // (1 B instead of 4 B for the HBM-bound 1x1 convolutions that read them next: eas_conv_fwd_u8 / eas_conv_wgrad_u8)
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -173,6 +175,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
             }
             const int64_t obase = ox.out_ctot ? (n * ox.out_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
             *reinterpret_cast<float4*>(spikes + (int64_t)t * Mo + obase) = s;
+            if (ox.u8)
+                *reinterpret_cast<uint32_t*>(ox.u8 + (int64_t)t * Mo + obase) =
+                    (uint32_t)s.x | ((uint32_t)s.y << 8) | ((uint32_t)s.z << 16) | ((uint32_t)s.w << 24);
         }
         if (v_out) *reinterpret_cast<float4*>(v_out + base) = v;
         if (mean_out) {
@@ -474,15 +479,16 @@ static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin&
 int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
                       const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                       int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
-                      const EasBnPending* pending, const float* residual, int out_ctot, eas_stream_t stream) {
+                      const EasBnPending* pending, const float* residual, int out_ctot, uint8_t* spikes_u8, eas_stream_t stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !spikes || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out | (uintptr_t)residual) & 15) return EAS_ERR_INVALID_ARG;
+    if ((uintptr_t)spikes_u8 & 3) return EAS_ERR_INVALID_ARG;
     if ((out_ctot != 0 && out_ctot < C) || (y_ctot != 0 && (y_ctot < C || y_bcast))) return EAS_ERR_INVALID_ARG;
     BnFin fin;
     if (int rc = fin_from(pending, mean, invstd, fin)) return rc;
-    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot, y_ctot == C ? 0 : y_ctot};
+    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot, y_ctot == C ? 0 : y_ctot, spikes_u8};
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
@@ -502,7 +508,7 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
                    int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
                    eas_stream_t stream) {
     return eas_bn_lif_fwd_ex(y, 0, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, v_in, v_out, w_logit, k_const, v_th,
-                             v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, stream);
+                             v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, nullptr, stream);
 }
 
 static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,

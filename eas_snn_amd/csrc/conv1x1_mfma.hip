@@ -23,11 +23,11 @@ struct C1Geom {
     int MT, KSTEPS;
 };
 
-template <int XT>
-__device__ __forceinline__ void to_terms(const float (&v)[8], bf16x8 (&b)[XT]) {
+template <int XT, typename TIN = float>
+__device__ __forceinline__ void to_terms(const TIN (&v)[8], bf16x8 (&b)[XT]) {
     if constexpr (XT == 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[0][j] = (__bf16)v[j];
+        for (int j = 0; j < 8; ++j) b[0][j] = (__bf16)(float)v[j];      // TIN = uint8_t: spike bytes 0..255 are exact in bf16
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -44,8 +44,8 @@ __device__ __forceinline__ void to_terms(const float (&v)[8], bf16x8 (&b)[XT]) {
 
 // RAGK: Cin is not a multiple of 8 (the input gradient of the 1/4/num_classes-channel prediction convolutions, whose "input" is
 // grad_y): channel validity is then tested per channel instead of per 8-channel group.
-template <int XT, int WM, int WN, bool RAGK = false>
-__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+template <int XT, int WM, int WN, bool RAGK = false, typename TIN = float>
+__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const TIN* __restrict__ x, const bf16x8* __restrict__ wp,
                                                               const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -83,24 +83,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 
     // raw x of k-step ks: 8 channels (ks*16 + 8h + j) of this lane's pixel per N-tile.  Lanes without a pixel and channel
     // groups past Cin (Cin % 8 == 0) read the zero page with stride 0: unconditional loads, no per-element masking
-    auto fetch = [&](float (&raw)[WN][8], int ks) {
+    auto fetch = [&](TIN (&raw)[WN][8], int ks) {
         const int ch0 = ks * 16 + 8 * h;
         const bool ch_ok = ch0 < g.Cin;
+        const TIN* zero = reinterpret_cast<const TIN*>(eas_c1_zero_page);
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const bool ok = ch_ok && xoff[n] >= 0;
-            const float* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : eas_c1_zero_page;
+            const TIN* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : zero;
             const long cs = ok ? (long)g.HW : 0;
             if constexpr (RAGK) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) raw[n][j] = *((ok && ch0 + j < g.Cin) ? src + j * cs : eas_c1_zero_page);
+                for (int j = 0; j < 8; ++j) raw[n][j] = *((ok && ch0 + j < g.Cin) ? src + j * cs : zero);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) raw[n][j] = src[j * cs];
             }
         }
     };
-    auto step = [&](float (&raw)[WN][8], int ks) {
+    auto step = [&](TIN (&raw)[WN][8], int ks) {
         bf16x8 a[WM][3];
 #pragma unroll
         for (int m = 0; m < WM; ++m)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             bf16x8 b[XT];
-            to_terms<XT>(raw[n], b);
+            to_terms<XT, TIN>(raw[n], b);
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
                 if constexpr (XT == 1) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     };
 
     // channel loop, two raw buffers: the loads of k-step s+1 are in flight while k-step s is converted and multiplied
-    float r0[WN][8], r1[WN][8];
+    TIN r0[WN][8], r1[WN][8];
     fetch(r0, 0);
     int ks = 0;
     for (; ks + 1 < g.KSTEPS; ks += 2) {
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 // (WM x 3 KB per k-step) -- 64 KB per k-step and CU against 768 cycles of MFMA work.  Here the four waves of a block (same
 // output channels, different pixels) share them: the block loads each k-step's WM x 3 fragments once (coalesced 16-byte
 // loads), double-buffers them in LDS and every wave reads its operands with conflict-free ds_read_b128.  One barrier per k-step.
-template <int XT, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+template <int XT, int WM, int WN, typename TIN = float>
+__global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const TIN* __restrict__ x, const bf16x8* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     constexpr int NFRAG = WM * 3;                        // 1 KB fragments per k-step
     constexpr int NLD = (NFRAG * 64 + 255) / 256;        // 16-byte staging loads per thread and k-step
@@ -231,18 +232,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
             if (q < NFRAG * 64) (&As[buf][0][0])[q] = areg[it];
         }
     };
-    auto x_fetch = [&](float (&raw)[WN][8], int ks) {
+    auto x_fetch = [&](TIN (&raw)[WN][8], int ks) {
         const bool ch_ok = ks * 16 + 8 * h < g.Cin;
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const bool ok = ch_ok && xoff[n] >= 0;
-            const float* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : eas_c1_zero_page;
+            const TIN* src = ok ? x + xoff[n] + (long)ks * 16 * g.HW : reinterpret_cast<const TIN*>(eas_c1_zero_page);
             const long cs = ok ? (long)g.HW : 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[n][j] = src[j * cs];
         }
     };
-    auto step = [&](float (&raw)[WN][8], int buf) {
+    auto step = [&](TIN (&raw)[WN][8], int buf) {
         bf16x8 a[WM][3];
 #pragma unroll
         for (int m = 0; m < WM; ++m)
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
             for (int t = 0; t < 3; ++t) a[m][t] = As[buf][t * WM + m][lane];
         bf16x8 b[WN][XT];
 #pragma unroll
-        for (int n = 0; n < WN; ++n) to_terms<XT>(raw[n], b[n]);
+        for (int n = 0; n < WN; ++n) to_terms<XT, TIN>(raw[n], b[n]);
         if constexpr (XT == 1) {
 #pragma unroll
             for (int ta = 2; ta >= 0; --ta)
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         }
     };
 
-    float r0[WN][8], r1[WN][8];
+    TIN r0[WN][8], r1[WN][8];
     a_fetch(0);
     x_fetch(r0, 0);
     a_commit(0);
@@ -324,25 +325,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
     }
 }
 
-template <int XT, int WM, int WN>
-int launch_c1_shared(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
+template <int XT, int WM, int WN, typename TIN = float>
+int launch_c1_shared(const TIN* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
-    hipLaunchKernelGGL((conv1x1_mfma_sharedA_kernel<XT, WM, WN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    hipLaunchKernelGGL((conv1x1_mfma_sharedA_kernel<XT, WM, WN, TIN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
-template <int XT, int WM, int WN, bool RAGK = false>
-int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
+template <int XT, int WM, int WN, bool RAGK = false, typename TIN = float>
+int launch_c1(const TIN* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
-    hipLaunchKernelGGL((conv1x1_mfma_kernel<XT, WM, WN, RAGK>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    hipLaunchKernelGGL((conv1x1_mfma_kernel<XT, WM, WN, RAGK, TIN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
 }  // namespace
 
-// called by eas_conv_fwd (conv_mfma.hip) for ksize == 1, stride == 1
-int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st) {
+// wave-tile choice and launch for a 1x1 convolution; TIN = float (x_terms 1 or 3) or uint8_t (spike bytes, one term)
+template <typename TIN>
+static int conv1x1_dispatch_t(const TIN* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
+                              hipStream_t st) {
+    constexpr bool U8 = sizeof(TIN) == 1;
     C1Geom g{};
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
     g.tiles_per_img = (HW + 31) / 32;
@@ -359,7 +362,9 @@ int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias
     static const long want = getenv("EAS_C1_BLOCKS") ? atol(getenv("EAS_C1_BLOCKS")) : 512;
     if (blocks(wm, wn) < want) wn = 1;
     while (blocks(wm, wn) < want && wm > 1) wm >>= 1;
-    if (Cin % 8 != 0) {     // ragged input channels: the direct kernel with per-channel validity (few channels: one pixel tile per wave)
+    if constexpr (U8) {
+        if (Cin % 8 != 0 || x_terms != 1) return EAS_ERR_UNSUPPORTED;
+    } else if (Cin % 8 != 0) {     // ragged input channels: the direct kernel with per-channel validity (few channels: one pixel tile per wave)
         if (x_terms == 1) {
             if (g.MT >= 4) return launch_c1<1, 4, 1, true>(x, wp, bias, y, g, st);
             return g.MT >= 2 ? launch_c1<1, 2, 1, true>(x, wp, bias, y, g, st) : launch_c1<1, 1, 1, true>(x, wp, bias, y, g, st);
@@ -379,30 +384,44 @@ int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias
             if (blocks(sm, sn) < want_s) sn = 1;
             if (blocks(sm, sn) < want_s) sm = 2;
         }
-#define EAS_C1S(XT_)                                                                            \
-    do {                                                                                        \
-        if (sm == 4 && sn == 2) return launch_c1_shared<XT_, 4, 2>(x, wp, bias, y, g, st);      \
-        if (sm == 4) return launch_c1_shared<XT_, 4, 1>(x, wp, bias, y, g, st);                 \
-        if (sn == 2) return launch_c1_shared<XT_, 2, 2>(x, wp, bias, y, g, st);                 \
-        return launch_c1_shared<XT_, 2, 1>(x, wp, bias, y, g, st);                              \
+#define EAS_C1S(XT_)                                                                                 \
+    do {                                                                                             \
+        if (sm == 4 && sn == 2) return launch_c1_shared<XT_, 4, 2, TIN>(x, wp, bias, y, g, st);      \
+        if (sm == 4) return launch_c1_shared<XT_, 4, 1, TIN>(x, wp, bias, y, g, st);                 \
+        if (sn == 2) return launch_c1_shared<XT_, 2, 2, TIN>(x, wp, bias, y, g, st);                 \
+        return launch_c1_shared<XT_, 2, 1, TIN>(x, wp, bias, y, g, st);                              \
     } while (0)
         if (x_terms == 1) EAS_C1S(1);
-        EAS_C1S(3);
+        if constexpr (!U8) EAS_C1S(3);
 #undef EAS_C1S
     }
-#define EAS_C1(XT_)                                                                     \
-    do {                                                                                \
-        if (wm == 4 && wn == 2) return launch_c1<XT_, 4, 2>(x, wp, bias, y, g, st);     \
-        if (wm == 2 && wn == 2) return launch_c1<XT_, 2, 2>(x, wp, bias, y, g, st);     \
-        if (wm == 1 && wn == 2) return launch_c1<XT_, 1, 2>(x, wp, bias, y, g, st);     \
-        if (wm == 4) return launch_c1<XT_, 4, 1>(x, wp, bias, y, g, st);                \
-        if (wm == 2) return launch_c1<XT_, 2, 1>(x, wp, bias, y, g, st);                \
-        return launch_c1<XT_, 1, 1>(x, wp, bias, y, g, st);                             \
+#define EAS_C1(XT_)                                                                                  \
+    do {                                                                                             \
+        if (wm == 4 && wn == 2) return launch_c1<XT_, 4, 2, false, TIN>(x, wp, bias, y, g, st);      \
+        if (wm == 2 && wn == 2) return launch_c1<XT_, 2, 2, false, TIN>(x, wp, bias, y, g, st);      \
+        if (wm == 1 && wn == 2) return launch_c1<XT_, 1, 2, false, TIN>(x, wp, bias, y, g, st);      \
+        if (wm == 4) return launch_c1<XT_, 4, 1, false, TIN>(x, wp, bias, y, g, st);                 \
+        if (wm == 2) return launch_c1<XT_, 2, 1, false, TIN>(x, wp, bias, y, g, st);                 \
+        return launch_c1<XT_, 1, 1, false, TIN>(x, wp, bias, y, g, st);                              \
     } while (0)
     if (x_terms == 1) EAS_C1(1);
-    EAS_C1(3);
+    if constexpr (!U8) EAS_C1(3);
 #undef EAS_C1
+    return EAS_ERR_UNSUPPORTED;
 }
+
+// called by eas_conv_fwd (conv_mfma.hip) for ksize == 1, stride == 1
+int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
+                         hipStream_t st) {
+    return conv1x1_dispatch_t<float>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st);
+}
+
+// the same convolution reading spikes as bytes (eas_conv_fwd_u8)
+int eas_conv1x1_dispatch_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, hipStream_t st) {
+    return conv1x1_dispatch_t<uint8_t>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st);
+}
+
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient of a 1x1 convolution: dW[co][ci] = sum_{n,p} gy[n][co][p] * x[n][ci][p]   (reduction index = pixel).
@@ -530,9 +549,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_kernel(const float* __re
 // multiple of 16: the 16 lanes of a b128 pass cover all banks).  Block tile = (32*WVM) co x (32*WVN*NT) ci, 4 waves;
 // double-buffered: the next chunk's global loads are issued before the current chunk's MFMAs and written to the other
 // buffer after them (one barrier per chunk).
-template <int XT, int WVM, int WVN, int NT, int KS>
-__global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+// XU8: x is given as spike bytes (uint8, XT = 1): an x staging item is then 4 pixels = ONE 32-bit load instead of 16 bytes.
+template <int XT, int WVM, int WVN, int NT, int KS, bool XU8 = false>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __restrict__ x_, const float* __restrict__ gy,
                                                                 float* __restrict__ slabs, W1Geom g) {
+    static_assert(!XU8 || XT == 1, "spike bytes are one exact bf16 term");
+    const float* x = reinterpret_cast<const float*>(x_);
+    const uint8_t* x8 = reinterpret_cast<const uint8_t*>(x_);
     constexpr int KC = 16 * KS;                 // pixels per chunk
     constexpr int PITCH = KC * 2 + 16;          // bytes per channel row and term
     constexpr int RA = 32 * WVM, RB = 32 * WVN * NT;
@@ -582,6 +605,11 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const float* __r
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it * 256 >= ITEMS) continue;
+            if (XU8 && !it_isa[it]) {
+                const uint8_t* src8 = it_goff[it] >= 0 ? x8 + (long)img * g.Cin * g.HW + it_goff[it] + p0 : reinterpret_cast<const uint8_t*>(eas_c1_zero_page);
+                L[it][0] = __builtin_bit_cast(float, *(const uint32_t*)src8);
+                continue;
+            }
             const float* base = it_isa[it] ? gy + (long)img * g.Cout * g.HW : x + (long)img * g.Cin * g.HW;
             const float* src = it_goff[it] >= 0 ? base + it_goff[it] + p0 : eas_c1_zero_page;
             L[it] = *(const f32x4*)src;
@@ -593,6 +621,13 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const float* __r
             if (it * 256 >= ITEMS || it * 256 + tid >= ITEMS) continue;
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 t0, t1, t2;
+            if (XU8 && !it_isa[it]) {
+                const uint32_t w4 = __builtin_bit_cast(uint32_t, L[it][0]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t0[j] = (__bf16)(float)((w4 >> (8 * j)) & 0xffu);
+                *(bf16x4*)(buf + it_lofs[it]) = t0;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = L[it][j];
@@ -694,9 +729,9 @@ W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW) {
     return p;
 }
 
-template <int XT, int WVM, int WVN, int NT, int KS>
-int launch_w1_lds(const float* x, const float* gy, float* slabs, W1Geom g, int slices, hipStream_t st) {
-    auto kern = conv1x1_wgrad_lds_kernel<XT, WVM, WVN, NT, KS>;
+template <int XT, int WVM, int WVN, int NT, int KS, bool XU8 = false>
+int launch_w1_lds(const void* x, const float* gy, float* slabs, W1Geom g, int slices, hipStream_t st) {
+    auto kern = conv1x1_wgrad_lds_kernel<XT, WVM, WVN, NT, KS, XU8>;
     constexpr int PITCH = 16 * KS * 2 + 16;
     const size_t lds = (size_t)2 * (3 * 32 * WVM + XT * 32 * WVN * NT) * PITCH;
     static bool attr_set = false;
@@ -738,6 +773,16 @@ int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW) {
 }
 
 // slabs: eas_conv1x1_wgrad_slices(...) * Cout * Cin floats; the caller reduces them (conv_wgrad_reduce_kernel)
+// x as spike bytes (eas_conv_wgrad_u8): the LDS-staged form only
+int eas_conv1x1_wgrad_dispatch_u8(const uint8_t* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, hipStream_t st) {
+    W1Geom g{};
+    if (HW % 16 != 0 || !w1_use_lds()) return EAS_ERR_UNSUPPORTED;
+    const W1Plan p = w1_plan(g, NI, Cin, Cout, HW);
+#define EAS_W1(M_, N_, T_) (p.ks == 2 ? launch_w1_lds<1, M_, N_, T_, 2, true>(x, gy, slabs, g, p.slices, st) : launch_w1_lds<1, M_, N_, T_, 1, true>(x, gy, slabs, g, p.slices, st))
+    return p.wvm == 4 ? EAS_W1(4, 1, 4) : (p.wvm == 2 ? EAS_W1(2, 2, 2) : EAS_W1(1, 4, 1));
+#undef EAS_W1
+}
+
 int eas_conv1x1_wgrad_dispatch(const float* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st) {
     W1Geom g{};
     if (HW % 16 != 0) return EAS_ERR_UNSUPPORTED;

@@ -544,6 +544,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
                          hipStream_t st);
+int eas_conv1x1_dispatch_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, hipStream_t st);
 
 extern "C" {
 
@@ -640,6 +641,20 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                  int stride, int x_terms, int* inexact_flag, eas_stream_t stream) {
     return conv_fwd_impl(x, packed_w, bias, y, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, inexact_flag, stream, false);
+}
+
+// 1x1 convolution (stride 1) of a spike tensor given as BYTES (values 0..255: spikes and their SEW sums, as eas_bn_lif_fwd_ex writes
+// them next to the fp32 copy): the HBM-bound 1x1 layers read 1 B instead of 4 B per input element.  Same arithmetic and the same
+// result, bit for bit, as eas_conv_fwd with x_terms = 1 on the fp32 copy.
+int eas_conv_fwd_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                    eas_stream_t stream) {
+    if (!x || !packed_w || !y || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+    if (ksize != 1 || Cin % 8 != 0) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    const int rc = eas_conv1x1_dispatch_u8(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, eas_s(stream));
+    if (rc != EAS_OK) return rc;
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
 }
 
 // 1 when eas_conv_fwd has a tile for this geometry.  Rows whose staged patch does not fit LDS in one piece (3x3 layers with

@@ -39,8 +39,14 @@ struct WgGeom {
     int RT, rows_seg, nseg, rows_in, RS, Q;
     int total_rows, ntiles, kslices;
     int ci_blocks;
-    int pitchX, pitchY;      // row strides of x / grad_y in floats (a column part of a wider image keeps the image's pitch)
-    int own_lo, own_hi;      // grad_y columns of this (sub-)image that count; the others are read as zeros
+    int pitchX, pitchY;      // row strides of x / grad_y in floats = the full image widths
+    // Column parts (output rows wider than the 80-pixel reduction tile, or input rows whose staged patch does not fit LDS: stem and
+    // dark2.0 at 128x160 and wider): a tile is `Wo` output columns of the RT rows, Wo = full width / parts, and consecutive tile
+    // indices walk the parts of one row block (kslices is a multiple of parts, so a block always works on the same part and its
+    // per-thread geometry stays tile-independent).  The staged x rows then hold input columns part*Wo*S - hv .. (Wst of them,
+    // hv = one staging unit of halo on either side, units outside the image read the zero page) and there is no separately
+    // zeroed halo: lpad = 0, qshift = hv - 1.  One part: Wst = Wi, lpad = 1, qshift = 0.
+    int parts, Wst, lpad, qshift, hv;
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -96,8 +102,8 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     const int buf_bytes = A_BYTES + XT * b_term;
     const int npix = g.RT * g.Wo;
 
-    // zero the halo columns of the x image in both buffers (never written again)
-    {
+    // zero the halo columns of the x image in both buffers (never written again; column parts stage their halo like any unit)
+    if (g.parts == 1) {
         const int rows = g.nseg * g.rows_in;
         for (int i = tid; i < rows * 2 * 4 * PN * XT * 2; i += NT) {   // 2 sides x 4 16-byte pieces x planes x terms x buffers
             int rest = i;
@@ -108,6 +114,17 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             const int col = side ? g.RS - 1 : 0;
             *(uint4*)(smem + (size_t)buf * buf_bytes + A_BYTES + (size_t)pl * b_plane + ((size_t)row * g.RS + col) * ROWB + piece * 16) =
                 make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    if (PN == 1 && g.Cin - ci0 < 32) {
+        const int ng = (g.Cin - ci0 + 7) / 8;                  // groups [ng, 4) of every staged pixel row stay zero
+        for (int i = tid; i < g.Q * (4 - ng) * XT * 2; i += NT) {
+            int rest = i;
+            const int grp = ng + rest % (4 - ng); rest /= (4 - ng);
+            const int q = rest % g.Q; rest /= g.Q;
+            const int t = rest % XT, buf = rest / XT;
+            *(uint4*)(smem + (size_t)buf * buf_bytes + A_BYTES + (size_t)t * b_term + (size_t)q * ROWB + grp * 16) = make_uint4(0, 0, 0, 0);
         }
     }
 
@@ -126,14 +143,20 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             if (p < npix) {
                 const int rl = p / g.Wo, c = p - rl * g.Wo;
                 const int seg = rl / g.rows_seg, rr = rl - seg * g.rows_seg;
-                q = (seg * g.rows_in + rr * S) * g.RS + c * S;
+                q = (seg * g.rows_in + rr * S) * g.RS + c * S + g.qshift;
             }
             b_lane[ks][rd] = A_BYTES + pn * b_plane + q * ROWB + lane_col_bytes;   // + tap offset + term*b_term
         }
 
     // ---- staging items: item = VEC pixels x 8 channels; ids [0,nA) grad_y, [nA,nA+nB) x
     const int unitsA = TP / VEC, nA = unitsA * 4 * PM;
-    const int units_row = g.Wi / VEC, units_seg = g.rows_in * units_row, unitsB = g.nseg * units_seg, nB = unitsB * 4 * PN;
+    // 8-channel groups of x that exist (a layer with fewer than 32 input channels -- the stem has 8 -- stages only those; the
+    // other groups of its single plane are zeroed once, below)
+    const int nbg = PN == 1 ? (g.Cin - ci0 >= 32 ? 4 : (g.Cin - ci0 + 7) / 8) : 4 * PN;
+    const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, unitsB = g.nseg * units_seg, nB = unitsB * nbg;
+    const int part = g.parts > 1 ? (int)(blockIdx.x % g.parts) : 0;
+    const int ycol0 = part * g.Wo;                              // first grad_y column of this block's tiles
+    const int xcol0 = g.parts > 1 ? ycol0 * S - g.hv : 0;       // input column of the first staged unit (may be < 0)
     const int nitems = nA + nB;
     const size_t planeY = (size_t)g.Ho * g.pitchY, planeX = (size_t)g.Hi * g.pitchX;
     int it_kind[NIT], it_seg[NIT], it_row[NIT], it_col[NIT], it_ch[NIT], it_lofs[NIT];   // kind: 0 grad_y, 1 x, 2 padding (zeros)
@@ -161,13 +184,13 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             it_row[it] = rl;
             it_col[it] = cu * VEC;
             it_ch[it] = gi * 8;
-            it_lofs[it] = A_BYTES + (gi >> 2) * b_plane + ((seg * g.rows_in + rl) * g.RS + 1 + cu * VEC) * ROWB + (gi & 3) * 16;
+            it_lofs[it] = A_BYTES + (gi >> 2) * b_plane + ((seg * g.rows_in + rl) * g.RS + g.lpad + cu * VEC) * ROWB + (gi & 3) * 16;
         }
     }
 
     vecf L[NIT][8];
     auto fetch = [&](int it, int tile) {
-        const int rho0 = tile * g.RT;
+        const int rho0 = (g.parts > 1 ? tile / g.parts : tile) * g.RT;
         const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
         const int img = img0 + it_seg[it];
         const float* src;
@@ -175,14 +198,15 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
         bool ok;
         if (it_kind[it] == 1) {
             const int ir = r0 * S - 1 + it_row[it];
-            ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin;
+            const int gc = xcol0 + it_col[it];
+            ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin && gc >= 0 && gc < g.pitchX;
             const int ch = ci0 + it_ch[it] < g.Cin ? ci0 + it_ch[it] : g.Cin - 8;
-            src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.pitchX + it_col[it];
+            src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.pitchX + (ok ? gc : 0);
             plane = planeX;
         } else {
-            ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout && it_col[it] >= g.own_lo && it_col[it] < g.own_hi;
+            ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout;
             const int ch = co0 + it_ch[it] < g.Cout ? co0 + it_ch[it] : g.Cout - 8;
-            src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.pitchY + (ok ? it_col[it] : 0);
+            src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.pitchY + (ok ? ycol0 + it_col[it] : 0);
             plane = planeY;
         }
         const float* sp = ok ? src : eas_wg_zero_page;
@@ -322,7 +346,8 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
     auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC>;
     constexpr int NT = 192 * PM * PN;
     const size_t lds = (size_t)2 * (3 * PM * A_PLANE + (size_t)XT * PN * g.Q * ROWB);
-    const int nitems = (TP / VEC) * 4 * PM + g.nseg * g.rows_in * (g.Wi / VEC) * 4 * PN;
+    const int nbg = PN == 1 && g.Cin < 32 ? (g.Cin + 7) / 8 : 4 * PN;
+    const int nitems = (TP / VEC) * 4 * PM + g.nseg * g.rows_in * (g.Wst / VEC) * nbg;
     if (lds > 160 * 1024 || nitems > (PM * PN == 4 ? 1 : 2) * NT) {
         if (getenv("EAS_CONV_DBG")) fprintf(stderr, "wgrad launch: lds %zu nitems %d NT %d PM %d PN %d VEC %d RT %d Q %d\n", lds, nitems, NT, PM, PN, VEC, g.RT, g.Q);
         return EAS_ERR_UNSUPPORTED;
@@ -342,7 +367,7 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
 struct WgPlan { int pm, pn, kslices; };
 
 // block shape and number of pixel slices for a layer (shared by the workspace query and the launch)
-WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles) {
+WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts) {
     WgPlan p;
     p.pm = Cout >= 64 ? 2 : 1;
     p.pn = (Cin >= 64 && stride == 1 && x_terms == 1) ? 2 : 1;
@@ -351,108 +376,98 @@ WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles) {
     int ks = (256 * per_cu + yz - 1) / yz;
     if (ks > ntiles) ks = ntiles;
     if (ks < 1) ks = 1;
+    if (parts > 1) {                       // a block keeps its column part: slices in whole multiples of the parts
+        ks = (ks / parts) * parts;
+        if (ks < parts) ks = parts;
+    }
     p.kslices = ks;
     return p;
 }
 
-bool wg_geom_cap(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int cap) {
+// geometry of a layer cut into `parts` column parts per row (1 = whole rows), tile <= cap output pixels
+bool wg_geom_cap(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int cap, int parts) {
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.Hi = Hi; g.Wi = Wi;
     g.Ho = (Hi + 2 - 3) / stride + 1;
-    g.Wo = (Wi + 2 - 3) / stride + 1;
+    const int WoF = (Wi + 2 - 3) / stride + 1;
+    g.parts = parts;
+    g.pitchX = Wi; g.pitchY = WoF;
+    if (parts == 1) {
+        g.Wo = WoF; g.Wst = Wi; g.lpad = 1; g.qshift = 0; g.hv = 0;
+        g.RS = Wi + 2;
+    } else {
+        if (WoF % parts != 0 || Wi % 4 != 0 || ((WoF / parts) * stride) % 4 != 0 || (WoF / parts) % 4 != 0 || WoF * stride != Wi) return false;
+        g.Wo = WoF / parts; g.hv = 4; g.Wst = g.Wo * stride + 2 * g.hv; g.lpad = 0; g.qshift = g.hv - 1;
+        g.RS = g.Wst;
+    }
     g.RT = pick_rows(g.Ho, g.Wo, cap);
     if (g.RT == 0) return false;
     g.rows_seg = g.RT < g.Ho ? g.RT : g.Ho;
     g.nseg = g.RT / g.rows_seg;
     g.rows_in = (g.rows_seg - 1) * stride + 3;
-    g.RS = Wi + 2;
     g.Q = g.nseg * g.rows_in * g.RS;
     g.total_rows = NI * g.Ho;
-    g.ntiles = (g.total_rows + g.RT - 1) / g.RT;
-    g.pitchX = Wi; g.pitchY = g.Wo; g.own_lo = 0; g.own_hi = g.Wo;
+    g.ntiles = ((g.total_rows + g.RT - 1) / g.RT) * parts;
     return true;
 }
 
-// largest tile (<= 80 output pixels) whose double-buffered images and staging items fit the block
+// largest tile (<= 80 output pixels) whose double-buffered images and staging items fit the block; whole rows first, then 2, 4
+// and 8 column parts per row
 bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
-    for (int cap = TP; cap >= 2; cap /= 2) {
-        if (!wg_geom_cap(g, NI, Cin, Cout, Hi, Wi, stride, cap)) continue;
-        const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
-        const int vec = (Wi % 4 == 0 && g.Wo % 4 == 0) ? 4 : 2;
-        const size_t lds = (size_t)2 * (3 * p.pm * A_PLANE + (size_t)x_terms * p.pn * g.Q * ROWB);
-        const int nitems = (TP / vec) * 4 * p.pm + g.nseg * g.rows_in * (Wi / vec) * 4 * p.pn;
-        if (lds <= 160 * 1024 && nitems <= (p.pm * p.pn == 4 ? 1 : 2) * 192 * p.pm * p.pn) return true;
+    static const int force_parts = getenv("EAS_WG_PARTS") ? atoi(getenv("EAS_WG_PARTS")) : 0;      // development switch
+    for (int parts = force_parts > 0 ? force_parts : 1; parts <= 8; parts *= 2) {
+        for (int cap = TP; cap >= 8; cap /= 2) {
+            if (!wg_geom_cap(g, NI, Cin, Cout, Hi, Wi, stride, cap, parts)) continue;
+            const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, parts);
+            const int vec = parts > 1 ? 4 : ((Wi % 4 == 0 && g.Wo % 4 == 0) ? 4 : 2);
+            const size_t lds = (size_t)2 * (3 * p.pm * A_PLANE + (size_t)x_terms * p.pn * g.Q * ROWB);
+            const int nbg = p.pn == 1 && Cin < 32 ? (Cin + 7) / 8 : 4 * p.pn;
+            const int nitems = (TP / vec) * 4 * p.pm + g.nseg * g.rows_in * (g.Wst / vec) * nbg;
+            if (lds <= 160 * 1024 && nitems <= (p.pm * p.pn == 4 ? 1 : 2) * 192 * p.pm * p.pn) return true;
+        }
+        if (force_parts > 0) break;
     }
     return false;
-}
-
-// A layer whose output rows do not fit the 80-pixel reduction tile (or whose staged input rows do not fit LDS) is cut into
-// column parts: part p owns TW output columns and runs as a convolution over the sub-image made of its own columns plus
-// kExt more on each inner side (so every staged vector stays 16-byte aligned); grad_y columns outside the owned range are
-// read as zeros, which makes the sub-image's artificial zero halo irrelevant.  Row pitch stays the full image's.
-constexpr int kExt = 4;
-constexpr int kMaxParts = 16;
-struct WgPart { WgGeom g; WgPlan p; int xoff, yoff, slab0; };
-
-// returns the number of parts (0 = unsupported); total slab count in *slabs
-int wg_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms, WgPart* parts, int* slabs) {
-    WgGeom g{};
-    *slabs = 0;
-    if (wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) {
-        parts[0].g = g;
-        parts[0].p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles);
-        parts[0].xoff = parts[0].yoff = parts[0].slab0 = 0;
-        *slabs = parts[0].p.kslices;
-        return 1;
-    }
-    const int Wo = (Wi + 2 - 3) / stride + 1;
-    if (Wi % 4 != 0 || Wo % 4 != 0 || Wo * stride != Wi) return 0;
-    for (int TW = 40; TW >= 8; TW -= 4) {
-        if (Wo % TW != 0 || Wo / TW > kMaxParts || Wo / TW < 2) continue;
-        const int np = Wo / TW;
-        bool ok = true;
-        int total = 0;
-        for (int p = 0; p < np && ok; ++p) {
-            const int c0 = p * TW;
-            const int lo = c0 - kExt < 0 ? 0 : c0 - kExt, hi = c0 + TW + kExt > Wo ? Wo : c0 + TW + kExt;
-            WgGeom gp{};
-            ok = wg_geom(gp, NI, Cin, Cout, Hi, (hi - lo) * stride, stride, x_terms) && gp.Wo == hi - lo;
-            if (!ok) break;
-            gp.pitchX = Wi; gp.pitchY = Wo; gp.own_lo = c0 - lo; gp.own_hi = c0 - lo + TW;
-            parts[p].g = gp;
-            parts[p].p = wg_plan(Cin, Cout, stride, x_terms, gp.ntiles);
-            parts[p].xoff = lo * stride; parts[p].yoff = lo; parts[p].slab0 = total;
-            total += parts[p].p.kslices;
-        }
-        if (ok) {
-            *slabs = total;
-            return np;
-        }
-    }
-    return 0;
 }
 
 }  // namespace
 
 int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW);
 int eas_conv1x1_wgrad_dispatch(const float* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st);
+int eas_conv1x1_wgrad_dispatch_u8(const uint8_t* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, hipStream_t st);
 
 extern "C" {
 
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
     if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi) * Cout * Cin : 0;
     if (ksize != 3) return 0;
-    WgPart parts[kMaxParts];
-    int slabs = 0;
-    if (!wg_parts(NI, Cin, Cout, Hi, Wi, stride, x_terms, parts, &slabs)) return 0;
-    return (int64_t)slabs * Cout * Cin * 9;
+    WgGeom g{};
+    if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
+    return (int64_t)wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts).kslices * Cout * Cin * 9;
 }
 
-// number of column parts eas_conv_wgrad uses for a 3x3 layer: 1 = the whole image rows fit one reduction tile, > 1 = column
-// parts (slower per flop: narrower tiles, re-staged halos), 0 = unsupported
+// number of column parts per row eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, 2..8 = column parts
+// (same kernel, one launch), 0 = unsupported
 int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
-    WgPart parts[kMaxParts];
-    int slabs = 0;
-    return wg_parts(NI, Cin, Cout, Hi, Wi, stride, x_terms, parts, &slabs);
+    WgGeom g{};
+    return wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms) ? g.parts : 0;
+}
+
+// grad_w[Cout][Cin] of a 1x1 convolution whose input is given as spike BYTES (see eas_conv_fwd_u8); workspace as eas_conv_wgrad with
+// ksize 1, x_terms 1.  Same result, bit for bit, as eas_conv_wgrad on the fp32 copy.
+int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
+                      int ksize, eas_stream_t stream) {
+    if (!x || !grad_y || !grad_w || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+    if (ksize != 1 || ((uintptr_t)x & 3)) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi);
+    if (slices <= 0) return EAS_ERR_UNSUPPORTED;
+    const int rc1 = eas_conv1x1_wgrad_dispatch_u8(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, eas_s(stream));
+    if (rc1 != EAS_OK) return rc1;
+    EAS_CHECK_LAUNCH();
+    const int n1 = Cout * Cin;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n1 + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n1, slices);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
 }
 
 // grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and grad_y[NI][Cout][Ho][Wo].
@@ -476,23 +491,17 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
     }
     if (ksize != 3 || (stride != 1 && stride != 2) || Cin % 8 != 0 || Cout % 8 != 0 || Wi % 2 != 0) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
-    WgPart parts[kMaxParts];
-    int slabs = 0;
-    const int np = wg_parts(NI, Cin, Cout, Hi, Wi, stride, x_terms, parts, &slabs);
-    if (np == 0) return EAS_ERR_UNSUPPORTED;
+    WgGeom g{};
+    if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;
+    if (g.Wo % 2 != 0 || (g.Ho * g.pitchY) % 4 != 0) return EAS_ERR_UNSUPPORTED;
+    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts);
+    g.kslices = p.kslices;
+    const int slabs = p.kslices;
     hipStream_t st = eas_s(stream);
     const int n = Cout * Cin * 9;
     int rc = EAS_ERR_UNSUPPORTED;
-    for (int ip = 0; ip < np; ++ip) {
-        WgGeom g = parts[ip].g;
-        const WgPlan p = parts[ip].p;
-        if (g.Wo % 2 != 0 || (g.Ho * g.Wo) % 4 != 0) return EAS_ERR_UNSUPPORTED;
-        g.kslices = p.kslices;
-        const float* xp = x + parts[ip].xoff;
-        const float* gyp = grad_y + parts[ip].yoff;
-        float* wsp = workspace + (size_t)parts[ip].slab0 * n;
-        const bool v4 = g.Wi % 4 == 0 && g.Wo % 4 == 0 && parts[ip].xoff % 4 == 0 && parts[ip].yoff % 4 == 0;
-#define EAS_WG(S_, XT_, PM_, PN_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4>(xp, gyp, wsp, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2>(xp, gyp, wsp, g, st))
+    const bool v4 = g.parts > 1 || (g.Wi % 4 == 0 && g.Wo % 4 == 0);
+#define EAS_WG(S_, XT_, PM_, PN_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4>(x, grad_y, workspace, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2>(x, grad_y, workspace, g, st))
 #define EAS_WG_SHAPE(S_, XT_)                                                  \
     do {                                                                       \
         if (p.pm == 2 && p.pn == 2) rc = EAS_WG(S_, XT_, 2, 2);                \
@@ -500,15 +509,14 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
         else if (p.pn == 2) rc = EAS_WG(S_, XT_, 1, 2);                        \
         else rc = EAS_WG(S_, XT_, 1, 1);                                       \
     } while (0)
-        if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1);
-        else if (stride == 1) EAS_WG_SHAPE(1, 3);
-        else if (x_terms == 1) EAS_WG_SHAPE(2, 1);
-        else EAS_WG_SHAPE(2, 3);
+    if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1);
+    else if (stride == 1) EAS_WG_SHAPE(1, 3);
+    else if (x_terms == 1) EAS_WG_SHAPE(2, 1);
+    else EAS_WG_SHAPE(2, 3);
 #undef EAS_WG_SHAPE
 #undef EAS_WG
-        if (rc != EAS_OK) return rc;
-        EAS_CHECK_LAUNCH();
-    }
+    if (rc != EAS_OK) return rc;
+    EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grad_w, n, slabs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -128,6 +128,29 @@ def _alpha_arg(sg_id, alpha):
     return float(alpha)
 
 
+# Spike tensors leave the fused BN+LIF kernels twice: as fp32 (what autograd, the 3x3 kernels and any outside reader see) and, when
+# asked for, once more as BYTES attached to the fp32 tensor as ``t._eas_u8`` (same shape, uint8).  The HBM-bound 1x1 convolutions
+# and their weight gradients read the byte copy: 1 B instead of 4 B per input element (eas_conv_fwd_u8 / eas_conv_wgrad_u8).
+SPIKE_BYTES = os.environ.get('EAS_SPIKE_BYTES', '1') == '1'      # development switch: 0 = fp32 only
+
+
+def spike_bytes(t):
+    """the uint8 copy of a spike tensor, or None"""
+    u = getattr(t, '_eas_u8', None)
+    return u if u is not None and u.shape == t.shape else None
+
+
+def fold_time(x_seq):
+    """[T, N, ...] -> [T*N, ...] keeping the spike tags (small-integer mark, byte copy)"""
+    x = x_seq.flatten(0, 1)
+    if is_small_int(x_seq):
+        mark_small_int(x)
+    u = spike_bytes(x_seq)
+    if u is not None:
+        x._eas_u8 = u.flatten(0, 1)
+    return x
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -243,10 +266,11 @@ def _channel_slice_of(g, Cc):
 class _BNLIFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v, t_bcast,
-                residual, cat_buf, cat_c0):
+                residual, cat_buf, cat_c0, u8_buf):
         """y: [T,N,C,H,W], or [N,C,H,W] standing for ``t_bcast`` identical time steps.  residual [T,N,C,H,W]: the output is
         spikes + residual (SEW shortcut).  cat_buf [T,N,Ctot,H,W]: the output is written as channels cat_c0.. of it and
-        returned as a view (concatenation in place)."""
+        returned as a view (concatenation in place).  u8_buf: True = also emit the byte copy of the output (fourth result);
+        a uint8 tensor shaped like cat_buf = write the byte copy into its channels cat_c0.. (returned as a view)."""
         running_mean, running_var, use_batch_stats, momentum, eps = bn_state
         _dev(y, gamma, beta, v_in, w)
         L = _lib.lib()
@@ -283,9 +307,15 @@ class _BNLIFFn(torch.autograd.Function):
             ctot = 0
         v_out = torch.empty(plane, dtype=torch.float32, device=dev) if write_v else None
         mo = torch.empty(plane, dtype=torch.float32, device=dev) if want_mean else None
-        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()), L.eas_bn_lif_fwd_ex, ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-              ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW, int(bool(t_bcast)),
-              C.byref(pend) if pend is not None else None, ptr(residual), ctot, stream())
+        u8 = None
+        if torch.is_tensor(u8_buf):
+            assert cat_buf is not None and u8_buf.dtype == torch.uint8 and u8_buf.shape == cat_buf.shape and u8_buf.is_contiguous()
+            u8 = u8_buf.narrow(2, cat_c0, Cc)
+        elif u8_buf:
+            u8 = torch.empty((T,) + tuple(plane), dtype=torch.uint8, device=dev)
+        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()) + (u8.numel() if u8 is not None else 0), L.eas_bn_lif_fwd_ex, ptr(y), 0, ptr(mean),
+              ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW,
+              int(bool(t_bcast)), C.byref(pend) if pend is not None else None, ptr(residual), ctot, ptr(u8), stream())
         del keep
         learn = sg_id == SG_PATAN
         if learn:
@@ -295,14 +325,16 @@ class _BNLIFFn(torch.autograd.Function):
         ctx.has_residual = residual is not None
         if v_out is not None:
             ctx.mark_non_differentiable(v_out)
-        return spikes, v_out, mo
+        if u8 is not None:
+            ctx.mark_non_differentiable(u8)
+        return spikes, v_out, mo, u8
 
     @staticmethod
-    def backward(ctx, g_s, g_v, g_mean):
+    def backward(ctx, g_s, g_v, g_mean, _g_u8):
         y, mean, invstd, gamma, beta, v_in, w, alpha_t = ctx.saved_tensors
         k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW, bcast = ctx.cfg
         L = _lib.lib()
-        nout = 18
+        nout = 19
         if g_s is None and g_mean is None:
             return (torch.zeros_like(y),) + (None,) * (nout - 1)
         g_res = g_s if ctx.has_residual else None          # d(spikes + residual)/d residual = identity: the same tensor, no copy
@@ -330,7 +362,7 @@ class _BNLIFFn(torch.autograd.Function):
             _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
                   ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma),
                   ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
-        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 5 + (ga,) + (None,) * 3 + (g_res, None, None)
+        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 5 + (ga,) + (None,) * 3 + (g_res, None, None, None)
 
 
 class _JoinFn(torch.autograd.Function):
@@ -351,10 +383,13 @@ class _JoinFn(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
-def join_channels(buf, *parts):
+def join_channels(buf, *parts, u8_buf=None):
+    """u8_buf: the byte copy of the whole concatenation (its channel slices were written by the producers of ``parts``)"""
     out = _JoinFn.apply(buf, *parts)
     if all(is_small_int(p) for p in parts):
         mark_small_int(out)
+        if u8_buf is not None and all(spike_bytes(p) is not None for p in parts):
+            out._eas_u8 = u8_buf
     return out
 
 
@@ -374,7 +409,8 @@ class _BNLIF2Fn(torch.autograd.Function):
         outs, saved, cfgs = [], [], []
         c0 = 0
         for gamma, beta, w, cfg in ((gamma_a, beta_a, w_a, cfg_a), (gamma_b, beta_b, w_b, cfg_b)):
-            (running_mean, running_var, use_batch_stats, momentum, eps), v_in, k_const, v_th, v_reset, flags, sg_id, alpha, write_v, cat, Cc = cfg
+            (running_mean, running_var, use_batch_stats, momentum, eps), v_in, k_const, v_th, v_reset, flags, sg_id, alpha, write_v, cat, Cc = cfg[:11]
+            want_u8 = cfg[11] if len(cfg) > 11 else False
             _dev(gamma, beta, v_in, w)
             v_in = _f32c(v_in)
             yp = y12.data_ptr() + 4 * c0 * HW
@@ -395,24 +431,30 @@ class _BNLIF2Fn(torch.autograd.Function):
                 spikes = torch.empty((T, N, Cc, H, W), dtype=torch.float32, device=dev)
                 ctot = 0
             v_out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev) if write_v else None
-            _call('eas_bn_lif_fwd', 8 * T * N * Cc * HW, L.eas_bn_lif_fwd_ex, yp, Ct, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-                  ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), None, T, N, Cc, HW, 0,
-                  C.byref(pend) if pend is not None else None, None, ctot, stream())
+            u8 = None
+            if want_u8:
+                if cat is not None and len(cat) > 2 and cat[2] is not None:
+                    u8 = cat[2].narrow(2, cat[1], Cc)
+                elif cat is None:
+                    u8 = torch.empty((T, N, Cc, H, W), dtype=torch.uint8, device=dev)
+            _call('eas_bn_lif_fwd', (8 + (1 if u8 is not None else 0)) * T * N * Cc * HW, L.eas_bn_lif_fwd_ex, yp, Ct, ptr(mean), ptr(invstd),
+                  ptr(gamma), ptr(beta), ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), None, T, N, Cc, HW, 0,
+                  C.byref(pend) if pend is not None else None, None, ctot, ptr(u8), stream())
             del keep
-            outs += [spikes, v_out]
+            outs += [spikes, v_out, u8]
             saved += [mean, invstd, gamma, beta, v_in, w]
             cfgs.append((k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), Cc, c0))
             c0 += Cc
         ctx.save_for_backward(y12, *saved)
         ctx.cfgs = cfgs
         ctx.dims = (T, N, Ct, HW)
-        for v in (outs[1], outs[3]):
+        for v in (outs[1], outs[2], outs[4], outs[5]):
             if v is not None:
                 ctx.mark_non_differentiable(v)
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g_sa, g_va, g_sb, g_vb):
+    def backward(ctx, g_sa, g_va, _g_ua, g_sb, g_vb, _g_ub):
         y12, *saved = ctx.saved_tensors
         T, N, Ct, HW = ctx.dims
         L = _lib.lib()
@@ -443,17 +485,22 @@ class _BNLIF2Fn(torch.autograd.Function):
 
 def bn_lif_pair(y12, a, b):
     """a / b: (gamma, beta, w, cfg) of the two layers, cfg = (bn_state, v_in, k_const, v_th, v_reset, flags, surrogate id, alpha,
-    write_v, cat or None, channels).  Returns (spikes_a, v_a, spikes_b, v_b)."""
-    return _BNLIF2Fn.apply(y12, a[0], a[1], a[2], b[0], b[1], b[2], a[3], b[3])
+    write_v, cat (buffer, first channel[, byte buffer]) or None, channels[, emit byte copy]).  Returns (spikes_a, v_a, spikes_b, v_b);
+    the byte copies are attached to the spike tensors (``spike_bytes``)."""
+    sa, va, ua, sb, vb, ub = _BNLIF2Fn.apply(y12, a[0], a[1], a[2], b[0], b[1], b[2], a[3], b[3])
+    if ua is not None:
+        sa._eas_u8 = ua
+    if ub is not None:
+        sb._eas_u8 = ub
+    return sa, va, sb, vb
 
 
 def conv2d_weight(x, weight, stride=1, small_int=None):
     """functional form of ``conv2d`` for a weight tensor that is not a module parameter (e.g. two concatenated 1x1 weights)"""
     if small_int is None:
         small_int = is_small_int(x)
-    if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
-        raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
-    return _ConvFn.apply(x, weight, None, stride, 1 if small_int else 3, None)
+    _verify_tags(x, small_int)
+    return _ConvFn.apply(x, weight, None, stride, 1 if small_int else 3, None, spike_bytes(x) if small_int else None)
 
 
 def bn_lif_supported(y_seq, T):
@@ -461,16 +508,24 @@ def bn_lif_supported(y_seq, T):
 
 
 def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_stats, momentum, eps, v_in, w, k_const,
-                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None, t_bcast=0, residual=None, cat=None):
+                     v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None, t_bcast=0, residual=None, cat=None,
+                     emit_bytes=False):
     """Fused BatchNorm(step_mode='m') + multi-step LIF on the conv output y_seq [T,N,C,H,W]
-    (or one plane [N,C,H,W] shared by ``t_bcast`` identical steps)."""
+    (or one plane [N,C,H,W] shared by ``t_bcast`` identical steps).  cat = (buffer, first channel[, byte buffer]);
+    emit_bytes: also write the output as bytes (attached to the returned spike tensor, see ``spike_bytes``)."""
     if write_v is None:
         write_v = _STATE_WRITEBACK
     state = (running_mean, running_var, bool(use_batch_stats), None if momentum is None else float(momentum), float(eps))
     sg_id = SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate)
-    return _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags), sg_id,
-                          _alpha_arg(sg_id, alpha), bool(want_mean), bool(write_v), int(t_bcast), residual,
-                          cat[0] if cat is not None else None, int(cat[1]) if cat is not None else 0)
+    u8_arg = False
+    if emit_bytes and SPIKE_BYTES:
+        u8_arg = (cat[2] if len(cat) > 2 and cat[2] is not None else False) if cat is not None else True
+    spikes, v_out, mo, u8 = _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags), sg_id,
+                                           _alpha_arg(sg_id, alpha), bool(want_mean), bool(write_v), int(t_bcast), residual,
+                                           cat[0] if cat is not None else None, int(cat[1]) if cat is not None else 0, u8_arg)
+    if u8 is not None:
+        spikes._eas_u8 = u8
+    return spikes, v_out, mo
 
 
 # Number of identical copies the current batch stands for (set by SeqToANNContainer while it runs a stateless block
@@ -939,24 +994,47 @@ def conv_pack_weights(w, mode=0):
     return packed
 
 
-def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms):
-    """conv2d(x [NI,Cin,H,W], packed weights), padding ksize//2, on the matrix cores."""
+def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
+    """conv2d(x [NI,Cin,H,W], packed weights), padding ksize//2, on the matrix cores.  x_u8: the byte copy of a spike tensor x
+    (1x1 convolutions read it instead of x: same result, a quarter of the input traffic)."""
     _dev(x, packed, bias)
-    x = _f32c(x)
     NI, Cin, Hi, Wi = x.shape
     pad = ksize // 2
     Ho, Wo = (Hi + 2 * pad - ksize) // stride + 1, (Wi + 2 * pad - ksize) // stride + 1
     y = torch.empty((NI, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     fl = 2.0 * y.numel() * Cin * ksize * ksize
+    if x_u8 is not None:
+        assert ksize == 1 and stride == 1 and x_terms == 1 and x_u8.dtype == torch.uint8 and x_u8.shape == x.shape
+        x_u8 = x_u8.contiguous()
+        _call('eas_conv_fwd', x_u8.numel() + 4 * y.numel(), _lib.lib().eas_conv_fwd_u8, ptr(x_u8), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout,
+              Hi, Wi, ksize, stream(), flops=fl, issue_flops=fl * 3)
+        return y
+    x = _f32c(x)
     _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
           ksize, stride, x_terms, None, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
     return y
 
 
-def conv_wgrad(x, gy, ksize, stride, x_terms):
-    """grad_w [Cout,Cin,3,3] of conv2d(x, w, stride, padding 1) given grad_y, on the matrix cores (deterministic)."""
-    _dev(x, gy)
-    x, gy = _f32c(x), _f32c(gy)
+def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None):
+    """grad_w [Cout,Cin,k,k] of conv2d(x, w, stride, padding k//2) given grad_y, on the matrix cores (deterministic).
+    x_u8: byte copy of a spike tensor (1x1 only): read instead of x."""
+    _dev(gy)
+    gy = _f32c(gy)
+    if x_u8 is not None:
+        NI, Cin, Hi, Wi = x_u8.shape
+        Cout = gy.shape[1]
+        L = _lib.lib()
+        nws = L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, Hi, Wi, 1, 1, 1)
+        if nws <= 0:
+            raise _lib.EasHipError('eas_conv_wgrad_u8: unsupported configuration')
+        ws = torch.empty(nws, dtype=torch.float32, device=gy.device)
+        gw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=gy.device)
+        fl = 2.0 * gy.numel() * Cin
+        _call('eas_conv_wgrad', x_u8.numel() + 4 * gy.numel(), L.eas_conv_wgrad_u8, ptr(x_u8), ptr(gy), ptr(gw), ptr(ws), NI, Cin, Cout, Hi, Wi, 1,
+              stream(), flops=fl, issue_flops=fl * 3)
+        return gw
+    _dev(x)
+    x = _f32c(x)
     NI, Cin, Hi, Wi = x.shape
     Cout = gy.shape[1]
     L = _lib.lib()
@@ -990,6 +1068,17 @@ def is_small_int(t):
     return getattr(t, '_eas_small_int', False)
 
 
+def _verify_tags(x, small_int):
+    """test-suite check (VERIFY_SMALL_INT, host sync): a tagged tensor is exact in bf16 and its byte copy equals it"""
+    if not (small_int and VERIFY_SMALL_INT):
+        return
+    if not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
+        raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
+    u = spike_bytes(x)
+    if u is not None and not bool((u.to(torch.float32) == x).all()):
+        raise _lib.EasHipError('the byte copy of a spike tensor differs from its fp32 values')
+
+
 def conv_eligible(x, conv):
     k = conv.kernel_size[0]
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.groups == 1 and conv.dilation == (1, 1)
@@ -1012,23 +1101,26 @@ def conv_fwd_supported(NI, Cin, Cout, Hi, Wi, k, stride, x_terms):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, x_terms, packs):
-        """packs: {mode: packed weights} made from the current values of ``w`` (packed_weights scope), or None."""
+    def forward(ctx, x, w, bias, stride, x_terms, packs, x_u8=None):
+        """packs: {mode: packed weights} made from the current values of ``w`` (packed_weights scope), or None.
+        x_u8: byte copy of the spike tensor x (1x1 convolutions: forward and weight gradient read it instead of x)."""
         _dev(x, w, bias)
         k, Cout = w.shape[-1], w.shape[0]
+        if x_u8 is not None and not (k == 1 and stride == 1 and x_terms == 1 and x.shape[-1] * x.shape[-2] % 16 == 0):
+            x_u8 = None
         if conv_fwd_supported(x.shape[0], x.shape[1], Cout, x.shape[2], x.shape[3], k, stride, x_terms):
             pk = packs[0] if packs and 0 in packs else conv_pack_weights(w, 0)
-            y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms)
+            y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms, x_u8)
         else:       # no tile for this geometry (not reached by the EAS-SNN models): library forward
             y = torch.ops.aten.convolution(x, w, bias, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, x_u8)
         ctx.cfg = (k, stride, x_terms, bias is not None)
         ctx.packs = packs        # valid for the backward of this forward (same weights; autograd forbids changing them in between)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, x_u8 = ctx.saved_tensors
         k, stride, x_terms, has_bias = ctx.cfg
         packs = ctx.packs
         gy = _f32c(gy)
@@ -1057,7 +1149,7 @@ class _ConvFn(torch.autograd.Function):
             except _lib.EasHipError:        # no tile for this width (checked before anything is launched): library input gradient
                 gx = None
         if own_w:
-            gw = conv_wgrad(x, gy, k, stride, x_terms)
+            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8)
         need_d = ctx.needs_input_grad[0] and not own_d
         need_w = ctx.needs_input_grad[1] and not own_w
         if need_d or need_w:
@@ -1067,7 +1159,7 @@ class _ConvFn(torch.autograd.Function):
             gw = rw if need_w else gw
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def _static_conv_ok(conv):
@@ -1182,12 +1274,11 @@ def conv2d(x, conv, small_int=None):
         return conv._conv_forward(x, conv.weight, conv.bias)
     if small_int is None:
         small_int = is_small_int(x)
-    if small_int and VERIFY_SMALL_INT and not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
-        raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
+    _verify_tags(x, small_int)
     packs = getattr(conv, '_eas_packs', None)
     if packs is not None and (_PACK_SCOPE is None or packs.get('gen') != _PACK_SCOPE):
         packs = None            # not inside the forward that made this packing: pack the weight as it is now
-    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs)
+    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs, spike_bytes(x) if small_int else None)
 
 
 # ------------------------------------------------------------------------------------------------ SPP pooling block

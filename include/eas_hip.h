@@ -197,6 +197,8 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
  *   (network_blocks.py:99-104) without a separate addition; out_ctot (0 or >= C): the spikes are written as C consecutive
  *   channels of a [T][N][out_ctot][HW] tensor, `spikes` pointing at the first of them -- the concatenations of CSPLayer
  *   (network_blocks.py:183-188) happen in place.  mean_out is the rate of the spikes themselves (without residual).
+ *   spikes_u8 (nullable): the output values once more as BYTES in the same layout (spikes and SEW sums are small integers):
+ *   the HBM-bound 1x1 convolutions that consume them read 1 B instead of 4 B per element (eas_conv_fwd_u8, eas_conv_wgrad_u8).
  * eas_bn_lif_bwd_ex: grad_s_ctot (0 or >= C): grad_s is such a channel slice of a wider gradient tensor.
  * y_ctot (0 or >= C) in all three: y -- and grad_y in the backward -- are C consecutive channels of a [T][N][y_ctot][HW]
  *   tensor, the pointers at the first of them: ONE convolution (concatenated weights) feeds the two 1x1 branches of a CSPLayer
@@ -214,7 +216,7 @@ int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, doub
 int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
                       const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                       int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
-                      const EasBnPending* pending, const float* residual, int out_ctot, eas_stream_t stream);
+                      const EasBnPending* pending, const float* residual, int out_ctot, uint8_t* spikes_u8, eas_stream_t stream);
 int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
@@ -314,8 +316,13 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
-/* 1 when eas_conv_fwd has a tile for this geometry, else 0 (it would return EAS_ERR_UNSUPPORTED): one tile's staged input
- * rows must fit LDS, which general fp32 inputs of 3x3 convolutions on rows wider than ~280 pixels do not. */
+/* 1x1 convolution (stride 1) of a spike tensor given as BYTES (uint8 [NI][Cin][Hi][Wi], values 0..255: what eas_bn_lif_fwd_ex writes
+ * to spikes_u8): same arithmetic and the same result, bit for bit, as eas_conv_fwd with x_terms = 1 on the fp32 copy, reading
+ * 1 B instead of 4 B per input element (the 1x1 layers are HBM-bound).  Cin % 8 == 0. */
+int eas_conv_fwd_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi,
+                    int ksize, eas_stream_t stream);
+/* 1 when eas_conv_fwd has a tile for this geometry, else 0 (it would return EAS_ERR_UNSUPPORTED).  3x3 layers whose staged input
+ * rows do not fit LDS in one piece (real-valued inputs on rows wider than ~280 pixels) run in 2, 4 or 8 column parts. */
 int eas_conv_fwd_supported(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
 /* Input gradient of a stride-2 3x3 convolution: grad_x[NI][Cin][Hi][Wi] from grad_y[NI][Cout][Ho][Wo] and the weights
  * packed with mode 2 (eas_conv_pack_weights), by parity class of the input pixel (1/2/2/4 taps per class). */
@@ -328,11 +335,15 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
  * or three; per-block partial sums are reduced in fixed order through `workspace`
  * (eas_conv_wgrad_workspace_floats(...) floats) -- deterministic. */
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
-/* number of column parts eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, > 1 = column parts
- * (correct but slower per flop), 0 = unsupported. */
+/* number of column parts per row eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, 2..8 = column parts
+ * (same kernel, one launch), 0 = unsupported. */
 int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms);
 int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi,
                    int Wi, int ksize, int stride, int x_terms, eas_stream_t stream);
+/* grad_w[Cout][Cin] of a 1x1 convolution whose input is given as spike BYTES (see eas_conv_fwd_u8); workspace as eas_conv_wgrad
+ * with ksize 1, stride 1, x_terms 1; bit-identical to eas_conv_wgrad on the fp32 copy. */
+int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
+                      int ksize, eas_stream_t stream);
 
 /* SPP pooling block fused: out[N][4C][H][W] = cat[x, maxpool_k0(x), maxpool_k1(x), maxpool_k2(x)] (stride 1, padding k/2,
  * odd k; ATen tie rule: first maximum in row-major order) and its backward (arg-max recomputed from x; deterministic gather).

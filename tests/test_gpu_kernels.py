@@ -920,7 +920,7 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('NI,Cin,Cout,H,W,s', [(1, 8, 16, 6, 320, 1), (1, 16, 32, 8, 640, 2), (1, 16, 16, 4, 640, 1), (2, 8, 48, 12, 320, 1),
+@pytest.mark.parametrize('NI,Cin,Cout,H,W,s', [(1, 8, 16, 6, 320, 1), (1, 16, 32, 8, 320, 2), (1, 16, 16, 4, 640, 1), (2, 8, 48, 12, 320, 1),
                                                (2, 48, 96, 12, 320, 2)])
 def test_conv_on_rows_too_wide_for_one_lds_patch_runs_in_column_parts(dev, NI, Cin, Cout, H, W, s):
     """Real-valued 3x3 inputs on rows whose staged patch does not fit LDS in one piece (the stem / dark2.0 of the 1 Mpx
@@ -980,6 +980,50 @@ def test_prediction_conv_input_gradient_on_own_kernel(dev, Cout, H, W):
     for name, got, ref in (('y', y, y64), ('grad_x', xd.grad, x64.grad), ('grad_w', conv.weight.grad, w64.grad)):
         err = (got.detach().double().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
         assert err < 1e-5, f'{name}: {err:.2e}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,N,Cin,Cout,H,W,sew', [(3, 2, 32, 64, 16, 20, False), (3, 4, 64, 32, 8, 12, True), (5, 1, 128, 256, 4, 8, False),
+                                                  (3, 2, 256, 512, 8, 10, True)])
+def test_spike_bytes_feed_the_1x1_convolutions_bit_identically(dev, monkeypatch, T, N, Cin, Cout, H, W, sew):
+    """The fused BN+LIF kernel writes its spikes (and SEW sums) a second time as bytes; the 1x1 convolution reading them next
+    (eas_conv_fwd_u8) and its weight gradient (eas_conv_wgrad_u8) give exactly the results of the fp32 route: byte copy == fp32
+    spikes, y and grad_w bit-identical, grad_x untouched by the switch."""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    gen = torch.Generator().manual_seed(T * 100 + Cin)
+    yin = torch.randn(T, N, Cin, H, W, generator=gen).to(dev)
+    gamma, beta = (torch.rand(Cin, generator=gen) + 0.5).to(dev), (torch.randn(Cin, generator=gen) * 0.3).to(dev)
+    res = (torch.rand(T, N, Cin, H, W, generator=gen) < 0.3).float().to(dev) if sew else None
+    if res is not None:
+        ops.mark_small_int(res)
+    rm, rv = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+    wl = torch.zeros((), device=dev)
+    spikes, _, _ = ops.bn_lif_multistep(yin, gamma, beta, rm, rv, True, 0.03, 1e-3, None, wl, 0.0, 1.0, 0.0, 0, 'atan', 2.0, residual=res,
+                                        emit_bytes=True)
+    u8 = ops.spike_bytes(spikes)
+    assert u8 is not None and u8.dtype == torch.uint8 and torch.equal(u8.float(), spikes)
+    assert float(spikes.max()) == (2.0 if sew else 1.0)
+    ops.mark_small_int(spikes)
+    conv = nn.Conv2d(Cin, Cout, 1, 1, 0, bias=False).to(dev)
+    gy = torch.randn(T * N, Cout, H, W, generator=gen).to(dev)
+    outs = []
+    for use_bytes in (True, False):
+        x = spikes.detach().clone().requires_grad_(True)
+        if use_bytes:
+            x._eas_u8 = u8
+        ops.mark_small_int(x)
+        x4 = ops.fold_time(x)
+        assert (ops.spike_bytes(x4) is not None) == use_bytes
+        conv.weight.grad = None
+        y = ops.conv2d(x4, conv)
+        y.backward(gy)
+        outs.append((y.detach().clone(), conv.weight.grad.clone(), x.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    w64 = conv.weight.detach().double().cpu()
+    y64 = torch.nn.functional.conv2d(spikes.flatten(0, 1).double().cpu(), w64)
+    assert (outs[0][0].double().cpu() - y64).abs().max().item() / y64.abs().max().item() < 1e-5
 
 
 @pytest.mark.gpu
