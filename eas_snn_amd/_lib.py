@@ -46,6 +46,8 @@ PROTOTYPES = {
     'eas_upcat_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 5 + [_P]),
     'eas_focus': (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_event_voxel_grid': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'eas_event_window_search': (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P]),
+    'eas_event_histogram_dat_ranges': (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P, _P, _P]),
     'eas_stacked_hist_event_sum': (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P, _P]),
     'eas_lif_fwd': (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P, _P, C.c_int, C.c_int64, _P]),
     'eas_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,

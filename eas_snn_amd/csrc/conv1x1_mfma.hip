@@ -176,6 +176,131 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const TIN* __restr
     }
 }
 
+// Spike-byte input (eas_conv_fwd_u8), direct form.  Per-lane byte loads would issue as many load instructions as the fp32 form
+// (the texture path processes instructions, not bytes), so the quarter of the bytes would buy nothing.  Instead every lane
+// fetches 16 consecutive pixels of ONE channel with a single 16-byte load (a k-step of a wave = 16 channels x 32*WN pixels =
+// 512*WN bytes = 32*WN lanes), the wave parks them in its private LDS slice ([tile][channel][32 pixels], double-buffered, no
+// block barrier: a wave only reads what it wrote) and each lane picks the 8 channel bytes of its pixel from there
+// (8 ds_read_u8 per tile and k-step against 3*WM MFMAs).  HW % 16 == 0.
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv1x1_u8_kernel(const uint8_t* __restrict__ x, const bf16x8* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[4][2][WN * 16 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int mt0 = blockIdx.y * WM;
+    const int tile0 = (blockIdx.x * 4 + wave) * WN;
+    if (tile0 >= g.total_tiles) return;
+
+    long yoff[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int t = tile0 + n;
+        const int img = t / g.tiles_per_img, p = (t - img * g.tiles_per_img) * 32 + r;
+        yoff[n] = (t < g.total_tiles && p < g.HW) ? (long)img * g.Cout * g.HW + p : -1;
+    }
+    // staging role of this lane: channel j of the k-step, 16-pixel chunk c of tile sn
+    const int sj = lane & 15, sc = (lane >> 4) & 1, sn = lane >> 5;
+    long soff = -1;
+    if (sn < WN) {
+        const int t = tile0 + sn;
+        const int img = t / g.tiles_per_img, p0 = (t - img * g.tiles_per_img) * 32 + 16 * sc;
+        if (t < g.total_tiles && p0 < g.HW) soff = ((long)img * g.Cin + sj) * g.HW + p0;
+    }
+    const int s_lds = (sn * 16 + sj) * 32 + 16 * sc;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+    const size_t a_term = (size_t)g.MT * g.KSTEPS * 64;
+    const bf16x8* ap[WM];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const int mt = (mt0 + m) < g.MT ? (mt0 + m) : g.MT - 1;
+        ap[m] = wp + (size_t)mt * g.KSTEPS * 64 + lane;
+    }
+    auto fetch = [&](int ks) -> uint4 {
+        const bool ok = soff >= 0 && ks * 16 + sj < g.Cin;
+        const uint8_t* src = ok ? x + soff + (long)ks * 16 * g.HW : reinterpret_cast<const uint8_t*>(eas_c1_zero_page);
+        return *reinterpret_cast<const uint4*>(src);
+    };
+    auto commit = [&](int buf, const uint4& v) {
+        if (sn < WN) *reinterpret_cast<uint4*>(&stage[wave][buf][s_lds]) = v;
+    };
+    auto step = [&](int buf, int ks) {
+        bf16x8 a[WM][3];
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[m][t] = ap[m][t * a_term + (size_t)ks * 64];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            bf16x8 b;
+            const uint8_t* q = &stage[wave][buf][(n * 16 + 8 * h) * 32 + r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (__bf16)(float)q[j * 32];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b, acc[m][n], 0, 0, 0);
+            }
+        }
+    };
+
+    uint4 v = fetch(0);
+    commit(0, v);
+    for (int ks = 0; ks < g.KSTEPS; ++ks) {
+        const bool more = ks + 1 < g.KSTEPS;
+        if (more) v = fetch(ks + 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // this wave's LDS writes of buffer ks & 1 are visible to its reads
+        __builtin_amdgcn_wave_barrier();
+        step(ks & 1, ks);
+        if (more) commit((ks + 1) & 1, v);
+    }
+
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        if (mt0 + m >= g.MT) continue;
+        const int co0 = (mt0 + m) * 32 + 4 * h;
+        const bool full = (mt0 + m) * 32 + 32 <= g.Cout;
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (e & 3) + 8 * (e >> 2);
+                bv[e] = co < g.Cout ? bias[co] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            if (yoff[n] < 0) continue;
+            float* yp = y + yoff[n] + (long)co0 * g.HW;
+            if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+            }
+        }
+    }
+}
+
+template <int WM, int WN>
+int launch_c1_u8(const uint8_t* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
+    dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
+    hipLaunchKernelGGL((conv1x1_u8_kernel<WM, WN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    return EAS_OK;
+}
+
 // Variant for layers with many input channels and few pixels (dark5: 256..1024 channels on 15 360 pixels).  There the direct
 // kernel is bound by the texture path, not by HBM or the matrix cores: every wave fetches its own copy of the weight fragments
 // (WM x 3 KB per k-step) -- 64 KB per k-step and CU against 768 cycles of MFMA work.  Here the four waves of a block (same
@@ -404,6 +529,17 @@ static int conv1x1_dispatch_t(const TIN* x, const void* packed_w, const float* b
         if (wm == 2) return launch_c1<XT_, 2, 1, false, TIN>(x, wp, bias, y, g, st);                 \
         return launch_c1<XT_, 1, 1, false, TIN>(x, wp, bias, y, g, st);                              \
     } while (0)
+    if constexpr (U8) {
+        static const bool staged = !(getenv("EAS_C1_U8_FORM") && getenv("EAS_C1_U8_FORM")[0] == 'b');     // development: "bytes" = per-lane byte loads
+        if (staged && HW % 16 == 0) {
+            if (wm == 4 && wn == 2) return launch_c1_u8<4, 2>(x, wp, bias, y, g, st);
+            if (wm == 2 && wn == 2) return launch_c1_u8<2, 2>(x, wp, bias, y, g, st);
+            if (wm == 1 && wn == 2) return launch_c1_u8<1, 2>(x, wp, bias, y, g, st);
+            if (wm == 4) return launch_c1_u8<4, 1>(x, wp, bias, y, g, st);
+            if (wm == 2) return launch_c1_u8<2, 1>(x, wp, bias, y, g, st);
+            return launch_c1_u8<1, 1>(x, wp, bias, y, g, st);
+        }
+    }
     if (x_terms == 1) EAS_C1(1);
     if constexpr (!U8) EAS_C1(3);
 #undef EAS_C1

@@ -143,6 +143,80 @@ __global__ __launch_bounds__(EAS_BLOCK) void event_hist_dat_kernel(const uint2* 
     }
 }
 
+// ---- timestamp-window search on the device (second half) ------------------------------------------
+// GEN1Dataset.search_events (yolox/data/datasets/gen1.py:217-232) over PSEELoader.seek_time / load_delta_t
+// (yolox/utils/psee_loader/io/psee_loader.py:128-238), per label: the events of [ts + w0, ts + w0 + (w1 - w0)); while that is
+// empty the window steps back by its own length, num_slice + 2 attempts at most.  The reader's quirks are kept, because they
+// decide which events a sample is made of:
+//   seek_time(T): T past the last timestamp -> end of file; T <= 0 -> first event AND current time 0 (not T); otherwise a
+//   bisection that probes t[middle] while more than 100 000 events remain -- a probe that equals T exactly leaves the reader
+//   one event AFTER the probed one -- then the first event with t >= T;  load_delta_t(d): events up to the first with
+//   t >= current time + d.
+// One thread per label; a recording is records [file_offsets[f], file_offsets[f + 1]) of the .dat image in HBM.
+constexpr int64_t kSeekTermCriterion = 100000;
+
+__device__ __forceinline__ int64_t lower_bound_rec(const uint2* __restrict__ rec, int64_t lo, int64_t hi, int64_t key) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)rec[mid].x < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(EAS_WAVE) void event_window_search_kernel(const uint2* __restrict__ rec, const int64_t* __restrict__ file_offsets,
+                                                                       const int32_t* __restrict__ file_id,
+                                                                       const int64_t* __restrict__ label_t, int B, int64_t w0, int64_t w1,
+                                                                       int num_slice, int64_t* __restrict__ ranges) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int f = file_id ? file_id[b] : 0;
+    const int64_t base = file_offsets[f], n = file_offsets[f + 1] - base;
+    const uint2* r = rec + base;
+    const int64_t delta = w1 - w0;
+    const int64_t total = n > 0 ? (int64_t)r[n - 1].x : 0;
+    int64_t cur = label_t[b] + w0;
+    int64_t a = 0, e = 0;
+    for (int attempt = 0; attempt <= num_slice + 1; ++attempt, cur -= delta) {
+        int64_t pos, now;
+        if (cur > total) { pos = n; now = total + 1; }
+        else if (cur <= 0) { pos = 0; now = 0; }
+        else {
+            int64_t low = 0, high = n;
+            pos = -1;
+            while (high - low > kSeekTermCriterion) {
+                const int64_t middle = (low + high) / 2;
+                const int64_t mid = (int64_t)r[middle].x;
+                if (mid > cur) high = middle;
+                else if (mid < cur) low = middle + 1;
+                else { pos = middle + 1; break; }
+            }
+            if (pos < 0) pos = lower_bound_rec(r, low, high, cur);
+            now = cur;
+        }
+        a = pos;
+        e = pos >= n ? pos : lower_bound_rec(r, pos, n, now + delta);
+        if (e > a) break;
+    }
+    ranges[2 * b] = base + a;
+    ranges[2 * b + 1] = base + e;
+}
+
+// micro-slice count frames of arbitrary (possibly overlapping) record ranges: blockIdx.y = sample, blocks stride over its range
+__global__ __launch_bounds__(EAS_BLOCK) void event_hist_dat_ranges_kernel(const uint2* __restrict__ rec, const int64_t* __restrict__ ranges,
+                                                                          int Tm, int H, int W, int32_t* __restrict__ out,
+                                                                          uint32_t* __restrict__ oob) {
+    const int b = blockIdx.y;
+    const int64_t a = ranges[2 * b], e = ranges[2 * b + 1];
+    if (e <= a) return;
+    SampleWin w;
+    w.t0 = rec[a].x;
+    w.win = (rec[e - 1].x - w.t0) / (uint32_t)Tm;
+    for (int64_t i = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 v = rec[i];
+        bin_dat(v.x, v.y, w, b, Tm, H, W, out, oob);
+    }
+}
+
 // LDS-privatised form of the histogram for streams with many events per frame: one block owns one (sample, micro-slice,
 // band of rows) and keeps that band's two polarity planes in LDS (<= 150 KB).  The events of a micro-slice are a
 // contiguous run of the time-sorted stream (two binary searches = the reference's np.searchsorted, gen1.py:324-325), so the
@@ -463,6 +537,30 @@ int eas_event_histogram(const uint32_t* t, const uint16_t* x, const uint16_t* y,
                         const int64_t* sample_offsets, int B, int Tm, int H, int W, int32_t* out,
                         uint32_t* oob_count, eas_stream_t stream) {
     return histogram_impl(t, x, y, p, nev, sample_offsets, B, Tm, H, W, out, oob_count, nullptr, 0, 0, nullptr, stream);
+}
+
+int eas_event_window_search(const void* records, const int64_t* file_offsets, int F, const int32_t* file_id, const int64_t* label_t, int B,
+                            int64_t window_lo, int64_t window_hi, int num_slice, int64_t* ranges, eas_stream_t stream) {
+    if (!records || !file_offsets || !label_t || !ranges || F < 1 || B < 1 || window_hi - window_lo < 1 || num_slice < 0) return EAS_ERR_INVALID_ARG;
+    if ((uintptr_t)records & 7) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(event_window_search_kernel, dim3((B + EAS_WAVE - 1) / EAS_WAVE), dim3(EAS_WAVE), 0, eas_s(stream), (const uint2*)records,
+                       file_offsets, file_id, label_t, B, window_lo, window_hi, num_slice, ranges);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_event_histogram_dat_ranges(const void* records, const int64_t* ranges, int B, int Tm, int H, int W, int32_t* out, uint32_t* oob_count,
+                                   eas_stream_t stream) {
+    if (!records || !ranges || !out || B < 1 || Tm < 1 || H < 1 || W < 1 || ((uintptr_t)records & 7)) return EAS_ERR_INVALID_ARG;
+    hipStream_t st = eas_s(stream);
+    EAS_CLEAR_ERR();
+    if (hipMemsetAsync(out, 0, (size_t)B * Tm * 2 * H * W * sizeof(int32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    if (oob_count && hipMemsetAsync(oob_count, 0, sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
+    // the ranges live on the device (no host read): a fixed number of blocks per sample strides over whatever it holds
+    hipLaunchKernelGGL(event_hist_dat_ranges_kernel, dim3(64, B), dim3(EAS_BLOCK), 0, st, (const uint2*)records, ranges, Tm, H, W, out, oob_count);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
 }
 
 int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc, int Wc, float* out, eas_stream_t stream);

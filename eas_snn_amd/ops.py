@@ -634,6 +634,40 @@ def event_histogram_dat(records, sample_offsets, Tm, H, W, return_oob=False):
     return (out, oob) if return_oob else out
 
 
+def event_window_search(records, label_t, window, num_slice, file_offsets=None, file_id=None):
+    """Record ranges int64 [B, 2] of the events GEN1Dataset.search_events returns for every label (gen1.py:217-232), found on the
+    device.  records: the record area(s) of .dat recording(s) already in HBM (uint8 [8*nev] or any 8-byte-record view);
+    label_t int64 [B] label timestamps (us); window = (lo, hi) us relative to the label; file_offsets int64 [F+1] (record index of
+    every recording's first event; default: one recording) and file_id int32 [B]."""
+    _dev(records, label_t, file_offsets, file_id)
+    rec = records.contiguous().view(torch.uint8)
+    assert rec.numel() % 8 == 0 and label_t.dtype == torch.int64
+    nev = rec.numel() // 8
+    if file_offsets is None:
+        file_offsets = torch.tensor([0, nev], dtype=torch.int64, device=rec.device)
+    assert file_offsets.dtype == torch.int64 and (file_id is None or file_id.dtype == torch.int32)
+    B = label_t.numel()
+    ranges = torch.empty((B, 2), dtype=torch.int64, device=rec.device)
+    check(_lib.lib().eas_event_window_search(ptr(rec), ptr(file_offsets.contiguous()), file_offsets.numel() - 1,
+                                             ptr(file_id.contiguous() if file_id is not None else None), ptr(label_t.contiguous()), B,
+                                             int(window[0]), int(window[1]), int(num_slice), ptr(ranges), stream()), 'eas_event_window_search')
+    return ranges
+
+
+def event_histogram_dat_ranges(records, ranges, Tm, H, W, return_oob=False):
+    """Count frames int32 [B, Tm, 2, H, W] of the record ranges [B, 2] (``event_window_search``) of a .dat image in HBM: label
+    timestamps in, frames out, nothing read back to the host in between."""
+    _dev(records, ranges)
+    rec = records.contiguous().view(torch.uint8)
+    assert ranges.dtype == torch.int64 and ranges.dim() == 2 and ranges.shape[1] == 2
+    B = ranges.shape[0]
+    out = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=rec.device)
+    oob = torch.empty(1, dtype=torch.int32, device=rec.device) if return_oob else None
+    _call('eas_event_histogram_dat', 8 * (rec.numel() // 8) + 4 * out.numel(), _lib.lib().eas_event_histogram_dat_ranges, ptr(rec),
+          ptr(ranges.contiguous()), B, Tm, H, W, ptr(out), ptr(oob), stream())
+    return (out, oob) if return_oob else out
+
+
 def event_frames(t, x, y, p, sample_offsets, Tm, H, W, Hc, Wc):
     """raw events -> fp32 count frames on the zero-padded model canvas [B, Tm, 2, Hc, Wc] in one call (K1 + canvas)."""
     _dev(t, x, y, p, sample_offsets)

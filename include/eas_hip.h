@@ -108,6 +108,22 @@ int eas_event_time_surface(const uint32_t* t, const uint16_t* x, const uint16_t*
                            const int64_t* sample_offsets, int B, int num_slices, int H, int W, double tau,
                            uint32_t* workspace, double* out, eas_stream_t stream);
 
+/* Timestamp-window search on the device: replaces GEN1Dataset.search_events (yolox/data/datasets/gen1.py:217-232) and the
+ * PSEELoader.seek_time / load_delta_t calls under it (yolox/utils/psee_loader/io/psee_loader.py:128-238).  `records` is the
+ * record area of one or more .dat recordings in HBM (8 bytes per event, timestamps ascending inside a recording), recording f
+ * being records [file_offsets[f], file_offsets[f+1]).  For label b (recording file_id[b] -- NULL = recording 0 --, label time
+ * label_t[b] in us) ranges[2b], ranges[2b+1] receive the first / one-past-last RECORD index (into `records`) of the events of
+ * [label_t + window_lo, + (window_hi - window_lo)); an empty window steps back by its own length, num_slice + 2 attempts at most
+ * (the reference's zero_trigger rule).  The reader's behaviour is reproduced exactly, including seek_time's reset for targets
+ * <= 0 and its bisection probes on recordings of more than 100 000 events (a probe that equals the target leaves the reader one
+ * event past it).  Index work: bit-exact. */
+int eas_event_window_search(const void* records, const int64_t* file_offsets, int F, const int32_t* file_id, const int64_t* label_t, int B,
+                            int64_t window_lo, int64_t window_hi, int num_slice, int64_t* ranges, eas_stream_t stream);
+/* eas_event_histogram_dat for samples given as device-resident record ranges (the output of eas_event_window_search; the ranges
+ * of neighbouring labels overlap): out int32 [B][Tm][2][H][W], zeroed by the call.  No host read of the ranges. */
+int eas_event_histogram_dat_ranges(const void* records, const int64_t* ranges, int B, int Tm, int H, int W, int32_t* out,
+                                   uint32_t* oob_count, eas_stream_t stream);
+
 /* Config-4 input (BASELINE configs[3]): RVT stacked histogram -> per-polarity counts on the model canvas.  Replaces
  * RVTGEN4Dataset.generate_slices(..., method='event_sum') (yolox/data/datasets/rvt_gen4.py:109-125: reshape
  * [n][2*nbins][H][W] -> [n][2][nbins][H][W], sum over the bins, zero slices in FRONT when fewer than num_slice

@@ -272,6 +272,61 @@ def decode_dat_records(rec):
     return rec[:, 0].copy(), x.astype(np.uint16), y.astype(np.uint16), pp.astype(np.uint8)
 
 
+SEEK_TERM_CRITERION = 100000      # PSEELoader.seek_time's default term_criterion (psee_loader.py:196)
+
+
+def seek_time(t, final_time):
+    """(event index the reader stands at, its current_time) after PSEELoader.seek_time(final_time) on a recording with sorted
+    timestamps ``t`` (yolox/utils/psee_loader/io/psee_loader.py:196-238), quirks included:
+      * final_time past the last event -> end of file;  final_time <= 0 -> reset(): index 0 and current_time 0 (not final_time);
+      * the bisection probes ``t[middle]`` while more than 100 000 events remain; a probe that hits final_time EXACTLY returns at
+        once with the reader standing one event AFTER the probed one (np.fromfile has consumed it);
+      * otherwise the index of the first event with t >= final_time (np.searchsorted, side='left')."""
+    n = len(t)
+    total = int(t[-1]) if n else 0
+    if final_time > total:
+        return n, total + 1
+    if final_time <= 0:
+        return 0, 0
+    low, high = 0, n
+    while high - low > SEEK_TERM_CRITERION:
+        middle = (low + high) // 2
+        mid = int(t[middle])
+        if mid > final_time:
+            high = middle
+        elif mid < final_time:
+            low = middle + 1
+        else:
+            return middle + 1, final_time
+    return low + int(np.searchsorted(t[low:high], final_time)), final_time
+
+
+def load_delta_t(t, pos, current_time, delta_t):
+    """[pos, end): the events PSEELoader.load_delta_t(delta_t) returns from reader position ``pos`` (psee_loader.py:128-170): all
+    events from there with t < current_time + delta_t."""
+    if pos >= len(t):
+        return pos, pos
+    final_time = current_time + delta_t
+    return pos, pos + int(np.searchsorted(t[pos:], final_time))
+
+
+def search_events(t, timestamp, window, num_slice):
+    """Event index range [start, end) GEN1Dataset.search_events returns for the label at ``timestamp`` with the 'fix_t' policy
+    (yolox/data/datasets/gen1.py:217-232): the window [timestamp + window[0], + (window[1] - window[0])) first; while it is empty
+    it is moved back by its own length, for at most num_slice + 2 attempts in all; the last attempt's (possibly empty) range is
+    returned."""
+    delta = window[1] - window[0]
+    cur = timestamp + window[0]
+    zero_trigger = 0
+    while True:
+        pos, now = seek_time(t, cur)
+        a, e = load_delta_t(t, pos, now, delta)
+        if e > a or zero_trigger > num_slice:
+            return a, e
+        zero_trigger += 1
+        cur -= delta
+
+
 def encode_dat_file(t, x, y, p, height=240, width=304):
     """A ``.dat`` file image (header + 8-byte records) for synthetic events -- test input only."""
     head = ('% Data file containing Event2D events.\n% Version 2\n% Date 2024-1-1 0:0:0\n'

@@ -363,6 +363,67 @@ def gen_lif_layer():
          gdecay=_np(lay.cell.decay.grad))
 
 
+# ----------------------------------------------------------------------------- 8f rank 1: timestamp window search
+def gen_window_search():
+    """GEN1Dataset.search_events (gen1.py:217-232) with the real PSEELoader (psee_loader.py) on synthetic .dat recordings written
+    to a temp dir: the event index range it returns for a set of label timestamps, incl. the cases its bisection treats specially
+    (> 100 000 events: probes that hit a timestamp exactly; windows before the first / after the last event; empty windows that
+    make it step back).  Stored: the timestamps of each recording (its x / y / p are regenerated from the seed by the tests) and
+    (timestamp -> first event index, event count, first and last timestamp of the returned events)."""
+    import types
+    from yolox.data.datasets.gen1 import GEN1Dataset
+    from yolox.utils.psee_loader.io import dat_events_tools as dat_tools
+    from oracle import events_ref
+    # NumPy 2 compatibility only: parse_header hands back the event size as a numpy uint8 scalar, and PSEELoader's
+    # ``(end - start) // ev_size`` then raises under NumPy >= 2 (the reference pins 1.26, where the scalar is promoted).  The wrapper
+    # converts the two header bytes to Python ints; no arithmetic changes.
+    real_parse = dat_tools.parse_header
+    dat_tools.parse_header = lambda f: tuple(int(v) if isinstance(v, np.integer) else v for v in real_parse(f))
+    rng = np.random.default_rng(77)
+    arrays, names = {}, []
+    recs = {
+        # name: (timestamps, window, num_slice)
+        'long': ((5_000 + np.cumsum(rng.integers(0, 25, 250_000))).astype(np.uint32), (-200000, 0), 1),     # gaps 0..24 us: many equal timestamps
+        'gappy': (np.concatenate([np.sort(rng.integers(1_000, 50_000, 3000)), np.sort(rng.integers(2_000_000, 2_050_000, 3000))]).astype(np.uint32),
+                  (-100000, 0), 4),
+        'short': (np.sort(rng.integers(10, 90_000, 500)).astype(np.uint32), (-50000, 0), 1),
+    }
+    for name, (t, window, num_slice) in recs.items():
+        root = tempfile.mkdtemp(prefix='eas_dat_')
+        n = len(t)
+        x = rng.integers(0, 304, n).astype(np.uint16)
+        y = rng.integers(0, 240, n).astype(np.uint16)
+        p = rng.integers(0, 2, n).astype(np.uint8)
+        with open(os.path.join(root, f'{name}_td.dat'), 'wb') as fh:
+            fh.write(events_ref.encode_dat_file(t, x, y, p))
+        me = types.SimpleNamespace(files=[os.path.join(root, f'{name}_bbox.npy')], slice_policy='fix_t',
+                                   slice_args={'window': window, 'num_slice': num_slice})
+        stamps = [int(t[0]), int(t[-1]), int(t[-1]) + 1, int(t[-1]) + 150_000, int(t[-1]) + 10_000_000, 1, 50, int(t[n // 2]),
+                  int(t[n // 2]) + 1, int(t[n // 3]) - window[0], 1_000_000, 1_234_567, 2_500_000, 3_200_000]
+        if n > 200_000:
+            # a label whose window start equals the timestamp of a bisection probe: middle = n // 2 is the first probe
+            stamps += [int(t[n // 2]) - window[0], int(t[n // 4]) - window[0], int(t[n // 2 + n // 4]) - window[0]]
+        out = []
+        for ts in stamps:
+            ev = GEN1Dataset.search_events(me, 0, ts)
+            if len(ev):
+                first = int(np.searchsorted(t, ev['t'][0], side='left'))
+                while not (np.array_equal(t[first:first + len(ev)], ev['t']) and np.array_equal(x[first:first + len(ev)], ev['x'])):
+                    first += 1                      # equal timestamps: find the run by content
+                out.append((ts, first, len(ev), int(ev['t'][0]), int(ev['t'][-1])))
+            else:
+                out.append((ts, -1, 0, 0, 0))
+        arrays[f'{name}/t0'] = np.uint32(t[0])
+        arrays[f'{name}/gaps'] = np.diff(t).astype(np.uint32 if np.diff(t).max() > 255 else np.uint8)     # timestamps as gaps (compresses)
+        arrays[f'{name}/cfg'] = np.array([window[0], window[1], num_slice], np.int64)
+        arrays[f'{name}/result'] = np.array(out, np.int64)
+        names.append(name)
+        print(f'    {name}: {n} events, {sum(1 for o in out if o[2])} non-empty of {len(out)} searches')
+    dat_tools.parse_header = real_parse
+    arrays['cases'] = np.array(names)
+    save('window_search', **arrays)
+
+
 # ----------------------------------------------------------------------------- 8f rank 3: SOP / energy estimate
 def gen_energy():
     """EventEvaluator.energy_estimation (yolox/evaluators/event_evaluator.py:466-565) itself, run on the CPU: its CUDA-only tensor
@@ -655,11 +716,11 @@ def gen_models():
 def main():
     torch.set_num_threads(8)
     setup_reference_imports()
-    which = sys.argv[1:] or ['events', 'reps', 'augment', 'embeddings', 'lif', 'patan', 'stacked_hist', 'energy', 'blocks', 'models']
+    which = sys.argv[1:] or ['events', 'reps', 'augment', 'embeddings', 'lif', 'patan', 'stacked_hist', 'energy', 'window', 'blocks', 'models']
     for w in which:
         print(f'[{w}]')
         {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
-         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy}[w]()
+         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy, 'window': gen_window_search}[w]()
     assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
 
 

@@ -193,6 +193,51 @@ def test_event_histogram_full_size_properties(dev):
         assert np.array_equal(out[b].cpu().numpy(), ref.astype(np.int32))
 
 
+def test_window_search_on_the_device_matches_the_reference_reader(dev):
+    """eas_event_window_search against the ranges the reference's GEN1Dataset.search_events / PSEELoader returned
+    (tests/golden/window_search.npz): every label of a recording in one call, all three recordings as ONE multi-file image as well;
+    then label timestamps -> count frames with nothing read back in between (eas_event_histogram_dat_ranges) against the oracle's
+    micro_sum of the reference's event range."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    from test_oracle_golden import _window_search_cases
+    cases = list(_window_search_cases())
+    images, offs = [], [0]
+    rng = np.random.default_rng(5)
+    recs = {}
+    for name, t, window, ns, rows in cases:
+        n = len(t)
+        x = rng.integers(0, 304, n).astype(np.uint16); y = rng.integers(0, 240, n).astype(np.uint16); p = rng.integers(0, 2, n).astype(np.uint8)
+        img = events_ref.encode_dat_file(t, x, y, p)
+        start, _, _ = events_ref.parse_dat_header(img)
+        recs[name] = (np.frombuffer(img[start:], np.uint8).copy(), x, y, p)
+    for name, t, window, ns, rows in cases:
+        rec = _t(recs[name][0], dev)
+        labels = torch.tensor([int(r[0]) for r in rows], dtype=torch.int64, device=dev)
+        got = ops.event_window_search(rec, labels, window, ns).cpu().numpy()
+        for (ts, first, cnt, ta, tb), (a, e) in zip(rows, got):
+            assert e - a == cnt and (cnt == 0 or a == first), (name, int(ts), (int(a), int(e)), (int(first), int(cnt)))
+        # frames of the searched ranges, Tm = 4, against the oracle on the same events
+        frames = ops.event_histogram_dat_ranges(rec, torch.from_numpy(got).to(dev), 4, 240, 304).cpu().numpy()
+        _, x, y, p = recs[name]
+        for i, (a, e) in enumerate(got[:6]):
+            want = events_ref.micro_sum(t[a:e], x[a:e], y[a:e], p[a:e], 4, 240, 304).astype(np.int32) if e > a else np.zeros((4, 2, 240, 304), np.int32)
+            assert np.array_equal(frames[i], want), (name, i)
+    # same windows (one common window / num_slice) over a multi-recording image
+    window, ns = cases[0][2], cases[0][3]
+    allrec = np.concatenate([recs[c[0]][0] for c in cases])
+    file_off = np.cumsum([0] + [len(recs[c[0]][0]) // 8 for c in cases]).astype(np.int64)
+    lab, fid, want = [], [], []
+    for f, (name, t, _, _, rows) in enumerate(cases):
+        for ts in [int(r[0]) for r in rows[:8]]:
+            a, e = events_ref.search_events(t, ts, window, ns)
+            lab.append(ts); fid.append(f); want.append((file_off[f] + a, file_off[f] + e))
+    got = ops.event_window_search(_t(allrec, dev), torch.tensor(lab, dtype=torch.int64, device=dev), window, ns,
+                                  file_offsets=torch.from_numpy(file_off).to(dev), file_id=torch.tensor(fid, dtype=torch.int32, device=dev)).cpu().numpy()
+    for (a, e), (wa, we) in zip(got, want):
+        assert e - a == we - wa and (we == wa or a == wa)
+
+
 def test_stacked_hist_event_sum_golden_bit_exact(dev):
     """eas_stacked_hist_event_sum (config-4 input) against outputs of the reference's RVTGEN4Dataset.generate_slices('event_sum')
     (rvt_gen4.py:109-125): every fixture case as one ragged batch per representation geometry (young sequences = zero slices in
