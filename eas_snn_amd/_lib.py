@@ -16,6 +16,11 @@ _lib = None
 _f32p, _i32p, _u32p, _u16p, _u8p, _i64p, _f64p = (C.c_void_p,) * 7   # raw device addresses
 _P = C.c_void_p
 
+class EasWgradReduceJob(C.Structure):
+    """include/eas_hip.h: EasWgradReduceJob"""
+    _fields_ = [('slabs', C.c_void_p), ('grad_w', C.c_void_p), ('n', C.c_int), ('slabs_count', C.c_int)]
+
+
 class EasBnPending(C.Structure):
     """include/eas_hip.h EasBnPending: statistics whose finalize happens inside the consuming kernel."""
     _fields_ = [('partial', C.c_void_p), ('chunks', C.c_int), ('replicas', C.c_int), ('count', C.c_double), ('eps', C.c_float),
@@ -93,6 +98,9 @@ PROTOTYPES = {
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
     'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
     'eas_conv_wgrad_u8': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
+    'eas_conv_wgrad_partial': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P]),
+    'eas_conv_wgrad_u8_partial': (C.c_int, [_P] * 3 + [C.c_int] * 6 + [_P]),
+    'eas_conv_wgrad_reduce_many': (C.c_int, [_P, C.c_int, _P]),
     'eas_spp_pool_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
 }

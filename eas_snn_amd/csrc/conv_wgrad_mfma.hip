@@ -334,6 +334,49 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float*
     if (kl == 0 && i < n) gw[i] = (float)(((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
 }
 
+// The same reduction for MANY weight gradients in one launch (eas_conv_wgrad_reduce_many): a training step has ~80 weight
+// gradients whose slab reductions are each a few microseconds of work behind a launch; their results are not needed before the
+// optimizer step, so the host collects them and reduces them together.  Jobs travel BY VALUE in the kernel arguments (no device
+// table to fill, graph-capturable); block -> job by the prefix of 64-output blocks.
+constexpr int kReduceJobsPerLaunch = 96;
+struct ReduceJobs {
+    const float* slabs[kReduceJobsPerLaunch];
+    float* gw[kReduceJobsPerLaunch];
+    int n[kReduceJobsPerLaunch];
+    int kslices[kReduceJobsPerLaunch];
+    int first_block[kReduceJobsPerLaunch + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_many_kernel(const ReduceJobs jobs) {
+    __shared__ double part[4][64];
+    int lo = 0, hi = jobs.njobs;                 // job j owns blocks [first_block[j], first_block[j+1])
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (jobs.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const float* __restrict__ slabs = jobs.slabs[lo];
+    const int n = jobs.n[lo], kslices = jobs.kslices[lo];
+    const int o = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int i = ((int)blockIdx.x - jobs.first_block[lo]) * 64 + o;
+    double s = 0.0;
+    if (i < n) {                                  // identical summation order to conv_wgrad_reduce_kernel: bit-identical results
+        int k = kl;
+        for (; k + 12 < kslices; k += 16) {
+            const float a = slabs[(size_t)k * n + i], b = slabs[(size_t)(k + 4) * n + i], c = slabs[(size_t)(k + 8) * n + i],
+                        d = slabs[(size_t)(k + 12) * n + i];
+            s += (double)a;
+            s += (double)b;
+            s += (double)c;
+            s += (double)d;
+        }
+        for (; k < kslices; k += 4) s += (double)slabs[(size_t)k * n + i];
+    }
+    part[kl][o] = s;
+    __syncthreads();
+    if (kl == 0 && i < n) jobs.gw[lo][i] = (float)(((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
+}
+
 int pick_rows(int Ho, int Wo, int cap) {
     int best = 0;
     for (int rt = 1; rt * Wo <= cap; ++rt)
@@ -454,9 +497,10 @@ int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, 
 
 // grad_w[Cout][Cin] of a 1x1 convolution whose input is given as spike BYTES (see eas_conv_fwd_u8); workspace as eas_conv_wgrad with
 // ksize 1, x_terms 1.  Same result, bit for bit, as eas_conv_wgrad on the fp32 copy.
-int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
-                      int ksize, eas_stream_t stream) {
-    if (!x || !grad_y || !grad_w || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+// slab kernel only; returns the number of slabs written (> 0) or a negative status
+static int wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                            eas_stream_t stream) {
+    if (!x || !grad_y || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
     if (ksize != 1 || ((uintptr_t)x & 3)) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi);
@@ -464,17 +508,31 @@ int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, floa
     const int rc1 = eas_conv1x1_wgrad_dispatch_u8(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, eas_s(stream));
     if (rc1 != EAS_OK) return rc1;
     EAS_CHECK_LAUNCH();
+    return slices;
+}
+
+int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
+                      int ksize, eas_stream_t stream) {
+    if (!grad_w) return EAS_ERR_INVALID_ARG;
+    const int slices = wgrad_u8_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stream);
+    if (slices < 0) return slices;
     const int n1 = Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n1 + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n1, slices);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
 
+int eas_conv_wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                              eas_stream_t stream) {
+    return wgrad_u8_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stream);
+}
+
 // grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and grad_y[NI][Cout][Ho][Wo].
 // x_terms as in eas_conv_fwd.  workspace: eas_conv_wgrad_workspace_floats(...) floats.
-int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                   int stride, int x_terms, eas_stream_t stream) {
-    if (!x || !grad_y || !grad_w || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
+// slab kernel only; returns the number of slabs written (> 0) or a negative status
+static int wgrad_partial(const float* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                         int stride, int x_terms, eas_stream_t stream) {
+    if (!x || !grad_y || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
     if ((x_terms != 1 && x_terms != 3)) return EAS_ERR_UNSUPPORTED;
     if (ksize == 1) {
         if (stride != 1) return EAS_ERR_UNSUPPORTED;
@@ -484,10 +542,7 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
         const int rc1 = eas_conv1x1_wgrad_dispatch(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, x_terms, eas_s(stream));
         if (rc1 != EAS_OK) return rc1;
         EAS_CHECK_LAUNCH();
-        const int n1 = Cout * Cin;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n1 + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n1, slices);
-        EAS_CHECK_LAUNCH();
-        return EAS_OK;
+        return slices;
     }
     if (ksize != 3 || (stride != 1 && stride != 2) || Cin % 8 != 0 || Cout % 8 != 0 || Wi % 2 != 0) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
@@ -517,8 +572,44 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
 #undef EAS_WG
     if (rc != EAS_OK) return rc;
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grad_w, n, slabs);
+    (void)n;
+    return slabs;
+}
+
+int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                   int stride, int x_terms, eas_stream_t stream) {
+    if (!grad_w) return EAS_ERR_INVALID_ARG;
+    const int slabs = wgrad_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, stream);
+    if (slabs < 0) return slabs;
+    const int n = Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n, slabs);
     EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_conv_wgrad_partial(const float* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                           int stride, int x_terms, eas_stream_t stream) {
+    return wgrad_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, stream);
+}
+
+int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_stream_t stream) {
+    if (!jobs || njobs < 1) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    for (int j0 = 0; j0 < njobs; j0 += kReduceJobsPerLaunch) {
+        ReduceJobs a;
+        a.njobs = njobs - j0 < kReduceJobsPerLaunch ? njobs - j0 : kReduceJobsPerLaunch;
+        int blocks = 0;
+        for (int j = 0; j < a.njobs; ++j) {
+            const EasWgradReduceJob& q = jobs[j0 + j];
+            if (!q.slabs || !q.grad_w || q.n < 1 || q.slabs_count < 1) return EAS_ERR_INVALID_ARG;
+            a.slabs[j] = q.slabs; a.gw[j] = q.grad_w; a.n[j] = q.n; a.kslices[j] = q.slabs_count;
+            a.first_block[j] = blocks;
+            blocks += (q.n + 63) / 64;
+        }
+        a.first_block[a.njobs] = blocks;
+        hipLaunchKernelGGL(conv_wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, eas_s(stream), a);
+        EAS_CHECK_LAUNCH();
+    }
     return EAS_OK;
 }
 

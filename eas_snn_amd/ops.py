@@ -131,7 +131,10 @@ def _alpha_arg(sg_id, alpha):
 # Spike tensors leave the fused BN+LIF kernels twice: as fp32 (what autograd, the 3x3 kernels and any outside reader see) and, when
 # asked for, once more as BYTES attached to the fp32 tensor as ``t._eas_u8`` (same shape, uint8).  The HBM-bound 1x1 convolutions
 # and their weight gradients read the byte copy: 1 B instead of 4 B per input element (eas_conv_fwd_u8 / eas_conv_wgrad_u8).
-SPIKE_BYTES = os.environ.get('EAS_SPIKE_BYTES', '1') == '1'      # development switch: 0 = fp32 only
+# Measured on MI355X (bench.py, same box, A/B): the byte copies lower the input traffic of the 1x1 kernels but not their time
+# (conv family 9.88 -> 9.82 ms, weight gradients 5.59 -> 5.69 ms) and cost 0.11 ms in eas_bn_lif_fwd: 26.10 -> 26.44 ms per step.
+# So they are OFF by default (EAS_SPIKE_BYTES=1 switches them on); the kernels are kept and tested -- see DESIGN.md 7b.
+SPIKE_BYTES = os.environ.get('EAS_SPIKE_BYTES', '0') == '1'
 
 
 def spike_bytes(t):
@@ -1049,7 +1052,52 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
     return y
 
 
-def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None):
+# Deferred slab reductions.  Every weight gradient is slab kernel + fixed-order reduction of the slabs; inside a backward pass the
+# ~80 reductions of a training step (each a few microseconds of work behind a launch) are collected and done by ONE launch when
+# the autograd engine finishes the pass (eas_conv_wgrad_reduce_many; queue_callback), before anything can read a ``.grad``.
+# Outside a backward pass, or with EAS_DEFER_WGRAD_REDUCE=0, each gradient is reduced at once.  Same summation order either way.
+DEFER_WGRAD_REDUCE = os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1'
+_PENDING_REDUCE = []
+
+
+def _flush_wgrad_reductions():
+    global _PENDING_REDUCE
+    jobs, _PENDING_REDUCE = _PENDING_REDUCE, []
+    if not jobs:
+        return
+    arr = (_lib.EasWgradReduceJob * len(jobs))(*[_lib.EasWgradReduceJob(ws.data_ptr(), gw.data_ptr(), gw.numel(), n) for ws, gw, n in jobs])
+    t0 = _timer_mark()
+    check(_lib.lib().eas_conv_wgrad_reduce_many(arr, len(jobs), stream()), 'eas_conv_wgrad_reduce_many')
+    _timer_add('eas_conv_wgrad', t0, 0)
+
+
+def _wgrad_finish(ws, gw, nslabs, defer):
+    """reduce the slabs in ``ws`` into ``gw``: now, or together with the other weight gradients at the end of the backward pass"""
+    if defer:
+        if not _PENDING_REDUCE:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_reductions)
+        _PENDING_REDUCE.append((ws, gw, int(nslabs)))
+    else:
+        arr = (_lib.EasWgradReduceJob * 1)(_lib.EasWgradReduceJob(ws.data_ptr(), gw.data_ptr(), gw.numel(), int(nslabs)))
+        check(_lib.lib().eas_conv_wgrad_reduce_many(arr, 1, stream()), 'eas_conv_wgrad_reduce_many')
+
+
+def _partial_call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
+    """like _call for the *_partial entry points, whose non-negative return value is the slab count"""
+    if _TIMER is None:
+        rc = fn(*args)
+    else:
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        rc = fn(*args)
+        e_.record()
+        _TIMER.add(name, s_, e_, nbytes, flops, issue_flops)
+    if rc <= 0:
+        check(rc if rc < 0 else -2, name)
+    return rc
+
+
+def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False):
     """grad_w [Cout,Cin,k,k] of conv2d(x, w, stride, padding k//2) given grad_y, on the matrix cores (deterministic).
     x_u8: byte copy of a spike tensor (1x1 only): read instead of x."""
     _dev(gy)
@@ -1064,8 +1112,9 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None):
         ws = torch.empty(nws, dtype=torch.float32, device=gy.device)
         gw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=gy.device)
         fl = 2.0 * gy.numel() * Cin
-        _call('eas_conv_wgrad', x_u8.numel() + 4 * gy.numel(), L.eas_conv_wgrad_u8, ptr(x_u8), ptr(gy), ptr(gw), ptr(ws), NI, Cin, Cout, Hi, Wi, 1,
-              stream(), flops=fl, issue_flops=fl * 3)
+        ns = _partial_call('eas_conv_wgrad', x_u8.numel() + 4 * gy.numel(), L.eas_conv_wgrad_u8_partial, ptr(x_u8), ptr(gy), ptr(ws), NI, Cin, Cout,
+                           Hi, Wi, 1, stream(), flops=fl, issue_flops=fl * 3)
+        _wgrad_finish(ws, gw, ns, defer)
         return gw
     _dev(x)
     x = _f32c(x)
@@ -1078,8 +1127,9 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None):
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     gw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
     fl = 2.0 * gy.numel() * Cin * ksize * ksize
-    _call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad, ptr(x), ptr(gy), ptr(gw), ptr(ws), NI, Cin, Cout, Hi, Wi, ksize,
-          stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+    ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
+                       ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+    _wgrad_finish(ws, gw, ns, defer)
     return gw
 
 
@@ -1183,7 +1233,7 @@ class _ConvFn(torch.autograd.Function):
             except _lib.EasHipError:        # no tile for this width (checked before anything is launched): library input gradient
                 gx = None
         if own_w:
-            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8)
+            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8, defer=DEFER_WGRAD_REDUCE)
         need_d = ctx.needs_input_grad[0] and not own_d
         need_w = ctx.needs_input_grad[1] and not own_w
         if need_d or need_w:

@@ -361,6 +361,23 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
 int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
                       int ksize, eas_stream_t stream);
 
+/* Deferred slab reduction.  eas_conv_wgrad = slab kernel + a fixed-order reduction of the slabs; a training step has ~80 weight
+ * gradients and nothing reads them before the optimizer step, so the host may launch only the slab kernels
+ * (eas_conv_wgrad_partial / eas_conv_wgrad_u8_partial: same arguments without grad_w, return the number of slabs written, > 0, or a
+ * negative status) and reduce ALL of them with one launch: eas_conv_wgrad_reduce_many(jobs on the HOST, njobs).  Same summation
+ * order as eas_conv_wgrad: bit-identical gradients. */
+typedef struct {
+    const float* slabs;   /* the workspace a *_partial call filled */
+    float* grad_w;        /* n floats */
+    int n;                /* Cout*Cin*ksize*ksize */
+    int slabs_count;      /* return value of the *_partial call */
+} EasWgradReduceJob;
+int eas_conv_wgrad_partial(const float* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                           int stride, int x_terms, eas_stream_t stream);
+int eas_conv_wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                              eas_stream_t stream);
+int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_stream_t stream);
+
 /* SPP pooling block fused: out[N][4C][H][W] = cat[x, maxpool_k0(x), maxpool_k1(x), maxpool_k2(x)] (stride 1, padding k/2,
  * odd k; ATen tie rule: first maximum in row-major order) and its backward (arg-max recomputed from x; deterministic gather).
  * Replaces SPPBottleneck.forward's three MaxPool2d + torch.cat (yolox/models/network_blocks.py:143-147).  H*W <= 1024. */
