@@ -306,11 +306,16 @@ def main():
     ev = data.events_to_device(data.synth_event_batch(args.batch, args.events, *SENSOR, seed=rank), dev)
     targets = data.synth_targets(args.batch, CANVAS, dev)
 
+    # the slab reductions of all weight gradients in one launch at the end of the backward pass; DistributedDataParallel copies
+    # gradients into its buckets inside the pass, so not there
+    defer = ops.deferred_wgrad_reductions(not (net is not model) and os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1')
+
     def fwd_bwd():
         frames = data.events_to_frames(ev, exp.Tm, SENSOR, CANVAS)
         out = net(frames, targets)
         opt.zero_grad(set_to_none=True)
-        out['total_loss'].backward()
+        with defer:
+            out['total_loss'].backward()
         if flat_sync is not None:
             flat_sync.pack()
         return out['total_loss']

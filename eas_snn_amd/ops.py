@@ -1052,12 +1052,33 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
     return y
 
 
-# Deferred slab reductions.  Every weight gradient is slab kernel + fixed-order reduction of the slabs; inside a backward pass the
-# ~80 reductions of a training step (each a few microseconds of work behind a launch) are collected and done by ONE launch when
-# the autograd engine finishes the pass (eas_conv_wgrad_reduce_many; queue_callback), before anything can read a ``.grad``.
-# Outside a backward pass, or with EAS_DEFER_WGRAD_REDUCE=0, each gradient is reduced at once.  Same summation order either way.
-DEFER_WGRAD_REDUCE = os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1'
-_PENDING_REDUCE = []
+# Deferred slab reductions.  Every weight gradient is slab kernel + fixed-order reduction of the slabs.  A training loop that
+# owns its backward pass can switch ``deferred_wgrad_reductions`` on: the ~80 reductions of a step (each a few microseconds of work
+# behind a launch) are then collected and done by ONE launch when the autograd engine finishes the pass
+# (eas_conv_wgrad_reduce_many via queue_callback) -- the gradient tensors handed to autograd are filled a little later on the same
+# stream.  That is only sound when nothing reads a weight gradient DURING the backward pass, so it is off by default and the
+# operator falls back to the immediate reduction whenever it cannot know: a parameter that already has a ``.grad`` (accumulation
+# over several backward passes, DistributedDataParallel's bucket views), a weight that contributes twice to one pass (everything
+# pending is reduced first), any call outside a backward pass.  DistributedDataParallel with copy hooks reads gradients inside the
+# pass: leave the switch off there.  Same summation order either way: bit-identical gradients.
+DEFER_WGRAD_REDUCE = os.environ.get('EAS_DEFER_WGRAD_REDUCE', '0') == '1'
+_PENDING_REDUCE = []          # (workspace tensor kept alive, grad_w data_ptr, numel, slab count, weight data_ptr)
+
+
+class deferred_wgrad_reductions:
+    """``with ops.deferred_wgrad_reductions():`` around forward + backward of a training step (see above)"""
+
+    def __init__(self, flag=True):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        global DEFER_WGRAD_REDUCE
+        self.prev, DEFER_WGRAD_REDUCE = DEFER_WGRAD_REDUCE, self.flag
+
+    def __exit__(self, *exc):
+        global DEFER_WGRAD_REDUCE
+        DEFER_WGRAD_REDUCE = self.prev
+        _flush_wgrad_reductions()
 
 
 def _flush_wgrad_reductions():
@@ -1065,18 +1086,23 @@ def _flush_wgrad_reductions():
     jobs, _PENDING_REDUCE = _PENDING_REDUCE, []
     if not jobs:
         return
-    arr = (_lib.EasWgradReduceJob * len(jobs))(*[_lib.EasWgradReduceJob(ws.data_ptr(), gw.data_ptr(), gw.numel(), n) for ws, gw, n in jobs])
+    arr = (_lib.EasWgradReduceJob * len(jobs))(*[_lib.EasWgradReduceJob(ws.data_ptr(), gptr, gn, n) for ws, gptr, gn, n, _ in jobs])
     t0 = _timer_mark()
     check(_lib.lib().eas_conv_wgrad_reduce_many(arr, len(jobs), stream()), 'eas_conv_wgrad_reduce_many')
     _timer_add('eas_conv_wgrad', t0, 0)
 
 
-def _wgrad_finish(ws, gw, nslabs, defer):
-    """reduce the slabs in ``ws`` into ``gw``: now, or together with the other weight gradients at the end of the backward pass"""
+def _wgrad_finish(ws, gw, nslabs, defer, wkey=None):
+    """reduce the slabs in ``ws`` into ``gw``: now, or together with the other weight gradients at the end of the backward pass.
+    Only the ADDRESS of ``gw`` is kept: autograd must stay the sole owner of the tensor so that AccumulateGrad adopts it as the
+    parameter's ``.grad`` instead of cloning it (a clone would be taken before the reduction has run)."""
+    if defer and wkey is not None and any(j[4] == wkey for j in _PENDING_REDUCE):
+        _flush_wgrad_reductions()           # a second contribution to the same weight: autograd adds the two as soon as this returns
+        defer = False
     if defer:
         if not _PENDING_REDUCE:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_reductions)
-        _PENDING_REDUCE.append((ws, gw, int(nslabs)))
+        _PENDING_REDUCE.append((ws, gw.data_ptr(), gw.numel(), int(nslabs), wkey))
     else:
         arr = (_lib.EasWgradReduceJob * 1)(_lib.EasWgradReduceJob(ws.data_ptr(), gw.data_ptr(), gw.numel(), int(nslabs)))
         check(_lib.lib().eas_conv_wgrad_reduce_many(arr, 1, stream()), 'eas_conv_wgrad_reduce_many')
@@ -1097,7 +1123,7 @@ def _partial_call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     return rc
 
 
-def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False):
+def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False, wkey=None):
     """grad_w [Cout,Cin,k,k] of conv2d(x, w, stride, padding k//2) given grad_y, on the matrix cores (deterministic).
     x_u8: byte copy of a spike tensor (1x1 only): read instead of x."""
     _dev(gy)
@@ -1114,7 +1140,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False):
         fl = 2.0 * gy.numel() * Cin
         ns = _partial_call('eas_conv_wgrad', x_u8.numel() + 4 * gy.numel(), L.eas_conv_wgrad_u8_partial, ptr(x_u8), ptr(gy), ptr(ws), NI, Cin, Cout,
                            Hi, Wi, 1, stream(), flops=fl, issue_flops=fl * 3)
-        _wgrad_finish(ws, gw, ns, defer)
+        _wgrad_finish(ws, gw, ns, defer, wkey)
         return gw
     _dev(x)
     x = _f32c(x)
@@ -1129,7 +1155,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False):
     fl = 2.0 * gy.numel() * Cin * ksize * ksize
     ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
                        ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
-    _wgrad_finish(ws, gw, ns, defer)
+    _wgrad_finish(ws, gw, ns, defer, wkey)
     return gw
 
 
@@ -1233,7 +1259,7 @@ class _ConvFn(torch.autograd.Function):
             except _lib.EasHipError:        # no tile for this width (checked before anything is launched): library input gradient
                 gx = None
         if own_w:
-            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8, defer=DEFER_WGRAD_REDUCE)
+            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8, defer=DEFER_WGRAD_REDUCE and w.is_leaf and w.grad is None, wkey=w.data_ptr())
         need_d = ctx.needs_input_grad[0] and not own_d
         need_w = ctx.needs_input_grad[1] and not own_w
         if need_d or need_w:

@@ -1036,6 +1036,7 @@ def test_spike_bytes_feed_the_1x1_convolutions_bit_identically(dev, monkeypatch,
     spikes, y and grad_w bit-identical, grad_x untouched by the switch."""
     import torch.nn as nn
     from eas_snn_amd import ops
+    monkeypatch.setattr(ops, 'SPIKE_BYTES', True)            # off by default (no step-time gain measured, DESIGN.md 7b)
     gen = torch.Generator().manual_seed(T * 100 + Cin)
     yin = torch.randn(T, N, Cin, H, W, generator=gen).to(dev)
     gamma, beta = (torch.rand(Cin, generator=gen) + 0.5).to(dev), (torch.randn(Cin, generator=gen) * 0.3).to(dev)

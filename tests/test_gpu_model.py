@@ -326,6 +326,34 @@ def test_train_step_is_bit_reproducible(dev, name):
     assert not diff, f'run-to-run gradient differences in {diff}'
 
 
+def test_deferred_weight_gradient_reductions_are_bit_identical(dev):
+    """ops.deferred_wgrad_reductions(): the slab reductions of all weight gradients of a backward pass in ONE launch at its end
+    (eas_conv_wgrad_reduce_many) -- same loss, every parameter gradient bit-identical to the immediate reductions, also on a second
+    pass that ACCUMULATES into existing gradients (where the operator must fall back to the immediate form by itself)."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import functional
+    g, model = _build('model_s_true_64', dev)
+    model.train()
+    model.head.use_l1 = True
+    x, tg = torch.from_numpy(g['x']).to(dev), torch.from_numpy(g['targets']).to(dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(deferred, passes):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        for _ in range(passes):
+            out = model(x, tg)
+            with ops.deferred_wgrad_reductions(deferred):
+                out['total_loss'].backward()
+            functional.reset_net(model)
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+    for passes in (1, 2):
+        a, b = run(False, passes), run(True, passes)
+        diff = [n for n in a if not torch.equal(a[n], b[n])]
+        assert not diff, f'{passes} pass(es): {diff[:5]}'
+    assert not ops._PENDING_REDUCE
+
+
 def test_forward_after_fused_adam_step_uses_updated_weights(dev):
     """The packed MFMA weights must follow the optimizer: ``torch.optim.Adam(fused=True)`` (what EventExp.get_optimizer builds on
     the GPU) rewrites parameters without touching ``Tensor._version``.  Forward -> backward -> fused Adam steps -> forward again
