@@ -21,10 +21,15 @@ class EasWgradReduceJob(C.Structure):
     _fields_ = [('slabs', C.c_void_p), ('grad_w', C.c_void_p), ('n', C.c_int), ('slabs_count', C.c_int)]
 
 
+class EasCoop(C.Structure):
+    """include/eas_hip.h EasCoop: buffers of the in-kernel exchange between the blocks of a channel."""
+    _fields_ = [('slots', C.c_void_p), ('tickets', C.c_void_p), ('err', C.c_void_p), ('capacity', C.c_int)]
+
+
 class EasBnPending(C.Structure):
     """include/eas_hip.h EasBnPending: statistics whose finalize happens inside the consuming kernel."""
     _fields_ = [('partial', C.c_void_p), ('chunks', C.c_int), ('replicas', C.c_int), ('count', C.c_double), ('eps', C.c_float),
-                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p)]
+                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('coop', C.POINTER(EasCoop))]
 
 
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
@@ -63,6 +68,7 @@ PROTOTYPES = {
     'eas_time_mean': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     'eas_bn_workspace_doubles': (C.c_int64, [C.c_int]),
+    'eas_coop_slot_words': (C.c_int64, [C.c_int]),
     'eas_bn_lif_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
@@ -73,10 +79,10 @@ PROTOTYPES = {
     'eas_bn_lif_fwd_ex': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P, _P]),
     'eas_bn_lif_bwd_ex': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
-                                    C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+                                    C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasCoop), _P]),
     'eas_bn_lif_bwd_patan': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P,
-                                       _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
-    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 3 + [_P]),
+                                       _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasCoop), _P]),
+    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 3 + [C.POINTER(EasCoop), _P]),
     'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, _P]),
     'eas_arsnn_step_bwd': (C.c_int, [_P] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,

@@ -129,11 +129,39 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
                                                                const float* __restrict__ beta, const float* v_in, float* v_out,
                                                                EasLifParams p, float* __restrict__ spikes,
                                                                float* __restrict__ mean_out, int N, int C, int HW, int bcast,
-                                                               BnFin fin, BnLifOut ox) {
+                                                               BnFin fin, BnLifOut ox, EasCoopDev co) {
     __shared__ float st[2];
+    __shared__ double red[NW];
+    __shared__ double shd[2];
     const int c = blockIdx.y;
     float mu, istd;
-    if (fin.part) {
+    if (fin.coop) {
+        // batch statistics in this launch: sums over this block's own (image, pixel group) chunk and all T planes of it (one plane
+        // when the T steps share it), exchanged between the channel's blocks; the apply loop below re-reads the chunk from L2
+        const int hw4s = HW / VEC;
+        const int Cys = ox.y_ctot ? ox.y_ctot : C;
+        const int64_t ytss = bcast ? 0 : (int64_t)N * Cys * HW;
+        const int Tst = bcast ? 1 : T_;
+        double s = 0.0, ss = 0.0;
+        GroupWalk gs((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4s);
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (int64_t)N * hw4s; g += (int64_t)gridDim.x * blockDim.x, gs.next()) {
+            const int64_t yb = ((int64_t)gs.n * Cys + c) * (int64_t)HW + (int64_t)gs.q * VEC;
+            float4 v[T_];
+#pragma unroll
+            for (int t = 0; t < T_; ++t)
+                if (t < Tst) v[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * ytss + yb);
+#pragma unroll
+            for (int t = 0; t < T_; ++t)
+                if (t < Tst) {
+                    s += (double)v[t].x + (double)v[t].y + (double)v[t].z + (double)v[t].w;
+                    ss += (double)v[t].x * v[t].x + (double)v[t].y * v[t].y + (double)v[t].z * v[t].z + (double)v[t].w * v[t].w;
+                }
+        }
+        const double mine[2] = {eas_block_sum<double, NW>(s, red), eas_block_sum<double, NW>(ss, red)};
+        double tot[2];
+        eas_channel_allreduce<2>(co, c, gridDim.x, mine, tot, shd);
+        bn_from_totals(fin, c, tot[0], tot[1], blockIdx.x == 0 && threadIdx.x == 0, mu, istd);
+    } else if (fin.part) {
         bn_finalize_in_block(fin, c, st, mu, istd);
     } else {
         mu = mean[c];
@@ -210,6 +238,130 @@ __device__ __forceinline__ void recompute_dz(const float (&yv)[T_], const float 
                                            alpha, dkt, gx, da);
         dz[t] = gx;
         dk += dkt;
+    }
+}
+
+// One launch for both passes (EasCoop): pass 1 over the block's chunk, the channel's four sums exchanged in the kernel, pass 2 over
+// the same chunk (grad_s / y come from L2 / Infinity Cache this time), dL/dw and dL/dalpha summed over the channels by the last
+// channel to finish.
+template <int T_, bool HARD, bool DI, bool STRICT>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_coop_kernel(
+    const float* __restrict__ grad_s, const float* __restrict__ grad_mean, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
+    int batch_stats, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot,
+    const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha, EasCoopDev co) {
+    __shared__ double red[NW];
+    __shared__ double shd[4];
+    __shared__ int shi;
+    if (alpha_dev) alpha = fabsf(*alpha_dev);
+    const int c = blockIdx.y;
+    const float mu = mean[c], istd = invstd[c];
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
+    const float k = eas_lif_k(p);
+    const float omk = 1.0f - k;
+    const bool detach = (p.flags & EAS_LIF_DETACH_RESET) != 0;
+    const int hw4 = HW / VEC;
+    const int64_t groups = (int64_t)N * hw4;
+    const int64_t M = (int64_t)N * C * HW;
+    const float invT = 1.0f / (float)T_;
+    const int Cy = y_ctot ? y_ctot : C;
+    const int64_t My = (int64_t)N * Cy * HW;
+    const int64_t yts = bcast ? 0 : My;
+    const int64_t Mg = gs_ctot ? (int64_t)N * gs_ctot * HW : M;
+    const float vr0 = HARD ? p.v_reset : 0.0f;
+    float m1 = 0.f, m2 = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        float s1 = 0.f, s2 = 0.f, dk = 0.f, da = 0.f;
+        GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+            const int64_t n = gw.n;
+            const int q = gw.q;
+            const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+            const int64_t ybase = (n * Cy + c) * (int64_t)HW + (int64_t)q * VEC;
+            float4 ys[T_], gsv[T_];
+#pragma unroll
+            for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + ybase);
+            float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grad_mean) {
+                gm = *reinterpret_cast<const float4*>(grad_mean + base);
+                gm.x *= invT; gm.y *= invT; gm.z *= invT; gm.w *= invT;
+            }
+#pragma unroll
+            for (int t = 0; t < T_; ++t) {
+                gsv[t] = gm;
+                if (grad_s) {
+                    const int64_t gbase = gs_ctot ? (n * gs_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
+                    const float4 g4 = *reinterpret_cast<const float4*>(grad_s + (int64_t)t * Mg + gbase);
+                    gsv[t].x += g4.x; gsv[t].y += g4.y; gsv[t].z += g4.z; gsv[t].w += g4.w;
+                }
+            }
+            float4 v0 = make_float4(vr0, vr0, vr0, vr0);
+            if (v_init) v0 = *reinterpret_cast<const float4*>(v_init + base);
+            float4 outv[T_];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float yv[T_], gs[T_], dz[T_];
+#pragma unroll
+                for (int t = 0; t < T_; ++t) {
+                    yv[t] = reinterpret_cast<const float*>(&ys[t])[e];
+                    gs[t] = reinterpret_cast<const float*>(&gsv[t])[e];
+                }
+                float dke = 0.f;
+                recompute_dz<T_, HARD, DI, STRICT>(yv, gs, reinterpret_cast<const float*>(&v0)[e], scale, shift, k, omk, p, detach, sg_id, alpha,
+                                                   dz, dke, da);
+#pragma unroll
+                for (int t = 0; t < T_; ++t) {
+                    const float xhat = (yv[t] - mu) * istd;
+                    if (pass) {
+                        reinterpret_cast<float*>(&outv[t])[e] = scale * (dz[t] - m1 - xhat * m2);
+                    } else {
+                        s1 += dz[t];
+                        s2 += dz[t] * xhat;
+                    }
+                }
+                dk += dke;
+            }
+            if (pass) {
+                if (bcast) {
+                    float4 a = outv[0];
+#pragma unroll
+                    for (int t = 1; t < T_; ++t) { a.x += outv[t].x; a.y += outv[t].y; a.z += outv[t].z; a.w += outv[t].w; }
+                    *reinterpret_cast<float4*>(grad_y + ybase) = a;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * My + ybase) = outv[t];
+                }
+            }
+        }
+        if (pass == 0) {
+            const double t1 = eas_block_sum<double, NW>((double)s1, red);
+            const double t2 = eas_block_sum<double, NW>((double)s2, red);
+            const double t3 = eas_block_sum<double, NW>((double)dk, red);
+            const double t4 = sg_id == EAS_SG_PATAN ? eas_block_sum<double, NW>((double)da, red) : 0.0;
+            const double mine[4] = {t1, t2, t3, t4};
+            double tot[4];
+            eas_channel_allreduce<4>(co, c, gridDim.x, mine, tot, shd);
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                grad_beta[c] = (float)tot[0];
+                grad_gamma[c] = (float)tot[1];
+            }
+            const double cnt = (double)T_ * N * HW;
+            if (batch_stats) {
+                m1 = (float)(tot[0] / cnt);
+                m2 = (float)(tot[1] / cnt);
+            }
+            if (blockIdx.x == 0) {         // the neuron's scalar gradients: sums over all channels, by the last channel to arrive
+                double all;
+                if (grad_w && eas_all_channels_sum(co, 0, c, C, tot[2], all, shd, &shi) && threadIdx.x == 0) *grad_w = (float)all * (k * (1.0f - k));
+                if (grad_alpha && eas_all_channels_sum(co, 1, c, C, tot[3], all, shd, &shi) && threadIdx.x == 0) {
+                    const float a = *alpha_dev;
+                    *grad_alpha = (float)all * (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f));
+                }
+            }
+        }
     }
 }
 
@@ -365,10 +517,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
 template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_fwd_t(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                  const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-                 int bcast, const BnFin& fin, const BnLifOut& ox, hipStream_t st) {
+                 int bcast, const BnFin& fin, const BnLifOut& ox, const EasCoopDev& co, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
-                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox);
+                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, co);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -376,9 +528,9 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
 template <bool HARD, bool DI, bool STRICT>
 int launch_fwd(int T, const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-               int bcast, const BnFin& fin, const BnLifOut& ox, hipStream_t st) {
+               int bcast, const BnFin& fin, const BnLifOut& ox, const EasCoopDev& co, hipStream_t st) {
 #define EAS_CASE(TT) \
-    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, st);
+    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, co, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -390,8 +542,16 @@ template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
-                 int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, hipStream_t st) {
+                 int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, const EasCoopDev& co,
+                 hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    if (co.slots) {
+        hipLaunchKernelGGL((bn_lif_bwd_coop_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean, y, mean,
+                           invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, N, C, HW, bcast,
+                           gs_ctot, y_ctot, alpha_dev, grad_alpha, co);
+        EAS_CHECK_LAUNCH();
+        return EAS_OK;
+    }
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
                        grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
@@ -408,12 +568,12 @@ int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* 
                const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
                float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
                double* ws, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha,
-               hipStream_t st) {
+               const EasCoopDev& co, hipStream_t st) {
 #define EAS_CASE(TT)                                                                                               \
     case TT:                                                                                                       \
         return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
                                                   batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, y_ctot,         \
-                                                  alpha_dev, grad_alpha, st);
+                                                  alpha_dev, grad_alpha, co, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -465,8 +625,29 @@ int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, doub
     return stats_partial(y, TN, C, HW, workspace, y_ctot == C ? 0 : y_ctot, eas_s(stream));
 }
 
+static EasCoopDev coop_dev(const EasCoop* c) {
+    EasCoopDev d{};
+    if (c) {
+        d.slots = (unsigned long long*)c->slots;
+        d.tickets = c->tickets;
+        d.err = c->err;
+        d.capacity = c->capacity;
+    }
+    return d;
+}
+
+int64_t eas_coop_slot_words(int capacity) { return capacity < 1 ? 0 : (int64_t)capacity * EAS_BN_MAX_CHUNKS * EAS_COOP_K + 2 * (int64_t)capacity; }
+
 static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin& fin) {
     fin = BnFin{};
+    if (pend && !pend->partial && pend->coop) {
+        if (!pend->coop->slots || !pend->coop->tickets || !pend->coop->err) return EAS_ERR_INVALID_ARG;
+        if (!(pend->count >= 1.0) || pend->replicas < 1 || (pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
+        fin.coop = 1; fin.replicas = pend->replicas; fin.count = pend->count;
+        fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
+        fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
+        return EAS_OK;
+    }
     if (!pend || !pend->partial) return EAS_OK;
     if (pend->chunks < 1 || pend->chunks > kMaxChunks || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
     if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
@@ -488,13 +669,15 @@ int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, co
     if ((out_ctot != 0 && out_ctot < C) || (y_ctot != 0 && (y_ctot < C || y_bcast))) return EAS_ERR_INVALID_ARG;
     BnFin fin;
     if (int rc = fin_from(pending, mean, invstd, fin)) return rc;
+    if (fin.coop && pending->coop->capacity < C) return EAS_ERR_INVALID_ARG;
+    const EasCoopDev co = fin.coop ? coop_dev(pending->coop) : EasCoopDev{};
     const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot, y_ctot == C ? 0 : y_ctot, spikes_u8};
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
 #define EAS_DISPATCH(H, D, S) \
-    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, fin, ox, st)
+    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, fin, ox, co, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -516,8 +699,10 @@ static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* gr
                            const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                            float alpha, const float* alpha_dev, float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma,
                            float* grad_beta, float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast,
-                           eas_stream_t stream) {
-    if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
+                           const EasCoop* coop, eas_stream_t stream) {
+    if (coop && (!coop->slots || !coop->tickets || !coop->err || coop->capacity < C)) return EAS_ERR_INVALID_ARG;
+    const EasCoopDev co = coop_dev(coop);
+    if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || (!workspace && !coop) ||
         (!grad_s && !grad_mean) || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
     if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;
@@ -536,7 +721,7 @@ static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* gr
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
                                batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, yc,    \
-                               alpha_dev, grad_alpha, st)
+                               alpha_dev, grad_alpha, co, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -549,21 +734,21 @@ int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_me
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop, eas_stream_t stream) {
     if (surrogate == EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;      // learnable slope: eas_bn_lif_bwd_patan
     return bn_lif_bwd_impl(grad_s, grad_s_ctot, grad_mean, y, y_ctot, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset,
                            flags, surrogate, alpha, nullptr, nullptr, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C,
-                           HW, y_bcast, stream);
+                           HW, y_bcast, coop, stream);
 }
 
 int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, const float* v_init,
                          const float* w_logit, float k_const, float v_th, float v_reset, int flags, const float* alpha,
                          float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
+                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop, eas_stream_t stream) {
     return bn_lif_bwd_impl(grad_s, grad_s_ctot, grad_mean, y, y_ctot, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset,
                            flags, EAS_SG_PATAN, 0.f, alpha, grad_alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C,
-                           HW, y_bcast, stream);
+                           HW, y_bcast, coop, stream);
 }
 
 int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,
@@ -572,7 +757,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
                    float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
                    float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
     return eas_bn_lif_bwd_ex(grad_s, 0, grad_mean, y, 0, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset, flags,
-                             surrogate, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C, HW, y_bcast, stream);
+                             surrogate, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C, HW, y_bcast, nullptr, stream);
 }
 
 }  // extern "C"

@@ -83,7 +83,29 @@ struct BnFin {
     float* invstd_out;
     float* rmean;           // nullable
     float* rvar;
+    int coop;               // 1: no partials were computed beforehand -- the consuming kernel sums its own chunk and the blocks of a
+                            // channel exchange the sums in the kernel (eas_channel_allreduce)
 };
+
+// mean / invstd of channel c from its totals (sum, sum of squares); `publish` (one block per channel): write them for the backward
+// and update the running statistics.  Every thread may call it: same double arithmetic, same result.
+__device__ __forceinline__ void bn_from_totals(const BnFin& f, int c, double s, double ss, bool publish, float& mu, float& istd) {
+    const double m = s / f.count;
+    double var = ss / f.count - m * m;
+    if (var < 0.0) var = 0.0;
+    mu = (float)m;
+    istd = (float)(1.0 / sqrt(var + (double)f.eps));
+    if (publish) {
+        f.mean_out[c] = mu;
+        f.invstd_out[c] = istd;
+        if (f.rmean) {
+            const double full = f.count * f.replicas;
+            const double unbiased = full > 1.0 ? var * full / (full - 1.0) : var;
+            f.rmean[c] = (float)((1.0 - f.momentum) * f.rmean[c] + f.momentum * m);
+            f.rvar[c] = (float)((1.0 - f.momentum) * f.rvar[c] + f.momentum * unbiased);
+        }
+    }
+}
 
 __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, float* st, float& mu, float& istd) {
     if (threadIdx.x < EAS_WAVE) {
@@ -115,6 +137,129 @@ __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, floa
     __syncthreads();
     mu = st[0];
     istd = st[1];
+}
+
+// ------------------------------------------------------------------------------------------------ in-kernel channel all-reduce
+// The BN kernels decompose as blockIdx.y = channel, blockIdx.x = chunk.  Batch statistics (forward) and the two BN-backward sums
+// couple all chunks of a channel; instead of a separate partial-sum launch + a second pass over the data from HBM, the blocks of a
+// channel exchange their K partial sums INSIDE one launch and go on with the data they have just read (L2 / Infinity-Cache hits):
+//   every block publishes its partials with agent-scope atomic stores (XCD L2s are not coherent for plain stores) into
+//   slots[c][chunk][k]; wave 0 of every block polls the channel's slots until none holds the EMPTY pattern and sums them in chunk
+//   order (identical result in every block, deterministic); the last block to have read (per-channel ticket) puts EMPTY back, so
+//   the buffer is clean for the next launch on the stream.  No fences: only the exchanged words travel through agent-scope
+//   atomics.  Progress: work-groups are dispatched in linear order (blockIdx.x fastest), so at most one channel is partially
+//   resident and its missing blocks are the next to be dispatched; a bounded spin turns a lost block into an error flag.
+#define EAS_COOP_EMPTY 0x7FF4DEADBEEF0001ull      /* a signalling-NaN bit pattern no sum of finite or NaN data produces */
+#define EAS_COOP_SPIN_LIMIT (1 << 22)
+#define EAS_COOP_K 4                              /* 64-bit words per slot */
+
+struct EasCoopDev {
+    unsigned long long* slots;     // NULL: the kernel's non-cooperative form.  [capacity][EAS_BN_MAX_CHUNKS][EAS_COOP_K], then 2*capacity channel words
+    int* tickets;                  // [capacity] per-channel departure counters + [1] global one, zero between launches
+    int* err;                      // set to 1 when a spin limit was hit
+    int capacity;                  // channels the buffers were sized for
+};
+
+template <int K>
+__device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int c, int nchunks, const double (&mine)[K], double (&tot)[K],
+                                                      double* sh) {
+    static_assert(K <= EAS_COOP_K, "slot width");
+    unsigned long long* base = co.slots + (size_t)c * EAS_BN_MAX_CHUNKS * EAS_COOP_K;
+    if (threadIdx.x == 0) {      // `mine` is valid in thread 0 (eas_block_sum)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            unsigned long long bits = (unsigned long long)__double_as_longlong(mine[k]);
+            if (bits == EAS_COOP_EMPTY) bits ^= 1ull;
+            __hip_atomic_store(base + (size_t)blockIdx.x * EAS_COOP_K + k, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x < EAS_WAVE) {
+        const int j = threadIdx.x;
+        double v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = 0.0;
+        if (j < nchunks) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                unsigned long long b;
+                int spins = 0;
+                for (;;) {
+                    b = __hip_atomic_load(base + (size_t)j * EAS_COOP_K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (b != EAS_COOP_EMPTY || ++spins > EAS_COOP_SPIN_LIMIT) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (b == EAS_COOP_EMPTY) {
+                    *co.err = 1;
+                    b = 0ull;
+                }
+                v[k] = __longlong_as_double((long long)b);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = eas_wave_sum(v[k]);
+        int last = 0;
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) sh[k] = v[k];
+            last = __hip_atomic_fetch_add(co.tickets + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1;
+        }
+        last = __shfl(last, 0, EAS_WAVE);
+        if (last) {              // every block of the channel has read: clean up for the next launch
+            if (j < nchunks) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    __hip_atomic_store(base + (size_t)j * EAS_COOP_K + k, EAS_COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (j == 0) __hip_atomic_store(co.tickets + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot[k] = sh[k];
+    __syncthreads();
+}
+
+// Sum over ALL channels of one double per channel (the neuron's dL/dw, dL/dalpha): block 0 of every channel publishes its
+// channel's value; the last one to arrive (global ticket) adds them in channel order with its first wave.  Returns true in that
+// block (all threads), with the sum in `total`.
+__device__ __forceinline__ bool eas_all_channels_sum(const EasCoopDev& co, int word, int c, int C, double mine, double& total, double* sh,
+                                                     int* shi) {
+    unsigned long long* vals = co.slots + (size_t)co.capacity * EAS_BN_MAX_CHUNKS * EAS_COOP_K + (size_t)word * co.capacity;
+    if (threadIdx.x == 0) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+        if (bits == EAS_COOP_EMPTY) bits ^= 1ull;
+        __hip_atomic_store(vals + c, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *shi = __hip_atomic_fetch_add(co.tickets + co.capacity + word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C - 1;
+    }
+    __syncthreads();
+    const bool last = *shi != 0;
+    if (last && threadIdx.x < EAS_WAVE) {
+        // the ticket only elects the summing block; every value is polled for (no ordering assumed between a value and its ticket)
+        double a = 0.0;
+        for (int i = threadIdx.x; i < C; i += EAS_WAVE) {
+            unsigned long long b;
+            int spins = 0;
+            for (;;) {
+                b = __hip_atomic_load(vals + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b != EAS_COOP_EMPTY || ++spins > EAS_COOP_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (b == EAS_COOP_EMPTY) {
+                *co.err = 1;
+                b = 0ull;
+            }
+            a += __longlong_as_double((long long)b);
+            __hip_atomic_store(vals + i, EAS_COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a = eas_wave_sum(a);
+        if (threadIdx.x == 0) {
+            *sh = a;
+            __hip_atomic_store(co.tickets + co.capacity + word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    total = *sh;
+    return last;
 }
 
 // (image, float4-group-in-plane) of group index g0 and its advance by `stride` groups, without a 64-bit division per group

@@ -242,14 +242,56 @@ class _TimeMeanFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ K4 (BN + LIF)
+# In-kernel channel exchange (include/eas_hip.h EasCoop, csrc/eas_common.h): with it the BN kernels compute their batch statistics
+# themselves (no eas_bn_stats_partial launch, the data is read from HBM once and from L2 the second time) and the two passes of
+# their backward are one launch.  One set of buffers per device, shared by every layer (kernels of a stream run one after another and
+# each leaves the buffers clean).  EAS_COOP_BN=0 (development switch) selects the separate launches.
+COOP_BN = os.environ.get('EAS_COOP_BN', '1') == '1'
+COOP_CAPACITY = 4096                  # channels
+_COOP = {}
+
+
+def coop_buffers(device):
+    """(EasCoop struct, tensors kept alive) of ``device``"""
+    key = str(device)
+    c = _COOP.get(key)
+    if c is None:
+        L = _lib.lib()
+        empty = C.c_int64(0x7FF4DEADBEEF0001).value
+        slots = torch.full((L.eas_coop_slot_words(COOP_CAPACITY),), empty, dtype=torch.int64, device=device)
+        tickets = torch.zeros(COOP_CAPACITY + 8, dtype=torch.int32, device=device)
+        err = torch.zeros(1, dtype=torch.int32, device=device)
+        c = _COOP[key] = (_lib.EasCoop(slots.data_ptr(), tickets.data_ptr(), err.data_ptr(), COOP_CAPACITY), slots, tickets, err)
+    return c
+
+
+def coop_error(device):
+    """True if a block of a cooperative kernel ever gave up waiting for its channel (host sync; tests call it)"""
+    c = _COOP.get(str(device))
+    return bool(c[3].item()) if c is not None else False
+
+
+def _coop_ptr(device, channels):
+    """pointer argument for the C ABI, or None when the cooperative form is switched off / does not apply"""
+    if not COOP_BN or channels > COOP_CAPACITY:
+        return None
+    return C.pointer(coop_buffers(device)[0])
+
+
 def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=None, y_ctot=0):
-    """launch the partial-sum pass of the batch statistics; the consumer kernel finalizes (EasBnPending)."""
+    """batch statistics of the consumer kernel: cooperative (computed inside it, EasCoop) or, with EAS_COOP_BN=0, the partial-sum
+    launch whose result the consumer finalizes (EasBnPending)."""
+    cp = _coop_ptr(dev, Cc)
+    if cp is not None:
+        pend = _lib.EasBnPending(None, 0, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
+                                 ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, cp)
+        return pend, None
     ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
     chunks = L.eas_bn_stats_partial(ptr(y) if y_ptr is None else y_ptr, y_ctot, TN, Cc, HW, ptr(ws), stream())
     if chunks <= 0:
         check(chunks if chunks < 0 else -1, 'eas_bn_stats_partial')
     pend = _lib.EasBnPending(ptr(ws), chunks, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
-                             ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None)
+                             ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, None)
     return pend, ws
 
 
@@ -352,7 +394,8 @@ class _BNLIFFn(torch.autograd.Function):
         gbeta = torch.empty_like(beta)
         want_w = w is not None and ctx.needs_input_grad[5]
         gw = torch.empty_like(w) if want_w else None
-        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
+        cp = _coop_ptr(y.device, Cc)
+        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device) if cp is None else None
         nsteps = T * N * Cc * HW
         nbytes = 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel())
         ga = None
@@ -360,11 +403,11 @@ class _BNLIFFn(torch.autograd.Function):
             ga = torch.empty_like(alpha_t) if ctx.needs_input_grad[11] else None
             _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_patan, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
                   ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, ptr(alpha_t), ptr(ga), int(batch_stats), ptr(gy), ptr(ggamma),
-                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
+                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), cp, stream())
         else:
             _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
                   ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma),
-                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
+                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), cp, stream())
         return (gy, ggamma, gbeta, None, None, gw) + (None,) * 5 + (ga,) + (None,) * 3 + (g_res, None, None, None)
 
 
@@ -477,11 +520,12 @@ class _BNLIF2Fn(torch.autograd.Function):
                 ctot = _channel_slice_of(g_s, Cc) if g_s.dtype == torch.float32 else 0
                 if ctot == 0:
                     g_s = _f32c(g_s)
-                ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device)
+                cp = _coop_ptr(y12.device, Cc)
+                ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device) if cp is None else None
                 off = 4 * c0 * HW
                 _call('eas_bn_lif_bwd', 12 * T * N * Cc * HW, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, None, y12.data_ptr() + off, Ct, ptr(mean),
                       ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats),
-                      gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, 0, stream())
+                      gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, 0, cp, stream())
             res += [ggamma, gbeta, gw]
         return (gy12,) + tuple(res) + (None, None)
 
@@ -585,9 +629,10 @@ class _BNSiLUFn(torch.autograd.Function):
         L = _lib.lib()
         g = _f32c(g)
         gy, ggamma, gbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
-        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
+        cp = _coop_ptr(y.device, Cc)
+        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device) if cp is None else None
         _call('eas_bn_silu_bwd', 12 * y.numel(), L.eas_bn_silu_bwd, ptr(g), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, stream())
+              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, cp, stream())
         return gy, ggamma, gbeta, None
 
 

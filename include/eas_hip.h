@@ -219,14 +219,30 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
  * y_ctot (0 or >= C) in all three: y -- and grad_y in the backward -- are C consecutive channels of a [T][N][y_ctot][HW]
  *   tensor, the pointers at the first of them: ONE convolution (concatenated weights) feeds the two 1x1 branches of a CSPLayer
  *   (network_blocks.py:175-188), its input is read once and its input gradient needs no addition of two branch gradients. */
+/* In-kernel exchange between the blocks of a channel (csrc/eas_common.h: eas_channel_allreduce).  With an EasCoop the BN kernels
+ * need no partial-sum launch before them and no second launch for their backward's apply pass: the blocks of a channel (grid = chunks x
+ * channels) swap their partial sums through `slots` with agent-scope atomics and continue on the data they have just read.  The
+ * buffers belong to the caller, are shared by all layers of a stream (a kernel leaves them clean) and must be initialised ONCE:
+ * slots: eas_coop_slot_words(capacity) 64-bit words all equal to EAS_COOP_EMPTY_WORD; tickets: capacity + 8 int32 zeros; err: one
+ * int32 zero (set to 1 if a block ever waited in vain -- it never should).  capacity >= the largest channel count used. */
+#define EAS_COOP_EMPTY_WORD 0x7FF4DEADBEEF0001ull
 typedef struct {
-    const double* partial;   /* workspace filled by eas_bn_stats_partial; NULL = statistics already final */
+    void* slots;
+    int* tickets;
+    int* err;
+    int capacity;
+} EasCoop;
+int64_t eas_coop_slot_words(int capacity);
+
+typedef struct {
+    const double* partial;   /* workspace filled by eas_bn_stats_partial; NULL = statistics already final (or computed in-kernel: coop) */
     int chunks;              /* its return value */
     int replicas;            /* as eas_bn_stats */
     double count;            /* TN * HW */
     float eps, momentum;
     float* running_mean;     /* nullable pair */
     float* running_var;
+    const EasCoop* coop;     /* not NULL (and partial NULL): the consuming kernel computes the batch statistics itself, see EasCoop */
 } EasBnPending;
 int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, double* workspace, eas_stream_t stream);
 int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
@@ -237,13 +253,17 @@ int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_me
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop,
+                      eas_stream_t stream);
+/* coop (nullable) in the backward calls: both passes in ONE launch (pass 2 re-reads grad_s / y from L2 / Infinity Cache instead of
+ * HBM); `workspace` is then unused and may be NULL. */
 /* eas_bn_lif_bwd_ex for the learnable arctan surrogate (see eas_lif_bwd_patan). */
 int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, const float* v_init,
                          const float* w_logit, float k_const, float v_th, float v_reset, int flags, const float* alpha,
                          float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
+                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop,
+                         eas_stream_t stream);
 
 /* BatchNorm2d + SiLU fused for the real-valued BaseConv blocks (stem, PAFPN neck, head:
  * yolox/models/network_blocks.py:52-53 with nn.SiLU); y: conv output [N][C][HW]; mean/invstd from eas_bn_stats
@@ -256,7 +276,7 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
                        float* out, int N, int C, int HW, const EasBnPending* pending, eas_stream_t stream);
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                    double* workspace, int N, int C, int HW, eas_stream_t stream);
+                    double* workspace, int N, int C, int HW, const EasCoop* coop, eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  adaptive sampler step (AdaptiveRSNNEmbedding.forward loop body,

@@ -683,6 +683,51 @@ def test_bn_lif_fused_vs_oracle(dev, T, N, C, H, W, train):
     assert int(hbn.num_batches_tracked) == int(rbn.num_batches_tracked)
 
 
+@pytest.mark.parametrize('T,N,C,H,W', [(3, 2, 8, 12, 16), (3, 64, 32, 64, 80), (5, 3, 200, 8, 12), (1, 4, 16, 4, 4), (7, 2, 64, 16, 20)])
+def test_cooperative_bn_kernels_equal_the_separate_launches(dev, monkeypatch, T, N, C, H, W):
+    """EasCoop: batch statistics computed inside eas_bn_lif_fwd_ex / eas_bn_silu_fwd_ex and both backward passes in one launch (the
+    blocks of a channel exchange their partial sums through agent-scope atomics) against the separate-launch forms: spikes bit-identical,
+    statistics / gradients to fp32 rounding (the partial sums are grouped differently), run-to-run bit-identical, the shared buffers
+    clean after every call, no block ever waited in vain."""
+    from eas_snn_amd import ops
+    gen = torch.Generator().manual_seed(C * 7 + T)
+    y = (torch.randn(T, N, C, H, W, generator=gen) * 1.3 + 0.2).to(dev)
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(dev), (torch.randn(C, generator=gen) * 0.3).to(dev)
+    g_s = torch.randn(T, N, C, H, W, generator=gen).to(dev)
+    res = {}
+    for coop in (True, False, True):
+        monkeypatch.setattr(ops, 'COOP_BN', coop)
+        yy = y.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        wl = torch.zeros((), device=dev, requires_grad=True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        s, v, _ = ops.bn_lif_multistep(yy, ga, be, rm, rv, True, 0.03, 1e-3, None, wl, 0.0, 1.0, 0.0, 0, 'atan', 2.0, write_v=True)
+        s.backward(g_s)
+        lif = (s.detach().clone(), v.clone(), rm.clone(), rv.clone(), yy.grad.clone(), ga.grad.clone(), be.grad.clone(), wl.grad.clone())
+        # BN + SiLU on the first time step
+        y0 = y[0].clone().requires_grad_(True)
+        bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        o = ops.bn_silu(y0, bn)
+        o.backward(g_s[0])
+        silu = (o.detach().clone(), bn.running_mean.clone(), bn.running_var.clone(), y0.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        if coop and 'coop' in res:
+            for a, b in zip(res['coop'], lif + silu):
+                assert torch.equal(a, b), 'cooperative kernels are not run-to-run deterministic'
+        res['coop' if coop else 'sep'] = lif + silu
+    if ops._COOP:
+        cst, slots, tickets, err = ops.coop_buffers(dev)
+        assert not ops.coop_error(dev)
+        assert int(tickets.abs().sum()) == 0 and bool((slots == slots[0]).all()), 'the exchange buffers were not left clean'
+    a, b = res['coop'], res['sep']
+    assert torch.equal(a[0], b[0]), 'spikes differ'
+    names = ['spikes', 'v', 'running_mean', 'running_var', 'grad_y', 'grad_gamma', 'grad_beta', 'grad_w', 'silu', 'silu rm', 'silu rv', 'silu grad_y',
+             'silu grad_gamma', 'silu grad_beta']
+    for n_, x1, x2 in zip(names, a, b):
+        torch.testing.assert_close(x1, x2, rtol=2e-5, atol=2e-6, msg=lambda m, n_=n_: f'{n_}: {m}')
+
+
 @pytest.mark.parametrize('train', [True, False])
 def test_bn_lif_residual_and_inplace_concatenation(dev, train):
     """The SEW shortcut addition and the channel concatenation done inside the BN+LIF kernel (eas_bn_lif_fwd_ex residual /
