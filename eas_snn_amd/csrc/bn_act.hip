@@ -35,33 +35,35 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
     __shared__ float st[2];
     __shared__ double red[NW];
     __shared__ double shd[2];
-    const int c = blockIdx.y;
+    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= C) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
     float mu, istd;
     if (fin.coop) {
         // batch statistics in this launch: sums over this block's own chunk, exchanged between the channel's blocks
         double s = 0.0, ss = 0.0;
-        GroupWalk gs((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gs.next()) {
+        GroupWalk gs((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gs.next()) {
             const float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)gs.n * C + c) * (int64_t)HW + (int64_t)gs.q * VEC);
             s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
             ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
         }
         const double mine[2] = {eas_block_sum<double, NW>(s, red), eas_block_sum<double, NW>(ss, red)};
         double tot[2];
-        eas_channel_allreduce<2>(co, c, gridDim.x, mine, tot, shd);
-        bn_from_totals(fin, c, tot[0], tot[1], blockIdx.x == 0 && threadIdx.x == 0, mu, istd);
+        eas_channel_allreduce<2>(co, c, chunk, nchunks_g, mine, tot, shd);
+        bn_from_totals(fin, c, tot[0], tot[1], chunk == 0 && threadIdx.x == 0, mu, istd);
     } else if (fin.part) {
-        bn_finalize_in_block(fin, c, st, mu, istd);
+        bn_finalize_in_block(fin, c, st, mu, istd, chunk == 0);
     } else {
         mu = mean[c];
         istd = invstd[c];
     }
     const float scale = gamma[c] * istd;
     const float shift = beta[c] - mu * scale;
-    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
@@ -82,7 +84,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
                                                                 float* __restrict__ grad_beta, int N, int C, int HW) {
     __shared__ double red[NW];
     __shared__ float bc[2];
-    const int c = blockIdx.y;
+    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= C) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
     const float shift = beta[c] - mu * scale;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
                 const double cnt = (double)N * HW;
                 bc[0] = (float)(s1 / cnt);
                 bc[1] = (float)(s2 / cnt);
-                if (blockIdx.x == 0) {
+                if (chunk == 0) {
                     grad_beta[c] = (float)s1;
                     grad_gamma[c] = (float)s2;
                 }
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
         if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
     }
     float s1 = 0.f, s2 = 0.f;
-    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
         const double t1 = eas_block_sum<double, NW>((double)s1, red);
         const double t2 = eas_block_sum<double, NW>((double)s2, red);
         if (threadIdx.x == 0) {
-            part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 0] = t1;
-            part[((int64_t)c * kMaxChunks + blockIdx.x) * 2 + 1] = t2;
+            part[((int64_t)c * kMaxChunks + chunk) * 2 + 0] = t1;
+            part[((int64_t)c * kMaxChunks + chunk) * 2 + 1] = t2;
         }
     }
 }
@@ -154,7 +158,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_coop_kernel(const float
                                                                      float* __restrict__ grad_beta, int N, int C, int HW, EasCoopDev co) {
     __shared__ double red[NW];
     __shared__ double shd[2];
-    const int c = blockIdx.y;
+    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= C) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
     const float shift = beta[c] - mu * scale;
@@ -162,8 +168,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_coop_kernel(const float
     const int64_t groups = (int64_t)N * hw4;
     float s1 = 0.f, s2 = 0.f;
     {
-        GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
             const int64_t base = ((int64_t)gw.n * C + c) * (int64_t)HW + (int64_t)gw.q * VEC;
             const float4 yv = *reinterpret_cast<const float4*>(y + base);
             const float4 gv = *reinterpret_cast<const float4*>(grad_out + base);
@@ -179,15 +185,15 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_coop_kernel(const float
     }
     const double mine[2] = {eas_block_sum<double, NW>((double)s1, red), eas_block_sum<double, NW>((double)s2, red)};
     double tot[2];
-    eas_channel_allreduce<2>(co, c, gridDim.x, mine, tot, shd);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    eas_channel_allreduce<2>(co, c, chunk, nchunks_g, mine, tot, shd);
+    if (chunk == 0 && threadIdx.x == 0) {
         grad_beta[c] = (float)tot[0];
         grad_gamma[c] = (float)tot[1];
     }
     const double cnt = (double)N * HW;
     const float m1 = batch_stats ? (float)(tot[0] / cnt) : 0.f, m2 = batch_stats ? (float)(tot[1] / cnt) : 0.f;
-    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
         const int64_t base = ((int64_t)gw.n * C + c) * (int64_t)HW + (int64_t)gw.q * VEC;
         const float4 yv = *reinterpret_cast<const float4*>(y + base);
         const float4 gv = *reinterpret_cast<const float4*>(grad_out + base);
@@ -242,7 +248,7 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin, co);
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin, co);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -265,15 +271,15 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     if (coop) {
-        hipLaunchKernelGGL(bn_silu_bwd_coop_kernel, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta, batch_stats,
+        hipLaunchKernelGGL(bn_silu_bwd_coop_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta, batch_stats,
                            grad_y, grad_gamma, grad_beta, N, C, HW, coop_dev(coop));
         EAS_CHECK_LAUNCH();
         return EAS_OK;
     }
-    hipLaunchKernelGGL(bn_silu_bwd_kernel<false>, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL(bn_silu_bwd_kernel<false>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
                        batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_silu_bwd_kernel<true>, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
+    hipLaunchKernelGGL(bn_silu_bwd_kernel<true>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
                        batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
     __shared__ float st[2];
     __shared__ double red[NW];
     __shared__ double shd[2];
-    const int c = blockIdx.y;
+    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= C) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     float mu, istd;
     if (fin.coop) {
         // batch statistics in this launch: sums over this block's own (image, pixel group) chunk and all T planes of it (one plane
@@ -143,8 +145,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
         const int64_t ytss = bcast ? 0 : (int64_t)N * Cys * HW;
         const int Tst = bcast ? 1 : T_;
         double s = 0.0, ss = 0.0;
-        GroupWalk gs((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4s);
-        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (int64_t)N * hw4s; g += (int64_t)gridDim.x * blockDim.x, gs.next()) {
+        GroupWalk gs((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4s);
+        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < (int64_t)N * hw4s; g += (int64_t)nchunks_g * blockDim.x, gs.next()) {
             const int64_t yb = ((int64_t)gs.n * Cys + c) * (int64_t)HW + (int64_t)gs.q * VEC;
             float4 v[T_];
 #pragma unroll
@@ -159,10 +161,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
         }
         const double mine[2] = {eas_block_sum<double, NW>(s, red), eas_block_sum<double, NW>(ss, red)};
         double tot[2];
-        eas_channel_allreduce<2>(co, c, gridDim.x, mine, tot, shd);
-        bn_from_totals(fin, c, tot[0], tot[1], blockIdx.x == 0 && threadIdx.x == 0, mu, istd);
+        eas_channel_allreduce<2>(co, c, chunk, nchunks_g, mine, tot, shd);
+        bn_from_totals(fin, c, tot[0], tot[1], chunk == 0 && threadIdx.x == 0, mu, istd);
     } else if (fin.part) {
-        bn_finalize_in_block(fin, c, st, mu, istd);
+        bn_finalize_in_block(fin, c, st, mu, istd, chunk == 0);
     } else {
         mu = mean[c];
         istd = invstd[c];
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
     const int64_t M = (int64_t)N * C * HW;
     const int Cy = ox.y_ctot ? ox.y_ctot : C;
     const int64_t yts = bcast ? 0 : (int64_t)N * Cy * HW;       // T identical input frames: one plane stands for all steps
-    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_coop_kernel(
     __shared__ double shd[4];
     __shared__ int shi;
     if (alpha_dev) alpha = fabsf(*alpha_dev);
-    const int c = blockIdx.y;
+    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= C) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
     const float shift = beta[c] - mu * scale;
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_coop_kernel(
     float m1 = 0.f, m2 = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
         float s1 = 0.f, s2 = 0.f, dk = 0.f, da = 0.f;
-        GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+        GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
             const int64_t n = gw.n;
             const int q = gw.q;
             const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
@@ -343,8 +347,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_coop_kernel(
             const double t4 = sg_id == EAS_SG_PATAN ? eas_block_sum<double, NW>((double)da, red) : 0.0;
             const double mine[4] = {t1, t2, t3, t4};
             double tot[4];
-            eas_channel_allreduce<4>(co, c, gridDim.x, mine, tot, shd);
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
+            eas_channel_allreduce<4>(co, c, chunk, nchunks_g, mine, tot, shd);
+            if (chunk == 0 && threadIdx.x == 0) {
                 grad_beta[c] = (float)tot[0];
                 grad_gamma[c] = (float)tot[1];
             }
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_coop_kernel(
                 m1 = (float)(tot[0] / cnt);
                 m2 = (float)(tot[1] / cnt);
             }
-            if (blockIdx.x == 0) {         // the neuron's scalar gradients: sums over all channels, by the last channel to arrive
+            if (chunk == 0) {         // the neuron's scalar gradients: sums over all channels, by the last channel to arrive
                 double all;
                 if (grad_w && eas_all_channels_sum(co, 0, c, C, tot[2], all, shd, &shi) && threadIdx.x == 0) *grad_w = (float)all * (k * (1.0f - k));
                 if (grad_alpha && eas_all_channels_sum(co, 1, c, C, tot[3], all, shd, &shi) && threadIdx.x == 0) {
@@ -376,7 +380,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     __shared__ double red[NW];
     __shared__ float bc[2];
     if (alpha_dev) alpha = fabsf(*alpha_dev);    // learnable slope (EAS_SG_PATAN)
-    const int c = blockIdx.y;
+    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= C) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
     const float shift = beta[c] - mu * scale;
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
                 const double cnt = (double)T_ * N * HW;
                 bc[0] = (float)(s1 / cnt);
                 bc[1] = (float)(s2 / cnt);
-                if (blockIdx.x == 0) {
+                if (chunk == 0) {
                     grad_beta[c] = (float)s1;
                     grad_gamma[c] = (float)s2;
                 }
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         if (batch_stats) { m1 = bc[0]; m2 = bc[1]; }
     }
     float s1 = 0.f, s2 = 0.f, dk = 0.f, da = 0.f;
-    GroupWalk gw((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, hw4);
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x, gw.next()) {
+    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
+    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
             }
         }
     }
-    if (APPLY && grad_w && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (APPLY && grad_w && chunk == 0 && c == 0) {
         // dL/dw of the (scalar) PLIF decay: fixed-order sum of every (channel, chunk) partial of pass 1, by one block
         double acc = 0.0;
         for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         const double tot = eas_block_sum<double, NW>(acc, red);
         if (threadIdx.x == 0) *grad_w = (float)tot * (k * (1.0f - k));
     }
-    if (APPLY && grad_alpha && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (APPLY && grad_alpha && chunk == 0 && c == 0) {
         // dL/dalpha of the learnable surrogate slope: same fixed-order sum over slot 3 of the partials
         double acc = 0.0;
         for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         double t4 = 0.0;
         if (sg_id == EAS_SG_PATAN) t4 = eas_block_sum<double, NW>((double)da, red);
         if (threadIdx.x == 0) {
-            double* o = part + ((int64_t)c * kMaxChunks + blockIdx.x) * 4;
+            double* o = part + ((int64_t)c * kMaxChunks + chunk) * 4;
             o[0] = t1; o[1] = t2; o[2] = t3; o[3] = t4;
         }
     }
@@ -519,7 +525,7 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
                  const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
                  int bcast, const BnFin& fin, const BnLifOut& ox, const EasCoopDev& co, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
+    hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
                        invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, co);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -546,17 +552,17 @@ int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, co
                  hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     if (co.slots) {
-        hipLaunchKernelGGL((bn_lif_bwd_coop_kernel<T_, HARD, DI, STRICT>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean, y, mean,
+        hipLaunchKernelGGL((bn_lif_bwd_coop_kernel<T_, HARD, DI, STRICT>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean, y, mean,
                            invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, N, C, HW, bcast,
                            gs_ctot, y_ctot, alpha_dev, grad_alpha, co);
         EAS_CHECK_LAUNCH();
         return EAS_OK;
     }
-    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
+    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
                        grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), dim3(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
+    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
                        grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, grad_alpha);
     EAS_CHECK_LAUNCH();

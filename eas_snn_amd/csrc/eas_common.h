@@ -107,7 +107,7 @@ __device__ __forceinline__ void bn_from_totals(const BnFin& f, int c, double s, 
     }
 }
 
-__device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, float* st, float& mu, float& istd) {
+__device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, float* st, float& mu, float& istd, bool publish) {
     if (threadIdx.x < EAS_WAVE) {
         double s = 0.0, ss = 0.0;
         if ((int)threadIdx.x < f.nchunks) {
@@ -122,7 +122,7 @@ __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, floa
             if (var < 0.0) var = 0.0;
             st[0] = (float)m;
             st[1] = (float)(1.0 / sqrt(var + (double)f.eps));
-            if (blockIdx.x == 0) {
+            if (publish) {                  // one block per channel
                 f.mean_out[c] = st[0];
                 f.invstd_out[c] = st[1];
                 if (f.rmean) {
@@ -147,34 +147,51 @@ __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, floa
 //   slots[c][chunk][k]; wave 0 of every block polls the channel's slots until none holds the EMPTY pattern and sums them in chunk
 //   order (identical result in every block, deterministic); the last block to have read (per-channel ticket) puts EMPTY back, so
 //   the buffer is clean for the next launch on the stream.  No fences: only the exchanged words travel through agent-scope
-//   atomics.  Progress: work-groups are dispatched in linear order (blockIdx.x fastest), so at most one channel is partially
-//   resident and its missing blocks are the next to be dispatched; a bounded spin turns a lost block into an error flag.
+//   atomics.  Grid = (8, chunks, ceil(C / 8)), channel = blockIdx.z * 8 + blockIdx.x: work-groups are dealt round-robin over the 8
+//   XCDs in linear order (observed; a matter of speed only), so all chunks of a channel run on ONE XCD, one channel after the other --
+//   no block waits for another XCD's queue (with channels spread over the XCDs every XCD ran at the pace of the slowest and filled
+//   its CUs with waiting blocks: measured 1.7x slower than separate launches).  Progress under any placement: work-groups are
+//   dispatched in linear order, so at most one channel per queue is partially resident and its missing blocks are the next to be
+//   dispatched; a bounded spin turns a lost block into an error flag.
+#define EAS_CHAN_GRID(chunks, C) dim3(8, (chunks), ((C) + 7) / 8)
 #define EAS_COOP_EMPTY 0x7FF4DEADBEEF0001ull      /* a signalling-NaN bit pattern no sum of finite or NaN data produces */
 #define EAS_COOP_SPIN_LIMIT (1 << 22)
 #define EAS_COOP_K 4                              /* 64-bit words per slot */
 
 struct EasCoopDev {
     unsigned long long* slots;     // NULL: the kernel's non-cooperative form.  [capacity][EAS_BN_MAX_CHUNKS][EAS_COOP_K], then 2*capacity channel words
-    int* tickets;                  // [capacity] per-channel departure counters + [1] global one, zero between launches
+    int* tickets;                  // [capacity] arrival counters, [8] global ones, [capacity] departure counters; all zero between launches
     int* err;                      // set to 1 when a spin limit was hit
     int capacity;                  // channels the buffers were sized for
 };
 
 template <int K>
-__device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int c, int nchunks, const double (&mine)[K], double (&tot)[K],
-                                                      double* sh) {
+__device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int c, int chunk, int nchunks, const double (&mine)[K],
+                                                      double (&tot)[K], double* sh) {
     static_assert(K <= EAS_COOP_K, "slot width");
     unsigned long long* base = co.slots + (size_t)c * EAS_BN_MAX_CHUNKS * EAS_COOP_K;
+    int* arrive = co.tickets + c;
+    int* depart = co.tickets + co.capacity + 8 + c;
     if (threadIdx.x == 0) {      // `mine` is valid in thread 0 (eas_block_sum)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             unsigned long long bits = (unsigned long long)__double_as_longlong(mine[k]);
             if (bits == EAS_COOP_EMPTY) bits ^= 1ull;
-            __hip_atomic_store(base + (size_t)blockIdx.x * EAS_COOP_K + k, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(base + (size_t)chunk * EAS_COOP_K + k, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __builtin_amdgcn_s_waitcnt(0);          // the partials have been acknowledged before this block counts as arrived
+        __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x < EAS_WAVE) {
         const int j = threadIdx.x;
+        // ONE lane polls ONE word (the channel's arrival counter) at a low rate: thousands of resident blocks polling their 64 slots
+        // directly saturate the fabric with uncached loads and slow the blocks that still compute
+        if (j == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunks && ++spins <= EAS_COOP_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(32);
+        }
+        __builtin_amdgcn_wave_barrier();
         double v[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = 0.0;
@@ -183,10 +200,10 @@ __device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int 
             for (int k = 0; k < K; ++k) {
                 unsigned long long b;
                 int spins = 0;
-                for (;;) {
+                for (;;) {      // safety net: a slot whose store is not visible yet although its block has arrived
                     b = __hip_atomic_load(base + (size_t)j * EAS_COOP_K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (b != EAS_COOP_EMPTY || ++spins > EAS_COOP_SPIN_LIMIT) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(8);
                 }
                 if (b == EAS_COOP_EMPTY) {
                     *co.err = 1;
@@ -201,7 +218,7 @@ __device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int 
         if (j == 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) sh[k] = v[k];
-            last = __hip_atomic_fetch_add(co.tickets + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1;
+            last = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1;
         }
         last = __shfl(last, 0, EAS_WAVE);
         if (last) {              // every block of the channel has read: clean up for the next launch
@@ -210,7 +227,10 @@ __device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int 
                 for (int k = 0; k < K; ++k)
                     __hip_atomic_store(base + (size_t)j * EAS_COOP_K + k, EAS_COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (j == 0) __hip_atomic_store(co.tickets + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (j == 0) {
+                __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     __syncthreads();

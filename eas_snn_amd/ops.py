@@ -245,8 +245,14 @@ class _TimeMeanFn(torch.autograd.Function):
 # In-kernel channel exchange (include/eas_hip.h EasCoop, csrc/eas_common.h): with it the BN kernels compute their batch statistics
 # themselves (no eas_bn_stats_partial launch, the data is read from HBM once and from L2 the second time) and the two passes of
 # their backward are one launch.  One set of buffers per device, shared by every layer (kernels of a stream run one after another and
-# each leaves the buffers clean).  EAS_COOP_BN=0 (development switch) selects the separate launches.
-COOP_BN = os.environ.get('EAS_COOP_BN', '1') == '1'
+# each leaves the buffers clean).
+# MEASURED (MI355X, bench.py, same box): the cooperative form is SLOWER -- 28.3 ms per step against 25.7 ms with separate launches
+# (first form: every block polling its channel's 64 slots), 40-44 ms with a single polled arrival counter per channel, also with all
+# chunks of a channel placed on one XCD.  A cross-block exchange costs several fabric round trips (~2 us each: publish, arrive, poll,
+# read, depart) inside blocks that hold 2-10 us of work, and a waiting block keeps its CU slot; a kernel boundary costs a few
+# microseconds of launch gap but no occupancy.  So it is OFF by default (EAS_COOP_BN=1 switches it on); kernels and test are kept --
+# DESIGN.md 7b.
+COOP_BN = os.environ.get('EAS_COOP_BN', '0') == '1'
 COOP_CAPACITY = 4096                  # channels
 _COOP = {}
 
@@ -259,7 +265,7 @@ def coop_buffers(device):
         L = _lib.lib()
         empty = C.c_int64(0x7FF4DEADBEEF0001).value
         slots = torch.full((L.eas_coop_slot_words(COOP_CAPACITY),), empty, dtype=torch.int64, device=device)
-        tickets = torch.zeros(COOP_CAPACITY + 8, dtype=torch.int32, device=device)
+        tickets = torch.zeros(2 * COOP_CAPACITY + 8, dtype=torch.int32, device=device)
         err = torch.zeros(1, dtype=torch.int32, device=device)
         c = _COOP[key] = (_lib.EasCoop(slots.data_ptr(), tickets.data_ptr(), err.data_ptr(), COOP_CAPACITY), slots, tickets, err)
     return c

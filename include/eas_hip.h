@@ -223,7 +223,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
  * need no partial-sum launch before them and no second launch for their backward's apply pass: the blocks of a channel (grid = chunks x
  * channels) swap their partial sums through `slots` with agent-scope atomics and continue on the data they have just read.  The
  * buffers belong to the caller, are shared by all layers of a stream (a kernel leaves them clean) and must be initialised ONCE:
- * slots: eas_coop_slot_words(capacity) 64-bit words all equal to EAS_COOP_EMPTY_WORD; tickets: capacity + 8 int32 zeros; err: one
+ * slots: eas_coop_slot_words(capacity) 64-bit words all equal to EAS_COOP_EMPTY_WORD; tickets: 2 * capacity + 8 int32 zeros; err: one
  * int32 zero (set to 1 if a block ever waited in vain -- it never should).  capacity >= the largest channel count used. */
 #define EAS_COOP_EMPTY_WORD 0x7FF4DEADBEEF0001ull
 typedef struct {
