@@ -64,8 +64,6 @@ class AdaptiveRSNNEmbedding(nn.Module):
     def __init__(self, kernel_size, in_channel=2, out_channel=2, Ts=1, split=False, spike_attach=False, write_zero=False,
                  abs=False, depth=1, readout='sum', **kwargs_spikes):
         super().__init__()
-        if split:
-            raise NotImplementedError('split=True builds extra convs the reference never uses in forward')
         _check_spike_fn(kwargs_spikes)
         self.kernel_size, self.Ts, self.abs, self.split, self.readout = kernel_size, Ts, abs, split, readout
         self.write_zero, self.spike_attach = write_zero, spike_attach
@@ -76,6 +74,11 @@ class AdaptiveRSNNEmbedding(nn.Module):
         self.depth = int(depth)
         self.gate_conv = _conv_stack(out_channel, out_channel * 2, kernel_size, self.depth)
         self.input_conv = _conv_stack(in_channel, out_channel * 2, kernel_size, self.depth)
+        if split:
+            # the reference's forward never calls these two (embedding.py:100-102, 141-226): they exist so that parameter counts,
+            # optimizer groups and checkpoints written with split=True match
+            self.gate_conv_agg = nn.Conv2d(out_channel, out_channel * 2, kernel_size, padding=kernel_size // 2)
+            self.input_conv_agg = nn.Conv2d(in_channel, out_channel * 2, kernel_size, padding=kernel_size // 2)
         self._init_weight()
 
     def _init_weight(self):
@@ -85,6 +88,9 @@ class AdaptiveRSNNEmbedding(nn.Module):
         for m in self.gate_conv.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_uniform_(m.weight, nonlinearity='sigmoid')
+        if self.split:
+            nn.init.kaiming_uniform_(self.input_conv_agg.weight, nonlinearity='sigmoid')
+            nn.init.orthogonal_(self.gate_conv_agg.weight, gain=nn.init.calculate_gain('relu'))
 
     def forward(self, events, record=False, v_record=False):
         if events.dim() < 5:        # parameter-registration passthrough used by get_model_info (embedding.py:144-146)

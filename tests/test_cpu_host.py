@@ -307,3 +307,15 @@ def test_bench_launcher_reports_a_failing_rank():
     """a rank that dies takes the launch down with a non-zero code instead of leaving the others in a collective"""
     r = _run_bench(['--gpus', '2', '--selftest-cpu', '--steps', '1', '--warmup', '0'], env_extra={'EAS_BENCH_SELFTEST_FAIL_RANK': '1'})
     assert r.returncode != 0
+
+
+def test_sampler_split_option_builds_the_reference_parameter_set():
+    """split=True adds two convolutions the reference's forward never calls (embedding.py:100-102); they must exist so that
+    checkpoints and optimizer groups of such a configuration match (key order = construction order of the reference)."""
+    from yolox.models.activation import Rectangle
+    from yolox.models.embedding import AdaptiveRSNNEmbedding
+    m = AdaptiveRSNNEmbedding(5, split=True, depth=2, nb_steps=4, thresh=1.0, vreset=0.0, spike_fn=Rectangle)
+    assert list(m.state_dict()) == ['gate_conv.0.weight', 'gate_conv.0.bias', 'gate_conv.2.weight', 'gate_conv.2.bias', 'input_conv.0.weight',
+                                    'input_conv.0.bias', 'input_conv.2.weight', 'input_conv.2.bias', 'gate_conv_agg.weight', 'gate_conv_agg.bias',
+                                    'input_conv_agg.weight', 'input_conv_agg.bias']
+    assert m.gate_conv_agg.weight.shape == (4, 2, 5, 5) and m.input_conv_agg.weight.shape == (4, 2, 5, 5)
