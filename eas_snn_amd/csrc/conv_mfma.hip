@@ -201,9 +201,9 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // steps of the current chunk and written to the other LDS buffer during its last steps, so each load has several thousand
 // cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
 template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
-__global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
-                                                            const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
-                                                            ConvGeom g) {
+__device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
+                                               float* __restrict__ y, int* __restrict__ inexact, const ConvGeom& g, const int part,
+                                               unsigned char* smem) {
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     constexpr int PIXB = CCH * 2;  // bytes per staged pixel and term
     constexpr int NSTEPS = (CCH / 16) * TAPS;
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     constexpr bool BPF = XT == 1 && NSTEPS > 1;   // B-fragment prefetch one step ahead
     static_assert(WVM * WVN == 4 || WVM * WVN == 8, "4 or 8 waves per block");
     static_assert(CCH % 16 == 0, "ci chunk is a multiple of the MFMA k");
-    extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WVN, wn = wave % WVN;
     const int r = lane & 31, h = lane >> 5;
@@ -229,7 +228,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         const int rows = g.nseg * g.rows_in;
         const int hcols = g.RS - g.Wst;
         const int per_row = hcols * (PIXB / 16);
-        for (int i = tid; i < rows * per_row * XT * 2; i += NT) {
+        const int nbuf_k = g.KSTEPS * 16 <= CCH ? 1 : 2;    // a single channel chunk uses (and owns) one buffer only
+        for (int i = tid; i < rows * per_row * XT * nbuf_k; i += NT) {
             const int row = fdiv(i, g.m_hrow), k = i - row * per_row;
             const int bt = fdiv(row, g.m_rows), rw = row - bt * rows;   // bt = buffer*XT + term
             const int hc = k / (PIXB / 16), kk = k - hc * (PIXB / 16);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
         qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S + g.qshift) * 16 + h * grp;
         const int rho = rho0 + rl;
         const int img = fdiv(rho, g.m_Ho), orow = rho - img * g.Ho;
-        const int yr = orow * g.os + g.oph, yc = ((int)blockIdx.z * g.Wo + c) * g.os + g.opw;
+        const int yr = orow * g.os + g.oph, yc = (part * g.Wo + c) * g.os + g.opw;
         ybase[j] = (p < npix && rho < g.total_rows && yr < g.oH && yc < g.oW) ? (((long)img * g.Cout * g.oH + yr) * g.oW + yc) : -1;
     }
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
     const size_t plane = (size_t)g.Hi * g.Wi;
     const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
     const int nitems = units * (CCH / 8);
-    const int gcol0 = g.gx0 + (int)blockIdx.z * g.Wo * S;      // input column of the first staged unit (may be < 0 for part 0)
+    const int gcol0 = g.gx0 + part * g.Wo * S;      // input column of the first staged unit (may be < 0 for part 0)
     int gofs[NIT], lofs[NIT], gch[NIT];   // gofs < 0: row (or, with column parts, unit) outside the image (zeros)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -455,23 +455,84 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
 }
 
 template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
-int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
-    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
-    const size_t lds = (size_t)2 * g.Q * CCH * 2 * XT;
+__global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
+                                                            ConvGeom g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem);
+}
+
+// Input gradient of a stride-2 3x3 convolution in ONE launch: blockIdx.z = parity class of the input pixel, every class a stride-1
+// tap-list convolution over grad_y with its own tap count (1, 2, 2, 4), channel chunk (64, 32, 32, 16: four MFMA steps per chunk
+// each), weights and tile geometry -- the four class kernels used to be four launches, each leaving most CUs idle on the small
+// maps and each staging grad_y by itself.
+struct S2Geoms {
+    ConvGeom g[4];
+    const bf16x8* wp[4];
+};
+
+template <int WM, int WN, int WVM, int WVN, int VEC, int NIT>
+__global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_dgrad_s2_kernel(const float* __restrict__ gy, float* __restrict__ gx, const S2Geoms sg) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int cls = blockIdx.z;
+    if ((int)blockIdx.x * sg.g[cls].RT >= sg.g[cls].total_rows) return;
+    switch (cls) {
+        case 0: conv_tile_body<1, 1, 3, WM, WN, WVM, WVN, 64, VEC, NIT>(gy, sg.wp[0], nullptr, gx, nullptr, sg.g[0], 0, smem); break;
+        case 1: conv_tile_body<2, 1, 3, WM, WN, WVM, WVN, 32, VEC, NIT>(gy, sg.wp[1], nullptr, gx, nullptr, sg.g[1], 0, smem); break;
+        case 2: conv_tile_body<2, 1, 3, WM, WN, WVM, WVN, 32, VEC, NIT>(gy, sg.wp[2], nullptr, gx, nullptr, sg.g[2], 0, smem); break;
+        default: conv_tile_body<4, 1, 3, WM, WN, WVM, WVN, 16, VEC, NIT>(gy, sg.wp[3], nullptr, gx, nullptr, sg.g[3], 0, smem); break;
+    }
+}
+
+static void conv_geom_magics(ConvGeom& g, int VEC, int CCH) {
+    const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
+    const int rows = g.nseg * g.rows_in, per_row = (g.RS - g.Wst) * (CCH * 2 / 16);
+    g.m_Wo = fdiv_magic(g.Wo); g.m_rows_seg = fdiv_magic(g.rows_seg); g.m_Ho = fdiv_magic(g.Ho);
+    g.m_units = fdiv_magic(units); g.m_units_seg = fdiv_magic(units_seg); g.m_units_row = fdiv_magic(units_row);
+    g.m_hrow = fdiv_magic(per_row); g.m_rows = fdiv_magic(rows);
+}
+
+template <int WM, int WN, int WVM, int WVN, int VEC, int NIT>
+int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
+    auto kern = conv_dgrad_s2_kernel<WM, WN, WVM, WVN, VEC, NIT>;
+    static const int cch[4] = {64, 32, 32, 16};
+    size_t lds = 0;
+    int gx_blocks = 0;
+    for (int c = 0; c < 4; ++c) {
+        ConvGeom& g = sg.g[c];
+        const int nbuf = g.KSTEPS * 16 <= cch[c] ? 1 : 2;
+        const size_t l = (size_t)nbuf * g.Q * cch[c] * 2 * 3;
+        lds = l > lds ? l : lds;
+        const int units = g.nseg * g.rows_in * (g.Wst / VEC);
+        if (g.total_rows >= (1 << 20) || units >= (1 << 20)) return EAS_ERR_UNSUPPORTED;
+        conv_geom_magics(g, VEC, cch[c]);
+        const int b = (g.total_rows + g.RT - 1) / g.RT;
+        gx_blocks = b > gx_blocks ? b : gx_blocks;
+    }
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
         attr_set = true;
     }
-    {
-        const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
-        const int rows = g.nseg * g.rows_in, per_row = (g.RS - g.Wst) * (CCH * 2 / 16);
-        if (g.total_rows >= (1 << 20) || units >= (1 << 20)) return EAS_ERR_UNSUPPORTED;     // fdiv range
-        g.m_Wo = fdiv_magic(g.Wo); g.m_rows_seg = fdiv_magic(g.rows_seg); g.m_Ho = fdiv_magic(g.Ho);
-        g.m_units = fdiv_magic(units); g.m_units_seg = fdiv_magic(units_seg); g.m_units_row = fdiv_magic(units_row);
-        g.m_hrow = fdiv_magic(per_row); g.m_rows = fdiv_magic(rows);
+    dim3 grid(gx_blocks, (sg.g[0].MT + WVM * WM - 1) / (WVM * WM), 4);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, gy, gx, sg);
+    return EAS_OK;
+}
+
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
+    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
+    const int nbuf = g.KSTEPS * 16 <= CCH ? 1 : 2;      // one channel chunk: the second (prefetch) buffer is never used
+    const size_t lds = (size_t)nbuf * g.Q * CCH * 2 * XT;
+    if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
+        attr_set = true;
     }
+    if (g.total_rows >= (1 << 20) || g.nseg * g.rows_in * (g.Wst / VEC) >= (1 << 20)) return EAS_ERR_UNSUPPORTED;     // fdiv range
+    conv_geom_magics(g, VEC, CCH);
     dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM), g.parts);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
     return EAS_OK;
@@ -492,21 +553,31 @@ template <int TAPS, int S, int XT, int CCH, int VEC>
 int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
     // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
     // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
-    struct Cand { int wm, wvm, bn, threads, nit; launch_fn fn; };
+    struct Cand { int wm, wvm, bn, threads, nit, wn; launch_fn fn; };
     constexpr int N8 = XT == 1 ? 2 : 1, N4 = 2;   // staging items per thread (register budget: 2 waves per SIMD either way)
-    const Cand cands[7] = {
-        {1, 2, 640, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
-        {1, 8, 160, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
-        {1, 1, 640, 256, N4, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
-        {1, 4, 160, 256, N4, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>}};
-    // cost model (measured on MI355X, scripts/dev_conv.py): every block of one shape takes about the same time whatever part
-    // of its pixel tile is valid; one block per CU; a round of 8-wave blocks costs ~1.27x a round of 4-wave blocks
+    // wave tile = 32 channels x WN 32-pixel tiles.  WN = 5 (160 pixels) is the efficient shape; WN = 3 (96 pixels: two 40-pixel rows,
+    // four 20-pixel rows or one 8x10 image) exists for the small maps of the neck / head and of dark4 / dark5, where 160-pixel wave
+    // tiles leave most of the 256 CUs without a block (64 images of 8x10 with 128 channels are 16 eight-wave blocks)
+    const Cand cands[14] = {
+        {1, 2, 640, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
+        {1, 8, 160, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
+        {1, 1, 640, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
+        {1, 4, 160, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>},
+        {1, 2, 384, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 4, CCH, VEC, N8>}, {1, 4, 192, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 2, CCH, VEC, N8>},
+        {1, 8, 96, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 8, 1, CCH, VEC, N8>}, {1, 1, 768, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 8, CCH, VEC, N8>},
+        {1, 1, 384, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 4, CCH, VEC, N4>}, {1, 2, 192, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 2, CCH, VEC, N4>},
+        {1, 4, 96, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 1, CCH, VEC, N4>}};
+    // cost model (measured on MI355X, scripts/dev_conv.py, scripts/dev_conv_calls.py): one block per CU; a round of 8-wave blocks costs
+    // ~1.27x a round of 4-wave blocks; a block's time is a fixed part (prologue, first patch, epilogue) plus its MFMA work, which
+    // goes with WN whatever part of the pixel tile is valid
     int best = -1;
     double best_cost = 0.0;
     int best_valid = 0;
     ConvGeom best_g = g;
     static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
-    for (int i = 0; i < 7; ++i) {
+    static const int ncand = getenv("EAS_CONV_NCAND") ? atoi(getenv("EAS_CONV_NCAND")) : 14;  // development: 7 = the 160-pixel wave tiles only
+    const int nbuf = g.KSTEPS * 16 <= CCH ? 1 : 2;
+    for (int i = 0; i < ncand; ++i) {
         const Cand& c = cands[i];
         if (force >= 0 && i != force) continue;
         if ((c.wvm * c.wm - 1) * 32 >= g.Cout && !(c.wvm == 1 && c.wm == 1)) continue;   // every wave row (and M-tile) has channels to compute
@@ -519,16 +590,16 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
             t.nseg = t.RT / t.rows_seg;
             t.rows_in = (t.rows_seg - 1) * S + g.ext_h;
             t.Q = t.nseg * t.rows_in * t.RS;
-            fits = (size_t)2 * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wst / VEC) * (CCH / 8) <= c.nit * c.threads;
+            fits = (size_t)nbuf * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wst / VEC) * (CCH / 8) <= c.nit * c.threads;
             cap = t.RT * g.Wo;
         }
         if (!fits) continue;
         const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm)) * g.parts;
         // resident blocks per CU: one 8-wave block, or two 4-wave blocks when their LDS fits twice (independent barriers
         // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
-        const size_t lds_bytes = (size_t)2 * t.Q * CCH * 2 * XT;
+        const size_t lds_bytes = (size_t)nbuf * t.Q * CCH * 2 * XT;
         const int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
-        const double round_cost = c.threads == 512 ? 1.27 : (bpc == 2 ? 1.2 : 1.0);
+        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 ? 1.2 : 1.0)) * (0.3 + 0.7 * c.wn / 5.0);
         const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
         const int valid = t.RT * g.Wo;
         if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && valid > best_valid)) {
@@ -676,9 +747,10 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
     const int MT = (Cin + 31) / 32, KSTEPS = (Cout + 15) / 16;
     const int cum[4] = {0, 1, 3, 5};
     const bool v4 = Wo % 4 == 0;
+    S2Geoms sg{};
     for (int cls = 0; cls < 4; ++cls) {
         const int ph = cls >> 1, pw = cls & 1;
-        ConvGeom g{};
+        ConvGeom& g = sg.g[cls];
         g.NI = NI; g.Cin = Cout; g.Cout = Cin; g.Hi = Ho; g.Wi = Wo; g.Ho = Ho; g.Wo = Wo;
         g.RS = Wo + pw;
         g.pad_t = g.pad_l = 0;
@@ -690,7 +762,83 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
         g.total_rows = NI * Ho;
         g.Wst = Wo; g.gx0 = 0; g.qshift = 0; g.parts = 1;
         g.dbg = dbg;
-        const bf16x8* wp = (const bf16x8*)packed_w + (size_t)3 * MT * KSTEPS * 64 * cum[cls];
+        sg.wp[cls] = (const bf16x8*)packed_w + (size_t)3 * MT * KSTEPS * 64 * cum[cls];
+    }
+    static const int one_launch = getenv("EAS_S2_FORM") ? (getenv("EAS_S2_FORM")[0] == '1') : 1;   // development: 0 = four launches
+    if (one_launch) {
+        // one block shape for the four classes, a tile geometry per class (their staged patches differ: taps, channel chunk)
+        typedef int (*s2_fn)(const float*, float*, S2Geoms, hipStream_t);
+        struct Shape { int wvm, bn, threads, nit, wn; s2_fn f4, f2; };
+        const Shape shapes[14] = {
+            {2, 640, 512, 1, 5, launch_s2<1, 5, 2, 4, 4, 1>, launch_s2<1, 5, 2, 4, 2, 1>}, {4, 320, 512, 1, 5, launch_s2<1, 5, 4, 2, 4, 1>, launch_s2<1, 5, 4, 2, 2, 1>},
+            {8, 160, 512, 1, 5, launch_s2<1, 5, 8, 1, 4, 1>, launch_s2<1, 5, 8, 1, 2, 1>}, {1, 1280, 512, 1, 5, launch_s2<1, 5, 1, 8, 4, 1>, launch_s2<1, 5, 1, 8, 2, 1>},
+            {1, 640, 256, 2, 5, launch_s2<1, 5, 1, 4, 4, 2>, launch_s2<1, 5, 1, 4, 2, 2>}, {2, 320, 256, 2, 5, launch_s2<1, 5, 2, 2, 4, 2>, launch_s2<1, 5, 2, 2, 2, 2>},
+            {4, 160, 256, 2, 5, launch_s2<1, 5, 4, 1, 4, 2>, launch_s2<1, 5, 4, 1, 2, 2>},
+            {2, 384, 512, 1, 3, launch_s2<1, 3, 2, 4, 4, 1>, launch_s2<1, 3, 2, 4, 2, 1>}, {4, 192, 512, 1, 3, launch_s2<1, 3, 4, 2, 4, 1>, launch_s2<1, 3, 4, 2, 2, 1>},
+            {8, 96, 512, 1, 3, launch_s2<1, 3, 8, 1, 4, 1>, launch_s2<1, 3, 8, 1, 2, 1>}, {1, 768, 512, 1, 3, launch_s2<1, 3, 1, 8, 4, 1>, launch_s2<1, 3, 1, 8, 2, 1>},
+            {1, 384, 256, 2, 3, launch_s2<1, 3, 1, 4, 4, 2>, launch_s2<1, 3, 1, 4, 2, 2>}, {2, 192, 256, 2, 3, launch_s2<1, 3, 2, 2, 4, 2>, launch_s2<1, 3, 2, 2, 2, 2>},
+            {4, 96, 256, 2, 3, launch_s2<1, 3, 4, 1, 4, 2>, launch_s2<1, 3, 4, 1, 2, 2>}};
+        static const int cch[4] = {64, 32, 32, 16};
+        static const double work[4] = {0.45, 0.65, 0.65, 1.0};      // relative block time of the classes (1, 2, 2, 4 taps)
+        const int vec = v4 ? 4 : 2;
+        int best = -1;
+        double best_cost = 0.0;
+        S2Geoms best_sg = sg;
+        double four[4] = {1e30, 1e30, 1e30, 1e30};      // the same model's cost of each class as a launch of its own (its best shape)
+        for (int i = 0; i < 14; ++i) {
+            const Shape& c = shapes[i];
+            if ((c.wvm - 1) * 32 >= Cin && c.wvm != 1) continue;
+            S2Geoms t = sg;
+            bool ok = true;
+            double load = 0.0;
+            size_t lds_max = 0;
+            for (int cls = 0; cls < 4 && ok; ++cls) {
+                ConvGeom& g = t.g[cls];
+                const int nbuf = g.KSTEPS * 16 <= cch[cls] ? 1 : 2;
+                bool fits = false;
+                for (int cap = c.bn; cap >= g.Wo && !fits; cap -= 32) {
+                    g.RT = pick_rows(g.Ho, g.Wo, cap);
+                    if (g.RT == 0) break;
+                    g.rows_seg = g.RT < g.Ho ? g.RT : g.Ho;
+                    g.nseg = g.RT / g.rows_seg;
+                    g.rows_in = (g.rows_seg - 1) + g.ext_h;
+                    g.Q = g.nseg * g.rows_in * g.RS;
+                    fits = (size_t)nbuf * g.Q * cch[cls] * 2 * 3 <= 160 * 1024 && g.nseg * g.rows_in * (g.Wst / vec) * (cch[cls] / 8) <= c.nit * c.threads;
+                    cap = g.RT * g.Wo;
+                }
+                ok = fits;
+                if (!ok) break;
+                const size_t l = (size_t)nbuf * g.Q * cch[cls] * 2 * 3;
+                lds_max = l > lds_max ? l : lds_max;
+                const long blocks = (long)((g.total_rows + g.RT - 1) / g.RT) * ((MT + c.wvm - 1) / c.wvm);
+                load += work[cls] * (double)blocks;
+                const int bpc1 = c.threads == 512 ? 1 : (2 * l <= 160 * 1024 ? 2 : 1);
+                const double alone = (double)((blocks + 256 * bpc1 - 1) / (256 * bpc1)) * (c.threads == 512 ? 1.27 : (bpc1 == 2 ? 1.2 : 1.0)) *
+                                     (0.3 + 0.7 * c.wn / 5.0) * work[cls];
+                if (alone < four[cls]) four[cls] = alone;
+            }
+            if (!ok) continue;
+            const int bpc = c.threads == 512 ? 1 : (2 * lds_max <= 160 * 1024 ? 2 : 1);
+            const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 ? 1.2 : 1.0)) * (0.3 + 0.7 * c.wn / 5.0);
+            double rounds = load / (256.0 * bpc);
+            if (rounds < 1.0) rounds = 1.0;
+            const double cost = rounds * round_cost;
+            if (best < 0 || cost < best_cost) {
+                best = i; best_cost = cost; best_sg = t;
+            }
+        }
+        // large maps: every class fills the chip by itself and does better with a tile of its own -> four launches
+        if (best >= 0 && four[0] + four[1] + four[2] + four[3] < 0.97 * best_cost) best = -1;
+        if (best >= 0) {
+            const int rc = v4 ? shapes[best].f4(grad_y, grad_x, best_sg, st) : shapes[best].f2(grad_y, grad_x, best_sg, st);
+            if (rc != EAS_OK) return rc;
+            EAS_CHECK_LAUNCH();
+            return EAS_OK;
+        }
+    }
+    for (int cls = 0; cls < 4; ++cls) {
+        const ConvGeom& g = sg.g[cls];
+        const bf16x8* wp = sg.wp[cls];
         int rc;
         if (cls == 0) rc = v4 ? dispatch_tile<1, 1, 3, 64, 4>(grad_y, wp, nullptr, grad_x, nullptr, g, st) : dispatch_tile<1, 1, 3, 64, 2>(grad_y, wp, nullptr, grad_x, nullptr, g, st);
         else if (cls == 3) rc = v4 ? dispatch_tile<4, 1, 3, 16, 4>(grad_y, wp, nullptr, grad_x, nullptr, g, st) : dispatch_tile<4, 1, 3, 16, 2>(grad_y, wp, nullptr, grad_x, nullptr, g, st);
