@@ -47,6 +47,7 @@ struct WgGeom {
     // hv = one staging unit of halo on either side, units outside the image read the zero page) and there is no separately
     // zeroed halo: lpad = 0, qshift = hv - 1.  One part: Wst = Wi, lpad = 1, qshift = 0.
     int parts, Wst, lpad, qshift, hv;
+    int pn;                  // ci tiles per block chosen by wg_geom (1 or 2)
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -410,10 +411,13 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
 struct WgPlan { int pm, pn, kslices; };
 
 // block shape and number of pixel slices for a layer (shared by the workspace query and the launch)
-WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts) {
+// pn = 2 (a block owns 64 input channels: grad_y is staged by half as many blocks) for spike inputs with >= 64 channels whenever the two
+// x planes fit LDS next to the grad_y tile (always at stride 1; at stride 2 on the small maps, where the layers with many channels
+// are bound by re-staging the same pixels from L2 in every (co, ci) block)
+WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts, int pn) {
     WgPlan p;
     p.pm = Cout >= 64 ? 2 : 1;
-    p.pn = (Cin >= 64 && stride == 1 && x_terms == 1) ? 2 : 1;
+    p.pn = pn;
     const int yz = ((Cout + 32 * p.pm - 1) / (32 * p.pm)) * ((Cin + 32 * p.pn - 1) / (32 * p.pn));
     const int per_cu = 4 / (p.pm * p.pn);                   // resident blocks per CU (12 waves of <= 168 registers)
     int ks = (256 * per_cu + yz - 1) / yz;
@@ -457,10 +461,13 @@ bool wg_geom_cap(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int strid
 // and 8 column parts per row
 bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
     static const int force_parts = getenv("EAS_WG_PARTS") ? atoi(getenv("EAS_WG_PARTS")) : 0;      // development switch
+    static const int pn2_s2 = getenv("EAS_WG_PN2_S2") ? atoi(getenv("EAS_WG_PN2_S2")) : 1;       // development switch
     for (int parts = force_parts > 0 ? force_parts : 1; parts <= 8; parts *= 2) {
-        for (int cap = TP; cap >= 8; cap /= 2) {
+        for (int cap = TP; cap >= 8; cap /= 2)
+          for (int pn = (Cin >= 64 && x_terms == 1 && (stride == 1 || (pn2_s2 && cap == TP))) ? 2 : 1; pn >= 1; --pn) {
             if (!wg_geom_cap(g, NI, Cin, Cout, Hi, Wi, stride, cap, parts)) continue;
-            const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, parts);
+            g.pn = pn;
+            const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, parts, pn);
             const int vec = parts > 1 ? 4 : ((Wi % 4 == 0 && g.Wo % 4 == 0) ? 4 : 2);
             const size_t lds = (size_t)2 * (3 * p.pm * A_PLANE + (size_t)x_terms * p.pn * g.Q * ROWB);
             const int nbg = p.pn == 1 && Cin < 32 ? (Cin + 7) / 8 : 4 * p.pn;
@@ -485,7 +492,7 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
     if (ksize != 3) return 0;
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
-    return (int64_t)wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts).kslices * Cout * Cin * 9;
+    return (int64_t)wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn).kslices * Cout * Cin * 9;
 }
 
 // number of column parts per row eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, 2..8 = column parts
@@ -549,7 +556,7 @@ static int wgrad_partial(const float* x, const float* grad_y, float* workspace, 
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;
     if (g.Wo % 2 != 0 || (g.Ho * g.pitchY) % 4 != 0) return EAS_ERR_UNSUPPORTED;
-    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts);
+    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn);
     g.kslices = p.kslices;
     const int slabs = p.kslices;
     hipStream_t st = eas_s(stream);
