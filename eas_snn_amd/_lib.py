@@ -29,7 +29,7 @@ class EasCoop(C.Structure):
 class EasBnPending(C.Structure):
     """include/eas_hip.h EasBnPending: statistics whose finalize happens inside the consuming kernel."""
     _fields_ = [('partial', C.c_void_p), ('chunks', C.c_int), ('replicas', C.c_int), ('count', C.c_double), ('eps', C.c_float),
-                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('coop', C.POINTER(EasCoop))]
+                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('coop', C.POINTER(EasCoop)), ('pitch', C.c_int)]
 
 
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
@@ -100,6 +100,8 @@ PROTOTYPES = {
     'eas_conv_wgrad_parts': (C.c_int, [C.c_int] * 7),
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
     'eas_conv_fwd_u8': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
+    'eas_conv_fwd_stats': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P, _P, C.c_int, _P]),
+    'eas_conv_fwd_stats_blocks': (C.c_int, [C.c_int] * 8),
     'eas_conv_dgrad_s2': (C.c_int, [_P] * 3 + [C.c_int] * 5 + [_P]),
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
     'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
@@ -152,7 +154,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError = ABI mismatch, also loud
             fn.restype = res
             fn.argtypes = args
-        if handle.eas_abi_version() != 2:
+        if handle.eas_abi_version() != 3:
             raise EasHipError('libeas_hip.so ABI version mismatch; rebuild')
         _lib = handle
     return _lib

@@ -71,10 +71,13 @@ class BaseConv(nn.Module):
         channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer).  emit_bytes: the spikes are
         also written as bytes for a 1x1 convolution that reads them next (callers whose consumer is a 3x3 convolution pass False)."""
         if self.spiking():
-            return self.bn.fused_with(self.act, self.conv(x), want_mean=self.emit_rate, residual=residual, cat=cat,
+            with ops.conv_stats_scope(self.bn._use_batch_stats()):      # the convolution sums its output for the BN behind it
+                y = self.conv(x)
+            return self.bn.fused_with(self.act, y, want_mean=self.emit_rate, residual=residual, cat=cat,
                                       emit_bytes=emit_bytes and x.dim() == 5)
         assert residual is None and cat is None
-        y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
+        with ops.conv_stats_scope(self.bn.training or self.bn.running_mean is None):
+            y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
                 and (self.bn.momentum is not None or not self.bn.training)):
             return ops.bn_silu(y, self.bn)          # one statistics pass + one fused normalise/SiLU pass (HIP)
@@ -176,7 +179,8 @@ class CSPLayer(nn.Module):
                 if sink is not None:
                     sink(c1, x4, 1)
                     sink(c2, x4, 1)
-                y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
+                with ops.conv_stats_scope(self.conv1.bn._use_batch_stats() and self.conv2.bn._use_batch_stats()):
+                    y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
                 a, b = sj_layer.fused_pair(self.conv1.bn, self.conv1.act, self.conv2.bn, self.conv2.act, y12,
                                            cat_a=None if len(self.m) else (buf, 0, buf8), cat_b=(buf, h, buf8))
             else:

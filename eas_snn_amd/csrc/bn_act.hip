@@ -239,9 +239,9 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
         fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
         co = coop_dev(pend->coop);
     } else if (pend && pend->partial) {
-        if (pend->chunks < 1 || pend->chunks > kMaxChunks || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
+        if (pend->chunks < 1 || pend->chunks > (pend->pitch ? pend->pitch : kMaxChunks) || pend->pitch < 0 || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
         if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
-        fin.part = pend->partial; fin.nchunks = pend->chunks; fin.replicas = pend->replicas; fin.count = pend->count;
+        fin.part = pend->partial; fin.nchunks = pend->chunks; fin.pitch = pend->pitch ? pend->pitch : kMaxChunks; fin.replicas = pend->replicas; fin.count = pend->count;
         fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
         fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
     }

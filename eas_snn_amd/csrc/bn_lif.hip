@@ -761,9 +761,9 @@ static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin&
         return EAS_OK;
     }
     if (!pend || !pend->partial) return EAS_OK;
-    if (pend->chunks < 1 || pend->chunks > kMaxChunks || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
+    if (pend->chunks < 1 || pend->chunks > (pend->pitch ? pend->pitch : kMaxChunks) || pend->pitch < 0 || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
     if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
-    fin.part = pend->partial; fin.nchunks = pend->chunks; fin.replicas = pend->replicas; fin.count = pend->count;
+    fin.part = pend->partial; fin.nchunks = pend->chunks; fin.pitch = pend->pitch ? pend->pitch : kMaxChunks; fin.replicas = pend->replicas; fin.count = pend->count;
     fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
     fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
     return EAS_OK;

@@ -17,11 +17,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // loads of lanes without a pixel / channel groups past Cin read these zeros (stride 0) instead of being masked
 __device__ __attribute__((aligned(32))) float eas_c1_zero_page[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+// pixel blocks (grid.x) of the last launch / geometry query of this thread: the statistics partials per channel
+thread_local int tl_c1_blocks = 0;
+
 struct C1Geom {
     int NI, Cin, Cout, HW;
     int tiles_per_img, total_tiles;   // 32-pixel tiles
     int MT, KSTEPS;
+    double* stats;                    // BatchNorm statistics in the epilogue (eas_conv_fwd_stats): [Cout][stats_nb][2], stats_nb = gridDim.x
+    int stats_nb;
 };
+
+// statistics epilogue of the 1x1 kernels: 4 waves of a block = 4 pixel groups of the same WM * 32 channels
+template <int WM, int WN, typename ACC>
+__device__ __forceinline__ void c1_stats(const ACC (&acc)[WM][WN], const long (&yoff)[WN], double* red, const C1Geom& g, int mt0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool valid[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) valid[n] = yoff[n] >= 0;
+    eas_conv_stats_wave<WM, WN>(acc, valid, reinterpret_cast<float*>(red + 4 * WM * 64) + wave * EAS_STATS_SCRATCH, red + wave * (WM * 64), lane);
+    __syncthreads();
+    if ((int)threadIdx.x < WM * 32)
+        eas_conv_stats_store(red, WM * 64, 4, (int)threadIdx.x, mt0 * 32 + (int)threadIdx.x, g.Cout, g.stats, g.stats_nb, (int)blockIdx.x);
+}
 
 template <int XT, typename TIN = float>
 __device__ __forceinline__ void to_terms(const TIN (&v)[8], bf16x8 (&b)[XT]) {
@@ -51,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const TIN* __restr
     const int r = lane & 31, h = lane >> 5;
     const int mt0 = blockIdx.y * WM;
     const int tile0 = (blockIdx.x * 4 + wave) * WN;
-    if (tile0 >= g.total_tiles) return;
+    if (tile0 >= g.total_tiles && !g.stats) return;      // with statistics every wave reaches the block reduction (its lanes hold no pixel)
 
     // per-lane pixel of each N-tile
     long xoff[WN];    // element offset of (img, channel 8h, pixel) ; -1: no pixel
@@ -142,6 +160,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const TIN* __restr
         step(r1, ks + 1);
     }
     if (ks < g.KSTEPS) step(r0, ks);
+
+    if (g.stats) {
+        __shared__ __align__(16) double red[4 * WM * 64 + 2 * EAS_STATS_SCRATCH];      // [wave][WM * 32][2] doubles, then the waves' float patches
+        c1_stats<WM, WN>(acc, yoff, red, g, mt0);
+    }
 
     // lean epilogue: one pointer per (M-tile, pixel tile), rows by multiples of the channel stride, bias once per M-tile,
     // per-element channel check only for a ragged last M-tile
@@ -419,6 +442,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const TIN*
     }
     if (ks < g.KSTEPS) step(r0, 0);
 
+    if (g.stats) {
+        __shared__ __align__(16) double red[4 * WM * 64 + 2 * EAS_STATS_SCRATCH];      // [wave][WM * 32][2] doubles, then the waves' float patches
+        c1_stats<WM, WN>(acc, yoff, red, g, mt0);
+    }
+
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         if (mt0 + m >= g.MT) continue;
@@ -453,6 +481,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const TIN*
 template <int XT, int WM, int WN, typename TIN = float>
 int launch_c1_shared(const TIN* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
+    tl_c1_blocks = (int)grid.x;
+    if (!y) return EAS_OK;            // geometry query
+    if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
     hipLaunchKernelGGL((conv1x1_mfma_sharedA_kernel<XT, WM, WN, TIN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
@@ -460,6 +491,9 @@ int launch_c1_shared(const TIN* x, const bf16x8* wp, const float* bias, float* y
 template <int XT, int WM, int WN, bool RAGK = false, typename TIN = float>
 int launch_c1(const TIN* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
+    tl_c1_blocks = (int)grid.x;
+    if (!y) return EAS_OK;            // geometry query
+    if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
     hipLaunchKernelGGL((conv1x1_mfma_kernel<XT, WM, WN, RAGK, TIN>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
@@ -469,9 +503,11 @@ int launch_c1(const TIN* x, const bf16x8* wp, const float* bias, float* y, C1Geo
 // wave-tile choice and launch for a 1x1 convolution; TIN = float (x_terms 1 or 3) or uint8_t (spike bytes, one term)
 template <typename TIN>
 static int conv1x1_dispatch_t(const TIN* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                              hipStream_t st) {
+                              hipStream_t st, double* stats = nullptr, int stats_nb = 0) {
     constexpr bool U8 = sizeof(TIN) == 1;
+    if (U8 && stats) return EAS_ERR_UNSUPPORTED;
     C1Geom g{};
+    g.stats = stats; g.stats_nb = stats_nb;
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
     g.tiles_per_img = (HW + 31) / 32;
     g.total_tiles = NI * g.tiles_per_img;
@@ -548,8 +584,11 @@ static int conv1x1_dispatch_t(const TIN* x, const void* packed_w, const float* b
 
 // called by eas_conv_fwd (conv_mfma.hip) for ksize == 1, stride == 1
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st) {
-    return conv1x1_dispatch_t<float>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st);
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out) {
+    tl_c1_blocks = 0;
+    const int rc = conv1x1_dispatch_t<float>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb);
+    if (nb_out) *nb_out = tl_c1_blocks;
+    return rc;
 }
 
 // the same convolution reading spikes as bytes (eas_conv_fwd_u8)

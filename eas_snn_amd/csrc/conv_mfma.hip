@@ -60,6 +60,10 @@ struct ConvGeom {
     // ceil(2^40 / d) for the divisors of the per-thread geometry set-up: n / d == (n * m) >> 40 for n, d < 2^20
     unsigned long long m_Wo, m_rows_seg, m_Ho, m_units, m_units_seg, m_units_row, m_hrow, m_rows;
     int dbg;       // development ablation switches (EAS_CONV_DBG): 2 no staging after chunk 0, 4 weights from one address, 16 no barrier
+    // BatchNorm statistics in the epilogue (eas_conv_fwd_stats): not NULL = every block also writes the sum and the sum of squares of
+    // its output tile per channel to stats[(co * stats_nb + pixel block) * 2 + {0, 1}] (doubles); stats_nb = gridDim.x * parts
+    double* stats;
+    int stats_nb;
 };
 
 // exact n / d for n, d < 2^20 with m = ceil(2^40 / d): a multiply-shift instead of the ~25-instruction integer division
@@ -419,6 +423,23 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         if (!(g.dbg & 16)) __syncthreads();
     }
 
+    // ---- BatchNorm statistics of the tile (block-uniform branch): per-wave sums over its valid pixels by DPP, the WVN waves that share
+    // the channels added in wave order, one float2 per channel and block.  The staging buffers are free after the last barrier.
+    if (g.stats) {
+        double* red = reinterpret_cast<double*>(smem + (size_t)WVM * WVN * EAS_STATS_SCRATCH * sizeof(float));
+        bool valid[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) valid[j] = ybase[j] >= 0;
+        eas_conv_stats_wave<WM, WN>(acc, valid, reinterpret_cast<float*>(smem) + wave * EAS_STATS_SCRATCH, red + wave * (WM * 64), lane);
+        __syncthreads();
+        if (tid < WVM * WM * 32) {
+            const int wmi = tid / (WM * 32), t = tid - wmi * (WM * 32);
+            const int co = (blockIdx.y * WVM + wmi) * WM * 32 + t;
+            eas_conv_stats_store(red + wmi * WVN * (WM * 64), WM * 64, WVN, t, co, g.Cout, g.stats, g.stats_nb,
+                                 (int)blockIdx.x + (int)gridDim.x * part);
+        }
+    }
+
     // ---- epilogue: D tile (col = pixel = lane&31, row = (e&3) + 8*(e>>2) + 4*h) -> y NCHW.  Lean on purpose: one pointer per
     // (M-tile, pixel tile), rows reached by adding multiples of the channel stride; bias values loaded once per M-tile;
     // the per-element channel bound check only for a ragged last M-tile (the epilogue used to be as long as the main loop).
@@ -524,8 +545,10 @@ template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, in
 int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
     auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
     const int nbuf = g.KSTEPS * 16 <= CCH ? 1 : 2;      // one channel chunk: the second (prefetch) buffer is never used
-    const size_t lds = (size_t)nbuf * g.Q * CCH * 2 * XT;
+    size_t lds = (size_t)nbuf * g.Q * CCH * 2 * XT;
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
+    if (g.stats && lds < (size_t)WVM * WVN * (EAS_STATS_SCRATCH * sizeof(float) + WM * 64 * sizeof(double)))
+        lds = (size_t)WVM * WVN * (EAS_STATS_SCRATCH * sizeof(float) + WM * 64 * sizeof(double));
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
@@ -534,6 +557,7 @@ int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, in
     if (g.total_rows >= (1 << 20) || g.nseg * g.rows_in * (g.Wst / VEC) >= (1 << 20)) return EAS_ERR_UNSUPPORTED;     // fdiv range
     conv_geom_magics(g, VEC, CCH);
     dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM), g.parts);
+    if (g.stats && (int)(grid.x * g.parts) != g.stats_nb) return EAS_ERR_INVALID_ARG;
     hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
     return EAS_OK;
 }
@@ -548,6 +572,10 @@ int pick_rows(int Ho, int Wo, int BN) {
 }
 
 typedef int (*launch_fn)(const float*, const bf16x8*, const float*, float*, int*, ConvGeom, hipStream_t);
+
+// pixel blocks per channel (grid.x * parts) of the tile the last dispatch_tile call of this thread chose: the number of statistics
+// partials eas_conv_fwd_stats writes per channel
+thread_local int tl_pixel_blocks = 0;
 
 template <int TAPS, int S, int XT, int CCH, int VEC>
 int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
@@ -607,6 +635,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         }
     }
     if (best < 0) return EAS_ERR_UNSUPPORTED;
+    tl_pixel_blocks = ((best_g.total_rows + best_g.RT - 1) / best_g.RT) * best_g.parts;
     if (!y) return EAS_OK;                       // geometry query (eas_conv_fwd_supported): a tile exists, nothing is launched
     return cands[best].fn(x, wp, bias, y, inexact, best_g, st);
 }
@@ -614,7 +643,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
 }  // namespace
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st);
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out);
 int eas_conv1x1_dispatch_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, hipStream_t st);
 
 extern "C" {
@@ -650,8 +679,10 @@ int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream)
 // with grad_y as x and Cin/Cout swapped), padding ksize/2.  x_terms = 1: x holds small integers (spikes and their SEW sums,
 // exact in bf16; `inexact_flag`, if given, is set to 1 should any element not be); x_terms = 3: general fp32 input.
 static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                         int stride, int x_terms, int* inexact_flag, eas_stream_t stream, bool query) {
+                         int stride, int x_terms, int* inexact_flag, eas_stream_t stream, bool query, double* stats = nullptr, int stats_nb = 0,
+                         int* nb_out = nullptr) {
     if (!query && (!x || !packed_w || !y)) return EAS_ERR_INVALID_ARG;
+    if (stats && (bias || stats_nb < 1)) return EAS_ERR_INVALID_ARG;
     if (NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || (ksize == 3 && (Cin % 8 != 0 || Wi % 2 != 0))) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
@@ -671,10 +702,12 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     g.Wst = Wi; g.gx0 = 0; g.qshift = 0; g.parts = 1;
     static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
     g.dbg = dbg;
+    g.stats = stats; g.stats_nb = stats_nb;
     const bf16x8* wp = (const bf16x8*)packed_w;
     hipStream_t st = eas_s(stream);
     int rc = EAS_ERR_UNSUPPORTED;
     const bool v4 = Wi % 4 == 0;
+    tl_pixel_blocks = 0;
 #define EAS_CONV_DISPATCH(TAPS_, S_, CCH_)                                                                                        \
     rc = x_terms == 1 ? (v4 ? dispatch_tile<TAPS_, S_, 1, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
                             : dispatch_tile<TAPS_, S_, 1, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))                          \
@@ -702,8 +735,13 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
         else { EAS_CONV_DISPATCH(9, 2, 16); }
         if (force_parts > 0) break;
     }
-    if (ksize == 1 && stride == 1) rc = query ? EAS_OK : eas_conv1x1_dispatch(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, x_terms, st);
+    if (ksize == 1 && stride == 1) {
+        int nb1 = 0;
+        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1);
+        tl_pixel_blocks = nb1;
+    }
 #undef EAS_CONV_DISPATCH
+    if (nb_out) *nb_out = rc == EAS_OK ? tl_pixel_blocks : 0;
     if (rc != EAS_OK || query) return rc;
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -712,6 +750,24 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                  int stride, int x_terms, int* inexact_flag, eas_stream_t stream) {
     return conv_fwd_impl(x, packed_w, bias, y, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, inexact_flag, stream, false);
+}
+
+// eas_conv_fwd (no bias) that also leaves the per-channel sums of its output for the BatchNorm behind it: stats[Cout][nb][2] doubles,
+// (sum, sum of squares) of every pixel block's tile, nb = eas_conv_fwd_stats_blocks(same geometry).  The consumer (eas_bn_lif_fwd_ex /
+// eas_bn_silu_fwd_ex with EasBnPending.partial = stats, chunks = pitch = nb) adds them in a fixed order: no separate statistics pass over y.
+int eas_conv_fwd_stats(const float* x, const void* packed_w, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride,
+                       int x_terms, int* inexact_flag, double* stats, int nb, eas_stream_t stream) {
+    if (!stats || nb < 1) return EAS_ERR_INVALID_ARG;
+    return conv_fwd_impl(x, packed_w, nullptr, y, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, inexact_flag, stream, false, stats, nb);
+}
+
+// number of statistics partials per channel eas_conv_fwd_stats writes for this geometry (the pixel blocks of the tile it picks);
+// 0 = no tile (eas_conv_fwd_supported is 0)
+int eas_conv_fwd_stats_blocks(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
+    int nb = 0;
+    const int rc = conv_fwd_impl(nullptr, nullptr, nullptr, nullptr, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, nullptr, nullptr, true, nullptr, 0,
+                                 &nb);
+    return rc == EAS_OK ? nb : 0;
 }
 
 // 1x1 convolution (stride 1) of a spike tensor given as BYTES (values 0..255: spikes and their SEW sums, as eas_bn_lif_fwd_ex writes

@@ -68,6 +68,106 @@ __device__ __forceinline__ T eas_block_sum(T v, T* smem) {
     return r;
 }
 
+// ---- sums over the 32 lanes that share lane>>5 (the pixel columns of a 32x32 MFMA accumulator), DPP only (no LDS):
+// butterfly inside the quads, mirror inside the half rows and rows of 16, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3.
+// The total of lanes 0..31 is valid in lanes 16..31, the total of lanes 32..63 in lanes 48..63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float eas_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float eas_half_wave_sum(float v) {
+    v += eas_dpp<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v += eas_dpp<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    v += eas_dpp<0x141, 0xF>(v);     // row_half_mirror
+    v += eas_dpp<0x140, 0xF>(v);     // row_mirror
+    v += eas_dpp<0x142, 0xA>(v);     // row_bcast15 into rows 1 and 3 (other rows add 0)
+    return v;
+}
+
+// Per-channel sums of a convolution's output tile for the BatchNorm that follows (eas_conv_fwd_stats): the wave's accumulators
+// acc[WM][WN] (32 channels x 32 pixels each: pixel = lane & 31, channel = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)), `valid[n]` = this
+// lane's pixel of tile n exists.  Writes sum and sum of squares of the wave's WM * 32 channels to red[(m * 32 + channel) * 2 + {0, 1}].
+// Vector-ALU budget matters here (the waves of a SIMD share it and the MFMA kernels' epilogues are short): the sums over the wave's pixel
+// tiles are packed-fp32 operations, and the sum over the 32 pixel lanes goes through a wave-private LDS patch (`scratch`,
+// EAS_STATS_SCRATCH floats: 16 ds_write_b32, then lane c < 32 reads the 32 lane values of channel c with 8 conflict-free ds_read_b128 and
+// adds them in lane order) instead of 5 DPP steps per value.
+#define EAS_STATS_PITCH 36                          // floats per channel row of the patch (32 lanes + 4: b128 rows land on distinct banks)
+#define EAS_STATS_SCRATCH (32 * EAS_STATS_PITCH)    // floats per wave
+template <int WM, int WN, typename ACC>
+__device__ __forceinline__ void eas_conv_stats_wave(const ACC (&acc)[WM][WN], const bool (&valid)[WN], float* scratch, double* red, int lane) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int h = lane >> 5, r = lane & 31;
+    bool all = true;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) all = all && valid[n];
+    const bool uniform_all = __all(all);
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        f2 s[8], q[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { s[p] = f2{0.0f, 0.0f}; q[p] = f2{0.0f, 0.0f}; }
+        if (uniform_all) {
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const f2 a = f2{acc[m][n][2 * p], acc[m][n][2 * p + 1]};
+                    s[p] += a;
+                    q[p] = __builtin_elementwise_fma(a, a, q[p]);
+                }
+        } else {
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const f2 a = f2{valid[n] ? acc[m][n][2 * p] : 0.0f, valid[n] ? acc[m][n][2 * p + 1] : 0.0f};
+                    s[p] += a;
+                    q[p] = __builtin_elementwise_fma(a, a, q[p]);
+                }
+        }
+#pragma unroll
+        for (int stat = 0; stat < 2; ++stat) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const f2 v = stat ? q[e >> 1] : s[e >> 1];
+                scratch[(4 * h + (e & 3) + 8 * (e >> 2)) * EAS_STATS_PITCH + r] = (e & 1) ? v.y : v.x;
+            }
+            // the wave's own LDS writes are visible to its own later reads (LDS executes a wave's operations in order): only the
+            // compiler must keep the order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 32) {
+                const float4* row = reinterpret_cast<const float4*>(scratch + lane * EAS_STATS_PITCH);
+                double t = 0.0;        // from here on in double (full-rate v_add_f64): sum of squares minus squared sum cancels downstream
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float4 v = row[k];
+                    t += (double)v.x; t += (double)v.y; t += (double)v.z; t += (double)v.w;
+                }
+                red[(m * 32 + lane) * 2 + stat] = t;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// The waves of a block that computed the same channels (NWV waves, `red` = their eas_conv_stats_wave outputs, wave w at
+// red + w * wave_stride) added in wave order; thread t < nch handles the block's channel t: co = first channel + t.
+// stats[(co * nb + block) * 2 + {0, 1}].  Call after a __syncthreads().
+__device__ __forceinline__ void eas_conv_stats_store(const double* red, int wave_stride, int nwv, int t, int co, int Cout, double* stats, int nb,
+                                                     int block) {
+    if (co >= Cout) return;
+    double s = 0.0, q = 0.0;
+    for (int w = 0; w < nwv; ++w) {
+        s += red[w * wave_stride + t * 2 + 0];
+        q += red[w * wave_stride + t * 2 + 1];
+    }
+    *reinterpret_cast<double2*>(stats + ((int64_t)co * nb + block) * 2) = make_double2(s, q);
+}
+
 #define EAS_BN_MAX_CHUNKS 64   // chunk partials per channel in the BN workspaces (kMaxChunks of bn_lif.hip / bn_act.hip)
 
 // ------------------------------------------------------------------------------------------------ fused finalize
@@ -75,8 +175,10 @@ __device__ __forceinline__ T eas_block_sum(T v, T* smem) {
 // same fixed order (identical result in every block), block 0 of the channel publishes mean / invstd for the backward
 // and updates the running statistics.  Saves one launch per layer (74 per SYOLOX-S step).
 struct BnFin {
-    const double* part;     // NULL: mean / invstd are inputs
-    int nchunks, replicas;
+    const double* part;     // NULL: mean / invstd are inputs; else [C][pitch][2] partial sums, nchunks <= pitch of them used per channel
+                            // (eas_bn_stats_partial: pitch 64; the producing convolution's epilogue, eas_conv_fwd_stats: pitch = nchunks
+                            // = its pixel blocks, possibly thousands)
+    int nchunks, pitch, replicas;
     double count;
     float eps, momentum;
     float* mean_out;
@@ -108,11 +210,61 @@ __device__ __forceinline__ void bn_from_totals(const BnFin& f, int c, double s, 
 }
 
 __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, float* st, float& mu, float& istd, bool publish) {
+    if (f.nchunks > EAS_WAVE) {
+        // many partials (a convolution epilogue's), added in a fixed order (the same in every block of the channel and in every run).
+        // Up to 1024: the first wave alone (no extra barrier in front of the block's work); more: every thread helps.
+        const double2* p = reinterpret_cast<const double2*>(f.part) + (int64_t)c * f.pitch;
+        if (f.nchunks <= 1024) {
+            if (threadIdx.x < EAS_WAVE) {
+                double s = 0.0, ss = 0.0;
+                for (int i = threadIdx.x; i < f.nchunks; i += EAS_WAVE) {
+                    const double2 v = p[i];
+                    s += v.x;
+                    ss += v.y;
+                }
+                s = eas_wave_sum(s);
+                ss = eas_wave_sum(ss);
+                if (threadIdx.x == 0) {
+                    float m_, i_;
+                    bn_from_totals(f, c, s, ss, publish, m_, i_);
+                    st[0] = m_;
+                    st[1] = i_;
+                }
+            }
+        } else {
+            __shared__ double fred[2][EAS_BLOCK / EAS_WAVE];
+            double s = 0.0, ss = 0.0;
+            for (int i = threadIdx.x; i < f.nchunks; i += blockDim.x) {
+                const double2 v = p[i];
+                s += v.x;
+                ss += v.y;
+            }
+            s = eas_wave_sum(s);
+            ss = eas_wave_sum(ss);
+            if ((threadIdx.x & (EAS_WAVE - 1)) == 0) {
+                fred[0][threadIdx.x / EAS_WAVE] = s;
+                fred[1][threadIdx.x / EAS_WAVE] = ss;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                s = 0.0; ss = 0.0;
+                for (int w = 0; w < (int)(blockDim.x / EAS_WAVE); ++w) { s += fred[0][w]; ss += fred[1][w]; }
+                float m_, i_;
+                bn_from_totals(f, c, s, ss, publish, m_, i_);
+                st[0] = m_;
+                st[1] = i_;
+            }
+        }
+        __syncthreads();
+        mu = st[0];
+        istd = st[1];
+        return;
+    }
     if (threadIdx.x < EAS_WAVE) {
         double s = 0.0, ss = 0.0;
         if ((int)threadIdx.x < f.nchunks) {
-            s = f.part[((int64_t)c * EAS_BN_MAX_CHUNKS + threadIdx.x) * 2 + 0];
-            ss = f.part[((int64_t)c * EAS_BN_MAX_CHUNKS + threadIdx.x) * 2 + 1];
+            s = f.part[((int64_t)c * f.pitch + threadIdx.x) * 2 + 0];
+            ss = f.part[((int64_t)c * f.pitch + threadIdx.x) * 2 + 1];
         }
         s = eas_wave_sum(s);
         ss = eas_wave_sum(ss);

@@ -284,9 +284,65 @@ def _coop_ptr(device, channels):
     return C.pointer(coop_buffers(device)[0])
 
 
-def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=None, y_ctot=0):
-    """batch statistics of the consumer kernel: cooperative (computed inside it, EasCoop) or, with EAS_COOP_BN=0, the partial-sum
-    launch whose result the consumer finalizes (EasBnPending)."""
+# Convolution -> BatchNorm hand-over (eas_conv_fwd_stats, north_star's fused conv -> BN -> LIF step): inside ``conv_stats_scope`` a
+# matrix-core convolution also leaves the per-channel sums of its output tile by tile, and the BN kernel that consumes exactly that
+# tensor next adds them up instead of reading y once more (no eas_bn_stats_partial launch).  The slot holds the convolution output
+# itself, so its address cannot be reused while the slot is valid; a BN call on anything else falls back to the statistics pass.
+CONV_STATS = os.environ.get('EAS_CONV_STATS', '1') == '1'
+CONV_STATS_MAX_BLOCKS = int(os.environ.get('EAS_CONV_STATS_MAX_BLOCKS', '4096'))     # partials per channel the consumers still add cheaply
+_WANT_CONV_STATS = False
+_CONV_STATS_SLOT = None          # (y [NI,Cout,Ho,Wo], nb, stats [Cout*nb*2] fp64)
+_STATS_BLOCKS = {}
+
+
+class conv_stats_scope:
+    """``with ops.conv_stats_scope(bn_uses_batch_statistics):`` around the convolution whose output goes straight into a fused BN kernel"""
+
+    def __init__(self, flag=True):
+        self.flag = bool(flag) and CONV_STATS
+
+    def __enter__(self):
+        global _WANT_CONV_STATS
+        self.prev, _WANT_CONV_STATS = _WANT_CONV_STATS, self.flag
+
+    def __exit__(self, *exc):
+        global _WANT_CONV_STATS
+        _WANT_CONV_STATS = self.prev
+
+
+def _conv_stats_blocks(L, geom):
+    nb = _STATS_BLOCKS.get(geom)
+    if nb is None:
+        nb = _STATS_BLOCKS[geom] = L.eas_conv_fwd_stats_blocks(*geom)
+    return nb
+
+
+def _take_conv_stats(base_ptr, count, Ctot, keep=False):
+    """(stats tensor, nb) if the tensor at ``base_ptr`` ([.., Ctot, H, W] with ``count`` elements per channel) is the output of the last
+    convolution that summed its tiles, else None; the slot is cleared unless ``keep`` (two consumers of one output)."""
+    global _CONV_STATS_SLOT
+    slot = _CONV_STATS_SLOT
+    if slot is None:
+        return None
+    y, nb, stats = slot
+    if not keep:
+        _CONV_STATS_SLOT = None
+    if y.data_ptr() != base_ptr or y.shape[1] != Ctot or y.shape[0] * y.shape[2] * y.shape[3] != count:
+        return None
+    return stats, nb
+
+
+def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=None, y_ctot=0, keep_slot=False):
+    """batch statistics of the consumer kernel: the producing convolution's tile sums (conv_stats_scope), cooperative (computed inside
+    it, EasCoop) or the partial-sum launch whose result the consumer finalizes (EasBnPending)."""
+    got = _take_conv_stats(y.data_ptr(), TN * HW, y_ctot if y_ctot else Cc, keep_slot)
+    if got is not None:
+        stats, nb = got
+        c0 = 0 if y_ptr is None else (y_ptr - y.data_ptr()) // (4 * HW)
+        pend = _lib.EasBnPending(stats.data_ptr() + 16 * c0 * nb, nb, int(replicas), float(TN) * HW, float(eps),
+                                 float(momentum if momentum is not None else 0.0), ptr(running_mean) if momentum is not None else None,
+                                 ptr(running_var) if momentum is not None else None, None, nb)
+        return pend, stats
     cp = _coop_ptr(dev, Cc)
     if cp is not None:
         pend = _lib.EasBnPending(None, 0, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
@@ -471,7 +527,8 @@ class _BNLIF2Fn(torch.autograd.Function):
                 mean = torch.empty(Cc, dtype=torch.float32, device=dev)
                 invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
                 t0 = _timer_mark()
-                pend, keep = _pending_stats(L, y12, T * N, Cc, HW, 1, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct)
+                pend, keep = _pending_stats(L, y12, T * N, Cc, HW, 1, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct,
+                                            keep_slot=c0 == 0)
                 _timer_add('eas_bn_stats', t0, 4 * T * N * Cc * HW)
             else:
                 mean = running_mean
@@ -1098,7 +1155,17 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
               Hi, Wi, ksize, stream(), flops=fl, issue_flops=fl * 3)
         return y
     x = _f32c(x)
-    _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
+    L = _lib.lib()
+    if _WANT_CONV_STATS and bias is None:
+        global _CONV_STATS_SLOT
+        nb = _conv_stats_blocks(L, (NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms))
+        if 0 < nb <= CONV_STATS_MAX_BLOCKS:
+            stats = torch.empty(Cout * nb * 2, dtype=torch.float64, device=x.device)
+            _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd_stats, ptr(x), ptr(packed), ptr(y), NI, Cin, Cout, Hi, Wi,
+                  ksize, stride, x_terms, None, ptr(stats), nb, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+            _CONV_STATS_SLOT = (y, nb, stats)
+            return y
+    _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
           ksize, stride, x_terms, None, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
     return y
 

@@ -243,6 +243,8 @@ typedef struct {
     float* running_mean;     /* nullable pair */
     float* running_var;
     const EasCoop* coop;     /* not NULL (and partial NULL): the consuming kernel computes the batch statistics itself, see EasCoop */
+    int pitch;               /* partials allocated per channel in `partial`: 0 = what eas_bn_stats_partial writes (64); the statistics buffer of
+                                eas_conv_fwd_stats: its nb (= chunks; a channel slice: partial = stats + first_channel * nb * 2) */
 } EasBnPending;
 int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, double* workspace, eas_stream_t stream);
 int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
@@ -352,6 +354,15 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
+/* Fused conv -> BN statistics (the conv -> BN -> LIF step of network_blocks.py:52-53 without a statistics pass over y): eas_conv_fwd
+ * without bias whose epilogue also sums its output tile per channel -- stats[Cout][nb][2] doubles, (sum, sum of squares) of each of the
+ * nb pixel blocks of the launch; nb = eas_conv_fwd_stats_blocks(same geometry) (0 = no tile).  Hand the buffer to the BatchNorm kernel
+ * behind it as EasBnPending.partial with chunks = pitch = nb (a channel slice: stats + first_channel * nb * 2); it adds the partials in a
+ * fixed order, so results are reproducible run to run.  y is bit-identical to eas_conv_fwd's.  (Per lane the tile's <= 5 pixel values are
+ * added in fp32, everything above that in double.) */
+int eas_conv_fwd_stats(const float* x, const void* packed_w, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride,
+                       int x_terms, int* inexact_flag, double* stats, int nb, eas_stream_t stream);
+int eas_conv_fwd_stats_blocks(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
 /* 1x1 convolution (stride 1) of a spike tensor given as BYTES (uint8 [NI][Cin][Hi][Wi], values 0..255: what eas_bn_lif_fwd_ex writes
  * to spikes_u8): same arithmetic and the same result, bit for bit, as eas_conv_fwd with x_terms = 1 on the fp32 copy, reading
  * 1 B instead of 4 B per input element (the 1x1 layers are HBM-bound).  Cin % 8 == 0. */

@@ -1009,6 +1009,81 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         assert err < 1e-5, f'{name}: {err:.2e}'
 
 
+STATS_CASES = [c for c in CONV_CASES if c[2] != 2] + [(6, 64, 96, 32, 40, 1, 1, True), (64, 512, 512, 8, 10, 1, 1, False), (1, 16, 32, 8, 320, 3, 2, False),
+                                                   (12, 32, 48, 64, 80, 3, 1, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('NI,Cin,Cout,H,W,k,s,spikes', STATS_CASES)
+def test_conv_epilogue_statistics(dev, NI, Cin, Cout, H, W, k, s, spikes):
+    """eas_conv_fwd_stats (the fused conv -> BN statistics of network_blocks.py:52-53): y bit-identical to eas_conv_fwd, and the per-block
+    partial sums add up to the per-channel sum / sum of squares of y (fp64 of the same y) to the fp32 rounding of a lane's own few values -- every
+    kernel family (3x3 stride 1 / 2, column parts, 1x1 direct / shared-fragment), ragged channel counts, tiles spanning images."""
+    from eas_snn_amd import _lib, ops
+    L = _lib.lib()
+    x, w = _conv_case(NI, Cin, Cout, H, W, k, spikes, seed=NI * 77 + Cout)
+    xd, wd = x.to(dev), w.to(dev)
+    xt = 1 if spikes else 3
+    if not L.eas_conv_fwd_supported(NI, Cin, Cout, H, W, k, s, xt):
+        pytest.skip('no tile (Cin % 8 != 0 for 3x3)')
+    nb = L.eas_conv_fwd_stats_blocks(NI, Cin, Cout, H, W, k, s, xt)
+    assert nb > 0
+    pk = ops.conv_pack_weights(wd, 0)
+    y0 = ops.conv_fwd_packed(xd, pk, None, Cout, k, s, xt)
+    Ho, Wo = y0.shape[-2:]
+    y1 = torch.full_like(y0, float('nan'))
+    stats = torch.full((Cout, nb, 2), float('nan'), device=dev, dtype=torch.float64)
+    rc = L.eas_conv_fwd_stats(ops.ptr(xd), ops.ptr(pk), ops.ptr(y1), NI, Cin, Cout, H, W, k, s, xt, None, ops.ptr(stats), nb, ops.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.isfinite(stats).all()
+    y64 = y0.double()
+    ref_s, ref_q = y64.sum((0, 2, 3)), (y64 * y64).sum((0, 2, 3))
+    got = stats.sum(1)
+    scale_s = y64.abs().sum((0, 2, 3)) + 1e-30
+    assert ((got[:, 0] - ref_s).abs() / scale_s).max().item() < 3e-7       # fp32 only for the <= 5 pixel values a lane adds
+    assert ((got[:, 1] - ref_q).abs() / (ref_q + 1e-30)).max().item() < 3e-7
+    # a wrong partial count is refused before anything is launched
+    assert L.eas_conv_fwd_stats(ops.ptr(xd), ops.ptr(pk), ops.ptr(y1), NI, Cin, Cout, H, W, k, s, xt, None, ops.ptr(stats), nb + 1, ops.stream()) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,N,Cin,C,H,W,k', [(3, 4, 32, 64, 16, 20, 3), (3, 2, 64, 40, 32, 40, 1), (1, 8, 16, 32, 64, 80, 3), (3, 2, 512, 256, 8, 10, 1)])
+def test_bn_lif_on_convolution_statistics_matches_statistics_pass(dev, monkeypatch, T, N, Cin, C, H, W, k):
+    """conv -> BN+LIF with the statistics taken from the convolution epilogue (ops.conv_stats_scope) against the same layers with the
+    separate statistics pass: mean / invstd / running statistics to 1e-6 relative, spikes equal except where a membrane potential sits within
+    rounding of the threshold (none in these cases), gradients to 1e-5."""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(T * 100 + C)
+    x = (torch.rand(T * N, Cin, H, W, generator=g) < 0.3).float().to(dev)
+    conv = nn.Conv2d(Cin, C, k, 1, k // 2, bias=False).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.1).to(dev).requires_grad_(True)
+    w = torch.tensor(0.3, device=dev, requires_grad=True)
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        for p in (conv.weight, gamma, beta, w):
+            p.grad = None
+        with ops.conv_stats_scope(fused):
+            y = ops.conv2d(x, conv, small_int=True)
+        assert (ops._CONV_STATS_SLOT is not None) == fused
+        spikes, v, _ = ops.bn_lif_multistep(y.view(T, N, C, H, W), gamma, beta, rm, rv, True, 0.1, 1e-5, None, w, 0.0, 1.0, 0.0,
+                                            ops.FLAG_DECAY_INPUT, 'atan', 2.0)
+        assert ops._CONV_STATS_SLOT is None
+        gs = torch.randn(spikes.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        (spikes * gs).sum().backward()
+        res.append((spikes.detach().clone(), rm.clone(), rv.clone(), conv.weight.grad.clone(), gamma.grad.clone(), beta.grad.clone()))
+    (s0, rm0, rv0, gw0, gg0, gb0), (s1, rm1, rv1, gw1, gg1, gb1) = res
+    torch.testing.assert_close(rm1, rm0, rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-6, atol=1e-8)
+    assert (s0 != s1).float().mean().item() < 1e-5
+    for a, b in ((gw0, gw1), (gg0, gg1), (gb0, gb1)):
+        assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item() + 1e-7
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('NI,Cin,Cout,H,W,s', [(1, 8, 16, 6, 320, 1), (1, 16, 32, 8, 320, 2), (1, 16, 16, 4, 640, 1), (2, 8, 48, 12, 320, 1),
                                                (2, 48, 96, 12, 320, 2)])
