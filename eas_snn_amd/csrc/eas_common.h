@@ -211,49 +211,38 @@ __device__ __forceinline__ void bn_from_totals(const BnFin& f, int c, double s, 
 
 __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, float* st, float& mu, float& istd, bool publish) {
     if (f.nchunks > EAS_WAVE) {
-        // many partials (a convolution epilogue's), added in a fixed order (the same in every block of the channel and in every run).
-        // Up to 1024: the first wave alone (no extra barrier in front of the block's work); more: every thread helps.
+        // many partials (a convolution epilogue's), added in a fixed order (the same in every block of the channel and in every run):
+        // thread t takes partials t, t + blockDim, ...; four loads in flight per thread (the finalize is pure load latency in front of
+        // the block's work: a one-wave loop over 384 partials cost +12 us on a 38 us layer), then the block tree.
+        __shared__ double fred[2][EAS_BLOCK / EAS_WAVE];
         const double2* p = reinterpret_cast<const double2*>(f.part) + (int64_t)c * f.pitch;
-        if (f.nchunks <= 1024) {
-            if (threadIdx.x < EAS_WAVE) {
-                double s = 0.0, ss = 0.0;
-                for (int i = threadIdx.x; i < f.nchunks; i += EAS_WAVE) {
-                    const double2 v = p[i];
-                    s += v.x;
-                    ss += v.y;
-                }
-                s = eas_wave_sum(s);
-                ss = eas_wave_sum(ss);
-                if (threadIdx.x == 0) {
-                    float m_, i_;
-                    bn_from_totals(f, c, s, ss, publish, m_, i_);
-                    st[0] = m_;
-                    st[1] = i_;
-                }
-            }
-        } else {
-            __shared__ double fred[2][EAS_BLOCK / EAS_WAVE];
-            double s = 0.0, ss = 0.0;
-            for (int i = threadIdx.x; i < f.nchunks; i += blockDim.x) {
-                const double2 v = p[i];
-                s += v.x;
-                ss += v.y;
-            }
-            s = eas_wave_sum(s);
-            ss = eas_wave_sum(ss);
-            if ((threadIdx.x & (EAS_WAVE - 1)) == 0) {
-                fred[0][threadIdx.x / EAS_WAVE] = s;
-                fred[1][threadIdx.x / EAS_WAVE] = ss;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                s = 0.0; ss = 0.0;
-                for (int w = 0; w < (int)(blockDim.x / EAS_WAVE); ++w) { s += fred[0][w]; ss += fred[1][w]; }
-                float m_, i_;
-                bn_from_totals(f, c, s, ss, publish, m_, i_);
-                st[0] = m_;
-                st[1] = i_;
-            }
+        const int B = blockDim.x, n = f.nchunks;
+        double s = 0.0, ss = 0.0;
+        for (int i = threadIdx.x; i < n; i += 4 * B) {
+            const double2 z = make_double2(0.0, 0.0);
+            const double2 v0 = p[i];
+            const double2 v1 = i + B < n ? p[i + B] : z;
+            const double2 v2 = i + 2 * B < n ? p[i + 2 * B] : z;
+            const double2 v3 = i + 3 * B < n ? p[i + 3 * B] : z;
+            s += v0.x; ss += v0.y;
+            s += v1.x; ss += v1.y;
+            s += v2.x; ss += v2.y;
+            s += v3.x; ss += v3.y;
+        }
+        s = eas_wave_sum(s);
+        ss = eas_wave_sum(ss);
+        if ((threadIdx.x & (EAS_WAVE - 1)) == 0) {
+            fred[0][threadIdx.x / EAS_WAVE] = s;
+            fred[1][threadIdx.x / EAS_WAVE] = ss;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s = 0.0; ss = 0.0;
+            for (int w = 0; w < (int)(blockDim.x / EAS_WAVE); ++w) { s += fred[0][w]; ss += fred[1][w]; }
+            float m_, i_;
+            bn_from_totals(f, c, s, ss, publish, m_, i_);
+            st[0] = m_;
+            st[1] = i_;
         }
         __syncthreads();
         mu = st[0];
