@@ -627,11 +627,17 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
         const size_t lds_bytes = (size_t)nbuf * t.Q * CCH * 2 * XT;
         const int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
-        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 ? 1.2 : 1.0)) * (0.3 + 0.7 * c.wn / 5.0);
+        // (two co-resident 4-wave blocks cost 1.2 rounds of one -- but only when there are more blocks than CUs: a grid of <= 256 blocks
+        // puts one block on a CU whatever its LDS size)
+        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * c.wn / 5.0);
         const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
+        // ties: the larger valid pixel count; among grids of lone blocks (<= 256) first the shape with more waves along the channels
+        // (they share one staged pixel patch: the smaller patch per block is the shorter prologue; 8x10 head layers: 35-38 us against
+        // 44-50 us for the four-pixel-group shape)
         const int valid = t.RT * g.Wo;
-        if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && valid > best_valid)) {
-            best = i; best_cost = cost; best_valid = valid; best_g = t;
+        const int rank = (blocks <= 256 ? c.wvm * 4096 : 0) + (valid < 4096 ? valid : 4095);
+        if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rank > best_valid)) {
+            best = i; best_cost = cost; best_valid = rank; best_g = t;
         }
     }
     if (best < 0) return EAS_ERR_UNSUPPORTED;

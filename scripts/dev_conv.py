@@ -95,7 +95,8 @@ def bench_shapes():
         ('dark3.conv3 1x1', 192, 128, 128, 32, 40, 1, 1, True), ('dark2.conv1 1x1', 192, 64, 32, 64, 80, 1, 1, True),
         ('dark5.spp.conv2 1x1', 192, 1024, 512, 8, 10, 1, 1, True),
         ('dgrad dark2.m', 192, 32, 32, 64, 80, 3, 1, False), ('dgrad dark3.m', 192, 64, 64, 32, 40, 3, 1, False),
-        ('dgrad dark4.m', 192, 128, 128, 16, 20, 3, 1, False), ('dgrad dark5.m', 192, 256, 256, 8, 10, 3, 1, False)]
+        ('dgrad dark4.m', 192, 128, 128, 16, 20, 3, 1, False), ('dgrad dark5.m', 192, 256, 256, 8, 10, 3, 1, False),
+        ('head 8x10 (ann)', 64, 128, 128, 8, 10, 3, 1, False), ('neck 8x10 (ann)', 64, 256, 256, 8, 10, 3, 1, False)]
 
 
 def time_():
@@ -168,3 +169,24 @@ def c1time():
 
 if __name__ == '__main__' and sys.argv[1:] == ['c1time']:
     c1time()
+
+
+def tile_acc():
+    """development: forward of the EAS_SHAPES layers with the tile forced by EAS_CONV_TILE against fp64 (max error / max |y|)"""
+    for idx in [int(a) for a in os.environ.get('EAS_SHAPES', '16,5,17,2').split(',')]:
+        name, NI, Cin, Cout, H, W, k, s, sp = bench_shapes()[idx]
+        x, w = make(NI, Cin, Cout, H, W, k, sp)
+        pk = ops.conv_pack_weights(w, 0)
+        try:
+            y = ops.conv_fwd_packed(x, pk, None, Cout, k, s, 1 if sp else 3)
+        except Exception as e:
+            print(f'tile={os.environ.get("EAS_CONV_TILE")} {name:20s} unsupported ({type(e).__name__})')
+            continue
+        ref = F.conv2d(x[:8].double(), w.double(), stride=s, padding=k // 2)
+        err = (y[:8].double() - ref).abs().max().item() / ref.abs().max().item()
+        t = timeit(lambda: ops.conv_fwd_packed(x, pk, None, Cout, k, s, 1 if sp else 3), reps=20)
+        print(f'tile={os.environ.get("EAS_CONV_TILE")} {name:20s} {t * 1e3:8.1f} us  err {err:.1e}', flush=True)
+
+
+if __name__ == '__main__' and sys.argv[1:] == ['tile_acc']:
+    tile_acc()

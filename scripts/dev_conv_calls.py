@@ -43,7 +43,7 @@ def wrap(name, argnames):
     setattr(L, name, f)
 
 
-for n in ('eas_conv_fwd', 'eas_conv_dgrad_s2', 'eas_conv_wgrad_partial', 'eas_conv_fwd_u8'):
+for n in ('eas_conv_fwd', 'eas_conv_fwd_stats', 'eas_conv_dgrad_s2', 'eas_conv_wgrad_partial', 'eas_conv_fwd_u8'):
     wrap(n, None)
 
 
