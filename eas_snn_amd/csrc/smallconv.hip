@@ -373,8 +373,19 @@ bool wgrad_on_mfma(int k) {
     return k >= 5;
 }
 
+// Forward / input gradient at k = 5 also exist in a matrix-core form (smallconv_mfma.hip).  It is exact and correct but NOT faster than
+// this file's vector-ALU kernel (64 images of 256x320, 4 -> 4: 98 us against 90 us; see the header there), so it only runs on request:
+// EAS_SC_FORM=mfma (read per call so that a test can compare the two forms in one process).
+bool conv_on_mfma(int k) {
+    const char* e = getenv("EAS_SC_FORM");
+    return e && e[0] == 'm' && k == 5;
+}
+
 }  // namespace
 
+// smallconv_mfma.hip
+int eas_sc5_mfma(const float* x, const float* w, const float* b, const float* mask, float* y, int N, int Cin, int Cout, int H, int W,
+                 int relu, int dgrad, int x_terms, hipStream_t st);
 // smallconv_wgrad_mfma.hip
 int eas_sw_mfma_partials(const float* gy, const float* x, float* partial, int max_blocks, int N, int Cin, int Cout, int H, int W,
                          int k, hipStream_t st);
@@ -387,6 +398,11 @@ int eas_smallconv_fwd(const float* x, const float* w, const float* b, float* y, 
     if (bad_ptr(y)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
+    if (conv_on_mfma(k)) {
+        const int rc = eas_sc5_mfma(x, w, b, nullptr, y, N, Cin, Cout, H, W, relu, 0, 3, st);
+        if (rc == EAS_OK) { EAS_CHECK_LAUNCH(); return EAS_OK; }
+        if (rc != EAS_ERR_UNSUPPORTED) return rc;
+    }
     if (Cin == 2 && Cout == 4) return launch_conv_k<2, 4, false>(k, x, w, b, nullptr, y, N, H, W, relu, st);
     if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, false>(k, x, w, b, nullptr, y, N, H, W, relu, st);
     if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, false>(k, x, w, b, nullptr, y, N, H, W, relu, st);
@@ -399,6 +415,11 @@ int eas_smallconv_bwd_input(const float* grad_y, const float* w, const float* re
     if (bad_ptr(grad_x) || bad_ptr(relu_mask)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
+    if (conv_on_mfma(k)) {
+        const int rc = eas_sc5_mfma(grad_y, w, nullptr, relu_mask, grad_x, N, Cin, Cout, H, W, 0, 1, 3, st);
+        if (rc == EAS_OK) { EAS_CHECK_LAUNCH(); return EAS_OK; }
+        if (rc != EAS_ERR_UNSUPPORTED) return rc;
+    }
     // the kernel's "input" is grad_y (Cout channels), its "output" grad_x (Cin channels)
     if (Cin == 2 && Cout == 4) return launch_conv_k<4, 2, true>(k, grad_y, w, nullptr, relu_mask, grad_x, N, H, W, 0, st);
     if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, true>(k, grad_y, w, nullptr, relu_mask, grad_x, N, H, W, 0, st);

@@ -824,11 +824,16 @@ def test_arsnn_golden(dev, name):
 
 # ------------------------------------------------------------------------------------------------ sampler convs
 @pytest.mark.parametrize('cin,cout,k,N,H,W', [(2, 4, 5, 3, 32, 64), (4, 4, 5, 2, 48, 80), (2, 4, 7, 2, 20, 36), (4, 4, 3, 1, 16, 64),
-                                               (2, 2, 5, 2, 17, 30), (4, 4, 7, 1, 256, 320), (2, 4, 3, 5, 33, 130)])
-def test_smallconv_vs_fp64_reference(dev, cin, cout, k, N, H, W):
+                                               (2, 2, 5, 2, 17, 30), (4, 4, 7, 1, 256, 320), (2, 4, 3, 5, 33, 130), (4, 4, 5, 2, 37, 250)])
+@pytest.mark.parametrize('form', ['fma', 'mfma'])
+def test_smallconv_vs_fp64_reference(dev, monkeypatch, form, cin, cout, k, N, H, W):
     """eas_smallconv_{fwd,bwd_input,bwd_weight} against an fp64 torch convolution on the CPU (tile edges, halos,
-    H/W not multiples of the 16x64 tile, W not a multiple of 4, fused ReLU / ReLU-mask epilogues)."""
+    H/W not multiples of the 16x64 tile, W not a multiple of 4, fused ReLU / ReLU-mask epilogues).  form: the vector-ALU kernels (default)
+    or, for k = 5, the opt-in matrix-core forward / input gradient of smallconv_mfma.hip (EAS_SC_FORM is read per call)."""
     from eas_snn_amd import ops
+    if form == 'mfma' and k != 5:
+        pytest.skip('the matrix-core form exists for 5x5 kernels')
+    monkeypatch.setenv('EAS_SC_FORM', form)
     rng = np.random.default_rng(cin * 100 + cout * 10 + k)
     x = rng.standard_normal((N, cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
