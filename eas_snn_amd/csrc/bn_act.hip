@@ -3,6 +3,8 @@
 // blockIdx.y = channel, blockIdx.x = chunk of that channel's N*HW/4 float4 groups; statistics come from
 // eas_bn_stats.  HBM traffic per element: fwd 8 B (read y, write out); bwd 20 B (two passes over y and grad_out
 // because the BN backward needs sum(dz) and sum(dz*xhat) first, then writes grad_y); nothing but y is saved.
+#include <stdlib.h>
+
 #include "eas_common.h"
 
 namespace {
@@ -149,6 +151,82 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
     }
 }
 
+// Small maps (the 8x10 / 16x20 levels of neck and head: a channel's N*HW values fit the registers of ONE block): both passes in one
+// launch without any exchange between blocks -- block = channel, every thread keeps its <= GPT float4 groups of grad_out and y in
+// registers (all loads issued up front: one memory latency), the block adds (sum dz, sum dz*xhat) in a fixed order and writes grad_y
+// from the registers: 12 B per element instead of 20 and one launch instead of two (these layers are launch-bound: ~6 us per launch
+// for 2.6 MB).  Same per-element arithmetic as the two-pass kernels.
+template <int NT, int GPT>
+__global__ __launch_bounds__(NT) void bn_silu_bwd_small_kernel(const float* __restrict__ grad_out, const float* __restrict__ y,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int batch_stats, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+                                                              float* __restrict__ grad_beta, int N, int C, int HW) {
+    constexpr int NWV = NT / EAS_WAVE;
+    __shared__ double red[2][NWV];
+    __shared__ float bc[2];
+    const int c = blockIdx.x;
+    const float mu = mean[c], istd = invstd[c];
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
+    const int hw4 = HW / VEC;
+    const int groups = N * hw4;
+    float4 yv[GPT], gv[GPT];
+    int64_t base[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const int g = threadIdx.x + i * NT;
+        const int gg = g < groups ? g : groups - 1;          // surplus threads re-read the last group (not used)
+        const int n = gg / hw4, q = gg - n * hw4;
+        base[i] = ((int64_t)n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        yv[i] = *reinterpret_cast<const float4*>(y + base[i]);
+        gv[i] = *reinterpret_cast<const float4*>(grad_out + base[i]);
+    }
+    float s1 = 0.f, s2 = 0.f;
+    float dz[GPT][4], xh[GPT][4];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const float ys[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w};
+        const float gs[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
+        const bool live = threadIdx.x + i * NT < groups;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dz[i][e] = gs[e] * silu_grad(fmaf(ys[e], scale, shift));
+            xh[i][e] = (ys[e] - mu) * istd;
+            if (live) {
+                s1 += dz[i][e];
+                s2 += dz[i][e] * xh[i][e];
+            }
+        }
+    }
+    double t1 = eas_wave_sum((double)s1), t2 = eas_wave_sum((double)s2);
+    if ((threadIdx.x & (EAS_WAVE - 1)) == 0) {
+        red[0][threadIdx.x / EAS_WAVE] = t1;
+        red[1][threadIdx.x / EAS_WAVE] = t2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t1 = 0.0; t2 = 0.0;
+        for (int w = 0; w < NWV; ++w) { t1 += red[0][w]; t2 += red[1][w]; }
+        const double cnt = (double)N * HW;
+        bc[0] = (float)(t1 / cnt);
+        bc[1] = (float)(t2 / cnt);
+        grad_beta[c] = (float)t1;
+        grad_gamma[c] = (float)t2;
+    }
+    __syncthreads();
+    const float m1 = batch_stats ? bc[0] : 0.f, m2 = batch_stats ? bc[1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        if (threadIdx.x + i * NT < groups) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = scale * (dz[i][e] - m1 - xh[i][e] * m2);
+            *reinterpret_cast<float4*>(grad_y + base[i]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // both passes of the backward in one launch: the blocks of a channel exchange (sum dz, sum dz*xhat) in the kernel and write grad_y
 // from grad_out / y they have just read (eas_channel_allreduce)
 __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_coop_kernel(const float* __restrict__ grad_out, const float* __restrict__ y,
@@ -270,6 +348,23 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    {
+        // one block per channel where a channel fits the registers of a block (see bn_silu_bwd_small_kernel); EAS_BNSILU_BWD=two keeps
+        // the two-pass launches (development)
+        static const bool small_ok = !(getenv("EAS_BNSILU_BWD") && getenv("EAS_BNSILU_BWD")[0] == 't');
+        constexpr int GPT = 6;
+        const int64_t groups = (int64_t)N * (HW / VEC);
+        if (small_ok && !coop && C >= 64 && groups <= 1024 * GPT) {
+#define EAS_SMALL(NT_) hipLaunchKernelGGL((bn_silu_bwd_small_kernel<NT_, GPT>), dim3(C), dim3(NT_), 0, st, grad_out, y, mean, invstd, gamma, beta, \
+                                           batch_stats, grad_y, grad_gamma, grad_beta, N, C, HW)
+            if (groups <= 256 * GPT) EAS_SMALL(256);
+            else if (groups <= 512 * GPT) EAS_SMALL(512);
+            else EAS_SMALL(1024);
+#undef EAS_SMALL
+            EAS_CHECK_LAUNCH();
+            return EAS_OK;
+        }
+    }
     if (coop) {
         hipLaunchKernelGGL(bn_silu_bwd_coop_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta, batch_stats,
                            grad_y, grad_gamma, grad_beta, N, C, HW, coop_dev(coop));

@@ -888,7 +888,9 @@ def test_smallconv_weight_gradient_forms(dev, monkeypatch, cin, cout, k, N, H, W
 
 
 # ------------------------------------------------------------------------------------------------ BN + SiLU (ANN blocks)
-@pytest.mark.parametrize('N,C,H,W,train', [(4, 16, 12, 20, True), (4, 16, 12, 20, False), (1, 3, 2, 2, True), (64, 128, 32, 40, True)])
+@pytest.mark.parametrize('N,C,H,W,train', [(4, 16, 12, 20, True), (4, 16, 12, 20, False), (1, 3, 2, 2, True), (64, 128, 32, 40, True),
+                                           # channels that fit one block: the one-launch backward (256 / 512 / 1024 threads, ragged last groups)
+                                           (64, 128, 8, 10, True), (64, 64, 16, 20, True), (32, 96, 16, 20, True), (3, 64, 6, 10, False), (5, 72, 4, 20, True)])
 def test_bn_silu_fused_vs_torch(dev, N, C, H, W, train):
     from eas_snn_amd import ops
     torch.manual_seed(N + C)
