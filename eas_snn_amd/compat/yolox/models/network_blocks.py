@@ -4,6 +4,8 @@
 What is different: once ``convert_to_spiking`` has swapped ``bn``/``act`` for the multi-step BatchNorm and a
 spiking neuron, ``BaseConv.forward`` runs conv -> [BN + LIF fused in one HIP kernel pair] instead of three
 separate module calls."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -75,13 +77,19 @@ class BaseConv(nn.Module):
                 y = self.conv(x)
             return self.bn.fused_with(self.act, y, want_mean=self.emit_rate, residual=residual, cat=cat,
                                       emit_bytes=emit_bytes and x.dim() == 5)
-        assert residual is None and cat is None
+        assert residual is None
         with ops.conv_stats_scope(self.bn.training or self.bn.running_mean is None):
             y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
-        if (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
-                and (self.bn.momentum is not None or not self.bn.training)):
-            return ops.bn_silu(y, self.bn)          # one statistics pass + one fused normalise/SiLU pass (HIP)
+        if self.ann_fusable(y):
+            return ops.bn_silu(y, self.bn, cat=cat)     # the statistics from the convolution + one fused normalise/SiLU pass (HIP)
+        assert cat is None
         return self.act(self.bn(y))
+
+    def ann_fusable(self, y):
+        """BN + SiLU of this (real-valued) block run as the fused HIP kernel on ``y`` (then the output can also go straight into a
+        concatenation buffer)"""
+        return (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
+                and (self.bn.momentum is not None or not self.bn.training))
 
     def fuseforward(self, x):
         return self.act(self.conv(x))
@@ -111,7 +119,9 @@ class Bottleneck(nn.Module):
         if _fusable(self.conv2, x):
             # SEW residual (spike sums 0/1/2..) and the caller's concatenation from the BN+LIF kernel of conv2
             return self.conv2(h, residual=x if self.use_add else None, cat=cat)
-        assert cat is None
+        if cat is not None:                      # real-valued block without a shortcut: conv2's BN + SiLU writes into the buffer
+            assert not self.use_add
+            return self.conv2(h, cat=cat)
         y = self.conv2(h)
         if not self.use_add:
             return y
@@ -191,7 +201,36 @@ class CSPLayer(nn.Module):
                     a = blk(a)
                 a = self.m[-1](a, cat=(buf, 0, buf8))
             return self.conv3(ops.join_channels(buf, a, b, u8_buf=buf8))
+        if self._ann_inplace_cat(x):
+            # real-valued CSPLayer (PAFPN neck): both branches write their BN + SiLU output into the two halves of the concatenation
+            # (no torch.cat; the backward reads the two halves of the gradient in place)
+            N = x.shape[0]
+            h = self.conv2.conv.out_channels
+            buf = torch.empty((N, 2 * h) + tuple(x.shape[-2:]), dtype=torch.float32, device=x.device)
+            b = self.conv2(x, cat=(buf, h))
+            a = self.conv1(x, cat=None if len(self.m) else (buf, 0))
+            if len(self.m):
+                for blk in self.m[:-1]:
+                    a = blk(a)
+                a = self.m[-1](a, cat=(buf, 0))
+            return self.conv3(ops.join_channels(buf, a, b))
         return self.conv3(_cat((self.m(self.conv1(x)), self.conv2(x))))
+
+    def _ann_inplace_cat(self, x):
+        if os.environ.get('EAS_ANN_INPLACE_CAT', '1') != '1':       # development switch
+            return False
+        last = self.m[-1] if len(self.m) else self.conv1
+        if not (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and not self.conv1.spiking() and not self.conv2.spiking()
+                and type(self.conv2.conv) is nn.Conv2d and _stride1(self.conv2.conv) and not torch.nn.modules.module._global_forward_hooks):
+            return False
+        if isinstance(last, Bottleneck):
+            tail = last.conv2
+            if last.use_add or not isinstance(tail, BaseConv) or tail.spiking() or type(tail.conv) is not nn.Conv2d or not _stride1(tail.conv):
+                return False
+        else:
+            tail = last
+        probe = x[:, :1]          # shape / dtype probe for bn_silu_supported (same H, W as every output of the layer)
+        return tail.ann_fusable(probe) and self.conv2.ann_fusable(probe) and not tail._forward_hooks and not self.conv2._forward_hooks
 
 
 class Focus(nn.Module):

@@ -657,9 +657,22 @@ class replicated:
         _REPLICAS = self.prev
 
 
+def _channel_slice_of4(g, Cc):
+    """total channel count if ``g`` [N,C,H,W] is a channel slice of a contiguous wider tensor (what the backward of an in-place
+    concatenation hands out), Cc if it is contiguous itself, else 0."""
+    if g.is_contiguous():
+        return Cc
+    N, C_, H, W = g.shape
+    st = g.stride()
+    if st[3] == 1 and st[2] == W and st[1] == H * W and st[0] % (H * W) == 0 and st[0] // (H * W) > C_ and (g.data_ptr() % 16) == 0:
+        return st[0] // (H * W)
+    return 0
+
+
 class _BNSiLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn_state):
+    def forward(ctx, y, gamma, beta, bn_state, cat_buf=None, cat_c0=0):
+        """cat_buf [N,Ctot,H,W]: the result is written as channels cat_c0.. of it and returned as a view (concatenation in place)."""
         running_mean, running_var, use_batch_stats, momentum, eps, replicas = bn_state
         _dev(y, gamma, beta)
         L = _lib.lib()
@@ -677,9 +690,15 @@ class _BNSiLUFn(torch.autograd.Function):
             pend = keep = None
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-        out = torch.empty_like(y)
+        if cat_buf is not None:
+            assert cat_buf.is_contiguous() and cat_buf.dtype == torch.float32 and cat_buf.shape[0] == N and cat_buf.shape[2:] == y.shape[2:]
+            out = cat_buf.narrow(1, cat_c0, Cc)
+            ctot = cat_buf.shape[1]
+        else:
+            out = torch.empty_like(y)
+            ctot = 0
         _call('eas_bn_silu_fwd', 8 * y.numel(), L.eas_bn_silu_fwd_ex, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), N, Cc,
-              HW, C.byref(pend) if pend is not None else None, stream())
+              HW, C.byref(pend) if pend is not None else None, ctot, stream())
         del keep
         ctx.save_for_backward(y, mean, invstd, gamma, beta)
         ctx.cfg = (bool(use_batch_stats), N, Cc, HW)
@@ -690,27 +709,34 @@ class _BNSiLUFn(torch.autograd.Function):
         y, mean, invstd, gamma, beta = ctx.saved_tensors
         batch_stats, N, Cc, HW = ctx.cfg
         L = _lib.lib()
-        g = _f32c(g)
-        gy, ggamma, gbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
         cp = _coop_ptr(y.device, Cc)
+        # the gradient of an in-place concatenation arrives as a channel slice of the concatenation's gradient: read in place
+        ctot = _channel_slice_of4(g, Cc) if (g.dim() == 4 and g.dtype == torch.float32 and cp is None) else 0
+        if ctot == 0:
+            g = _f32c(g)
+        gy, ggamma, gbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
         ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device) if cp is None else None
         _call('eas_bn_silu_bwd', 12 * y.numel(), L.eas_bn_silu_bwd, ptr(g), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, cp, stream())
-        return gy, ggamma, gbeta, None
+              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, cp, stream())
+        return gy, ggamma, gbeta, None, None, None
 
 
 def bn_silu_supported(y):
     return y.is_cuda and y.dim() == 4 and y.dtype == torch.float32 and (y.shape[-1] * y.shape[-2]) % 4 == 0
 
 
-def bn_silu(y, bn):
-    """silu(batch_norm(y)) for a plain ``nn.BatchNorm2d`` module ``bn`` (running statistics updated like F.batch_norm)."""
+def bn_silu(y, bn, cat=None):
+    """silu(batch_norm(y)) for a plain ``nn.BatchNorm2d`` module ``bn`` (running statistics updated like F.batch_norm).
+    cat = (buffer [N,Ctot,H,W], first channel): the result is written into that channel range of the buffer and returned as a view
+    (the caller joins the buffer with ``join_channels``)."""
     batch = bn.training or (bn.running_mean is None and bn.running_var is None)
     update = batch and bn.training and bn.track_running_stats
     if update and bn.num_batches_tracked is not None:
         bump_counter(bn.num_batches_tracked)
     state = (bn.running_mean if (update or not batch) else None, bn.running_var if (update or not batch) else None, bool(batch),
              float(bn.momentum) if update else None, float(bn.eps), _REPLICAS)
+    if cat is not None:
+        return _BNSiLUFn.apply(y, bn.weight, bn.bias, state, cat[0], cat[1])
     return _BNSiLUFn.apply(y, bn.weight, bn.bias, state)
 
 

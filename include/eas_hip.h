@@ -273,12 +273,16 @@ int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad
  * workspace: eas_bn_workspace_doubles(C) doubles. */
 int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                     float* out, int N, int C, int HW, eas_stream_t stream);
-/* eas_bn_silu_fwd with the statistics finalize folded in (see EasBnPending above): mean / invstd become outputs. */
+/* eas_bn_silu_fwd with the statistics finalize folded in (see EasBnPending above): mean / invstd become outputs.
+ * out_ctot (0 or >= C): out is C consecutive channels of a [N][out_ctot][HW] tensor, the pointer at the first of them -- the
+ * torch.cat((x_1, x_2), dim=1) of the ANN CSPLayer (network_blocks.py:183-188) happens in place. */
 int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
-                       float* out, int N, int C, int HW, const EasBnPending* pending, eas_stream_t stream);
+                       float* out, int N, int C, int HW, const EasBnPending* pending, int out_ctot, eas_stream_t stream);
+/* grad_out_ctot (0 or >= C): grad_out is such a channel slice of a wider gradient tensor (no contiguous copy of the slice).  Channels
+ * whose N*HW values fit the registers of one block (the 8x10 / 16x20 maps) run both passes in one launch. */
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                    double* workspace, int N, int C, int HW, const EasCoop* coop, eas_stream_t stream);
+                    double* workspace, int N, int C, int HW, int grad_out_ctot, const EasCoop* coop, eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  adaptive sampler step (AdaptiveRSNNEmbedding.forward loop body,

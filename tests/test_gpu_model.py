@@ -598,6 +598,42 @@ def test_csp_single_convolution_for_both_branches_is_identical(dev, train, monke
         assert torch.equal(b0[k], b1[k]), k
 
 
+@pytest.mark.parametrize('n,H,W', [(1, 16, 20), (2, 8, 10), (1, 32, 40)])
+def test_ann_csp_concatenation_in_place_is_bit_identical(dev, monkeypatch, n, H, W):
+    """Real-valued CSPLayer (PAFPN neck, shortcut=False): both branches' BN + SiLU kernels write into the two channel halves of one buffer
+    (eas_bn_silu_fwd_ex out_ctot) and their backward reads its half of the gradient in place (eas_bn_silu_bwd grad_out_ctot, incl. the
+    one-launch small-map form) -- against torch.cat of separate outputs and contiguous gradient copies: same kernels on the same values,
+    so outputs, running statistics and every gradient are bit-identical."""
+    import copy
+    from yolox.models.network_blocks import CSPLayer
+    torch.manual_seed(9)
+    base = CSPLayer(128, 128, n=n, shortcut=False)
+    for m in base.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    x = torch.randn(8, 128, H, W)
+    go = torch.randn(8, 128, H, W)
+    res = []
+    for inplace in (False, True):
+        net = copy.deepcopy(base).to(dev).train()
+        if not inplace:
+            monkeypatch.setattr(CSPLayer, '_ann_inplace_cat', lambda self, x_: False)
+        else:
+            monkeypatch.undo()
+            assert net._ann_inplace_cat(x.to(dev))
+        xd = x.to(dev).requires_grad_(True)
+        out = net(xd)
+        out.backward(go.to(dev))
+        res.append((out.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                    {k: b.clone() for k, b in net.named_buffers()}))
+    (o0, g0, p0, b0), (o1, g1, p1, b1) = res
+    assert torch.equal(o0, o1) and torch.equal(g0, g1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+
+
 def test_state_dict_roundtrip_and_writeback_switch(dev):
     from eas_snn_amd import ops
     from spikingjelly.activation_based import functional
