@@ -74,7 +74,7 @@ PROTOTYPES = {
     'eas_bn_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                  C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_silu_fwd': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
-    'eas_bn_silu_fwd_ex': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.POINTER(EasBnPending), C.c_int, _P]),
+    'eas_bn_silu_fwd_ex': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.POINTER(EasBnPending), C.c_int, C.c_int, _P]),
     'eas_bn_stats_partial': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_bn_lif_fwd_ex': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P, _P]),
@@ -82,7 +82,7 @@ PROTOTYPES = {
                                     C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasCoop), _P]),
     'eas_bn_lif_bwd_patan': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P,
                                        _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasCoop), _P]),
-    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 4 + [C.POINTER(EasCoop), _P]),
+    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 5 + [C.POINTER(EasCoop), _P]),
     'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, _P]),
     'eas_arsnn_step_bwd': (C.c_int, [_P] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,

@@ -156,6 +156,24 @@ class CSPLayer(nn.Module):
         self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
+    def _branch_convs(self):
+        """the nn.Conv2d of conv1 and of conv2 (inside their SeqToANNContainer once converted), or None"""
+        out = []
+        for blk in (self.conv1, self.conv2):
+            c = blk.conv[0] if isinstance(blk.conv, nn.Sequential) and len(blk.conv) == 1 else blk.conv
+            if type(c) is not nn.Conv2d:
+                return None
+            out.append(c)
+        return out
+
+    def eas_dual_convs(self):
+        """conv1 | conv2 read the same input: ``ops.packed_weights`` packs their concatenated weight for ``ops.conv2d_dual``"""
+        cs = self._branch_convs()
+        if cs is None or cs[0].kernel_size != (1, 1) or cs[1].kernel_size != (1, 1) or cs[0].bias is not None or cs[1].bias is not None \
+                or cs[0].in_channels != cs[1].in_channels or cs[0].groups != 1 or cs[1].groups != 1:
+            return []
+        return [('c12', cs[0], cs[1])]
+
     def _dual_ok(self):
         """conv1 / conv2 as one convolution: both plain bias-free 1x1 convolutions without hooks (EAS_NO_DUAL: development switch)"""
         import os
@@ -190,7 +208,10 @@ class CSPLayer(nn.Module):
                     sink(c1, x4, 1)
                     sink(c2, x4, 1)
                 with ops.conv_stats_scope(self.conv1.bn._use_batch_stats() and self.conv2.bn._use_batch_stats()):
-                    y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
+                    if ops.conv_dual_ok(x4, c1, c2):        # weights packed from the two parameters, no torch.cat
+                        y12 = ops.conv2d_dual(x4, c1, c2, self, 'c12').view(T, N, 2 * h, Ho, Wo)
+                    else:
+                        y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
                 a, b = sj_layer.fused_pair(self.conv1.bn, self.conv1.act, self.conv2.bn, self.conv2.act, y12,
                                            cat_a=None if len(self.m) else (buf, 0, buf8), cat_b=(buf, h, buf8))
             else:
@@ -207,8 +228,21 @@ class CSPLayer(nn.Module):
             N = x.shape[0]
             h = self.conv2.conv.out_channels
             buf = torch.empty((N, 2 * h) + tuple(x.shape[-2:]), dtype=torch.float32, device=x.device)
-            b = self.conv2(x, cat=(buf, h))
-            a = self.conv1(x, cat=None if len(self.m) else (buf, 0))
+            cs = self._branch_convs()
+            if (cs is not None and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL') and not ops.COOP_BN and self.conv1.ann_fusable(x[:, :1])
+                    and ops.conv_dual_ok(x, cs[0], cs[1])):
+                # conv1 and conv2 read the same x: ONE 1x1 convolution (weights packed from the two parameters), then the two BN + SiLU
+                # layers on the channel halves of its output; the input gradient is one convolution, no addition of two branch gradients
+                sink = ops.conv_sink()
+                if sink is not None:
+                    sink(cs[0], x, 1)
+                    sink(cs[1], x, 1)
+                with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (self.conv1.bn, self.conv2.bn))):
+                    y12 = ops.conv2d_dual(x, cs[0], cs[1], self, 'c12')
+                a, b = ops.bn_silu_pair(y12, self.conv1.bn, self.conv2.bn, cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
+            else:
+                b = self.conv2(x, cat=(buf, h))
+                a = self.conv1(x, cat=None if len(self.m) else (buf, 0))
             if len(self.m):
                 for blk in self.m[:-1]:
                     a = blk(a)

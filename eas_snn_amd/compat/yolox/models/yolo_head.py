@@ -5,6 +5,7 @@ The loss is the same computation as the reference's per-image loop, restated bat
 step issues no device->host synchronisation (the reference syncs several times per image:
 ``int(nlabel[b])``, ``.item()`` in simota_matching, boolean-mask indexing)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -70,10 +71,41 @@ class YOLOXHead(nn.Module):
                     m.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
 
     # ---- per-level raw predictions
+    def eas_dual_convs(self):
+        """the first cls / reg tower convolutions of a level read the same stem output: ``ops.packed_weights`` packs their concatenated
+        weight for ``ops.conv2d_dual``"""
+        out = []
+        for k in range(len(self.stems)):
+            a, b = self.cls_convs[k][0], self.reg_convs[k][0]
+            if isinstance(a, BaseConv) and isinstance(b, BaseConv) and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d \
+                    and a.conv.bias is None and b.conv.bias is None:
+                out.append((f'tower{k}', a.conv, b.conv))
+        return out
+
+    def _towers(self, k, x):
+        """cls_convs[k](x), reg_convs[k](x); their first convolutions as ONE convolution where the kernels allow it (x is read once, one
+        input gradient instead of two and an addition, twice the blocks on the small maps)"""
+        a, b = self.cls_convs[k][0], self.reg_convs[k][0]
+        if (isinstance(a, BaseConv) and isinstance(b, BaseConv) and not a.spiking() and not b.spiking() and x.dim() == 4
+                and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL') and not ops.COOP_BN
+                and a.ann_fusable(x[:, :1]) and b.ann_fusable(x[:, :1]) and ops.conv_dual_ok(x, a.conv, b.conv)):
+            sink = ops.conv_sink()
+            if sink is not None:
+                sink(a.conv, x, 1)
+                sink(b.conv, x, 1)
+            with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (a.bn, b.bn))):
+                y12 = ops.conv2d_dual(x, a.conv, b.conv, self, f'tower{k}')
+            ca, ra = ops.bn_silu_pair(y12, a.bn, b.bn)
+            for m in list(self.cls_convs[k])[1:]:
+                ca = m(ca)
+            for m in list(self.reg_convs[k])[1:]:
+                ra = m(ra)
+            return ca, ra
+        return self.cls_convs[k](x), self.reg_convs[k](x)
+
     def _level(self, k, x):
         x = self.stems[k](x)
-        cls_feat = self.cls_convs[k](x)
-        reg_feat = self.reg_convs[k](x)
+        cls_feat, reg_feat = self._towers(k, x)
         cls_out, reg_out, obj_out = _pred(self.cls_preds[k], cls_feat), _pred(self.reg_preds[k], reg_feat), _pred(self.obj_preds[k], reg_feat)
         if self.full_spike:        # mean input current over T (spiking_yolo_head.py:175-178)
             cls_out, reg_out, obj_out = ops.time_mean(cls_out), ops.time_mean(reg_out), ops.time_mean(obj_out)

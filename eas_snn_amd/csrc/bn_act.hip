@@ -33,7 +33,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ out, int N,
-                                                                int C, int HW, BnFin fin, EasCoopDev co, int out_ctot) {
+                                                                int C, int HW, BnFin fin, EasCoopDev co, int out_ctot, int y_ctot) {
     __shared__ float st[2];
     __shared__ double red[NW];
     __shared__ double shd[2];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
-        const float4 v = *reinterpret_cast<const float4*>(y + base);
+        const float4 v = *reinterpret_cast<const float4*>(y + (y_ctot ? (n * y_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base));
         float4 o;
         o.x = silu(fmaf(v.x, scale, shift)); o.y = silu(fmaf(v.y, scale, shift));
         o.z = silu(fmaf(v.z, scale, shift)); o.w = silu(fmaf(v.w, scale, shift));
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 int batch_stats, double* __restrict__ part, int nchunks,
                                                                 float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-                                                                float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot) {
+                                                                float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot, int y_ctot) {
     __shared__ double red[NW];
     __shared__ float bc[2];
     const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
         const int64_t n = gw.n;
         const int q = gw.q;
         const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
-        const float4 yv = *reinterpret_cast<const float4*>(y + base);
+        const int64_t ybase = y_ctot ? (n * y_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;       // y and grad_y: the same slice
+        const float4 yv = *reinterpret_cast<const float4*>(y + ybase);
         const float4 gv = *reinterpret_cast<const float4*>(grad_out + (go_ctot ? (n * go_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base));
         const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
         const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
                 s2 += dz * xhat;
             }
         }
-        if (APPLY) *reinterpret_cast<float4*>(grad_y + base) = make_float4(o[0], o[1], o[2], o[3]);
+        if (APPLY) *reinterpret_cast<float4*>(grad_y + ybase) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (!APPLY) {
         const double t1 = eas_block_sum<double, NW>((double)s1, red);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NT) void bn_silu_bwd_small_kernel(const float* __re
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               int batch_stats, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-                                                              float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot) {
+                                                              float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot, int y_ctot) {
     constexpr int NWV = NT / EAS_WAVE;
     __shared__ double red[2][NWV];
     __shared__ float bc[2];
@@ -178,9 +179,9 @@ __global__ __launch_bounds__(NT) void bn_silu_bwd_small_kernel(const float* __re
         const int g = threadIdx.x + i * NT;
         const int gg = g < groups ? g : groups - 1;          // surplus threads re-read the last group (not used)
         const int n = gg / hw4, q = gg - n * hw4;
-        base[i] = ((int64_t)n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        base[i] = ((int64_t)n * (y_ctot ? y_ctot : C) + c) * (int64_t)HW + (int64_t)q * VEC;      // of y and grad_y
         yv[i] = *reinterpret_cast<const float4*>(y + base[i]);
-        gv[i] = *reinterpret_cast<const float4*>(grad_out + (go_ctot ? ((int64_t)n * go_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base[i]));
+        gv[i] = *reinterpret_cast<const float4*>(grad_out + ((int64_t)n * (go_ctot ? go_ctot : C) + c) * (int64_t)HW + (int64_t)q * VEC);
     }
     float s1 = 0.f, s2 = 0.f;
     float dz[GPT][4], xh[GPT][4];
@@ -303,9 +304,12 @@ static EasCoopDev coop_dev(const EasCoop* c) {
 extern "C" {
 
 int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
-                       float* out, int N, int C, int HW, const EasBnPending* pend, int out_ctot, eas_stream_t stream) {
-    if (!y || !mean || !invstd || !gamma || !beta || !out || N < 1 || C < 1 || HW < 1 || (out_ctot != 0 && out_ctot < C)) return EAS_ERR_INVALID_ARG;
+                       float* out, int N, int C, int HW, const EasBnPending* pend, int out_ctot, int y_ctot, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || !out || N < 1 || C < 1 || HW < 1 || (out_ctot != 0 && out_ctot < C) || (y_ctot != 0 && y_ctot < C))
+        return EAS_ERR_INVALID_ARG;
     if (out_ctot == C) out_ctot = 0;
+    if (y_ctot == C) y_ctot = 0;
+    if (y_ctot && pend && !pend->partial && pend->coop) return EAS_ERR_UNSUPPORTED;     // the cooperative form reads a contiguous y
     if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
     BnFin fin{};
@@ -328,24 +332,25 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL(bn_silu_fwd_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin, co,
-                       out_ctot);
+                       out_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
 
 int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                     float* out, int N, int C, int HW, eas_stream_t stream) {
-    return eas_bn_silu_fwd_ex(y, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, out, N, C, HW, nullptr, 0, stream);
+    return eas_bn_silu_fwd_ex(y, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, out, N, C, HW, nullptr, 0, 0, stream);
 }
 
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                    double* workspace, int N, int C, int HW, int go_ctot, const EasCoop* coop, eas_stream_t stream) {
+                    double* workspace, int N, int C, int HW, int go_ctot, int y_ctot, const EasCoop* coop, eas_stream_t stream) {
     if (!grad_out || !y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || (!workspace && !coop) ||
-        N < 1 || C < 1 || HW < 1 || (go_ctot != 0 && go_ctot < C))
+        N < 1 || C < 1 || HW < 1 || (go_ctot != 0 && go_ctot < C) || (y_ctot != 0 && y_ctot < C))
         return EAS_ERR_INVALID_ARG;
     if (go_ctot == C) go_ctot = 0;
-    if (go_ctot && coop) return EAS_ERR_UNSUPPORTED;       // the cooperative form reads a contiguous grad_out
+    if (y_ctot == C) y_ctot = 0;
+    if ((go_ctot || y_ctot) && coop) return EAS_ERR_UNSUPPORTED;       // the cooperative form reads contiguous tensors
     if (coop && (!coop->slots || !coop->tickets || !coop->err || coop->capacity < C)) return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)grad_out | (uintptr_t)grad_y) & 15) return EAS_ERR_INVALID_ARG;
@@ -360,7 +365,7 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
         const int64_t groups = (int64_t)N * (HW / VEC);
         if (small_ok && !coop && C >= 64 && groups <= 1024 * GPT) {
 #define EAS_SMALL(NT_) hipLaunchKernelGGL((bn_silu_bwd_small_kernel<NT_, GPT>), dim3(C), dim3(NT_), 0, st, grad_out, y, mean, invstd, gamma, beta, \
-                                           batch_stats, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot)
+                                           batch_stats, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot)
             if (groups <= 256 * GPT) EAS_SMALL(256);
             else if (groups <= 512 * GPT) EAS_SMALL(512);
             else EAS_SMALL(1024);
@@ -376,10 +381,10 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
         return EAS_OK;
     }
     hipLaunchKernelGGL(bn_silu_bwd_kernel<false>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
-                       batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot);
+                       batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_silu_bwd_kernel<true>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
-                       batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot);
+                       batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

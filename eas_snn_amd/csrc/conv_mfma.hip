@@ -82,9 +82,15 @@ __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16&
 // weights [Cout][Cin][KS][KS] fp32 -> A fragments: wp[term][mt][kstep][tap][lane] (8 bf16 each)
 //   mode 0 (forward):        M = Cout, K = Cin :  A[m][k][tap] = w[m][k][tap]
 //   mode 1 (input gradient): M = Cin,  K = Cout:  A[m][k][tap] = w[k][m][TAPS-1-tap]      (transposed + flipped)
+// wb / ca: the [Cout][Cin][KS][KS] tensor may be the concatenation along Cout of two tensors, w (output channels [0, ca)) and wb
+// (the rest) -- the one convolution that computes two layers reading the same input (conv1 | conv2 of a CSPLayer, the first cls / reg
+// tower convolutions of the head) is packed straight from its two parameters, without a torch.cat.  wb == nullptr: one tensor.
 __device__ __forceinline__ void pack_fragment(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout, int Cin, int TAPS, int mode,
-                                              int idx, int total) {
+                                              int idx, int total, const float* __restrict__ wb = nullptr, int ca = 0) {
     const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
+    auto wat = [&](int co, int ci, int tap) {
+        return (wb && co >= ca) ? wb[((size_t)(co - ca) * Cin + ci) * TAPS + tap] : w[((size_t)co * Cin + ci) * TAPS + tap];
+    };
     const int KSTEPS = (K + 15) / 16;
     const int lane = idx & 63;
     int rest = idx >> 6;
@@ -98,7 +104,7 @@ __device__ __forceinline__ void pack_fragment(const float* __restrict__ w, bf16x
     for (int j = 0; j < 8; ++j) {
         const int k = ks * 16 + 8 * (lane >> 5) + j;
         float v = 0.0f;
-        if (m < M && k < K) v = mode ? w[((size_t)k * Cin + m) * TAPS + (TAPS - 1 - tap)] : w[((size_t)m * Cin + k) * TAPS + tap];
+        if (m < M && k < K) v = mode ? wat(k, m, TAPS - 1 - tap) : wat(m, k, tap);
         __bf16 a, b, c;
         split3(v, a, b, c);
         t0[j] = a;
@@ -162,16 +168,19 @@ __global__ void conv_pack_weights_kernel(const float* __restrict__ w, bf16x8* __
     }
 }
 
-// every weight tensor of a model in ONE launch (blockIdx.y = job): a job is six int64 {w, packed, Cout, Cin, ksize, mode}
+// every weight tensor of a model in ONE launch (blockIdx.y = job): a job is eight int64 {w, packed, Cout, Cin, ksize, mode, wb, ca}
+// (wb != 0: the weight is the concatenation [w (ca output channels) ; wb] along Cout, Cout = the total; modes 0 and 1 only)
 __global__ void conv_pack_weights_many_kernel(const long long* __restrict__ jobs) {
-    const long long* j = jobs + (size_t)blockIdx.y * 6;
+    const long long* j = jobs + (size_t)blockIdx.y * 8;
     const float* w = (const float*)j[0];
     bf16x8* wp = (bf16x8*)j[1];
     const int Cout = (int)j[2], Cin = (int)j[3], ksize = (int)j[4], mode = (int)j[5];
+    const float* wb = (const float*)j[6];
+    const int ca = (int)j[7];
     const int total = pack_total(Cout, Cin, ksize, mode);
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         if (mode == 2) pack_fragment_s2dgrad(w, wp, Cout, Cin, idx);
-        else pack_fragment(w, wp, Cout, Cin, ksize * ksize, mode, idx, total);
+        else pack_fragment(w, wp, Cout, Cin, ksize * ksize, mode, idx, total, wb, ca);
     }
 }
 
@@ -671,8 +680,9 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
     return EAS_OK;
 }
 
-// jobs: device array of njobs x 6 int64 {weight pointer, packed pointer, Cout, Cin, ksize, mode}; one launch packs them all
-// (the weights of a model only change at the optimizer step, so a training step needs this once)
+// jobs: device array of njobs x 8 int64 {weight pointer, packed pointer, Cout, Cin, ksize, mode, second weight pointer or 0, output
+// channels of the first}; one launch packs them all (the weights of a model only change at the optimizer step, so a training step needs
+// this once).  A second pointer packs the concatenation of two weight tensors along Cout (modes 0 and 1).
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream) {
     if (!jobs || njobs < 1) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();

@@ -698,7 +698,7 @@ class _BNSiLUFn(torch.autograd.Function):
             out = torch.empty_like(y)
             ctot = 0
         _call('eas_bn_silu_fwd', 8 * y.numel(), L.eas_bn_silu_fwd_ex, ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), N, Cc,
-              HW, C.byref(pend) if pend is not None else None, ctot, stream())
+              HW, C.byref(pend) if pend is not None else None, ctot, 0, stream())
         del keep
         ctx.save_for_backward(y, mean, invstd, gamma, beta)
         ctx.cfg = (bool(use_batch_stats), N, Cc, HW)
@@ -717,8 +717,98 @@ class _BNSiLUFn(torch.autograd.Function):
         gy, ggamma, gbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
         ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device) if cp is None else None
         _call('eas_bn_silu_bwd', 12 * y.numel(), L.eas_bn_silu_bwd, ptr(g), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, cp, stream())
+              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, 0, cp, stream())
         return gy, ggamma, gbeta, None, None, None
+
+
+class _BNSiLU2Fn(torch.autograd.Function):
+    """Two BN + SiLU layers on the two channel ranges of ONE convolution output y12 [N,Ca+Cb,H,W] (two real-valued convolutions that read
+    the same input computed as one, ``conv2d_dual``): each reads its channel slice in place, the backward writes both slices of ONE
+    gradient tensor -- the convolution's input gradient needs no addition of two branch gradients."""
+
+    @staticmethod
+    def forward(ctx, y12, gamma_a, beta_a, gamma_b, beta_b, state_a, state_b, cat_a, cat_b):
+        L = _lib.lib()
+        y12 = _f32c(y12)
+        N, Ct, H, W = y12.shape
+        HW = H * W
+        dev = y12.device
+        outs, saved, cfgs = [], [], []
+        c0 = 0
+        for gamma, beta, state, cat in ((gamma_a, beta_a, state_a, cat_a), (gamma_b, beta_b, state_b, cat_b)):
+            running_mean, running_var, use_batch_stats, momentum, eps, replicas = state
+            Cc = gamma.shape[0]
+            _dev(gamma, beta)
+            yp = y12.data_ptr() + 4 * c0 * HW
+            pend = keep = None
+            if use_batch_stats:
+                mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+                invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+                t0 = _timer_mark()
+                pend, keep = _pending_stats(L, y12, N, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct,
+                                            keep_slot=c0 == 0)
+                _timer_add('eas_bn_stats', t0, 4 * N * Cc * HW)
+            else:
+                mean = running_mean
+                invstd = torch.rsqrt(running_var + eps)
+            if cat is not None:
+                out = cat[0].narrow(1, cat[1], Cc)
+                ctot = cat[0].shape[1]
+            else:
+                out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev)
+                ctot = 0
+            _call('eas_bn_silu_fwd', 8 * N * Cc * HW, L.eas_bn_silu_fwd_ex, yp, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(out), N, Cc, HW,
+                  C.byref(pend) if pend is not None else None, ctot, Ct, stream())
+            del keep
+            outs.append(out)
+            saved += [mean, invstd, gamma, beta]
+            cfgs.append((bool(use_batch_stats), Cc, c0))
+            c0 += Cc
+        assert c0 == Ct
+        ctx.save_for_backward(y12, *saved)
+        ctx.cfgs = cfgs
+        ctx.dims = (N, Ct, HW)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        y12, *saved = ctx.saved_tensors
+        N, Ct, HW = ctx.dims
+        L = _lib.lib()
+        gy12 = torch.empty_like(y12)
+        res = []
+        for i, g in enumerate((g_a, g_b)):
+            mean, invstd, gamma, beta = saved[4 * i:4 * i + 4]
+            batch_stats, Cc, c0 = ctx.cfgs[i]
+            ggamma, gbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            if g is None:
+                gy12.narrow(1, c0, Cc).zero_()
+                ggamma.zero_(); gbeta.zero_()
+            else:
+                ctot = _channel_slice_of4(g, Cc) if (g.dim() == 4 and g.dtype == torch.float32) else 0
+                if ctot == 0:
+                    g = _f32c(g)
+                ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device)
+                off = 4 * c0 * HW
+                _call('eas_bn_silu_bwd', 12 * N * Cc * HW, L.eas_bn_silu_bwd, ptr(g), y12.data_ptr() + off, ptr(mean), ptr(invstd), ptr(gamma),
+                      ptr(beta), int(batch_stats), gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, Ct, None, stream())
+            res += [ggamma, gbeta]
+        return (gy12,) + tuple(res) + (None, None, None, None)
+
+
+def _bn_state(bn):
+    batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    update = batch and bn.training and bn.track_running_stats
+    if update and bn.num_batches_tracked is not None:
+        bump_counter(bn.num_batches_tracked)
+    return (bn.running_mean if (update or not batch) else None, bn.running_var if (update or not batch) else None, bool(batch),
+            float(bn.momentum) if update else None, float(bn.eps), _REPLICAS)
+
+
+def bn_silu_pair(y12, bn_a, bn_b, cat_a=None, cat_b=None):
+    """(silu(bn_a(y12[:, :Ca])), silu(bn_b(y12[:, Ca:]))) for the output y12 of ``conv2d_dual``; cat_a / cat_b = (buffer, first channel)
+    as in ``bn_silu``.  Not with the cooperative statistics (EAS_COOP_BN)."""
+    return _BNSiLU2Fn.apply(y12, bn_a.weight, bn_a.bias, bn_b.weight, bn_b.bias, _bn_state(bn_a), _bn_state(bn_b), cat_a, cat_b)
 
 
 def bn_silu_supported(y):
@@ -729,12 +819,7 @@ def bn_silu(y, bn, cat=None):
     """silu(batch_norm(y)) for a plain ``nn.BatchNorm2d`` module ``bn`` (running statistics updated like F.batch_norm).
     cat = (buffer [N,Ctot,H,W], first channel): the result is written into that channel range of the buffer and returned as a view
     (the caller joins the buffer with ``join_channels``)."""
-    batch = bn.training or (bn.running_mean is None and bn.running_var is None)
-    update = batch and bn.training and bn.track_running_stats
-    if update and bn.num_batches_tracked is not None:
-        bump_counter(bn.num_batches_tracked)
-    state = (bn.running_mean if (update or not batch) else None, bn.running_var if (update or not batch) else None, bool(batch),
-             float(bn.momentum) if update else None, float(bn.eps), _REPLICAS)
+    state = _bn_state(bn)
     if cat is not None:
         return _BNSiLUFn.apply(y, bn.weight, bn.bias, state, cat[0], cat[1])
     return _BNSiLUFn.apply(y, bn.weight, bn.bias, state)
@@ -1444,10 +1529,14 @@ def prepack_conv_weights(model):
     convs = plan['convs'] if plan else [m for m in model.modules() if _static_conv_ok(m) and m.weight.is_cuda]
     if not convs:
         return None
+    # pairs of convolutions that read the same input and run as ONE convolution (``conv2d_dual``): modules that have them list them as
+    # eas_dual_convs() -> [(key, conv_a, conv_b)]; their concatenated weight is packed straight from the two parameters
+    duals = plan['duals'] if plan else [(m, key, a, b) for m in model.modules() if hasattr(m, 'eas_dual_convs') for key, a, b in m.eas_dual_convs()
+                                        if a.weight.is_cuda]
     L = _lib.lib()
-    ptrs = tuple(c.weight.data_ptr() for c in convs)
+    ptrs = tuple(c.weight.data_ptr() for c in convs) + tuple(p for _, _, a, b in duals for p in (a.weight.data_ptr(), b.weight.data_ptr()))
     if not plan or plan['ptrs'] != ptrs:
-        jobs, packs = [], []
+        jobs, packs, dpacks = [], [], []
         dev = convs[0].weight.device
         for c in convs:
             k, Cout, Cin = c.kernel_size[0], c.out_channels, c.in_channels
@@ -1455,9 +1544,16 @@ def prepack_conv_weights(model):
             d = {}
             for m in modes:
                 d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)
-                jobs.append([c.weight.data_ptr(), d[m].data_ptr(), Cout, Cin, k, m])
+                jobs.append([c.weight.data_ptr(), d[m].data_ptr(), Cout, Cin, k, m, 0, 0])
             packs.append(d)
-        plan = {'convs': convs, 'packs': packs, 'ptrs': ptrs, 'njobs': len(jobs),
+        for _, _, a, b in duals:
+            k, Ca, Cout, Cin = a.kernel_size[0], a.out_channels, a.out_channels + b.out_channels, a.in_channels
+            d = {}
+            for m in (0, 1):
+                d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)
+                jobs.append([a.weight.data_ptr(), d[m].data_ptr(), Cout, Cin, k, m, b.weight.data_ptr(), Ca])
+            dpacks.append(d)
+        plan = {'convs': convs, 'packs': packs, 'duals': duals, 'dpacks': dpacks, 'ptrs': ptrs, 'njobs': len(jobs),
                 'jobs': torch.tensor(jobs, dtype=torch.int64).to(dev)}
         object.__setattr__(model, '_eas_pack_plan', plan)
     check(L.eas_conv_pack_weights_many(ptr(plan['jobs']), plan['njobs'], stream()), 'eas_conv_pack_weights_many')
@@ -1465,7 +1561,76 @@ def prepack_conv_weights(model):
     for c, d in zip(convs, plan['packs']):
         d['gen'] = _PACK_GEN
         object.__setattr__(c, '_eas_packs', d)
+    for (owner, key, _, _), d in zip(duals, plan['dpacks']):
+        d['gen'] = _PACK_GEN
+        reg = getattr(owner, '_eas_dual_packs', None)
+        if reg is None:
+            reg = {}
+            object.__setattr__(owner, '_eas_dual_packs', reg)
+        reg[key] = d
     return _PACK_GEN
+
+
+class _ConvDualFn(torch.autograd.Function):
+    """conv(x, [wa ; wb]) for two stride-1 convolutions without bias that read the same x (same kernel size): one forward, ONE input
+    gradient (no addition of two branch gradients), one weight-gradient launch whose result is handed out as its two row blocks."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb, x_terms, packs):
+        _dev(x, wa, wb)
+        k, Ca, Cout = wa.shape[-1], wa.shape[0], wa.shape[0] + wb.shape[0]
+        pk = packs[0] if packs else conv_pack_weights(torch.cat([wa, wb], 0), 0)
+        y = conv_fwd_packed(x, pk, None, Cout, k, 1, x_terms)
+        ctx.save_for_backward(x, wa, wb)
+        ctx.cfg = (k, x_terms, Ca)
+        ctx.packs = packs
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wa, wb = ctx.saved_tensors
+        k, x_terms, Ca = ctx.cfg
+        gy = _f32c(gy)
+        gx = ga = gb = None
+        if ctx.needs_input_grad[0]:
+            pk = ctx.packs[1] if ctx.packs else conv_pack_weights(torch.cat([wa, wb], 0), 1)
+            gx = conv_fwd_packed(gy, pk, None, x.shape[1], k, 1, 3)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gw = conv_wgrad(x, gy, k, 1, x_terms)
+            ga, gb = gw[:Ca], gw[Ca:]
+        return gx, ga, gb, None, None
+
+
+def conv_dual_ok(x, conv_a, conv_b):
+    """the two convolutions can run as one (``conv2d_dual``) on ``x`` [NI,Cin,H,W]"""
+    if os.environ.get('EAS_DUAL_CONV', '1') != '1':       # development switch: concatenate the weights with torch.cat instead
+        return False
+    if not (_static_conv_ok(conv_a) and _static_conv_ok(conv_b) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        return False
+    k, Cin, Cout = conv_a.kernel_size[0], conv_a.in_channels, conv_a.out_channels + conv_b.out_channels
+    if (conv_b.kernel_size[0] != k or conv_b.in_channels != Cin or conv_a.stride != (1, 1) or conv_b.stride != (1, 1)
+            or conv_a.bias is not None or conv_b.bias is not None or Cout % 8 != 0 or SPIKE_BYTES):
+        return False
+    if any(c._forward_hooks or c._forward_pre_hooks for c in (conv_a, conv_b)) or torch.nn.modules.module._global_forward_hooks:
+        return False
+    NI, _, H, W = x.shape
+    xt = 1 if is_small_int(x) else 3
+    L = _lib.lib()
+    return bool(conv_fwd_supported(NI, Cin, Cout, H, W, k, 1, xt) and conv_fwd_supported(NI, Cout, Cin, H, W, k, 1, 3)
+                and L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, H, W, k, 1, xt) > 0 and (k == 1 or (W % 2 == 0 and (H * W) % 4 == 0)))
+
+
+def conv2d_dual(x, conv_a, conv_b, owner=None, key=None):
+    """[conv_a(x) ; conv_b(x)] along the channels as ONE convolution (caller checked ``conv_dual_ok``).  owner / key: where
+    ``packed_weights`` left the packing of the concatenated weight (owner.eas_dual_convs())."""
+    small = is_small_int(x)
+    _verify_tags(x, small)
+    packs = None
+    if owner is not None:
+        packs = (getattr(owner, '_eas_dual_packs', None) or {}).get(key)
+        if packs is not None and (_PACK_SCOPE is None or packs.get('gen') != _PACK_SCOPE):
+            packs = None        # not inside the forward that made this packing: pack the weights as they are now
+    return _ConvDualFn.apply(x, conv_a.weight, conv_b.weight, 1 if small else 3, packs)
 
 
 class packed_weights:

@@ -277,12 +277,15 @@ int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, cons
  * out_ctot (0 or >= C): out is C consecutive channels of a [N][out_ctot][HW] tensor, the pointer at the first of them -- the
  * torch.cat((x_1, x_2), dim=1) of the ANN CSPLayer (network_blocks.py:183-188) happens in place. */
 int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* gamma, const float* beta,
-                       float* out, int N, int C, int HW, const EasBnPending* pending, int out_ctot, eas_stream_t stream);
-/* grad_out_ctot (0 or >= C): grad_out is such a channel slice of a wider gradient tensor (no contiguous copy of the slice).  Channels
+                       float* out, int N, int C, int HW, const EasBnPending* pending, int out_ctot, int y_ctot, eas_stream_t stream);
+/* y_ctot (0 or >= C) in both: y -- and grad_y in the backward -- are C consecutive channels of a [N][y_ctot][HW] tensor (the output of ONE
+ * convolution with concatenated weights feeding two BN + SiLU layers: conv1 | conv2 of the real-valued CSPLayer, the first cls / reg
+ * tower convolutions of the head).
+ * grad_out_ctot (0 or >= C): grad_out is such a channel slice of a wider gradient tensor (no contiguous copy of the slice).  Channels
  * whose N*HW values fit the registers of one block (the 8x10 / 16x20 maps) run both passes in one launch. */
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                    double* workspace, int N, int C, int HW, int grad_out_ctot, const EasCoop* coop, eas_stream_t stream);
+                    double* workspace, int N, int C, int HW, int grad_out_ctot, int y_ctot, const EasCoop* coop, eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  adaptive sampler step (AdaptiveRSNNEmbedding.forward loop body,
@@ -353,8 +356,11 @@ int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k);
  *     weights packed in mode 1, x_terms = 3. */
 int64_t eas_conv_packed_weight_bytes(int Cout, int Cin, int ksize, int mode);
 int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int ksize, int mode, eas_stream_t stream);
-/* the same for many weight tensors in one launch: `jobs` is a device array of njobs x 6 int64
- * {weight pointer, packed pointer, Cout, Cin, ksize, mode} */
+/* the same for many weight tensors in one launch: `jobs` is a device array of njobs x 8 int64
+ * {weight pointer, packed pointer, Cout, Cin, ksize, mode, second weight pointer or 0, Cout of the first}.  With a second pointer the
+ * packed weight is the concatenation of the two tensors along Cout (Cout = the total; modes 0 and 1): ONE convolution then computes two
+ * layers that read the same input -- conv1 | conv2 of a CSPLayer (network_blocks.py:175-188), the first cls / reg tower convolutions of
+ * the head (yolo_head.py) -- without a torch.cat of their weights. */
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);

@@ -606,6 +606,7 @@ def test_ann_csp_concatenation_in_place_is_bit_identical(dev, monkeypatch, n, H,
     so outputs, running statistics and every gradient are bit-identical."""
     import copy
     from yolox.models.network_blocks import CSPLayer
+    monkeypatch.setenv('EAS_NO_DUAL', '1')      # conv1 / conv2 as separate convolutions in both runs: this test isolates the concatenation
     torch.manual_seed(9)
     base = CSPLayer(128, 128, n=n, shortcut=False)
     for m in base.modules():
@@ -620,6 +621,7 @@ def test_ann_csp_concatenation_in_place_is_bit_identical(dev, monkeypatch, n, H,
             monkeypatch.setattr(CSPLayer, '_ann_inplace_cat', lambda self, x_: False)
         else:
             monkeypatch.undo()
+            monkeypatch.setenv('EAS_NO_DUAL', '1')
             assert net._ann_inplace_cat(x.to(dev))
         xd = x.to(dev).requires_grad_(True)
         out = net(xd)
@@ -630,6 +632,52 @@ def test_ann_csp_concatenation_in_place_is_bit_identical(dev, monkeypatch, n, H,
     assert torch.equal(o0, o1) and torch.equal(g0, g1)
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+
+
+@pytest.mark.parametrize('which', ['csp', 'head'])
+def test_real_valued_dual_convolution_matches_separate_convolutions(dev, monkeypatch, which):
+    """Two real-valued convolutions that read the same input as ONE convolution (ops.conv2d_dual: weights packed from the two
+    parameters; ops.bn_silu_pair on the channel halves): conv1 | conv2 of the PAFPN CSPLayer and the first cls / reg tower convolutions
+    of the head.  Forward values and running statistics are bit-identical to the separate convolutions (same products, same order per
+    output channel); gradients agree to rounding (one input-gradient accumulation instead of two sums and an addition)."""
+    import copy
+    from eas_snn_amd import ops
+    from yolox.models.network_blocks import CSPLayer
+    from yolox.models.yolo_head import YOLOXHead
+    torch.manual_seed(11)
+    if which == 'csp':
+        base = CSPLayer(128, 128, n=1, shortcut=False)
+        x = torch.randn(8, 128, 16, 20)
+        run = lambda net, xd: net(xd)
+    else:
+        base = YOLOXHead(3, width=0.5)
+        x = torch.randn(8, 128, 8, 10)
+        run = lambda net, xd: torch.cat(net._towers(2, xd), 1)
+    for m in base.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    res = []
+    for nodual in ('1', ''):
+        if nodual:
+            monkeypatch.setenv('EAS_NO_DUAL', '1')
+        else:
+            monkeypatch.delenv('EAS_NO_DUAL', raising=False)
+        net = copy.deepcopy(base).to(dev).train()
+        xd = x.to(dev).requires_grad_(True)
+        with ops.packed_weights(net):
+            out = run(net, xd)
+        go = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        out.backward(go)
+        res.append((out.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    {k: b.clone() for k, b in net.named_buffers()}))
+    (o0, g0, p0, b0), (o1, g1, p1, b1) = res
+    assert torch.equal(o0, o1)
+    assert set(p0) == set(p1) and len(p0) > 0
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=2e-6 * float(g0.abs().max()))
+    for k in p0:
+        torch.testing.assert_close(p1[k], p0[k], rtol=1e-5, atol=2e-6 * float(p0[k].abs().max()) + 1e-12, msg=k)
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
 
