@@ -638,13 +638,20 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         const int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
         // (two co-resident 4-wave blocks cost 1.2 rounds of one -- but only when there are more blocks than CUs: a grid of <= 256 blocks
         // puts one block on a CU whatever its LDS size)
-        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * c.wn / 5.0);
+        // a step's MFMAs (3 * WN with one-term inputs, 6 * WN with three) hide the ~450-cycle latency of the next step's weight
+        // fragments only when they last that long: with spike inputs a 3-tile wave (288 MFMA cycles per step) waits on every step and
+        // costs nearly as much as a 5-tile wave (dark5.m.conv2: 71 us against 62 us for the 160-pixel shape the old model ranked behind)
+        static const double lat = getenv("EAS_CONV_STEP_LAT") ? atof(getenv("EAS_CONV_STEP_LAT")) : 450.0;   // development
+        const double per_tile = XT == 1 ? 96.0 : 192.0;
+        const double mfma_part = (c.wn * per_tile > lat ? c.wn * per_tile : lat) / (5.0 * per_tile);
+        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part);
         const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
         // ties: the larger valid pixel count; among grids of lone blocks (<= 256) first the shape with more waves along the channels
         // (they share one staged pixel patch: the smaller patch per block is the shorter prologue; 8x10 head layers: 35-38 us against
         // 44-50 us for the four-pixel-group shape)
         const int valid = t.RT * g.Wo;
-        const int rank = (blocks <= 256 ? c.wvm * 4096 : 0) + (valid < 4096 ? valid : 4095);
+        static const int tie_wvm = getenv("EAS_CONV_TIE_WVM") ? atoi(getenv("EAS_CONV_TIE_WVM")) : 1;        // development: 0 = lone blocks only
+        const int rank = ((blocks <= 256 || tie_wvm) ? c.wvm * 4096 : 0) + (valid < 4096 ? valid : 4095);
         if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rank > best_valid)) {
             best = i; best_cost = cost; best_valid = rank; best_g = t;
         }
