@@ -101,6 +101,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restr
     __shared__ unsigned amax[kMaxPlane];
     __shared__ float gp[3][kMaxPlane];
     __shared__ float tcol[3][kMaxPlane];
+    __shared__ unsigned brow[kMaxPlane];
     const long long p0 = (long long)blockIdx.x * g.ppb;
     const int np = (int)(g.planes - p0 < g.ppb ? g.planes - p0 : g.ppb);
     const int work = np * g.HW;
@@ -115,6 +116,13 @@ __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restr
     }
     __syncthreads();
     spp_argmax(plane, rowarg, amax, g, work);
+    __syncthreads();
+    // row of each pool's arg-max, worked out once per pixel (the column pass below compares it 5 + 9 + 13 times per pixel: the integer
+    // division inside that loop was most of the kernel's instructions)
+    for (int idx = threadIdx.x; idx < work; idx += blockDim.x) {
+        const unsigned pk = amax[idx];
+        brow[idx] = ((pk & 1023u) / g.W) | ((((pk >> 10) & 1023u) / g.W) << 10) | ((((pk >> 20) & 1023u) / g.W) << 20);
+    }
     __syncthreads();
     // Separable gather.  Output (a, b) of pool j sends its gradient to (row, col) = (bestrow_j(a, b), rowarg_j(bestrow, b)):
     //   tcol_j(h, b) = sum over a in [h - r, h + r] of g_j(a, b) where bestrow_j(a, b) == h          (column pass)
@@ -131,8 +139,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void spp_bwd_kernel(const float* __restr
             float t = 0.f;
             for (int a = a0; a <= a1; ++a) {
                 const int q = base + a * g.W + b;
-                const int bestrow = (int)((amax[q] >> (10 * j)) & 1023u) / g.W;
-                if (bestrow == h) t += gp[j][q];
+                if ((int)((brow[q] >> (10 * j)) & 1023u) == h) t += gp[j][q];
             }
             tcol[j][idx] = t;
         }
