@@ -59,10 +59,16 @@ __global__ __launch_bounds__(EAS_BLOCK) void arsnn_step_fwd_kernel(
         const float4 ci = *reinterpret_cast<const float4*>(conv_in + cb + c.plane);
         const float4 gr = *reinterpret_cast<const float4*>(conv_rec + cb);
         const float4 cr = *reinterpret_cast<const float4*>(conv_rec + cb + c.plane);
-        const float4 vv = *reinterpret_cast<const float4*>(v + i);
-        const float4 vs = *reinterpret_cast<const float4*>(vsum + i);
-        int4 sg = *reinterpret_cast<const int4*>(seg + i);
-        int4 tl = *reinterpret_cast<const int4*>(t_last + i);
+        // v == NULL: the first step of a sequence -- zero potentials and sums, no segment written yet (seg = 0, t_last = -1): the state
+        // tensors need no zero fill before and no read here (seg / t_last are then outputs only)
+        float4 vv = make_float4(0.f, 0.f, 0.f, 0.f), vs = vv;
+        int4 sg = make_int4(0, 0, 0, 0), tl = make_int4(-1, -1, -1, -1);
+        if (v) {
+            vv = *reinterpret_cast<const float4*>(v + i);
+            vs = *reinterpret_cast<const float4*>(vsum + i);
+            sg = *reinterpret_cast<const int4*>(seg + i);
+            tl = *reinterpret_cast<const int4*>(t_last + i);
+        }
         if (seg_before) *reinterpret_cast<int4*>(seg_before + i) = sg;
         if (tl_before) *reinterpret_cast<int4*>(tl_before + i) = tl;
         float4 vo, vso, sp, ga, vn;
@@ -131,7 +137,8 @@ __global__ __launch_bounds__(EAS_BLOCK) void arsnn_step_bwd_kernel(
         const int64_t cb = n * 2 * c.plane + r;
         float gg, gc, gvp, gvsp;
         step_elem_bwd(g_v_out ? g_v_out[i] : 0.f, g_vsum_out ? g_vsum_out[i] : 0.f, g_spike ? g_spike[i] : 0.f, g_agg, i,
-                      v_prev[i], vsum_prev[i], gate_save[i], vn_save[i], seg_before[i], tl_before[i], c, gg, gc, gvp, gvsp);
+                      v_prev ? v_prev[i] : 0.f, vsum_prev ? vsum_prev[i] : 0.f, gate_save[i], vn_save[i], seg_before[i], tl_before[i], c, gg, gc,
+                      gvp, gvsp);
         g_conv[cb] = gg;
         g_conv[cb + c.plane] = gc;
         g_v_prev[i] = gvp;
@@ -183,7 +190,7 @@ int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float*
                        float* gate_save, float* vn_save, int32_t* seg_before, int32_t* t_last_before, int t,
                        int Ts, int readout, int spike_attach, float thresh, float v_reset, int soft_reset, int N,
                        int C2, int HW, eas_stream_t stream) {
-    if (!conv_in || !conv_rec || !v || !vsum || !seg || !t_last || !agg || !v_out || !vsum_out || !spike_out)
+    if (!conv_in || !conv_rec || (v == nullptr) != (vsum == nullptr) || !seg || !t_last || !agg || !v_out || !vsum_out || !spike_out)
         return EAS_ERR_INVALID_ARG;
     if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 3) return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0) return EAS_ERR_UNSUPPORTED;
@@ -205,7 +212,7 @@ int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const floa
                        const int32_t* seg_before, const int32_t* t_last_before, float* g_conv, float* g_v_prev,
                        float* g_vsum_prev, int t, int Ts, int readout, int spike_attach, float thresh,
                        float v_reset, int soft_reset, float sg_alpha, int N, int C2, int HW, eas_stream_t stream) {
-    if (!g_agg || !v_prev || !vsum_prev || !gate_save || !vn_save || !seg_before || !t_last_before || !g_conv ||
+    if (!g_agg || (v_prev == nullptr) != (vsum_prev == nullptr) || !gate_save || !vn_save || !seg_before || !t_last_before || !g_conv ||
         !g_v_prev || !g_vsum_prev)
         return EAS_ERR_INVALID_ARG;
     if (N < 1 || C2 < 1 || HW < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 3 || !(sg_alpha > 0.f))

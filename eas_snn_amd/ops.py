@@ -1052,8 +1052,10 @@ class _ARSNNFn(torch.autograd.Function):
             X, in_ins = ev, []
         C2 = X.shape[2] // 2
         shape = (N, C2, H, W)
-        v = torch.zeros(shape, device=dev)
-        vsum = torch.zeros(shape, device=dev)
+        v = vsum = None          # first step: the kernel takes zero potentials / sums, seg = 0, t_last = -1 (no zero fills)
+        if os.environ.get('EAS_ARSNN_ZERO_FILL') == '1':     # development: explicit zero state tensors
+            v = torch.zeros(shape, device=dev)
+            vsum = torch.zeros(shape, device=dev)
         # inputs of every gate conv for all Tm steps, written in place by the producing kernels: the batched weight
         # gradient reads them as one [Tm*N,...] tensor (no concatenation).  gate_in[0][t] = spike entering step t.
         keep = need_grad and d_gate
@@ -1064,8 +1066,10 @@ class _ARSNNFn(torch.autograd.Function):
         else:
             gate_in = None
             spike = torch.zeros(shape, device=dev)
-        seg = torch.zeros(shape, dtype=torch.int32, device=dev)
-        tl = torch.full(shape, -1, dtype=torch.int32, device=dev)
+        seg = torch.empty(shape, dtype=torch.int32, device=dev)
+        tl = torch.empty(shape, dtype=torch.int32, device=dev)
+        if Tm == 0 or v is not None:
+            seg.zero_(); tl.fill_(-1)
         agg = torch.zeros((1 if running else Ts,) + shape, device=dev)
         zero_rec = None if d_gate else torch.zeros((N, 2 * C2, H, W), device=dev)
         saved = []
@@ -1077,14 +1081,14 @@ class _ARSNNFn(torch.autograd.Function):
                 R, g_ins = _conv_stack_fwd(spike, pg, k, [gate_in[i + 1][t] for i in range(d_gate - 1)] if keep else None)
             else:
                 R, g_ins = zero_rec, []
-            v_n, vs_n = torch.empty_like(v), torch.empty_like(v)
-            sp_n = gate_in[0][t + 1] if keep and t + 1 < Tm else torch.empty_like(v)
+            v_n, vs_n = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
+            sp_n = gate_in[0][t + 1] if keep and t + 1 < Tm else torch.empty(shape, device=dev)
             if need_grad:
-                gate, vn = torch.empty_like(v), torch.empty_like(v)
+                gate, vn = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
                 seg_b, tl_b = torch.empty_like(seg), torch.empty_like(tl)
             else:
                 gate = vn = seg_b = tl_b = None
-            _call('eas_arsnn_step_fwd', 38 * v.numel(), L.eas_arsnn_step_fwd, ptr(X[t]), ptr(R), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
+            _call('eas_arsnn_step_fwd', 38 * v_n.numel(), L.eas_arsnn_step_fwd, ptr(X[t]), ptr(R), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
                   ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, 3 if running else readout,
                   int(sat), thresh, v_reset, int(soft), N, C2, HW, st)
             if need_grad:

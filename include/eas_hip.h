@@ -296,7 +296,9 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
  * SpikingEmbedding / LIFEmbedding (embedding.py:229-316, 28-76): vsum is a running sum that is never reset and no
  * segment is written.  v_reset_mode: 0 hard reset to
  * v_reset, 1 soft (v - thresh*spike).  Saved for backward: gate, vn (pre-reset), seg_before,
- * t_last_before (all nullable in inference). */
+ * t_last_before (all nullable in inference).
+ * v == vsum == NULL (forward) / v_prev == vsum_prev == NULL (backward): the first step of a sequence -- zero potentials and sums,
+ * seg = 0, t_last = -1 (embedding.py:159-167); seg / t_last are then outputs only, so the caller needs no zero fills. */
 int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float* v, const float* vsum,
                        int32_t* seg, int32_t* t_last, float* agg, float* v_out, float* vsum_out, float* spike_out,
                        float* gate_save, float* vn_save, int32_t* seg_before, int32_t* t_last_before, int t,
