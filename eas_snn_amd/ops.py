@@ -1059,13 +1059,19 @@ class _ARSNNFn(torch.autograd.Function):
         # inputs of every gate conv for all Tm steps, written in place by the producing kernels: the batched weight
         # gradient reads them as one [Tm*N,...] tensor (no concatenation).  gate_in[0][t] = spike entering step t.
         keep = need_grad and d_gate
+        # Step 0 of the gate stack.  The spike entering it is the constant 0 for every sample, so gate_conv(0) is ONE image (bias terms and
+        # border effects) shared by the whole batch: computed on one zero image and broadcast, and its backward runs once on the gradient
+        # summed over the batch (the stack is linear in its output gradient given the shared input) -- two N-image convolutions, one
+        # N-image input gradient and a quarter of the batched weight-gradient work less.  EAS_ARSNN_STEP0=full: development switch.
+        fast0 = bool(d_gate) and Tm > 0 and _CONV_SINK is None and os.environ.get('EAS_ARSNN_STEP0', 'shared') != 'full'
         if keep:
             gate_in = [torch.empty((Tm, N, pg[2 * i].shape[1], H, W), device=dev) for i in range(d_gate)]
-            gate_in[0][0].zero_()
+            if not fast0:
+                gate_in[0][0].zero_()
             spike = gate_in[0][0]
         else:
             gate_in = None
-            spike = torch.zeros(shape, device=dev)
+            spike = None if fast0 else torch.zeros(shape, device=dev)
         seg = torch.empty(shape, dtype=torch.int32, device=dev)
         tl = torch.empty(shape, dtype=torch.int32, device=dev)
         if Tm == 0 or v is not None:
@@ -1077,7 +1083,10 @@ class _ARSNNFn(torch.autograd.Function):
         for t in range(Tm):
             if _CONV_SINK is not None and d_gate:
                 _CONV_SINK.sampler_spikes.append(spike)
-            if d_gate:
+            if d_gate and t == 0 and fast0:
+                R1, g_ins = _conv_stack_fwd(torch.zeros((1,) + shape[1:], device=dev), pg, k)         # one image
+                R = R1.expand(N, *R1.shape[1:]).contiguous()
+            elif d_gate:
                 R, g_ins = _conv_stack_fwd(spike, pg, k, [gate_in[i + 1][t] for i in range(d_gate - 1)] if keep else None)
             else:
                 R, g_ins = zero_rec, []
@@ -1107,6 +1116,7 @@ class _ARSNNFn(torch.autograd.Function):
             pre_relu = out
             out = torch.relu(out)
         ctx.cfg = cfg
+        ctx.fast0 = fast0
         ctx.dims = (Tm, N, Cin, C2, H, W)
         # ``agg`` is this node's own output unless ``running``: keeping it on ctx would tie output -> grad_fn -> ctx -> output
         # into a reference cycle (Ts*N*C2*H*W floats held until the cyclic GC runs); the backward reads it in running mode only
@@ -1158,15 +1168,30 @@ class _ARSNNFn(torch.autograd.Function):
             g_v, g_vs = g_vp, g_vsp
             g = gX[t]
             for i in range(d_gate - 1, -1, -1):           # g = gradient at the output of gate conv i = g_stage[i][t]
-                if i == 0 and t == 0:
-                    break                      # spike input of step 0 is the constant 0
+                if t == 0 and (i == 0 or ctx.fast0):
+                    break                      # spike input of step 0 is the constant 0 (fast0: the whole step-0 stack is done below)
                 # ReLU in front of conv i fused as a mask
                 g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None, out=g_stage[i - 1][t] if i > 0 else None)
             g_spike = g if (t > 0 and d_gate) else None
         grads_g = []
+        t0 = 1 if ctx.fast0 else 0
         for i in range(d_gate):
-            gw, gb = smallconv_bwd_weight(g_stage[i].flatten(0, 1), gate_in[i].flatten(0, 1), pg[2 * i])
+            if Tm > t0:
+                gw, gb = smallconv_bwd_weight(g_stage[i][t0:].flatten(0, 1), gate_in[i][t0:].flatten(0, 1), pg[2 * i])
+            else:
+                gw, gb = torch.zeros_like(pg[2 * i]), torch.zeros_like(pg[2 * i + 1])
             grads_g += [gw, gb]
+        if ctx.fast0:
+            # step 0: the stack's input is the same zero image for every sample, so its parameter gradients are those of ONE image
+            # with the output gradient summed over the batch
+            g1 = gX[0].sum(0, keepdim=True)
+            g_ins0 = saved[0][0]
+            for i in range(d_gate - 1, -1, -1):
+                gw, gb = smallconv_bwd_weight(g1, g_ins0[i], pg[2 * i])
+                grads_g[2 * i] = grads_g[2 * i] + gw
+                grads_g[2 * i + 1] = grads_g[2 * i + 1] + gb
+                if i > 0:
+                    g1 = smallconv_bwd_input(g1, pg[2 * i], g_ins0[i])
         # input conv stack, all Tm steps at once
         grads_in = [None] * (2 * d_in)
         g = gX.view(Tm * N, 2 * C2, H, W)

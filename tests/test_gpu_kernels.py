@@ -822,6 +822,32 @@ def test_arsnn_golden(dev, name):
     assert nbad <= ARSNN_MAX_FLIPS.get(name, 0), f'{name}: {nbad} output elements differ (expected at most {ARSNN_MAX_FLIPS.get(name, 0)})'
 
 
+def test_sampler_step0_gate_stack_shared_by_the_batch(dev, monkeypatch):
+    """Step 0 of the adaptive sampler's gate stack sees the constant-zero spike for every sample: computed on ONE zero image and broadcast,
+    backward once on the batch-summed gradient (ops._ARSNNFn fast0) -- against the per-sample computation (EAS_ARSNN_STEP0=full): outputs
+    and last-spike records bit-identical, parameter gradients equal to rounding (the batch sum moves in front of the convolutions)."""
+    from eas_snn_amd import ops
+    torch.manual_seed(4)
+    Tm, N, H, W = 4, 6, 32, 48
+    ev = torch.poisson(torch.full((Tm, N, 2, H, W), 0.4)).to(dev)
+    pin = [(torch.randn(4, 2, 5, 5) * 0.3), torch.randn(4) * 0.1, torch.randn(4, 4, 5, 5) * 0.2, torch.randn(4) * 0.1]
+    pg = [(torch.randn(4, 2, 5, 5) * 0.3), torch.randn(4) * 0.1, torch.randn(4, 4, 5, 5) * 0.2, torch.randn(4) * 0.1]
+    go = torch.randn(3, N, 2, H, W).to(dev)
+    res = []
+    for mode in ('full', 'shared'):
+        monkeypatch.setenv('EAS_ARSNN_STEP0', mode)
+        a = [p.clone().to(dev).requires_grad_(True) for p in pin]
+        b = [p.clone().to(dev).requires_grad_(True) for p in pg]
+        out, rec = ops.arsnn_forward(ev, a, b, 5, 3, 'sum', True, True, False, 1.0, 0.0, record=True)
+        (out * go).sum().backward()
+        res.append((out.detach().clone(), rec.clone(), [p.grad.clone() for p in a + b]))
+    (o0, r0, g0), (o1, r1, g1) = res
+    assert torch.equal(o0, o1) and torch.equal(r0, r1) and float(o0.abs().sum()) > 0
+    for x, y in zip(g0, g1):
+        assert float(x.abs().max()) > 0
+        torch.testing.assert_close(y, x, rtol=2e-4, atol=2e-5 * float(x.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------------ sampler convs
 @pytest.mark.parametrize('cin,cout,k,N,H,W', [(2, 4, 5, 3, 32, 64), (4, 4, 5, 2, 48, 80), (2, 4, 7, 2, 20, 36), (4, 4, 3, 1, 16, 64),
                                                (2, 2, 5, 2, 17, 30), (4, 4, 7, 1, 256, 320), (2, 4, 3, 5, 33, 130), (4, 4, 5, 2, 37, 250)])
