@@ -713,6 +713,52 @@ def gen_models():
               f'finite {bool(torch.isfinite(logits).all())}')
 
 
+def gen_model_train_m():
+    """BASELINE configs[2] shaped train step (SYOLOX-M, full_spike_v2, T=5, RPD) of the UNMODIFIED reference classes on a 64x96 canvas:
+    losses, the norm of every parameter gradient, every small gradient in full and a strided sample (<= 1024 elements) of every
+    gradient for the elementwise comparison in tests/test_gpu_model.py::test_model_train_step_golden."""
+    from yolox.exp import get_exp
+    from spikingjelly.activation_based import functional
+    from oracle.fill import ANN_KEYS, poisson_events, procedural_fill_
+    name, us, (B, H, W) = 'model_m_fullv2_t5_64x96_train', 'full_spike_v2', (2, 64, 96)
+    exp = get_exp(None, 'e-yolox-m')
+    exp.merge(['T', '5', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
+               'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True', 'spike_fn', 'atan', 'use_spike', us])
+    torch.manual_seed(80)
+    model = exp.get_model()
+    crc = procedural_fill_(model, conv_gain=2.0, ann_regex=ANN_KEYS[us])
+    x = torch.from_numpy(poisson_events((B, 1, exp.Tm, 2, H, W), 0.5, seed=zlib.crc32(name.encode()) % 1000))
+    tg = torch.zeros(B, 50, 5)
+    for b in range(B):
+        tg[b, 0] = torch.tensor([0, W * 0.3, H * 0.4, W * 0.25, H * 0.3])
+        tg[b, 1] = torch.tensor([1, W * 0.7, H * 0.6, W * 0.2, H * 0.35])
+    model.train()
+    model.head.use_l1 = True
+    out = model(x, tg)
+    out['total_loss'].backward()
+    functional.reset_net(model)
+    arrays = dict(x=_np(x), targets=_np(tg), crc=np.uint32(crc), keys=np.array(list(model.state_dict().keys())), gain=np.float32(2.0))
+    for k in ('total_loss', 'iou_loss', 'l1_loss', 'conf_loss', 'cls_loss'):
+        arrays[f'loss/{k}'] = np.float32(float(out[k]))
+    arrays['loss/num_fg'] = np.float32(out['num_fg'])
+    gn = {}
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        g = p.grad.detach().reshape(-1)
+        gn[n] = float(g.norm())
+        if g.numel() <= 1024:
+            arrays[f'grad/{n}'] = _np(p.grad)
+        else:
+            arrays[f'gradsample/{n}'] = _np(g[::g.numel() // 1024][:1024])
+    arrays['gradnorm_keys'] = np.array(list(gn))
+    arrays['gradnorm_vals'] = np.array(list(gn.values()), np.float32)
+    for n, b in model.named_buffers():
+        if n.endswith('running_mean') and ('dark2' in n or 'dark5' in n or 'head.stems' in n):
+            arrays[f'buf/{n}'] = _np(b)
+    save(name, **arrays)
+    print(f'    {name}: loss {float(out["total_loss"]):.5f}, {len(gn)} parameter gradients')
+
+
 def main():
     torch.set_num_threads(8)
     setup_reference_imports()
@@ -720,7 +766,7 @@ def main():
     for w in which:
         print(f'[{w}]')
         {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
-         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy, 'window': gen_window_search}[w]()
+         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy, 'window': gen_window_search, 'model_train_m': gen_model_train_m}[w]()
     assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
 
 
