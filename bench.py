@@ -162,15 +162,37 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _visible_gpus():
+    """GPUs this process may use, counted WITHOUT the HIP runtime (torch.cuda.device_count() may run hipInit in the parent, which must
+    not hold the GPU when it starts its children): the visibility variables if set, else the KFD topology (nodes with SIMDs are
+    GPUs).  None when neither is readable -- then the children report a missing device themselves."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(',') if t.strip() != ''])
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as fh:
+                for ln in fh:
+                    if ln.startswith('simd_count') and int(ln.split()[1]) > 0:
+                        n += 1
+        return n
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def launch_ranks(args):
-    """Start one child process per GPU and wait for them.  Runs BEFORE anything in this process touches the GPU (counting devices
-    does not initialise it); the children are fresh interpreters, never an exec of a process that holds the GPU.  Rank 0's JSON
-    line reaches stdout through the inherited descriptor.  Returns the exit code (non-zero when any rank failed)."""
+    """Start one child process per GPU and wait for them.  Runs BEFORE anything in this process touches the GPU (devices are counted
+    from the environment / sysfs, not through the HIP runtime); the children are fresh interpreters, never an exec of a process that
+    holds the GPU.  Rank 0's JSON line reaches stdout through the inherited descriptor.  Returns the exit code (non-zero when any
+    rank failed)."""
     import subprocess
     n = args.gpus
     if not args.selftest_cpu:
-        have = torch.cuda.device_count()
-        if have < n:
+        have = _visible_gpus()
+        if have is not None and have < n:
             print(f'bench.py: --gpus {n} but only {have} GPU(s) visible', file=sys.stderr)
             return 2
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')

@@ -67,7 +67,7 @@ class Trainer:
     def train(self):
         self.before_train()
         # every iteration ends with reset_net, so the final membrane potentials never need to reach HBM (scoped: restored on exit)
-        with ops.no_state_writeback() if self.exp.use_spike else contextlib.nullcontext():
+        with ops.no_state_writeback() if self.exp.use_spike not in (False, 'False') else contextlib.nullcontext():
             self._train_epochs()
 
     def _train_epochs(self):
@@ -87,7 +87,7 @@ class Trainer:
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()
-        if self.exp.use_spike:
+        if self.exp.use_spike not in (False, 'False'):
             functional.reset_net(self.model)
         if self.use_model_ema:
             self.ema_model.update(self.model)

@@ -137,14 +137,20 @@ class YOLOXHead(nn.Module):
                 if self.use_l1:
                     origin_preds.append(reg_out.flatten(2).permute(0, 2, 1))
             else:
-                out = torch.cat([reg_out, obj_out.sigmoid(), cls_out.sigmoid()], 1)
+                out = (reg_out, obj_out, cls_out)
             outputs.append(out)
         if self.training:
             return self.get_losses(torch.cat(grids, 1), torch.cat(strides, 1), labels, torch.cat(outputs, 1),
                                    torch.cat(origin_preds, 1) if self.use_l1 else None)
+        return self.assemble_eval(outputs)
+
+    def assemble_eval(self, raws):
+        """inference output [B, A, 5 + num_classes] from the per-level raw maps (reg, obj, cls): sigmoid on objectness / classes,
+        levels concatenated along the anchors, boxes decoded (yolo_head.py:187-199 of the reference)"""
+        outputs = [torch.cat([reg_out, obj_out.sigmoid(), cls_out.sigmoid()], 1) for reg_out, obj_out, cls_out in raws]
         self.hw = [o.shape[-2:] for o in outputs]
         out = torch.cat([o.flatten(start_dim=2) for o in outputs], dim=2).permute(0, 2, 1)
-        return self.decode_outputs(out, dtype=xin[0].type()) if self.decode_in_inference else out
+        return self.decode_outputs(out, dtype=out.type()) if self.decode_in_inference else out
 
     def decode_outputs(self, outputs, dtype=None):
         grids, strides = [], []

@@ -15,7 +15,6 @@ import torch.nn as nn
 
 from spikingjelly.activation_based import layer, neuron
 
-_STATELESS = (nn.Conv2d, nn.Upsample, nn.MaxPool2d)
 _ANN_ACTIVATIONS = (nn.ReLU, nn.SiLU, nn.LeakyReLU)
 
 
@@ -31,12 +30,15 @@ def _plif(spike_fn):
 def _replacement(name, child, spike_fn):
     """the module that takes ``child``'s place, or None when the child is to be descended into"""
     from yolox.models.network_blocks import Focus
-    if isinstance(child, Focus) or isinstance(child, _STATELESS):
+    # rule order as in the reference (utils_snn.py:23-56): the name rule for '*act' children comes before the MaxPool2d rule
+    if isinstance(child, Focus) or isinstance(child, (nn.Conv2d, nn.Upsample)):
         return layer.SeqToANNContainer(child)
     if isinstance(child, nn.BatchNorm2d):
         return layer.BatchNorm2d(child.num_features, child.eps, child.momentum, step_mode='m')
     if name.endswith('act') or isinstance(child, _ANN_ACTIVATIONS):
         return _plif(spike_fn)
+    if isinstance(child, nn.MaxPool2d):
+        return layer.SeqToANNContainer(child)
     return None
 
 

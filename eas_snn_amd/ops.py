@@ -291,7 +291,7 @@ def _coop_ptr(device, channels):
 CONV_STATS = os.environ.get('EAS_CONV_STATS', '1') == '1'
 CONV_STATS_MAX_BLOCKS = int(os.environ.get('EAS_CONV_STATS_MAX_BLOCKS', '4096'))     # partials per channel the consumers still add cheaply
 _WANT_CONV_STATS = False
-_CONV_STATS_SLOT = None          # (y [NI,Cout,Ho,Wo], nb, stats [Cout*nb*2] fp64)
+_CONV_STATS_SLOT = None          # (y [NI,Cout,Ho,Wo], nb, stats [Cout*nb*2] fp64, y._version)
 _STATS_BLOCKS = {}
 
 
@@ -324,12 +324,18 @@ def _take_conv_stats(base_ptr, count, Ctot, keep=False):
     slot = _CONV_STATS_SLOT
     if slot is None:
         return None
-    y, nb, stats = slot
+    y, nb, stats, ver = slot
     if not keep:
         _CONV_STATS_SLOT = None
-    if y.data_ptr() != base_ptr or y.shape[1] != Ctot or y.shape[0] * y.shape[2] * y.shape[3] != count:
-        return None
+    if y.data_ptr() != base_ptr or y.shape[1] != Ctot or y.shape[0] * y.shape[2] * y.shape[3] != count or y._version != ver:
+        return None                    # another tensor, or y was modified in place since the convolution summed it
     return stats, nb
+
+
+def clear_conv_stats():
+    """drop a convolution's tile sums nobody consumed (end of a model forward: the slot must not pin tensors across steps)"""
+    global _CONV_STATS_SLOT
+    _CONV_STATS_SLOT = None
 
 
 def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=None, y_ctot=0, keep_slot=False):
@@ -1303,7 +1309,7 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
             stats = torch.empty(Cout * nb * 2, dtype=torch.float64, device=x.device)
             _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd_stats, ptr(x), ptr(packed), ptr(y), NI, Cin, Cout, Hi, Wi,
                   ksize, stride, x_terms, None, ptr(stats), nb, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
-            _CONV_STATS_SLOT = (y, nb, stats)
+            _CONV_STATS_SLOT = (y, nb, stats, y._version)
             return y
     _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
           ksize, stride, x_terms, None, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
@@ -1320,7 +1326,7 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
 # pending is reduced first), any call outside a backward pass.  DistributedDataParallel with copy hooks reads gradients inside the
 # pass: leave the switch off there.  Same summation order either way: bit-identical gradients.
 DEFER_WGRAD_REDUCE = os.environ.get('EAS_DEFER_WGRAD_REDUCE', '0') == '1'
-_PENDING_REDUCE = []          # (workspace tensor kept alive, grad_w data_ptr, numel, slab count, weight data_ptr)
+_PENDING_REDUCE = []          # (slab workspace kept alive, grad_w address, numel, slab count, weight parameter)
 
 
 class deferred_wgrad_reductions:
@@ -1333,34 +1339,58 @@ class deferred_wgrad_reductions:
         global DEFER_WGRAD_REDUCE
         self.prev, DEFER_WGRAD_REDUCE = DEFER_WGRAD_REDUCE, self.flag
 
-    def __exit__(self, *exc):
-        global DEFER_WGRAD_REDUCE
+    def __exit__(self, exc_type, *exc):
+        global DEFER_WGRAD_REDUCE, _PENDING_REDUCE
         DEFER_WGRAD_REDUCE = self.prev
+        if exc_type is not None:
+            # the backward pass did not finish: the gradient tensors of the pending jobs may already be gone (their addresses are all
+            # that is kept) -- nothing is written, the jobs are dropped
+            _PENDING_REDUCE = []
+            return
         _flush_wgrad_reductions()
 
 
 def _flush_wgrad_reductions():
+    """Reduce every pending slab set into its gradient tensor in ONE launch.  A job is only valid while the tensor handed to autograd is
+    still the parameter's ``.grad`` (AccumulateGrad adopted it, nothing has been added to it in place): anything else means the
+    deferral was switched on for a backward pass it is not sound for, and fails loudly instead of writing through a stale address."""
     global _PENDING_REDUCE
     jobs, _PENDING_REDUCE = _PENDING_REDUCE, []
     if not jobs:
         return
+    for ws, gptr, gn, n, w in jobs:
+        g = w.grad
+        if g is None or g.data_ptr() != gptr or g.numel() != gn or g._version != 0:
+            raise _lib.EasHipError(
+                'deferred_wgrad_reductions: a weight gradient handed to autograd is not (or no longer exclusively) the parameter\'s .grad '
+                '-- gradient hooks, create_graph, a second consumer of the weight or a non-contiguous weight; run this backward pass '
+                'without the deferral (the unreduced buffer was NOT written)')
     arr = (_lib.EasWgradReduceJob * len(jobs))(*[_lib.EasWgradReduceJob(ws.data_ptr(), gptr, gn, n) for ws, gptr, gn, n, _ in jobs])
     t0 = _timer_mark()
     check(_lib.lib().eas_conv_wgrad_reduce_many(arr, len(jobs), stream()), 'eas_conv_wgrad_reduce_many')
     _timer_add('eas_conv_wgrad', t0, 0)
 
 
-def _wgrad_finish(ws, gw, nslabs, defer, wkey=None):
+def _can_defer(w):
+    """the slab reduction of this weight's gradient may wait for the end of the backward pass: the gradient tensor returned now will be
+    adopted as ``w.grad`` by AccumulateGrad as it is (leaf without a gradient yet, plain backward without create_graph, no tensor
+    hooks that could read or replace it, the layout autograd expects)"""
+    return (DEFER_WGRAD_REDUCE and w.is_leaf and w.grad is None and not torch.is_grad_enabled() and not w._backward_hooks
+            and not getattr(w, '_post_accumulate_grad_hooks', None) and w.is_contiguous())
+
+
+def _wgrad_finish(ws, gw, nslabs, defer, w=None):
     """reduce the slabs in ``ws`` into ``gw``: now, or together with the other weight gradients at the end of the backward pass.
-    Only the ADDRESS of ``gw`` is kept: autograd must stay the sole owner of the tensor so that AccumulateGrad adopts it as the
-    parameter's ``.grad`` instead of cloning it (a clone would be taken before the reduction has run)."""
-    if defer and wkey is not None and any(j[4] == wkey for j in _PENDING_REDUCE):
+    Only the ADDRESS of ``gw`` is kept (plus the parameter it belongs to): autograd must stay the sole owner of the tensor so that
+    AccumulateGrad adopts it as the parameter's ``.grad`` instead of cloning it (a clone would be taken before the reduction has
+    run); ``_flush_wgrad_reductions`` checks that this is what happened before it writes."""
+    if defer and w is not None and any(j[4] is w for j in _PENDING_REDUCE):
         _flush_wgrad_reductions()           # a second contribution to the same weight: autograd adds the two as soon as this returns
         defer = False
-    if defer:
+    if defer and w is not None:
         if not _PENDING_REDUCE:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_reductions)
-        _PENDING_REDUCE.append((ws, gw.data_ptr(), gw.numel(), int(nslabs), wkey))
+        _PENDING_REDUCE.append((ws, gw.data_ptr(), gw.numel(), int(nslabs), w))
     else:
         arr = (_lib.EasWgradReduceJob * 1)(_lib.EasWgradReduceJob(ws.data_ptr(), gw.data_ptr(), gw.numel(), int(nslabs)))
         check(_lib.lib().eas_conv_wgrad_reduce_many(arr, 1, stream()), 'eas_conv_wgrad_reduce_many')
@@ -1381,7 +1411,7 @@ def _partial_call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     return rc
 
 
-def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False, wkey=None):
+def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False, w=None):
     """grad_w [Cout,Cin,k,k] of conv2d(x, w, stride, padding k//2) given grad_y, on the matrix cores (deterministic).
     x_u8: byte copy of a spike tensor (1x1 only): read instead of x."""
     _dev(gy)
@@ -1398,7 +1428,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False, wkey=None)
         fl = 2.0 * gy.numel() * Cin
         ns = _partial_call('eas_conv_wgrad', x_u8.numel() + 4 * gy.numel(), L.eas_conv_wgrad_u8_partial, ptr(x_u8), ptr(gy), ptr(ws), NI, Cin, Cout,
                            Hi, Wi, 1, stream(), flops=fl, issue_flops=fl * 3)
-        _wgrad_finish(ws, gw, ns, defer, wkey)
+        _wgrad_finish(ws, gw, ns, defer, w)
         return gw
     _dev(x)
     x = _f32c(x)
@@ -1413,7 +1443,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False, wkey=None)
     fl = 2.0 * gy.numel() * Cin * ksize * ksize
     ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
                        ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
-    _wgrad_finish(ws, gw, ns, defer, wkey)
+    _wgrad_finish(ws, gw, ns, defer, w)
     return gw
 
 
@@ -1517,7 +1547,7 @@ class _ConvFn(torch.autograd.Function):
             except _lib.EasHipError:        # no tile for this width (checked before anything is launched): library input gradient
                 gx = None
         if own_w:
-            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8, defer=DEFER_WGRAD_REDUCE and w.is_leaf and w.grad is None, wkey=w.data_ptr())
+            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8, defer=_can_defer(w), w=w)
         need_d = ctx.needs_input_grad[0] and not own_d
         need_w = ctx.needs_input_grad[1] and not own_w
         if need_d or need_w:
@@ -1679,6 +1709,8 @@ class packed_weights:
     def __exit__(self, *exc):
         global _PACK_SCOPE
         _PACK_SCOPE = self.prev
+        if self.prev is None:
+            clear_conv_stats()
 
 
 # Statistics tap (eas_snn_amd/stats.py): when set, every convolution input of the model is shown to it before the

@@ -42,9 +42,13 @@ class FlatGradAllReduce:
         if self.flat is None:
             self.flat = torch.empty(sum(self.sizes), dtype=grads[0].dtype, device=grads[0].device)
             self.views = [c.view_as(p) for c, p in zip(self.flat.split(self.sizes), self.params)]
-        if grads[0].data_ptr() == self.views[0].data_ptr():
-            return                                   # gradients were accumulated into the attached views: already packed
-        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+        stray = [i for i, (g, v) in enumerate(zip(grads, self.views)) if g.data_ptr() != v.data_ptr()]
+        if not stray:
+            return                                   # every gradient was accumulated into its attached view: already packed
+        if len(stray) == len(grads):
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+        else:                                        # a mix (partial zero_grad / partial backward): copy the ones that live elsewhere
+            torch._foreach_copy_([self.views[i] for i in stray], [grads[i] for i in stray])
 
     def reduce(self):
         """ONE all-reduce of the flat buffer, then the 1/world scale (SUM + scale: every backend has it, gloo has no AVG)"""

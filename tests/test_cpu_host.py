@@ -324,20 +324,26 @@ def test_sampler_split_option_builds_the_reference_parameter_set():
 def test_convolution_statistics_slot_is_only_taken_by_the_tensor_it_belongs_to():
     """Host logic of the conv -> BN hand-over (ops.conv_stats_scope, ops._take_conv_stats): the statistics of a convolution are used
     only by a BN call on exactly that output (same storage address, channel count and element count per channel), a first of two
-    consumers may leave them in place, anything else gets None and clears the slot -- a BN on an unrelated tensor falls back to its own
+    consumers may leave them in place, anything else (another tensor, an output modified in place since) gets None and clears the slot -- a BN on an unrelated tensor falls back to its own
     statistics pass."""
     from eas_snn_amd import ops
     y = torch.zeros(6, 8, 4, 5)
     stats = torch.zeros(8 * 3 * 2, dtype=torch.float64)
     try:
-        ops._CONV_STATS_SLOT = (y, 3, stats)
+        ops._CONV_STATS_SLOT = (y, 3, stats, y._version)
         assert ops._take_conv_stats(y.data_ptr(), 6 * 20, 8, keep=True) == (stats, 3)      # first consumer of a pair
         assert ops._take_conv_stats(y.data_ptr(), 6 * 20, 8) == (stats, 3)                 # second one clears
         assert ops._CONV_STATS_SLOT is None and ops._take_conv_stats(y.data_ptr(), 6 * 20, 8) is None
         other = torch.zeros(6, 8, 4, 5)
         for args in ((other.data_ptr(), 6 * 20, 8), (y.data_ptr(), 6 * 20, 4), (y.data_ptr(), 3 * 20, 8)):
-            ops._CONV_STATS_SLOT = (y, 3, stats)
+            ops._CONV_STATS_SLOT = (y, 3, stats, y._version)
             assert ops._take_conv_stats(*args) is None and ops._CONV_STATS_SLOT is None
+        ops._CONV_STATS_SLOT = (y, 3, stats, y._version)
+        y.add_(1.0)                                                                         # modified in place after the convolution summed it
+        assert ops._take_conv_stats(y.data_ptr(), 6 * 20, 8) is None and ops._CONV_STATS_SLOT is None
+        ops._CONV_STATS_SLOT = (y, 3, stats, y._version)
+        ops.clear_conv_stats()                                                              # end of a model forward: nothing stays pinned
+        assert ops._CONV_STATS_SLOT is None
         with ops.conv_stats_scope(True):
             assert ops._WANT_CONV_STATS == ops.CONV_STATS
             with ops.conv_stats_scope(False):

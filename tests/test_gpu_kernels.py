@@ -671,13 +671,17 @@ def test_bn_lif_fused_vs_oracle(dev, T, N, C, H, W, train):
     hr = zr.detach().numpy()
     flips = sh.detach().cpu().numpy() != sr.detach().numpy()
     assert flips.mean() < 1e-3
-    if flips.any():
-        pytest.skip('threshold-rounding spike flip in this draw; gradients not comparable')
-    np.testing.assert_allclose(hnode.v.cpu().numpy(), rnode.v.detach().numpy(), rtol=RTOL, atol=2e-5)
-    np.testing.assert_allclose(yh.grad.cpu().numpy(), yr.grad.numpy(), rtol=2e-3, atol=2e-5)
-    np.testing.assert_allclose(hbn.weight.grad.cpu().numpy(), rbn.weight.grad.numpy(), rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(hbn.bias.grad.cpu().numpy(), rbn.bias.grad.numpy(), rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(hnode.w.grad.item(), rnode.w.grad.item(), rtol=2e-3, atol=1e-4)
+    # a neuron whose spike train flipped (rounding at the threshold) is left out of the elementwise comparisons -- the recurrence is per
+    # neuron, so every other neuron's potential and grad_y must still match; the per-channel / scalar gradients get one neuron's worth
+    # of slack per flip (a flipped step changes dz of that neuron by at most |g| * max surrogate slope over the T steps)
+    same = np.broadcast_to(~flips.any(axis=0), flips.shape)
+    nflip = int(flips.any(axis=0).sum())
+    slack = nflip * T * float(np.abs(g_np).max()) * 2.0
+    np.testing.assert_allclose(hnode.v.cpu().numpy()[same[0]], rnode.v.detach().numpy()[same[0]], rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(yh.grad.cpu().numpy()[same], yr.grad.numpy()[same], rtol=2e-3, atol=2e-5 + (1e-3 if nflip else 0.0))
+    np.testing.assert_allclose(hbn.weight.grad.cpu().numpy(), rbn.weight.grad.numpy(), rtol=2e-3, atol=2e-4 + slack)
+    np.testing.assert_allclose(hbn.bias.grad.cpu().numpy(), rbn.bias.grad.numpy(), rtol=2e-3, atol=2e-4 + slack)
+    np.testing.assert_allclose(hnode.w.grad.item(), rnode.w.grad.item(), rtol=2e-3, atol=1e-4 + slack)
     np.testing.assert_allclose(hbn.running_mean.cpu().numpy(), rbn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(hbn.running_var.cpu().numpy(), rbn.running_var.numpy(), rtol=1e-5, atol=1e-6)
     assert int(hbn.num_batches_tracked) == int(rbn.num_batches_tracked)

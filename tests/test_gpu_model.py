@@ -111,7 +111,8 @@ def test_model_logits_golden(dev, name):
         # ~3 M neuron-steps per layer: a handful of neurons sit within conv rounding error of v_th, and the spiking
         # backbone amplifies every flip (chaotic cascade), so end-to-end bit parity at this size is not attainable by
         # ANY conv that sums in another order than ATen-CPU.  Parity at this size is asserted layer by layer with
-        # oracle inputs (test_layerwise_teacher_forced_parity_256x320); here only sanity of the bulk statistics.
+        # oracle inputs (test_layerwise_teacher_forced_parity_256x320: the spiking backbone; test_neck_and_head_teacher_forced_every_logit:
+        # the real-valued neck + head, EVERY logit at 1e-4); end to end only the bulk statistics can be asserted.
         assert abs(np.median(got[..., 4]) - np.median(ref[..., 4])) < 0.05 and abs(got[..., 2:4].mean() / ref[..., 2:4].mean() - 1) < 0.1
         return
     assert frac > 0.97
@@ -179,6 +180,33 @@ def _teacher_forced(dev, exp_name, cfg, shape, train, max_flip=2e-5):
         return f
     names = [n for n, m in ref.named_modules() if isinstance(m, model_ref.BaseConv) and isinstance(getattr(m, 'act', None), sj_ref.BaseNode)]
     hooks = [ref.get_submodule(n).register_forward_hook(mk(n)) for n in names]
+    # the prediction convolutions (reg / obj / cls of every level; no neuron behind them, so no flip excuse): the oracle's input in, EVERY
+    # output element within 1e-4 (relative + 1e-4 of the map's largest value); their outputs are kept for the decode check below
+    raws = {}
+    stats['pred_worst'] = 0.0
+
+    def mkpred(kind, k):
+        hm = getattr(hip.head, f'{kind}_preds')[k]
+
+        def f(mod, inp, out):
+            from yolox.models.yolo_head import _pred
+            xd = inp[0].detach().to(dev)
+            if float(xd.abs().max()) <= 16 and bool((xd == xd.round()).all()):
+                ops.mark_small_int(xd)
+            with torch.no_grad():
+                got = _pred(hm, xd)
+            want = out.detach()
+            if want.dim() == 5:                         # converted head (full_spike_v2): mean current over T (spiking_yolo_head.py:175-178)
+                got, want = ops.time_mean(got), want.mean(0)
+            raws[(kind, k)] = want
+            g, w = got.cpu().numpy(), want.numpy()
+            err = np.abs(g - w) / (RTOL * np.abs(w) + RTOL * max(float(np.abs(w).max()), 1e-6))
+            stats['pred_worst'] = max(stats['pred_worst'], float(err.max()))
+            assert err.max() <= 1.0, f'{kind}_preds[{k}]: worst element {err.max():.2f} x the 1e-4 tolerance'
+        return f
+    for k in range(3):
+        for kind in ('reg', 'obj', 'cls'):
+            hooks.append(getattr(ref.head, f'{kind}_preds')[k].register_forward_hook(mkpred(kind, k)))
     x = torch.from_numpy(fill.poisson_events(shape, 0.5, seed=3))
     with torch.no_grad():
         if train:
@@ -186,14 +214,19 @@ def _teacher_forced(dev, exp_name, cfg, shape, train, max_flip=2e-5):
             tg[:, 0] = torch.tensor([0, 0.3 * W, 0.4 * H, 0.25 * W, 0.3 * H])
             ref(x, tg)
         else:
-            ref(x)
+            want_logits = ref(x)
     for h in hooks:
         h.remove()
     sj_ref.reset_net(ref)
-    assert stats['layers'] == len(names)
+    assert stats['layers'] == len(names) and len(raws) == 9
+    if not train:
+        # decode (sigmoid, level concatenation, grid / stride arithmetic, exp) on the oracle's raw maps: every output element
+        with torch.no_grad():
+            got = hip.head.assemble_eval([tuple(raws[(kind, k)].to(dev) for kind in ('reg', 'obj', 'cls')) for k in range(3)]).cpu().numpy()
+        np.testing.assert_allclose(got, want_logits.numpy(), rtol=RTOL, atol=RTOL)
     print(f"teacher-forced {exp_name} {cfg.get('use_spike')} T={cfg.get('T', 3)} {H}x{W} {'train' if train else 'eval'}: {stats['layers']} layers, "
           f"{stats['flips']} spike flips in {stats['steps']} neuron-steps (worst layer {stats['worst_flip']:.2e}), worst membrane-potential "
-          f"rel err {stats['worst_v']:.2e}")
+          f"rel err {stats['worst_v']:.2e}; prediction convolutions: worst element at {stats['pred_worst']:.2f} of the 1e-4 tolerance")
     return stats
 
 
@@ -204,7 +237,185 @@ def test_layerwise_teacher_forced_parity_256x320(dev, train):
     assert st['layers'] == 34
 
 
+@pytest.mark.parametrize('train', [False, True])
+def test_neck_and_head_teacher_forced_every_logit(dev, train):
+    """BASELINE configs[1] at the benchmark canvas (SYOLOX-S, use_spike=True, 256x320, B=2): the real-valued PAFPN neck and the head,
+    fed the ORACLE's backbone outputs (firing rates of dark3 / dark4 / dark5).  Nothing behind that point is a neuron, so there is no
+    spike-flip excuse: EVERY logit [B, 1680, 7] of the eval forward (neck, towers, prediction convolutions, sigmoid, decode) must be
+    within 1e-4 (relative + absolute) of the oracle's; in train mode (batch-statistics BatchNorm) every raw prediction map and the
+    running statistics of every neck / head BatchNorm."""
+    from eas_snn_amd import ops
+    from oracle import fill, model_ref, sj_ref
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    H, W, B = 256, 320, 2
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(_exp_opts(dict(use_spike='True'), H, W))
+    hip = exp.get_model()
+    ref = model_ref.build_model(use_spike='True')
+    rx = fill.ANN_KEYS['True']
+    assert fill.procedural_fill_(hip, 2.0, ann_regex=rx) == fill.procedural_fill_(ref, 2.0, ann_regex=rx)
+    hip.to(dev).train(train); ref.train(train)
+    feats, raws = {}, {}
+    hooks = [ref.backbone.backbone.register_forward_hook(lambda m, i, o: feats.update({k: v.detach() for k, v in o.items()}))]
+    for k in range(3):
+        for kind in ('reg', 'obj', 'cls'):
+            hooks.append(getattr(ref.head, f'{kind}_preds')[k].register_forward_hook(
+                lambda m, i, o, key=(kind, k): raws.__setitem__(key, o.detach())))
+    x = torch.from_numpy(fill.poisson_events((B, 1, 4, 2, H, W), 0.5, seed=21))
+    with torch.no_grad():
+        if train:
+            tg = torch.zeros(B, 50, 5)
+            tg[:, 0] = torch.tensor([0, 0.3 * W, 0.4 * H, 0.25 * W, 0.3 * H])
+            ref(x, tg)
+        else:
+            want = ref(x).numpy()
+    for h in hooks:
+        h.remove()
+    sj_ref.reset_net(ref)
+    rates = [feats[f].mean(0).to(dev) for f in ('dark3', 'dark4', 'dark5')]        # spiking_yolo_pafpn.py:98
+    assert all(0.0 < float(r.mean()) < 1.0 for r in rates), 'the oracle backbone must fire for this test to mean something'
+    hip.backbone._features = lambda _x: rates                                       # the neck of the HIP model on the oracle's firing rates
+    with torch.no_grad(), ops.packed_weights(hip):
+        fpn = hip.backbone(None)
+        if not train:
+            got = hip.head(fpn).cpu().numpy()
+        else:
+            got_raws = [hip.head._level(k, hip.head._prepare(f)) for k, f in enumerate(fpn)]
+    del hip.backbone._features
+    functional.reset_net(hip)
+    if not train:
+        assert got.shape == want.shape == (B, 1680, 7)
+        err = np.abs(got - want) / (RTOL * np.abs(want) + RTOL)
+        print(f'neck + head on the oracle firing rates, eval: worst logit at {err.max():.3f} of the 1e-4 tolerance ({got.size} logits)')
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=RTOL)
+        return
+    worst = 0.0
+    for k in range(3):
+        for j, kind in enumerate(('reg', 'obj', 'cls')):
+            g, w = got_raws[k][j].cpu().numpy(), raws[(kind, k)].numpy()
+            worst = max(worst, float((np.abs(g - w) / (RTOL * np.abs(w) + RTOL)).max()))
+            np.testing.assert_allclose(g, w, rtol=RTOL, atol=RTOL, err_msg=f'{kind}[{k}]')
+    nbn = 0
+    rbufs = dict(ref.named_buffers())
+    for n, b in hip.named_buffers():
+        if (n.startswith('head.') or (n.startswith('backbone.') and not n.startswith('backbone.backbone.'))) and n.endswith(('running_mean', 'running_var')):
+            np.testing.assert_allclose(b.cpu().numpy(), rbufs[n].numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+            nbn += 1
+    assert nbn == 2 * 39          # 24 neck + 15 head BatchNorm layers
+    print(f'neck + head on the oracle firing rates, train-mode BN: worst raw prediction at {worst:.3f} of the 1e-4 tolerance, {nbn} running statistics')
+
+
+def _grad_close(got, want, what, rtol=5e-4, atol_rel=1e-5, mask=None, extra_atol=0.0):
+    """elementwise: |got - want| <= rtol * |want| + atol_rel * max|want| (+ extra); returns the worst element in units of that bound"""
+    got, want = got.astype(np.float64), want.astype(np.float64)
+    bound = rtol * np.abs(want) + atol_rel * max(float(np.abs(want).max()), 1e-30) + extra_atol
+    ratio = np.abs(got - want) / bound
+    if mask is not None:
+        ratio = ratio[mask]
+    worst = float(ratio.max()) if ratio.size else 0.0
+    assert worst <= 1.0, f'{what}: worst element {worst:.2f} x the tolerance (rtol {rtol}, atol {atol_rel} of max |g|)'
+    return worst
+
+
+def _teacher_forced_backward(dev, exp_name, cfg, shape, expect_layers):
+    """Backward of every spiking conv -> BN -> PLIF block in isolation, train mode (batch-statistics BatchNorm): the oracle model runs a
+    whole training step (forward, loss, backward) on the CPU; for every block its input x and the gradient that reached its output are
+    recorded, then the oracle block and the HIP block are each run on exactly that (x, grad_out): grad_x, grad of the convolution
+    weight, of gamma / beta and of the PLIF w are compared ELEMENTWISE (5e-4 relative + 1e-5 of the tensor's largest value; measured
+    on MI355X: the worst element of any block sits at 0.3 of that bound).  Where a
+    spike flipped (potential within rounding of the threshold), the 3x3 neighbourhood of the flipped pixels is left out of grad_x
+    and the parameter gradients get the flipped neurons' worth of slack."""
+    from eas_snn_amd import ops
+    from oracle import fill, model_ref, sj_ref
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    H, W = shape[-2:]
+    exp = get_exp(None, exp_name)
+    exp.merge(_exp_opts(cfg, H, W))
+    hip = exp.get_model()
+    ref = model_ref.build_model(**cfg)
+    rx = fill.ANN_KEYS[cfg['use_spike']]
+    assert fill.procedural_fill_(hip, 2.0, ann_regex=rx) == fill.procedural_fill_(ref, 2.0, ann_regex=rx)
+    hip.to(dev).train(); ref.train()
+    ref.head.use_l1 = True
+    names = [n for n, m in ref.named_modules() if isinstance(m, model_ref.BaseConv) and isinstance(getattr(m, 'act', None), sj_ref.BaseNode)]
+    rec = {}
+
+    def mk(name):
+        def f(mod, inp, out):
+            rec[name] = [inp[0].detach().clone(), None]
+            out.register_hook(lambda g: rec[name].__setitem__(1, g.detach().clone()))
+        return f
+    hooks = [ref.get_submodule(n).register_forward_hook(mk(n)) for n in names]
+    x = torch.from_numpy(fill.poisson_events(shape, 0.5, seed=5))
+    tg = torch.zeros(shape[0], 50, 5)
+    tg[:, 0] = torch.tensor([0, 0.3 * W, 0.4 * H, 0.25 * W, 0.3 * H])
+    tg[:, 1] = torch.tensor([1, 0.7 * W, 0.6 * H, 0.2 * W, 0.35 * H])
+    ref(x, tg)['total_loss'].backward()
+    for h in hooks:
+        h.remove()
+    sj_ref.reset_net(ref)
+    ref.zero_grad(set_to_none=True)
+    assert len(rec) == expect_layers and all(v[1] is not None for v in rec.values())
+    stats = dict(layers=0, flips=0, worst=0.0, worst_name='')
+    for name in names:
+        x_in, g_out = rec.pop(name)
+        rb, hb = ref.get_submodule(name), hip.get_submodule(name)
+        xr = x_in.clone().requires_grad_(True)
+        out_r = rb(xr)
+        out_r.backward(g_out)
+        sj_ref.reset_net(rb)
+        xh = x_in.to(dev)
+        if float(x_in.abs().max()) <= 16 and bool((x_in == x_in.round()).all()):
+            ops.mark_small_int(xh)
+        xh.requires_grad_(True)
+        out_h = hb(xh)
+        out_h = out_h[0] if isinstance(out_h, tuple) else out_h
+        out_h.backward(g_out.to(dev))
+        functional.reset_net(hb)
+        flips = (out_h.detach().cpu() != out_r.detach())
+        nflip = int(flips.sum())
+        assert nflip <= 4e-5 * flips.numel() + 1, f'{name}: {nflip} spike flips'
+        mask, slack = None, 0.0
+        if nflip:
+            # grad_x: a flipped output pixel reaches the input pixels under the kernel (and, at stride 2, their up-sampled positions);
+            # leave out a generous neighbourhood at every time step and channel
+            bad = flips.any(dim=2, keepdim=True).any(dim=0, keepdim=True).float()               # [1,N,1,Ho,Wo]
+            s_ = x_in.shape[-1] // out_r.shape[-1]
+            bad = torch.nn.functional.max_pool2d(bad[0], 5, 1, 2)
+            bad = torch.nn.functional.interpolate(bad, scale_factor=s_, mode='nearest') if s_ > 1 else bad
+            bad = torch.nn.functional.max_pool2d(bad, 2 * s_ + 1, 1, s_)
+            mask = np.broadcast_to(~bad.bool().numpy()[None], tuple(x_in.shape))
+            slack = nflip * float(g_out.abs().max()) * 4.0
+        w = _grad_close(xh.grad.cpu().numpy(), xr.grad.numpy(), f'{name} grad_x', mask=mask, extra_atol=1e-3 * float(xr.grad.abs().max()) if nflip else 0.0)
+        pr = dict(rb.named_parameters())
+        for pn, p in hb.named_parameters():
+            assert p.grad is not None and pr[pn].grad is not None, f'{name}.{pn}'
+            scale = float(x_in.abs().max()) if 'conv' in pn else 1.0
+            w = max(w, _grad_close(p.grad.cpu().numpy(), pr[pn].grad.numpy(), f'{name}.{pn}', extra_atol=slack * scale))
+        hb.zero_grad(set_to_none=True); rb.zero_grad(set_to_none=True)
+        stats['layers'] += 1; stats['flips'] += nflip
+        if w > stats['worst']:
+            stats['worst'], stats['worst_name'] = w, name
+    print(f"teacher-forced backward {exp_name} {cfg.get('use_spike')} T={cfg.get('T', 3)} {H}x{W}: {stats['layers']} blocks, {stats['flips']} spike flips, "
+          f"worst gradient element at {stats['worst']:.3f} of the tolerance ({stats['worst_name']})")
+    return stats
+
+
+def test_layerwise_teacher_forced_backward_256x320(dev):
+    """BASELINE configs[1] (SYOLOX-S, T=3, 256x320): backward of all 34 spiking blocks against the oracle, elementwise."""
+    st = _teacher_forced_backward(dev, 'e-yolox-s', dict(use_spike='True'), (1, 1, 4, 2, 256, 320), 34)
+    assert st['layers'] == 34
+
+
 M_WIDTH = dict(depth=0.67, width=0.75)
+
+
+def test_layerwise_teacher_forced_backward_m_t5_256x320(dev):
+    """BASELINE configs[2] (SYOLOX-M, full_spike_v2, T=5, 256x320): backward of all 97 spiking blocks (backbone, neck, head)."""
+    st = _teacher_forced_backward(dev, 'e-yolox-m', dict(M_WIDTH, use_spike='full_spike_v2', T=5, Tm=4, num_classes=2), (1, 1, 4, 2, 256, 320), 97)
+    assert st['layers'] == 97
 FULL_CANVAS_CASES = {
     # BASELINE configs[2]: SYOLOX-M, full_spike_v2, T=5, RPD, 256x320
     'cfg3_m_t5_256x320': ('e-yolox-m', dict(M_WIDTH, use_spike='full_spike_v2', T=5, Tm=4, num_classes=2), (1, 1, 4, 2, 256, 320)),
@@ -275,8 +486,19 @@ def test_sampler_parity_at_256x320(dev):
         assert rel < 2e-3 + 50 * bad.mean(), f'{n}: {rel:.2e}'
 
 
-@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64', 'model_s_true_patan_64'])
+MODELS['model_m_fullv2_t5_64x96_train'] = ('e-yolox-m', ['use_spike', 'full_spike_v2', 'T', '5'])
+USE_SPIKE['model_m_fullv2_t5_64x96_train'] = 'full_spike_v2'
+
+
+@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64', 'model_s_true_patan_64', 'model_m_fullv2_t5_64x96_train'])
 def test_model_train_step_golden(dev, name):
+    """One training step (loss terms, every parameter gradient) against the UNMODIFIED reference classes' step on the same input
+    (tests/golden/model_*.npz): losses, the norm of every gradient, and -- elementwise -- every gradient the fixture stores in full
+    (``grad/``: PLIF w, sampler, BN gamma, small tensors) or as a strided sample of <= 1024 elements (``gradsample/``, the M fixture:
+    SYOLOX-M full_spike_v2 T=5, BASELINE configs[2]'s model).  End to end a single rounding-level spike flip in the forward changes
+    every gradient behind it, so the elementwise bar is statistical here (the share of elements within
+    1e-3 relative + 2e-5 of the tensor's maximum); the per-block elementwise bar without that caveat is
+    test_layerwise_teacher_forced_backward_*."""
     from spikingjelly.activation_based import functional
     g, model = _build(name, dev)
     model.train()
@@ -295,6 +517,25 @@ def test_model_train_step_golden(dev, name):
     rel = np.array(rel)
     print(f'{name}: grad-norm rel err median {np.median(rel):.2e} max {rel.max():.2e}')
     assert np.median(rel) < 1e-3 and (rel < 5e-2).mean() > 0.95
+    params = dict(model.named_parameters())
+    ok = tot = tensors = exact_tensors = 0
+    for key in g.files:
+        if key.startswith('grad/'):
+            n = key[5:]
+            got = params[n].grad.detach().cpu().numpy()
+        elif key.startswith('gradsample/'):
+            n = key[11:]
+            flat = params[n].grad.detach().reshape(-1)
+            got = flat[::flat.numel() // 1024][:1024].cpu().numpy()
+        else:
+            continue
+        want = g[key]
+        assert got.shape == want.shape, key
+        close = np.abs(got - want) <= 1e-3 * np.abs(want) + 2e-5 * max(float(np.abs(want).max()), 1e-30)
+        ok += int(close.sum()); tot += close.size; tensors += 1; exact_tensors += int(close.all())
+    assert tensors > 30
+    print(f'{name}: {ok / tot * 100:.3f}% of {tot} stored gradient elements within tolerance; {exact_tensors} of {tensors} tensors entirely')
+    assert ok / tot > 0.97 and exact_tensors / tensors > 0.8
 
 
 @pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64', 'model_s_true_256x320'])
@@ -700,7 +941,7 @@ def test_state_dict_roundtrip_and_writeback_switch(dev):
         finally:
             ops.set_state_writeback(True)
         functional.reset_net(model)
-    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)     # MIOpen may pick another conv algorithm on the second call
+    assert torch.equal(a, b)            # every convolution is an own kernel with a fixed summation order: bit-identical
 
 
 CONFIG_CASES = {
