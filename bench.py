@@ -58,25 +58,24 @@ def pmc_traffic(entry, launches_per_call):
         return None
 
 
-SENSOR = (240, 304)
-CANVAS = (256, 320)
-OPTS = ['T', '3', 'Tm', '4', 'embedding', 'arsnn', 'num_classes', '2', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum',
-        'embedding_depth', '2', 'embedding_ksize', '5', 'write_zero', 'True', 'use_spike', 'True', 'spike_fn', 'atan',
-        'input_size', '(256,320)', 'test_size', '(256,320)']
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='samples per GPU')
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4, 5),
+                    help='BASELINE.json configuration (eas_snn_amd/workloads.py): 2 = SYOLOX-S T=3 Gen1 (the headline metric, default); 3 = SYOLOX-M '
+                         'T=5 RPD Gen1; 4 = SYOLOX-M 1Mpx stacked histogram T=3; 5 = SYOLOX-M N-Caltech101 T=7')
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU (default: the configuration\'s: 64 for config 2, 32 for 3-5)')
     ap.add_argument('--events', type=int, default=200_000, help='events per sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-batch', type=int, default=None)
+    ap.add_argument('--h2d', action='store_true',
+                    help='stream a fresh pinned host batch of raw input to the device every step on a side stream (the reference\'s '
+                         'DataPrefetcher shape, yolox/data/data_prefetcher.py:31-44): PCIe-inclusive rate, reported as such')
     ap.add_argument('--selftest-cpu', action='store_true',
-                    help='no GPU: run the launcher, rendezvous (gloo), barrier / max-over-ranks timing and the flat gradient '
-                         'exchange on a stand-in CPU module (tests/test_cpu_host.py)')
+                    help='no GPU: run the launcher, rendezvous (gloo), barrier / max-over-ranks timing and the trainer\'s step object with the '
+                         'bucketed gradient exchange on a stand-in CPU module (tests/test_cpu_host.py)')
     return ap.parse_args()
 
 
@@ -92,26 +91,37 @@ def _cpu_model():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(cpu_batch, n_events):
-    """The oracle (a port: torch-CPU restatement validated against the reference) on a bounded sample of the same
-    workload: same model/config, batch ``cpu_batch``, numpy event binning + fwd + bwd + Adam + reset per iteration."""
+def cpu_baseline(w, cpu_batch, n_events):
+    """The oracle (a port: torch-CPU restatement validated against the reference) on a bounded sample of the same workload: same
+    model / configuration, batch ``cpu_batch``, numpy input reduction (event binning / stacked-histogram sum) + fwd + bwd + Adam +
+    reset per iteration.  The thread count is the best of a 16 / 32 / 64 / 128 sweep on this host
+    (profiles/r03_cpu_baseline_threads.txt); EAS_CPU_THREADS overrides it."""
     from oracle import events_ref, model_ref, sj_ref
-    # intra-op threads: all host cores up to 32 (beyond that ATen's CPU convs at these sizes get slower, not faster)
-    threads = min(os.cpu_count() or 1, 32)
+    threads = int(os.environ.get('EAS_CPU_THREADS', min(os.cpu_count() or 1, 32)))
     torch.set_num_threads(threads)
     torch.manual_seed(80)
-    model = model_ref.build_model(use_spike='True')
+    model = model_ref.build_model(**w['oracle'])
     model.head.use_l1 = True
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    streams = [events_ref.synth_events(n_events, *SENSOR, seed=100 + b) for b in range(cpu_batch)]
+    sensor, canvas, Tm = tuple(w['sensor']), tuple(w['canvas']), w['Tm']
+    if w['input'] == 'events':
+        streams = [events_ref.synth_events(n_events, *sensor, seed=100 + b) for b in range(cpu_batch)]
+    else:
+        rng = np.random.default_rng(7)
+        hists = [rng.poisson(0.03, (Tm, 20) + sensor).clip(0, 255).astype(np.uint8) for _ in range(cpu_batch)]
     tg = torch.zeros(cpu_batch, 50, 5)
-    tg[:, 0] = torch.tensor([0, 0.3 * 320, 0.4 * 256, 0.25 * 320, 0.3 * 256])
-    tg[:, 1] = torch.tensor([1, 0.7 * 320, 0.6 * 256, 0.2 * 320, 0.35 * 256])
+    tg[:, 0] = torch.tensor([0, 0.3 * canvas[1], 0.4 * canvas[0], 0.25 * canvas[1], 0.3 * canvas[0]])
+    tg[:, 1] = torch.tensor([1, 0.7 * canvas[1], 0.6 * canvas[0], 0.2 * canvas[1], 0.35 * canvas[0]])
+
+    def make_frames(b):
+        if w['input'] == 'events':
+            return events_ref.micro_sum(*streams[b], Tm, *sensor)
+        return events_ref.stacked_hist_event_sum(hists[b], Tm, *sensor)[0]
 
     def step():
-        frames = np.zeros((cpu_batch, 1, 4, 2) + CANVAS, np.float32)
-        for b, (t, x, y, p) in enumerate(streams):
-            frames[b, 0, :, :, :SENSOR[0], :SENSOR[1]] = events_ref.micro_sum(t, x, y, p, 4, *SENSOR)
+        frames = np.zeros((cpu_batch, 1, Tm, 2) + canvas, np.float32)
+        for b in range(cpu_batch):
+            frames[b, 0, :, :, :sensor[0], :sensor[1]] = make_frames(b)
         out = model(torch.from_numpy(frames), tg)
         opt.zero_grad()
         out['total_loss'].backward()
@@ -128,17 +138,21 @@ def cpu_baseline(cpu_batch, n_events):
         el = time.time() - t0
         if el > 12.0 or n >= 5 or warm > 20.0:   # bounded sample: ~10-30 s of CPU work
             break
-    # SURVEY 8(d) side figures: K1's numpy restatement single-threaded (how a DataLoader worker runs it) and the eval
-    # forward of one sample (BASELINE configs[0]), both bounded to a few seconds
-    t1 = time.time()
-    k1_n = 0
-    while time.time() - t1 < 1.5:
-        events_ref.micro_sum(*streams[k1_n % cpu_batch], 4, *SENSOR)
-        k1_n += 1
-    k1_rate = k1_n * n_events / (time.time() - t1)
+    res = {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port', 'cpu_model': _cpu_model(),
+           'host_logical_cpus': os.cpu_count(),
+           'sample': f"oracle (torch-CPU fp32) {w['name']}: fwd+bwd+Adam+reset, batch {cpu_batch}, {n} iterations, input reduced with numpy"}
+    if w['input'] == 'events':
+        # SURVEY 8(d) side figures: K1's numpy restatement single-threaded (how a DataLoader worker runs it) and the eval forward of one
+        # sample (BASELINE configs[0] for config 2), both bounded to a few seconds
+        t1 = time.time()
+        k1_n = 0
+        while time.time() - t1 < 1.5:
+            events_ref.micro_sum(*streams[k1_n % cpu_batch], Tm, *sensor)
+            k1_n += 1
+        res['k1_numpy_events_per_s_1thread'] = round(k1_n * n_events / (time.time() - t1))
     model.eval()
-    one = torch.from_numpy(np.zeros((1, 1, 4, 2) + CANVAS, np.float32))
-    one[0, 0, :, :, :SENSOR[0], :SENSOR[1]] = torch.from_numpy(events_ref.micro_sum(*streams[0], 4, *SENSOR).astype(np.float32))
+    one = torch.from_numpy(np.zeros((1, 1, Tm, 2) + canvas, np.float32))
+    one[0, 0, :, :, :sensor[0], :sensor[1]] = torch.from_numpy(np.asarray(make_frames(0), np.float32))
     with torch.no_grad():
         model(one)
         sj_ref.reset_net(model)
@@ -147,12 +161,8 @@ def cpu_baseline(cpu_batch, n_events):
             model(one)
             sj_ref.reset_net(model)
             ev_n += 1
-    ev_rate = ev_n / (time.time() - t2)
-    return {'value': round(cpu_batch * n / el, 3), 'unit': 'event-frames/s', 'cores': threads, 'kind': 'port', 'cpu_model': _cpu_model(),
-            'host_logical_cpus': os.cpu_count(),
-            'sample': f'oracle (torch-CPU fp32) SYOLOX-S T=3 256x320 fwd+bwd+Adam, batch {cpu_batch}, {n} iterations, '
-                      f'{n_events} events/sample binned with numpy',
-            'k1_numpy_events_per_s_1thread': round(k1_rate), 'eval_forward_1_sample_frames_per_s': round(ev_rate, 2)}
+    res['eval_forward_1_sample_frames_per_s'] = round(ev_n / (time.time() - t2), 2)
+    return res
 
 
 def _free_port():
@@ -219,24 +229,41 @@ def launch_ranks(args):
     return rc
 
 
+class _StandIn(torch.nn.Module):
+    """CPU stand-in with the module names the trainer's overlapped exchange cuts at (sampler | backbone.backbone || neck / head)"""
+
+    def __init__(self):
+        super().__init__()
+        self.embedding = torch.nn.Linear(16, 16)
+        self.backbone = torch.nn.Module()
+        self.backbone.backbone = torch.nn.Linear(16, 16)
+        self.head = torch.nn.Linear(16, 4)
+
+    def forward(self, x, targets=None):
+        return {'total_loss': self.head(torch.tanh(self.backbone.backbone(self.embedding(x)))).sum()}
+
+
 def selftest_cpu(args, world, rank):
-    """The N-rank protocol of this file without a GPU: gloo rendezvous from the launcher's environment, flat gradient exchange on a
-    stand-in module, barrier-bracketed timed region, max over ranks, one JSON line from rank 0."""
-    from eas_snn_amd.parallel import FlatGradAllReduce
+    """The N-rank protocol of this file without a GPU: gloo rendezvous from the launcher's environment, the trainer's step object
+    (yolox/core/trainer.py::TrainStep: forward, split backward, bucketed gradient exchange, optimizer step) on a stand-in module,
+    barrier-bracketed timed region, max over ranks, one JSON line from rank 0."""
+    from eas_snn_amd import workloads
+    from eas_snn_amd.parallel import BucketedGradAllReduce
+    from yolox.core.trainer import DEFAULT_CUT, DEFAULT_LOWER, TrainStep
     if os.environ.get('EAS_BENCH_SELFTEST_FAIL_RANK') == str(rank):     # test hook: this rank dies before the rendezvous
         sys.exit(7)
+    w = workloads.get(args.config)
     if world > 1:
         dist.init_process_group('gloo')
     torch.manual_seed(rank)
-    net = torch.nn.Linear(16, 4)
-    sync = FlatGradAllReduce(net) if world > 1 else None
-    x = torch.full((8, 16), float(rank + 1))
-
-    def step():
-        net.zero_grad(set_to_none=True)
-        net(x).sum().backward()
-        if sync is not None:
-            sync.sync()
+    net = _StandIn()
+    exchange = BucketedGradAllReduce(net, split=DEFAULT_LOWER) if world > 1 else None
+    if world > 1:
+        ref = _StandIn()
+        ref.load_state_dict(net.state_dict())           # rank 0's values after the constructor's broadcast: a plain-backward twin
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    x = torch.full((8, 16), float(rank + 1)) + torch.arange(16.0) * 0.01
+    step = TrainStep(net, opt, lambda: (x, None), exchange=exchange, reset=False, defer_wgrad=False, cut=DEFAULT_CUT)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -247,20 +274,24 @@ def selftest_cpu(args, world, rank):
     if world > 1:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    g = net.weight.grad.clone()
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        lo, hi = g.clone(), g.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert torch.equal(lo, hi), 'ranks hold different averaged gradients'
+        # the split backward + bucketed exchange must equal: plain backward on every rank, gradients averaged over the ranks
+        ref(x)['total_loss'].backward()
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            want = q.grad.clone()
+            dist.all_reduce(want, op=dist.ReduceOp.SUM)
+            want /= world
+            assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7), f'{n}: bucketed exchange differs from the averaged plain backward'
+            lo, hi = p.grad.clone(), p.grad.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), 'ranks hold different averaged gradients'
     if rank == 0:
-        # d(sum)/dW = 8 * x per output row; averaged over ranks r = 1..world
-        want = 8.0 * sum(range(1, world + 1)) / world
-        assert torch.allclose(g, torch.full_like(g, want)), (g[0, 0].item(), want)
         print(json.dumps({'selftest': True, 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': round(float(el) / args.steps * 1e3, 4), 'backend': 'gloo',
-                          'gradient_exchange': 'flat' if world > 1 else None,
+                          'gradient_exchange': (f'{exchange.nbuckets} buckets' if exchange is not None else None),
+                          'config': {'workload': w['name'], 'config': w['config']},
                           'spawned_by_bench': os.environ.get('EAS_BENCH_SPAWNED') == '1'}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -281,7 +312,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    force_ddp = os.environ.get('EAS_BENCH_FORCE_DDP') == '1'     # development: exercise the DDP/RCCL path with one rank
+    force_ddp = os.environ.get('EAS_BENCH_FORCE_DDP') == '1'     # development: exercise the exchange / RCCL path with one rank
     if world > 1 or force_ddp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if force_ddp and world == 1:
@@ -295,139 +326,73 @@ def main():
     # and a later graph capture breaks if that was the default stream
     torch.cuda.set_stream(torch.cuda.Stream())
 
+    import types
     import eas_snn_amd
-    from eas_snn_amd import data, ops
-    from spikingjelly.activation_based import functional
-    from yolox.exp import get_exp
+    from eas_snn_amd import ops, workloads
     eas_snn_amd.hip_library()
     ops.set_state_writeback(False)           # every step ends with reset_net (as yolox/core/trainer.py:115-117)
 
-    exp = get_exp(None, 'e-yolox-s')
-    exp.merge(OPTS)
+    w = workloads.get(args.config)
+    batch = args.batch or w['batch']
+    exp = workloads.build_exp(w)
+    exp.ema = False                          # the measured step is forward + backward + exchange + Adam + reset_net
+    exp.output_dir = os.environ.get('EAS_BENCH_OUT', '/tmp/eas_bench_out')
     torch.manual_seed(80)
-    model = exp.get_model().to(dev)
+    # THE STEP IS THE TRAINER'S: model, optimizer, gradient exchange and the iteration itself (eager or HIP-graph replays) come from
+    # yolox.core.Trainer (compat/yolox/core/trainer.py, what tools/train_event.py runs); this file only feeds it and times it.
+    trainer = exp.get_trainer(types.SimpleNamespace(batch_size=batch * world, fp16=False, experiment_name=f'bench_config{w["config"]}',
+                                                     ckpt=None, resume=False))
+    model = trainer.setup(force_exchange=force_ddp)
     model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
     model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'    # development switch: 0 = tensor-op SimOTA
     model.head.fused_loss = os.environ.get('EAS_FUSED_LOSS', '1') == '1'        # development switch: 0 = tensor-op loss terms
-    opt = exp.get_optimizer(args.batch * world)
-    net = model
-    flat_sync = None
-    # gradient exchange at N > 1: one flat RCCL all-reduce after backward (eas_snn_amd/parallel.py; ~7 ms less host work per step
-    # than DistributedDataParallel, which hides a 0.6 ms all-reduce but pushes the host to 0.83 of the step) -- EAS_BENCH_DP=ddp
-    # selects DistributedDataParallel (bucketed, overlapped with backward) instead
-    dp_mode = os.environ.get('EAS_BENCH_DP', 'flat')
-    if world > 1 or force_ddp:
-        if dp_mode == 'ddp':
-            # gradients live inside the all-reduce buckets (no per-parameter copy kernels)
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                            gradient_as_bucket_view=True)
-        else:
-            from eas_snn_amd.parallel import FlatGradAllReduce
-            flat_sync = FlatGradAllReduce(model)
+    multi = world > 1 or force_ddp
 
-    ev = data.events_to_device(data.synth_event_batch(args.batch, args.events, *SENSOR, seed=rank), dev)
-    targets = data.synth_targets(args.batch, CANVAS, dev)
+    raw, inputs_fn = workloads.device_inputs(w, batch, args.events, dev, seed=rank)
+    h2d = _H2DFeeder(raw) if args.h2d else None
+    step = trainer.step_fn(inputs_fn)
 
-    # the slab reductions of all weight gradients in one launch at the end of the backward pass; DistributedDataParallel copies
-    # gradients into its buckets inside the pass, so not there
-    defer = ops.deferred_wgrad_reductions(not (net is not model) and os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1')
+    def one():
+        if h2d is not None:
+            h2d.next()
+        return step()
 
-    def fwd_bwd():
-        frames = data.events_to_frames(ev, exp.Tm, SENSOR, CANVAS)
-        out = net(frames, targets)
-        opt.zero_grad(set_to_none=True)
-        with defer:
-            out['total_loss'].backward()
-        if flat_sync is not None:
-            flat_sync.pack()
-        return out['total_loss']
-
-    def update():
-        if flat_sync is not None:
-            flat_sync.attach()
-        opt.step()
-        functional.reset_net(model)
-
-    def step():
-        loss_ = fwd_bwd()
-        if flat_sync is not None:
-            flat_sync.reduce()               # the one collective of the step: RCCL all-reduce of the flat gradient buffer
-        update()
-        return loss_
-
-    # Launch mode.  The step has no host synchronisation, so it can be captured into HIP graphs and replayed.  One GPU: ONE
-    # graph for the whole step; the warm-up times a few eager steps and a few replays and the timed region uses whichever was
-    # faster (eager wins by ~3 % while the host stays ahead of the GPU, loses by 2x on a busy host).  N > 1 (flat exchange):
-    # TWO graphs -- forward + backward + gradient packing | Adam + reset -- with the RCCL all-reduce launched eagerly between
-    # them, so a rank costs the host three calls per step instead of ~1100 kernel launches (eight ranks share one host).
-    # DistributedDataParallel (EAS_BENCH_DP=ddp) stays eager: its reducer hooks cannot be captured.
+    # Launch mode.  The step has no host synchronisation, so it can be captured into HIP graphs and replayed (TrainStep.capture): one
+    # graph on one GPU -- the warm-up times a few eager steps and a few replays and the timed region uses whichever was faster --
+    # and graph replays with the eager RCCL all-reduces between them at N > 1.  DistributedDataParallel (EAS_DP=ddp) stays eager.
     # EAS_BENCH_GRAPH=0/1 forces eager/graph.
     mode = os.environ.get('EAS_BENCH_GRAPH', 'auto')
     for _ in range(max(args.warmup - 2, 1)):
-        loss = step()
+        loss = one()
     torch.cuda.synchronize()
     t_a = time.perf_counter()
-    step()
-    loss = step()
+    one()
+    loss = one()
     t_enq = time.perf_counter() - t_a
     torch.cuda.synchronize()
     t_tot = time.perf_counter() - t_a
-    graph = None
     probe = {}
-    launch = 'eager launches'
-    multi = world > 1 or force_ddp
-    run = step
-    if mode in ('1', 'auto') and not (multi and dp_mode == 'ddp'):
-        for gr in opt.param_groups:
-            gr['capturable'] = True
-        for st_ in opt.state.values():         # Adam's step counters live on the host in eager mode; a captured step needs them on the device
-            if torch.is_tensor(st_.get('step')):
-                st_['step'] = st_['step'].to(dev)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        if not multi:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = step()
-            graph.replay()                       # warm-up replay
-            run = graph.replay
-            launch = 'hip-graph replay of the whole step'
-            if mode == 'auto':
-                def clock(fn, n=4):
-                    torch.cuda.synchronize()
-                    t = time.perf_counter()
-                    for _ in range(n):
-                        fn()
-                    torch.cuda.synchronize()
-                    return (time.perf_counter() - t) / n * 1e3
-                probe = {'eager_ms': round(clock(step), 3), 'graph_ms': round(clock(graph.replay), 3)}
-                if probe['eager_ms'] < probe['graph_ms']:
-                    run, launch = step, 'eager launches'         # eager is faster on this host right now
-        else:
-            pool = torch.cuda.graph_pool_handle()
-            g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_a, pool=pool):
-                loss = fwd_bwd()
-            flat_sync.reduce()
-            with torch.cuda.graph(g_b, pool=pool):
-                update()
-            graph = (g_a, g_b)
-
-            def run():
-                g_a.replay()
-                flat_sync.reduce()
-                g_b.replay()
-            run()                                # warm-up replay
-            launch = 'two hip-graph replays per step (fwd+bwd+pack | adam+reset) with the eager RCCL all-reduce between them'
+    if mode in ('1', 'auto') and trainer.net is trainer.bare_model:
+        step.capture(warm=3)
+        if not multi and mode == 'auto':
+            def clock(fn, n=4):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3
+            probe = {'eager_ms': round(clock(step.eager), 3), 'graph_ms': round(clock(step.replay), 3)}
+            if probe['eager_ms'] < probe['graph_ms']:
+                step.uncapture()                     # eager is faster on this host right now
+    launch = step.launch
     timer = ops.KernelTimer() if rank == 0 else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        r = run()
-        loss = r if r is not None else loss
+        loss = one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -435,13 +400,28 @@ def main():
     # Per-kernel durations behind `roofline`: HIP events around every C-ABI call, on the stream the kernels are launched on, in
     # eager steps of this same process right after the timed region (same kernels, same data).  Not inside it: events cannot be
     # recorded into a captured graph, and ~1400 event records per eager step would slow the timed region itself by ~10 %.
-    # With more than one rank every rank runs these steps (the DDP all-reduce needs all of them); rank 0 records.
+    # With more than one rank every rank runs these steps (the all-reduces need all of them); rank 0 records.
     timed_steps = 3
     ops.set_timer(timer)
     for _ in range(timed_steps):
-        step()
+        step.eager()
     torch.cuda.synchronize()
     ops.set_timer(None)
+    # inference side figure: eval-mode forward of the same batch (no loss, no backward), a few repetitions
+    eval_fps = None
+    if rank == 0 and not multi:
+        from spikingjelly.activation_based import functional
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(inputs_fn()[0]); functional.reset_net(model)
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            for _ in range(5):
+                model(inputs_fn()[0]); functional.reset_net(model)
+            torch.cuda.synchronize()
+            eval_fps = round(5 * batch / (time.perf_counter() - t_e), 1)
+        model.train()
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -449,7 +429,7 @@ def main():
     assert torch.isfinite(loss), 'training step produced a non-finite loss'
 
     if rank == 0:
-        frames_total = args.batch * world * args.steps
+        frames_total = batch * world * args.steps
         summ = timer.summary()
         fam = {k: dict(calls=v['calls'], ms_per_step=round(v['ms'] / timed_steps, 4),
                        GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
@@ -457,9 +437,10 @@ def main():
         dom = max(summ, key=lambda k: summ[k]['ms'])
         d = summ[dom]
         sec = d['ms'] * 1e-3
-        common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1),
+        common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4),
+                  'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1) if w['config'] == 2 else None,
                   'traffic_source': 'committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes over this command (profiles/pmc_traffic_latest.json, '
-                                    'scripts/gpu_profile.sh), not re-measured in this run',
+                                    'scripts/gpu_profile.sh), not re-measured in this run; config 2 only',
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
                   'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'}
@@ -477,6 +458,7 @@ def main():
                         'scheme_ceiling_tflops': round(scheme_ceiling, 1), 'frac_of_scheme_ceiling': round(achieved / scheme_ceiling, 4),
                         'mfma_bf16_issued_tflops': round(d['issue_flops'] / sec / 1e12, 1), 'mfma_bf16_peak_tflops': BF16_MFMA_PEAK_TF,
                         'mfma_bf16_util': round(d['issue_flops'] / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                        'mfma_busy_measured': mfma_busy_measured(),
                         'algorithmic_GBps': round(d['bytes'] / sec / 1e9, 1)}
         else:
             achieved = d['bytes'] / sec / 1e9
@@ -484,29 +466,77 @@ def main():
                         'frac': round(achieved / HBM_PEAK_GBS, 4)}
         roofline.update(common)
         # the dominant HBM-bound family as well (the elementwise/BN/LIF kernels of the step)
-        hbm_fams = {k: v for k, v in summ.items() if v['flops'] == 0}
+        hbm_fams = {k: v for k, v in summ.items() if v['flops'] == 0 and v['bytes'] > 0}
         if hbm_fams:
             hk = max(hbm_fams, key=lambda k: hbm_fams[k]['ms'])
             hv = hbm_fams[hk]
             roofline['hbm_dominant'] = {'kernel': hk, 'achieved': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                                         'unit': 'GB/s', 'frac': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        'traffic': pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1),
+                                        'traffic': pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1) if w['config'] == 2 else None,
                                         'algorithmic_bytes_per_call': round(hv['bytes'] / hv['calls'])}
-        line = {'metric': 'event-frames/sec (T=3) SYOLOX-S Gen1 304x240', 'value': round(frames_total / elapsed, 2),
+        metric = ('event-frames/sec (T=3) SYOLOX-S Gen1 304x240' if w['config'] == 2 else f'event-frames/sec, BASELINE config {w["config"]}')
+        line = {'metric': metric, 'value': round(frames_total / elapsed, 2),
                 'unit': 'event-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': 'SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, batch 64/GPU, '
-                                       'raw events -> histogram -> fwd + bwd + Adam + reset_net',
-                           'global_batch': args.batch * world, 'events_per_sample': args.events, 'parallelism': f'dp{world}', 'gradient_exchange': (dp_mode if (world > 1 or force_ddp) else None),
+                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (yolox.core.Trainer step)",
+                           'baseline_config': w['config'], 'global_batch': batch * world,
+                           'events_per_sample': args.events if w['input'] == 'events' else None, 'parallelism': f'dp{world}',
+                           'gradient_exchange': ((f'{trainer.exchange.nbuckets} flat bucket(s)' if trainer.exchange is not None else trainer.dp) if multi else None),
                            'launch': launch, 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
-                           'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3)},
+                           'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3),
+                           'h2d_per_step': (h2d.describe() if h2d is not None else None)},
                 'roofline': roofline}
+        if eval_fps is not None:
+            line['eval_forward_frames_per_s'] = {'value': eval_fps, 'batch': batch, 'note': 'model.eval() forward + reset_net on the same batch, one GPU'}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.events)
+            line['cpu_baseline'] = cpu_baseline(w, args.cpu_batch or (8 if w['config'] == 2 else 2), args.events)
         print(json.dumps(line), flush=True)
     if world > 1 or force_ddp:
         dist.destroy_process_group()
+
+
+class _H2DFeeder:
+    """--h2d: every step a copy of the raw input batch crosses PCIe from pinned host memory on a SIDE stream into a staging buffer while
+    the previous step computes (the reference's DataPrefetcher shape, yolox/data/data_prefetcher.py:18,31-44); at the start of a step
+    the main stream waits for that copy and moves the staged batch into the buffers the (captured) step reads -- a device-to-device
+    copy, ~0.06 ms for 115 MB -- then the next transfer starts."""
+
+    def __init__(self, raw):
+        self.dev_tensors = list(raw.values()) if isinstance(raw, dict) else [raw]
+        self.host = [t.cpu().pin_memory() for t in self.dev_tensors]
+        self.stage = [torch.empty_like(t) for t in self.dev_tensors]
+        self.stream = torch.cuda.Stream()
+        self.bytes = sum(t.numel() * t.element_size() for t in self.host)
+        self._issue()
+
+    def _issue(self):
+        with torch.cuda.stream(self.stream):
+            for s_, h in zip(self.stage, self.host):
+                s_.copy_(h, non_blocking=True)
+
+    def next(self):
+        main = torch.cuda.current_stream()
+        main.wait_stream(self.stream)                 # the transfer issued during the previous step has landed in the staging buffers
+        for d, s_ in zip(self.dev_tensors, self.stage):
+            d.copy_(s_)                               # device to device, on the main stream, in front of the step
+        self.stream.wait_stream(main)                 # the staging buffers are free again once that copy has run
+        self._issue()                                 # the next batch crosses PCIe while this step computes
+
+    def describe(self):
+        return {'bytes': self.bytes, 'GB_per_s_needed_at_this_step_rate': None, 'source': 'pinned host memory -> staging (side stream) -> step buffers (D2D)'}
+
+
+def mfma_busy_measured():
+    """time-weighted SQ_VALU_MFMA_BUSY_CYCLES share over the dense-convolution kernels of one config-2 step, from the committed counter
+    pass (profiles/conv_sq_counters_latest.json, scripts/pmc_conv_step.sh): rocprofv3 --pmc cannot run inside this process"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'conv_sq_counters_latest.json')) as fh:
+            c = json.load(fh)
+        rows = [v for k, v in c.items() if 'smallconv' not in k and v.get('mfma_busy_frac') is not None and v.get('total_us_under_profiler')]
+        return round(sum(v['mfma_busy_frac'] * v['total_us_under_profiler'] for v in rows) / sum(v['total_us_under_profiler'] for v in rows), 4)
+    except (OSError, KeyError, ValueError, ZeroDivisionError, TypeError):
+        return None
 
 
 if __name__ == '__main__':

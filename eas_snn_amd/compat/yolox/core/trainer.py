@@ -1,17 +1,245 @@
-"""Training loop (reference: yolox/core/trainer.py:36-419), reduced to what the hot path needs:
-model -> device, optimizer, DDP(broadcast_buffers=False) over RCCL, EMA, per-iteration
-forward / backward / step / reset_net, LR schedule, 'latest' checkpoint.  Evaluation, TensorBoard/W&B
-logging and dataset prefetching are out of scope (synthetic loader yields GPU tensors)."""
+"""Training loop (reference: yolox/core/trainer.py:36-419), reduced to what the hot path needs: model -> device, optimizer,
+data-parallel gradient exchange over RCCL, EMA, per-iteration forward / backward / step / reset_net, LR schedule, 'latest'
+checkpoint.  Evaluation, TensorBoard/W&B logging and dataset prefetching are out of scope (the synthetic loader yields GPU tensors).
+
+What is different from the reference's loop, and why (MI355X):
+
+* ``TrainStep`` is the iteration itself -- inputs -> forward -> loss -> zero_grad -> backward -> gradient exchange -> optimizer step
+  -> reset_net (trainer.py:95-117 of the reference) -- as ONE object that can launch it eagerly or, since the iteration has no host
+  synchronisation, as HIP-graph replays: one graph on one GPU; with N > 1 ranks (forward + backward of the head and the neck) |
+  (backward of the backbone) | (optimizer + reset) with the RCCL all-reduces launched eagerly between them, the first one on a side
+  stream while the backbone's backward replays.  ``bench.py`` measures exactly this object (``Trainer.step_fn``): the measured step
+  IS the drop-in step.
+* gradient exchange: ``eas_snn_amd.parallel.BucketedGradAllReduce`` (flat buckets, a handful of collectives) instead of
+  ``DistributedDataParallel`` (trainer.py:174-176) -- same averaged gradients, per-rank BatchNorm statistics like
+  ``broadcast_buffers=False``; ``EAS_DP=ddp`` selects DistributedDataParallel (eager launches only: its hooks cannot be captured).
+* the learning rate lives in a device scalar per parameter group, so the schedule keeps working under graph replay.
+"""
 import contextlib
 import os
 import time
 
 import torch
+import torch.distributed as dist
 from torch.nn.parallel import DistributedDataParallel as DDP
 
 from eas_snn_amd import ops
+from eas_snn_amd.parallel import BucketedGradAllReduce
 from yolox.utils import (ModelEMA, get_local_rank, get_model_info, get_rank, get_world_size, is_parallel, load_ckpt,
                          save_checkpoint, setup_logger)
+
+
+def _reset_net(model):
+    from spikingjelly.activation_based import functional
+    functional.reset_net(model)
+
+
+class TrainStep:
+    """One training iteration.  ``inputs_fn() -> (inps, targets)`` produces the batch on the device (inside the captured region:
+    e.g. the event histogram of raw events held in static buffers, or ``exp.preprocess`` of static input tensors).
+
+    ``eager()`` launches the iteration kernel by kernel; ``capture()`` records it into HIP graphs after which ``__call__`` replays
+    them; ``__call__`` before ``capture()`` is ``eager()``.  ``loss`` / ``outputs`` hold the (device) results of the last iteration.
+
+    cut: names of sub-modules whose outputs split the backward pass (two autograd calls: first everything above the cut, then the
+    rest) so that the gradient buckets of the upper part are exchanged while the lower part's backward still runs.  Only used
+    with an exchange (N > 1)."""
+
+    def __init__(self, model, optimizer, inputs_fn, exchange=None, net=None, reset=True, defer_wgrad=True, cut=()):
+        self.model, self.optimizer, self.inputs_fn = model, optimizer, inputs_fn
+        self.net = model if net is None else net                 # DistributedDataParallel wrapper, if any
+        self.exchange = exchange                                 # BucketedGradAllReduce or None
+        self.reset = reset
+        self.defer = bool(defer_wgrad) and self.net is model     # DDP copies gradients into its buckets inside the pass: not there
+        self.cut = tuple(cut) if exchange is not None and exchange.nbuckets > 1 else ()
+        self.graphs = None
+        self.launch = 'eager launches'
+        self.loss = None
+        self.outputs = None
+        self._cut_pairs = []
+        self._side = None
+
+    # ---- the phases of an iteration
+    def _split_at(self, obj):
+        """the outputs of a cut module, every tensor that carries a graph replaced by a detached leaf (same storage, same eas tags): the
+        part of the model above the cut builds its own autograd graph on the leaves, so its backward is a plain ``loss.backward()`` that
+        ends at them; the graph below the cut is run afterwards from the gradients the leaves received"""
+        if torch.is_tensor(obj):
+            if not (obj.requires_grad and obj.grad_fn is not None):
+                return obj
+            leaf = obj.detach().requires_grad_(True)
+            for k, v in obj.__dict__.items():
+                if k.startswith('_eas_'):
+                    setattr(leaf, k, v)
+            self._cut_pairs.append((obj, leaf))
+            return leaf
+        if isinstance(obj, dict):
+            return type(obj)((k, self._split_at(v)) for k, v in obj.items())
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._split_at(v) for v in obj)
+        return obj
+
+    def _forward(self):
+        inps, targets = self.inputs_fn()
+        hooks = []
+        self._cut_pairs = []
+        for name in self.cut:
+            hooks.append(self.model.get_submodule(name).register_forward_hook(lambda m, i, o: self._split_at(o)))
+        try:
+            self.outputs = self.net(inps, targets)
+        finally:
+            for h in hooks:
+                h.remove()
+        self.loss = self.outputs['total_loss']
+        self.optimizer.zero_grad(set_to_none=True)
+
+    def _backward_upper(self):
+        """backward of everything above the cut (head, neck): its parameter gradients and the gradients reaching the cut tensors"""
+        with ops.deferred_wgrad_reductions(self.defer):
+            self.loss.backward()
+        self._cut_grads = [(orig, leaf.grad) for orig, leaf in self._cut_pairs if leaf.grad is not None]
+        self._cut_pairs = []
+        self.exchange.pack(0)
+
+    def _backward_lower(self):
+        ts, gs = [t for t, _ in self._cut_grads], [g for _, g in self._cut_grads]
+        with ops.deferred_wgrad_reductions(self.defer):
+            torch.autograd.backward(ts, gs)
+        self._cut_grads = None
+        for b in range(1, self.exchange.nbuckets):
+            self.exchange.pack(b)
+
+    def _backward_all(self):
+        with ops.deferred_wgrad_reductions(self.defer):
+            self.loss.backward()
+        if self.exchange is not None:
+            for b in range(self.exchange.nbuckets):
+                self.exchange.pack(b)
+
+    def _update(self):
+        if self.exchange is not None:
+            self.exchange.attach()
+        self.optimizer.step()
+        if self.reset:
+            _reset_net(self.model)
+
+    def _reduce_upper_async(self):
+        """bucket 0's all-reduce on the side stream, behind everything the main stream has queued so far"""
+        if not self.exchange.flat[0].is_cuda:           # CPU tensors (gloo tests): nothing to overlap with
+            self.exchange.reduce(0)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self.exchange.reduce(0)
+
+    def _reduce_rest(self):
+        for b in range(1, self.exchange.nbuckets):
+            self.exchange.reduce(b)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    # ---- launch forms
+    def eager(self):
+        self._forward()
+        if self.cut and self._cut_pairs:
+            self._backward_upper()
+            self._reduce_upper_async()
+            self._backward_lower()
+            self._reduce_rest()
+        else:
+            self._backward_all()
+            if self.exchange is not None:
+                for b in range(self.exchange.nbuckets):
+                    self.exchange.reduce(b)
+        self._update()
+        return self.loss
+
+    def make_capturable(self):
+        """Adam's step counters live on the host in eager mode; a captured step needs them (and the learning rate) on the device"""
+        dev = next(self.model.parameters()).device
+        for gr in self.optimizer.param_groups:
+            if 'capturable' in gr:
+                gr['capturable'] = True
+        for st_ in self.optimizer.state.values():
+            if torch.is_tensor(st_.get('step')):
+                st_['step'] = st_['step'].to(dev)
+
+    def capture(self, warm=3):
+        """record the iteration into HIP graph(s); returns a description of the launch form.  Not with DistributedDataParallel."""
+        if self.net is not self.model:
+            raise RuntimeError('DistributedDataParallel iterations cannot be captured (reducer hooks); use the bucketed exchange')
+        self.make_capturable()
+        for _ in range(warm):
+            self.eager()
+        torch.cuda.synchronize()
+        if self.exchange is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forward()
+                self._backward_all()
+                self._update()
+            self.graphs = (g,)
+            self.launch = 'hip-graph replay of the whole step'
+        elif self.cut:
+            pool = torch.cuda.graph_pool_handle()
+            g_a, g_b, g_c = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_a, pool=pool):
+                self._forward()
+                self._backward_upper()
+            self._reduce_upper_async()
+            with torch.cuda.graph(g_b, pool=pool):
+                self._backward_lower()
+            self._reduce_rest()
+            with torch.cuda.graph(g_c, pool=pool):
+                self._update()
+            self.graphs = (g_a, g_b, g_c)
+            self.launch = ('three hip-graph replays per step (fwd + bwd head/neck | bwd backbone | adam + reset); RCCL all-reduces eager '
+                           'between them, the first one on a side stream under the backbone backward')
+        else:
+            pool = torch.cuda.graph_pool_handle()
+            g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_a, pool=pool):
+                self._forward()
+                self._backward_all()
+            for b in range(self.exchange.nbuckets):
+                self.exchange.reduce(b)
+            with torch.cuda.graph(g_b, pool=pool):
+                self._update()
+            self.graphs = (g_a, g_b)
+            self.launch = 'two hip-graph replays per step (fwd+bwd+pack | adam+reset) with the eager RCCL all-reduce between them'
+        self.replay()                                 # warm-up replay
+        return self.launch
+
+    def replay(self):
+        gs = self.graphs
+        if len(gs) == 1:
+            gs[0].replay()
+        elif len(gs) == 2:
+            gs[0].replay()
+            for b in range(self.exchange.nbuckets):
+                self.exchange.reduce(b)
+            gs[1].replay()
+        else:
+            gs[0].replay()
+            self._reduce_upper_async()
+            gs[1].replay()
+            self._reduce_rest()
+            gs[2].replay()
+        return self.loss
+
+    def uncapture(self):
+        self.graphs, self.launch = None, 'eager launches'
+
+    def __call__(self):
+        return self.replay() if self.graphs is not None else self.eager()
+
+
+# the EAS-SNN models split for the overlapped exchange: the outputs of DEFAULT_CUT (the CSPDarknet inside the PAFPN) separate "head +
+# neck" (bucket 0, finished first by the backward pass) from the parameters of DEFAULT_LOWER (backbone + sampler, bucket 1)
+DEFAULT_CUT = ('backbone.backbone',)
+DEFAULT_LOWER = ('backbone.backbone', 'embedding')
 
 
 class Trainer:
@@ -23,34 +251,63 @@ class Trainer:
             raise NotImplementedError('the HIP hot path computes in fp32 (reference parity); --fp16 is not provided')
         self.is_distributed = get_world_size() > 1
         self.rank, self.local_rank = get_rank(), get_local_rank()
-        self.device = 'cuda:{}'.format(self.local_rank)
+        self.device = 'cuda:{}'.format(self.local_rank) if torch.cuda.is_available() else 'cpu'
         self.use_model_ema = exp.ema
         self.input_size = exp.input_size
         self.start_epoch = 0
         self.file_name = os.path.join(exp.output_dir, getattr(args, 'experiment_name', None) or exp.exp_name)
         self.log = []
+        self.step = None
+        self.exchange = None
         if self.rank == 0:
             os.makedirs(self.file_name, exist_ok=True)
         setup_logger(self.file_name, distributed_rank=self.rank, filename='train_log.txt', mode='a')
 
-    def before_train(self):
-        torch.cuda.set_device(self.local_rank)
+    # ---- model, optimizer, gradient exchange (shared by train() and bench.py)
+    def setup(self, dp=None, force_exchange=False):
+        """model -> device, optimizer, data-parallel exchange.  dp: 'buckets' (default; BucketedGradAllReduce), 'flat' (one bucket) or
+        'ddp' (DistributedDataParallel, the reference's choice)."""
+        if self.device != 'cpu':
+            torch.cuda.set_device(self.local_rank)
         model = self.exp.get_model()
         self.model_info = get_model_info(model, self.exp.test_size)
         model.to(self.device)
         self.optimizer = self.exp.get_optimizer(self.args.batch_size)
         model = self.resume_train(model)
+        self.bare_model = model
+        self.dp = dp or os.environ.get('EAS_DP', 'buckets')
+        self.net = model
+        if self.is_distributed or force_exchange:
+            if self.dp == 'ddp':
+                # per-rank BN running stats until all_reduce_norm, like the reference (trainer.py:175-176)
+                self.net = DDP(model, device_ids=[self.local_rank] if self.device != 'cpu' else None, broadcast_buffers=False,
+                               gradient_as_bucket_view=True)
+            else:
+                self.exchange = BucketedGradAllReduce(model, split=DEFAULT_LOWER if self.dp == 'buckets' else ())
+        self.model = self.net
+        return model
+
+    def step_fn(self, inputs_fn, reset=None):
+        """the training iteration of this trainer as a ``TrainStep`` (what ``train_one_iter`` runs and ``bench.py`` measures)"""
+        if reset is None:
+            reset = self.exp.use_spike not in (False, 'False')
+        cut = DEFAULT_CUT if (self.exchange is not None and self.exchange.nbuckets > 1) else ()
+        return TrainStep(self.bare_model, self.optimizer, inputs_fn, exchange=self.exchange, net=self.net, reset=reset,
+                         defer_wgrad=os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1', cut=cut)
+
+    def before_train(self):
+        self.setup()
         self.train_loader = self.exp.get_data_loader(batch_size=self.args.batch_size, is_distributed=self.is_distributed,
                                                      no_aug=True, cache_img=getattr(self.args, 'cache', None))
         self.max_iter = len(self.train_loader)
         self.lr_scheduler = self.exp.get_lr_scheduler(self.exp.basic_lr_per_img * self.args.batch_size, self.max_iter)
-        if self.is_distributed:
-            # per-rank BN running stats until all_reduce_norm, like the reference (trainer.py:175-176)
-            model = DDP(model, device_ids=[self.local_rank], broadcast_buffers=False)
         if self.use_model_ema:
-            self.ema_model = ModelEMA(model, 0.9998)
+            self.ema_model = ModelEMA(self.bare_model, 0.9998)
             self.ema_model.updates = self.max_iter * self.start_epoch
-        self.model = model
+        # launch form of the iterations: HIP-graph replay on the GPU unless switched off (EAS_TRAIN_GRAPH=0) or DistributedDataParallel
+        self.use_graph = (self.device != 'cpu' and self.net is self.bare_model and os.environ.get('EAS_TRAIN_GRAPH', '1') == '1')
+        self._static = None
+        self._iters_done = 0
 
     def resume_train(self, model):
         ckpt_file = getattr(self.args, 'ckpt', None)
@@ -72,34 +329,51 @@ class Trainer:
 
     def _train_epochs(self):
         for self.epoch in range(self.start_epoch, self.max_epoch):
-            (self.model.module if is_parallel(self.model) else self.model).head.use_l1 = True   # no_aug from epoch 0
+            self.bare_model.head.use_l1 = True          # no_aug from epoch 0 (trainer.py:157, 231-238 of the reference)
             for self.iter, (inps, targets) in enumerate(self.train_loader):
                 self.train_one_iter(inps, targets)
             self.save_ckpt('latest')
 
+    def _set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            if torch.is_tensor(g['lr']):
+                g['lr'].fill_(lr)                        # device scalar: read by the (captured) optimizer kernels
+            else:
+                g['lr'] = lr
+
     def train_one_iter(self, inps, targets):
-        from spikingjelly.activation_based import functional
         t0 = time.time()
         inps, targets = inps.to(self.device, torch.float32), targets.to(self.device, torch.float32)
-        inps, targets = self.exp.preprocess(inps, targets, self.input_size)
-        outputs = self.model(inps, targets)
-        loss = outputs['total_loss']
-        self.optimizer.zero_grad()
-        loss.backward()
-        self.optimizer.step()
-        if self.exp.use_spike not in (False, 'False'):
-            functional.reset_net(self.model)
+        if self._static is None:
+            # static input buffers: every batch is copied into them, so an iteration captured once can be replayed on new data
+            self._static = (inps.clone(), targets.clone())
+            self.step = self.step_fn(lambda: self.exp.preprocess(self._static[0], self._static[1], self.input_size))
+            if self.use_graph:
+                for g in self.optimizer.param_groups:    # the schedule writes a device scalar the captured Adam reads
+                    g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=self.device)
+        else:
+            self._static[0].copy_(inps)
+            self._static[1].copy_(targets)
+        if self.use_graph and self.step.graphs is None and self._iters_done == 2:
+            self.step.capture(warm=0)                    # two eager iterations have initialised allocator and optimizer state
+            loss = self.step.loss
+        else:
+            loss = self.step()
+        self._iters_done += 1
         if self.use_model_ema:
-            self.ema_model.update(self.model)
+            self.ema_model.update(self.bare_model)
         lr = self.lr_scheduler.update_lr(self.epoch * self.max_iter + self.iter + 1)
-        for g in self.optimizer.param_groups:
-            g['lr'] = lr
+        self._set_lr(lr)
         if (self.iter + 1) % self.exp.print_interval == 0:
             self.log.append(dict(epoch=self.epoch, iter=self.iter, loss=float(loss), lr=lr, iter_time=time.time() - t0))
 
     def save_ckpt(self, ckpt_name, update_best_ckpt=False):
         if self.rank != 0:
             return
-        save_model = self.ema_model.ema if self.use_model_ema else self.model
-        state = {'start_epoch': self.epoch + 1, 'model': save_model.state_dict(), 'optimizer': self.optimizer.state_dict()}
+        save_model = self.ema_model.ema if self.use_model_ema else self.bare_model
+        opt_state = self.optimizer.state_dict()
+        for g in opt_state['param_groups']:              # checkpoints keep plain numbers
+            if torch.is_tensor(g.get('lr')):
+                g['lr'] = float(g['lr'])
+        state = {'start_epoch': self.epoch + 1, 'model': save_model.state_dict(), 'optimizer': opt_state}
         save_checkpoint(state, update_best_ckpt, self.file_name, ckpt_name)

@@ -348,19 +348,19 @@ def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, runn
         pend = _lib.EasBnPending(stats.data_ptr() + 16 * c0 * nb, nb, int(replicas), float(TN) * HW, float(eps),
                                  float(momentum if momentum is not None else 0.0), ptr(running_mean) if momentum is not None else None,
                                  ptr(running_var) if momentum is not None else None, None, nb)
-        return pend, stats
+        return pend, stats, 0                # no launch: the consumer adds the convolution's tile sums
     cp = _coop_ptr(dev, Cc)
     if cp is not None:
         pend = _lib.EasBnPending(None, 0, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
                                  ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, cp)
-        return pend, None
+        return pend, None, 0
     ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
     chunks = L.eas_bn_stats_partial(ptr(y) if y_ptr is None else y_ptr, y_ctot, TN, Cc, HW, ptr(ws), stream())
     if chunks <= 0:
         check(chunks if chunks < 0 else -1, 'eas_bn_stats_partial')
     pend = _lib.EasBnPending(ptr(ws), chunks, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
                              ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, None)
-    return pend, ws
+    return pend, ws, 4 * TN * Cc * HW        # the statistics launch read y once
 
 
 def _channel_slice_of(g, Cc):
@@ -402,9 +402,10 @@ class _BNLIFFn(torch.autograd.Function):
             mean = torch.empty(Cc, dtype=torch.float32, device=dev)
             invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
             t0 = _timer_mark()
-            pend, keep = _pending_stats(L, y, N if t_bcast else T * N, Cc, HW, T if t_bcast else 1, eps, momentum, running_mean,
-                                        running_var, dev)
-            _timer_add('eas_bn_stats', t0, 4 * y.numel())
+            pend, keep, nb_ = _pending_stats(L, y, N if t_bcast else T * N, Cc, HW, T if t_bcast else 1, eps, momentum, running_mean,
+                                             running_var, dev)
+            if nb_:
+                _timer_add('eas_bn_stats', t0, nb_)
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
@@ -533,9 +534,10 @@ class _BNLIF2Fn(torch.autograd.Function):
                 mean = torch.empty(Cc, dtype=torch.float32, device=dev)
                 invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
                 t0 = _timer_mark()
-                pend, keep = _pending_stats(L, y12, T * N, Cc, HW, 1, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct,
-                                            keep_slot=c0 == 0)
-                _timer_add('eas_bn_stats', t0, 4 * T * N * Cc * HW)
+                pend, keep, nb_ = _pending_stats(L, y12, T * N, Cc, HW, 1, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct,
+                                                 keep_slot=c0 == 0)
+                if nb_:
+                    _timer_add('eas_bn_stats', t0, nb_)
             else:
                 mean = running_mean
                 invstd = torch.rsqrt(running_var + eps)
@@ -690,8 +692,9 @@ class _BNSiLUFn(torch.autograd.Function):
             mean = torch.empty(Cc, dtype=torch.float32, device=dev)
             invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
             t0 = _timer_mark()
-            pend, keep = _pending_stats(L, y, N, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev)
-            _timer_add('eas_bn_stats', t0, 4 * y.numel())
+            pend, keep, nb_ = _pending_stats(L, y, N, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev)
+            if nb_:
+                _timer_add('eas_bn_stats', t0, nb_)
         else:
             pend = keep = None
             mean = running_mean
@@ -751,9 +754,10 @@ class _BNSiLU2Fn(torch.autograd.Function):
                 mean = torch.empty(Cc, dtype=torch.float32, device=dev)
                 invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
                 t0 = _timer_mark()
-                pend, keep = _pending_stats(L, y12, N, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct,
-                                            keep_slot=c0 == 0)
-                _timer_add('eas_bn_stats', t0, 4 * N * Cc * HW)
+                pend, keep, nb_ = _pending_stats(L, y12, N, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=yp, y_ctot=Ct,
+                                                 keep_slot=c0 == 0)
+                if nb_:
+                    _timer_add('eas_bn_stats', t0, nb_)
             else:
                 mean = running_mean
                 invstd = torch.rsqrt(running_var + eps)

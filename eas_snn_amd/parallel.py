@@ -1,66 +1,94 @@
 """Data-parallel gradient exchange for one process per GPU over RCCL/xGMI.
 
-The reference wraps the model in ``DistributedDataParallel`` (yolox/core/trainer.py:174-176); the compat trainer does the
-same.  ``FlatGradAllReduce`` is the lean equivalent for a step that has no unused parameters: after ``backward`` every
-gradient is packed into ONE contiguous buffer (a handful of launches), averaged over the ranks with ONE all-reduce
-(35.8 MB for SYOLOX-S: ~0.6 ms on eight xGMI-connected GPUs) and unpacked into the ``.grad`` tensors.  It trades DDP's
-overlap of that all-reduce with the backward pass for ~7 ms less host work per step (DDP's per-parameter hooks and bucket
-bookkeeping; measured on MI355X: host enqueue share 0.83 of a 32 ms step with DDP, 0.60 without) -- with eight ranks
-launching ~1100 kernels per step from one host, staying ahead of the GPU matters more than hiding half a millisecond.
+The reference wraps the model in ``DistributedDataParallel`` (yolox/core/trainer.py:174-176).  ``BucketedGradAllReduce`` is the lean
+equivalent for a step that has no unused parameters: the gradients are packed into a few persistent flat buffers ("buckets", one
+concatenation kernel each), every bucket is averaged over the ranks with ONE all-reduce, and ``attach()`` points every ``p.grad`` at
+its slice of the reduced buffer (no unpack copy).  Buckets follow the order in which the backward pass finishes them: bucket 0 =
+the parameters ABOVE a cut of the model (head + neck), the following buckets = the parameters below it (backbone + sampler), so the
+training step (yolox/core/trainer.py::TrainStep) can launch bucket 0's all-reduce on a side stream while the backbone's backward
+still runs -- the overlap DDP gets from its reducer hooks, without the per-parameter host work (measured on MI355X: host enqueue
+share 0.83 of a 32 ms step with DDP, 0.60 without) and without anything that cannot sit between HIP-graph replays.
+xGMI is point to point (7 links x ~153 GB/s per GPU): a ring all-reduce of SYOLOX-S's 35.8 MB is ~0.6 ms on eight GPUs, SYOLOX-M's
+101 MB ~1.2-1.7 ms; few large collectives are the right shape for it.
 Initial parameter values are broadcast from rank 0 exactly as DDP's constructor does.
 """
 import torch
 import torch.distributed as dist
 
 
-class FlatGradAllReduce:
-    """``pack()`` -> ``reduce()`` -> ``attach()`` between backward and the optimizer step (``sync()`` does all three).
+class BucketedGradAllReduce:
+    """``pack(b)`` -> ``reduce(b)`` per bucket, then ``attach()`` before the optimizer step (``sync()`` does it all).
 
-    The flat buffer is allocated once, so the three phases can live in different HIP graphs: ``pack`` at the end of a captured
-    forward+backward, ``reduce`` (the RCCL call) launched eagerly between two graph replays, ``attach`` at the start of a captured
-    optimizer step.  ``attach`` launches nothing: it makes every ``p.grad`` a view of the reduced buffer, which the optimizer
-    reads in place (no unpack copy)."""
+    split: names of the sub-modules whose parameters form the LOWER part of the model (everything the backward pass reaches last);
+    with an empty split there is one bucket (``FlatGradAllReduce``).  The flat buffers are allocated once, so the phases can live in
+    different HIP graphs: ``pack`` at the end of a captured backward, ``reduce`` (the RCCL call) launched eagerly between two graph
+    replays, ``attach`` at the start of a captured optimizer step.  ``attach`` launches nothing: it makes every ``p.grad`` a view
+    of the reduced buffer, which the optimizer reads in place."""
 
-    def __init__(self, module, process_group=None, broadcast_parameters=True):
+    def __init__(self, module, split=(), process_group=None, broadcast_parameters=True):
         self.group = process_group
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        self.sizes = [p.numel() for p in self.params]
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        lower = tuple(s + '.' for s in split)
+        is_low = [bool(lower) and n.startswith(lower) for n, _ in named]
+        groups = [[p for (n, p), lo in zip(named, is_low) if not lo], [p for (n, p), lo in zip(named, is_low) if lo]]
+        self.buckets = [g for g in groups if g]
+        self.params = [p for g in self.buckets for p in g]
+        self.sizes = [[p.numel() for p in g] for g in self.buckets]
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.flat = None
-        self.views = None
+        self.flat = [None] * len(self.buckets)
+        self.views = [None] * len(self.buckets)
         if broadcast_parameters and dist.is_initialized():
             with torch.no_grad():
-                flat = torch.cat([p.detach().reshape(-1) for p in self.params])
-                dist.broadcast(flat, src=0, group=process_group)
-                torch._foreach_copy_([p.detach() for p in self.params], [c.view_as(p) for c, p in zip(flat.split(self.sizes), self.params)])
+                for g, sz in zip(self.buckets, self.sizes):
+                    flat = torch.cat([p.detach().reshape(-1) for p in g])
+                    dist.broadcast(flat, src=0, group=process_group)
+                    torch._foreach_copy_([p.detach() for p in g], [c.view_as(p) for c, p in zip(flat.split(sz), g)])
 
-    def pack(self):
-        """all gradients -> the flat buffer (one concatenation kernel family)"""
-        grads = [p.grad for p in self.params]
+    @property
+    def nbuckets(self):
+        return len(self.buckets)
+
+    def bucket_params(self, b):
+        return list(self.buckets[b])
+
+    def pack(self, b=None):
+        """the gradients of bucket b (default: every bucket) -> its flat buffer (one concatenation kernel)"""
+        if b is None:
+            for i in range(self.nbuckets):
+                self.pack(i)
+            return
+        params = self.buckets[b]
+        grads = [p.grad for p in params]
         if any(g is None for g in grads):
-            raise RuntimeError('FlatGradAllReduce: a parameter has no gradient (unused parameters need DistributedDataParallel)')
-        if self.flat is None:
-            self.flat = torch.empty(sum(self.sizes), dtype=grads[0].dtype, device=grads[0].device)
-            self.views = [c.view_as(p) for c, p in zip(self.flat.split(self.sizes), self.params)]
-        stray = [i for i, (g, v) in enumerate(zip(grads, self.views)) if g.data_ptr() != v.data_ptr()]
+            raise RuntimeError('BucketedGradAllReduce: a parameter has no gradient (unused parameters need DistributedDataParallel)')
+        if self.flat[b] is None:
+            self.flat[b] = torch.empty(sum(self.sizes[b]), dtype=grads[0].dtype, device=grads[0].device)
+            self.views[b] = [c.view_as(p) for c, p in zip(self.flat[b].split(self.sizes[b]), params)]
+        views = self.views[b]
+        stray = [i for i, (g, v) in enumerate(zip(grads, views)) if g.data_ptr() != v.data_ptr()]
         if not stray:
             return                                   # every gradient was accumulated into its attached view: already packed
         if len(stray) == len(grads):
-            torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat[b])
         else:                                        # a mix (partial zero_grad / partial backward): copy the ones that live elsewhere
-            torch._foreach_copy_([self.views[i] for i in stray], [grads[i] for i in stray])
+            torch._foreach_copy_([views[i] for i in stray], [grads[i] for i in stray])
 
-    def reduce(self):
-        """ONE all-reduce of the flat buffer, then the 1/world scale (SUM + scale: every backend has it, gloo has no AVG)"""
+    def reduce(self, b=None):
+        """ONE all-reduce of bucket b's flat buffer, then the 1/world scale (SUM + scale: every backend has it, gloo has no AVG)"""
+        if b is None:
+            for i in range(self.nbuckets):
+                self.reduce(i)
+            return
         if dist.is_initialized():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
-                self.flat.mul_(1.0 / self.world)
+                self.flat[b].mul_(1.0 / self.world)
 
     def attach(self):
-        """``p.grad`` := the parameter's slice of the reduced buffer (host-side pointer assignment, no launch)"""
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        """``p.grad`` := the parameter's slice of its reduced bucket (host-side pointer assignment, no launch)"""
+        for params, views in zip(self.buckets, self.views):
+            for p, v in zip(params, views):
+                p.grad = v
 
     def sync(self):
         """average the gradients over the ranks (call between backward and the optimizer step)"""
@@ -69,3 +97,10 @@ class FlatGradAllReduce:
         self.pack()
         self.reduce()
         self.attach()
+
+
+class FlatGradAllReduce(BucketedGradAllReduce):
+    """one bucket: every gradient in ONE flat buffer, ONE all-reduce per step"""
+
+    def __init__(self, module, process_group=None, broadcast_parameters=True):
+        super().__init__(module, (), process_group, broadcast_parameters)

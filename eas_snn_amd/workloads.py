@@ -1,0 +1,74 @@
+"""The BASELINE.json configurations as runnable workloads: experiment options, input pipeline on the device, batch per GPU.
+
+Used by bench.py (``--config``), scripts/ and the tests, so that "config 3" means the same thing everywhere:
+
+  2  SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, use_spike=True, batch 64/GPU            -- the headline metric
+  3  SYOLOX-M Gen1 304x240 (canvas 256x320), T=5 with RPD (write_zero), full_spike_v2, batch 32/GPU (2 GPUs in BASELINE)
+  4  SYOLOX-M 1 Mpx 640x360: RVT stacked histogram u8 [B,Tm,2*10,360,640] -> event_sum -> canvas 384x640, T=3, 3 classes (8 GPUs)
+  5  SYOLOX-M N-Caltech101 180x240 (canvas 192x256), 100 classes, T=7, Tm=8, Ts=7 long-sequence adaptive sampling (4 GPUs)
+
+Reference: exps/default/e_yolox_{s,m}.py, yolox/exp/event_yolox_base.py (options), yolox/data/datasets/gen1.py:313-360 (micro_sum),
+rvt_gen4.py:109-125 (stacked histogram, event_sum), ncaltech.py:26 (sensor size).  All inputs are synthetic (no datasets here)."""
+import torch
+
+from . import data, ops
+
+COMMON = ['embedding', 'arsnn', 'spike_attach', 'True', 'thresh', '1', 'readout', 'sum', 'embedding_depth', '2', 'embedding_ksize', '5',
+          'write_zero', 'True', 'spike_fn', 'atan']
+
+WORKLOADS = {
+    2: dict(name='SYOLOX-S Gen1 304x240 (canvas 256x320), T=3, Tm=4, arsnn sampler, use_spike=True', exp='e-yolox-s', baseline_gpus=1,
+            opts=['T', '3', 'Tm', '4', 'num_classes', '2', 'use_spike', 'True'], sensor=(240, 304), canvas=(256, 320), Tm=4, batch=64,
+            input='events', oracle=dict(use_spike='True')),
+    3: dict(name='SYOLOX-M Gen1 304x240 (canvas 256x320), T=5 with RPD, Tm=4, full_spike_v2', exp='e-yolox-m', baseline_gpus=2,
+            opts=['T', '5', 'Tm', '4', 'num_classes', '2', 'use_spike', 'full_spike_v2'], sensor=(240, 304), canvas=(256, 320), Tm=4, batch=32,
+            input='events', oracle=dict(depth=0.67, width=0.75, use_spike='full_spike_v2', T=5, Tm=4, num_classes=2)),
+    4: dict(name='SYOLOX-M 1Mpx 640x360 stacked histogram nbins=10 (u8 [B,Tm,20,360,640] -> event_sum -> canvas 384x640), T=3, 3 classes, full_spike_v2',
+            exp='e-yolox-m', baseline_gpus=8, opts=['T', '3', 'Tm', '4', 'num_classes', '3', 'use_spike', 'full_spike_v2'], sensor=(360, 640),
+            canvas=(384, 640), Tm=4, batch=32, input='stacked_hist', oracle=dict(depth=0.67, width=0.75, use_spike='full_spike_v2', T=3, Tm=4, num_classes=3)),
+    5: dict(name='SYOLOX-M N-Caltech101 180x240 (canvas 192x256), 100 classes, T=7, Tm=8, Ts=7 long-sequence adaptive sampling, full_spike_v2',
+            exp='e-yolox-m', baseline_gpus=4, opts=['T', '7', 'Tm', '8', 'Ts', '7', 'num_classes', '100', 'use_spike', 'full_spike_v2'],
+            sensor=(180, 240), canvas=(192, 256), Tm=8, batch=32, input='events',
+            oracle=dict(depth=0.67, width=0.75, use_spike='full_spike_v2', T=7, Tm=8, Ts=7, num_classes=100)),
+}
+
+
+def get(config):
+    if int(config) not in WORKLOADS:
+        raise KeyError(f'config {config}: BASELINE.json configs 2..5 are runnable workloads (config 1 is the CPU plumbing case)')
+    return dict(WORKLOADS[int(config)], config=int(config))
+
+
+def exp_opts(w):
+    return COMMON + list(w['opts']) + ['input_size', str(tuple(w['canvas'])), 'test_size', str(tuple(w['canvas']))]
+
+
+def build_exp(w):
+    from yolox.exp import get_exp
+    exp = get_exp(None, w['exp'])
+    exp.merge(exp_opts(w))
+    return exp
+
+
+def device_inputs(w, batch, n_events, device, seed=0):
+    """Synthetic raw input of one batch, resident on the device, and ``inputs_fn() -> (frames [B,1,Tm,2,Hc,Wc] fp32, targets)``, the
+    per-step device pipeline from that raw input (the histogram / the stacked-histogram reduction are part of the step)."""
+    canvas, Tm = tuple(w['canvas']), w['Tm']
+    targets = data.synth_targets(batch, canvas, device)
+    if w['input'] == 'events':
+        ev = data.events_to_device(data.synth_event_batch(batch, n_events, *w['sensor'], seed=seed), device)
+        return ev, (lambda: (data.events_to_frames(ev, Tm, tuple(w['sensor']), canvas), targets))
+    if w['input'] == 'stacked_hist':
+        g = torch.Generator().manual_seed(1 + seed)
+        H, W = w['sensor']
+        hist = torch.poisson(torch.full((batch, Tm, 20, H, W), 0.03), generator=g).clamp_(max=255).to(torch.uint8).to(device)
+        return hist, (lambda: (ops.stacked_hist_event_sum(hist, *canvas), targets))
+    raise KeyError(w['input'])
+
+
+def algorithmic_input_bytes(w, batch, n_events):
+    """bytes of raw input one step reads: 9 B per event, or the u8 stacked histogram"""
+    if w['input'] == 'events':
+        return 9 * batch * n_events
+    H, W = w['sensor']
+    return batch * w['Tm'] * 20 * H * W

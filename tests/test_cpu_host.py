@@ -294,7 +294,25 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['spawned_by_bench'] and rec['gradient_exchange'] == 'flat'
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['spawned_by_bench'] and rec['gradient_exchange'] == '2 buckets'
+    assert rec['config']['config'] == 2
+
+
+def test_bench_selftest_takes_the_other_baseline_configs():
+    """`bench.py --selftest-cpu --config 3 --gpus 2`: the same verb selects BASELINE configs 3..5 (the line names the workload)"""
+    import json
+    r = _run_bench(['--gpus', '2', '--selftest-cpu', '--config', '3', '--steps', '2', '--warmup', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert rec['config']['config'] == 3 and 'SYOLOX-M' in rec['config']['workload'] and 'T=5' in rec['config']['workload']
+    from eas_snn_amd import workloads
+    for c, gpus in ((2, 1), (3, 2), (4, 8), (5, 4)):
+        w = workloads.get(c)
+        assert w['baseline_gpus'] == gpus
+        exp = workloads.build_exp(w)
+        assert tuple(exp.input_size) == tuple(w['canvas']) and exp.Tm == w['Tm']
+    with pytest.raises(KeyError):
+        workloads.get(1)
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
@@ -352,3 +370,127 @@ def test_convolution_statistics_slot_is_only_taken_by_the_tensor_it_belongs_to()
         assert not ops._WANT_CONV_STATS
     finally:
         ops._CONV_STATS_SLOT = None
+
+
+# ------------------------------------------------------------------------------------------------ the drop-in trainer on gloo
+class _ToyStateful(torch.nn.Module):
+    """a module with reset(): counts how often the trainer resets the network"""
+
+    def __init__(self):
+        super().__init__()
+        self.resets = 0
+
+    def reset(self):
+        self.resets += 1
+
+    def forward(self, x):
+        return x
+
+
+class _ToyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embedding = torch.nn.Linear(6, 6)
+        self.backbone = torch.nn.Module()
+        self.backbone.backbone = torch.nn.Sequential(torch.nn.Linear(6, 6), _ToyStateful())
+        self.head = torch.nn.Linear(6, 3)
+
+    def forward(self, x, targets=None):
+        h = torch.tanh(self.backbone.backbone(self.embedding(x)))
+        return {'total_loss': ((self.head(h) - targets) ** 2).mean()}
+
+
+class _ToyExp:
+    max_epoch, ema, input_size, test_size, exp_name, use_spike = 1, True, (8, 8), (8, 8), 'toy', 'True'
+    basic_lr_per_img, print_interval = 1e-2 / 4, 1
+
+    def __init__(self, out):
+        self.output_dir, self.model = out, None
+
+    def get_model(self):
+        if self.model is None:
+            torch.manual_seed(3)
+            self.model = _ToyNet()
+        return self.model
+
+    def get_optimizer(self, batch_size):
+        return torch.optim.Adam(self.model.parameters(), lr=self.basic_lr_per_img * batch_size)
+
+    def get_data_loader(self, batch_size, is_distributed, no_aug=False, cache_img=None):
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        g = torch.Generator().manual_seed(100 + rank)
+        return [(torch.randn(4, 6, generator=g), torch.randn(4, 3, generator=g)) for _ in range(3)]
+
+    def get_lr_scheduler(self, lr, iters_per_epoch):
+        from yolox.utils import LRScheduler
+        return LRScheduler('yoloxwarmcos', lr, iters_per_epoch, self.max_epoch, warmup_epochs=0, warmup_lr_start=0, no_aug_epochs=0, min_lr_ratio=0.05)
+
+    def preprocess(self, inputs, targets, tsize):
+        return inputs, targets
+
+
+def _trainer_worker(tag, out_dir):
+    """yolox.core.Trainer (the drop-in training loop, compat/yolox/core/trainer.py) for one epoch of three iterations on every rank:
+    bucketed gradient exchange with the split backward, Adam, reset_net, EMA, LR schedule, checkpoint."""
+    import types
+    import torch.distributed as dist
+    from yolox.core import Trainer
+    rank, world = dist.get_rank(), dist.get_world_size()
+    exp = _ToyExp(out_dir)
+    tr = Trainer(exp, types.SimpleNamespace(batch_size=8, fp16=False, experiment_name=f'toy_{tag}', ckpt=None, resume=False))
+    tr.train()
+    assert tr.exchange is not None and tr.exchange.nbuckets == 2 and tr.step.cut == ('backbone.backbone',)
+    assert tr.step.graphs is None and len(tr.log) == 3                      # CPU: eager launches; one log row per iteration
+    assert tr.bare_model.backbone.backbone[1].resets == 3 and tr.ema_model.updates == 3
+    # every rank ends with the same parameters (same averaged gradients) that differ from the start
+    torch.manual_seed(3)
+    fresh = _ToyNet()
+    for (n, p), q in zip(tr.bare_model.named_parameters(), fresh.parameters()):
+        both = [torch.zeros_like(p) for _ in range(world)]
+        dist.all_gather(both, p.detach())
+        assert torch.equal(both[0], both[1]), n
+        assert not torch.equal(p.detach(), q.detach()), n
+    # and they are what a single process computes from the two ranks' batches with plain backward + averaged gradients
+    opt = torch.optim.Adam(fresh.parameters(), lr=exp.basic_lr_per_img * 8)
+    loaders = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        loaders.append([(torch.randn(4, 6, generator=g), torch.randn(4, 3, generator=g)) for _ in range(3)])
+    sched = exp.get_lr_scheduler(exp.basic_lr_per_img * 8, 3)
+    for it in range(3):
+        grads = None
+        for r in range(world):
+            fresh.zero_grad(set_to_none=True)
+            fresh(*loaders[r][it])['total_loss'].backward()
+            gs = [p.grad.clone() for p in fresh.parameters()]
+            grads = gs if grads is None else [a + b for a, b in zip(grads, gs)]
+        for p, g_ in zip(fresh.parameters(), grads):
+            p.grad = g_ / world
+        opt.step()
+        for gr in opt.param_groups:
+            gr['lr'] = sched.update_lr(it + 1)
+    for (n, p), q in zip(tr.bare_model.named_parameters(), fresh.parameters()):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6, msg=n)
+    if rank == 0:
+        assert os.path.exists(os.path.join(out_dir, f'toy_{tag}', 'latest_ckpt.pth'))
+    open(os.path.join(out_dir, f'ok_{tag}_{rank}'), 'w').write('ok')
+
+
+def test_trainer_runs_two_ranks_on_gloo(tmp_path):
+    """The drop-in Trainer at world size 2 (gloo): its TrainStep -- the object bench.py measures -- with the bucketed exchange and the
+    backward pass split at the backbone, against a single-process restatement (plain backward, gradients averaged by hand)."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import eas_snn_amd\n"
+        "from yolox.core import launch\n"
+        "from test_cpu_host import _trainer_worker\n"
+        "if __name__ == '__main__':\n"
+        "    launch(_trainer_worker, 2, 1, 0, backend='gloo', dist_url='auto', args=('t', %r))\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), str(tmp_path))
+    script = tmp_path / 'run_trainer.py'
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert (tmp_path / 'ok_t_0').exists() and (tmp_path / 'ok_t_1').exists()

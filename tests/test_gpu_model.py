@@ -567,6 +567,43 @@ def test_train_step_is_bit_reproducible(dev, name):
     assert not diff, f'run-to-run gradient differences in {diff}'
 
 
+def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(dev):
+    """yolox.core.trainer.TrainStep (the iteration tools/train_event.py runs and bench.py measures): the backward pass split at the
+    backbone with the gradients packed into two flat buckets (the N > 1 form, here without a process group), eagerly and as three
+    HIP-graph replays, against the plain one-backward step: every parameter gradient bit-identical."""
+    from eas_snn_amd.parallel import BucketedGradAllReduce
+    from yolox.core.trainer import DEFAULT_CUT, DEFAULT_LOWER, TrainStep
+    g, model = _build('model_s_true_64', dev)
+    model.train()
+    model.head.use_l1 = True
+    x, tg = torch.from_numpy(g['x']).to(dev), torch.from_numpy(g['targets']).to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    torch.cuda.set_stream(torch.cuda.Stream())          # capture needs a non-default stream for the AccumulateGrad nodes
+    try:
+        plain = TrainStep(model, opt, lambda: (x, tg))
+        plain()
+        want = {n: p.grad.clone() for n, p in model.named_parameters()}
+        loss0 = plain.loss.detach().clone()
+        ex = BucketedGradAllReduce(model, split=DEFAULT_LOWER, broadcast_parameters=False)
+        assert ex.nbuckets == 2
+        step = TrainStep(model, opt, lambda: (x, tg), exchange=ex, cut=DEFAULT_CUT)
+        assert step.cut == DEFAULT_CUT
+        step()
+        assert torch.equal(step.loss.detach(), loss0)
+        bad = [n for n, p in model.named_parameters() if not torch.equal(p.grad, want[n])]
+        assert not bad, f'split backward + buckets differ from the plain backward in {bad[:5]}'
+        assert all(p.grad.data_ptr() == v.data_ptr() for ps, vs in zip(ex.buckets, ex.views) for p, v in zip(ps, vs))   # attached views
+        launch = step.capture(warm=1)
+        assert 'three hip-graph replays' in launch
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        bad = [n for n, p in model.named_parameters() if not torch.equal(p.grad, want[n])]
+        assert not bad, f'graph replays differ from the plain backward in {bad[:5]}'
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+
+
 def test_deferred_weight_gradient_reductions_are_bit_identical(dev):
     """ops.deferred_wgrad_reductions(): the slab reductions of all weight gradients of a backward pass in ONE launch at its end
     (eas_conv_wgrad_reduce_many) -- same loss, every parameter gradient bit-identical to the immediate reductions, also on a second
