@@ -174,9 +174,17 @@ class TrainStep:
         for _ in range(warm):
             self.eager()
         torch.cuda.synchronize()
+        # With a process group alive, its watchdog thread polls events of collectives in flight: nothing may be pending when a capture
+        # starts (synchronize), and the capture only polices the capturing thread's own API calls (thread_local) -- kernels launched
+        # on the capturing stream by the autograd thread are recorded either way.
+        mode = 'thread_local' if dist.is_initialized() else 'global'
+
+        def graph(g, pool=None):
+            torch.cuda.synchronize()
+            return torch.cuda.graph(g, pool=pool, capture_error_mode=mode)
         if self.exchange is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with graph(g):
                 self._forward()
                 self._backward_all()
                 self._update()
@@ -185,14 +193,14 @@ class TrainStep:
         elif self.cut:
             pool = torch.cuda.graph_pool_handle()
             g_a, g_b, g_c = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_a, pool=pool):
+            with graph(g_a, pool):
                 self._forward()
                 self._backward_upper()
             self._reduce_upper_async()
-            with torch.cuda.graph(g_b, pool=pool):
+            with graph(g_b, pool):
                 self._backward_lower()
             self._reduce_rest()
-            with torch.cuda.graph(g_c, pool=pool):
+            with graph(g_c, pool):
                 self._update()
             self.graphs = (g_a, g_b, g_c)
             self.launch = ('three hip-graph replays per step (fwd + bwd head/neck | bwd backbone | adam + reset); RCCL all-reduces eager '
@@ -200,15 +208,16 @@ class TrainStep:
         else:
             pool = torch.cuda.graph_pool_handle()
             g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_a, pool=pool):
+            with graph(g_a, pool):
                 self._forward()
                 self._backward_all()
             for b in range(self.exchange.nbuckets):
                 self.exchange.reduce(b)
-            with torch.cuda.graph(g_b, pool=pool):
+            with graph(g_b, pool):
                 self._update()
             self.graphs = (g_a, g_b)
             self.launch = 'two hip-graph replays per step (fwd+bwd+pack | adam+reset) with the eager RCCL all-reduce between them'
+        torch.cuda.synchronize()
         self.replay()                                 # warm-up replay
         return self.launch
 

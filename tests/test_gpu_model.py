@@ -571,6 +571,7 @@ def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(de
     """yolox.core.trainer.TrainStep (the iteration tools/train_event.py runs and bench.py measures): the backward pass split at the
     backbone with the gradients packed into two flat buckets (the N > 1 form, here without a process group), eagerly and as three
     HIP-graph replays, against the plain one-backward step: every parameter gradient bit-identical."""
+    from eas_snn_amd import ops
     from eas_snn_amd.parallel import BucketedGradAllReduce
     from yolox.core.trainer import DEFAULT_CUT, DEFAULT_LOWER, TrainStep
     g, model = _build('model_s_true_64', dev)
@@ -593,7 +594,11 @@ def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(de
         bad = [n for n, p in model.named_parameters() if not torch.equal(p.grad, want[n])]
         assert not bad, f'split backward + buckets differ from the plain backward in {bad[:5]}'
         assert all(p.grad.data_ptr() == v.data_ptr() for ps, vs in zip(ex.buckets, ex.views) for p, v in zip(ps, vs))   # attached views
-        launch = step.capture(warm=1)
+        verify, ops.VERIFY_SMALL_INT = ops.VERIFY_SMALL_INT, False      # the tag check reads the device: not inside a capture
+        try:
+            launch = step.capture(warm=1)
+        finally:
+            ops.VERIFY_SMALL_INT = verify
         assert 'three hip-graph replays' in launch
         for _ in range(2):
             step()
