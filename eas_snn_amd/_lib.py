@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeas_hip.so')
+LIB_PATH = os.environ.get('EAS_LIB') or os.path.join(_HERE, 'libeas_hip.so')      # EAS_LIB: development (a variant build, scripts/build_variant.sh)
 CSRC = os.path.join(_HERE, 'csrc')
 
 _lib = None

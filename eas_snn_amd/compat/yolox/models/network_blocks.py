@@ -72,6 +72,8 @@ class BaseConv(nn.Module):
         """residual / cat: only for converted (spiking) blocks on the fused BN+LIF path -- the SEW shortcut addition and the
         channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer).  emit_bytes: the spikes are
         also written as bytes for a 1x1 convolution that reads them next (callers whose consumer is a 3x3 convolution pass False)."""
+        if ops._TIMER is not None:
+            ops.set_tag(getattr(self, '_eas_name', None))            # development: per-layer timing (scripts/layer_times.py)
         if self.spiking():
             with ops.conv_stats_scope(self.bn._use_batch_stats()):      # the convolution sums its output for the BN behind it
                 y = self.conv(x)

@@ -62,9 +62,12 @@ class KernelTimer:
 
     def __init__(self):
         self.rec = {}
+        self.tagged = {}
 
     def add(self, name, start, end, nbytes, flops=0.0, issue_flops=0.0):
         self.rec.setdefault(name, []).append((start, end, nbytes, flops, issue_flops))
+        if _TAG is not None:                      # development: per-layer breakdown (scripts/layer_times.py)
+            self.tagged.setdefault((_TAG, name), []).append((start, end, nbytes, flops, issue_flops))
 
     def summary(self):
         """per entry point: calls, total ms, algorithmic bytes, algorithmic flops (2 x MAC) and matrix-core flops issued
@@ -78,6 +81,13 @@ class KernelTimer:
 
 
 _TIMER = None
+_TAG = None          # development: label (layer name, phase) attached to the timed calls, see KernelTimer.tagged
+
+
+def set_tag(tag):
+    global _TAG
+    prev, _TAG = _TAG, tag
+    return prev
 
 
 def set_timer(timer):
@@ -1518,6 +1528,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, x_u8)
         ctx.cfg = (k, stride, x_terms, bias is not None)
         ctx.packs = packs        # valid for the backward of this forward (same weights; autograd forbids changing them in between)
+        ctx.tag = _TAG
         return y
 
     @staticmethod
@@ -1528,6 +1539,8 @@ class _ConvFn(torch.autograd.Function):
         gy = _f32c(gy)
         gx = gw = gb = None
         Cin = w.shape[1]
+        if _TIMER is not None and ctx.tag is not None:
+            set_tag(ctx.tag)
         # the input gradient of a stride-1 convolution is eas_conv_fwd on grad_y with the weights packed transposed + flipped
         # (1x1: any channel count -- the 1/4/num_classes-channel prediction convolutions included; 3x3: Cout in whole 8-groups)
         own_d = (ctx.needs_input_grad[0] and stride == 1 and (k == 1 or w.shape[0] % 8 == 0)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""development: per-layer GPU time of the dense convolutions of one training step (HIP events around the C-ABI calls, tagged with the
+BaseConv that issued them; the dual convolutions of CSPLayer / head towers are issued outside a BaseConv and appear under the tag of
+the previous layer).  usage: layer_times.py [config] [batch]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import types
+
+import torch
+
+import eas_snn_amd
+from eas_snn_amd import ops, workloads
+
+
+def main():
+    config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    w = workloads.get(config)
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else w['batch']
+    dev = torch.device('cuda:0')
+    torch.cuda.set_stream(torch.cuda.Stream())
+    ops.set_state_writeback(False)
+    exp = workloads.build_exp(w)
+    exp.ema = False
+    exp.output_dir = '/tmp/eas_layer_times'
+    torch.manual_seed(80)
+    tr = exp.get_trainer(types.SimpleNamespace(batch_size=batch, fp16=False, experiment_name='lt', ckpt=None, resume=False))
+    model = tr.setup()
+    model.head.use_l1 = True
+    for n, m in model.named_modules():
+        object.__setattr__(m, '_eas_name', n)
+    raw, inputs_fn = workloads.device_inputs(w, batch, 200_000, dev)
+    step = tr.step_fn(inputs_fn)
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    reps = 3
+    for _ in range(reps):
+        step.eager()
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    rows = []
+    for (tag, name), items in timer.tagged.items():
+        ms = sum(a.elapsed_time(b) for a, b, *_ in items) / reps
+        fl = sum(it[3] for it in items) / reps
+        isf = sum(it[4] for it in items) / reps
+        rows.append((ms, tag, name, len(items) // reps, fl, isf))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows if r[2] in ('eas_conv_fwd', 'eas_conv_wgrad'))
+    print(f'config {config} batch {batch}: tagged conv time {tot:.2f} ms/step')
+    for ms, tag, name, calls, fl, isf in rows[:70]:
+        tf = fl / ms / 1e9 if ms > 0 and fl > 0 else 0.0
+        ceil = (2500.0 * fl / isf) if isf > 0 else 0.0
+        print(f'{ms:7.3f} ms  {calls:2d} calls  {name:16s} {tf:7.1f} TF  {(tf / ceil if ceil else 0):5.2f} of ceiling   {tag}')
+
+
+if __name__ == '__main__':
+    main()
