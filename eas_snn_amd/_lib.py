@@ -21,6 +21,12 @@ class EasWgradReduceJob(C.Structure):
     _fields_ = [('slabs', C.c_void_p), ('grad_w', C.c_void_p), ('n', C.c_int), ('slabs_count', C.c_int)]
 
 
+class EasSmallconvPackJob(C.Structure):
+    """include/eas_hip.h: EasSmallconvPackJob"""
+    _fields_ = [('w', C.c_void_p), ('wr', C.c_void_p), ('Cin', C.c_int), ('Cout', C.c_int), ('k', C.c_int), ('mode', C.c_int),
+                ('o_total', C.c_int), ('o_off', C.c_int)]
+
+
 class EasCoop(C.Structure):
     """include/eas_hip.h EasCoop: buffers of the in-kernel exchange between the blocks of a channel."""
     _fields_ = [('slots', C.c_void_p), ('tickets', C.c_void_p), ('err', C.c_void_p), ('capacity', C.c_int)]
@@ -89,6 +95,11 @@ PROTOTYPES = {
                                                  C.c_float, C.c_int, C.c_int, C.c_int, _P]),
     'eas_arsnn_tail_fwd': (C.c_int, [_P] * 6 + [C.c_int] * 7 + [_P]),
     'eas_arsnn_tail_bwd': (C.c_int, [_P] * 6 + [C.c_int] * 7 + [_P]),
+    'eas_arsnn_fused_step_fwd': (C.c_int, [_P] * 19 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                                       C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_smallconv_packed_floats': (C.c_int64, [C.c_int] * 3),
+    'eas_smallconv_pack_weights': (C.c_int, [_P, C.c_int, _P]),
+    'eas_smallconv_bwd_input_dual': (C.c_int, [_P] * 6 + [C.c_int] * 4 + [_P]),
     'eas_smallconv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 7 + [_P]),
     'eas_smallconv_bwd_input': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
     'eas_smallconv_bwd_weight': (C.c_int, [_P] * 5 + [C.c_int] * 6 + [_P]),
@@ -154,7 +165,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError = ABI mismatch, also loud
             fn.restype = res
             fn.argtypes = args
-        if handle.eas_abi_version() != 3:
+        if handle.eas_abi_version() != 4:
             raise EasHipError('libeas_hip.so ABI version mismatch; rebuild')
         _lib = handle
     return _lib

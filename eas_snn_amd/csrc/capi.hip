@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int eas_abi_version(void) { return 3; }   // 3: eas_conv_fwd_stats, EasBnPending.pitch; 2: eas_bn_lif_fwd_ex gained spikes_u8; eas_conv_fwd_u8 / eas_conv_wgrad_u8, *_patan, eas_stacked_hist_event_sum
+int eas_abi_version(void) { return 4; }   // 4: sampler convolutions take weights arranged by eas_smallconv_pack_weights; eas_arsnn_fused_step_fwd, eas_smallconv_bwd_input_dual; 3: eas_conv_fwd_stats, EasBnPending.pitch; 2: eas_bn_lif_fwd_ex gained spikes_u8; eas_conv_fwd_u8 / eas_conv_wgrad_u8, *_patan, eas_stacked_hist_event_sum
 
 const char* eas_status_string(int status) {
     switch (status) {

@@ -13,83 +13,22 @@
 #include <stdlib.h>
 
 #include "eas_common.h"
+#include "smallconv_core.h"
 
 namespace {
 
-constexpr int TH = 16, TW = 64, LWS = 80, NT = 256;
-
-template <int K>
-struct Geo {
-    static constexpr int PAD = K / 2;
-    static constexpr int LH = TH + K - 1;
-    static constexpr int LW = TW + K - 1;
-    static constexpr int NV = 4 + K - 1;          // input values a thread needs per row
-    static constexpr int NV4 = (NV + 3) / 4;
-};
-
-// Tile staging with register prefetch (issue-early / write-late): every thread owns PER elements of the
-// [CIN][LH][LW] input window (origin (y0-PAD, x0-PAD), zero filled outside the image).  `load` issues all PER
-// global loads back to back (out-of-range lanes read element 0 and are zeroed by a select, so there are no
-// branches and the loads stay in flight across the compute phase of the previous tile); `store` writes them to
-// LDS (channel planes PLANE floats apart, rows LWS floats apart).
-template <int CIN, int K, int PLANE, int PITCH = LWS>
-struct Stager {
-    using G = Geo<K>;
-    static constexpr int NE = CIN * G::LH * G::LW;
-    static constexpr int PER = (NE + NT - 1) / NT;
-    // Which window element a thread stages does not depend on the tile: (channel, row, column) -> image-relative offset, packed
-    // (row, column) and LDS offset are worked out ONCE per thread (the divisions by the window width / height per element and
-    // tile were as many vector-ALU instructions as the convolution's FMAs); per tile only the bounds test and one add remain.
-    int rel[PER];        // (c * H + r) * W + col, relative to the window origin
-    int rc[PER];         // r | col << 8, or -1 for the surplus elements of the last slice
-    int lofs[PER];       // c * PLANE + r * PITCH + col
-
-    __device__ __forceinline__ void init(int H, int W) {
-#pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int idx = threadIdx.x + it * NT;
-            const int col = idx % G::LW;
-            const int r = (idx / G::LW) % G::LH;
-            const int c = idx / (G::LW * G::LH);
-            rel[it] = (c * H + r) * W + col;
-            rc[it] = idx < NE ? (r | (col << 8)) : -1;
-            lofs[it] = c * PLANE + r * PITCH + col;
-        }
-    }
-
-    __device__ __forceinline__ void load(const float* __restrict__ x, float (&pre)[PER], int n, int H, int W, int y0, int x0) const {
-        const int oy = y0 - G::PAD, ox = x0 - G::PAD;
-        const float* win = x + ((int64_t)n * CIN * H + oy) * W + ox;       // window origin (may lie outside the image)
-#pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int r = rc[it] & 255, col = rc[it] >> 8;
-            const unsigned gy = (unsigned)(oy + r), gx = (unsigned)(ox + col);
-            const bool ok = rc[it] >= 0 && gy < (unsigned)H && gx < (unsigned)W;
-            const float v = *(ok ? win + rel[it] : x);
-            pre[it] = ok ? v : 0.f;
-        }
-    }
-
-    __device__ __forceinline__ void store(float* __restrict__ lds, const float (&pre)[PER]) const {
-#pragma unroll
-        for (int it = 0; it < PER; ++it)
-            if (rc[it] >= 0) lds[lofs[it]] = pre[it];
-    }
-};
-
-// FWD:   y[n][o] = b[o] + sum_{i,ky,kx} w[o][i][ky][kx] * x[n][i][. + ky - PAD][. + kx - PAD]          (CIN=Cin, COUT=Cout)
-// DGRAD: gx[n][o] = sum_{i,ky,kx} w[i][o][K-1-ky][K-1-kx] * gy[n][i][. + ky - PAD][. + kx - PAD]       (CIN=Cout, COUT=Cin)
-template <int CIN, int COUT, int K, bool DGRAD>
-__global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// y[n][o] = (b[o]) + sum_{i,ky,kx} wr[i][ky][kx][o] * x[n][i][. + ky - PAD][. + kx - PAD], optional ReLU, optional mask (result zeroed
+// where mask <= 0: the ReLU in front of the convolution whose input gradient this is).  DUAL: COUT = 2 * CO outputs of which the
+// first CO go to y (masked by mask) and the rest to y2 (masked by mask2): two input gradients that share grad_y in one pass.
+template <int CIN, int COUT, int K, bool DUAL>
+__global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restrict__ x, const float* __restrict__ wr,
                                                           const float* __restrict__ b, const float* __restrict__ mask,
-                                                          float* __restrict__ y, int N, int H, int W, int relu) {
+                                                          float* __restrict__ y, const float* __restrict__ mask2, float* __restrict__ y2, int N,
+                                                          int H, int W, int relu) {
     using G = Geo<K>;
-    // Row pitch 128 floats (a multiple of the 64-bank row): ds_read_b128 serves the lanes in the groups {0-3,12-15,20-27},
-    // {4-11,16-19,28-31}, ...; with lane = (row << 4) | column-quad a group then touches column quads 0-3 and 12-15 of one row and
-    // 4-11 of the next -- every bank once.  (The earlier pitch of 80 floats shifted the second row by 16 banks onto the first
-    // row's quads 12-15: PMC showed 62 % of the LDS cycles as bank conflicts; the kernel gained 3 %, it is not LDS-bound.)
-    constexpr int LWF = 128;
+    constexpr int LWF = 128;        // row pitch: a multiple of the 64-bank row (conflict-free ds_read_b128 for this lane -> (row, quad) map)
     constexpr int PLANE = G::LH * LWF;
+    constexpr int CO = DUAL ? COUT / 2 : COUT;
     using St = Stager<CIN, K, PLANE, LWF>;
     St st;
     st.init(H, W);
@@ -98,70 +37,93 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
     const int ntiles = N * tiles_x * tiles_y;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     float pre[St::PER];
+    unsigned okm = 0;
     int tile = blockIdx.x;
     if (tile < ntiles)
-        st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
+        okm = st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
     for (; tile < ntiles; tile += gridDim.x) {
         const int n = tile / (tiles_x * tiles_y);
         const int ty0 = ((tile / tiles_x) % tiles_y) * TH, tx0 = (tile % tiles_x) * TW;
         __syncthreads();                               // readers of the previous tile are done
-        st.store(lds, pre);
+        st.store(lds, pre, okm);
         __syncthreads();
         const int nxt = tile + gridDim.x;              // next tile's loads fly during this tile's FMAs
         if (nxt < ntiles)
-            st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
-        float acc[COUT][4];
+            okm = st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
+        f2 acc[4][COUT / 2];
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) {
-            const float bv = (!DGRAD && b) ? b[o] : 0.f;
+        for (int op = 0; op < COUT / 2; ++op) {
+            const f2 bv = b ? f2{b[2 * op], b[2 * op + 1]} : f2{0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[o][j] = bv;
-        }
-#pragma unroll 1
-        for (int i = 0; i < CIN; ++i) {                // not unrolled: keeps the live set small
-#pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                float v[G::NV4 * 4];
-                const float4* row = reinterpret_cast<const float4*>(lds + i * PLANE + (ty + ky) * LWF + 4 * tx);
-#pragma unroll
-                for (int q = 0; q < G::NV4; ++q) {
-                    const float4 t = row[q];
-                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-                }
-#pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-                    for (int o = 0; o < COUT; ++o) {
-                        const float wv = DGRAD ? w[((i * COUT + o) * K + (K - 1 - ky)) * K + (K - 1 - kx)]
-                                               : w[((o * CIN + i) * K + ky) * K + kx];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(wv, v[j + kx], acc[o][j]);
-                    }
-                }
-            }
+            for (int j = 0; j < 4; ++j) acc[j][op] = bv;
         }
         const int oy = ty0 + ty, ox = tx0 + 4 * tx;
-        if (oy < H && ox < W) {
+        const bool inside = oy < H && ox < W, vec = ox + 3 < W && (W & 3) == 0;
+        // the ReLU masks of the thread's outputs are requested in front of the arithmetic, like the next tile (vector form only)
+        float4 mk4[COUT];
+        if (mask && inside && vec) {
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
-                const int64_t off = (((int64_t)n * COUT + o) * H + oy) * W + ox;
-                float r[4] = {acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+                const bool second = DUAL && o >= CO;
+                mk4[o] = *reinterpret_cast<const float4*>((second ? mask2 : mask) + ((((int64_t)n * CO + (second ? o - CO : o)) * H + oy) * W + ox));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sc_accumulate<CIN, COUT, K, LWF>(lds, PLANE, wr, acc, tx, ty);
+        if (inside) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const bool second = DUAL && o >= CO;
+                const int oc = second ? o - CO : o;
+                const int64_t off = (((int64_t)n * CO + oc) * H + oy) * W + ox;
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = (o & 1) ? acc[j][o >> 1].y : acc[j][o >> 1].x;
                 if (relu) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j], 0.f);
                 }
-                if (ox + 3 < W && (W & 3) == 0) {
-                    if (mask) {
-                        const float4 m = *reinterpret_cast<const float4*>(mask + off);
+                const float* mk = second ? mask2 : mask;
+                float* dst = second ? y2 : y;
+                if (vec) {
+                    if (mk) {
+                        const float4 m = mk4[o];
                         r[0] = m.x > 0.f ? r[0] : 0.f; r[1] = m.y > 0.f ? r[1] : 0.f;
                         r[2] = m.z > 0.f ? r[2] : 0.f; r[3] = m.w > 0.f ? r[3] : 0.f;
                     }
-                    *reinterpret_cast<float4*>(y + off) = make_float4(r[0], r[1], r[2], r[3]);
+                    *reinterpret_cast<float4*>(dst + off) = make_float4(r[0], r[1], r[2], r[3]);
                 } else {
-                    for (int j = 0; j < 4 && ox + j < W; ++j) y[off + j] = (mask && !(mask[off + j] > 0.f)) ? 0.f : r[j];
+                    for (int j = 0; j < 4 && ox + j < W; ++j) dst[off + j] = (mk && !(mk[off + j] > 0.f)) ? 0.f : r[j];
                 }
             }
         }
+    }
+}
+
+// wr[ci][ky][kx][o_total] from w[Cout][Cin][k][k]: mode 0 (forward) wr[i][ky][kx][o_off + o] = w[o][i][ky][kx];
+// mode 1 (input gradient: the kernel's input channels are the convolution's OUTPUT channels) wr[co][ky][kx][o_off + ci] =
+// w[co][ci][k-1-ky][k-1-kx].  Up to 8 tensors per launch (jobs by value: graph-capturable, no device table).
+constexpr int kPackJobs = 8;
+struct PackJobs {
+    const float* w[kPackJobs];
+    float* wr[kPackJobs];
+    int Cin[kPackJobs], Cout[kPackJobs], k[kPackJobs], mode[kPackJobs], o_total[kPackJobs], o_off[kPackJobs];
+};
+
+__global__ void smallconv_pack_kernel(const PackJobs jobs) {
+    const int j = blockIdx.x;
+    const float* __restrict__ w = jobs.w[j];
+    float* __restrict__ wr = jobs.wr[j];
+    const int Cin = jobs.Cin[j], Cout = jobs.Cout[j], k = jobs.k[j], mode = jobs.mode[j], ot = jobs.o_total[j], oo = jobs.o_off[j];
+    const int ni = mode ? Cout : Cin, no = mode ? Cin : Cout;
+    for (int e = threadIdx.x; e < ni * k * k * no; e += blockDim.x) {
+        const int o = e % no;
+        int rest = e / no;
+        const int kx = rest % k; rest /= k;
+        const int ky = rest % k;
+        const int i = rest / k;
+        const float v = mode ? w[((i * Cin + o) * k + (k - 1 - ky)) * k + (k - 1 - kx)] : w[((o * Cin + i) * k + ky) * k + kx];
+        wr[((i * k + ky) * k + kx) * ot + oo + o] = v;
     }
 }
 
@@ -205,6 +167,7 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
     st.init(H, W);
     constexpr int GPER = (LG / 4 + NT - 1) / NT;
     float pre[St::PER];
+    unsigned okm = 0;
     float4 preg[GPER];
     auto load_gy = [&](int t) {
         const int n = t / (tiles_x * tiles_y);
@@ -231,12 +194,12 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
     };
     int tile = blockIdx.x;
     if (tile < ntiles) {
-        st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
+        okm = st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
         load_gy(tile);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                           // previous tile's readers are done
-        st.store(lx, pre);
+        st.store(lx, pre, okm);
 #pragma unroll
         for (int it = 0; it < GPER; ++it) {
             const int idx = threadIdx.x + it * NT;
@@ -245,7 +208,7 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
         __syncthreads();
         const int nxt = tile + gridDim.x;          // next tile's loads fly during this tile's FMAs
         if (nxt < ntiles) {
-            st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
+            okm = st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
             load_gy(nxt);
         }
         for (int u = grp; u < UNITS; u += GROUPS) {
@@ -335,15 +298,15 @@ __global__ __launch_bounds__(EAS_WAVE) void smallconv_wgrad_finalize(const float
 constexpr int kWgradBlocks = 512;
 constexpr int kConvBlocks = 256 * 6;
 
-template <int CIN, int COUT, bool DGRAD>
-int launch_conv_k(int k, const float* x, const float* w, const float* b, const float* mask, float* y, int N, int H, int W,
-                  int relu, hipStream_t st) {
+template <int CIN, int COUT, bool DUAL>
+int launch_conv_k(int k, const float* x, const float* wr, const float* b, const float* mask, float* y, const float* mask2, float* y2, int N,
+                  int H, int W, int relu, hipStream_t st) {
     int tiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     if (tiles > kConvBlocks) tiles = kConvBlocks;      // persistent blocks loop over tiles with register prefetch
     switch (k) {
-        case 3: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 3, DGRAD>), dim3(tiles), dim3(NT), 0, st, x, w, b, mask, y, N, H, W, relu); break;
-        case 5: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 5, DGRAD>), dim3(tiles), dim3(NT), 0, st, x, w, b, mask, y, N, H, W, relu); break;
-        case 7: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 7, DGRAD>), dim3(tiles), dim3(NT), 0, st, x, w, b, mask, y, N, H, W, relu); break;
+        case 3: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 3, DUAL>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N, H, W, relu); break;
+        case 5: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 5, DUAL>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N, H, W, relu); break;
+        case 7: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 7, DUAL>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N, H, W, relu); break;
         default: return EAS_ERR_UNSUPPORTED;
     }
     EAS_CHECK_LAUNCH();
@@ -373,58 +336,67 @@ bool wgrad_on_mfma(int k) {
     return k >= 5;
 }
 
-// Forward / input gradient at k = 5 also exist in a matrix-core form (smallconv_mfma.hip).  It is exact and correct but NOT faster than
-// this file's vector-ALU kernel (64 images of 256x320, 4 -> 4: 98 us against 90 us; see the header there), so it only runs on request:
-// EAS_SC_FORM=mfma (read per call so that a test can compare the two forms in one process).
-bool conv_on_mfma(int k) {
-    const char* e = getenv("EAS_SC_FORM");
-    return e && e[0] == 'm' && k == 5;
-}
-
 }  // namespace
 
-// smallconv_mfma.hip
-int eas_sc5_mfma(const float* x, const float* w, const float* b, const float* mask, float* y, int N, int Cin, int Cout, int H, int W,
-                 int relu, int dgrad, int x_terms, hipStream_t st);
 // smallconv_wgrad_mfma.hip
 int eas_sw_mfma_partials(const float* gy, const float* x, float* partial, int max_blocks, int N, int Cin, int Cout, int H, int W,
                          int k, hipStream_t st);
 
 extern "C" {
 
-int eas_smallconv_fwd(const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout, int H,
+int64_t eas_smallconv_packed_floats(int n_in, int k, int o_total) { return (int64_t)n_in * k * k * o_total; }
+
+int eas_smallconv_pack_weights(const EasSmallconvPackJob* jobs, int njobs, eas_stream_t stream) {
+    if (!jobs || njobs < 1 || njobs > kPackJobs) return EAS_ERR_INVALID_ARG;
+    PackJobs pj{};
+    for (int j = 0; j < njobs; ++j) {
+        const EasSmallconvPackJob& q = jobs[j];
+        const int no = q.mode ? q.Cin : q.Cout;
+        if (!q.w || !q.wr || q.Cin < 1 || q.Cout < 1 || (q.k != 3 && q.k != 5 && q.k != 7) || (q.mode != 0 && q.mode != 1) || q.o_off < 0 ||
+            q.o_off + no > q.o_total || ((uintptr_t)q.wr & 15))
+            return EAS_ERR_INVALID_ARG;
+        pj.w[j] = q.w; pj.wr[j] = q.wr; pj.Cin[j] = q.Cin; pj.Cout[j] = q.Cout; pj.k[j] = q.k; pj.mode[j] = q.mode;
+        pj.o_total[j] = q.o_total; pj.o_off[j] = q.o_off;
+    }
+    EAS_CLEAR_ERR();
+    hipLaunchKernelGGL(smallconv_pack_kernel, dim3(njobs), dim3(256), 0, eas_s(stream), pj);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_smallconv_fwd(const float* x, const float* wr, const float* b, float* y, int N, int Cin, int Cout, int H,
                       int W, int k, int relu, eas_stream_t stream) {
-    if (!x || !w || !y || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
-    if (bad_ptr(y)) return EAS_ERR_INVALID_ARG;
+    if (!x || !wr || !y || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
+    if (bad_ptr(y) || bad_ptr(wr)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
-    if (conv_on_mfma(k)) {
-        const int rc = eas_sc5_mfma(x, w, b, nullptr, y, N, Cin, Cout, H, W, relu, 0, 3, st);
-        if (rc == EAS_OK) { EAS_CHECK_LAUNCH(); return EAS_OK; }
-        if (rc != EAS_ERR_UNSUPPORTED) return rc;
-    }
-    if (Cin == 2 && Cout == 4) return launch_conv_k<2, 4, false>(k, x, w, b, nullptr, y, N, H, W, relu, st);
-    if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, false>(k, x, w, b, nullptr, y, N, H, W, relu, st);
-    if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, false>(k, x, w, b, nullptr, y, N, H, W, relu, st);
+    if (Cin == 2 && Cout == 4) return launch_conv_k<2, 4, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st);
+    if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st);
+    if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st);
     return EAS_ERR_UNSUPPORTED;
 }
 
-int eas_smallconv_bwd_input(const float* grad_y, const float* w, const float* relu_mask, float* grad_x, int N, int Cin,
+int eas_smallconv_bwd_input(const float* grad_y, const float* wr, const float* relu_mask, float* grad_x, int N, int Cin,
                             int Cout, int H, int W, int k, eas_stream_t stream) {
-    if (!grad_y || !w || !grad_x || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
-    if (bad_ptr(grad_x) || bad_ptr(relu_mask)) return EAS_ERR_INVALID_ARG;
+    if (!grad_y || !wr || !grad_x || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
+    if (bad_ptr(grad_x) || bad_ptr(relu_mask) || bad_ptr(wr)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
-    if (conv_on_mfma(k)) {
-        const int rc = eas_sc5_mfma(grad_y, w, nullptr, relu_mask, grad_x, N, Cin, Cout, H, W, 0, 1, 3, st);
-        if (rc == EAS_OK) { EAS_CHECK_LAUNCH(); return EAS_OK; }
-        if (rc != EAS_ERR_UNSUPPORTED) return rc;
-    }
     // the kernel's "input" is grad_y (Cout channels), its "output" grad_x (Cin channels)
-    if (Cin == 2 && Cout == 4) return launch_conv_k<4, 2, true>(k, grad_y, w, nullptr, relu_mask, grad_x, N, H, W, 0, st);
-    if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, true>(k, grad_y, w, nullptr, relu_mask, grad_x, N, H, W, 0, st);
-    if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, true>(k, grad_y, w, nullptr, relu_mask, grad_x, N, H, W, 0, st);
+    if (Cin == 2 && Cout == 4) return launch_conv_k<4, 2, false>(k, grad_y, wr, nullptr, relu_mask, grad_x, nullptr, nullptr, N, H, W, 0, st);
+    if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, false>(k, grad_y, wr, nullptr, relu_mask, grad_x, nullptr, nullptr, N, H, W, 0, st);
+    if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, false>(k, grad_y, wr, nullptr, relu_mask, grad_x, nullptr, nullptr, N, H, W, 0, st);
     return EAS_ERR_UNSUPPORTED;
+}
+
+// two input gradients of the same grad_y [N][4][H][W] in one pass: grad_xa = mask_a (.) convT(w_a, grad_y), grad_xb = mask_b (.) convT(w_b,
+// grad_y) for two 4 -> 4 convolutions; wr = both weight tensors packed with mode 1, o_total 8, o_off 0 / 4
+int eas_smallconv_bwd_input_dual(const float* grad_y, const float* wr, const float* mask_a, const float* mask_b, float* grad_xa,
+                                 float* grad_xb, int N, int H, int W, int k, eas_stream_t stream) {
+    if (!grad_y || !wr || !grad_xa || !grad_xb || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
+    if (bad_ptr(grad_xa) || bad_ptr(grad_xb) || bad_ptr(mask_a) || bad_ptr(mask_b) || bad_ptr(wr)) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    return launch_conv_k<4, 8, true>(k, grad_y, wr, nullptr, mask_a, grad_xa, mask_b, grad_xb, N, H, W, 0, eas_s(stream));
 }
 
 int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k) {

@@ -995,28 +995,62 @@ def event_time_surface(t, x, y, p, sample_offsets, num_slices, H, W, tau=50e3):
 
 
 # ------------------------------------------------------------------------------------------------ K3
-def smallconv_fwd(x, w, b, relu=False, out=None):
+def smallconv_pack(jobs):
+    """Arrange sampler convolution weights for the vector-ALU kernels (eas_smallconv_pack_weights; up to 8 per launch).
+    jobs: (w [Cout,Cin,k,k], mode, o_total, o_off, wr or None) -- mode 0 forward, mode 1 input gradient; several weights may share one
+    packed tensor ``wr`` side by side along its output axis (o_total / o_off).  Returns the packed tensors, one per job."""
+    L = _lib.lib()
+    arr = (_lib.EasSmallconvPackJob * len(jobs))()
+    outs = []
+    for j, (w, mode, o_total, o_off, wr) in enumerate(jobs):
+        w = _f32c(w)
+        Cout, Cin, k = w.shape[0], w.shape[1], w.shape[-1]
+        if wr is None:
+            wr = torch.empty(L.eas_smallconv_packed_floats(Cout if mode else Cin, k, o_total), dtype=torch.float32, device=w.device)
+        arr[j] = _lib.EasSmallconvPackJob(w.data_ptr(), wr.data_ptr(), Cin, Cout, k, int(mode), int(o_total), int(o_off))
+        outs.append(wr)
+    check(L.eas_smallconv_pack_weights(arr, len(jobs), stream()), 'eas_smallconv_pack_weights')
+    return outs
+
+
+def smallconv_fwd(x, w, b, relu=False, out=None, wr=None):
     """Direct LDS-tiled conv (stride 1, 'same' padding) for the sampler's tiny-channel stacks.  ``out``: a contiguous
-    [N,Cout,H,W] destination (e.g. one step's slice of a time-batched buffer) instead of a fresh tensor."""
-    x, w = _f32c(x), _f32c(w)
+    [N,Cout,H,W] destination (e.g. one step's slice of a time-batched buffer) instead of a fresh tensor.  ``wr``: the weight already
+    arranged by ``smallconv_pack`` (mode 0); else it is arranged here."""
+    x = _f32c(x)
     N, Cin, H, W = x.shape
     Cout, k = w.shape[0], w.shape[-1]
+    if wr is None:
+        wr = smallconv_pack([(w, 0, Cout, 0, None)])[0]
     y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device) if out is None else out
     assert y.is_contiguous() and y.shape == (N, Cout, H, W)
-    _call('eas_smallconv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_smallconv_fwd, ptr(x), ptr(w), ptr(b), ptr(y), N, Cin, Cout,
+    _call('eas_smallconv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_smallconv_fwd, ptr(x), ptr(wr), ptr(b), ptr(y), N, Cin, Cout,
           H, W, k, int(relu), stream())
     return y
 
 
-def smallconv_bwd_input(gy, w, relu_mask=None, out=None):
-    gy, w = _f32c(gy), _f32c(w)
+def smallconv_bwd_input(gy, w, relu_mask=None, out=None, wr=None):
+    """``wr``: the weight arranged by ``smallconv_pack`` with mode 1"""
+    gy = _f32c(gy)
     N, Cout, H, W = gy.shape
     Cin, k = w.shape[1], w.shape[-1]
+    if wr is None:
+        wr = smallconv_pack([(w, 1, Cin, 0, None)])[0]
     gx = torch.empty((N, Cin, H, W), dtype=torch.float32, device=gy.device) if out is None else out
     assert gx.is_contiguous() and gx.shape == (N, Cin, H, W)
-    _call('eas_smallconv_bwd_input', 4 * (gy.numel() + gx.numel()), _lib.lib().eas_smallconv_bwd_input, ptr(gy), ptr(w),
+    _call('eas_smallconv_bwd_input', 4 * (gy.numel() + gx.numel()), _lib.lib().eas_smallconv_bwd_input, ptr(gy), ptr(wr),
           ptr(relu_mask), ptr(gx), N, Cin, Cout, H, W, k, stream())
     return gx
+
+
+def smallconv_bwd_input_dual(gy, wr8, k, mask_a, mask_b, out_a, out_b):
+    """input gradients of two 4 -> 4 convolutions that received the same grad_y [N,4,H,W], in one pass (wr8: both weights packed with
+    mode 1 side by side, o_total 8); each masked by the ReLU output in front of its convolution"""
+    gy = _f32c(gy)
+    N, C4, H, W = gy.shape
+    assert C4 == 4 and out_a.is_contiguous() and out_b.is_contiguous() and out_a.shape == gy.shape == out_b.shape
+    _call('eas_smallconv_bwd_input', 4 * 3 * gy.numel(), _lib.lib().eas_smallconv_bwd_input_dual, ptr(gy), ptr(wr8), ptr(mask_a), ptr(mask_b),
+          ptr(out_a), ptr(out_b), N, H, W, int(k), stream())
 
 
 def smallconv_bwd_weight(gy, x, w):
@@ -1031,20 +1065,28 @@ def smallconv_bwd_weight(gy, x, w):
     return gw, gb
 
 
-def _conv_stack_fwd(x, params, k, mids=None):
+def _conv_stack_fwd(x, params, k, mids=None, packs=None):
     """Conv(k, pad k//2) [+ ReLU + Conv]*: returns (out, inputs of every conv).  ReLU is fused into the producing conv.
-    ``mids[i]``: destination of conv i's output for i < n-1 (the input of conv i+1)."""
+    ``mids[i]``: destination of conv i's output for i < n-1 (the input of conv i+1); ``packs[i]``: conv i's arranged weight."""
     ins = []
     n = len(params) // 2
     for i in range(n):
         ins.append(x)
-        x = smallconv_fwd(x, params[2 * i], params[2 * i + 1], relu=(i < n - 1), out=mids[i] if mids is not None and i < n - 1 else None)
+        x = smallconv_fwd(x, params[2 * i], params[2 * i + 1], relu=(i < n - 1), out=mids[i] if mids is not None and i < n - 1 else None,
+                          wr=packs[i] if packs is not None else None)
     return x, ins
+
+
+# K3 in one launch per micro-step (eas_arsnn_fused_step_fwd): the second convolutions of the input stack and of the gate stack run inside
+# the step kernel, the two input gradients of those convolutions share one pass over the step's gradient (eas_smallconv_bwd_input_dual).
+# EAS_ARSNN_FUSED=0: development switch, the separate launches.
+ARSNN_FUSED = os.environ.get('EAS_ARSNN_FUSED', '1') == '1'
 
 
 class _ARSNNFn(torch.autograd.Function):
     """Whole adaptive-sampler loop as ONE autograd node (embedding.py:141-226): conv stacks via eas_smallconv_*,
-    the per-step integrate / fire / reset / segment-write via eas_arsnn_step_*.
+    the per-step integrate / fire / reset / segment-write via eas_arsnn_step_* (depth-2 stacks with four hidden channels: the second
+    convolutions inside eas_arsnn_fused_step_fwd).
 
     ``running`` in the configuration selects the plain gated recurrence of the simpler embeddings instead
     (SpikingEmbedding "rsnn" embedding.py:229-316, LIFEmbedding "snn" :28-76): no segments, the output is the running sum
@@ -1065,12 +1107,25 @@ class _ARSNNFn(torch.autograd.Function):
         dev = ev.device
         need_grad = any(ctx.needs_input_grad[2:]) or ctx.needs_input_grad[0]
         st = stream()
-        if d_in:
-            X, in_ins = _conv_stack_fwd(ev.view(Tm * N, Cin, H, W), pin, k)
+        # every convolution weight arranged for the kernels by ONE launch
+        jobs = [(pin[2 * i], 0, pin[2 * i].shape[0], 0, None) for i in range(d_in)] + [(pg[2 * i], 0, pg[2 * i].shape[0], 0, None) for i in range(d_gate)]
+        pk = smallconv_pack(jobs) if jobs else []
+        pk_in, pk_g = pk[:d_in], pk[d_in:]
+        fused = bool(ARSNN_FUSED and d_in == 2 and d_gate in (0, 2) and W % 4 == 0 and pin[2].shape[:2] == (4, 4) and pin[0].shape[0] == 4
+                     and (d_gate == 0 or (pg[2].shape[:2] == (4, 4) and pg[0].shape[0] == 4)) and _CONV_SINK is None and Tm > 0)
+        if fused:
+            # first convolution + ReLU of the input stack for all Tm steps at once; the second one runs inside the step kernel
+            A_in = smallconv_fwd(ev.view(Tm * N, Cin, H, W), pin[0], pin[1], relu=True, wr=pk_in[0]).view(Tm, N, 4, H, W)
+            in_ins = [ev.view(Tm * N, Cin, H, W), A_in.view(Tm * N, 4, H, W)]
+            X = None
+            C2 = 2
+        elif d_in:
+            X, in_ins = _conv_stack_fwd(ev.view(Tm * N, Cin, H, W), pin, k, packs=pk_in)
             X = X.view(Tm, N, X.shape[1], H, W)
+            C2 = X.shape[2] // 2
         else:
             X, in_ins = ev, []
-        C2 = X.shape[2] // 2
+            C2 = X.shape[2] // 2
         shape = (N, C2, H, W)
         v = vsum = None          # first step: the kernel takes zero potentials / sums, seg = 0, t_last = -1 (no zero fills)
         if os.environ.get('EAS_ARSNN_ZERO_FILL') == '1':     # development: explicit zero state tensors
@@ -1092,24 +1147,33 @@ class _ARSNNFn(torch.autograd.Function):
         else:
             gate_in = None
             spike = None if fast0 else torch.zeros(shape, device=dev)
-        seg = torch.empty(shape, dtype=torch.int32, device=dev)
-        tl = torch.empty(shape, dtype=torch.int32, device=dev)
+        seg = torch.empty(shape, dtype=torch.int8, device=dev)        # segment counter 0..Ts and last-spike step -1..Tm-1: one byte each
+        tl = torch.empty(shape, dtype=torch.int8, device=dev)
         if Tm == 0 or v is not None:
             seg.zero_(); tl.fill_(-1)
         agg = torch.zeros((1 if running else Ts,) + shape, device=dev)
-        zero_rec = None if d_gate else torch.zeros((N, 2 * C2, H, W), device=dev)
+        zero_rec = None if (d_gate or fused) else torch.zeros((N, 2 * C2, H, W), device=dev)
         saved = []
         t_rec = []
         for t in range(Tm):
             if _CONV_SINK is not None and d_gate:
                 _CONV_SINK.sampler_spikes.append(spike)
+            a_g = r_const = R = None
+            g_ins = []
             if d_gate and t == 0 and fast0:
-                R1, g_ins = _conv_stack_fwd(torch.zeros((1,) + shape[1:], device=dev), pg, k)         # one image
-                R = R1.expand(N, *R1.shape[1:]).contiguous()
+                R1, g_ins = _conv_stack_fwd(torch.zeros((1,) + shape[1:], device=dev), pg, k, packs=pk_g)         # one image
+                if fused:
+                    r_const = R1[0]
+                else:
+                    R = R1.expand(N, *R1.shape[1:]).contiguous()
+            elif d_gate and fused:
+                # first gate convolution + ReLU (kept for its weight gradient); the second one runs inside the step kernel
+                a_g = smallconv_fwd(spike, pg[0], pg[1], relu=True, out=gate_in[1][t] if keep else None, wr=pk_g[0])
+                g_ins = [spike, a_g]
             elif d_gate:
-                R, g_ins = _conv_stack_fwd(spike, pg, k, [gate_in[i + 1][t] for i in range(d_gate - 1)] if keep else None)
-            else:
-                R, g_ins = zero_rec, []
+                R, g_ins = _conv_stack_fwd(spike, pg, k, [gate_in[i + 1][t] for i in range(d_gate - 1)] if keep else None, packs=pk_g)
+            elif not fused:
+                R = zero_rec
             v_n, vs_n = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
             sp_n = gate_in[0][t + 1] if keep and t + 1 < Tm else torch.empty(shape, device=dev)
             if need_grad:
@@ -1117,14 +1181,20 @@ class _ARSNNFn(torch.autograd.Function):
                 seg_b, tl_b = torch.empty_like(seg), torch.empty_like(tl)
             else:
                 gate = vn = seg_b = tl_b = None
-            _call('eas_arsnn_step_fwd', 38 * v_n.numel(), L.eas_arsnn_step_fwd, ptr(X[t]), ptr(R), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
-                  ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, 3 if running else readout,
-                  int(sat), thresh, v_reset, int(soft), N, C2, HW, st)
+            if fused:
+                _call('eas_arsnn_step_fwd', 38 * v_n.numel(), L.eas_arsnn_fused_step_fwd, ptr(A_in[t]), ptr(pk_in[1]), ptr(pin[3]), ptr(a_g),
+                      ptr(pk_g[1]) if d_gate else None, ptr(pg[3]) if d_gate else None, ptr(r_const), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
+                      ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, 3 if running else readout,
+                      int(sat), thresh, v_reset, int(soft), N, H, W, k, st)
+            else:
+                _call('eas_arsnn_step_fwd', 38 * v_n.numel(), L.eas_arsnn_step_fwd, ptr(X[t]), ptr(R), ptr(v), ptr(vsum), ptr(seg), ptr(tl),
+                      ptr(agg), ptr(v_n), ptr(vs_n), ptr(sp_n), ptr(gate), ptr(vn), ptr(seg_b), ptr(tl_b), t, Ts, 3 if running else readout,
+                      int(sat), thresh, v_reset, int(soft), N, C2, HW, st)
             if need_grad:
                 saved.append((g_ins, v, vsum, gate, vn, seg_b, tl_b))
             v, vsum, spike = v_n, vs_n, sp_n
             if record:
-                t_rec.append(tl.clone())
+                t_rec.append(tl.to(torch.int32))
         pre_relu = None
         if running:
             out = vsum if running == 'sum' else v
@@ -1137,10 +1207,12 @@ class _ARSNNFn(torch.autograd.Function):
             out = torch.relu(out)
         ctx.cfg = cfg
         ctx.fast0 = fast0
+        ctx.fused = fused
         ctx.dims = (Tm, N, Cin, C2, H, W)
         # ``agg`` is this node's own output unless ``running``: keeping it on ctx would tie output -> grad_fn -> ctx -> output
         # into a reference cycle (Ts*N*C2*H*W floats held until the cyclic GC runs); the backward reads it in running mode only
-        # (as a valid dummy pointer).  ``pre_relu`` likewise is ``out`` before the ReLU, a distinct tensor.
+        # (as a valid dummy pointer).  ``pre_relu`` likewise is ``out`` before the ReLU, a distinct tensor.  The tensors are
+        # intermediates this node created itself (none is an input or an output of the node), so they need no version tracking.
         ctx.saved = (saved, in_ins, spike, seg, tl, pre_relu, agg if running else None, gate_in)
         ctx.params = params
         ctx.ev_needs_grad = ctx.needs_input_grad[0]
@@ -1156,6 +1228,7 @@ class _ARSNNFn(torch.autograd.Function):
         Tm, N, Cin, C2, H, W = ctx.dims
         saved, in_ins, spike_last, seg, tl, pre_relu, agg, gate_in = ctx.saved
         params = ctx.params
+        fused = ctx.fused
         pin, pg = params[:2 * d_in], params[2 * d_in:]
         HW = H * W
         st = stream()
@@ -1164,6 +1237,18 @@ class _ARSNNFn(torch.autograd.Function):
             g_out = g_out * (pre_relu > 0)
         dev = g_out.device
         shape = (N, C2, H, W)
+        # the weights arranged for the input-gradient kernels by ONE launch
+        jobs, slot = [], {}
+        if fused and d_gate:
+            wr8 = torch.empty(L.eas_smallconv_packed_floats(4, k, 8), dtype=torch.float32, device=dev)
+            jobs += [(pin[2], 1, 8, 0, wr8), (pg[2], 1, 8, 4, wr8)]
+        for name, w, need in (('in1', pin[2] if d_in > 1 else None, d_in > 1), ('in0', pin[0] if d_in else None, d_in and ctx.ev_needs_grad),
+                              ('g1', pg[2] if d_gate > 1 else None, d_gate > 1), ('g0', pg[0] if d_gate else None, bool(d_gate))):
+            if need:
+                slot[name] = len(jobs)
+                jobs.append((w, 1, w.shape[1], 0, None))
+        pk = smallconv_pack(jobs) if jobs else []
+        wr = {n: pk[i] for n, i in slot.items()}
         if running:
             g_agg = agg                                  # never read in running mode (no segment writes); a valid pointer
             zeros = torch.zeros(shape, device=dev)
@@ -1179,6 +1264,7 @@ class _ARSNNFn(torch.autograd.Function):
         # gradient reaching each conv of the gate stack at every step, written into time-batched buffers by the producing
         # kernels (batched weight-grad at the end); the last conv's is gX itself
         g_stage = [torch.empty((Tm, N, pg[2 * i].shape[0], H, W), device=dev) for i in range(d_gate - 1)] + ([gX] if d_gate else [])
+        gA_in = torch.empty((Tm, N, 4, H, W), device=dev) if fused else None      # gradient at the input stack's hidden planes
         for t in range(Tm - 1, -1, -1):
             g_ins, v_prev, vs_prev, gate, vn, seg_b, tl_b = saved[t]
             g_vp, g_vsp = torch.empty_like(g_v), torch.empty_like(g_v)
@@ -1186,12 +1272,25 @@ class _ARSNNFn(torch.autograd.Function):
                                        ptr(seg_b), ptr(tl_b), ptr(gX[t]), ptr(g_vp), ptr(g_vsp), t, Ts, 3 if running else readout,
                                        int(sat), thresh, v_reset, int(soft), 1.0, N, C2, HW, st), 'eas_arsnn_step_bwd')
             g_v, g_vs = g_vp, g_vsp
+            if fused:
+                a_in_t = in_ins[1].view(Tm, N, 4, H, W)[t]
+                if d_gate and not (t == 0 and ctx.fast0) and t > 0:
+                    # both second convolutions' input gradients from one pass over gX[t], each masked by its ReLU
+                    smallconv_bwd_input_dual(gX[t], wr8, k, a_in_t, g_ins[1], gA_in[t], g_stage[0][t])
+                    g_spike = smallconv_bwd_input(g_stage[0][t], pg[0], None, wr=wr['g0'])
+                else:
+                    smallconv_bwd_input(gX[t], pin[2], a_in_t, out=gA_in[t], wr=wr['in1'])
+                    if d_gate and t == 0 and not ctx.fast0:
+                        smallconv_bwd_input(gX[t], pg[2], g_ins[1], out=g_stage[0][t], wr=wr['g1'])
+                    g_spike = None
+                continue
             g = gX[t]
             for i in range(d_gate - 1, -1, -1):           # g = gradient at the output of gate conv i = g_stage[i][t]
                 if t == 0 and (i == 0 or ctx.fast0):
                     break                      # spike input of step 0 is the constant 0 (fast0: the whole step-0 stack is done below)
                 # ReLU in front of conv i fused as a mask
-                g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None, out=g_stage[i - 1][t] if i > 0 else None)
+                g = smallconv_bwd_input(g, pg[2 * i], g_ins[i] if i > 0 else None, out=g_stage[i - 1][t] if i > 0 else None,
+                                        wr=wr.get('g%d' % i))
             g_spike = g if (t > 0 and d_gate) else None
         grads_g = []
         t0 = 1 if ctx.fast0 else 0
@@ -1211,14 +1310,16 @@ class _ARSNNFn(torch.autograd.Function):
                 grads_g[2 * i] = grads_g[2 * i] + gw
                 grads_g[2 * i + 1] = grads_g[2 * i + 1] + gb
                 if i > 0:
-                    g1 = smallconv_bwd_input(g1, pg[2 * i], g_ins0[i])
+                    g1 = smallconv_bwd_input(g1, pg[2 * i], g_ins0[i], wr=wr['g1'])
         # input conv stack, all Tm steps at once
         grads_in = [None] * (2 * d_in)
         g = gX.view(Tm * N, 2 * C2, H, W)
         for i in range(d_in - 1, -1, -1):
             grads_in[2 * i], grads_in[2 * i + 1] = smallconv_bwd_weight(g, in_ins[i], pin[2 * i])
-            if i > 0 or ctx.ev_needs_grad:
-                g = smallconv_bwd_input(g, pin[2 * i], in_ins[i] if i > 0 else None)
+            if fused and i == 1:
+                g = gA_in.view(Tm * N, 4, H, W)              # the step loop already produced this input gradient
+            elif i > 0 or ctx.ev_needs_grad:
+                g = smallconv_bwd_input(g, pin[2 * i], in_ins[i] if i > 0 else None, wr=wr.get('in%d' % i))
             else:
                 g = None
         g_ev = g.view(Tm, N, Cin, H, W) if ctx.ev_needs_grad else None

@@ -299,25 +299,37 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
  * t_last_before (all nullable in inference).
  * v == vsum == NULL (forward) / v_prev == vsum_prev == NULL (backward): the first step of a sequence -- zero potentials and sums,
  * seg = 0, t_last = -1 (embedding.py:159-167); seg / t_last are then outputs only, so the caller needs no zero fills. */
+/* seg (segments written so far, 0..Ts) and t_last (step of the last spike, -1..Tm-1) are int8 tensors: Ts, Tm <= 127. */
 int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float* v, const float* vsum,
-                       int32_t* seg, int32_t* t_last, float* agg, float* v_out, float* vsum_out, float* spike_out,
-                       float* gate_save, float* vn_save, int32_t* seg_before, int32_t* t_last_before, int t,
+                       int8_t* seg, int8_t* t_last, float* agg, float* v_out, float* vsum_out, float* spike_out,
+                       float* gate_save, float* vn_save, int8_t* seg_before, int8_t* t_last_before, int t,
                        int Ts, int readout, int spike_attach, float thresh, float v_reset, int soft_reset, int N,
                        int C2, int HW, eas_stream_t stream);
 
+/* eas_arsnn_step_fwd with the SECOND convolutions of the input stack and of the gate stack inside the launch (embedding.py:171-176;
+ * C2 = 2): their 4 + 4 output planes per pixel never reach HBM.  a_in [N][4][H][W] = ReLU(conv1_in(events of this micro-step)),
+ * a_g [N][4][H][W] = ReLU(conv1_gate(spikes entering the step)) or NULL -- then r_const [4][H][W] (nullable = zeros) is the gate stack's
+ * output for every sample (step 0: the constant-zero spike input).  wr_in / wr_g: eas_smallconv_pack_weights mode 0, o_total 4;
+ * b_in / b_g [4] nullable.  State arguments as eas_arsnn_step_fwd.  Results are bit-identical to the separate launches. */
+int eas_arsnn_fused_step_fwd(const float* a_in, const float* wr_in, const float* b_in, const float* a_g, const float* wr_g, const float* b_g,
+                             const float* r_const, const float* v, const float* vsum, int8_t* seg, int8_t* t_last, float* agg, float* v_out,
+                             float* vsum_out, float* spike_out, float* gate_save, float* vn_save, int8_t* seg_before, int8_t* t_last_before,
+                             int t, int Ts, int readout, int spike_attach, float thresh, float v_reset, int soft_reset, int N, int H, int W, int k,
+                             eas_stream_t stream);
+
 int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const float* g_spike, const float* g_agg,
                        const float* v_prev, const float* vsum_prev, const float* gate_save, const float* vn_save,
-                       const int32_t* seg_before, const int32_t* t_last_before, float* g_conv, float* g_v_prev,
+                       const int8_t* seg_before, const int8_t* t_last_before, float* g_conv, float* g_v_prev,
                        float* g_vsum_prev, int t, int Ts, int readout, int spike_attach, float thresh,
                        float v_reset, int soft_reset, float sg_alpha, int N, int C2, int HW, eas_stream_t stream);
 
 /* tail write (embedding.py:203-217): at elements whose LAST spike is 0 and seg < Ts add
  * (sum|last|avg readout) * (write_zero ? 0 : 1) into agg[seg]; optional relu (abs=True, :218-220)
  * is applied by eas_relu_inplace. */
-int eas_arsnn_tail_fwd(const float* v, const float* vsum, const float* spike_last, const int32_t* seg,
-                       const int32_t* t_last, float* agg, int Tm, int Ts, int readout, int write_zero, int N,
+int eas_arsnn_tail_fwd(const float* v, const float* vsum, const float* spike_last, const int8_t* seg,
+                       const int8_t* t_last, float* agg, int Tm, int Ts, int readout, int write_zero, int N,
                        int C2, int HW, eas_stream_t stream);
-int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int32_t* seg, const int32_t* t_last,
+int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int8_t* seg, const int8_t* t_last,
                        float* g_v, float* g_vsum, int Tm, int Ts, int readout, int write_zero, int N, int C2,
                        int HW, eas_stream_t stream);
 
@@ -325,15 +337,32 @@ int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int32_
  * Direct convolution for the sampler's conv stacks, Conv2d(2->4,k,p=k/2) [+ReLU+Conv2d(4->4,k)]
  * (yolox/models/embedding.py:106-111; replaces the F.conv2d calls and their autograd): stride 1, "same" zero
  * padding, NCHW fp32, (Cin,Cout) in {(2,4),(4,4),(2,2)}, k in {3,5,7}.  LDS-tiled (16x64 output tile + halo for all
- * input channels staged once; every output channel computed from registers).
- * x: [N][Cin][H][W], w: [Cout][Cin][k][k], b: [Cout] (nullable), y: [N][Cout][H][W]; relu != 0 applies max(.,0). */
-int eas_smallconv_fwd(const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout, int H,
+ * input channels staged once; every output channel computed from registers with packed fp32 FMAs).
+ *
+ * The kernels read their weights through the scalar cache in the order wr[n_in][k][k][o_total] (output channel fastest);
+ * eas_smallconv_pack_weights arranges up to 8 weight tensors per launch: mode 0 (forward) wr[i][ky][kx][o_off + o] = w[o][i][ky][kx],
+ * mode 1 (input gradient) wr[co][ky][kx][o_off + ci] = w[co][ci][k-1-ky][k-1-kx].  wr: eas_smallconv_packed_floats(n_in, k, o_total)
+ * floats, 16-byte aligned, n_in = Cin (mode 0) or Cout (mode 1). */
+typedef struct {
+    const float* w;          /* [Cout][Cin][k][k] */
+    float* wr;
+    int Cin, Cout, k, mode;
+    int o_total, o_off;      /* the packed tensor may hold several weight tensors side by side along its output axis */
+} EasSmallconvPackJob;
+int64_t eas_smallconv_packed_floats(int n_in, int k, int o_total);
+int eas_smallconv_pack_weights(const EasSmallconvPackJob* jobs, int njobs, eas_stream_t stream);
+/* x: [N][Cin][H][W], wr: weights packed with mode 0 (o_total = Cout), b: [Cout] (nullable), y: [N][Cout][H][W]; relu != 0 applies max(.,0). */
+int eas_smallconv_fwd(const float* x, const float* wr, const float* b, float* y, int N, int Cin, int Cout, int H,
                       int W, int k, int relu, eas_stream_t stream);
-/* grad_x = correlation of grad_y with the flipped, channel-transposed filter; when relu_mask != NULL
- * (the ReLU OUTPUT that fed this conv's input... i.e. the tensor the gradient flows back into), grad_x is zeroed
+/* grad_x = correlation of grad_y with the flipped, channel-transposed filter (wr: packed with mode 1, o_total = Cin); when
+ * relu_mask != NULL (the ReLU output that fed this conv's input, i.e. the tensor the gradient flows back into), grad_x is zeroed
  * where relu_mask <= 0 (fused ReLU backward). */
-int eas_smallconv_bwd_input(const float* grad_y, const float* w, const float* relu_mask, float* grad_x, int N, int Cin,
+int eas_smallconv_bwd_input(const float* grad_y, const float* wr, const float* relu_mask, float* grad_x, int N, int Cin,
                             int Cout, int H, int W, int k, eas_stream_t stream);
+/* The input gradients of TWO 4 -> 4 convolutions that received the same grad_y [N][4][H][W] (the second convolutions of the sampler's
+ * input stack and gate stack) in one pass over grad_y: wr = both weights packed with mode 1, o_total 8, o_off 0 and 4. */
+int eas_smallconv_bwd_input_dual(const float* grad_y, const float* wr, const float* mask_a, const float* mask_b, float* grad_xa,
+                                 float* grad_xb, int N, int H, int W, int k, eas_stream_t stream);
 /* grad_w [Cout][Cin][k][k] and grad_b [Cout] (nullable); deterministic two-stage reduction through
  * workspace (eas_smallconv_wgrad_workspace_floats(Cin,Cout,k) floats). */
 int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w, float* grad_b, float* workspace,

@@ -855,15 +855,11 @@ def test_sampler_step0_gate_stack_shared_by_the_batch(dev, monkeypatch):
 # ------------------------------------------------------------------------------------------------ sampler convs
 @pytest.mark.parametrize('cin,cout,k,N,H,W', [(2, 4, 5, 3, 32, 64), (4, 4, 5, 2, 48, 80), (2, 4, 7, 2, 20, 36), (4, 4, 3, 1, 16, 64),
                                                (2, 2, 5, 2, 17, 30), (4, 4, 7, 1, 256, 320), (2, 4, 3, 5, 33, 130), (4, 4, 5, 2, 37, 250)])
-@pytest.mark.parametrize('form', ['fma', 'mfma'])
-def test_smallconv_vs_fp64_reference(dev, monkeypatch, form, cin, cout, k, N, H, W):
+def test_smallconv_vs_fp64_reference(dev, cin, cout, k, N, H, W):
     """eas_smallconv_{fwd,bwd_input,bwd_weight} against an fp64 torch convolution on the CPU (tile edges, halos,
-    H/W not multiples of the 16x64 tile, W not a multiple of 4, fused ReLU / ReLU-mask epilogues).  form: the vector-ALU kernels (default)
-    or, for k = 5, the opt-in matrix-core forward / input gradient of smallconv_mfma.hip (EAS_SC_FORM is read per call)."""
+    H/W not multiples of the 16x64 tile, W not a multiple of 4, fused ReLU / ReLU-mask epilogues; weights through
+    eas_smallconv_pack_weights in both arrangements)."""
     from eas_snn_amd import ops
-    if form == 'mfma' and k != 5:
-        pytest.skip('the matrix-core form exists for 5x5 kernels')
-    monkeypatch.setenv('EAS_SC_FORM', form)
     rng = np.random.default_rng(cin * 100 + cout * 10 + k)
     x = rng.standard_normal((N, cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32)
@@ -885,6 +881,57 @@ def test_smallconv_vs_fp64_reference(dev, monkeypatch, form, cin, cout, k, N, H,
     scale = np.sqrt(N * H * W)
     np.testing.assert_allclose(gw.cpu().numpy(), wd.grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(gb.cpu().numpy(), gy.astype(np.float64).sum((0, 2, 3)), rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize('k,N,H,W', [(5, 2, 48, 80), (3, 1, 16, 64), (7, 2, 20, 36), (5, 3, 37, 250), (5, 2, 256, 320)])
+def test_smallconv_dual_input_gradient_equals_two_single_ones(dev, k, N, H, W):
+    """eas_smallconv_bwd_input_dual (the input gradients of the sampler's two 4 -> 4 second convolutions from ONE pass over the step's
+    gradient, each masked by its ReLU) against two eas_smallconv_bwd_input calls: bit-identical (same products, same order)."""
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(k * 100 + H)
+    gy = torch.randn(N, 4, H, W, generator=g).to(dev)
+    wa, wb = (torch.randn(4, 4, k, k, generator=g) * 0.2).to(dev), (torch.randn(4, 4, k, k, generator=g) * 0.2).to(dev)
+    ma, mb = torch.randn(N, 4, H, W, generator=g).to(dev), torch.randn(N, 4, H, W, generator=g).to(dev)
+    want_a, want_b = ops.smallconv_bwd_input(gy, wa, ma), ops.smallconv_bwd_input(gy, wb, mb)
+    wr8 = torch.empty(4 * k * k * 8, device=dev)
+    ops.smallconv_pack([(wa, 1, 8, 0, wr8), (wb, 1, 8, 4, wr8)])
+    got_a, got_b = torch.empty_like(gy), torch.empty_like(gy)
+    if W % 4 == 0:
+        ops.smallconv_bwd_input_dual(gy, wr8, k, ma, mb, got_a, got_b)
+        assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b) and float(want_a.abs().sum()) > 0
+    ref = torch.nn.grad.conv2d_input(gy.shape, wa.double().cpu(), gy.double().cpu(), padding=k // 2) * (ma.cpu() > 0)
+    torch.testing.assert_close(want_a.double().cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('Tm,N,H,W,Ts,readout,k,fast0', [(4, 2, 32, 64, 1, 'sum', 5, 'shared'), (4, 3, 48, 80, 3, 'last', 5, 'full'),
+                                                          (8, 1, 20, 36, 7, 'avg', 3, 'shared'), (3, 2, 64, 96, 2, 'sum', 7, 'shared')])
+def test_sampler_fused_step_equals_separate_launches(dev, monkeypatch, Tm, N, H, W, Ts, readout, k, fast0):
+    """K3 with the second convolutions inside the micro-step kernel (eas_arsnn_fused_step_fwd) and the dual input gradient, against the
+    separate launches (EAS_ARSNN_FUSED=0): adaptive frames, last-spike records and every gradient bit-identical."""
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(Tm * 10 + Ts)
+    ev = torch.poisson(torch.full((Tm, N, 2, H, W), 0.6), generator=g).to(dev)
+    pin = [torch.randn(4, 2, k, k, generator=g) * 0.25, torch.randn(4, generator=g) * 0.1, torch.randn(4, 4, k, k, generator=g) * 0.2,
+           torch.randn(4, generator=g) * 0.1 + 0.2]
+    pg = [torch.randn(4, 2, k, k, generator=g) * 0.25, torch.randn(4, generator=g) * 0.1, torch.randn(4, 4, k, k, generator=g) * 0.2,
+          torch.randn(4, generator=g) * 0.1]
+    go = torch.randn(Ts, N, 2, H, W, generator=g).to(dev)
+    monkeypatch.setenv('EAS_ARSNN_STEP0', fast0)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'ARSNN_FUSED', fused)
+        a = [p.clone().to(dev).requires_grad_(True) for p in pin]
+        b = [p.clone().to(dev).requires_grad_(True) for p in pg]
+        e = ev.clone().requires_grad_(True)
+        # 'last' reads the post-reset potential: soft reset there (a hard reset to 0 with RPD gives all-zero frames)
+        out, rec = ops.arsnn_forward(e, a, b, k, Ts, readout, True, readout != 'last', False, 1.0, None if readout == 'last' else 0.0, record=True)
+        (out * go).sum().backward()
+        res.append((out.detach().clone(), rec.clone(), [p.grad.clone() for p in a + b] + [e.grad.clone()]))
+    (o0, r0, g0), (o1, r1, g1) = res
+    assert torch.equal(o0, o1) and torch.equal(r0, r1) and float(o0.abs().sum()) > 0
+    assert sum(float(x.abs().max()) > 0 for x in g0) >= 5
+    for i, (x, y) in enumerate(zip(g0, g1)):        # the same products summed in the same order in both forms: every gradient bit-identical
+        assert torch.equal(x, y), i
 
 
 @pytest.mark.parametrize('cin,cout,k,N,H,W', [(2, 4, 5, 3, 32, 64), (4, 4, 5, 2, 48, 80), (2, 4, 7, 2, 20, 36), (4, 4, 3, 1, 16, 64),
