@@ -27,15 +27,10 @@ class EasSmallconvPackJob(C.Structure):
                 ('o_total', C.c_int), ('o_off', C.c_int)]
 
 
-class EasCoop(C.Structure):
-    """include/eas_hip.h EasCoop: buffers of the in-kernel exchange between the blocks of a channel."""
-    _fields_ = [('slots', C.c_void_p), ('tickets', C.c_void_p), ('err', C.c_void_p), ('capacity', C.c_int)]
-
-
 class EasBnPending(C.Structure):
     """include/eas_hip.h EasBnPending: statistics whose finalize happens inside the consuming kernel."""
     _fields_ = [('partial', C.c_void_p), ('chunks', C.c_int), ('replicas', C.c_int), ('count', C.c_double), ('eps', C.c_float),
-                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('coop', C.POINTER(EasCoop)), ('pitch', C.c_int)]
+                ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('pitch', C.c_int)]
 
 
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
@@ -74,7 +69,6 @@ PROTOTYPES = {
     'eas_time_mean': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
     'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     'eas_bn_workspace_doubles': (C.c_int64, [C.c_int]),
-    'eas_coop_slot_words': (C.c_int64, [C.c_int]),
     'eas_bn_lif_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_lif_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
@@ -83,12 +77,12 @@ PROTOTYPES = {
     'eas_bn_silu_fwd_ex': (C.c_int, [_P] * 6 + [C.c_int] * 3 + [C.POINTER(EasBnPending), C.c_int, C.c_int, _P]),
     'eas_bn_stats_partial': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_bn_lif_fwd_ex': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,
-                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P, _P]),
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasBnPending), _P, C.c_int, _P, _P, C.c_int, _P]),
     'eas_bn_lif_bwd_ex': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
-                                    C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasCoop), _P]),
+                                    C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_lif_bwd_patan': (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P,
-                                       _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EasCoop), _P]),
-    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 5 + [C.POINTER(EasCoop), _P]),
+                                       _P, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'eas_bn_silu_bwd': (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 4 + [C.c_int] * 5 + [_P]),
     'eas_arsnn_step_fwd': (C.c_int, [_P] * 14 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, _P]),
     'eas_arsnn_step_bwd': (C.c_int, [_P] * 13 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
@@ -110,15 +104,16 @@ PROTOTYPES = {
     'eas_conv_fwd_supported': (C.c_int, [C.c_int] * 8),
     'eas_conv_wgrad_parts': (C.c_int, [C.c_int] * 7),
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
-    'eas_conv_fwd_u8': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
+    'eas_conv_fwd_planes': (C.c_int, [_P] * 4 + [C.c_int] * 7 + [_P, C.c_int, _P]),
+    'eas_spike_planes_from_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
+    'eas_spike_planes_to_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
     'eas_conv_fwd_stats': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P, _P, C.c_int, _P]),
     'eas_conv_fwd_stats_blocks': (C.c_int, [C.c_int] * 8),
     'eas_conv_dgrad_s2': (C.c_int, [_P] * 3 + [C.c_int] * 5 + [_P]),
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
     'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
-    'eas_conv_wgrad_u8': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
     'eas_conv_wgrad_partial': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P]),
-    'eas_conv_wgrad_u8_partial': (C.c_int, [_P] * 3 + [C.c_int] * 6 + [_P]),
+    'eas_conv_wgrad_planes_partial': (C.c_int, [_P] * 3 + [C.c_int] * 7 + [_P]),
     'eas_conv_wgrad_reduce_many': (C.c_int, [_P, C.c_int, _P]),
     'eas_spp_pool_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),

@@ -23,7 +23,7 @@ class SeqToANNContainer(nn.Sequential, base.StepModule):
         """The wrapped stateless module(s) on a [N,C,H,W] batch; a lone Conv2d goes to the matrix-core kernels."""
         if len(self_) == 1 and type(self_[0]) is nn.Conv2d and x.is_cuda:
             return ops.conv2d(x, self_[0])
-        return nn.Sequential.forward(self_, x)
+        return nn.Sequential.forward(self_, ops.dense(x))
 
     def forward(self, x_seq):
         base = getattr(x_seq, '_eas_base', None)
@@ -36,7 +36,7 @@ class SeqToANNContainer(nn.Sequential, base.StepModule):
             y._eas_base = y0
             return y
         small = ops.is_small_int(x_seq)
-        x = ops.fold_time(x_seq)            # [T*N, ...] with the spike tags (small-integer mark, byte copy) carried along
+        x = ops.fold_time(x_seq)            # [T*N, ...] with the spike tags (small-integer mark, spike planes) carried along
         y = self._run_inner(x)
         y = y.view(x_seq.shape[0], x_seq.shape[1], *y.shape[1:])
         if small and len(self) == 1 and isinstance(self[0], (nn.MaxPool2d, nn.Upsample)):
@@ -69,18 +69,19 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
         return bool(self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
                     and (self.momentum is not None or not self.training))
 
-    def fused_with(self, node, y_seq, want_mean=False, residual=None, cat=None, emit_bytes=False):
+    def fused_with(self, node, y_seq, want_mean=False, residual=None, cat=None, planes=False):
         """spikes = node(self(y_seq)) for y_seq [T,N,C,H,W] without materialising the BN output.
         residual: the result is spikes + residual (SEW shortcut) from the same kernel; cat = (buffer [T,N,Ctot,H,W], first
-        channel[, uint8 buffer of the same shape]): the result is written into that channel range of the buffer(s) and returned as
-        a view; emit_bytes: the kernel also writes the result as bytes for the 1x1 convolutions that read it next."""
+        channel[, spike planes of the buffer]): the result is written into that channel range of the buffer and returned as
+        a view; planes: the result is written as bf16 spike planes and the returned tensor is the ghost that carries them
+        (eas_snn_amd.ops "SPIKE PLANES")."""
         if not self.can_fuse(y_seq):
             if cat is not None:
                 raise RuntimeError('in-place concatenation needs the fused BN+LIF path (callers check network_blocks._fusable)')
             y_seq = y_seq.contiguous()
             out = node(self(y_seq))
             if residual is not None:
-                out = out + residual
+                out = out + ops.dense(residual)
             return (out, ops.time_mean(out)) if want_mean else out
         batch = self._use_batch_stats()
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
@@ -93,7 +94,7 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
             self.running_var if (update or not batch) else None, batch, self.momentum if update else None, self.eps,
             node._v_in(y_seq[0]), a['w'], a['k_const'], a['v_th'], a['v_reset'], a['flags'], a['surrogate'], a['alpha'],
             want_mean=want_mean, t_bcast=0 if base is None else y_seq.shape[0], residual=residual, cat=cat,
-            emit_bytes=emit_bytes and (residual is None or ops.is_small_int(residual)))
+            planes=planes)
         if v_out is not None:
             node.v = v_out
         if residual is None or ops.is_small_int(residual):
@@ -112,11 +113,12 @@ class Conv2d(nn.Conv2d, base.StepModule):
         return functional.seq_to_ann_forward(x, super().forward)
 
 
-def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None, emit_bytes=True):
+def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None, planes_a=False, planes_b=False):
     """spikes of node_a(bn_a(y12[:, :, :Ca])) and node_b(bn_b(y12[:, :, Ca:])) from ONE convolution output y12 [T,N,Ca+Cb,H,W]
-    (ops.bn_lif_pair): the two 1x1 branches of a CSPLayer.  cat_a / cat_b = (buffer, first channel) as in ``fused_with``."""
+    (ops.bn_lif_pair): the two 1x1 branches of a CSPLayer.  cat_a / cat_b = (buffer, first channel[, its planes]) and planes_a / planes_b
+    as in ``fused_with``."""
     packs = []
-    for bn, node, cat in ((bn_a, node_a, cat_a), (bn_b, node_b, cat_b)):
+    for bn, node, cat, planes in ((bn_a, node_a, cat_a, planes_a), (bn_b, node_b, cat_b, planes_b)):
         batch = bn._use_batch_stats()
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             ops.bump_counter(bn.num_batches_tracked)
@@ -126,7 +128,7 @@ def fused_pair(bn_a, node_a, bn_b, node_b, y12, cat_a=None, cat_b=None, emit_byt
                  None if not update or bn.momentum is None else float(bn.momentum), float(bn.eps))
         cfg = (state, node._v_in(y12[0, :, :bn.num_features]), float(a['k_const']), float(a['v_th']), float(a['v_reset']), int(a['flags']),
                ops.SURROGATE_IDS[a['surrogate']] if isinstance(a['surrogate'], str) else int(a['surrogate']), float(a['alpha']),
-               bool(ops.state_writeback()), cat, int(bn.num_features), bool(emit_bytes and ops.SPIKE_BYTES))
+               bool(ops.state_writeback()), cat, int(bn.num_features), bool(planes) and bn.num_features % 8 == 0)
         packs.append((bn.weight, bn.bias, a['w'], cfg))
     sa, va, sb, vb = ops.bn_lif_pair(y12, packs[0], packs[1])
     if va is not None:

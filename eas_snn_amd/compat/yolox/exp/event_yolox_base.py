@@ -101,6 +101,8 @@ class EventExp(BaseExp):
                 self.model = YOLOX(backbone, head, embedding)
             else:
                 raise ValueError(f'use_spike={self.use_spike!r}')
+            from yolox.models.network_blocks import enable_spike_planes
+            enable_spike_planes(self.model)       # converted blocks hand their spikes on as bf16 planes inside the model's forward
         for m in self.model.modules():                                          # init_yolo (:179-183)
             if isinstance(m, nn.BatchNorm2d):
                 m.eps = 1e-3

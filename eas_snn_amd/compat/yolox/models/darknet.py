@@ -1,6 +1,8 @@
 """CSPDarknet backbone (reference: yolox/models/darknet.py:97-180); same attribute names -> same checkpoint keys."""
 from torch import nn
 
+from eas_snn_amd import ops
+
 from .network_blocks import BaseConv, CSPLayer, DWConv, Focus, SPPBottleneck
 
 
@@ -31,4 +33,5 @@ class CSPDarknet(nn.Module):
             feats[name] = x                # (spikes, firing_rate) when the stage's last conv emits its rate
             if isinstance(x, tuple):
                 x = x[0]
-        return {k: v for k, v in feats.items() if k in self.out_features}
+        # what leaves the backbone is a real tensor (a stage may have handed its spikes on as planes, see ops.dense)
+        return {k: (v if isinstance(v, tuple) else ops.dense(v)) for k, v in feats.items() if k in self.out_features}

@@ -24,8 +24,10 @@ def get_activation(name='silu', inplace=True):
 
 def _cat(parts):
     """Channel concatenation; a concatenation of spike tensors is still a spike tensor."""
-    out = torch.cat(list(parts), dim=-3)
-    if all(ops.is_small_int(p) for p in parts):
+    small = all(ops.is_small_int(p) for p in parts)
+    parts = [ops.dense(p) for p in parts]
+    out = torch.cat(parts, dim=-3)
+    if small:
         ops.mark_small_int(out)
     return out
 
@@ -64,21 +66,23 @@ class BaseConv(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels)
         self.act = get_activation(act, inplace=True)
         self.emit_rate = False     # spiking only: also return the firing rate (mean over T) from the fused kernel
+        self.planes_out = False    # spiking only: the fused BN+LIF kernel writes its spikes as bf16 spike planes (ops "SPIKE PLANES"); set
+                                   # by ``enable_spike_planes`` on blocks whose readers take planes or unpack them (ops.dense)
 
     def spiking(self):
         return isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d)
 
-    def forward(self, x, residual=None, cat=None, emit_bytes=True):
+    def forward(self, x, residual=None, cat=None):
         """residual / cat: only for converted (spiking) blocks on the fused BN+LIF path -- the SEW shortcut addition and the
-        channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer).  emit_bytes: the spikes are
-        also written as bytes for a 1x1 convolution that reads them next (callers whose consumer is a 3x3 convolution pass False)."""
+        channel concatenation of the caller happen inside the BN+LIF kernel (see Bottleneck / CSPLayer); cat = (buffer, first channel[,
+        spike planes of the buffer])."""
         if ops._TIMER is not None:
             ops.set_tag(getattr(self, '_eas_name', None))            # development: per-layer timing (scripts/layer_times.py)
         if self.spiking():
             with ops.conv_stats_scope(self.bn._use_batch_stats()):      # the convolution sums its output for the BN behind it
                 y = self.conv(x)
             return self.bn.fused_with(self.act, y, want_mean=self.emit_rate, residual=residual, cat=cat,
-                                      emit_bytes=emit_bytes and x.dim() == 5)
+                                      planes=self.wants_planes() and x.dim() == 5)
         assert residual is None
         with ops.conv_stats_scope(self.bn.training or self.bn.running_mean is None):
             y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
@@ -86,6 +90,9 @@ class BaseConv(nn.Module):
             return ops.bn_silu(y, self.bn, cat=cat)     # the statistics from the convolution + one fused normalise/SiLU pass (HIP)
         assert cat is None
         return self.act(self.bn(y))
+
+    def wants_planes(self):
+        return self.planes_out and ops.planes_enabled()
 
     def ann_fusable(self, y):
         """BN + SiLU of this (real-valued) block run as the fused HIP kernel on ``y`` (then the output can also go straight into a
@@ -117,7 +124,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, cat=None):
         """cat = (buffer, first channel): write the block's output into that channel range of a concatenation buffer."""
-        h = self.conv1(x, emit_bytes=False) if self.conv1.spiking() else self.conv1(x)      # read by the 3x3 conv2 only
+        h = self.conv1(x)
         if _fusable(self.conv2, x):
             # SEW residual (spike sums 0/1/2..) and the caller's concatenation from the BN+LIF kernel of conv2
             return self.conv2(h, residual=x if self.use_add else None, cat=cat)
@@ -127,8 +134,9 @@ class Bottleneck(nn.Module):
         y = self.conv2(h)
         if not self.use_add:
             return y
-        out = y + x                              # SEW residual: spike sums 0/1/2.. when spiking
-        if ops.is_small_int(y) and ops.is_small_int(x):
+        small = ops.is_small_int(y) and ops.is_small_int(x)
+        out = ops.dense(y) + ops.dense(x)        # SEW residual: spike sums 0/1/2.. when spiking
+        if small:
             ops.mark_small_int(out)
         return out
 
@@ -146,6 +154,7 @@ class SPPBottleneck(nn.Module):
         ks = [_pool_ksize(m) for m in self.m]
         if all(k is not None for k in ks) and ops.spp_pool_supported(x, ks):
             return self.conv2(ops.spp_pool_cat(x, ks))      # three poolings + concatenation in one kernel
+        x = ops.dense(x)
         return self.conv2(_cat([x] + [m(x) for m in self.m]))
 
 
@@ -198,8 +207,14 @@ class CSPLayer(nn.Module):
             T, N = x.shape[:2]
             h = self.conv2.conv[0].out_channels if isinstance(self.conv2.conv, nn.Sequential) else self.conv2.conv.out_channels
             Ho, Wo = x.shape[-2:]
-            buf = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.float32, device=x.device)
-            buf8 = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.uint8, device=x.device) if ops.SPIKE_BYTES else None   # byte copy for conv3
+            if tail.wants_planes() and self.conv2.wants_planes() and h % 8 == 0:
+                # the concatenation exists as spike planes only (read by conv3): a ghost stands for it in the autograd graph
+                sp_buf = ops.new_planes(T, N, 2 * h, Ho, Wo, x.device)
+                buf = ops.ghost((T, N, 2 * h, Ho, Wo), x.device)
+            else:
+                sp_buf = None
+                buf = torch.empty((T, N, 2 * h, Ho, Wo), dtype=torch.float32, device=x.device)
+            want_a = (sp_buf is not None) if not len(self.m) else self.conv1.wants_planes()
             if self._dual_ok():
                 # conv1 and conv2 read the same x: ONE 1x1 convolution with the concatenated weights, then the two BN+LIF layers on
                 # the two channel halves of its output (x read once; the input gradient is one convolution, no branch addition)
@@ -215,15 +230,16 @@ class CSPLayer(nn.Module):
                     else:
                         y12 = ops.conv2d_weight(x4, torch.cat([c1.weight, c2.weight], 0)).view(T, N, 2 * h, Ho, Wo)
                 a, b = sj_layer.fused_pair(self.conv1.bn, self.conv1.act, self.conv2.bn, self.conv2.act, y12,
-                                           cat_a=None if len(self.m) else (buf, 0, buf8), cat_b=(buf, h, buf8))
+                                           cat_a=None if len(self.m) else (buf, 0, sp_buf), cat_b=(buf, h, sp_buf),
+                                           planes_a=want_a, planes_b=sp_buf is not None)
             else:
-                a = self.conv1(x, cat=None if len(self.m) else (buf, 0, buf8))
-                b = self.conv2(x, cat=(buf, h, buf8))
+                a = self.conv1(x, cat=None if len(self.m) else (buf, 0, sp_buf))
+                b = self.conv2(x, cat=(buf, h, sp_buf))
             if len(self.m):
                 for blk in self.m[:-1]:
                     a = blk(a)
-                a = self.m[-1](a, cat=(buf, 0, buf8))
-            return self.conv3(ops.join_channels(buf, a, b, u8_buf=buf8))
+                a = self.m[-1](a, cat=(buf, 0, sp_buf))
+            return self.conv3(ops.join_channels(buf, a, b, sp_buf=sp_buf))
         if self._ann_inplace_cat(x):
             # real-valued CSPLayer (PAFPN neck): both branches write their BN + SiLU output into the two halves of the concatenation
             # (no torch.cat; the backward reads the two halves of the gradient in place)
@@ -231,7 +247,7 @@ class CSPLayer(nn.Module):
             h = self.conv2.conv.out_channels
             buf = torch.empty((N, 2 * h) + tuple(x.shape[-2:]), dtype=torch.float32, device=x.device)
             cs = self._branch_convs()
-            if (cs is not None and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL') and not ops.COOP_BN and self.conv1.ann_fusable(x[:, :1])
+            if (cs is not None and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL') and self.conv1.ann_fusable(x[:, :1])
                     and ops.conv_dual_ok(x, cs[0], cs[1])):
                 # conv1 and conv2 read the same x: ONE 1x1 convolution (weights packed from the two parameters), then the two BN + SiLU
                 # layers on the channel halves of its output; the input gradient is one convolution, no addition of two branch gradients
@@ -281,3 +297,13 @@ class Focus(nn.Module):
             return self.conv(ops.focus(x))                 # the four strided slices + concatenation as one permutation kernel
         parts = (x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2])
         return self.conv(torch.cat(parts, dim=1))
+
+
+def enable_spike_planes(net, flag=True):
+    """Let every converted (spiking) BaseConv inside ``net`` hand its spikes on as bf16 spike planes (ops "SPIKE PLANES").  For a network
+    whose spike tensors stay inside these blocks (the spiking CSPDarknet: every reader is a convolution here, a block that unpacks, or
+    CSPDarknet.forward, which unpacks what it hands out)."""
+    for m in net.modules():
+        if isinstance(m, BaseConv) and m.spiking():
+            m.planes_out = bool(flag)
+    return net

@@ -5,7 +5,7 @@ from eas_snn_amd import ops
 from yolox.utils.utils_snn import convert_to_spiking
 
 from .darknet import CSPDarknet
-from .network_blocks import CSPLayer
+from .network_blocks import CSPLayer, enable_spike_planes
 from .yolo_pafpn import YOLOPAFPN
 
 
@@ -17,6 +17,7 @@ class SpikingYOLOPAFPN(YOLOPAFPN):
         self.in_features = in_features
         self.in_channels = in_channels
         self._build_neck(depth, width, in_channels, depthwise, act)
+        enable_spike_planes(self.backbone)          # spikes between the backbone's layers as bf16 planes (its readers are its own blocks)
         for f in in_features:                       # last block of each output stage emits its firing rate
             last = getattr(self.backbone, f)[-1]
             if isinstance(last, CSPLayer):

@@ -87,7 +87,7 @@ class YOLOXHead(nn.Module):
         input gradient instead of two and an addition, twice the blocks on the small maps)"""
         a, b = self.cls_convs[k][0], self.reg_convs[k][0]
         if (isinstance(a, BaseConv) and isinstance(b, BaseConv) and not a.spiking() and not b.spiking() and x.dim() == 4
-                and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL') and not ops.COOP_BN
+                and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL')
                 and a.ann_fusable(x[:, :1]) and b.ann_fusable(x[:, :1]) and ops.conv_dual_ok(x, a.conv, b.conv)):
             sink = ops.conv_sink()
             if sink is not None:

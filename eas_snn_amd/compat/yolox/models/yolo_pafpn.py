@@ -12,7 +12,7 @@ def _cat2(a, b):
     """torch.cat([a, b], channel axis) with a one-kernel backward (two contiguous gradients instead of two slice copies)"""
     if ops.upcat_supported(a, b, 1):
         return ops.upsample_cat(a, b, 1)
-    return torch.cat([a, b], -3)
+    return torch.cat([ops.dense(a), ops.dense(b)], -3)
 
 
 class YOLOPAFPN(nn.Module):
@@ -48,7 +48,7 @@ class YOLOPAFPN(nn.Module):
         if (type(up) is nn.Upsample and up.mode == 'nearest' and up.scale_factor in (2, 2.0, (2, 2), (2.0, 2.0)) and up.size is None
                 and ops.upcat_supported(low, skip, 2)):
             return ops.upsample_cat(low, skip, 2)
-        return torch.cat([self.upsample(low), skip], -3)
+        return torch.cat([self.upsample(low), ops.dense(skip)], -3)
 
     def forward(self, x):
         x2, x1, x0 = self._features(x)

@@ -114,10 +114,9 @@ __global__ __launch_bounds__(NT, 2) void arsnn_fused_step_fwd_kernel(
     const float* __restrict__ vsum, eas_state_t* __restrict__ seg, eas_state_t* __restrict__ t_last, float* __restrict__ agg,
     float* __restrict__ v_out, float* __restrict__ vsum_out, float* __restrict__ spike_out, float* __restrict__ gate_save,
     float* __restrict__ vn_save, eas_state_t* __restrict__ seg_before, eas_state_t* __restrict__ tl_before, StepCfg c, int N, int H, int W) {
-    using G = Geo<K>;
-    constexpr int LWF = 128;
-    constexpr int PLANE = G::LH * LWF;
-    using St = Stager<4, K, PLANE, LWF>;
+    using SG = Stage<4, K, true>;                 // W % 4 == 0 (launcher): aligned-quad staging
+    constexpr int LWF = SG::PITCH, PLANE = SG::PLANE;
+    using St = typename SG::St;
     St st;
     st.init(H, W);
     __shared__ __attribute__((aligned(16))) float lds[4 * PLANE];
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(NT, 2) void arsnn_fused_step_fwd_kernel(
     const int ntiles = N * tiles_x * tiles_y;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int HW = H * W;
-    float pre[St::PER];
+    float4 pre[St::PER];
     unsigned okm = 0;
     int tile = blockIdx.x;
     if (tile < ntiles)
@@ -172,13 +171,13 @@ __global__ __launch_bounds__(NT, 2) void arsnn_fused_step_fwd_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) { X[j][op] = bx; R[j][op] = bg; }
         }
-        sc_accumulate<4, 4, K, LWF>(lds, PLANE, wr_in, X, tx, ty);
+        sc_accumulate<4, 4, K, LWF, SG::NQ, SG::OFS>(lds, PLANE, wr_in, X, tx, ty);
         if (HAS_G) {
             __syncthreads();
             st.store(lds, pre, okm);
             __syncthreads();
             if (nxt < ntiles) okm = st.load(a_in, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
-            sc_accumulate<4, 4, K, LWF>(lds, PLANE, wr_g, R, tx, ty);
+            sc_accumulate<4, 4, K, LWF, SG::NQ, SG::OFS>(lds, PLANE, wr_g, R, tx, ty);
         }
         if (inside) {
 #pragma unroll
@@ -350,7 +349,7 @@ int eas_arsnn_fused_step_fwd(const float* a_in, const float* wr_in, const float*
         return EAS_ERR_INVALID_ARG;
     if (N < 1 || H < 1 || W < 1 || Ts < 1 || t < 0 || readout < 0 || readout > 3) return EAS_ERR_INVALID_ARG;
     if (W % 4 != 0 || (k != 3 && k != 5 && k != 7) || Ts > 127 || t > 126) return EAS_ERR_UNSUPPORTED;
-    if (((uintptr_t)wr_in | (uintptr_t)wr_g | (uintptr_t)r_const | (uintptr_t)v | (uintptr_t)vsum | (uintptr_t)seg | (uintptr_t)t_last |
+    if (((uintptr_t)a_in | (uintptr_t)a_g | (uintptr_t)wr_in | (uintptr_t)wr_g | (uintptr_t)r_const | (uintptr_t)v | (uintptr_t)vsum | (uintptr_t)seg | (uintptr_t)t_last |
          (uintptr_t)v_out | (uintptr_t)vsum_out | (uintptr_t)spike_out | (uintptr_t)gate_save | (uintptr_t)vn_save | (uintptr_t)seg_before |
          (uintptr_t)t_last_before) & 15)
         return EAS_ERR_INVALID_ARG;

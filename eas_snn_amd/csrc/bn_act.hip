@@ -33,30 +33,15 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ out, int N,
-                                                                int C, int HW, BnFin fin, EasCoopDev co, int out_ctot, int y_ctot) {
+                                                                int C, int HW, BnFin fin, int out_ctot, int y_ctot) {
     __shared__ float st[2];
-    __shared__ double red[NW];
-    __shared__ double shd[2];
     const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
     if (c >= C) return;
     const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
     float mu, istd;
-    if (fin.coop) {
-        // batch statistics in this launch: sums over this block's own chunk, exchanged between the channel's blocks
-        double s = 0.0, ss = 0.0;
-        GroupWalk gs((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
-        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gs.next()) {
-            const float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)gs.n * C + c) * (int64_t)HW + (int64_t)gs.q * VEC);
-            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-            ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-        }
-        const double mine[2] = {eas_block_sum<double, NW>(s, red), eas_block_sum<double, NW>(ss, red)};
-        double tot[2];
-        eas_channel_allreduce<2>(co, c, chunk, nchunks_g, mine, tot, shd);
-        bn_from_totals(fin, c, tot[0], tot[1], chunk == 0 && threadIdx.x == 0, mu, istd);
-    } else if (fin.part) {
+    if (fin.part) {
         bn_finalize_in_block(fin, c, st, mu, istd, chunk == 0);
     } else {
         mu = mean[c];
@@ -228,77 +213,6 @@ __global__ __launch_bounds__(NT) void bn_silu_bwd_small_kernel(const float* __re
     }
 }
 
-// both passes of the backward in one launch: the blocks of a channel exchange (sum dz, sum dz*xhat) in the kernel and write grad_y
-// from grad_out / y they have just read (eas_channel_allreduce)
-__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_coop_kernel(const float* __restrict__ grad_out, const float* __restrict__ y,
-                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                     int batch_stats, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-                                                                     float* __restrict__ grad_beta, int N, int C, int HW, EasCoopDev co) {
-    __shared__ double red[NW];
-    __shared__ double shd[2];
-    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
-    if (c >= C) return;
-    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
-    const float mu = mean[c], istd = invstd[c];
-    const float scale = gamma[c] * istd;
-    const float shift = beta[c] - mu * scale;
-    const int hw4 = HW / VEC;
-    const int64_t groups = (int64_t)N * hw4;
-    float s1 = 0.f, s2 = 0.f;
-    {
-        GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
-        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
-            const int64_t base = ((int64_t)gw.n * C + c) * (int64_t)HW + (int64_t)gw.q * VEC;
-            const float4 yv = *reinterpret_cast<const float4*>(y + base);
-            const float4 gv = *reinterpret_cast<const float4*>(grad_out + base);
-            const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
-            const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dz = gs[e] * silu_grad(fmaf(ys[e], scale, shift));
-                s1 += dz;
-                s2 += dz * ((ys[e] - mu) * istd);
-            }
-        }
-    }
-    const double mine[2] = {eas_block_sum<double, NW>((double)s1, red), eas_block_sum<double, NW>((double)s2, red)};
-    double tot[2];
-    eas_channel_allreduce<2>(co, c, chunk, nchunks_g, mine, tot, shd);
-    if (chunk == 0 && threadIdx.x == 0) {
-        grad_beta[c] = (float)tot[0];
-        grad_gamma[c] = (float)tot[1];
-    }
-    const double cnt = (double)N * HW;
-    const float m1 = batch_stats ? (float)(tot[0] / cnt) : 0.f, m2 = batch_stats ? (float)(tot[1] / cnt) : 0.f;
-    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
-    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
-        const int64_t base = ((int64_t)gw.n * C + c) * (int64_t)HW + (int64_t)gw.q * VEC;
-        const float4 yv = *reinterpret_cast<const float4*>(y + base);
-        const float4 gv = *reinterpret_cast<const float4*>(grad_out + base);
-        const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
-        const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float dz = gs[e] * silu_grad(fmaf(ys[e], scale, shift));
-            o[e] = scale * (dz - m1 - ((ys[e] - mu) * istd) * m2);
-        }
-        *reinterpret_cast<float4*>(grad_y + base) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-}
-
-static EasCoopDev coop_dev(const EasCoop* c) {
-    EasCoopDev d{};
-    if (c) {
-        d.slots = (unsigned long long*)c->slots;
-        d.tickets = c->tickets;
-        d.err = c->err;
-        d.capacity = c->capacity;
-    }
-    return d;
-}
-
 }  // namespace
 
 extern "C" {
@@ -309,19 +223,10 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
         return EAS_ERR_INVALID_ARG;
     if (out_ctot == C) out_ctot = 0;
     if (y_ctot == C) y_ctot = 0;
-    if (y_ctot && pend && !pend->partial && pend->coop) return EAS_ERR_UNSUPPORTED;     // the cooperative form reads a contiguous y
     if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
     BnFin fin{};
-    EasCoopDev co{};
-    if (pend && !pend->partial && pend->coop) {
-        if (!pend->coop->slots || !pend->coop->tickets || !pend->coop->err || pend->coop->capacity < C) return EAS_ERR_INVALID_ARG;
-        if (!(pend->count >= 1.0) || pend->replicas < 1 || (pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
-        fin.coop = 1; fin.replicas = pend->replicas; fin.count = pend->count;
-        fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
-        fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
-        co = coop_dev(pend->coop);
-    } else if (pend && pend->partial) {
+    if (pend && pend->partial) {
         if (pend->chunks < 1 || pend->chunks > (pend->pitch ? pend->pitch : kMaxChunks) || pend->pitch < 0 || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
         if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
         fin.part = pend->partial; fin.nchunks = pend->chunks; fin.pitch = pend->pitch ? pend->pitch : kMaxChunks; fin.replicas = pend->replicas; fin.count = pend->count;
@@ -331,7 +236,7 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin, co,
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin,
                        out_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -344,14 +249,12 @@ int eas_bn_silu_fwd(const float* y, const float* mean, const float* invstd, cons
 
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                    double* workspace, int N, int C, int HW, int go_ctot, int y_ctot, const EasCoop* coop, eas_stream_t stream) {
-    if (!grad_out || !y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || (!workspace && !coop) ||
+                    double* workspace, int N, int C, int HW, int go_ctot, int y_ctot, eas_stream_t stream) {
+    if (!grad_out || !y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
         N < 1 || C < 1 || HW < 1 || (go_ctot != 0 && go_ctot < C) || (y_ctot != 0 && y_ctot < C))
         return EAS_ERR_INVALID_ARG;
     if (go_ctot == C) go_ctot = 0;
     if (y_ctot == C) y_ctot = 0;
-    if ((go_ctot || y_ctot) && coop) return EAS_ERR_UNSUPPORTED;       // the cooperative form reads contiguous tensors
-    if (coop && (!coop->slots || !coop->tickets || !coop->err || coop->capacity < C)) return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)y | (uintptr_t)grad_out | (uintptr_t)grad_y) & 15) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
@@ -363,7 +266,7 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
         static const bool small_ok = !(getenv("EAS_BNSILU_BWD") && getenv("EAS_BNSILU_BWD")[0] == 't');
         constexpr int GPT = 6;
         const int64_t groups = (int64_t)N * (HW / VEC);
-        if (small_ok && !coop && C >= 64 && groups <= 1024 * GPT) {
+        if (small_ok && C >= 64 && groups <= 1024 * GPT) {
 #define EAS_SMALL(NT_) hipLaunchKernelGGL((bn_silu_bwd_small_kernel<NT_, GPT>), dim3(C), dim3(NT_), 0, st, grad_out, y, mean, invstd, gamma, beta, \
                                            batch_stats, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot)
             if (groups <= 256 * GPT) EAS_SMALL(256);
@@ -373,12 +276,6 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
             EAS_CHECK_LAUNCH();
             return EAS_OK;
         }
-    }
-    if (coop) {
-        hipLaunchKernelGGL(bn_silu_bwd_coop_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta, batch_stats,
-                           grad_y, grad_gamma, grad_beta, N, C, HW, coop_dev(coop));
-        EAS_CHECK_LAUNCH();
-        return EAS_OK;
     }
     hipLaunchKernelGGL(bn_silu_bwd_kernel<false>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
                        batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot);

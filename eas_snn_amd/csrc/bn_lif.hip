@@ -119,9 +119,12 @@ struct BnLifOut {
     const float* residual;   // nullable [T][N][C][HW]: spikes_out = spikes + residual (SEW shortcut, network_blocks.py:99-104)
     int out_ctot;            // 0: dense; else spikes are channels of a [T][N][out_ctot][HW] tensor (pointer already at channel 0 of the slice)
     int y_ctot;              // 0: dense; else y is such a channel slice of a [T][N][y_ctot][HW] tensor (one convolution feeding two BN+LIF layers)
-    uint8_t* u8;             // nullable: the same output values (0/1 spikes or SEW sums <= 255) once more as bytes, laid out like `spikes`
-                             // (1 B instead of 4 B for the HBM-bound 1x1 convolutions that read them next: eas_conv_fwd_u8 / eas_conv_wgrad_u8)
 };
+
+// Spike planes (eas_hip.h "spike planes"): the output values (0/1 spikes, SEW sums: exact in bf16) as bf16 in blocks of 8 channels,
+// [T*N][C/8][HW][8] -- the layout in which every consumer's matrix-core fragment (8 consecutive input channels of one pixel) is ONE
+// 16-byte load, at half the bytes of fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int T_, bool HARD, bool DI, bool STRICT>
@@ -131,41 +134,13 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
                                                                const float* __restrict__ beta, const float* v_in, float* v_out,
                                                                EasLifParams p, float* __restrict__ spikes,
                                                                float* __restrict__ mean_out, int N, int C, int HW, int bcast,
-                                                               BnFin fin, BnLifOut ox, EasCoopDev co) {
+                                                               BnFin fin, BnLifOut ox) {
     __shared__ float st[2];
-    __shared__ double red[NW];
-    __shared__ double shd[2];
     const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
     if (c >= C) return;
     const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     float mu, istd;
-    if (fin.coop) {
-        // batch statistics in this launch: sums over this block's own (image, pixel group) chunk and all T planes of it (one plane
-        // when the T steps share it), exchanged between the channel's blocks; the apply loop below re-reads the chunk from L2
-        const int hw4s = HW / VEC;
-        const int Cys = ox.y_ctot ? ox.y_ctot : C;
-        const int64_t ytss = bcast ? 0 : (int64_t)N * Cys * HW;
-        const int Tst = bcast ? 1 : T_;
-        double s = 0.0, ss = 0.0;
-        GroupWalk gs((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4s);
-        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < (int64_t)N * hw4s; g += (int64_t)nchunks_g * blockDim.x, gs.next()) {
-            const int64_t yb = ((int64_t)gs.n * Cys + c) * (int64_t)HW + (int64_t)gs.q * VEC;
-            float4 v[T_];
-#pragma unroll
-            for (int t = 0; t < T_; ++t)
-                if (t < Tst) v[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * ytss + yb);
-#pragma unroll
-            for (int t = 0; t < T_; ++t)
-                if (t < Tst) {
-                    s += (double)v[t].x + (double)v[t].y + (double)v[t].z + (double)v[t].w;
-                    ss += (double)v[t].x * v[t].x + (double)v[t].y * v[t].y + (double)v[t].z * v[t].z + (double)v[t].w * v[t].w;
-                }
-        }
-        const double mine[2] = {eas_block_sum<double, NW>(s, red), eas_block_sum<double, NW>(ss, red)};
-        double tot[2];
-        eas_channel_allreduce<2>(co, c, chunk, nchunks_g, mine, tot, shd);
-        bn_from_totals(fin, c, tot[0], tot[1], chunk == 0 && threadIdx.x == 0, mu, istd);
-    } else if (fin.part) {
+    if (fin.part) {
         bn_finalize_in_block(fin, c, st, mu, istd, chunk == 0);
     } else {
         mu = mean[c];
@@ -207,14 +182,108 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_kernel(const float* __re
             }
             const int64_t obase = ox.out_ctot ? (n * ox.out_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
             *reinterpret_cast<float4*>(spikes + (int64_t)t * Mo + obase) = s;
-            if (ox.u8)
-                *reinterpret_cast<uint32_t*>(ox.u8 + (int64_t)t * Mo + obase) =
-                    (uint32_t)s.x | ((uint32_t)s.y << 8) | ((uint32_t)s.z << 16) | ((uint32_t)s.w << 24);
         }
         if (v_out) *reinterpret_cast<float4*>(v_out + base) = v;
         if (mean_out) {
             const float Tf = (float)T_;   // sum / T, like ATen's mean
             *reinterpret_cast<float4*>(mean_out + base) = make_float4(acc.x / Tf, acc.y / Tf, acc.z / Tf, acc.w / Tf);
+        }
+    }
+}
+
+// mean / invstd (and the running statistics) of every channel from the chunk partials, one block per channel, in the summation order of
+// bn_finalize_in_block: the statistics the plane-writing kernel below reads are bit-identical to the ones the fp32 kernel forms itself.
+__global__ __launch_bounds__(EAS_BLOCK) void bn_finalize_kernel(BnFin fin) {
+    __shared__ float st[2];
+    float mu, istd;
+    bn_finalize_in_block(fin, (int)blockIdx.x, st, mu, istd, true);
+}
+
+// The same layer writing its output as spike planes.  A thread owns the 8 channels of one group for PV consecutive pixels of an image:
+// 8 x T loads of PV floats (each channel row is contiguous over the lanes), the neuron over T in registers, and per step ONE 16-byte
+// store per pixel.  blockIdx -> (channel group, chunk of the group's N * HW / PV pixel groups).  residual: planes as well.
+template <int T_, bool HARD, bool DI, bool STRICT, int PV>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_sp_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* v_in, float* v_out,
+                                                                  EasLifParams p, bf16x8* __restrict__ planes, const bf16x8* __restrict__ res_planes,
+                                                                  float* __restrict__ mean_out, int N, int C, int HW, int bcast, int y_ctot,
+                                                                  int out_groups_tot, int res_groups_tot) {
+    typedef float vecp __attribute__((ext_vector_type(PV)));
+    const int grp = blockIdx.z * 8 + blockIdx.x;
+    const int G = C / 8;
+    if (grp >= G) return;
+    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
+    float scale[8], shift[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 8 * grp + j;
+        scale[j] = gamma[c] * invstd[c];
+        shift[j] = beta[c] - mean[c] * scale[j];
+    }
+    const float k = eas_lif_k(p);
+    const float omk = 1.0f - k;
+    const int hwp = HW / PV;
+    const int64_t groups = (int64_t)N * hwp;
+    const int Cy = y_ctot ? y_ctot : C;
+    const int64_t yts = bcast ? 0 : (int64_t)N * Cy * HW;
+    const float vr0 = HARD ? p.v_reset : 0.0f;
+    const float Tf = (float)T_;
+    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hwp);
+    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
+        const int64_t n = gw.n;
+        const int q = gw.q;
+        vecp ys[8][T_];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t yb = (n * Cy + 8 * grp + j) * (int64_t)HW + (int64_t)q * PV;
+#pragma unroll
+            for (int t = 0; t < T_; ++t) ys[j][t] = *reinterpret_cast<const vecp*>(y + (int64_t)t * yts + yb);
+        }
+        float v[8][PV], acc[8][PV];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            vecp v0;
+            if (v_in) v0 = *reinterpret_cast<const vecp*>(v_in + (n * C + 8 * grp + j) * (int64_t)HW + (int64_t)q * PV);
+#pragma unroll
+            for (int e = 0; e < PV; ++e) { v[j][e] = v_in ? v0[e] : vr0; acc[j][e] = 0.f; }
+        }
+#pragma unroll
+        for (int t = 0; t < T_; ++t) {
+            bf16x8 rp[PV];
+            if (res_planes) {
+#pragma unroll
+                for (int e = 0; e < PV; ++e) rp[e] = res_planes[(((int64_t)t * N + n) * res_groups_tot + grp) * (int64_t)HW + (int64_t)q * PV + e];
+            }
+#pragma unroll
+            for (int e = 0; e < PV; ++e) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float h, s;
+                    eas_lif_step<HARD, DI, STRICT>(v[j][e], fmaf(ys[j][t][e], scale[j], shift[j]), k, omk, p.v_th, p.v_reset, h, s);
+                    acc[j][e] += s;
+                    if (res_planes) s += (float)rp[e][j];
+                    o[j] = (__bf16)s;
+                }
+                planes[(((int64_t)t * N + n) * out_groups_tot + grp) * (int64_t)HW + (int64_t)q * PV + e] = o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t base = (n * C + 8 * grp + j) * (int64_t)HW + (int64_t)q * PV;
+            if (v_out) {
+                vecp o;
+#pragma unroll
+                for (int e = 0; e < PV; ++e) o[e] = v[j][e];
+                *reinterpret_cast<vecp*>(v_out + base) = o;
+            }
+            if (mean_out) {
+                vecp o;
+#pragma unroll
+                for (int e = 0; e < PV; ++e) o[e] = acc[j][e] / Tf;
+                *reinterpret_cast<vecp*>(mean_out + base) = o;
+            }
         }
     }
 }
@@ -245,218 +314,7 @@ __device__ __forceinline__ void recompute_dz(const float (&yv)[T_], const float 
     }
 }
 
-// One launch for both passes (EasCoop): pass 1 over the block's chunk, the channel's four sums exchanged in the kernel, pass 2 over
-// the same chunk (grad_s / y come from L2 / Infinity Cache this time), dL/dw and dL/dalpha summed over the channels by the last
-// channel to finish.
-template <int T_, bool HARD, bool DI, bool STRICT>
-__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_coop_kernel(
-    const float* __restrict__ grad_s, const float* __restrict__ grad_mean, const float* __restrict__ y,
-    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
-    int batch_stats, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-    float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot,
-    const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha, EasCoopDev co) {
-    __shared__ double red[NW];
-    __shared__ double shd[4];
-    __shared__ int shi;
-    if (alpha_dev) alpha = fabsf(*alpha_dev);
-    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
-    if (c >= C) return;
-    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
-    const float mu = mean[c], istd = invstd[c];
-    const float scale = gamma[c] * istd;
-    const float shift = beta[c] - mu * scale;
-    const float k = eas_lif_k(p);
-    const float omk = 1.0f - k;
-    const bool detach = (p.flags & EAS_LIF_DETACH_RESET) != 0;
-    const int hw4 = HW / VEC;
-    const int64_t groups = (int64_t)N * hw4;
-    const int64_t M = (int64_t)N * C * HW;
-    const float invT = 1.0f / (float)T_;
-    const int Cy = y_ctot ? y_ctot : C;
-    const int64_t My = (int64_t)N * Cy * HW;
-    const int64_t yts = bcast ? 0 : My;
-    const int64_t Mg = gs_ctot ? (int64_t)N * gs_ctot * HW : M;
-    const float vr0 = HARD ? p.v_reset : 0.0f;
-    float m1 = 0.f, m2 = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
-        float s1 = 0.f, s2 = 0.f, dk = 0.f, da = 0.f;
-        GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
-        for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
-            const int64_t n = gw.n;
-            const int q = gw.q;
-            const int64_t base = (n * C + c) * (int64_t)HW + (int64_t)q * VEC;
-            const int64_t ybase = (n * Cy + c) * (int64_t)HW + (int64_t)q * VEC;
-            float4 ys[T_], gsv[T_];
-#pragma unroll
-            for (int t = 0; t < T_; ++t) ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * yts + ybase);
-            float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grad_mean) {
-                gm = *reinterpret_cast<const float4*>(grad_mean + base);
-                gm.x *= invT; gm.y *= invT; gm.z *= invT; gm.w *= invT;
-            }
-#pragma unroll
-            for (int t = 0; t < T_; ++t) {
-                gsv[t] = gm;
-                if (grad_s) {
-                    const int64_t gbase = gs_ctot ? (n * gs_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
-                    const float4 g4 = *reinterpret_cast<const float4*>(grad_s + (int64_t)t * Mg + gbase);
-                    gsv[t].x += g4.x; gsv[t].y += g4.y; gsv[t].z += g4.z; gsv[t].w += g4.w;
-                }
-            }
-            float4 v0 = make_float4(vr0, vr0, vr0, vr0);
-            if (v_init) v0 = *reinterpret_cast<const float4*>(v_init + base);
-            float4 outv[T_];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float yv[T_], gs[T_], dz[T_];
-#pragma unroll
-                for (int t = 0; t < T_; ++t) {
-                    yv[t] = reinterpret_cast<const float*>(&ys[t])[e];
-                    gs[t] = reinterpret_cast<const float*>(&gsv[t])[e];
-                }
-                float dke = 0.f;
-                recompute_dz<T_, HARD, DI, STRICT>(yv, gs, reinterpret_cast<const float*>(&v0)[e], scale, shift, k, omk, p, detach, sg_id, alpha,
-                                                   dz, dke, da);
-#pragma unroll
-                for (int t = 0; t < T_; ++t) {
-                    const float xhat = (yv[t] - mu) * istd;
-                    if (pass) {
-                        reinterpret_cast<float*>(&outv[t])[e] = scale * (dz[t] - m1 - xhat * m2);
-                    } else {
-                        s1 += dz[t];
-                        s2 += dz[t] * xhat;
-                    }
-                }
-                dk += dke;
-            }
-            if (pass) {
-                if (bcast) {
-                    float4 a = outv[0];
-#pragma unroll
-                    for (int t = 1; t < T_; ++t) { a.x += outv[t].x; a.y += outv[t].y; a.z += outv[t].z; a.w += outv[t].w; }
-                    *reinterpret_cast<float4*>(grad_y + ybase) = a;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * My + ybase) = outv[t];
-                }
-            }
-        }
-        if (pass == 0) {
-            const double t1 = eas_block_sum<double, NW>((double)s1, red);
-            const double t2 = eas_block_sum<double, NW>((double)s2, red);
-            const double t3 = eas_block_sum<double, NW>((double)dk, red);
-            const double t4 = sg_id == EAS_SG_PATAN ? eas_block_sum<double, NW>((double)da, red) : 0.0;
-            const double mine[4] = {t1, t2, t3, t4};
-            double tot[4];
-            eas_channel_allreduce<4>(co, c, chunk, nchunks_g, mine, tot, shd);
-            if (chunk == 0 && threadIdx.x == 0) {
-                grad_beta[c] = (float)tot[0];
-                grad_gamma[c] = (float)tot[1];
-            }
-            const double cnt = (double)T_ * N * HW;
-            if (batch_stats) {
-                m1 = (float)(tot[0] / cnt);
-                m2 = (float)(tot[1] / cnt);
-            }
-            if (chunk == 0) {         // the neuron's scalar gradients: sums over all channels, by the last channel to arrive
-                double all;
-                if (grad_w && eas_all_channels_sum(co, 0, c, C, tot[2], all, shd, &shi) && threadIdx.x == 0) *grad_w = (float)all * (k * (1.0f - k));
-                if (grad_alpha && eas_all_channels_sum(co, 1, c, C, tot[3], all, shd, &shi) && threadIdx.x == 0) {
-                    const float a = *alpha_dev;
-                    *grad_alpha = (float)all * (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f));
-                }
-            }
-        }
-    }
-}
-
-// Pass 2 when pass 1 has parked dz = dL/dz in grad_y ("stash" form): grad_y = scale * (dz - mean(dz) - xhat * mean(dz * xhat)), a
-// streaming kernel over dz and y -- no second LIF recomputation.  Same expression, same bits.  Development form (see launch_bwd_t).
-template <int T_>
-__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean,
-                                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                                     int batch_stats, const double* __restrict__ part, int nchunks,
-                                                                     float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-                                                                     float* __restrict__ grad_beta, float* __restrict__ grad_w,
-                                                                     const float* __restrict__ w_logit, float k_const,
-                                                                     const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha, int N,
-                                                                     int C, int HW, int y_ctot) {
-    __shared__ double red[NW];
-    __shared__ float bc[2];
-    const int c = blockIdx.z * 8 + blockIdx.x;
-    if (c >= C) return;
-    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
-    const float mu = mean[c], istd = invstd[c];
-    const float scale = gamma[c] * istd;
-    if (threadIdx.x < EAS_WAVE) {
-        double s1 = 0.0, s2 = 0.0;
-        if ((int)threadIdx.x < nchunks) {
-            s1 = part[((int64_t)c * kMaxChunks + threadIdx.x) * 4 + 0];
-            s2 = part[((int64_t)c * kMaxChunks + threadIdx.x) * 4 + 1];
-        }
-        s1 = eas_wave_sum(s1);
-        s2 = eas_wave_sum(s2);
-        if (threadIdx.x == 0) {
-            const double cnt = (double)T_ * N * HW;
-            bc[0] = (float)(s1 / cnt);
-            bc[1] = (float)(s2 / cnt);
-            if (chunk == 0) {
-                grad_beta[c] = (float)s1;
-                grad_gamma[c] = (float)s2;
-            }
-        }
-    }
-    __syncthreads();
-    const float m1 = batch_stats ? bc[0] : 0.f, m2 = batch_stats ? bc[1] : 0.f;
-    const int hw4 = HW / VEC;
-    const int64_t groups = (int64_t)N * hw4;
-    const int Cy = y_ctot ? y_ctot : C;
-    const int64_t My = (int64_t)N * Cy * HW;
-    GroupWalk gw((int64_t)chunk * blockDim.x + threadIdx.x, (int64_t)nchunks_g * blockDim.x, hw4);
-    for (int64_t g = (int64_t)chunk * blockDim.x + threadIdx.x; g < groups; g += (int64_t)nchunks_g * blockDim.x, gw.next()) {
-        const int64_t ybase = ((int64_t)gw.n * Cy + c) * (int64_t)HW + (int64_t)gw.q * VEC;
-        float4 ys[T_], dz[T_];
-#pragma unroll
-        for (int t = 0; t < T_; ++t) {
-            ys[t] = *reinterpret_cast<const float4*>(y + (int64_t)t * My + ybase);
-            dz[t] = *reinterpret_cast<const float4*>(grad_y + (int64_t)t * My + ybase);
-        }
-#pragma unroll
-        for (int t = 0; t < T_; ++t) {
-            float4 o;
-            o.x = scale * (dz[t].x - m1 - ((ys[t].x - mu) * istd) * m2);
-            o.y = scale * (dz[t].y - m1 - ((ys[t].y - mu) * istd) * m2);
-            o.z = scale * (dz[t].z - m1 - ((ys[t].z - mu) * istd) * m2);
-            o.w = scale * (dz[t].w - m1 - ((ys[t].w - mu) * istd) * m2);
-            *reinterpret_cast<float4*>(grad_y + (int64_t)t * My + ybase) = o;
-        }
-    }
-    if (grad_w && chunk == 0 && c == 0) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
-            const int cc = i / nchunks, j = i - cc * nchunks;
-            acc += part[((int64_t)cc * kMaxChunks + j) * 4 + 2];
-        }
-        const double tot = eas_block_sum<double, NW>(acc, red);
-        const float k = w_logit ? eas_sigmoidf(*w_logit) : k_const;
-        if (threadIdx.x == 0) *grad_w = (float)tot * (k * (1.0f - k));
-    }
-    if (grad_alpha && chunk == 0 && c == 0) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
-            const int cc = i / nchunks, j = i - cc * nchunks;
-            acc += part[((int64_t)cc * kMaxChunks + j) * 4 + 3];
-        }
-        const double tot = eas_block_sum<double, NW>(acc, red);
-        if (threadIdx.x == 0) {
-            const float a = *alpha_dev;
-            *grad_alpha = (float)tot * (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f));
-        }
-    }
-}
-
-template <int T_, bool HARD, bool DI, bool STRICT, bool APPLY, bool STASH = false>
+template <int T_, bool HARD, bool DI, bool STRICT, bool APPLY>
 __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ grad_s, const float* __restrict__ grad_mean, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -555,14 +413,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
                 } else {
                     s1 += dz[t];
                     s2 += dz[t] * xhat;
-                    if (STASH) reinterpret_cast<float*>(&outv[t])[e] = dz[t];
                 }
             }
             dk += dke;
-        }
-        if (!APPLY && STASH) {           // dz parked in grad_y for the streaming pass 2 (bn_lif_bwd_apply_kernel)
-#pragma unroll
-            for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * My + ybase) = outv[t];
         }
         if (APPLY) {
             if (bcast) {                            // the T steps share one input plane: its gradient is their sum
@@ -615,10 +468,27 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
 template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_fwd_t(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                  const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-                 int bcast, const BnFin& fin, const BnLifOut& ox, const EasCoopDev& co, hipStream_t st) {
+                 int bcast, const BnFin& fin, const BnLifOut& ox, bf16x8* planes, const bf16x8* res_planes, int out_groups, int res_groups,
+                 hipStream_t st) {
+    if (planes) {
+        // spike planes out: the statistics are finalized by their own small launch (a block of this kernel owns 8 channels: finalizing
+        // them inside every block would cost 8x the partial-sum traffic), then one thread = 8 channels x PV pixels
+        if (fin.part) {              // publishes mean / invstd (the arrays this launch was given) and updates the running statistics
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(EAS_BLOCK), 0, st, fin);
+            EAS_CHECK_LAUNCH();
+        }
+        constexpr int PV = T_ <= 4 ? 4 : 2;
+        if (HW % PV != 0) return EAS_ERR_UNSUPPORTED;
+        const int chunks = pick_chunks((int64_t)N * (HW / PV), C / 8);
+        hipLaunchKernelGGL((bn_lif_fwd_sp_kernel<T_, HARD, DI, STRICT, PV>), EAS_CHAN_GRID(chunks, C / 8), dim3(EAS_BLOCK), 0, st, y,
+                           mean, invstd, gamma, beta, v_in,
+                           v_out, p, planes, res_planes, mean_out, N, C, HW, bcast, ox.y_ctot, out_groups, res_groups);
+        EAS_CHECK_LAUNCH();
+        return EAS_OK;
+    }
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
-                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, co);
+                       invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -626,9 +496,10 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
 template <bool HARD, bool DI, bool STRICT>
 int launch_fwd(int T, const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
-               int bcast, const BnFin& fin, const BnLifOut& ox, const EasCoopDev& co, hipStream_t st) {
+               int bcast, const BnFin& fin, const BnLifOut& ox, bf16x8* planes, const bf16x8* res_planes, int out_groups, int res_groups,
+               hipStream_t st) {
 #define EAS_CASE(TT) \
-    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, co, st);
+    case TT: return launch_fwd_t<TT, HARD, DI, STRICT>(y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox, planes, res_planes, out_groups, res_groups, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -640,30 +511,10 @@ template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg, float alpha,
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
-                 int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, const EasCoopDev& co,
-                 hipStream_t st) {
+                 int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    if (co.slots) {
-        hipLaunchKernelGGL((bn_lif_bwd_coop_kernel<T_, HARD, DI, STRICT>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean, y, mean,
-                           invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, N, C, HW, bcast,
-                           gs_ctot, y_ctot, alpha_dev, grad_alpha, co);
-        EAS_CHECK_LAUNCH();
-        return EAS_OK;
-    }
-    // development switch EAS_BNLIF_BWD=stash: pass 1 parks dz in grad_y and a streaming pass 2 finishes it (24 B per neuron-step and
-    // half the vector-ALU work instead of 20 B and two LIF recomputations).  Measured on MI355X: 2.66 ms per step against 2.55 ms for
-    // the recomputing form -- the backward is bound by bytes, not by the vector ALU -- so recomputing stays the default.
-    static const bool stash = getenv("EAS_BNLIF_BWD") && getenv("EAS_BNLIF_BWD")[0] == 's';
-    if (stash && !bcast) {
-        hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false, true>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
-                           grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                           grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
-        EAS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((bn_lif_bwd_apply_kernel<T_>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, batch_stats,
-                           ws, chunks, grad_y, grad_gamma, grad_beta, grad_w, p.w_logit, p.k_const, alpha_dev, grad_alpha, N, C, HW, y_ctot);
-        EAS_CHECK_LAUNCH();
-        return EAS_OK;
-    }
+    // two passes: the BatchNorm backward needs the channel's sums of dz and dz * xhat before any grad_y; pass 2 recomputes the neuron
+    // (cheaper than parking dz: measured)
     hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
                        grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
@@ -680,12 +531,12 @@ int launch_bwd(int T, const float* grad_s, const float* grad_mean, const float* 
                const float* invstd, const float* gamma, const float* beta, const float* v_init, EasLifParams p, int sg,
                float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w,
                double* ws, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha,
-               const EasCoopDev& co, hipStream_t st) {
+               hipStream_t st) {
 #define EAS_CASE(TT)                                                                                               \
     case TT:                                                                                                       \
         return launch_bwd_t<TT, HARD, DI, STRICT>(grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, \
                                                   batch_stats, grad_y, grad_gamma, grad_beta, grad_w, ws, N, C, HW, bcast, gs_ctot, y_ctot,         \
-                                                  alpha_dev, grad_alpha, co, st);
+                                                  alpha_dev, grad_alpha, st);
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default: return EAS_ERR_UNSUPPORTED;
@@ -737,29 +588,8 @@ int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, doub
     return stats_partial(y, TN, C, HW, workspace, y_ctot == C ? 0 : y_ctot, eas_s(stream));
 }
 
-static EasCoopDev coop_dev(const EasCoop* c) {
-    EasCoopDev d{};
-    if (c) {
-        d.slots = (unsigned long long*)c->slots;
-        d.tickets = c->tickets;
-        d.err = c->err;
-        d.capacity = c->capacity;
-    }
-    return d;
-}
-
-int64_t eas_coop_slot_words(int capacity) { return capacity < 1 ? 0 : (int64_t)capacity * EAS_BN_MAX_CHUNKS * EAS_COOP_K + 2 * (int64_t)capacity; }
-
 static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin& fin) {
     fin = BnFin{};
-    if (pend && !pend->partial && pend->coop) {
-        if (!pend->coop->slots || !pend->coop->tickets || !pend->coop->err) return EAS_ERR_INVALID_ARG;
-        if (!(pend->count >= 1.0) || pend->replicas < 1 || (pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
-        fin.coop = 1; fin.replicas = pend->replicas; fin.count = pend->count;
-        fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = mean; fin.invstd_out = invstd;
-        fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
-        return EAS_OK;
-    }
     if (!pend || !pend->partial) return EAS_OK;
     if (pend->chunks < 1 || pend->chunks > (pend->pitch ? pend->pitch : kMaxChunks) || pend->pitch < 0 || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
     if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
@@ -772,24 +602,33 @@ static int fin_from(const EasBnPending* pend, float* mean, float* invstd, BnFin&
 int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
                       const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                       int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
-                      const EasBnPending* pending, const float* residual, int out_ctot, uint8_t* spikes_u8, eas_stream_t stream) {
-    if (!y || !mean || !invstd || !gamma || !beta || !spikes || T < 1 || N < 1 || C < 1 || HW < 1)
+                      const EasBnPending* pending, const float* residual, int out_ctot, void* spikes_planes, const void* residual_planes,
+                      int residual_ctot, eas_stream_t stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || (!spikes && !spikes_planes) || (spikes && spikes_planes) || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
     if (HW % VEC != 0 || C > 65535 || T > 8) return EAS_ERR_UNSUPPORTED;
-    if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out | (uintptr_t)residual) & 15) return EAS_ERR_INVALID_ARG;
-    if ((uintptr_t)spikes_u8 & 3) return EAS_ERR_INVALID_ARG;
+    if (((uintptr_t)y | (uintptr_t)v_in | (uintptr_t)v_out | (uintptr_t)spikes | (uintptr_t)mean_out | (uintptr_t)residual |
+         (uintptr_t)spikes_planes | (uintptr_t)residual_planes) & 15)
+        return EAS_ERR_INVALID_ARG;
     if ((out_ctot != 0 && out_ctot < C) || (y_ctot != 0 && (y_ctot < C || y_bcast))) return EAS_ERR_INVALID_ARG;
+    if (spikes_planes) {
+        // planes are blocks of 8 channels: the layer's channels, its slice of a concatenation and a residual must be whole blocks
+        if (C % 8 != 0 || (out_ctot % 8) != 0 || residual || (residual_planes && (residual_ctot % 8 != 0 || (residual_ctot != 0 && residual_ctot < C))))
+            return EAS_ERR_UNSUPPORTED;
+    } else if (residual_planes) {
+        return EAS_ERR_UNSUPPORTED;
+    }
     BnFin fin;
     if (int rc = fin_from(pending, mean, invstd, fin)) return rc;
-    if (fin.coop && pending->coop->capacity < C) return EAS_ERR_INVALID_ARG;
-    const EasCoopDev co = fin.coop ? coop_dev(pending->coop) : EasCoopDev{};
-    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot, y_ctot == C ? 0 : y_ctot, spikes_u8};
+    const BnLifOut ox{residual, out_ctot == C ? 0 : out_ctot, y_ctot == C ? 0 : y_ctot};
     EasLifParams p{w_logit, k_const, v_th, v_reset, flags};
     const bool hard = flags & EAS_LIF_HARD_RESET, di = flags & EAS_LIF_DECAY_INPUT, strict = flags & EAS_LIF_FIRE_STRICT;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
-#define EAS_DISPATCH(H, D, S) \
-    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, fin, ox, co, st)
+    const int out_groups = (out_ctot ? out_ctot : C) / 8, res_groups = (residual_ctot ? residual_ctot : C) / 8;
+#define EAS_DISPATCH(H, D, S)                                                                                                          \
+    return launch_fwd<H, D, S>(T, y, mean, invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, y_bcast, fin, ox,           \
+                               (bf16x8*)spikes_planes, (const bf16x8*)residual_planes, out_groups, res_groups, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -803,7 +642,7 @@ int eas_bn_lif_fwd(const float* y, const float* mean, const float* invstd, const
                    int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
                    eas_stream_t stream) {
     return eas_bn_lif_fwd_ex(y, 0, const_cast<float*>(mean), const_cast<float*>(invstd), gamma, beta, v_in, v_out, w_logit, k_const, v_th,
-                             v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, nullptr, stream);
+                             v_reset, flags, spikes, mean_out, T, N, C, HW, y_bcast, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
@@ -811,10 +650,8 @@ static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* gr
                            const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                            float alpha, const float* alpha_dev, float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma,
                            float* grad_beta, float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast,
-                           const EasCoop* coop, eas_stream_t stream) {
-    if (coop && (!coop->slots || !coop->tickets || !coop->err || coop->capacity < C)) return EAS_ERR_INVALID_ARG;
-    const EasCoopDev co = coop_dev(coop);
-    if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || (!workspace && !coop) ||
+                           eas_stream_t stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || !grad_y || !grad_gamma || !grad_beta || !workspace ||
         (!grad_s && !grad_mean) || T < 1 || N < 1 || C < 1 || HW < 1)
         return EAS_ERR_INVALID_ARG;
     if (surrogate < EAS_SG_ATAN || surrogate > EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;
@@ -833,7 +670,7 @@ static int bn_lif_bwd_impl(const float* grad_s, int grad_s_ctot, const float* gr
 #define EAS_DISPATCH(H, D, S)                                                                                       \
     return launch_bwd<H, D, S>(T, grad_s, grad_mean, y, mean, invstd, gamma, beta, v_init, p, surrogate, alpha,     \
                                batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, N, C, HW, y_bcast, gs_ctot, yc,    \
-                               alpha_dev, grad_alpha, co, st)
+                               alpha_dev, grad_alpha, st)
     if (!hard && !di && !strict) EAS_DISPATCH(false, false, false);
     if (hard && !di && !strict) EAS_DISPATCH(true, false, false);
     if (!hard && di && !strict) EAS_DISPATCH(false, true, false);
@@ -846,21 +683,21 @@ int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_me
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop, eas_stream_t stream) {
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
     if (surrogate == EAS_SG_PATAN) return EAS_ERR_INVALID_ARG;      // learnable slope: eas_bn_lif_bwd_patan
     return bn_lif_bwd_impl(grad_s, grad_s_ctot, grad_mean, y, y_ctot, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset,
                            flags, surrogate, alpha, nullptr, nullptr, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C,
-                           HW, y_bcast, coop, stream);
+                           HW, y_bcast, stream);
 }
 
 int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, const float* v_init,
                          const float* w_logit, float k_const, float v_th, float v_reset, int flags, const float* alpha,
                          float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop, eas_stream_t stream) {
+                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
     return bn_lif_bwd_impl(grad_s, grad_s_ctot, grad_mean, y, y_ctot, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset,
                            flags, EAS_SG_PATAN, 0.f, alpha, grad_alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C,
-                           HW, y_bcast, coop, stream);
+                           HW, y_bcast, stream);
 }
 
 int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, const float* mean,
@@ -869,7 +706,7 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
                    float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
                    float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream) {
     return eas_bn_lif_bwd_ex(grad_s, 0, grad_mean, y, 0, mean, invstd, gamma, beta, v_init, w_logit, k_const, v_th, v_reset, flags,
-                             surrogate, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C, HW, y_bcast, nullptr, stream);
+                             surrogate, alpha, batch_stats, grad_y, grad_gamma, grad_beta, grad_w, workspace, T, N, C, HW, y_bcast, stream);
 }
 
 }  // extern "C"

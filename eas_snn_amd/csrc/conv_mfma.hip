@@ -213,10 +213,13 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // lane for VEC = 4) and VEC 16-byte LDS stores per term.  The next chunk's items are all requested during the first MFMA
 // steps of the current chunk and written to the other LDS buffer during its last steps, so each load has several thousand
 // cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+// PL: x is a spike-plane tensor (bf16 [NI][Cin/8][Hi*Wi][8], one exact term): the 8 channels of a staged pixel are 16 contiguous bytes
+// in HBM and in LDS -- a staging item is VEC 16-byte loads and VEC 16-byte LDS stores, no conversion, half the bytes of fp32.
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
 __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
                                                float* __restrict__ y, int* __restrict__ inexact, const ConvGeom& g, const int part,
                                                unsigned char* smem) {
+    static_assert(!PL || XT == 1, "spike planes are one exact bf16 term");
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     constexpr int PIXB = CCH * 2;  // bytes per staged pixel and term
     constexpr int NSTEPS = (CCH / 16) * TAPS;
@@ -283,7 +286,8 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         const int ir = r0 * S - g.pad_t + rl, img = img0 + seg;
         const int gc = gcol0 + cu * VEC;
         const bool ok = ir >= 0 && ir < g.Hi && img < g.NI && gc >= 0 && gc < g.Wi;
-        gofs[it] = ok ? (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + gc) : -1;
+        gofs[it] = ok ? (PL ? (int)((((size_t)img * (g.Cin / 8)) * g.Hi + ir) * g.Wi + gc)          // planes: in 16-byte units, group 0
+                            : (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + gc)) : -1;
         lofs[it] = ((seg * g.rows_in + rl) * g.RS + g.pad_l + cu * VEC) * 16 + gi * grp;
         gch[it] = gi * 8;
     }
@@ -324,21 +328,35 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 
     // loads are unconditional: a row outside the image or a channel group past Cin (Cin % 8 == 0: a group is valid or not as
     // a whole) reads the zero page with channel stride 0, so nothing branches, waits or needs masking around them
-    vecf L[NIT][8];
+    vecf L[NIT][PL ? 1 : 8];
+    u32x4 LP[NIT][PL ? VEC : 1];
     auto fetch = [&](int it, int c0) {
         const bool ok = gofs[it] >= 0 && c0 + gch[it] < g.Cin;
-        const float* src = ok ? x + (size_t)gofs[it] + (size_t)(c0 + gch[it]) * plane : eas_conv_zero_page;
-        const size_t cs = ok ? plane : 0;
+        if constexpr (PL) {
+            // VEC consecutive pixels of 8-channel group (c0 + gch) / 8: VEC x 16 contiguous bytes
+            const u32x4* src = ok ? reinterpret_cast<const u32x4*>(x) + (size_t)gofs[it] + (size_t)((c0 + gch[it]) >> 3) * plane
+                                  : reinterpret_cast<const u32x4*>(eas_conv_zero_page);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * cs);
+            for (int p = 0; p < VEC; ++p) LP[it][p] = src[ok ? p : 0];
+        } else {
+            const float* src = ok ? x + (size_t)gofs[it] + (size_t)(c0 + gch[it]) * plane : eas_conv_zero_page;
+            const size_t cs = ok ? plane : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(src + j * cs);
+        }
     };
     auto commit = [&](unsigned char* buf, int it, int c0) {
+        if constexpr (PL) {
 #pragma unroll
-        for (int p = 0; p < VEC; ++p) {
-            float v[8];
+            for (int p = 0; p < VEC; ++p) *(u32x4*)(buf + lofs[it] + p * 16) = LP[it][p];
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = L[it][j][p];
-            stage_store<XT>(buf + lofs[it] + p * 16, term_stride, v, inexact);
+            for (int p = 0; p < VEC; ++p) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = L[it][j][p];
+                stage_store<XT>(buf + lofs[it] + p * 16, term_stride, v, inexact);
+            }
         }
     };
 
@@ -484,12 +502,12 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     }
 }
 
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
 __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
                                                             ConvGeom g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem);
+    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem);
 }
 
 // Input gradient of a stride-2 3x3 convolution in ONE launch: blockIdx.z = parity class of the input pixel, every class a stride-1
@@ -550,9 +568,9 @@ int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
     return EAS_OK;
 }
 
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
 int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
-    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT>;
+    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL>;
     const int nbuf = g.KSTEPS * 16 <= CCH ? 1 : 2;      // one channel chunk: the second (prefetch) buffer is never used
     size_t lds = (size_t)nbuf * g.Q * CCH * 2 * XT;
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
@@ -586,7 +604,7 @@ typedef int (*launch_fn)(const float*, const bf16x8*, const float*, float*, int*
 // partials eas_conv_fwd_stats writes per channel
 thread_local int tl_pixel_blocks = 0;
 
-template <int TAPS, int S, int XT, int CCH, int VEC>
+template <int TAPS, int S, int XT, int CCH, int VEC, bool PL = false>
 int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
     // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
     // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
@@ -596,14 +614,14 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
     // four 20-pixel rows or one 8x10 image) exists for the small maps of the neck / head and of dark4 / dark5, where 160-pixel wave
     // tiles leave most of the 256 CUs without a block (64 images of 8x10 with 128 channels are 16 eight-wave blocks)
     const Cand cands[14] = {
-        {1, 2, 640, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8>}, {1, 4, 320, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8>},
-        {1, 8, 160, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8>}, {1, 1, 1280, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8>},
-        {1, 1, 640, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4>}, {1, 2, 320, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4>},
-        {1, 4, 160, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4>},
-        {1, 2, 384, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 4, CCH, VEC, N8>}, {1, 4, 192, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 2, CCH, VEC, N8>},
-        {1, 8, 96, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 8, 1, CCH, VEC, N8>}, {1, 1, 768, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 8, CCH, VEC, N8>},
-        {1, 1, 384, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 4, CCH, VEC, N4>}, {1, 2, 192, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 2, CCH, VEC, N4>},
-        {1, 4, 96, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 1, CCH, VEC, N4>}};
+        {1, 2, 640, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8, PL>}, {1, 4, 320, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8, PL>},
+        {1, 8, 160, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8, PL>}, {1, 1, 1280, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8, PL>},
+        {1, 1, 640, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4, PL>}, {1, 2, 320, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4, PL>},
+        {1, 4, 160, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4, PL>},
+        {1, 2, 384, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 4, CCH, VEC, N8, PL>}, {1, 4, 192, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 2, CCH, VEC, N8, PL>},
+        {1, 8, 96, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 8, 1, CCH, VEC, N8, PL>}, {1, 1, 768, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 8, CCH, VEC, N8, PL>},
+        {1, 1, 384, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 4, CCH, VEC, N4, PL>}, {1, 2, 192, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 2, CCH, VEC, N4, PL>},
+        {1, 4, 96, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 1, CCH, VEC, N4, PL>}};
     // cost model (measured on MI355X, scripts/dev_conv.py, scripts/dev_conv_calls.py): one block per CU; a round of 8-wave blocks costs
     // ~1.27x a round of 4-wave blocks; a block's time is a fixed part (prologue, first patch, epilogue) plus its MFMA work, which
     // goes with WN whatever part of the pixel tile is valid
@@ -665,8 +683,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
 }  // namespace
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st, double* stats, int stats_nb, int* nb_out);
-int eas_conv1x1_dispatch_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, hipStream_t st);
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes);
 
 extern "C" {
 
@@ -707,7 +724,13 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     if (!query && (!x || !packed_w || !y)) return EAS_ERR_INVALID_ARG;
     if (stats && (bias || stats_nb < 1)) return EAS_ERR_INVALID_ARG;
     if (NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || (ksize == 3 && (Cin % 8 != 0 || Wi % 2 != 0))) return EAS_ERR_UNSUPPORTED;
+    // x_terms: 1 = fp32 tensor holding small integers (one bf16 term), 3 = general fp32, 2 = SPIKE PLANES (bf16 [NI][Cin/8][Hi*Wi][8], one term)
+    const bool planes = x_terms == 2;
+    if (planes) x_terms = 1;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (x_terms != 1 && x_terms != 3) || (ksize == 3 && (Cin % 8 != 0 || Wi % 2 != 0)) ||
+        (planes && Cin % 8 != 0))
+        return EAS_ERR_UNSUPPORTED;
+    if (planes && !query && ((uintptr_t)x & 15)) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
     ConvGeom g{};
     const int pad = ksize / 2;
@@ -732,7 +755,9 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     const bool v4 = Wi % 4 == 0;
     tl_pixel_blocks = 0;
 #define EAS_CONV_DISPATCH(TAPS_, S_, CCH_)                                                                                        \
-    rc = x_terms == 1 ? (v4 ? dispatch_tile<TAPS_, S_, 1, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
+    rc = planes ? (v4 ? dispatch_tile<TAPS_, S_, 1, CCH_, 4, true>(x, wp, bias, y, inexact_flag, g, st)                           \
+                      : dispatch_tile<TAPS_, S_, 1, CCH_, 2, true>(x, wp, bias, y, inexact_flag, g, st))                          \
+       : x_terms == 1 ? (v4 ? dispatch_tile<TAPS_, S_, 1, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
                             : dispatch_tile<TAPS_, S_, 1, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))                          \
                       : (v4 ? dispatch_tile<TAPS_, S_, 3, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
                             : dispatch_tile<TAPS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
@@ -760,7 +785,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     }
     if (ksize == 1 && stride == 1) {
         int nb1 = 0;
-        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1);
+        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1, planes ? 1 : 0);
         tl_pixel_blocks = nb1;
     }
 #undef EAS_CONV_DISPATCH
@@ -793,18 +818,14 @@ int eas_conv_fwd_stats_blocks(int NI, int Cin, int Cout, int Hi, int Wi, int ksi
     return rc == EAS_OK ? nb : 0;
 }
 
-// 1x1 convolution (stride 1) of a spike tensor given as BYTES (values 0..255: spikes and their SEW sums, as eas_bn_lif_fwd_ex writes
-// them next to the fp32 copy): the HBM-bound 1x1 layers read 1 B instead of 4 B per input element.  Same arithmetic and the same
-// result, bit for bit, as eas_conv_fwd with x_terms = 1 on the fp32 copy.
-int eas_conv_fwd_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                    eas_stream_t stream) {
-    if (!x || !packed_w || !y || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if (ksize != 1 || Cin % 8 != 0) return EAS_ERR_UNSUPPORTED;
-    EAS_CLEAR_ERR();
-    const int rc = eas_conv1x1_dispatch_u8(x, packed_w, bias, y, NI, Cin, Cout, Hi * Wi, eas_s(stream));
-    if (rc != EAS_OK) return rc;
-    EAS_CHECK_LAUNCH();
-    return EAS_OK;
+// eas_conv_fwd / eas_conv_fwd_stats reading x as SPIKE PLANES (eas_hip.h): bf16 [NI][Cin/8][Hi*Wi][8] as eas_bn_lif_fwd_ex writes them.
+// Same products summed in the same order as eas_conv_fwd with x_terms = 1 on the fp32 values: bit-identical y.  stats / nb: nullable /
+// 0, else as eas_conv_fwd_stats (geometry queries: x_terms = 2).
+int eas_conv_fwd_planes(const void* x_planes, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                        int stride, double* stats, int nb, eas_stream_t stream) {
+    if (stats && (nb < 1 || bias)) return EAS_ERR_INVALID_ARG;
+    return conv_fwd_impl(reinterpret_cast<const float*>(x_planes), packed_w, bias, y, NI, Cin, Cout, Hi, Wi, ksize, stride, 2, nullptr, stream, false,
+                         stats, stats ? nb : 0);
 }
 
 // 1 when eas_conv_fwd has a tile for this geometry.  Rows whose staged patch does not fit LDS in one piece (3x3 layers with

@@ -88,10 +88,14 @@ __device__ __forceinline__ void stage_terms(unsigned char* dst, int term_stride,
     }
 }
 
-template <int S, int XT, int PM, int PN, int VEC>
+// XPL: x is a spike-plane tensor (bf16 [NI][Cin/8][Hi*Wi][8], XT = 1): an x staging item is VEC 16-byte loads copied as they are into
+// the pixel-major LDS image (the 8 channels of a pixel are 16 contiguous bytes in both).
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
 __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                         float* __restrict__ slabs, WgGeom g) {
+    static_assert(!XPL || XT == 1, "spike planes are one exact bf16 term");
     typedef float vecf __attribute__((ext_vector_type(VEC)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NW = 3 * PM * PN, NT = 64 * NW, NIT = PM * PN == 4 ? 1 : 2;   // staging items per thread (register budget of 12-wave blocks)
     constexpr int A_TERM = PM * A_PLANE, A_BYTES = 3 * A_TERM;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     }
 
     vecf L[NIT][8];
+    u32x4 LP[NIT][XPL ? VEC : 1];
     auto fetch = [&](int it, int tile) {
         const int rho0 = (g.parts > 1 ? tile / g.parts : tile) * g.RT;
         const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
@@ -202,6 +207,14 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             const int gc = xcol0 + it_col[it];
             ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin && gc >= 0 && gc < g.pitchX;
             const int ch = ci0 + it_ch[it] < g.Cin ? ci0 + it_ch[it] : g.Cin - 8;
+            if constexpr (XPL) {
+                // VEC consecutive pixels of one 8-channel group: VEC x 16 contiguous bytes
+                const u32x4* sp4 = ok ? reinterpret_cast<const u32x4*>(x) + (((size_t)img * (g.Cin / 8) + (ch >> 3)) * g.Hi + ir) * g.pitchX + gc
+                                      : reinterpret_cast<const u32x4*>(eas_wg_zero_page);
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) LP[it][p] = sp4[ok ? p : 0];
+                return;
+            }
             src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.pitchX + (ok ? gc : 0);
             plane = planeX;
         } else {
@@ -216,6 +229,11 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
         for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(sp + j * cs);
     };
     auto commit = [&](unsigned char* buf, int it) {
+        if (XPL && it_kind[it] == 1) {
+#pragma unroll
+            for (int p = 0; p < VEC; ++p) *(u32x4*)(buf + it_lofs[it] + p * ROWB) = LP[it][p];
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < VEC; ++p) {
             float v[8];
@@ -385,9 +403,9 @@ int pick_rows(int Ho, int Wo, int cap) {
     return best;
 }
 
-template <int S, int XT, int PM, int PN, int VEC>
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
 int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStream_t st) {
-    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC>;
+    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL>;
     constexpr int NT = 192 * PM * PN;
     const size_t lds = (size_t)2 * (3 * PM * A_PLANE + (size_t)XT * PN * g.Q * ROWB);
     const int nbg = PN == 1 && g.Cin < 32 ? (g.Cin + 7) / 8 : 4 * PN;
@@ -482,12 +500,13 @@ bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, i
 }  // namespace
 
 int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW);
-int eas_conv1x1_wgrad_dispatch(const float* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st);
-int eas_conv1x1_wgrad_dispatch_u8(const uint8_t* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, hipStream_t st);
+int eas_conv1x1_wgrad_dispatch(const void* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st,
+                               int planes);
 
 extern "C" {
 
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
+    if (x_terms == 2) x_terms = 1;          // spike planes: the geometry of one-term inputs
     if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi) * Cout * Cin : 0;
     if (ksize != 3) return 0;
     WgGeom g{};
@@ -498,40 +517,9 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
 // number of column parts per row eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, 2..8 = column parts
 // (same kernel, one launch), 0 = unsupported
 int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
+    if (x_terms == 2) x_terms = 1;
     WgGeom g{};
     return wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms) ? g.parts : 0;
-}
-
-// grad_w[Cout][Cin] of a 1x1 convolution whose input is given as spike BYTES (see eas_conv_fwd_u8); workspace as eas_conv_wgrad with
-// ksize 1, x_terms 1.  Same result, bit for bit, as eas_conv_wgrad on the fp32 copy.
-// slab kernel only; returns the number of slabs written (> 0) or a negative status
-static int wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                            eas_stream_t stream) {
-    if (!x || !grad_y || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if (ksize != 1 || ((uintptr_t)x & 3)) return EAS_ERR_UNSUPPORTED;
-    EAS_CLEAR_ERR();
-    const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi);
-    if (slices <= 0) return EAS_ERR_UNSUPPORTED;
-    const int rc1 = eas_conv1x1_wgrad_dispatch_u8(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, eas_s(stream));
-    if (rc1 != EAS_OK) return rc1;
-    EAS_CHECK_LAUNCH();
-    return slices;
-}
-
-int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
-                      int ksize, eas_stream_t stream) {
-    if (!grad_w) return EAS_ERR_INVALID_ARG;
-    const int slices = wgrad_u8_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stream);
-    if (slices < 0) return slices;
-    const int n1 = Cout * Cin;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n1 + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n1, slices);
-    EAS_CHECK_LAUNCH();
-    return EAS_OK;
-}
-
-int eas_conv_wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                              eas_stream_t stream) {
-    return wgrad_u8_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stream);
 }
 
 // grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and grad_y[NI][Cout][Ho][Wo].
@@ -540,13 +528,15 @@ int eas_conv_wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* work
 static int wgrad_partial(const float* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                          int stride, int x_terms, eas_stream_t stream) {
     if (!x || !grad_y || !workspace || NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
-    if ((x_terms != 1 && x_terms != 3)) return EAS_ERR_UNSUPPORTED;
+    const bool planes = x_terms == 2;       // x is a spike-plane tensor (bf16 [NI][Cin/8][Hi*Wi][8], one exact term)
+    if (planes) x_terms = 1;
+    if ((x_terms != 1 && x_terms != 3) || (planes && (Cin % 8 != 0 || ((uintptr_t)x & 15)))) return EAS_ERR_UNSUPPORTED;
     if (ksize == 1) {
         if (stride != 1) return EAS_ERR_UNSUPPORTED;
         EAS_CLEAR_ERR();
         const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi);
         if (slices <= 0) return EAS_ERR_UNSUPPORTED;
-        const int rc1 = eas_conv1x1_wgrad_dispatch(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, x_terms, eas_s(stream));
+        const int rc1 = eas_conv1x1_wgrad_dispatch(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, x_terms, eas_s(stream), planes ? 1 : 0);
         if (rc1 != EAS_OK) return rc1;
         EAS_CHECK_LAUNCH();
         return slices;
@@ -563,18 +553,20 @@ static int wgrad_partial(const float* x, const float* grad_y, float* workspace, 
     const int n = Cout * Cin * 9;
     int rc = EAS_ERR_UNSUPPORTED;
     const bool v4 = g.parts > 1 || (g.Wi % 4 == 0 && g.Wo % 4 == 0);
-#define EAS_WG(S_, XT_, PM_, PN_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4>(x, grad_y, workspace, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2>(x, grad_y, workspace, g, st))
-#define EAS_WG_SHAPE(S_, XT_)                                                  \
+#define EAS_WG(S_, XT_, PM_, PN_, PL_) (v4 ? launch_wgrad<S_, XT_, PM_, PN_, 4, PL_>(x, grad_y, workspace, g, st) : launch_wgrad<S_, XT_, PM_, PN_, 2, PL_>(x, grad_y, workspace, g, st))
+#define EAS_WG_SHAPE(S_, XT_, PL_)                                             \
     do {                                                                       \
-        if (p.pm == 2 && p.pn == 2) rc = EAS_WG(S_, XT_, 2, 2);                \
-        else if (p.pm == 2) rc = EAS_WG(S_, XT_, 2, 1);                        \
-        else if (p.pn == 2) rc = EAS_WG(S_, XT_, 1, 2);                        \
-        else rc = EAS_WG(S_, XT_, 1, 1);                                       \
+        if (p.pm == 2 && p.pn == 2) rc = EAS_WG(S_, XT_, 2, 2, PL_);           \
+        else if (p.pm == 2) rc = EAS_WG(S_, XT_, 2, 1, PL_);                   \
+        else if (p.pn == 2) rc = EAS_WG(S_, XT_, 1, 2, PL_);                   \
+        else rc = EAS_WG(S_, XT_, 1, 1, PL_);                                  \
     } while (0)
-    if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1);
-    else if (stride == 1) EAS_WG_SHAPE(1, 3);
-    else if (x_terms == 1) EAS_WG_SHAPE(2, 1);
-    else EAS_WG_SHAPE(2, 3);
+    if (planes && stride == 1) EAS_WG_SHAPE(1, 1, true);
+    else if (planes) EAS_WG_SHAPE(2, 1, true);
+    else if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1, false);
+    else if (stride == 1) EAS_WG_SHAPE(1, 3, false);
+    else if (x_terms == 1) EAS_WG_SHAPE(2, 1, false);
+    else EAS_WG_SHAPE(2, 3, false);
 #undef EAS_WG_SHAPE
 #undef EAS_WG
     if (rc != EAS_OK) return rc;
@@ -596,7 +588,15 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
 
 int eas_conv_wgrad_partial(const float* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                            int stride, int x_terms, eas_stream_t stream) {
+    if (x_terms == 2) return EAS_ERR_INVALID_ARG;      // spike planes go through eas_conv_wgrad_planes_partial
     return wgrad_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, stream);
+}
+
+// eas_conv_wgrad_partial with x given as SPIKE PLANES (bf16 [NI][Cin/8][Hi*Wi][8]): the same products in the same order as x_terms = 1 on
+// the fp32 values, bit-identical slabs; workspace: eas_conv_wgrad_workspace_floats(..., x_terms = 2)
+int eas_conv_wgrad_planes_partial(const void* x_planes, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                                  int stride, eas_stream_t stream) {
+    return wgrad_partial(reinterpret_cast<const float*>(x_planes), grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, 2, stream);
 }
 
 int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_stream_t stream) {

@@ -185,8 +185,6 @@ struct BnFin {
     float* invstd_out;
     float* rmean;           // nullable
     float* rvar;
-    int coop;               // 1: no partials were computed beforehand -- the consuming kernel sums its own chunk and the blocks of a
-                            // channel exchange the sums in the kernel (eas_channel_allreduce)
 };
 
 // mean / invstd of channel c from its totals (sum, sum of squares); `publish` (one block per channel): write them for the backward
@@ -280,148 +278,11 @@ __device__ __forceinline__ void bn_finalize_in_block(const BnFin& f, int c, floa
     istd = st[1];
 }
 
-// ------------------------------------------------------------------------------------------------ in-kernel channel all-reduce
-// The BN kernels decompose as blockIdx.y = channel, blockIdx.x = chunk.  Batch statistics (forward) and the two BN-backward sums
-// couple all chunks of a channel; instead of a separate partial-sum launch + a second pass over the data from HBM, the blocks of a
-// channel exchange their K partial sums INSIDE one launch and go on with the data they have just read (L2 / Infinity-Cache hits):
-//   every block publishes its partials with agent-scope atomic stores (XCD L2s are not coherent for plain stores) into
-//   slots[c][chunk][k]; wave 0 of every block polls the channel's slots until none holds the EMPTY pattern and sums them in chunk
-//   order (identical result in every block, deterministic); the last block to have read (per-channel ticket) puts EMPTY back, so
-//   the buffer is clean for the next launch on the stream.  No fences: only the exchanged words travel through agent-scope
-//   atomics.  Grid = (8, chunks, ceil(C / 8)), channel = blockIdx.z * 8 + blockIdx.x: work-groups are dealt round-robin over the 8
-//   XCDs in linear order (observed; a matter of speed only), so all chunks of a channel run on ONE XCD, one channel after the other --
-//   no block waits for another XCD's queue (with channels spread over the XCDs every XCD ran at the pace of the slowest and filled
-//   its CUs with waiting blocks: measured 1.7x slower than separate launches).  Progress under any placement: work-groups are
-//   dispatched in linear order, so at most one channel per queue is partially resident and its missing blocks are the next to be
-//   dispatched; a bounded spin turns a lost block into an error flag.
+// ------------------------------------------------------------------------------------------------ channel grids
+// The BN kernels decompose as (channel, chunk of the channel's pixel groups).  Grid = (8, chunks, ceil(C / 8)), channel = blockIdx.z * 8 +
+// blockIdx.x: work-groups are dealt round-robin over the 8 XCDs in linear order (observed; a matter of speed only), so all chunks of a
+// channel run on ONE XCD and share its L2.
 #define EAS_CHAN_GRID(chunks, C) dim3(8, (chunks), ((C) + 7) / 8)
-#define EAS_COOP_EMPTY 0x7FF4DEADBEEF0001ull      /* a signalling-NaN bit pattern no sum of finite or NaN data produces */
-#define EAS_COOP_SPIN_LIMIT (1 << 22)
-#define EAS_COOP_K 4                              /* 64-bit words per slot */
-
-struct EasCoopDev {
-    unsigned long long* slots;     // NULL: the kernel's non-cooperative form.  [capacity][EAS_BN_MAX_CHUNKS][EAS_COOP_K], then 2*capacity channel words
-    int* tickets;                  // [capacity] arrival counters, [8] global ones, [capacity] departure counters; all zero between launches
-    int* err;                      // set to 1 when a spin limit was hit
-    int capacity;                  // channels the buffers were sized for
-};
-
-template <int K>
-__device__ __forceinline__ void eas_channel_allreduce(const EasCoopDev& co, int c, int chunk, int nchunks, const double (&mine)[K],
-                                                      double (&tot)[K], double* sh) {
-    static_assert(K <= EAS_COOP_K, "slot width");
-    unsigned long long* base = co.slots + (size_t)c * EAS_BN_MAX_CHUNKS * EAS_COOP_K;
-    int* arrive = co.tickets + c;
-    int* depart = co.tickets + co.capacity + 8 + c;
-    if (threadIdx.x == 0) {      // `mine` is valid in thread 0 (eas_block_sum)
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            unsigned long long bits = (unsigned long long)__double_as_longlong(mine[k]);
-            if (bits == EAS_COOP_EMPTY) bits ^= 1ull;
-            __hip_atomic_store(base + (size_t)chunk * EAS_COOP_K + k, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __builtin_amdgcn_s_waitcnt(0);          // the partials have been acknowledged before this block counts as arrived
-        __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < EAS_WAVE) {
-        const int j = threadIdx.x;
-        // ONE lane polls ONE word (the channel's arrival counter) at a low rate: thousands of resident blocks polling their 64 slots
-        // directly saturate the fabric with uncached loads and slow the blocks that still compute
-        if (j == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunks && ++spins <= EAS_COOP_SPIN_LIMIT)
-                __builtin_amdgcn_s_sleep(32);
-        }
-        __builtin_amdgcn_wave_barrier();
-        double v[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = 0.0;
-        if (j < nchunks) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                unsigned long long b;
-                int spins = 0;
-                for (;;) {      // safety net: a slot whose store is not visible yet although its block has arrived
-                    b = __hip_atomic_load(base + (size_t)j * EAS_COOP_K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (b != EAS_COOP_EMPTY || ++spins > EAS_COOP_SPIN_LIMIT) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (b == EAS_COOP_EMPTY) {
-                    *co.err = 1;
-                    b = 0ull;
-                }
-                v[k] = __longlong_as_double((long long)b);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = eas_wave_sum(v[k]);
-        int last = 0;
-        if (j == 0) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) sh[k] = v[k];
-            last = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1;
-        }
-        last = __shfl(last, 0, EAS_WAVE);
-        if (last) {              // every block of the channel has read: clean up for the next launch
-            if (j < nchunks) {
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-                    __hip_atomic_store(base + (size_t)j * EAS_COOP_K + k, EAS_COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (j == 0) {
-                __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) tot[k] = sh[k];
-    __syncthreads();
-}
-
-// Sum over ALL channels of one double per channel (the neuron's dL/dw, dL/dalpha): block 0 of every channel publishes its
-// channel's value; the last one to arrive (global ticket) adds them in channel order with its first wave.  Returns true in that
-// block (all threads), with the sum in `total`.
-__device__ __forceinline__ bool eas_all_channels_sum(const EasCoopDev& co, int word, int c, int C, double mine, double& total, double* sh,
-                                                     int* shi) {
-    unsigned long long* vals = co.slots + (size_t)co.capacity * EAS_BN_MAX_CHUNKS * EAS_COOP_K + (size_t)word * co.capacity;
-    if (threadIdx.x == 0) {
-        unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
-        if (bits == EAS_COOP_EMPTY) bits ^= 1ull;
-        __hip_atomic_store(vals + c, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *shi = __hip_atomic_fetch_add(co.tickets + co.capacity + word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C - 1;
-    }
-    __syncthreads();
-    const bool last = *shi != 0;
-    if (last && threadIdx.x < EAS_WAVE) {
-        // the ticket only elects the summing block; every value is polled for (no ordering assumed between a value and its ticket)
-        double a = 0.0;
-        for (int i = threadIdx.x; i < C; i += EAS_WAVE) {
-            unsigned long long b;
-            int spins = 0;
-            for (;;) {
-                b = __hip_atomic_load(vals + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (b != EAS_COOP_EMPTY || ++spins > EAS_COOP_SPIN_LIMIT) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (b == EAS_COOP_EMPTY) {
-                *co.err = 1;
-                b = 0ull;
-            }
-            a += __longlong_as_double((long long)b);
-            __hip_atomic_store(vals + i, EAS_COOP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        a = eas_wave_sum(a);
-        if (threadIdx.x == 0) {
-            *sh = a;
-            __hip_atomic_store(co.tickets + co.capacity + word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    total = *sh;
-    return last;
-}
 
 // (image, float4-group-in-plane) of group index g0 and its advance by `stride` groups, without a 64-bit division per group
 struct GroupWalk {

@@ -20,23 +20,22 @@ namespace {
 // y[n][o] = (b[o]) + sum_{i,ky,kx} wr[i][ky][kx][o] * x[n][i][. + ky - PAD][. + kx - PAD], optional ReLU, optional mask (result zeroed
 // where mask <= 0: the ReLU in front of the convolution whose input gradient this is).  DUAL: COUT = 2 * CO outputs of which the
 // first CO go to y (masked by mask) and the rest to y2 (masked by mask2): two input gradients that share grad_y in one pass.
-template <int CIN, int COUT, int K, bool DUAL>
+template <int CIN, int COUT, int K, bool DUAL, bool VECW>
 __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restrict__ x, const float* __restrict__ wr,
                                                           const float* __restrict__ b, const float* __restrict__ mask,
                                                           float* __restrict__ y, const float* __restrict__ mask2, float* __restrict__ y2, int N,
                                                           int H, int W, int relu) {
-    using G = Geo<K>;
-    constexpr int LWF = 128;        // row pitch: a multiple of the 64-bank row (conflict-free ds_read_b128 for this lane -> (row, quad) map)
-    constexpr int PLANE = G::LH * LWF;
+    using SG = Stage<CIN, K, VECW>;
+    constexpr int LWF = SG::PITCH, PLANE = SG::PLANE;
     constexpr int CO = DUAL ? COUT / 2 : COUT;
-    using St = Stager<CIN, K, PLANE, LWF>;
+    using St = typename SG::St;
     St st;
     st.init(H, W);
     __shared__ __attribute__((aligned(16))) float lds[CIN * PLANE];
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = N * tiles_x * tiles_y;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float pre[St::PER];
+    typename SG::Pre pre[St::PER];
     unsigned okm = 0;
     int tile = blockIdx.x;
     if (tile < ntiles)
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        sc_accumulate<CIN, COUT, K, LWF>(lds, PLANE, wr, acc, tx, ty);
+        sc_accumulate<CIN, COUT, K, LWF, SG::NQ, SG::OFS>(lds, PLANE, wr, acc, tx, ty);
         if (inside) {
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
@@ -303,12 +302,21 @@ int launch_conv_k(int k, const float* x, const float* wr, const float* b, const 
                   int H, int W, int relu, hipStream_t st) {
     int tiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     if (tiles > kConvBlocks) tiles = kConvBlocks;      // persistent blocks loop over tiles with register prefetch
+    const bool vecw = (W & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+#define EAS_SC(K_)                                                                                                                             \
+    do {                                                                                                                                       \
+        if (vecw) hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, K_, DUAL, true>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, \
+                                     N, H, W, relu);                                                                                           \
+        else hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, K_, DUAL, false>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N,  \
+                                H, W, relu);                                                                                                   \
+    } while (0)
     switch (k) {
-        case 3: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 3, DUAL>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N, H, W, relu); break;
-        case 5: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 5, DUAL>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N, H, W, relu); break;
-        case 7: hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, 7, DUAL>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N, H, W, relu); break;
+        case 3: EAS_SC(3); break;
+        case 5: EAS_SC(5); break;
+        case 7: EAS_SC(7); break;
         default: return EAS_ERR_UNSUPPORTED;
     }
+#undef EAS_SC
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -138,29 +138,96 @@ def _alpha_arg(sg_id, alpha):
     return float(alpha)
 
 
-# Spike tensors leave the fused BN+LIF kernels twice: as fp32 (what autograd, the 3x3 kernels and any outside reader see) and, when
-# asked for, once more as BYTES attached to the fp32 tensor as ``t._eas_u8`` (same shape, uint8).  The HBM-bound 1x1 convolutions
-# and their weight gradients read the byte copy: 1 B instead of 4 B per input element (eas_conv_fwd_u8 / eas_conv_wgrad_u8).
-# Measured on MI355X (bench.py, same box, A/B): the byte copies lower the input traffic of the 1x1 kernels but not their time
-# (conv family 9.88 -> 9.82 ms, weight gradients 5.59 -> 5.69 ms) and cost 0.11 ms in eas_bn_lif_fwd: 26.10 -> 26.44 ms per step.
-# So they are OFF by default (EAS_SPIKE_BYTES=1 switches them on); the kernels are kept and tested -- see DESIGN.md 7b.
-SPIKE_BYTES = os.environ.get('EAS_SPIKE_BYTES', '0') == '1'
+# SPIKE PLANES.  Between the fused layers of the model a spike tensor [T,N,C,H,W] (0/1 spikes, SEW sums: exact in bf16) does not exist as
+# fp32 at all: the BN+LIF kernel writes it as bf16 in blocks of 8 channels, planes [T,N,C/8,H*W,8] (include/eas_hip.h "SPIKE PLANES"), the
+# form in which every consumer -- 1x1 / 3x3 convolution forward, their weight gradients, the SEW shortcut of the next BN+LIF kernel --
+# reads its operand with 16-byte loads and without conversion, at half the HBM bytes.  For autograd the tensor is represented by a GHOST:
+# an fp32 tensor of the logical shape that owns no storage (a NaN scalar expanded with stride 0) and carries the planes as ``t._eas_sp``.
+# Only code that asks for planes gets them (``planes=True`` of the fused blocks in compat/yolox/models/network_blocks.py, whose consumers are
+# the operators below); everything else -- API callers, hooks, statistics taps, kernels that read fp32 NCHW -- goes through ``dense(t)``,
+# which unpacks the planes (eas_spike_planes_to_f32).  A ghost that is read by accident yields NaN, never a plausible number.
+# EAS_SPIKE_PLANES=0: development switch, fp32 spikes everywhere (the round-2 data path).
+SPIKE_PLANES = os.environ.get('EAS_SPIKE_PLANES', '1') == '1'
+_GHOST_BASE = {}
+_PLANES_SCOPE = False    # inside the forward of a whole model (``packed_weights``) none of whose modules carries a forward hook
 
 
-def spike_bytes(t):
-    """the uint8 copy of a spike tensor, or None"""
-    u = getattr(t, '_eas_u8', None)
-    return u if u is not None and u.shape == t.shape else None
+def planes_enabled():
+    """spike planes may be produced right now: switched on, inside a model's own forward (``packed_weights`` -- a block called on its own
+    hands out fp32 spikes), and nothing that wants to see fp32 tensors is attached (module forward hooks, a statistics tap)"""
+    return SPIKE_PLANES and _PLANES_SCOPE and _CONV_SINK is None and not torch.nn.modules.module._global_forward_hooks
+
+
+def planes_of(t):
+    """the spike planes [.., C/8, H*W, 8] (bf16) a ghost tensor stands for, or None for an ordinary tensor"""
+    return getattr(t, '_eas_sp', None)
+
+
+def ghost(shape, device, planes=None):
+    """fp32 tensor of ``shape`` without storage (every element aliases one NaN); ``planes``: attached as the data it stands for"""
+    key = str(device)
+    base = _GHOST_BASE.get(key)
+    if base is None:
+        base = _GHOST_BASE[key] = torch.full((1,), float('nan'), dtype=torch.float32, device=device)
+    g = base.expand(tuple(shape))
+    if planes is not None:
+        g._eas_sp = planes
+        g._eas_small_int = True
+    return g
+
+
+def new_planes(T, N, C, H, W, device):
+    return torch.empty((T, N, C // 8, H * W, 8), dtype=torch.bfloat16, device=device)
+
+
+class _DenseFn(torch.autograd.Function):
+    """ghost -> real fp32 tensor (eas_spike_planes_to_f32); the gradient passes through unchanged"""
+
+    @staticmethod
+    def forward(ctx, g, sp):
+        shape = tuple(g.shape)
+        C_, H, W = shape[-3:]
+        NI = 1
+        for d in shape[:-3]:
+            NI *= d
+        out = torch.empty(shape, dtype=torch.float32, device=sp.device)
+        _call('eas_spike_planes', 6 * out.numel(), _lib.lib().eas_spike_planes_to_f32, ptr(sp), 0, ptr(out), 0, NI, C_, H * W, stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+def dense(t):
+    """``t`` as a real fp32 tensor: a ghost is unpacked from its planes (one pass, 6 B per element), anything else is returned as it is"""
+    sp = planes_of(t)
+    if sp is None:
+        return t
+    out = _DenseFn.apply(t, sp.contiguous())
+    mark_small_int(out)
+    return out
+
+
+def to_planes(x):
+    """a real fp32 spike tensor [.., C, H, W] (values exact in bf16) as planes (eas_spike_planes_from_f32); for tests and borders"""
+    x = _f32c(x)
+    shape = tuple(x.shape)
+    C_, H, W = shape[-3:]
+    NI = x.numel() // (C_ * H * W)
+    sp = torch.empty(shape[:-3] + (C_ // 8, H * W, 8), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().eas_spike_planes_from_f32(ptr(x), 0, ptr(sp), 0, NI, C_, H * W, stream()), 'eas_spike_planes_from_f32')
+    return sp
 
 
 def fold_time(x_seq):
-    """[T, N, ...] -> [T*N, ...] keeping the spike tags (small-integer mark, byte copy)"""
+    """[T, N, ...] -> [T*N, ...] keeping the spike tags (small-integer mark, planes of a ghost)"""
     x = x_seq.flatten(0, 1)
     if is_small_int(x_seq):
         mark_small_int(x)
-    u = spike_bytes(x_seq)
-    if u is not None:
-        x._eas_u8 = u.flatten(0, 1)
+    sp = planes_of(x_seq)
+    if sp is not None:
+        x._eas_sp = sp.flatten(0, 1)
     return x
 
 
@@ -233,7 +300,7 @@ def lif_multistep(x_seq, v_in, w, k_const, v_th, v_reset, flags, surrogate, alph
 
 def time_mean(x_seq):
     """[T, ...] -> mean over T (firing-rate readout), differentiable."""
-    return _TimeMeanFn.apply(x_seq)
+    return _TimeMeanFn.apply(dense(x_seq))
 
 
 class _TimeMeanFn(torch.autograd.Function):
@@ -252,48 +319,6 @@ class _TimeMeanFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ K4 (BN + LIF)
-# In-kernel channel exchange (include/eas_hip.h EasCoop, csrc/eas_common.h): with it the BN kernels compute their batch statistics
-# themselves (no eas_bn_stats_partial launch, the data is read from HBM once and from L2 the second time) and the two passes of
-# their backward are one launch.  One set of buffers per device, shared by every layer (kernels of a stream run one after another and
-# each leaves the buffers clean).
-# MEASURED (MI355X, bench.py, same box): the cooperative form is SLOWER -- 28.3 ms per step against 25.7 ms with separate launches
-# (first form: every block polling its channel's 64 slots), 40-44 ms with a single polled arrival counter per channel, also with all
-# chunks of a channel placed on one XCD.  A cross-block exchange costs several fabric round trips (~2 us each: publish, arrive, poll,
-# read, depart) inside blocks that hold 2-10 us of work, and a waiting block keeps its CU slot; a kernel boundary costs a few
-# microseconds of launch gap but no occupancy.  So it is OFF by default (EAS_COOP_BN=1 switches it on); kernels and test are kept --
-# DESIGN.md 7b.
-COOP_BN = os.environ.get('EAS_COOP_BN', '0') == '1'
-COOP_CAPACITY = 4096                  # channels
-_COOP = {}
-
-
-def coop_buffers(device):
-    """(EasCoop struct, tensors kept alive) of ``device``"""
-    key = str(device)
-    c = _COOP.get(key)
-    if c is None:
-        L = _lib.lib()
-        empty = C.c_int64(0x7FF4DEADBEEF0001).value
-        slots = torch.full((L.eas_coop_slot_words(COOP_CAPACITY),), empty, dtype=torch.int64, device=device)
-        tickets = torch.zeros(2 * COOP_CAPACITY + 8, dtype=torch.int32, device=device)
-        err = torch.zeros(1, dtype=torch.int32, device=device)
-        c = _COOP[key] = (_lib.EasCoop(slots.data_ptr(), tickets.data_ptr(), err.data_ptr(), COOP_CAPACITY), slots, tickets, err)
-    return c
-
-
-def coop_error(device):
-    """True if a block of a cooperative kernel ever gave up waiting for its channel (host sync; tests call it)"""
-    c = _COOP.get(str(device))
-    return bool(c[3].item()) if c is not None else False
-
-
-def _coop_ptr(device, channels):
-    """pointer argument for the C ABI, or None when the cooperative form is switched off / does not apply"""
-    if not COOP_BN or channels > COOP_CAPACITY:
-        return None
-    return C.pointer(coop_buffers(device)[0])
-
-
 # Convolution -> BatchNorm hand-over (eas_conv_fwd_stats, north_star's fused conv -> BN -> LIF step): inside ``conv_stats_scope`` a
 # matrix-core convolution also leaves the per-channel sums of its output tile by tile, and the BN kernel that consumes exactly that
 # tensor next adds them up instead of reading y once more (no eas_bn_stats_partial launch).  The slot holds the convolution output
@@ -349,27 +374,22 @@ def clear_conv_stats():
 
 
 def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, running_var, dev, y_ptr=None, y_ctot=0, keep_slot=False):
-    """batch statistics of the consumer kernel: the producing convolution's tile sums (conv_stats_scope), cooperative (computed inside
-    it, EasCoop) or the partial-sum launch whose result the consumer finalizes (EasBnPending)."""
+    """batch statistics of the consumer kernel: the producing convolution's tile sums (conv_stats_scope) or the partial-sum launch whose
+    result the consumer finalizes (EasBnPending)."""
     got = _take_conv_stats(y.data_ptr(), TN * HW, y_ctot if y_ctot else Cc, keep_slot)
     if got is not None:
         stats, nb = got
         c0 = 0 if y_ptr is None else (y_ptr - y.data_ptr()) // (4 * HW)
         pend = _lib.EasBnPending(stats.data_ptr() + 16 * c0 * nb, nb, int(replicas), float(TN) * HW, float(eps),
                                  float(momentum if momentum is not None else 0.0), ptr(running_mean) if momentum is not None else None,
-                                 ptr(running_var) if momentum is not None else None, None, nb)
+                                 ptr(running_var) if momentum is not None else None, nb)
         return pend, stats, 0                # no launch: the consumer adds the convolution's tile sums
-    cp = _coop_ptr(dev, Cc)
-    if cp is not None:
-        pend = _lib.EasBnPending(None, 0, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
-                                 ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, cp)
-        return pend, None, 0
     ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
     chunks = L.eas_bn_stats_partial(ptr(y) if y_ptr is None else y_ptr, y_ctot, TN, Cc, HW, ptr(ws), stream())
     if chunks <= 0:
         check(chunks if chunks < 0 else -1, 'eas_bn_stats_partial')
     pend = _lib.EasBnPending(ptr(ws), chunks, int(replicas), float(TN) * HW, float(eps), float(momentum if momentum is not None else 0.0),
-                             ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, None)
+                             ptr(running_mean) if momentum is not None else None, ptr(running_var) if momentum is not None else None, 0)
     return pend, ws, 4 * TN * Cc * HW        # the statistics launch read y once
 
 
@@ -389,11 +409,13 @@ def _channel_slice_of(g, Cc):
 class _BNLIFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, bn_state, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v, t_bcast,
-                residual, cat_buf, cat_c0, u8_buf):
+                residual, cat_buf, cat_c0, sp_arg, residual_sp):
         """y: [T,N,C,H,W], or [N,C,H,W] standing for ``t_bcast`` identical time steps.  residual [T,N,C,H,W]: the output is
         spikes + residual (SEW shortcut).  cat_buf [T,N,Ctot,H,W]: the output is written as channels cat_c0.. of it and
-        returned as a view (concatenation in place).  u8_buf: True = also emit the byte copy of the output (fourth result);
-        a uint8 tensor shaped like cat_buf = write the byte copy into its channels cat_c0.. (returned as a view)."""
+        returned as a view (concatenation in place).
+        sp_arg: None = fp32 output; True = the output as spike planes (fourth result; the first result is then a ghost, see ``ghost``);
+        a planes tensor [T,N,Ctot/8,HW,8] = the planes of ``cat_buf`` (itself a ghost): written into its groups cat_c0/8.. .
+        residual_sp: the planes of ``residual`` when that is a ghost."""
         running_mean, running_var, use_batch_stats, momentum, eps = bn_state
         _dev(y, gamma, beta, v_in, w)
         L = _lib.lib()
@@ -419,10 +441,29 @@ class _BNLIFFn(torch.autograd.Function):
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
+        planes = sp_arg is not None and sp_arg is not False
+        res_ctot = 0
         if residual is not None:
-            residual = _f32c(residual)
             assert not want_mean and residual.shape == (T,) + tuple(plane)
-        if cat_buf is not None:
+            if residual_sp is not None:
+                assert planes and residual_sp.is_contiguous() and residual_sp.shape == (T, N, Cc // 8, HW, 8)
+            else:
+                assert not planes
+                residual = _f32c(residual)
+        sp = None
+        if planes:
+            if torch.is_tensor(sp_arg):
+                assert cat_buf is not None and sp_arg.dtype == torch.bfloat16 and sp_arg.is_contiguous() and cat_c0 % 8 == 0 and \
+                    sp_arg.shape == (T, N, cat_buf.shape[2] // 8, HW, 8)
+                sp = sp_arg.narrow(2, cat_c0 // 8, Cc // 8)
+                spikes = cat_buf.narrow(2, cat_c0, Cc)
+                ctot = cat_buf.shape[2]
+            else:
+                assert cat_buf is None
+                sp = new_planes(T, N, Cc, plane[-2], plane[-1], dev)
+                spikes = ghost((T,) + tuple(plane), dev)
+                ctot = 0
+        elif cat_buf is not None:
             assert cat_buf.is_contiguous() and cat_buf.shape[:2] == (T, N) and cat_buf.shape[3:] == tuple(plane[2:])
             spikes = cat_buf.narrow(2, cat_c0, Cc)
             ctot = cat_buf.shape[2]
@@ -431,15 +472,11 @@ class _BNLIFFn(torch.autograd.Function):
             ctot = 0
         v_out = torch.empty(plane, dtype=torch.float32, device=dev) if write_v else None
         mo = torch.empty(plane, dtype=torch.float32, device=dev) if want_mean else None
-        u8 = None
-        if torch.is_tensor(u8_buf):
-            assert cat_buf is not None and u8_buf.dtype == torch.uint8 and u8_buf.shape == cat_buf.shape and u8_buf.is_contiguous()
-            u8 = u8_buf.narrow(2, cat_c0, Cc)
-        elif u8_buf:
-            u8 = torch.empty((T,) + tuple(plane), dtype=torch.uint8, device=dev)
-        _call('eas_bn_lif_fwd', 4 * (y.numel() + spikes.numel()) + (u8.numel() if u8 is not None else 0), L.eas_bn_lif_fwd_ex, ptr(y), 0, ptr(mean),
-              ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), ptr(mo), T, N, Cc, HW,
-              int(bool(t_bcast)), C.byref(pend) if pend is not None else None, ptr(residual), ctot, ptr(u8), stream())
+        nsteps = T * N * Cc * HW
+        _call('eas_bn_lif_fwd', (4 * y.numel() + (2 if planes else 4) * nsteps), L.eas_bn_lif_fwd_ex, ptr(y), 0, ptr(mean),
+              ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, None if planes else ptr(spikes), ptr(mo),
+              T, N, Cc, HW, int(bool(t_bcast)), C.byref(pend) if pend is not None else None, None if residual_sp is not None else ptr(residual), ctot,
+              ptr(sp), ptr(residual_sp), res_ctot, stream())
         del keep
         learn = sg_id == SG_PATAN
         if learn:
@@ -449,16 +486,16 @@ class _BNLIFFn(torch.autograd.Function):
         ctx.has_residual = residual is not None
         if v_out is not None:
             ctx.mark_non_differentiable(v_out)
-        if u8 is not None:
-            ctx.mark_non_differentiable(u8)
-        return spikes, v_out, mo, u8
+        if sp is not None:
+            ctx.mark_non_differentiable(sp)
+        return spikes, v_out, mo, sp
 
     @staticmethod
-    def backward(ctx, g_s, g_v, g_mean, _g_u8):
+    def backward(ctx, g_s, g_v, g_mean, _g_sp):
         y, mean, invstd, gamma, beta, v_in, w, alpha_t = ctx.saved_tensors
         k_const, v_th, v_reset, flags, sg_id, alpha, batch_stats, T, N, Cc, HW, bcast = ctx.cfg
         L = _lib.lib()
-        nout = 19
+        nout = 20
         if g_s is None and g_mean is None:
             return (torch.zeros_like(y),) + (None,) * (nout - 1)
         g_res = g_s if ctx.has_residual else None          # d(spikes + residual)/d residual = identity: the same tensor, no copy
@@ -473,8 +510,7 @@ class _BNLIFFn(torch.autograd.Function):
         gbeta = torch.empty_like(beta)
         want_w = w is not None and ctx.needs_input_grad[5]
         gw = torch.empty_like(w) if want_w else None
-        cp = _coop_ptr(y.device, Cc)
-        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device) if cp is None else None
+        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
         nsteps = T * N * Cc * HW
         nbytes = 4 * (2 * nsteps + gy.numel()) if not bcast else 4 * (nsteps + 2 * gy.numel())
         ga = None
@@ -482,12 +518,12 @@ class _BNLIFFn(torch.autograd.Function):
             ga = torch.empty_like(alpha_t) if ctx.needs_input_grad[11] else None
             _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_patan, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
                   ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, ptr(alpha_t), ptr(ga), int(batch_stats), ptr(gy), ptr(ggamma),
-                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), cp, stream())
+                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
         else:
             _call('eas_bn_lif_bwd', nbytes, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, ptr(g_mean), ptr(y), 0, ptr(mean), ptr(invstd), ptr(gamma),
                   ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats), ptr(gy), ptr(ggamma),
-                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), cp, stream())
-        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 5 + (ga,) + (None,) * 3 + (g_res, None, None, None)
+                  ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, int(bcast), stream())
+        return (gy, ggamma, gbeta, None, None, gw) + (None,) * 5 + (ga,) + (None,) * 3 + (g_res, None, None, None, None)
 
 
 class _JoinFn(torch.autograd.Function):
@@ -508,13 +544,13 @@ class _JoinFn(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
-def join_channels(buf, *parts, u8_buf=None):
-    """u8_buf: the byte copy of the whole concatenation (its channel slices were written by the producers of ``parts``)"""
+def join_channels(buf, *parts, sp_buf=None):
+    """sp_buf: the spike planes of the whole concatenation (``buf`` is then a ghost; the producers of ``parts`` wrote their channel groups)"""
     out = _JoinFn.apply(buf, *parts)
     if all(is_small_int(p) for p in parts):
         mark_small_int(out)
-        if u8_buf is not None and all(spike_bytes(p) is not None for p in parts):
-            out._eas_u8 = u8_buf
+        if sp_buf is not None:
+            out._eas_sp = sp_buf
     return out
 
 
@@ -535,7 +571,7 @@ class _BNLIF2Fn(torch.autograd.Function):
         c0 = 0
         for gamma, beta, w, cfg in ((gamma_a, beta_a, w_a, cfg_a), (gamma_b, beta_b, w_b, cfg_b)):
             (running_mean, running_var, use_batch_stats, momentum, eps), v_in, k_const, v_th, v_reset, flags, sg_id, alpha, write_v, cat, Cc = cfg[:11]
-            want_u8 = cfg[11] if len(cfg) > 11 else False
+            want_sp = cfg[11] if len(cfg) > 11 else False       # the output as spike planes (cat = (ghost buffer, first channel, its planes))
             _dev(gamma, beta, v_in, w)
             v_in = _f32c(v_in)
             yp = y12.data_ptr() + 4 * c0 * HW
@@ -551,24 +587,26 @@ class _BNLIF2Fn(torch.autograd.Function):
             else:
                 mean = running_mean
                 invstd = torch.rsqrt(running_var + eps)
+            sp = None
             if cat is not None:
                 spikes = cat[0].narrow(2, cat[1], Cc)
                 ctot = cat[0].shape[2]
+                if want_sp:
+                    assert len(cat) > 2 and cat[2] is not None and cat[1] % 8 == 0 and cat[2].is_contiguous()
+                    sp = cat[2].narrow(2, cat[1] // 8, Cc // 8)
+            elif want_sp:
+                sp = new_planes(T, N, Cc, H, W, dev)
+                spikes = ghost((T, N, Cc, H, W), dev)
+                ctot = 0
             else:
                 spikes = torch.empty((T, N, Cc, H, W), dtype=torch.float32, device=dev)
                 ctot = 0
             v_out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dev) if write_v else None
-            u8 = None
-            if want_u8:
-                if cat is not None and len(cat) > 2 and cat[2] is not None:
-                    u8 = cat[2].narrow(2, cat[1], Cc)
-                elif cat is None:
-                    u8 = torch.empty((T, N, Cc, H, W), dtype=torch.uint8, device=dev)
-            _call('eas_bn_lif_fwd', (8 + (1 if u8 is not None else 0)) * T * N * Cc * HW, L.eas_bn_lif_fwd_ex, yp, Ct, ptr(mean), ptr(invstd),
-                  ptr(gamma), ptr(beta), ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, ptr(spikes), None, T, N, Cc, HW, 0,
-                  C.byref(pend) if pend is not None else None, None, ctot, ptr(u8), stream())
+            _call('eas_bn_lif_fwd', (4 + (2 if sp is not None else 4)) * T * N * Cc * HW, L.eas_bn_lif_fwd_ex, yp, Ct, ptr(mean), ptr(invstd),
+                  ptr(gamma), ptr(beta), ptr(v_in), ptr(v_out), ptr(w), k_const, v_th, v_reset, flags, None if sp is not None else ptr(spikes), None, T, N,
+                  Cc, HW, 0, C.byref(pend) if pend is not None else None, None, ctot, ptr(sp), None, 0, stream())
             del keep
-            outs += [spikes, v_out, u8]
+            outs += [spikes, v_out, sp]
             saved += [mean, invstd, gamma, beta, v_in, w]
             cfgs.append((k_const, v_th, v_reset, flags, sg_id, alpha, bool(use_batch_stats), Cc, c0))
             c0 += Cc
@@ -601,25 +639,24 @@ class _BNLIF2Fn(torch.autograd.Function):
                 ctot = _channel_slice_of(g_s, Cc) if g_s.dtype == torch.float32 else 0
                 if ctot == 0:
                     g_s = _f32c(g_s)
-                cp = _coop_ptr(y12.device, Cc)
-                ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device) if cp is None else None
+                ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device)
                 off = 4 * c0 * HW
                 _call('eas_bn_lif_bwd', 12 * T * N * Cc * HW, L.eas_bn_lif_bwd_ex, ptr(g_s), ctot, None, y12.data_ptr() + off, Ct, ptr(mean),
                       ptr(invstd), ptr(gamma), ptr(beta), ptr(v_in), ptr(w), k_const, v_th, v_reset, flags, sg_id, alpha, int(batch_stats),
-                      gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, 0, cp, stream())
+                      gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(gw), ptr(ws), T, N, Cc, HW, 0, stream())
             res += [ggamma, gbeta, gw]
         return (gy12,) + tuple(res) + (None, None)
 
 
 def bn_lif_pair(y12, a, b):
     """a / b: (gamma, beta, w, cfg) of the two layers, cfg = (bn_state, v_in, k_const, v_th, v_reset, flags, surrogate id, alpha,
-    write_v, cat (buffer, first channel[, byte buffer]) or None, channels[, emit byte copy]).  Returns (spikes_a, v_a, spikes_b, v_b);
-    the byte copies are attached to the spike tensors (``spike_bytes``)."""
-    sa, va, ua, sb, vb, ub = _BNLIF2Fn.apply(y12, a[0], a[1], a[2], b[0], b[1], b[2], a[3], b[3])
-    if ua is not None:
-        sa._eas_u8 = ua
-    if ub is not None:
-        sb._eas_u8 = ub
+    write_v, cat (buffer, first channel[, planes of the buffer]) or None, channels[, output as spike planes]).  Returns (spikes_a, v_a,
+    spikes_b, v_b); with planes the spike tensors are ghosts that carry them (``planes_of``)."""
+    sa, va, pa, sb, vb, pb = _BNLIF2Fn.apply(y12, a[0], a[1], a[2], b[0], b[1], b[2], a[3], b[3])
+    if pa is not None:
+        sa._eas_sp = pa
+    if pb is not None:
+        sb._eas_sp = pb
     return sa, va, sb, vb
 
 
@@ -627,8 +664,10 @@ def conv2d_weight(x, weight, stride=1, small_int=None):
     """functional form of ``conv2d`` for a weight tensor that is not a module parameter (e.g. two concatenated 1x1 weights)"""
     if small_int is None:
         small_int = is_small_int(x)
+    if planes_of(x) is not None and not (small_int and _planes_conv_ok(x, weight, stride)):
+        x = dense(x)
     _verify_tags(x, small_int)
-    return _ConvFn.apply(x, weight, None, stride, 1 if small_int else 3, None, spike_bytes(x) if small_int else None)
+    return _ConvFn.apply(x, weight, None, stride, 1 if small_int else 3, None, planes_of(x) if small_int else None)
 
 
 def bn_lif_supported(y_seq, T):
@@ -637,22 +676,34 @@ def bn_lif_supported(y_seq, T):
 
 def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_stats, momentum, eps, v_in, w, k_const,
                      v_th, v_reset, flags, surrogate, alpha, want_mean=False, write_v=None, t_bcast=0, residual=None, cat=None,
-                     emit_bytes=False):
+                     planes=False):
     """Fused BatchNorm(step_mode='m') + multi-step LIF on the conv output y_seq [T,N,C,H,W]
-    (or one plane [N,C,H,W] shared by ``t_bcast`` identical steps).  cat = (buffer, first channel[, byte buffer]);
-    emit_bytes: also write the output as bytes (attached to the returned spike tensor, see ``spike_bytes``)."""
+    (or one plane [N,C,H,W] shared by ``t_bcast`` identical steps).  cat = (buffer, first channel[, planes of the buffer]);
+    planes: write the output as spike planes -- the returned spike tensor is then a ghost that carries them (``planes_of``); a ghost
+    residual is read from its planes."""
     if write_v is None:
         write_v = _STATE_WRITEBACK
     state = (running_mean, running_var, bool(use_batch_stats), None if momentum is None else float(momentum), float(eps))
     sg_id = SURROGATE_IDS[surrogate] if isinstance(surrogate, str) else int(surrogate)
-    u8_arg = False
-    if emit_bytes and SPIKE_BYTES:
-        u8_arg = (cat[2] if len(cat) > 2 and cat[2] is not None else False) if cat is not None else True
-    spikes, v_out, mo, u8 = _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags), sg_id,
+    C_ = y_seq.shape[-3]
+    res_sp = planes_of(residual) if residual is not None else None
+    cat_sp = cat is not None and len(cat) > 2 and cat[2] is not None
+    if residual is not None and res_sp is None and (cat_sp or planes) and C_ % 8 == 0 and is_small_int(residual):
+        res_sp = to_planes(residual)             # a shortcut that arrives as fp32 spikes next to an output kept as planes
+    planes = bool(planes or cat_sp) and C_ % 8 == 0 and (residual is None or res_sp is not None) and (cat is None or cat_sp)
+    if residual is not None and res_sp is not None and not planes:
+        residual, res_sp = dense(residual), None              # fp32 output asked for: the shortcut as fp32 as well
+    if cat_sp and not planes:
+        raise _lib.EasHipError('a concatenation buffer kept as spike planes needs producers that write planes')
+    sp_arg = None
+    if planes:
+        sp_arg = cat[2] if cat is not None else True
+    spikes, v_out, mo, sp = _BNLIFFn.apply(y_seq, gamma, beta, state, v_in, w, float(k_const), float(v_th), float(v_reset), int(flags), sg_id,
                                            _alpha_arg(sg_id, alpha), bool(want_mean), bool(write_v), int(t_bcast), residual,
-                                           cat[0] if cat is not None else None, int(cat[1]) if cat is not None else 0, u8_arg)
-    if u8 is not None:
-        spikes._eas_u8 = u8
+                                           cat[0] if cat is not None else None, int(cat[1]) if cat is not None else 0, sp_arg,
+                                           res_sp.contiguous() if res_sp is not None else None)
+    if sp is not None:
+        spikes._eas_sp = sp
     return spikes, v_out, mo
 
 
@@ -728,15 +779,14 @@ class _BNSiLUFn(torch.autograd.Function):
         y, mean, invstd, gamma, beta = ctx.saved_tensors
         batch_stats, N, Cc, HW = ctx.cfg
         L = _lib.lib()
-        cp = _coop_ptr(y.device, Cc)
         # the gradient of an in-place concatenation arrives as a channel slice of the concatenation's gradient: read in place
-        ctot = _channel_slice_of4(g, Cc) if (g.dim() == 4 and g.dtype == torch.float32 and cp is None) else 0
+        ctot = _channel_slice_of4(g, Cc) if (g.dim() == 4 and g.dtype == torch.float32) else 0
         if ctot == 0:
             g = _f32c(g)
         gy, ggamma, gbeta = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
-        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device) if cp is None else None
+        ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y.device)
         _call('eas_bn_silu_bwd', 12 * y.numel(), L.eas_bn_silu_bwd, ptr(g), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, 0, cp, stream())
+              int(batch_stats), ptr(gy), ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, 0, stream())
         return gy, ggamma, gbeta, None, None, None
 
 
@@ -811,7 +861,7 @@ class _BNSiLU2Fn(torch.autograd.Function):
                 ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=y12.device)
                 off = 4 * c0 * HW
                 _call('eas_bn_silu_bwd', 12 * N * Cc * HW, L.eas_bn_silu_bwd, ptr(g), y12.data_ptr() + off, ptr(mean), ptr(invstd), ptr(gamma),
-                      ptr(beta), int(batch_stats), gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, Ct, None, stream())
+                      ptr(beta), int(batch_stats), gy12.data_ptr() + off, ptr(ggamma), ptr(gbeta), ptr(ws), N, Cc, HW, ctot, Ct, stream())
             res += [ggamma, gbeta]
         return (gy12,) + tuple(res) + (None, None, None, None)
 
@@ -827,7 +877,7 @@ def _bn_state(bn):
 
 def bn_silu_pair(y12, bn_a, bn_b, cat_a=None, cat_b=None):
     """(silu(bn_a(y12[:, :Ca])), silu(bn_b(y12[:, Ca:]))) for the output y12 of ``conv2d_dual``; cat_a / cat_b = (buffer, first channel)
-    as in ``bn_silu``.  Not with the cooperative statistics (EAS_COOP_BN)."""
+    as in ``bn_silu``."""
     return _BNSiLU2Fn.apply(y12, bn_a.weight, bn_a.bias, bn_b.weight, bn_b.bias, _bn_state(bn_a), _bn_state(bn_b), cat_a, cat_b)
 
 
@@ -1400,25 +1450,32 @@ def conv_pack_weights(w, mode=0):
     return packed
 
 
-def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_u8=None):
-    """conv2d(x [NI,Cin,H,W], packed weights), padding ksize//2, on the matrix cores.  x_u8: the byte copy of a spike tensor x
-    (1x1 convolutions read it instead of x: same result, a quarter of the input traffic)."""
+def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_sp=None):
+    """conv2d(x [NI,Cin,H,W], packed weights), padding ksize//2, on the matrix cores.  x_sp: x is a ghost and these are its spike planes
+    [NI,Cin/8,H*W,8] (eas_conv_fwd_planes: same result, half the input bytes, no conversion)."""
     _dev(x, packed, bias)
     NI, Cin, Hi, Wi = x.shape
     pad = ksize // 2
     Ho, Wo = (Hi + 2 * pad - ksize) // stride + 1, (Wi + 2 * pad - ksize) // stride + 1
-    y = torch.empty((NI, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    y = torch.empty((NI, Cout, Ho, Wo), dtype=torch.float32, device=packed.device)
     fl = 2.0 * y.numel() * Cin * ksize * ksize
-    if x_u8 is not None:
-        assert ksize == 1 and stride == 1 and x_terms == 1 and x_u8.dtype == torch.uint8 and x_u8.shape == x.shape
-        x_u8 = x_u8.contiguous()
-        _call('eas_conv_fwd', x_u8.numel() + 4 * y.numel(), _lib.lib().eas_conv_fwd_u8, ptr(x_u8), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout,
-              Hi, Wi, ksize, stream(), flops=fl, issue_flops=fl * 3)
+    L = _lib.lib()
+    if x_sp is not None:
+        assert x_terms == 1 and x_sp.dtype == torch.bfloat16 and x_sp.shape == (NI, Cin // 8, Hi * Wi, 8)
+        x_sp = x_sp.contiguous()
+        stats, nb = None, 0
+        if _WANT_CONV_STATS and bias is None:
+            global _CONV_STATS_SLOT
+            nb = _conv_stats_blocks(L, (NI, Cin, Cout, Hi, Wi, ksize, stride, 2))
+            if 0 < nb <= CONV_STATS_MAX_BLOCKS:
+                stats = torch.empty(Cout * nb * 2, dtype=torch.float64, device=y.device)
+        _call('eas_conv_fwd', 2 * NI * Cin * Hi * Wi + 4 * y.numel(), L.eas_conv_fwd_planes, ptr(x_sp), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout,
+              Hi, Wi, ksize, stride, ptr(stats), nb if stats is not None else 0, stream(), flops=fl, issue_flops=fl * 3)
+        if stats is not None:
+            _CONV_STATS_SLOT = (y, nb, stats, y._version)
         return y
     x = _f32c(x)
-    L = _lib.lib()
     if _WANT_CONV_STATS and bias is None:
-        global _CONV_STATS_SLOT
         nb = _conv_stats_blocks(L, (NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms))
         if 0 < nb <= CONV_STATS_MAX_BLOCKS:
             stats = torch.empty(Cout * nb * 2, dtype=torch.float64, device=x.device)
@@ -1526,38 +1583,30 @@ def _partial_call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     return rc
 
 
-def conv_wgrad(x, gy, ksize, stride, x_terms, x_u8=None, defer=False, w=None):
+def conv_wgrad(x, gy, ksize, stride, x_terms, x_sp=None, defer=False, w=None):
     """grad_w [Cout,Cin,k,k] of conv2d(x, w, stride, padding k//2) given grad_y, on the matrix cores (deterministic).
-    x_u8: byte copy of a spike tensor (1x1 only): read instead of x."""
+    x_sp: x is a ghost, these are its spike planes (eas_conv_wgrad_planes_partial)."""
     _dev(gy)
     gy = _f32c(gy)
-    if x_u8 is not None:
-        NI, Cin, Hi, Wi = x_u8.shape
-        Cout = gy.shape[1]
-        L = _lib.lib()
-        nws = L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, Hi, Wi, 1, 1, 1)
-        if nws <= 0:
-            raise _lib.EasHipError('eas_conv_wgrad_u8: unsupported configuration')
-        ws = torch.empty(nws, dtype=torch.float32, device=gy.device)
-        gw = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=gy.device)
-        fl = 2.0 * gy.numel() * Cin
-        ns = _partial_call('eas_conv_wgrad', x_u8.numel() + 4 * gy.numel(), L.eas_conv_wgrad_u8_partial, ptr(x_u8), ptr(gy), ptr(ws), NI, Cin, Cout,
-                           Hi, Wi, 1, stream(), flops=fl, issue_flops=fl * 3)
-        _wgrad_finish(ws, gw, ns, defer, w)
-        return gw
-    _dev(x)
-    x = _f32c(x)
     NI, Cin, Hi, Wi = x.shape
     Cout = gy.shape[1]
     L = _lib.lib()
-    nws = L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms)
+    xt = 2 if x_sp is not None else x_terms
+    nws = L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, Hi, Wi, ksize, stride, xt)
     if nws <= 0:
         raise _lib.EasHipError('eas_conv_wgrad: unsupported configuration')
-    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-    gw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    ws = torch.empty(nws, dtype=torch.float32, device=gy.device)
+    gw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=gy.device)
     fl = 2.0 * gy.numel() * Cin * ksize * ksize
-    ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
-                       ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+    if x_sp is not None:
+        x_sp = x_sp.contiguous()
+        ns = _partial_call('eas_conv_wgrad', 2 * NI * Cin * Hi * Wi + 4 * gy.numel(), L.eas_conv_wgrad_planes_partial, ptr(x_sp), ptr(gy), ptr(ws), NI,
+                           Cin, Cout, Hi, Wi, ksize, stride, stream(), flops=fl, issue_flops=fl * 3)
+    else:
+        _dev(x)
+        x = _f32c(x)
+        ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
+                           ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
     _wgrad_finish(ws, gw, ns, defer, w)
     return gw
 
@@ -1582,14 +1631,17 @@ def is_small_int(t):
 
 
 def _verify_tags(x, small_int):
-    """test-suite check (VERIFY_SMALL_INT, host sync): a tagged tensor is exact in bf16 and its byte copy equals it"""
+    """test-suite check (VERIFY_SMALL_INT, host sync): a tagged tensor is exact in bf16; a ghost's planes hold small integers"""
     if not (small_int and VERIFY_SMALL_INT):
+        return
+    sp = planes_of(x)
+    if sp is not None:
+        v = sp.float()
+        if not bool(((v == v.round()) & (v >= 0) & (v <= 255)).all()):
+            raise _lib.EasHipError('the spike planes of a tensor do not hold small integers')
         return
     if not bool((x == x.to(torch.bfloat16).to(torch.float32)).all()):
         raise _lib.EasHipError('a tensor tagged as spikes / small integers is not exact in bf16')
-    u = spike_bytes(x)
-    if u is not None and not bool((u.to(torch.float32) == x).all()):
-        raise _lib.EasHipError('the byte copy of a spike tensor differs from its fp32 values')
 
 
 def conv_eligible(x, conv):
@@ -1612,21 +1664,35 @@ def conv_fwd_supported(NI, Cin, Cout, Hi, Wi, k, stride, x_terms):
     return r
 
 
+def _planes_conv_ok(x, w, stride):
+    """forward and weight gradient of conv(x [NI,Cin,H,W] as spike planes, w) both have a planes kernel for this geometry"""
+    NI, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[-1]
+    if not conv_fwd_supported(NI, Cin, Cout, H, W, k, stride, 2):
+        return False
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return bool(_lib.lib().eas_conv_wgrad_workspace_floats(NI, Cin, Cout, H, W, k, stride, 2) > 0
+                and (k == 1 or (Cout % 8 == 0 and Wo % 2 == 0 and (Ho * Wo) % 4 == 0)))
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, x_terms, packs, x_u8=None):
+    def forward(ctx, x, w, bias, stride, x_terms, packs, x_sp=None):
         """packs: {mode: packed weights} made from the current values of ``w`` (packed_weights scope), or None.
-        x_u8: byte copy of the spike tensor x (1x1 convolutions: forward and weight gradient read it instead of x)."""
+        x_sp: x is a ghost (see ``ghost``) and these are its spike planes: forward and weight gradient read them."""
         _dev(x, w, bias)
         k, Cout = w.shape[-1], w.shape[0]
-        if x_u8 is not None and not (k == 1 and stride == 1 and x_terms == 1 and x.shape[-1] * x.shape[-2] % 16 == 0):
-            x_u8 = None
-        if conv_fwd_supported(x.shape[0], x.shape[1], Cout, x.shape[2], x.shape[3], k, stride, x_terms):
+        if x_sp is not None:
+            assert x_terms == 1
+        if conv_fwd_supported(x.shape[0], x.shape[1], Cout, x.shape[2], x.shape[3], k, stride, 2 if x_sp is not None else x_terms):
             pk = packs[0] if packs and 0 in packs else conv_pack_weights(w, 0)
-            y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms, x_u8)
+            y = conv_fwd_packed(x, pk, bias, Cout, k, stride, x_terms, x_sp)
         else:       # no tile for this geometry (not reached by the EAS-SNN models): library forward
+            if x_sp is not None:
+                raise _lib.EasHipError('no matrix-core tile for a convolution on spike planes')
             y = torch.ops.aten.convolution(x, w, bias, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1)
-        ctx.save_for_backward(x, w, x_u8)
+        ctx.save_for_backward(x, w, x_sp)
         ctx.cfg = (k, stride, x_terms, bias is not None)
         ctx.packs = packs        # valid for the backward of this forward (same weights; autograd forbids changing them in between)
         ctx.tag = _TAG
@@ -1634,7 +1700,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, x_u8 = ctx.saved_tensors
+        x, w, x_sp = ctx.saved_tensors
         k, stride, x_terms, has_bias = ctx.cfg
         packs = ctx.packs
         gy = _f32c(gy)
@@ -1647,7 +1713,7 @@ class _ConvFn(torch.autograd.Function):
         own_d = (ctx.needs_input_grad[0] and stride == 1 and (k == 1 or w.shape[0] % 8 == 0)
                  and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3], k, 1, 3))
         own_w = ctx.needs_input_grad[1] and _lib.lib().eas_conv_wgrad_workspace_floats(
-            x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, x_terms) > 0 and (
+            x.shape[0], Cin, w.shape[0], x.shape[2], x.shape[3], k, stride, 2 if x_sp is not None else x_terms) > 0 and (
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
         own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and w.shape[0] % 8 == 0
                   and gy.shape[-1] % 2 == 0 and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3] + 2, k, 1, 3))
@@ -1665,9 +1731,11 @@ class _ConvFn(torch.autograd.Function):
             except _lib.EasHipError:        # no tile for this width (checked before anything is launched): library input gradient
                 gx = None
         if own_w:
-            gw = conv_wgrad(x, gy, k, stride, x_terms, x_u8, defer=_can_defer(w), w=w)
+            gw = conv_wgrad(x, gy, k, stride, x_terms, x_sp, defer=_can_defer(w), w=w)
         need_d = ctx.needs_input_grad[0] and not own_d
         need_w = ctx.needs_input_grad[1] and not own_w
+        if (need_d or need_w) and x_sp is not None:
+            raise _lib.EasHipError('no matrix-core kernel for the gradients of a convolution on spike planes')
         if need_d or need_w:
             rx, rw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, (stride, stride), (k // 2, k // 2), (1, 1), False, (0, 0), 1,
                                                             (need_d, need_w, False))
@@ -1753,19 +1821,19 @@ class _ConvDualFn(torch.autograd.Function):
     gradient (no addition of two branch gradients), one weight-gradient launch whose result is handed out as its two row blocks."""
 
     @staticmethod
-    def forward(ctx, x, wa, wb, x_terms, packs):
+    def forward(ctx, x, wa, wb, x_terms, packs, x_sp=None):
         _dev(x, wa, wb)
         k, Ca, Cout = wa.shape[-1], wa.shape[0], wa.shape[0] + wb.shape[0]
         pk = packs[0] if packs else conv_pack_weights(torch.cat([wa, wb], 0), 0)
-        y = conv_fwd_packed(x, pk, None, Cout, k, 1, x_terms)
-        ctx.save_for_backward(x, wa, wb)
+        y = conv_fwd_packed(x, pk, None, Cout, k, 1, x_terms, x_sp)
+        ctx.save_for_backward(x, wa, wb, x_sp)
         ctx.cfg = (k, x_terms, Ca)
         ctx.packs = packs
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, wa, wb = ctx.saved_tensors
+        x, wa, wb, x_sp = ctx.saved_tensors
         k, x_terms, Ca = ctx.cfg
         gy = _f32c(gy)
         gx = ga = gb = None
@@ -1773,9 +1841,9 @@ class _ConvDualFn(torch.autograd.Function):
             pk = ctx.packs[1] if ctx.packs else conv_pack_weights(torch.cat([wa, wb], 0), 1)
             gx = conv_fwd_packed(gy, pk, None, x.shape[1], k, 1, 3)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw = conv_wgrad(x, gy, k, 1, x_terms)
+            gw = conv_wgrad(x, gy, k, 1, x_terms, x_sp)
             ga, gb = gw[:Ca], gw[Ca:]
-        return gx, ga, gb, None, None
+        return gx, ga, gb, None, None, None
 
 
 def conv_dual_ok(x, conv_a, conv_b):
@@ -1786,12 +1854,12 @@ def conv_dual_ok(x, conv_a, conv_b):
         return False
     k, Cin, Cout = conv_a.kernel_size[0], conv_a.in_channels, conv_a.out_channels + conv_b.out_channels
     if (conv_b.kernel_size[0] != k or conv_b.in_channels != Cin or conv_a.stride != (1, 1) or conv_b.stride != (1, 1)
-            or conv_a.bias is not None or conv_b.bias is not None or Cout % 8 != 0 or SPIKE_BYTES):
+            or conv_a.bias is not None or conv_b.bias is not None or Cout % 8 != 0):
         return False
     if any(c._forward_hooks or c._forward_pre_hooks for c in (conv_a, conv_b)) or torch.nn.modules.module._global_forward_hooks:
         return False
     NI, _, H, W = x.shape
-    xt = 1 if is_small_int(x) else 3
+    xt = 2 if planes_of(x) is not None else (1 if is_small_int(x) else 3)
     L = _lib.lib()
     return bool(conv_fwd_supported(NI, Cin, Cout, H, W, k, 1, xt) and conv_fwd_supported(NI, Cout, Cin, H, W, k, 1, 3)
                 and L.eas_conv_wgrad_workspace_floats(NI, Cin, Cout, H, W, k, 1, xt) > 0 and (k == 1 or (W % 2 == 0 and (H * W) % 4 == 0)))
@@ -1807,7 +1875,7 @@ def conv2d_dual(x, conv_a, conv_b, owner=None, key=None):
         packs = (getattr(owner, '_eas_dual_packs', None) or {}).get(key)
         if packs is not None and (_PACK_SCOPE is None or packs.get('gen') != _PACK_SCOPE):
             packs = None        # not inside the forward that made this packing: pack the weights as they are now
-    return _ConvDualFn.apply(x, conv_a.weight, conv_b.weight, 1 if small else 3, packs)
+    return _ConvDualFn.apply(x, conv_a.weight, conv_b.weight, 1 if small else 3, packs, planes_of(x) if small else None)
 
 
 class packed_weights:
@@ -1820,14 +1888,20 @@ class packed_weights:
         self.model = model
 
     def __enter__(self):
-        global _PACK_SCOPE
-        self.prev = _PACK_SCOPE
+        global _PACK_SCOPE, _PLANES_SCOPE
+        self.prev = (_PACK_SCOPE, _PLANES_SCOPE)
         _PACK_SCOPE = prepack_conv_weights(self.model)
+        mods = getattr(self.model, '_eas_modules', None)
+        if mods is None:
+            mods = list(self.model.modules())
+            object.__setattr__(self.model, '_eas_modules', mods)
+        # a forward hook anywhere in the model may look at a spike tensor: fp32 spikes throughout then (see "SPIKE PLANES")
+        _PLANES_SCOPE = _PACK_SCOPE is not None and not any(m._forward_hooks or m._forward_pre_hooks for m in mods)
 
     def __exit__(self, *exc):
-        global _PACK_SCOPE
-        _PACK_SCOPE = self.prev
-        if self.prev is None:
+        global _PACK_SCOPE, _PLANES_SCOPE
+        _PACK_SCOPE, _PLANES_SCOPE = self.prev
+        if self.prev[0] is None:
             clear_conv_stats()
 
 
@@ -1850,7 +1924,7 @@ def conv_sink():
 def spike_sop(x, ksize, stride, cout):
     """(sum x, conv(x, ones).sum()) of a convolution input x [NI,Cin,H,W] as a device float64 tensor of 2 (eas_spike_sop)."""
     _dev(x)
-    x = _f32c(x)
+    x = _f32c(dense(x))
     NI, Cin, H, W = x.shape
     L = _lib.lib()
     out = torch.empty(2, dtype=torch.float64, device=x.device)
@@ -1865,18 +1939,22 @@ def conv2d(x, conv, small_int=None):
     A module that carries forward hooks (RecordHook in energy_estimation, event_evaluator.py:519-523; thop in
     get_model_info) is called the ordinary way so that the hooks fire."""
     if _CONV_SINK is not None:
+        x = dense(x)
         _CONV_SINK(conv, x, _REPLICAS)
     if conv._forward_hooks or conv._forward_pre_hooks or torch.nn.modules.module._global_forward_hooks:
-        return conv(x)
+        return conv(dense(x))
     if not conv_eligible(x, conv):
+        x = dense(x)
         return conv._conv_forward(x, conv.weight, conv.bias)
     if small_int is None:
         small_int = is_small_int(x)
+    if planes_of(x) is not None and not (small_int and _planes_conv_ok(x, conv.weight, conv.stride[0])):
+        x = dense(x)            # no planes form of this geometry: the fp32 form of the same kernels
     _verify_tags(x, small_int)
     packs = getattr(conv, '_eas_packs', None)
     if packs is not None and (_PACK_SCOPE is None or packs.get('gen') != _PACK_SCOPE):
         packs = None            # not inside the forward that made this packing: pack the weight as it is now
-    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs, spike_bytes(x) if small_int else None)
+    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs, planes_of(x) if small_int else None)
 
 
 # ------------------------------------------------------------------------------------------------ SPP pooling block
@@ -1913,6 +1991,7 @@ def spp_pool_supported(x, ks):
 
 def spp_pool_cat(x, ks):
     """cat[x, maxpool_k(x) for k in ks] along the channel axis of x [..., C, H, W] in one kernel (and one for the backward)."""
+    x = dense(x)
     out = _SPPFn.apply(x, tuple(int(k) for k in ks))
     if is_small_int(x):
         mark_small_int(out)
@@ -2084,6 +2163,7 @@ def upcat_supported(a, b, up):
 
 def upsample_cat(a, b, up=2):
     """cat[nearest-upsample(a, x up), b] along channels in one kernel (one more for the backward); up = 1: plain concatenation"""
+    a, b = dense(a), dense(b)
     out = _UpcatFn.apply(a, b, int(up))
     if up == 1 and is_small_int(a) and is_small_int(b):
         mark_small_int(out)

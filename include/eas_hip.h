@@ -213,36 +213,23 @@ int eas_bn_lif_bwd(const float* grad_s, const float* grad_mean, const float* y, 
  *   (network_blocks.py:99-104) without a separate addition; out_ctot (0 or >= C): the spikes are written as C consecutive
  *   channels of a [T][N][out_ctot][HW] tensor, `spikes` pointing at the first of them -- the concatenations of CSPLayer
  *   (network_blocks.py:183-188) happen in place.  mean_out is the rate of the spikes themselves (without residual).
- *   spikes_u8 (nullable): the output values once more as BYTES in the same layout (spikes and SEW sums are small integers):
- *   the HBM-bound 1x1 convolutions that consume them read 1 B instead of 4 B per element (eas_conv_fwd_u8, eas_conv_wgrad_u8).
+ *   spikes_planes: write the output as SPIKE PLANES instead of fp32 (`spikes` must then be NULL): bf16 in blocks of 8 channels,
+ *   [T*N][out_ctot/8][HW][8] -- spikes and SEW sums are exact in bf16, every consumer's matrix-core fragment (8 consecutive input
+ *   channels of one pixel) is one 16-byte load, at half the bytes of fp32 (eas_conv_fwd_planes, eas_conv_wgrad_planes_partial,
+ *   eas_spike_planes_to_f32).  residual_planes / residual_ctot: the SEW shortcut given as planes ([T*N][residual_ctot/8][HW][8]).
+ *   C, out_ctot, residual_ctot multiples of 8.
  * eas_bn_lif_bwd_ex: grad_s_ctot (0 or >= C): grad_s is such a channel slice of a wider gradient tensor.
  * y_ctot (0 or >= C) in all three: y -- and grad_y in the backward -- are C consecutive channels of a [T][N][y_ctot][HW]
  *   tensor, the pointers at the first of them: ONE convolution (concatenated weights) feeds the two 1x1 branches of a CSPLayer
  *   (network_blocks.py:175-188), its input is read once and its input gradient needs no addition of two branch gradients. */
-/* In-kernel exchange between the blocks of a channel (csrc/eas_common.h: eas_channel_allreduce).  With an EasCoop the BN kernels
- * need no partial-sum launch before them and no second launch for their backward's apply pass: the blocks of a channel (grid = chunks x
- * channels) swap their partial sums through `slots` with agent-scope atomics and continue on the data they have just read.  The
- * buffers belong to the caller, are shared by all layers of a stream (a kernel leaves them clean) and must be initialised ONCE:
- * slots: eas_coop_slot_words(capacity) 64-bit words all equal to EAS_COOP_EMPTY_WORD; tickets: 2 * capacity + 8 int32 zeros; err: one
- * int32 zero (set to 1 if a block ever waited in vain -- it never should).  capacity >= the largest channel count used. */
-#define EAS_COOP_EMPTY_WORD 0x7FF4DEADBEEF0001ull
 typedef struct {
-    void* slots;
-    int* tickets;
-    int* err;
-    int capacity;
-} EasCoop;
-int64_t eas_coop_slot_words(int capacity);
-
-typedef struct {
-    const double* partial;   /* workspace filled by eas_bn_stats_partial; NULL = statistics already final (or computed in-kernel: coop) */
+    const double* partial;   /* workspace filled by eas_bn_stats_partial; NULL = statistics already final */
     int chunks;              /* its return value */
     int replicas;            /* as eas_bn_stats */
     double count;            /* TN * HW */
     float eps, momentum;
     float* running_mean;     /* nullable pair */
     float* running_var;
-    const EasCoop* coop;     /* not NULL (and partial NULL): the consuming kernel computes the batch statistics itself, see EasCoop */
     int pitch;               /* partials allocated per channel in `partial`: 0 = what eas_bn_stats_partial writes (64); the statistics buffer of
                                 eas_conv_fwd_stats: its nb (= chunks; a channel slice: partial = stats + first_channel * nb * 2) */
 } EasBnPending;
@@ -250,22 +237,19 @@ int eas_bn_stats_partial(const float* y, int y_ctot, int TN, int C, int HW, doub
 int eas_bn_lif_fwd_ex(const float* y, int y_ctot, float* mean, float* invstd, const float* gamma, const float* beta,
                       const float* v_in, float* v_out, const float* w_logit, float k_const, float v_th, float v_reset,
                       int flags, float* spikes, float* mean_out, int T, int N, int C, int HW, int y_bcast,
-                      const EasBnPending* pending, const float* residual, int out_ctot, uint8_t* spikes_u8, eas_stream_t stream);
+                      const EasBnPending* pending, const float* residual, int out_ctot, void* spikes_planes, const void* residual_planes,
+                      int residual_ctot, eas_stream_t stream);
 int eas_bn_lif_bwd_ex(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* v_init,
                       const float* w_logit, float k_const, float v_th, float v_reset, int flags, int surrogate,
                       float alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop,
-                      eas_stream_t stream);
-/* coop (nullable) in the backward calls: both passes in ONE launch (pass 2 re-reads grad_s / y from L2 / Infinity Cache instead of
- * HBM); `workspace` is then unused and may be NULL. */
+                      float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
 /* eas_bn_lif_bwd_ex for the learnable arctan surrogate (see eas_lif_bwd_patan). */
 int eas_bn_lif_bwd_patan(const float* grad_s, int grad_s_ctot, const float* grad_mean, const float* y, int y_ctot, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, const float* v_init,
                          const float* w_logit, float k_const, float v_th, float v_reset, int flags, const float* alpha,
                          float* grad_alpha, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, const EasCoop* coop,
-                         eas_stream_t stream);
+                         float* grad_w, double* workspace, int T, int N, int C, int HW, int y_bcast, eas_stream_t stream);
 
 /* BatchNorm2d + SiLU fused for the real-valued BaseConv blocks (stem, PAFPN neck, head:
  * yolox/models/network_blocks.py:52-53 with nn.SiLU); y: conv output [N][C][HW]; mean/invstd from eas_bn_stats
@@ -285,7 +269,7 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
  * whose N*HW values fit the registers of one block (the 8x10 / 16x20 maps) run both passes in one launch. */
 int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta,
-                    double* workspace, int N, int C, int HW, int grad_out_ctot, int y_ctot, const EasCoop* coop, eas_stream_t stream);
+                    double* workspace, int N, int C, int HW, int grad_out_ctot, int y_ctot, eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  adaptive sampler step (AdaptiveRSNNEmbedding.forward loop body,
@@ -404,11 +388,19 @@ int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float*
 int eas_conv_fwd_stats(const float* x, const void* packed_w, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride,
                        int x_terms, int* inexact_flag, double* stats, int nb, eas_stream_t stream);
 int eas_conv_fwd_stats_blocks(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
-/* 1x1 convolution (stride 1) of a spike tensor given as BYTES (uint8 [NI][Cin][Hi][Wi], values 0..255: what eas_bn_lif_fwd_ex writes
- * to spikes_u8): same arithmetic and the same result, bit for bit, as eas_conv_fwd with x_terms = 1 on the fp32 copy, reading
- * 1 B instead of 4 B per input element (the 1x1 layers are HBM-bound).  Cin % 8 == 0. */
-int eas_conv_fwd_u8(const uint8_t* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi,
-                    int ksize, eas_stream_t stream);
+/* SPIKE PLANES: the storage form of spike tensors between the fused layers.  A spike tensor [NI][C][HW] (NI = T*N images; 0/1 spikes
+ * and SEW sums: exact in bf16) is kept as bf16 in blocks of 8 channels, planes[NI][C/8][HW][8] -- the MFMA operand of every consumer
+ * (8 consecutive input channels of one pixel) is one 16-byte load, at half the bytes of fp32.  Written by eas_bn_lif_fwd_ex
+ * (spikes_planes), read by eas_conv_fwd_planes / eas_conv_wgrad_planes_partial; converted at the borders of the fused path by
+ * eas_spike_planes_from_f32 / _to_f32.  C % 8 == 0, HW % 4 == 0, 16-byte aligned.  src_ctot / dst_ctot (0 = C): the C channels are a
+ * channel (group) slice of a wider tensor, the pointer at the first of them. */
+int eas_spike_planes_from_f32(const float* x, int src_ctot, void* planes, int dst_ctot, int64_t NI, int C, int HW, eas_stream_t stream);
+int eas_spike_planes_to_f32(const void* planes, int src_ctot, float* x, int dst_ctot, int64_t NI, int C, int HW, eas_stream_t stream);
+/* eas_conv_fwd / eas_conv_fwd_stats (1x1 and 3x3, stride 1 / 2) reading x as spike planes: the same products summed in the same order as
+ * eas_conv_fwd with x_terms = 1 on the fp32 values -- bit-identical y.  stats / nb: NULL / 0, or as eas_conv_fwd_stats.  The geometry
+ * queries (eas_conv_fwd_supported, eas_conv_fwd_stats_blocks, eas_conv_wgrad_workspace_floats) take x_terms = 2 for this input form. */
+int eas_conv_fwd_planes(const void* x_planes, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi,
+                        int ksize, int stride, double* stats, int nb, eas_stream_t stream);
 /* 1 when eas_conv_fwd has a tile for this geometry, else 0 (it would return EAS_ERR_UNSUPPORTED).  3x3 layers whose staged input
  * rows do not fit LDS in one piece (real-valued inputs on rows wider than ~280 pixels) run in 2, 4 or 8 column parts. */
 int eas_conv_fwd_supported(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
@@ -428,14 +420,9 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
 int eas_conv_wgrad_parts(int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms);
 int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi,
                    int Wi, int ksize, int stride, int x_terms, eas_stream_t stream);
-/* grad_w[Cout][Cin] of a 1x1 convolution whose input is given as spike BYTES (see eas_conv_fwd_u8); workspace as eas_conv_wgrad
- * with ksize 1, stride 1, x_terms 1; bit-identical to eas_conv_wgrad on the fp32 copy. */
-int eas_conv_wgrad_u8(const uint8_t* x, const float* grad_y, float* grad_w, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi,
-                      int ksize, eas_stream_t stream);
-
 /* Deferred slab reduction.  eas_conv_wgrad = slab kernel + a fixed-order reduction of the slabs; a training step has ~80 weight
  * gradients and nothing reads them before the optimizer step, so the host may launch only the slab kernels
- * (eas_conv_wgrad_partial / eas_conv_wgrad_u8_partial: same arguments without grad_w, return the number of slabs written, > 0, or a
+ * (eas_conv_wgrad_partial / eas_conv_wgrad_planes_partial: same arguments without grad_w, return the number of slabs written, > 0, or a
  * negative status) and reduce ALL of them with one launch: eas_conv_wgrad_reduce_many(jobs on the HOST, njobs).  Same summation
  * order as eas_conv_wgrad: bit-identical gradients. */
 typedef struct {
@@ -446,8 +433,9 @@ typedef struct {
 } EasWgradReduceJob;
 int eas_conv_wgrad_partial(const float* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                            int stride, int x_terms, eas_stream_t stream);
-int eas_conv_wgrad_u8_partial(const uint8_t* x, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
-                              eas_stream_t stream);
+/* x given as spike planes (see eas_conv_fwd_planes); workspace: eas_conv_wgrad_workspace_floats(..., x_terms = 2) */
+int eas_conv_wgrad_planes_partial(const void* x_planes, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
+                                  int stride, eas_stream_t stream);
 int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_stream_t stream);
 
 /* SPP pooling block fused: out[N][4C][H][W] = cat[x, maxpool_k0(x), maxpool_k1(x), maxpool_k2(x)] (stride 1, padding k/2,

@@ -687,49 +687,93 @@ def test_bn_lif_fused_vs_oracle(dev, T, N, C, H, W, train):
     assert int(hbn.num_batches_tracked) == int(rbn.num_batches_tracked)
 
 
-@pytest.mark.parametrize('T,N,C,H,W', [(3, 2, 8, 12, 16), (3, 64, 32, 64, 80), (5, 3, 200, 8, 12), (1, 4, 16, 4, 4), (7, 2, 64, 16, 20)])
-def test_cooperative_bn_kernels_equal_the_separate_launches(dev, monkeypatch, T, N, C, H, W):
-    """EasCoop: batch statistics computed inside eas_bn_lif_fwd_ex / eas_bn_silu_fwd_ex and both backward passes in one launch (the
-    blocks of a channel exchange their partial sums through agent-scope atomics) against the separate-launch forms: spikes bit-identical,
-    statistics / gradients to fp32 rounding (the partial sums are grouped differently), run-to-run bit-identical, the shared buffers
-    clean after every call, no block ever waited in vain."""
+@pytest.mark.parametrize('NI,C,H,W', [(1, 8, 2, 2), (6, 64, 16, 20), (3, 200, 8, 12), (2, 32, 5, 8)])
+def test_spike_planes_pack_and_unpack(dev, NI, C, H, W):
+    """eas_spike_planes_from_f32 / _to_f32: planes[NI][C/8][H*W][8] bf16 is the documented permutation of the fp32 tensor, and a ghost
+    unpacks (ops.dense) to exactly the tensor it stands for, with the gradient passed through."""
+    from eas_snn_amd import ops
+    gen = torch.Generator().manual_seed(NI * 31 + C)
+    x = torch.randint(0, 4, (NI, C, H, W), generator=gen).float().to(dev)
+    sp = ops.to_planes(x)
+    assert sp.dtype == torch.bfloat16 and sp.shape == (NI, C // 8, H * W, 8)
+    want = x.view(NI, C // 8, 8, H * W).permute(0, 1, 3, 2).to(torch.bfloat16)
+    assert torch.equal(sp, want)
+    g = ops.ghost(x.shape, dev, sp)
+    assert g.untyped_storage().nbytes() == 4 and bool(torch.isnan(g).all())          # no storage behind it, never a plausible value
+    g = g.detach().requires_grad_(True)
+    g._eas_sp = sp
+    d = ops.dense(g)
+    assert torch.equal(d, x) and ops.is_small_int(d)
+    gy = torch.randn(NI, C, H, W, generator=gen).to(dev)
+    d.backward(gy)
+    assert torch.equal(g.grad, gy)
+    assert ops.dense(x) is x
+
+
+@pytest.mark.parametrize('T,N,C,H,W,sew,cat,mean', [(3, 2, 8, 12, 16, False, False, False), (3, 4, 32, 16, 20, True, False, False),
+                                                    (5, 3, 200, 8, 12, True, True, False), (1, 4, 16, 4, 4, False, True, False),
+                                                    (7, 2, 64, 16, 20, False, False, True), (3, 2, 64, 6, 10, True, True, False)])
+def test_bn_lif_spike_planes_equal_the_fp32_output(dev, T, N, C, H, W, sew, cat, mean):
+    """The fused BN+LIF kernel writing its output as bf16 spike planes (own tensor or channel groups of a concatenation kept as planes,
+    SEW shortcut read from planes) against the fp32 form of the same call: spikes, potentials, firing rate, running statistics and
+    every gradient bit-identical."""
     from eas_snn_amd import ops
     gen = torch.Generator().manual_seed(C * 7 + T)
     y = (torch.randn(T, N, C, H, W, generator=gen) * 1.3 + 0.2).to(dev)
     gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(dev), (torch.randn(C, generator=gen) * 0.3).to(dev)
-    g_s = torch.randn(T, N, C, H, W, generator=gen).to(dev)
-    res = {}
-    for coop in (True, False, True):
-        monkeypatch.setattr(ops, 'COOP_BN', coop)
+    res = (torch.rand(T, N, C, H, W, generator=gen) < 0.3).float().to(dev) if sew else None
+    g_s = torch.randn(T, N, 2 * C if cat else C, H, W, generator=gen).to(dev)
+    g_m = torch.randn(N, C, H, W, generator=gen).to(dev)
+    out = []
+    for planes in (True, False):
         yy = y.clone().requires_grad_(True)
         ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
         wl = torch.zeros((), device=dev, requires_grad=True)
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        s, v, _ = ops.bn_lif_multistep(yy, ga, be, rm, rv, True, 0.03, 1e-3, None, wl, 0.0, 1.0, 0.0, 0, 'atan', 2.0, write_v=True)
-        s.backward(g_s)
-        lif = (s.detach().clone(), v.clone(), rm.clone(), rv.clone(), yy.grad.clone(), ga.grad.clone(), be.grad.clone(), wl.grad.clone())
-        # BN + SiLU on the first time step
-        y0 = y[0].clone().requires_grad_(True)
-        bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).to(dev).train()
-        with torch.no_grad():
-            bn.weight.copy_(gamma); bn.bias.copy_(beta)
-        o = ops.bn_silu(y0, bn)
-        o.backward(g_s[0])
-        silu = (o.detach().clone(), bn.running_mean.clone(), bn.running_var.clone(), y0.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
-        if coop and 'coop' in res:
-            for a, b in zip(res['coop'], lif + silu):
-                assert torch.equal(a, b), 'cooperative kernels are not run-to-run deterministic'
-        res['coop' if coop else 'sep'] = lif + silu
-    if ops._COOP:
-        cst, slots, tickets, err = ops.coop_buffers(dev)
-        assert not ops.coop_error(dev)
-        assert int(tickets.abs().sum()) == 0 and bool((slots == slots[0]).all()), 'the exchange buffers were not left clean'
-    a, b = res['coop'], res['sep']
-    assert torch.equal(a[0], b[0]), 'spikes differ'
-    names = ['spikes', 'v', 'running_mean', 'running_var', 'grad_y', 'grad_gamma', 'grad_beta', 'grad_w', 'silu', 'silu rm', 'silu rv', 'silu grad_y',
-             'silu grad_gamma', 'silu grad_beta']
-    for n_, x1, x2 in zip(names, a, b):
-        torch.testing.assert_close(x1, x2, rtol=2e-5, atol=2e-6, msg=lambda m, n_=n_: f'{n_}: {m}')
+        r = None
+        if res is not None:
+            r = res.clone().requires_grad_(True)
+            if planes:
+                r = ops.ghost(res.shape, dev).detach().requires_grad_(True)
+                r._eas_sp = ops.to_planes(res)
+            ops.mark_small_int(r)
+        ct = None
+        if cat:
+            if planes:
+                sp_buf = ops.new_planes(T, N, 2 * C, H, W, dev)
+                sp_buf.zero_()
+                buf = ops.ghost((T, N, 2 * C, H, W), dev)
+                ct = (buf, C, sp_buf)
+            else:
+                buf = torch.zeros(T, N, 2 * C, H, W, device=dev)
+                ct = (buf, C)
+        s, v, mo = ops.bn_lif_multistep(yy, ga, be, rm, rv, True, 0.03, 1e-3, None, wl, 0.0, 1.0, 0.0, 0, 'atan', 2.0, write_v=True,
+                                        want_mean=mean, residual=r, cat=ct, planes=planes)
+        if planes:
+            assert ops.planes_of(s) is not None and ops.planes_of(s).dtype == torch.bfloat16 and bool(torch.isnan(s).all())
+        else:
+            assert ops.planes_of(s) is None
+        if cat:
+            full = ops.join_channels(buf, s, sp_buf=sp_buf if planes else None)
+            ops.mark_small_int(full)
+            if planes:
+                full._eas_sp = sp_buf
+            val = ops.dense(full)
+            val.backward(g_s)
+        else:
+            val = ops.dense(s)
+            if mean:
+                (val * g_s).sum().add((mo * g_m).sum()).backward()
+            else:
+                val.backward(g_s)
+        out.append((val.detach().clone(), v.clone(), None if mo is None else mo.detach().clone(), rm.clone(), rv.clone(), yy.grad.clone(),
+                    ga.grad.clone(), be.grad.clone(), wl.grad.clone(), None if r is None else r.grad.clone()))
+    names = ['spikes', 'v', 'rate', 'running_mean', 'running_var', 'grad_y', 'grad_gamma', 'grad_beta', 'grad_w', 'grad_residual']
+    assert float(out[0][0].max()) >= 1.0
+    for n_, a, b in zip(names, out[0], out[1]):
+        assert (a is None) == (b is None), n_
+        if a is not None:
+            assert torch.equal(a, b), n_
 
 
 @pytest.mark.parametrize('train', [True, False])
@@ -1232,48 +1276,81 @@ def test_prediction_conv_input_gradient_on_own_kernel(dev, Cout, H, W):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('T,N,Cin,Cout,H,W,sew', [(3, 2, 32, 64, 16, 20, False), (3, 4, 64, 32, 8, 12, True), (5, 1, 128, 256, 4, 8, False),
-                                                  (3, 2, 256, 512, 8, 10, True)])
-def test_spike_bytes_feed_the_1x1_convolutions_bit_identically(dev, monkeypatch, T, N, Cin, Cout, H, W, sew):
-    """The fused BN+LIF kernel writes its spikes (and SEW sums) a second time as bytes; the 1x1 convolution reading them next
-    (eas_conv_fwd_u8) and its weight gradient (eas_conv_wgrad_u8) give exactly the results of the fp32 route: byte copy == fp32
-    spikes, y and grad_w bit-identical, grad_x untouched by the switch."""
+@pytest.mark.parametrize('T,N,Cin,Cout,H,W,k,stride,sew', [(3, 2, 32, 64, 16, 20, 1, 1, False), (3, 4, 64, 32, 8, 12, 1, 1, True),
+                                                           (5, 1, 128, 256, 4, 8, 1, 1, False), (3, 2, 256, 512, 8, 10, 1, 1, True),
+                                                           (3, 2, 32, 64, 16, 20, 3, 1, True), (3, 4, 64, 64, 8, 12, 3, 1, False),
+                                                           (3, 2, 64, 128, 16, 24, 3, 2, True), (2, 3, 72, 40, 12, 16, 3, 1, False),
+                                                           (3, 2, 200, 96, 8, 12, 1, 1, False)])
+def test_spike_planes_feed_the_convolutions_bit_identically(dev, T, N, Cin, Cout, H, W, k, stride, sew):
+    """A convolution that reads its input as bf16 spike planes (eas_conv_fwd_planes) and its weight gradient
+    (eas_conv_wgrad_planes_partial) give exactly the results of the fp32 route on the same spikes: y, the batch statistics the forward
+    leaves for the BatchNorm behind it, grad_w and grad_x bit-identical; and y matches float64."""
     import torch.nn as nn
     from eas_snn_amd import ops
-    monkeypatch.setattr(ops, 'SPIKE_BYTES', True)            # off by default (no step-time gain measured, DESIGN.md 7b)
-    gen = torch.Generator().manual_seed(T * 100 + Cin)
+    gen = torch.Generator().manual_seed(T * 100 + Cin + k)
     yin = torch.randn(T, N, Cin, H, W, generator=gen).to(dev)
     gamma, beta = (torch.rand(Cin, generator=gen) + 0.5).to(dev), (torch.randn(Cin, generator=gen) * 0.3).to(dev)
     res = (torch.rand(T, N, Cin, H, W, generator=gen) < 0.3).float().to(dev) if sew else None
+    r = None
     if res is not None:
-        ops.mark_small_int(res)
+        r = ops.ghost(res.shape, dev, ops.to_planes(res))
     rm, rv = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
     wl = torch.zeros((), device=dev)
-    spikes, _, _ = ops.bn_lif_multistep(yin, gamma, beta, rm, rv, True, 0.03, 1e-3, None, wl, 0.0, 1.0, 0.0, 0, 'atan', 2.0, residual=res,
-                                        emit_bytes=True)
-    u8 = ops.spike_bytes(spikes)
-    assert u8 is not None and u8.dtype == torch.uint8 and torch.equal(u8.float(), spikes)
+    ghost, _, _ = ops.bn_lif_multistep(yin, gamma, beta, rm, rv, True, 0.03, 1e-3, None, wl, 0.0, 1.0, 0.0, 0, 'atan', 2.0, residual=r,
+                                       planes=True)
+    sp = ops.planes_of(ghost)
+    assert sp is not None
+    spikes = ops.dense(ghost)
     assert float(spikes.max()) == (2.0 if sew else 1.0)
-    ops.mark_small_int(spikes)
-    conv = nn.Conv2d(Cin, Cout, 1, 1, 0, bias=False).to(dev)
-    gy = torch.randn(T * N, Cout, H, W, generator=gen).to(dev)
+    conv = nn.Conv2d(Cin, Cout, k, stride, k // 2, bias=False).to(dev)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    gy = torch.randn(T * N, Cout, Ho, Wo, generator=gen).to(dev)
     outs = []
-    for use_bytes in (True, False):
-        x = spikes.detach().clone().requires_grad_(True)
-        if use_bytes:
-            x._eas_u8 = u8
+    for use_planes in (True, False):
+        if use_planes:
+            x = ops.ghost(spikes.shape, dev).detach().requires_grad_(True)
+            x._eas_sp = sp
+        else:
+            x = spikes.detach().clone().requires_grad_(True)
         ops.mark_small_int(x)
         x4 = ops.fold_time(x)
-        assert (ops.spike_bytes(x4) is not None) == use_bytes
+        assert (ops.planes_of(x4) is not None) == use_planes
         conv.weight.grad = None
-        y = ops.conv2d(x4, conv)
+        with ops.conv_stats_scope(True):
+            y = ops.conv2d(x4, conv)
+        slot = ops._CONV_STATS_SLOT
+        stats = slot[2].clone() if slot is not None and slot[0] is y else None
+        ops.clear_conv_stats()
         y.backward(gy)
-        outs.append((y.detach().clone(), conv.weight.grad.clone(), x.grad.clone()))
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+        outs.append((y.detach().clone(), stats, conv.weight.grad.clone(), x.grad.clone()))
+    for n_, a, b in zip(('y', 'stats', 'grad_w', 'grad_x'), outs[0], outs[1]):
+        assert (a is None) == (b is None), n_
+        if a is not None:
+            assert torch.equal(a, b), n_
     w64 = conv.weight.detach().double().cpu()
-    y64 = torch.nn.functional.conv2d(spikes.flatten(0, 1).double().cpu(), w64)
+    y64 = torch.nn.functional.conv2d(spikes.flatten(0, 1).double().cpu(), w64, stride=stride, padding=k // 2)
     assert (outs[0][0].double().cpu() - y64).abs().max().item() / y64.abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_spike_planes_kernels_are_the_ones_that_run(dev):
+    """the planes entry points are reached for the model's layer shapes (no silent unpacking in front of the convolutions)"""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    try:
+        for Cin, Cout, k, stride, H, W in ((32, 64, 1, 1, 16, 20), (64, 64, 3, 1, 16, 20), (64, 128, 3, 2, 16, 24)):
+            x = (torch.rand(6, Cin, H, W) < 0.2).float().to(dev)
+            g = ops.ghost(x.shape, dev, ops.to_planes(x))
+            conv = nn.Conv2d(Cin, Cout, k, stride, k // 2, bias=False).to(dev)
+            y = ops.conv2d(g, conv)
+            y.sum().backward()
+            assert torch.equal(y, ops.conv2d(ops.mark_small_int(x), conv))
+    finally:
+        ops.set_timer(None)
+    torch.cuda.synchronize()
+    assert 'eas_spike_planes' not in timer.summary(), timer.summary().keys()
 
 
 @pytest.mark.gpu

@@ -567,6 +567,53 @@ def test_train_step_is_bit_reproducible(dev, name):
     assert not diff, f'run-to-run gradient differences in {diff}'
 
 
+@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64', 'model_s_true_256x320'])
+def test_spike_planes_and_fp32_spikes_give_bit_identical_steps(dev, name, monkeypatch):
+    """The spiking backbone with its spike tensors kept as bf16 spike planes (the default, ops "SPIKE PLANES") against the same step with
+    fp32 spike tensors (EAS_SPIKE_PLANES=0): loss, every parameter gradient and every BatchNorm buffer bit-identical -- the planes hold
+    exactly the values of the fp32 tensors and every kernel that reads them adds the same products in the same order."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import functional
+    from yolox.models.network_blocks import BaseConv
+    g, model = _build(name, dev)
+    model.train()
+    model.head.use_l1 = True
+    x = torch.from_numpy(g['x']).to(dev)
+    if 'targets' in g:
+        tg = torch.from_numpy(g['targets']).to(dev)
+    else:
+        from eas_snn_amd import data
+        tg = data.synth_targets(x.shape[0], tuple(x.shape[-2:]), dev)
+    nplanes = sum(1 for m in model.modules() if isinstance(m, BaseConv) and m.planes_out)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    for planes in (True, False):
+        monkeypatch.setattr(ops, 'SPIKE_PLANES', planes)
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        try:
+            out = model(x, tg)
+            out['total_loss'].backward()
+        finally:
+            ops.set_timer(None)
+        functional.reset_net(model)
+        torch.cuda.synchronize()
+        unpacks = timer.summary().get('eas_spike_planes', {}).get('calls', 0)
+        runs.append((out['total_loss'].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()},
+                     {n: b.clone() for n, b in model.named_buffers()}, unpacks))
+    assert nplanes > 20                                      # every converted block hands planes on
+    if '256x320' in name:
+        assert 0 < runs[0][3] <= 2, runs[0][3]               # unpacked only in front of the SPP pooling (fp32 kernel)
+    assert runs[1][3] == 0
+    assert torch.equal(runs[0][0], runs[1][0])
+    diff = sorted(n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[1][1][n]))
+    assert not diff, f'gradient differences in {diff[:5]}'
+    diff = sorted(n for n in runs[0][2] if not torch.equal(runs[0][2][n], runs[1][2][n]))
+    assert not diff, f'buffer differences in {diff[:5]}'
+
+
 def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(dev):
     """yolox.core.trainer.TrainStep (the iteration tools/train_event.py runs and bench.py measures): the backward pass split at the
     backbone with the gradients packed into two flat buckets (the N > 1 form, here without a process group), eagerly and as three
@@ -877,6 +924,50 @@ def test_csp_single_convolution_for_both_branches_is_identical(dev, train, monke
     torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
     for k in p0:
         torch.testing.assert_close(p1[k], p0[k], rtol=1e-5, atol=1e-6 * float(p0[k].abs().max()) + 1e-12, msg=k)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+
+
+@pytest.mark.parametrize('n,shortcut,dual', [(2, True, True), (1, False, True), (0, True, True), (3, True, False)])
+def test_csp_layer_on_spike_planes_is_bit_identical(dev, monkeypatch, n, shortcut, dual):
+    """A converted CSPLayer whose internal spike tensors (branch outputs, bottleneck outputs with their SEW shortcuts, the in-place
+    concatenation) are bf16 spike planes, inside a ``packed_weights`` scope as in the model's forward, against the same layer on fp32 spike
+    tensors: output, input gradient, parameter gradients and BatchNorm buffers bit-identical; a block called outside such a scope hands out
+    fp32 spikes."""
+    import copy
+    from eas_snn_amd import ops
+    from yolox.models.network_blocks import CSPLayer, enable_spike_planes
+    from yolox.utils.utils_snn import convert_to_spiking
+    from spikingjelly.activation_based import functional, surrogate
+    if not dual:
+        monkeypatch.setenv('EAS_NO_DUAL', '1')
+    torch.manual_seed(7 + n)
+    base = CSPLayer(64, 64, n=n, shortcut=shortcut)
+    convert_to_spiking(base, spike_fn=surrogate.ATan(2.0))
+    x = (torch.rand(3, 2, 64, 16, 20) < 0.3).float()
+    go = torch.randn(3, 2, 64, 16, 20)
+    res = []
+    for planes in (True, False):
+        net = enable_spike_planes(copy.deepcopy(base).to(dev).train(), planes)
+        if planes:
+            probe = net(ops.mark_small_int(x.to(dev)))
+            assert ops.planes_of(probe) is None and not bool(torch.isnan(probe).any())       # on its own: fp32 out
+            functional.reset_net(net)
+            net = enable_spike_planes(copy.deepcopy(base).to(dev).train(), True)
+        xd = ops.mark_small_int(x.to(dev)).requires_grad_(True)
+        with ops.packed_weights(net):
+            out = net(xd)
+            assert (ops.planes_of(out) is not None) == planes
+            val = ops.dense(out)
+        val.backward(go.to(dev))
+        functional.reset_net(net)
+        res.append((val.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                    {k: b.clone() for k, b in net.named_buffers()}))
+    (o0, g0, p0, b0), (o1, g1, p1, b1) = res
+    assert torch.equal(o0, o1) and float(o0.sum()) > 0
+    assert torch.equal(g0, g1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
 
