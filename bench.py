@@ -38,11 +38,15 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same
 # command, scripts/gpu_profile.sh; gfx950 corrections applied by scripts/pmc_summary.py).  C-ABI entry -> device kernels.
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
-PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
+PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel', 'bn_lif_fwd_sp_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
                'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
-               'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel'], 'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel'],
+               'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel'],
+               'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel', 'arsnn_fused_step_fwd_kernel'],
                'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel', 'smallconv_wgrad_mfma_kernel'],
-               'eas_conv_fwd': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel'], 'eas_conv_wgrad': ['conv_wgrad_mfma_kernel', 'conv1x1_wgrad_kernel']}
+               'eas_conv_fwd': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel', 'conv1x1_mfma_sharedA_kernel', 'conv_dgrad_s2_kernel',
+                                'conv_fwd_mfma_kernel[planes]', 'conv1x1_mfma_kernel[planes]', 'conv1x1_mfma_sharedA_kernel[planes]'],
+               'eas_conv_wgrad': ['conv_wgrad_mfma_kernel', 'conv1x1_wgrad_lds_kernel', 'conv_wgrad_mfma_kernel[planes]',
+                                  'conv1x1_wgrad_lds_kernel[planes]']}
 
 
 def pmc_traffic(entry, launches_per_call):
@@ -433,7 +437,8 @@ def main():
         summ = timer.summary()
         fam = {k: dict(calls=v['calls'], ms_per_step=round(v['ms'] / timed_steps, 4),
                        GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
-                       **({'TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} if v['flops'] > 0 else {})) for k, v in summ.items()}
+                       **({'TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} if v['flops'] > 0 else {}),
+                       roofline_frac=round(v['roof_ms'] / v['ms'], 3) if v['ms'] > 0 else None) for k, v in summ.items()}
         dom = max(summ, key=lambda k: summ[k]['ms'])
         d = summ[dom]
         sec = d['ms'] * 1e-3
@@ -459,6 +464,9 @@ def main():
                         'mfma_bf16_issued_tflops': round(d['issue_flops'] / sec / 1e12, 1), 'mfma_bf16_peak_tflops': BF16_MFMA_PEAK_TF,
                         'mfma_bf16_util': round(d['issue_flops'] / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
                         'mfma_busy_measured': mfma_busy_measured(),
+                        # per launch max(algorithmic bytes / 8 TB/s, bf16 term flops / 2.5 PFLOP/s), summed over this family's launches,
+                        # over the measured time: the small-channel layers are HBM-bound, so the term ceiling alone overstates the headroom
+                        'frac_of_per_launch_roofline': round(d['roof_ms'] / d['ms'], 4),
                         'algorithmic_GBps': round(d['bytes'] / sec / 1e9, 1)}
         else:
             achieved = d['bytes'] / sec / 1e9

@@ -199,9 +199,9 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_finalize_kernel(BnFin fin) {
     bn_finalize_in_block(fin, (int)blockIdx.x, st, mu, istd, true);
 }
 
-// The same layer writing its output as spike planes.  A thread owns the 8 channels of one group for PV consecutive pixels of an image:
-// 8 x T loads of PV floats (each channel row is contiguous over the lanes), the neuron over T in registers, and per step ONE 16-byte
-// store per pixel.  blockIdx -> (channel group, chunk of the group's N * HW / PV pixel groups).  residual: planes as well.
+// The same layer writing its output as spike planes.  A thread owns the 8 channels of one group for PV consecutive pixels of an image
+// (PV = 1 is what runs): 8 x T loads of PV floats (each channel row is contiguous over the lanes), the neuron over T in registers, and
+// per step ONE 16-byte store per pixel.  blockIdx -> (channel group, chunk of the group's N * HW / PV pixel groups).  residual: planes as well.
 template <int T_, bool HARD, bool DI, bool STRICT, int PV>
 __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_fwd_sp_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -477,8 +477,10 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(EAS_BLOCK), 0, st, fin);
             EAS_CHECK_LAUNCH();
         }
-        constexpr int PV = T_ <= 4 ? 4 : 2;
-        if (HW % PV != 0) return EAS_ERR_UNSUPPORTED;
+        // one pixel per thread: 8 x T dword loads (each channel row contiguous over the lanes) and T 16-byte stores, few registers, many
+        // waves in flight (measured on config 2: 1.02 ms per step for all layers against 1.10 / 1.24 ms with 2 / 4 pixels per thread and
+        // 1.10 ms for the fp32-writing kernel)
+        constexpr int PV = 1;
         const int chunks = pick_chunks((int64_t)N * (HW / PV), C / 8);
         hipLaunchKernelGGL((bn_lif_fwd_sp_kernel<T_, HARD, DI, STRICT, PV>), EAS_CHAN_GRID(chunks, C / 8), dim3(EAS_BLOCK), 0, st, y,
                            mean, invstd, gamma, beta, v_in,

@@ -69,14 +69,18 @@ class KernelTimer:
         if _TAG is not None:                      # development: per-layer breakdown (scripts/layer_times.py)
             self.tagged.setdefault((_TAG, name), []).append((start, end, nbytes, flops, issue_flops))
 
-    def summary(self):
-        """per entry point: calls, total ms, algorithmic bytes, algorithmic flops (2 x MAC) and matrix-core flops issued
-        (algorithmic x number of bf16 term products)."""
+    def summary(self, hbm_gbs=8000.0, mfma_tf=2500.0):
+        """per entry point: calls, total ms, algorithmic bytes, algorithmic flops (2 x MAC), matrix-core flops issued
+        (algorithmic x number of bf16 term products) and the sum of the launches' roofline times (roof_ms, see below)."""
         out = {}
         for name, items in self.rec.items():
             ms = sum(it[0].elapsed_time(it[1]) for it in items)
+            # per-launch roofline: a launch cannot finish before its algorithmic bytes have crossed HBM nor before its bf16 term products
+            # have gone through the matrix cores -- the larger of the two, summed over the launches (small-channel layers are HBM-bound,
+            # wide ones MFMA-bound; one ceiling for the whole family describes neither)
+            roof = sum(max(it[2] / (hbm_gbs * 1e9), it[4] / (mfma_tf * 1e12)) for it in items) * 1e3
             out[name] = dict(calls=len(items), ms=ms, bytes=sum(it[2] for it in items), flops=sum(it[3] for it in items),
-                             issue_flops=sum(it[4] for it in items))
+                             issue_flops=sum(it[4] for it in items), roof_ms=roof)
         return out
 
 
@@ -243,6 +247,7 @@ def _f32c(t):
 class _LIFFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v_in, w, k_const, v_th, v_reset, flags, sg_id, alpha, want_mean, write_v):
+        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         _dev(x, v_in, w)
         L = _lib.lib()
         x = _f32c(x)
@@ -416,6 +421,7 @@ class _BNLIFFn(torch.autograd.Function):
         sp_arg: None = fp32 output; True = the output as spike planes (fourth result; the first result is then a ghost, see ``ghost``);
         a planes tensor [T,N,Ctot/8,HW,8] = the planes of ``cat_buf`` (itself a ghost): written into its groups cat_c0/8.. .
         residual_sp: the planes of ``residual`` when that is a ghost."""
+        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         running_mean, running_var, use_batch_stats, momentum, eps = bn_state
         _dev(y, gamma, beta, v_in, w)
         L = _lib.lib()
@@ -562,6 +568,7 @@ class _BNLIF2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y12, gamma_a, beta_a, w_a, gamma_b, beta_b, w_b, cfg_a, cfg_b):
+        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         L = _lib.lib()
         y12 = _f32c(y12)
         T, N, Ct, H, W = y12.shape
@@ -797,6 +804,7 @@ class _BNSiLU2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y12, gamma_a, beta_a, gamma_b, beta_b, state_a, state_b, cat_a, cat_b):
+        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         L = _lib.lib()
         y12 = _f32c(y12)
         N, Ct, H, W = y12.shape
@@ -1145,6 +1153,7 @@ class _ARSNNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ev, cfg, *params):
+        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         _dev(ev, *params)
         L = _lib.lib()
         k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = cfg
@@ -1282,6 +1291,8 @@ class _ARSNNFn(torch.autograd.Function):
         pin, pg = params[:2 * d_in], params[2 * d_in:]
         HW = H * W
         st = stream()
+        if g_out is None:
+            return (None,) * (2 + len(params))
         g_out = _f32c(g_out)
         if ab:
             g_out = g_out * (pre_relu > 0)
@@ -2073,6 +2084,7 @@ class _DetLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, labels, strides, nc, use_l1, *raw):
+        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         L = len(raw) // 3
         regs, objs, clss = [_f32c(t) for t in raw[0::3]], [_f32c(t) for t in raw[1::3]], [_f32c(t) for t in raw[2::3]]
         _dev(labels, *regs)
@@ -2113,6 +2125,8 @@ class _DetLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, *_unused):
         grads = ctx.grads
+        if g_total is None:
+            return (None,) * (4 + len(grads))
         torch._foreach_mul_(grads, g_total * ctx.scale)
         return (None, None, None, None) + tuple(grads)
 

@@ -14,7 +14,7 @@ find $OUT/stats -name '*kernel_trace.csv' -delete
 RX='bn_lif|bn_stats|bn_silu|lif_fwd|lif_bwd|arsnn|event_hist|smallconv|conv_|conv1x1'
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RX" --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-python3 $ROOT/scripts/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
+python3 $ROOT/scripts/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json ${2:-} > $OUT/pmc_traffic.txt 2>&1
 find $OUT -name '*kernel_trace.csv' -delete
 find $OUT -name '*counter_collection.csv' -size +8M -delete
 tail -3 $OUT/bench_under_rocprof.log; head -30 $OUT/pmc_traffic.txt

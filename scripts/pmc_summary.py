@@ -3,7 +3,11 @@
 per-kernel HBM traffic per launch.  gfx950 corrections from the guide: both counters are in KiB; FETCH_SIZE reads
 exactly half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact.
 
-usage: pmc_summary.py <fetch_dir> <write_dir> <out.json>"""
+The x2 holds for 16-byte-per-lane loads only; other widths get the factor scripts/micro/fetch_calib measured on this GPU
+(--calibrate), per kernel by the width of its dominant read stream (READ_WIDTH).
+
+usage: pmc_summary.py <fetch_dir> <write_dir> <out.json> [calibration.json]
+       pmc_summary.py --calibrate <fetch_calib pmc dir> <calibration.json>"""
 import collections
 import csv
 import glob
@@ -16,7 +20,14 @@ import sys
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
-    return re.sub(r'[<(].*', '', name)
+    base = re.sub(r'[<(].*', '', name)
+    # the convolution kernels reading spike planes (last template argument true) are kept apart: other load width, other byte count
+    if base.startswith('conv') and re.search(r'true>', name.split('(')[0]):
+        base += '[planes]'
+    return base
+
+
+FULL = {}
 
 
 def load(d, counter):
@@ -27,22 +38,74 @@ def load(d, counter):
                 if row.get('Counter_Name') != counter:
                     continue
                 a = acc[short(row['Kernel_Name'])]
+                FULL.setdefault(short(row['Kernel_Name']), row['Kernel_Name'])
                 a[0] += 1
                 a[1] += float(row['Counter_Value'])
     return acc
 
 
+# Read width of the stream that dominates each kernel's HBM reads -> which calibration factor applies to its FETCH_SIZE.
+# 16: 16 bytes per lane (float4 / 8 x bf16); 8: float2; 4: one dword per lane; rows: 8 dword rows per thread (plane-writing BN+LIF).
+READ_WIDTH = [
+    (r'bn_lif_fwd_sp_kernel', 'rows'),
+    (r'bn_lif|bn_silu|bn_stats|lif_fwd|lif_bwd|spp_pool|upcat|focus|planes_', '16'),
+    (r'arsnn|smallconv', '16'),
+    (r'conv1x1_mfma.*<.*true>|conv_fwd_mfma.*true>|conv_wgrad_mfma.*true>|conv1x1_wgrad.*true>', '16'),     # spike planes: 16-byte loads
+    (r'conv1x1_mfma|conv1x1_wgrad', '4'),                                                                   # fp32 NCHW: one dword per channel row
+    (r'conv_fwd_mfma|conv_wgrad_mfma|conv_dgrad_s2', '16'),
+    (r'event_|histogram', '4'),
+]
+
+
+def width_of(full_name):
+    for rx, cls in READ_WIDTH:
+        if re.search(rx, full_name):
+            return cls
+    return '16'
+
+
+def calibrate(d, out_json):
+    """fetch_calib's kernels read 1 GiB each: factor = known bytes / (FETCH_SIZE KiB x 1024) per load width"""
+    known = float(1 << 30)
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        with open(f, newline='') as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') != 'FETCH_SIZE':
+                    continue
+                n = row['Kernel_Name']
+                cls = 'rows' if 'stream_read_rows' in n else ('16' if 'float4' in n or 'HIP_vector_type<float, 4' in n else
+                                                              '8' if 'float2' in n or 'HIP_vector_type<float, 2' in n else '4')
+                acc[cls].append(float(row['Counter_Value']))
+    out = {}
+    for cls, vals in sorted(acc.items()):
+        kib = sum(vals) / len(vals)
+        out[cls] = {'launches': len(vals), 'fetch_size_kib': kib, 'known_bytes': known, 'factor': round(known / (kib * 1024.0), 4)}
+        print(f'load width {cls:>4s}: FETCH_SIZE {kib * 1024 / 1e6:9.1f} MB for {known / 1e6:.1f} MB read -> factor {out[cls]["factor"]:.3f}')
+    with open(out_json, 'w') as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+
 def main():
+    if sys.argv[1] == '--calibrate':
+        return calibrate(sys.argv[2], sys.argv[3])
     fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+    cal = {}
+    if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+        cal = {k: v['factor'] for k, v in json.load(open(sys.argv[4])).items()}
     out = {}
     for k in sorted(set(fetch) | set(write)):
         nf, f = fetch.get(k, [0, 0.0])
         nw, w = write.get(k, [0, 0.0])
-        fetch_b = 2.0 * 1024.0 * f / max(nf, 1)
+        cls = width_of(FULL.get(k, k))
+        factor = cal.get(cls, 2.0)
+        fetch_b = factor * 1024.0 * f / max(nf, 1)
         write_b = 1024.0 * w / max(nw, 1)
         out[k] = {'launches': max(nf, nw), 'fetch_bytes_per_launch': round(fetch_b), 'write_bytes_per_launch': round(write_b),
-                  'hbm_bytes_per_launch': round(fetch_b + write_b),
-                  'note': 'FETCH_SIZE KiB x2 (gfx950 wide-read correction) + WRITE_SIZE KiB'}
+                  'hbm_bytes_per_launch': round(fetch_b + write_b), 'read_width_class': cls, 'fetch_factor': factor,
+                  'note': ('FETCH_SIZE KiB x %.3f (%s) + WRITE_SIZE KiB' %
+                           (factor, 'measured for this load width by scripts/micro/fetch_calib' if cls in cal else
+                            'gfx950 wide-read correction of MI355X_MICROARCH.md; this width not calibrated in this run'))}
     with open(sys.argv[3], 'w') as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     for k, v in out.items():
