@@ -28,6 +28,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int TP = 80;       // output pixels per tile (5 MFMA k-steps of 16)
 constexpr int KST = TP / 16;
+#ifndef EAS_WG_COMMIT_KS
+#define EAS_WG_COMMIT_KS (KST - 2)
+#endif
+constexpr int COMMIT_KS = EAS_WG_COMMIT_KS;      // k-step after which the next tile's registers are converted and written to LDS
 constexpr int ROWB = 64;     // bytes per staged pixel row of one 32-channel plane
 constexpr int A_PLANE = TP * ROWB;
 
@@ -170,7 +174,10 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
         int id = it * NT + tid;
         id = id < nitems ? id : nitems - 1;
         if (id < nA) {
-            const int gi = id / unitsA, u = id - gi * unitsA;
+            // channel group fastest: the lanes of one ds_write_b128 then spread over the four 16-byte pieces of a staged pixel row and
+            // over both channel planes (with the pixel unit fastest every lane of a wave wrote the SAME four banks -- rows 4 apart are
+            // 256 bytes apart; 5-8 % of the kernel time on the SYOLOX-M layers)
+            const int u = id / (4 * PM), gi = id - u * (4 * PM);
             const int p0 = u * VEC;
             const int rl = p0 / g.Wo, c = p0 - rl * g.Wo;
             it_kind[it] = p0 < npix ? 0 : 2;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             it_lofs[it] = (gi >> 2) * A_PLANE + p0 * ROWB + (gi & 3) * 16;
         } else {
             const int idb = id - nA;
-            const int gi = idb / unitsB, u = idb - gi * unitsB;
+            const int u = idb / nbg, gi = idb - u * nbg;
             const int seg = u / units_seg, rem = u - seg * units_seg;
             const int rl = rem / units_row, cu = rem - rl * units_row;
             it_kind[it] = 1;
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
                     acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[kw], 0, 0, 0);
                 }
             }
-            if (ks == KST - 2 && more) {
+            if (ks == COMMIT_KS && more) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
                     if (it * NT < nitems) commit(nxt, it);
@@ -426,26 +433,46 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
     return EAS_OK;
 }
 
+// blocks of this kernel instance a CU holds at once with `lds` bytes of dynamic LDS (registers, waves and LDS all count), cached
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
+int resident_wgrad(size_t lds) {
+    static size_t seen[16];
+    static int val[16], n = 0;
+    for (int i = 0; i < n; ++i)
+        if (seen[i] == lds) return val[i];
+    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 192 * PM * PN, lds) != hipSuccess || nb < 1) nb = 1;
+    if (n < 16) { seen[n] = lds; val[n] = nb; ++n; }
+    return nb;
+}
+
 struct WgPlan { int pm, pn, kslices; };
 
 // block shape and number of pixel slices for a layer (shared by the workspace query and the launch)
 // pn = 2 (a block owns 64 input channels: grad_y is staged by half as many blocks) for spike inputs with >= 64 channels whenever the two
 // x planes fit LDS next to the grad_y tile (always at stride 1; at stride 2 on the small maps, where the layers with many channels
 // are bound by re-staging the same pixels from L2 in every (co, ci) block)
-WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts, int pn) {
+WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts, int pn, int resident = 0) {
     WgPlan p;
     p.pm = Cout >= 64 ? 2 : 1;
     p.pn = pn;
     const int yz = ((Cout + 32 * p.pm - 1) / (32 * p.pm)) * ((Cin + 32 * p.pn - 1) / (32 * p.pn));
-    const int per_cu = 4 / (p.pm * p.pn);                   // resident blocks per CU (12 waves of <= 168 registers)
-    int ks = (256 * per_cu + yz - 1) / yz;
-    if (ks > ntiles) ks = ntiles;
-    if (ks < 1) ks = 1;
-    if (parts > 1) {                       // a block keeps its column part: slices in whole multiples of the parts
-        ks = (ks / parts) * parts;
-        if (ks < parts) ks = parts;
+    // Pixel slices: every block walks ntiles / ks tiles and the launch takes ceil(ks * yz / slots) rounds of the chip's block slots
+    // (slots = 256 CUs x the blocks of THIS kernel instance a CU really holds: registers, waves and LDS -- 108 KB of double-buffered LDS
+    // leave one, where the old rule of thumb "4 / (pm pn)" assumed two and sized the grid for 512 slots: 2.25 rounds).  The slice count
+    // with the fewest tile periods wins; ties go to fewer slabs.  resident = 0: geometry search only (pm / pn are all it reads).
+    const int slots = 256 * (resident > 0 ? resident : 1);
+    const int step = parts > 1 ? parts : 1;
+    int best = step;
+    long best_cost = -1;
+    for (int ks = step; ks <= ntiles && (long)ks * yz <= 4L * slots; ks += step) {
+        const long rounds = ((long)ks * yz + slots - 1) / slots;
+        const long cost = rounds * ((ntiles + ks - 1) / ks);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ks; }
     }
-    p.kslices = ks;
+    p.kslices = best;
     return p;
 }
 
@@ -497,6 +524,31 @@ bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, i
     return false;
 }
 
+// the plan of a layer whose geometry is fixed: block shape, then the residency of the kernel instance the launch will use, then slices
+WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms, bool planes) {
+    const WgPlan p0 = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn);
+    const size_t lds = (size_t)2 * (3 * p0.pm * A_PLANE + (size_t)x_terms * p0.pn * g.Q * ROWB);
+    const bool v4 = g.parts > 1 || (g.Wi % 4 == 0 && g.Wo % 4 == 0);
+    int res = 1;
+#define EAS_RS(S_, XT_, PM_, PN_, PL_) (v4 ? resident_wgrad<S_, XT_, PM_, PN_, 4, PL_>(lds) : resident_wgrad<S_, XT_, PM_, PN_, 2, PL_>(lds))
+#define EAS_RS_SHAPE(S_, XT_, PL_)                                              \
+    do {                                                                        \
+        if (p0.pm == 2 && p0.pn == 2) res = EAS_RS(S_, XT_, 2, 2, PL_);         \
+        else if (p0.pm == 2) res = EAS_RS(S_, XT_, 2, 1, PL_);                  \
+        else if (p0.pn == 2) res = EAS_RS(S_, XT_, 1, 2, PL_);                  \
+        else res = EAS_RS(S_, XT_, 1, 1, PL_);                                  \
+    } while (0)
+    if (planes && stride == 1) EAS_RS_SHAPE(1, 1, true);
+    else if (planes) EAS_RS_SHAPE(2, 1, true);
+    else if (stride == 1 && x_terms == 1) EAS_RS_SHAPE(1, 1, false);
+    else if (stride == 1) EAS_RS_SHAPE(1, 3, false);
+    else if (x_terms == 1) EAS_RS_SHAPE(2, 1, false);
+    else EAS_RS_SHAPE(2, 3, false);
+#undef EAS_RS_SHAPE
+#undef EAS_RS
+    return wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn, res);
+}
+
 }  // namespace
 
 int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW);
@@ -506,12 +558,13 @@ int eas_conv1x1_wgrad_dispatch(const void* x, const float* gy, float* slabs, int
 extern "C" {
 
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
-    if (x_terms == 2) x_terms = 1;          // spike planes: the geometry of one-term inputs
+    const bool planes = x_terms == 2;
+    if (planes) x_terms = 1;                // spike planes: the geometry of one-term inputs
     if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi) * Cout * Cin : 0;
     if (ksize != 3) return 0;
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
-    return (int64_t)wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn).kslices * Cout * Cin * 9;
+    return (int64_t)wg_plan_final(g, Cin, Cout, stride, x_terms, planes).kslices * Cout * Cin * 9;
 }
 
 // number of column parts per row eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, 2..8 = column parts
@@ -546,7 +599,7 @@ static int wgrad_partial(const float* x, const float* grad_y, float* workspace, 
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;
     if (g.Wo % 2 != 0 || (g.Ho * g.pitchY) % 4 != 0) return EAS_ERR_UNSUPPORTED;
-    const WgPlan p = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn);
+    const WgPlan p = wg_plan_final(g, Cin, Cout, stride, x_terms, planes);
     g.kslices = p.kslices;
     const int slabs = p.kslices;
     hipStream_t st = eas_s(stream);
