@@ -95,13 +95,26 @@ def _cpu_model():
     return platform.processor() or platform.machine()
 
 
+def _usable_cpus():
+    """CPUs this process can keep busy: the smaller of its affinity mask and its cgroup (v2) CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(w, cpu_batch, n_events):
     """The oracle (a port: torch-CPU restatement validated against the reference) on a bounded sample of the same workload: same
     model / configuration, batch ``cpu_batch``, numpy input reduction (event binning / stacked-histogram sum) + fwd + bwd + Adam +
-    reset per iteration.  The thread count is the best of a 16 / 32 / 64 / 128 sweep on this host
-    (profiles/r03_cpu_baseline_threads.txt); EAS_CPU_THREADS overrides it."""
+    reset per iteration.  Threads = the CPUs this process may really use (affinity mask and cgroup quota): on the GPU box 256 logical CPUs
+    are visible but the cgroup grants 16, and a 2..128 sweep peaks exactly there (13.9 frames/s at 16 threads, 8.5 at 32, 1.7 at 128:
+    profiles/r03_cpu_baseline_threads.txt, scripts/cpu_baseline_sweep.py); EAS_CPU_THREADS overrides it."""
     from oracle import events_ref, model_ref, sj_ref
-    threads = int(os.environ.get('EAS_CPU_THREADS', min(os.cpu_count() or 1, 32)))
+    threads = int(os.environ.get('EAS_CPU_THREADS', _usable_cpus()))
     torch.set_num_threads(threads)
     torch.manual_seed(80)
     model = model_ref.build_model(**w['oracle'])
