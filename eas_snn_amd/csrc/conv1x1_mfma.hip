@@ -754,8 +754,27 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __re
 
 struct W1Plan { int wvm, wvn, nt, ks, slices; };
 
-// block shape: all four waves busy whatever Cout is
-W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW) {
+// blocks of a kernel instance a CU holds at once (registers, waves and its dynamic LDS), cached per instance
+template <int XT, int WVM, int WVN, int NT, int KS, bool XPL>
+int resident_w1() {
+    static int nb = 0;
+    if (nb > 0) return nb;
+    auto kern = conv1x1_wgrad_lds_kernel<XT, WVM, WVN, NT, KS, XPL>;
+    constexpr int PITCH = 16 * KS * 2 + 16;
+    constexpr int B_TERM = XPL ? WVN * NT * 16 * KS * 64 : 32 * WVN * NT * PITCH;
+    const size_t lds = (size_t)2 * (3 * 32 * WVM * PITCH + XT * B_TERM);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256, lds) != hipSuccess || n < 1) n = 2;
+    nb = n;
+    return nb;
+}
+
+// block shape: all four waves busy whatever Cout is.  Pixel slices: every block walks per_slice chunks and the launch takes
+// ceil(slices * yz / slots) rounds of the chip's block slots (256 CUs x the blocks of the kernel instance a CU really holds); the slice
+// count with the fewest chunk periods wins, ties go to fewer slabs (the old rule aimed at 512 blocks whatever the instance: 540 blocks on
+// 512 slots are two rounds)
+W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW, int x_terms, bool planes) {
     W1Plan p;
     if (Cout > 64) { p.wvm = 4; p.wvn = 1; p.nt = 4; }
     else if (Cout > 32) { p.wvm = 2; p.wvn = 2; p.nt = 2; }
@@ -766,10 +785,28 @@ W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW) {
     g.ci_blocks = (Cin + RB - 1) / RB;
     const int yz = ((Cout + RA - 1) / RA) * g.ci_blocks;
     const int total_chunks = NI * (HW / (16 * p.ks));
-    static const int target = getenv("EAS_W1_BLOCKS") ? atoi(getenv("EAS_W1_BLOCKS")) : 512;
-    int slices = (target + yz - 1) / yz;
-    if (slices > total_chunks) slices = total_chunks;
-    g.per_slice = (total_chunks + slices - 1) / slices;
+    int res = 2;
+#define EAS_W1R(XT_, M_, N_, T_, PL_) (p.ks == 2 ? resident_w1<XT_, M_, N_, T_, 2, PL_>() : resident_w1<XT_, M_, N_, T_, 1, PL_>())
+#define EAS_W1R_SHAPE(XT_, PL_) (p.wvm == 4 ? EAS_W1R(XT_, 4, 1, 4, PL_) : (p.wvm == 2 ? EAS_W1R(XT_, 2, 2, 2, PL_) : EAS_W1R(XT_, 1, 4, 1, PL_)))
+    if (planes) res = EAS_W1R_SHAPE(1, true);
+    else res = x_terms == 1 ? EAS_W1R_SHAPE(1, false) : EAS_W1R_SHAPE(3, false);
+#undef EAS_W1R_SHAPE
+#undef EAS_W1R
+    static const int force = getenv("EAS_W1_BLOCKS") ? atoi(getenv("EAS_W1_BLOCKS")) : 0;      // development: the old rule with this target
+    int best = 1;
+    if (force > 0) {
+        best = (force + yz - 1) / yz;
+        if (best > total_chunks) best = total_chunks;
+    } else {
+        const long slots = 256L * res;
+        long best_cost = -1;
+        for (int sl = 1; sl <= total_chunks && (long)sl * yz <= 2 * slots; ++sl) {
+            const long rounds = ((long)sl * yz + slots - 1) / slots;
+            const long cost = rounds * ((total_chunks + sl - 1) / sl);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sl; }
+        }
+    }
+    g.per_slice = (total_chunks + best - 1) / best;
     p.slices = (total_chunks + g.per_slice - 1) / g.per_slice;
     return p;
 }
@@ -792,10 +829,10 @@ int launch_w1_lds(const void* x, const float* gy, float* slabs, W1Geom g, int sl
 
 }  // namespace
 
-int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW) {
+int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW, int x_terms, int planes) {
     W1Geom g{};
     if (HW % 16 != 0) return 0;
-    return w1_plan(g, NI, Cin, Cout, HW).slices;
+    return w1_plan(g, NI, Cin, Cout, HW, x_terms, planes != 0).slices;
 }
 
 // slabs: eas_conv1x1_wgrad_slices(...) * Cout * Cin floats; the caller reduces them (conv_wgrad_reduce_kernel)
@@ -804,7 +841,7 @@ int eas_conv1x1_wgrad_dispatch(const void* x, const float* gy, float* slabs, int
                                int planes) {
     W1Geom g{};
     if (HW % 16 != 0 || (planes && Cin % 8 != 0)) return EAS_ERR_UNSUPPORTED;
-    const W1Plan p = w1_plan(g, NI, Cin, Cout, HW);
+    const W1Plan p = w1_plan(g, NI, Cin, Cout, HW, x_terms, planes != 0);
 #define EAS_W1(XT_, M_, N_, T_, PL_) (p.ks == 2 ? launch_w1_lds<XT_, M_, N_, T_, 2, PL_>(x, gy, slabs, g, p.slices, st) : launch_w1_lds<XT_, M_, N_, T_, 1, PL_>(x, gy, slabs, g, p.slices, st))
 #define EAS_W1_SHAPE(XT_, PL_) (p.wvm == 4 ? EAS_W1(XT_, 4, 1, 4, PL_) : (p.wvm == 2 ? EAS_W1(XT_, 2, 2, 2, PL_) : EAS_W1(XT_, 1, 4, 1, PL_)))
     if (planes) return EAS_W1_SHAPE(1, true);

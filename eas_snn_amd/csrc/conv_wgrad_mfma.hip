@@ -551,7 +551,7 @@ WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms
 
 }  // namespace
 
-int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW);
+int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW, int x_terms, int planes);
 int eas_conv1x1_wgrad_dispatch(const void* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st,
                                int planes);
 
@@ -560,7 +560,7 @@ extern "C" {
 int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms) {
     const bool planes = x_terms == 2;
     if (planes) x_terms = 1;                // spike planes: the geometry of one-term inputs
-    if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi) * Cout * Cin : 0;
+    if (ksize == 1) return stride == 1 ? (int64_t)eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi, x_terms, planes ? 1 : 0) * Cout * Cin : 0;
     if (ksize != 3) return 0;
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
@@ -587,7 +587,7 @@ static int wgrad_partial(const float* x, const float* grad_y, float* workspace, 
     if (ksize == 1) {
         if (stride != 1) return EAS_ERR_UNSUPPORTED;
         EAS_CLEAR_ERR();
-        const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi);
+        const int slices = eas_conv1x1_wgrad_slices(NI, Cin, Cout, Hi * Wi, x_terms, planes ? 1 : 0);
         if (slices <= 0) return EAS_ERR_UNSUPPORTED;
         const int rc1 = eas_conv1x1_wgrad_dispatch(x, grad_y, workspace, NI, Cin, Cout, Hi * Wi, x_terms, eas_s(stream), planes ? 1 : 0);
         if (rc1 != EAS_OK) return rc1;
