@@ -96,11 +96,15 @@ def bench_shapes():
         ('dark5.spp.conv2 1x1', 192, 1024, 512, 8, 10, 1, 1, True),
         ('dgrad dark2.m', 192, 32, 32, 64, 80, 3, 1, False), ('dgrad dark3.m', 192, 64, 64, 32, 40, 3, 1, False),
         ('dgrad dark4.m', 192, 128, 128, 16, 20, 3, 1, False), ('dgrad dark5.m', 192, 256, 256, 8, 10, 3, 1, False),
-        ('head 8x10 (ann)', 64, 128, 128, 8, 10, 3, 1, False), ('neck 8x10 (ann)', 64, 256, 256, 8, 10, 3, 1, False)]
+        ('head 8x10 (ann)', 64, 128, 128, 8, 10, 3, 1, False), ('neck 8x10 (ann)', 64, 256, 256, 8, 10, 3, 1, False),
+        ('dark2.0 s2 (real x)', 64, 32, 64, 128, 160, 3, 2, False), ('stem (real x)', 64, 8, 32, 128, 160, 3, 1, False)]
 
 
 def time_():
-    for (name, NI, Cin, Cout, H, W, k, s, sp) in bench_shapes():
+    only = [int(a) for a in os.environ['EAS_SHAPES'].split(',')] if os.environ.get('EAS_SHAPES') else None
+    for idx, (name, NI, Cin, Cout, H, W, k, s, sp) in enumerate(bench_shapes()):
+        if only is not None and idx not in only:
+            continue
         x, w = make(NI, Cin, Cout, H, W, k, sp)
         pk = ops.conv_pack_weights(w, 0)
         t_own = timeit(lambda: ops.conv_fwd_packed(x, pk, None, Cout, k, s, 1 if sp else 3))
