@@ -168,7 +168,19 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     const int xcol0 = g.parts > 1 ? ycol0 * S - g.hv : 0;       // input column of the first staged unit (may be < 0)
     const int nitems = nA + nB;
     const size_t planeY = (size_t)g.Ho * g.pitchY, planeX = (size_t)g.Hi * g.pitchX;
-    int it_kind[NIT], it_seg[NIT], it_row[NIT], it_col[NIT], it_ch[NIT], it_lofs[NIT];   // kind: 0 grad_y, 1 x, 2 padding (zeros)
+    // Addresses: a staged element sits at  tile base (scalar: image img0, row r0 of the tile)  +  a per-item constant, so the constant is
+    // worked out ONCE (it_off, bytes) and a tile costs an item a bounds test instead of the whole 64-bit address arithmetic (the per-tile
+    // address code was 340 vector-ALU instructions per wave and tile against 45 MFMAs: the kernel was bound by the vector ALU).  Loads are
+    // raw buffer loads: the descriptor's base is the tile base, the 8 channel rows of an fp32 item differ by a SCALAR offset, and an item
+    // that is out of the image (halo rows, images past NI, channels past the tensor, padding) uses an offset past num_records, for which
+    // the hardware returns zeros without touching memory (the range check covers voffset + soffset: scripts/micro/buffer_oob.hip).
+    // Spike-input instances only (BUF): with three-term x the pointer form below measured 5-13 % faster (those instances spend twice the
+    // time in MFMAs per tile and lost more to the changed instruction order than they gained).
+    constexpr bool BUF = XT == 1;
+    constexpr unsigned OOB = 0x80000000u;     // = num_records of the descriptors
+    int it_kind[NIT], it_seg[NIT], it_row[NIT], it_lofs[NIT];   // kind: 0 grad_y, 1 x, 2 padding (zeros)
+    unsigned it_off[BUF ? NIT : 1];
+    int it_col[BUF ? 1 : NIT], it_ch[BUF ? 1 : NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int id = it * NT + tid;
@@ -183,8 +195,14 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             it_kind[it] = p0 < npix ? 0 : 2;
             it_seg[it] = rl / g.rows_seg;
             it_row[it] = rl - it_seg[it] * g.rows_seg;
-            it_col[it] = c;
-            it_ch[it] = gi * 8;
+            const int ch = co0 + gi * 8;
+            if constexpr (BUF) {
+                it_off[it] = (p0 < npix && ch < g.Cout)
+                                 ? (unsigned)((((size_t)it_seg[it] * g.Cout + ch) * g.Ho + it_row[it]) * g.pitchY + ycol0 + c) * 4u : OOB;
+            } else {
+                it_col[it] = c;
+                it_ch[it] = gi * 8;
+            }
             it_lofs[it] = (gi >> 2) * A_PLANE + p0 * ROWB + (gi & 3) * 16;
         } else {
             const int idb = id - nA;
@@ -194,46 +212,81 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             it_kind[it] = 1;
             it_seg[it] = seg;
             it_row[it] = rl;
-            it_col[it] = cu * VEC;
-            it_ch[it] = gi * 8;
+            const int ch = ci0 + gi * 8, gc = xcol0 + cu * VEC;
+            if constexpr (BUF) {
+                const bool sok = ch < g.Cin && gc >= 0 && gc < g.pitchX;
+                // relative to input row r0 * S - 1 of image img0 (the tile base): planes in 16-byte pixels of a group, fp32 in floats
+                it_off[it] = !sok ? OOB
+                             : XPL ? (unsigned)((((size_t)seg * (g.Cin / 8) + (ch >> 3)) * g.Hi + rl) * g.pitchX + gc) * 16u
+                                   : (unsigned)((((size_t)seg * g.Cin + ch) * g.Hi + rl) * g.pitchX + gc) * 4u;
+            } else {
+                it_col[it] = cu * VEC;
+                it_ch[it] = gi * 8;
+            }
             it_lofs[it] = A_BYTES + (gi >> 2) * b_plane + ((seg * g.rows_in + rl) * g.RS + g.lpad + cu * VEC) * ROWB + (gi & 3) * 16;
         }
     }
 
     vecf L[NIT][8];
     u32x4 LP[NIT][XPL ? VEC : 1];
+    const unsigned planeYb = (unsigned)planeY * 4u, planeXb = (unsigned)planeX * 4u;
     auto fetch = [&](int it, int tile) {
         const int rho0 = (g.parts > 1 ? tile / g.parts : tile) * g.RT;
         const int img0 = rho0 / g.Ho, r0 = rho0 - img0 * g.Ho;
-        const int img = img0 + it_seg[it];
-        const float* src;
-        size_t plane;
-        bool ok;
-        if (it_kind[it] == 1) {
-            const int ir = r0 * S - 1 + it_row[it];
-            const int gc = xcol0 + it_col[it];
-            ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin && gc >= 0 && gc < g.pitchX;
-            const int ch = ci0 + it_ch[it] < g.Cin ? ci0 + it_ch[it] : g.Cin - 8;
-            if constexpr (XPL) {
-                // VEC consecutive pixels of one 8-channel group: VEC x 16 contiguous bytes
-                const u32x4* sp4 = ok ? reinterpret_cast<const u32x4*>(x) + (((size_t)img * (g.Cin / 8) + (ch >> 3)) * g.Hi + ir) * g.pitchX + gc
-                                      : reinterpret_cast<const u32x4*>(eas_wg_zero_page);
-#pragma unroll
-                for (int p = 0; p < VEC; ++p) LP[it][p] = sp4[ok ? p : 0];
-                return;
+        if constexpr (!BUF) {
+            // pointer form: addresses from scratch per tile, lanes outside the image read a zero page with channel stride 0
+            const int img = img0 + it_seg[it];
+            const float* src;
+            size_t plane;
+            bool ok;
+            if (it_kind[it] == 1) {
+                const int ir = r0 * S - 1 + it_row[it];
+                const int gc = xcol0 + it_col[it];
+                ok = ir >= 0 && ir < g.Hi && img < g.NI && ci0 + it_ch[it] < g.Cin && gc >= 0 && gc < g.pitchX;
+                const int ch = ci0 + it_ch[it] < g.Cin ? ci0 + it_ch[it] : g.Cin - 8;
+                src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.pitchX + (ok ? gc : 0);
+                plane = planeX;
+            } else {
+                ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout;
+                const int ch = co0 + it_ch[it] < g.Cout ? co0 + it_ch[it] : g.Cout - 8;
+                src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.pitchY + (ok ? ycol0 + it_col[it] : 0);
+                plane = planeY;
             }
-            src = x + (((size_t)(ok ? img : 0) * g.Cin + ch) * g.Hi + (ok ? ir : 0)) * g.pitchX + (ok ? gc : 0);
-            plane = planeX;
-        } else {
-            ok = it_kind[it] == 0 && img < g.NI && co0 + it_ch[it] < g.Cout;
-            const int ch = co0 + it_ch[it] < g.Cout ? co0 + it_ch[it] : g.Cout - 8;
-            src = gy + (((size_t)(ok ? img : 0) * g.Cout + ch) * g.Ho + (ok ? r0 + it_row[it] : 0)) * g.pitchY + (ok ? ycol0 + it_col[it] : 0);
-            plane = planeY;
-        }
-        const float* sp = ok ? src : eas_wg_zero_page;
-        const size_t cs = ok ? plane : 0;
+            const float* sp = ok ? src : eas_wg_zero_page;
+            const size_t cs = ok ? plane : 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(sp + j * cs);
+            for (int j = 0; j < 8; ++j) L[it][j] = *(const vecf*)(sp + j * cs);
+        } else {
+        const bool img_ok = img0 + it_seg[it] < g.NI;
+        if (it_kind[it] == 1) {
+            const int r0s = r0 * S - 1;
+            const bool ok = img_ok && (unsigned)(r0s + it_row[it]) < (unsigned)g.Hi;
+            const unsigned voff = ok ? it_off[it] : OOB;
+            if constexpr (XPL) {
+                const char* base = reinterpret_cast<const char*>(x) + (((long)img0 * (g.Cin / 8)) * g.Hi + r0s) * (long)g.pitchX * 16;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) LP[it][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * p, 0, 0);
+            } else {
+                const char* base = reinterpret_cast<const char*>(x) + (((long)img0 * g.Cin) * g.Hi + r0s) * (long)g.pitchX * 4;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (VEC == 4) L[it][j] = __builtin_bit_cast(vecf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * planeXb, 0));
+                    else L[it][j] = __builtin_bit_cast(vecf, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, j * planeXb, 0));
+                }
+            }
+        } else {
+            const unsigned voff = img_ok ? it_off[it] : OOB;
+            const char* base = reinterpret_cast<const char*>(gy) + (((long)img0 * g.Cout) * g.Ho + r0) * (long)g.pitchY * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (VEC == 4) L[it][j] = __builtin_bit_cast(vecf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, j * planeYb, 0));
+                else L[it][j] = __builtin_bit_cast(vecf, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, j * planeYb, 0));
+            }
+        }
+        }
     };
     auto commit = [&](unsigned char* buf, int it) {
         if (XPL && it_kind[it] == 1) {
@@ -466,11 +519,17 @@ WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts
     const int slots = 256 * (resident > 0 ? resident : 1);
     const int step = parts > 1 ? parts : 1;
     int best = step;
-    long best_cost = -1;
+    static const double pen = getenv("EAS_WG_SHARE_PEN") ? atof(getenv("EAS_WG_SHARE_PEN")) : 0.0;      // development
+    const int res1 = resident > 0 ? resident : 1;
+    double best_cost = -1.0;
     for (int ks = step; ks <= ntiles && (long)ks * yz <= 4L * slots; ks += step) {
-        const long rounds = ((long)ks * yz + slots - 1) / slots;
-        const long cost = rounds * ((ntiles + ks - 1) / ks);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ks; }
+        const long blocks = (long)ks * yz;
+        const long rounds = (blocks + slots - 1) / slots;
+        // blocks that share a CU share its matrix cores: a tile period stretches by `pen` per co-resident block
+        long share = (blocks + 255) / 256;
+        if (share > res1) share = res1;
+        const double cost = (double)rounds * (double)((ntiles + ks - 1) / ks) * (1.0 + pen * (double)(share - 1));
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
     }
     p.kslices = best;
     return p;
