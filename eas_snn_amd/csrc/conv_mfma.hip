@@ -60,6 +60,8 @@ struct ConvGeom {
     // ceil(2^40 / d) for the divisors of the per-thread geometry set-up: n / d == (n * m) >> 40 for n, d < 2^20
     unsigned long long m_Wo, m_rows_seg, m_Ho, m_units, m_units_seg, m_units_row, m_hrow, m_rows;
     int dbg;       // development ablation switches (EAS_CONV_DBG): 2 no staging after chunk 0, 4 weights from one address, 16 no barrier
+    int single;    // one LDS buffer for the staged patch (the next channel chunk is written after a barrier): chosen by dispatch_tile where
+                   // the double-buffered patch leaves one block per CU and the single-buffered one two
     // BatchNorm statistics in the epilogue (eas_conv_fwd_stats): not NULL = every block also writes the sum and the sum of squares of
     // its output tile per channel to stats[(co * stats_nb + pixel block) * 2 + {0, 1}] (doubles); stats_nb = gridDim.x * parts
     double* stats;
@@ -244,7 +246,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         const int rows = g.nseg * g.rows_in;
         const int hcols = g.RS - g.Wst;
         const int per_row = hcols * (PIXB / 16);
-        const int nbuf_k = g.KSTEPS * 16 <= CCH ? 1 : 2;    // a single channel chunk uses (and owns) one buffer only
+        const int nbuf_k = (g.KSTEPS * 16 <= CCH || g.single) ? 1 : 2;    // a single channel chunk uses (and owns) one buffer only
         for (int i = tid; i < rows * per_row * XT * nbuf_k; i += NT) {
             const int row = fdiv(i, g.m_hrow), k = i - row * per_row;
             const int bt = fdiv(row, g.m_rows), rw = row - bt * rows;   // bt = buffer*XT + term
@@ -373,8 +375,9 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     int st = 0;
     bf16x8 bq[NSETS][WN];
     for (int c = 0; c < nchunks; ++c) {
-        const unsigned char* cur = smem + (c & 1) * buf_bytes;
-        unsigned char* nxt = smem + ((c + 1) & 1) * buf_bytes;
+        const bool single = g.single != 0;
+        const unsigned char* cur = smem + (single ? 0 : (c & 1)) * buf_bytes;
+        unsigned char* nxt = smem + (single ? 0 : ((c + 1) & 1)) * buf_bytes;
         const bool more = c + 1 < nchunks && !(g.dbg & 2);
         const int c1 = (c + 1) * CCH;
 #pragma unroll
@@ -436,13 +439,14 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
                         for (int j = 0; j < WN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
             }
-            if (SPREAD && more) {
+            if (SPREAD && more && !single) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
                     if (s == NSTEPS - NIT + it && it * NT < nitems) commit(nxt, it, c1);
             }
         }
-        if (!SPREAD && more) {
+        if (single && more) __syncthreads();
+        if ((!SPREAD || single) && more) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (it * NT < nitems) commit(nxt, it, c1);
@@ -571,7 +575,7 @@ int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
 template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
 int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
     auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL>;
-    const int nbuf = g.KSTEPS * 16 <= CCH ? 1 : 2;      // one channel chunk: the second (prefetch) buffer is never used
+    const int nbuf = (g.KSTEPS * 16 <= CCH || g.single) ? 1 : 2;      // one channel chunk: the second (prefetch) buffer is never used
     size_t lds = (size_t)nbuf * g.Q * CCH * 2 * XT;
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
     if (g.stats && lds < (size_t)WVM * WVN * (EAS_STATS_SCRATCH * sizeof(float) + WM * 64 * sizeof(double)))
@@ -631,12 +635,21 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
     ConvGeom best_g = g;
     static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
     static const int ncand = getenv("EAS_CONV_NCAND") ? atoi(getenv("EAS_CONV_NCAND")) : 14;  // development: 7 = the 160-pixel wave tiles only
-    const int nbuf = g.KSTEPS * 16 <= CCH ? 1 : 2;
-    for (int i = 0; i < ncand; ++i) {
+    const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
+    // Single-buffered patch (mode 1): for layers of few channel chunks whose double-buffered patch fills the LDS (real-valued inputs on wide
+    // rows: dark2.0, 135 -> 103 us) -- the second buffer buys one overlapped stage there, a second resident block overlaps everything.
+    // With more chunks the exposed write of every chunk costs more than it gains (4 chunks: 100 -> 122 us, 8: 125 -> 154 us).
+    static const int single_nch = getenv("EAS_CONV_SINGLE_NCH") ? atoi(getenv("EAS_CONV_SINGLE_NCH")) : 2;      // development: 0 = never
+    static const double single_pen = getenv("EAS_CONV_SINGLE_PEN") ? atof(getenv("EAS_CONV_SINGLE_PEN")) : 1.1;
+    for (int i = 0; i < ncand; ++i)
+      for (int mode = 0; mode < 2; ++mode) {
         const Cand& c = cands[i];
         if (force >= 0 && i != force) continue;
+        if (mode == 1 && (XT != 3 || nchunks < 2 || nchunks > single_nch)) continue;      // spike-input layers: 76 -> 84 us (the patch is a third)
+        const int nbuf = (nchunks == 1 || mode == 1) ? 1 : 2;
         if ((c.wvm * c.wm - 1) * 32 >= g.Cout && !(c.wvm == 1 && c.wm == 1)) continue;   // every wave row (and M-tile) has channels to compute
         ConvGeom t = g;
+        t.single = mode;
         bool fits = false;
         for (int cap = c.bn; cap >= g.Wo && !fits; cap -= 32) {   // shrink the pixel tile until patch + staging slots fit
             t.RT = pick_rows(g.Ho, g.Wo, cap);
@@ -653,7 +666,12 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         // resident blocks per CU: one 8-wave block, or two 4-wave blocks when their LDS fits twice (independent barriers
         // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
         const size_t lds_bytes = (size_t)nbuf * t.Q * CCH * 2 * XT;
-        const int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
+        int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
+        if (mode == 1) {
+            // worth it only where it buys the second resident block (launch bounds keep the registers of two blocks per CU available)
+            if (2 * lds_bytes > 160 * 1024 || 2 * (2 * lds_bytes) <= 160 * 1024) continue;
+            bpc = 2;
+        }
         // (two co-resident 4-wave blocks cost 1.2 rounds of one -- but only when there are more blocks than CUs: a grid of <= 256 blocks
         // puts one block on a CU whatever its LDS size)
         // a step's MFMAs (3 * WN with one-term inputs, 6 * WN with three) hide the ~450-cycle latency of the next step's weight
@@ -662,7 +680,8 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         static const double lat = getenv("EAS_CONV_STEP_LAT") ? atof(getenv("EAS_CONV_STEP_LAT")) : 450.0;   // development
         const double per_tile = XT == 1 ? 96.0 : 192.0;
         const double mfma_part = (c.wn * per_tile > lat ? c.wn * per_tile : lat) / (5.0 * per_tile);
-        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part);
+        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part) *
+                                  (mode == 1 ? single_pen * (c.threads == 512 && blocks > 256 ? 1.2 : 1.0) : 1.0);
         const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
         // ties: the larger valid pixel count; among grids of lone blocks (<= 256) first the shape with more waves along the channels
         // (they share one staged pixel patch: the smaller patch per block is the shorter prologue; 8x10 head layers: 35-38 us against
