@@ -52,6 +52,7 @@ struct WgGeom {
     // zeroed halo: lpad = 0, qshift = hv - 1.  One part: Wst = Wi, lpad = 1, qshift = 0.
     int parts, Wst, lpad, qshift, hv;
     int pn;                  // ci tiles per block chosen by wg_geom (1 or 2)
+    int single;              // one LDS buffer (the next tile is written after a barrier): where that lets a CU hold two blocks instead of one
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     // zero the halo columns of the x image in both buffers (never written again; column parts stage their halo like any unit)
     if (g.parts == 1) {
         const int rows = g.nseg * g.rows_in;
-        for (int i = tid; i < rows * 2 * 4 * PN * XT * 2; i += NT) {   // 2 sides x 4 16-byte pieces x planes x terms x buffers
+        for (int i = tid; i < rows * 2 * 4 * PN * XT * (g.single ? 1 : 2); i += NT) {   // 2 sides x 4 16-byte pieces x planes x terms x buffers
             int rest = i;
             const int piece = rest & 3; rest >>= 2;
             const int side = rest & 1; rest >>= 1;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
 
     if (PN == 1 && g.Cin - ci0 < 32) {
         const int ng = (g.Cin - ci0 + 7) / 8;                  // groups [ng, 4) of every staged pixel row stay zero
-        for (int i = tid; i < g.Q * (4 - ng) * XT * 2; i += NT) {
+        for (int i = tid; i < g.Q * (4 - ng) * XT * (g.single ? 1 : 2); i += NT) {
             int rest = i;
             const int grp = ng + rest % (4 - ng); rest /= (4 - ng);
             const int q = rest % g.Q; rest /= g.Q;
@@ -322,10 +323,11 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     }
     __syncthreads();
 
+    const bool single = g.single != 0;
     int par = 0;
-    for (; tile < g.ntiles; tile += g.kslices, par ^= 1) {
+    for (; tile < g.ntiles; tile += g.kslices, par ^= (single ? 0 : 1)) {
         const unsigned char* cur = smem + par * buf_bytes;
-        unsigned char* nxt = smem + (par ^ 1) * buf_bytes;
+        unsigned char* nxt = smem + (single ? 0 : (par ^ 1)) * buf_bytes;
         const bool more = tile + g.kslices < g.ntiles;
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
@@ -360,11 +362,17 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
                     acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[kw], 0, 0, 0);
                 }
             }
-            if (ks == COMMIT_KS && more) {
+            if (ks == COMMIT_KS && more && !single) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
                     if (it * NT < nitems) commit(nxt, it);
             }
+        }
+        if (single && more) {
+            __syncthreads();              // every wave has read its fragments of this tile: the buffer may be overwritten
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (it * NT < nitems) commit(nxt, it);
         }
         __syncthreads();
     }
@@ -467,7 +475,7 @@ template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
 int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStream_t st) {
     auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL>;
     constexpr int NT = 192 * PM * PN;
-    const size_t lds = (size_t)2 * (3 * PM * A_PLANE + (size_t)XT * PN * g.Q * ROWB);
+    const size_t lds = (size_t)(g.single ? 1 : 2) * (3 * PM * A_PLANE + (size_t)XT * PN * g.Q * ROWB);
     const int nbg = PN == 1 && g.Cin < 32 ? (g.Cin + 7) / 8 : 4 * PN;
     const int nitems = (TP / VEC) * 4 * PM + g.nseg * g.rows_in * (g.Wst / VEC) * nbg;
     if (lds > 160 * 1024 || nitems > (PM * PN == 4 ? 1 : 2) * NT) {
@@ -584,7 +592,7 @@ bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, i
 }
 
 // the plan of a layer whose geometry is fixed: block shape, then the residency of the kernel instance the launch will use, then slices
-WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms, bool planes) {
+WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms, bool planes, int& single) {
     const WgPlan p0 = wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn);
     const size_t lds = (size_t)2 * (3 * p0.pm * A_PLANE + (size_t)x_terms * p0.pn * g.Q * ROWB);
     const bool v4 = g.parts > 1 || (g.Wi % 4 == 0 && g.Wo % 4 == 0);
@@ -605,6 +613,37 @@ WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms
     else EAS_RS_SHAPE(2, 3, false);
 #undef EAS_RS_SHAPE
 #undef EAS_RS
+    // single-buffered LDS where the double-buffered tile leaves ONE block per CU and half of it two: the second block overlaps everything
+    // the first one waits for, which a second buffer inside one 6- or 12-wave block cannot (a tile's write is exposed instead: +15 %)
+    static const int single_env = getenv("EAS_WG_SINGLE") ? atoi(getenv("EAS_WG_SINGLE")) : -1;      // development: 0 never, 1 whenever it fits twice
+    single = 0;
+    static const int single_cap = getenv("EAS_WG_SINGLE_CAP") ? atoi(getenv("EAS_WG_SINGLE_CAP")) : 2;       // development
+    // (measured: 3-wave blocks -- layers of fewer than 64 output channels on the big maps -- gain 20-30 %: real-input 48 -> 48 channels at
+    // 64x80 699 -> 496 us; 6- and 12-wave blocks lose 5-8 %: they already keep the SIMDs' issue slots busy and the exposed write costs more)
+    if (single_env != 0 && res == 1 && (p0.pm * p0.pn == 1 || single_env == 1)) {
+        const size_t lds1 = lds / 2;
+        int res1 = 1;
+#define EAS_RS(S_, XT_, PM_, PN_, PL_) (v4 ? resident_wgrad<S_, XT_, PM_, PN_, 4, PL_>(lds1) : resident_wgrad<S_, XT_, PM_, PN_, 2, PL_>(lds1))
+#define EAS_RS_SHAPE(S_, XT_, PL_)                                              \
+    do {                                                                        \
+        if (p0.pm == 2 && p0.pn == 2) res1 = EAS_RS(S_, XT_, 2, 2, PL_);        \
+        else if (p0.pm == 2) res1 = EAS_RS(S_, XT_, 2, 1, PL_);                 \
+        else if (p0.pn == 2) res1 = EAS_RS(S_, XT_, 1, 2, PL_);                 \
+        else res1 = EAS_RS(S_, XT_, 1, 1, PL_);                                 \
+    } while (0)
+        if (planes && stride == 1) EAS_RS_SHAPE(1, 1, true);
+        else if (planes) EAS_RS_SHAPE(2, 1, true);
+        else if (stride == 1 && x_terms == 1) EAS_RS_SHAPE(1, 1, false);
+        else if (stride == 1) EAS_RS_SHAPE(1, 3, false);
+        else if (x_terms == 1) EAS_RS_SHAPE(2, 1, false);
+        else EAS_RS_SHAPE(2, 3, false);
+#undef EAS_RS_SHAPE
+#undef EAS_RS
+        if (res1 >= 2) {
+            single = 1;
+            res = res1 > single_cap ? single_cap : res1;
+        }
+    }
     return wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn, res);
 }
 
@@ -623,7 +662,8 @@ int64_t eas_conv_wgrad_workspace_floats(int NI, int Cin, int Cout, int Hi, int W
     if (ksize != 3) return 0;
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return 0;
-    return (int64_t)wg_plan_final(g, Cin, Cout, stride, x_terms, planes).kslices * Cout * Cin * 9;
+    int single = 0;
+    return (int64_t)wg_plan_final(g, Cin, Cout, stride, x_terms, planes, single).kslices * Cout * Cin * 9;
 }
 
 // number of column parts per row eas_conv_wgrad uses for a 3x3 layer: 1 = whole rows fit one reduction tile, 2..8 = column parts
@@ -658,8 +698,10 @@ static int wgrad_partial(const float* x, const float* grad_y, float* workspace, 
     WgGeom g{};
     if (!wg_geom(g, NI, Cin, Cout, Hi, Wi, stride, x_terms)) return EAS_ERR_UNSUPPORTED;
     if (g.Wo % 2 != 0 || (g.Ho * g.pitchY) % 4 != 0) return EAS_ERR_UNSUPPORTED;
-    const WgPlan p = wg_plan_final(g, Cin, Cout, stride, x_terms, planes);
+    int single = 0;
+    const WgPlan p = wg_plan_final(g, Cin, Cout, stride, x_terms, planes, single);
     g.kslices = p.kslices;
+    g.single = single;
     const int slabs = p.kslices;
     hipStream_t st = eas_s(stream);
     const int n = Cout * Cin * 9;
