@@ -638,8 +638,9 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
     const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
     // Single-buffered patch (mode 1): for layers of few channel chunks whose double-buffered patch fills the LDS (real-valued inputs on wide
     // rows: dark2.0, 135 -> 103 us) -- the second buffer buys one overlapped stage there, a second resident block overlaps everything.
-    // With more chunks the exposed write of every chunk costs more than it gains (4 chunks: 100 -> 122 us, 8: 125 -> 154 us).
-    static const int single_nch = getenv("EAS_CONV_SINGLE_NCH") ? atoi(getenv("EAS_CONV_SINGLE_NCH")) : 2;      // development: 0 = never
+    // With more chunks the exposed write of every chunk costs more than it gains (4 chunks: 100 -> 122 us, 8: 125 -> 154 us); three
+    // chunks (the 48-channel layers of SYOLOX-M) still gain: config 4 88.0 -> 87.5 ms.
+    static const int single_nch = getenv("EAS_CONV_SINGLE_NCH") ? atoi(getenv("EAS_CONV_SINGLE_NCH")) : 3;      // development: 0 = never
     static const double single_pen = getenv("EAS_CONV_SINGLE_PEN") ? atof(getenv("EAS_CONV_SINGLE_PEN")) : 1.1;
     for (int i = 0; i < ncand; ++i)
       for (int mode = 0; mode < 2; ++mode) {
