@@ -229,7 +229,11 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     }
 
     vecf L[NIT][8];
-    u32x4 LP[NIT][XPL ? VEC : 1];
+    // 12-wave instances (one item per thread, 168 registers): a spike-plane item, VEC x 16 bytes, lives in the first registers of the same
+    // array as raw bits -- an item is one or the other, and a separate array cost 16 registers they do not have (spills in the tile
+    // loop).  With two items per thread the compiler keeps the shared array in scratch instead, so those keep two arrays.
+    constexpr bool UNI = NIT == 1;
+    u32x4 LP[UNI ? 1 : NIT][(XPL && !UNI) ? VEC : 1];
     const unsigned planeYb = (unsigned)planeY * 4u, planeXb = (unsigned)planeX * 4u;
     auto fetch = [&](int it, int tile) {
         const int rho0 = (g.parts > 1 ? tile / g.parts : tile) * g.RT;
@@ -267,7 +271,18 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
                 const char* base = reinterpret_cast<const char*>(x) + (((long)img0 * (g.Cin / 8)) * g.Hi + r0s) * (long)g.pitchX * 16;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
 #pragma unroll
-                for (int p = 0; p < VEC; ++p) LP[it][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * p, 0, 0);
+                for (int p = 0; p < VEC; ++p) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * p, 0, 0);
+                    if constexpr (!UNI) {
+                        LP[it][p] = v;
+                    } else if constexpr (VEC == 4) {
+                        L[it][p] = __builtin_bit_cast(vecf, v);
+                    } else {
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        L[it][2 * p] = __builtin_bit_cast(vecf, (u32x2)__builtin_shufflevector(v, v, 0, 1));
+                        L[it][2 * p + 1] = __builtin_bit_cast(vecf, (u32x2)__builtin_shufflevector(v, v, 2, 3));
+                    }
+                }
             } else {
                 const char* base = reinterpret_cast<const char*>(x) + (((long)img0 * g.Cin) * g.Hi + r0s) * (long)g.pitchX * 4;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, OOB, 0x00020000);
@@ -292,7 +307,16 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     auto commit = [&](unsigned char* buf, int it) {
         if (XPL && it_kind[it] == 1) {
 #pragma unroll
-            for (int p = 0; p < VEC; ++p) *(u32x4*)(buf + it_lofs[it] + p * ROWB) = LP[it][p];
+            for (int p = 0; p < VEC; ++p) {
+                if constexpr (!UNI) {
+                    *(u32x4*)(buf + it_lofs[it] + p * ROWB) = LP[it][p];
+                } else if constexpr (VEC == 4) {
+                    *(vecf*)(buf + it_lofs[it] + p * ROWB) = L[it][p];
+                } else {
+                    *(vecf*)(buf + it_lofs[it] + p * ROWB) = L[it][2 * p];
+                    *(vecf*)(buf + it_lofs[it] + p * ROWB + 8) = L[it][2 * p + 1];
+                }
+            }
             return;
         }
 #pragma unroll
