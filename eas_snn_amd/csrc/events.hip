@@ -324,6 +324,127 @@ __global__ __launch_bounds__(kBandThreads) void event_hist_banded_kernel(const u
     }
 }
 
+// The same band form with 16-bit counters, two per LDS word: a band is twice as many rows (2 bands instead of 4 for the 240-row sensor:
+// every event is read by half as many blocks and the grid is two rounds of blocks instead of four), and the events come in aligned
+// groups of four (one 8-byte load each for x and y, one 4-byte load for p, instead of twelve 1- and 2-byte loads).  A counter cannot
+// overflow while the slice holds < 65536 events; a block whose slice holds more (known only on the device) counts its band in two halves
+// with 32-bit counters, one after the other -- the same LDS, the events read twice by that block only.  Bit-exact like the other forms.
+__global__ __launch_bounds__(kBandThreads) void event_hist_banded16_kernel(const uint32_t* __restrict__ t, const uint16_t* __restrict__ x,
+                                                                           const uint16_t* __restrict__ y, const uint8_t* __restrict__ p,
+                                                                           const int64_t* __restrict__ offsets, int64_t nev, int B, int Tm, int H,
+                                                                           int W, int rows, int nbands, int32_t* __restrict__ out,
+                                                                           uint32_t* __restrict__ oob, float* __restrict__ canvas, int Hc, int Wc) {
+    extern __shared__ int cnt[];            // packed: [2][rows][W] 16-bit counters; wide (fallback): [2][rows / 2 (rounded up)][W] 32-bit
+    __shared__ int64_t range[2];
+    const int L = blockIdx.x, tid = threadIdx.x;
+    const int sl = (L & 7) + 8 * (L / (8 * nbands)), band = (L >> 3) % nbands;      // XCD-aware order, see event_hist_banded_kernel
+    if (sl >= B * Tm) return;
+    const int b = sl / Tm, k = sl - b * Tm;
+    const int y0 = band * rows, y1 = y0 + rows < H ? y0 + rows : H;
+    if (tid == 0) {
+        const int64_t a = offsets[b], e = offsets[b + 1];
+        int64_t lo = 0, hi = 0;
+        if (e > a) {
+            const uint32_t t0 = t[a];
+            const uint32_t win = (t[e - 1] - t0) / (uint32_t)Tm;
+            if (win != 0) {
+                lo = lower_bound_t(t, a, e, t0 + (uint32_t)k * win);
+                hi = lower_bound_t(t, lo, e, t0 + (uint32_t)(k + 1) * win);
+            }
+        }
+        range[0] = lo;
+        range[1] = hi;
+    }
+    __syncthreads();
+    const int64_t lo = range[0], hi = range[1];
+    const bool packed = hi - lo < 65536;
+    const int hrows = (rows + 1) / 2;                         // rows per pass of the wide fallback
+    const int npass = packed ? 1 : 2;
+    unsigned bad = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int ya = packed ? y0 : y0 + pass * hrows;
+        const int yb = packed ? y1 : (ya + hrows < y1 ? ya + hrows : y1);
+        const int prow = packed ? rows : hrows;               // rows per polarity plane in this pass
+        const int plane = prow * W;
+        const int words = packed ? (2 * plane + 1) / 2 : 2 * plane;
+        __syncthreads();                                      // pass 1: pass 0's counters have been written out
+        for (int i = tid; i < words; i += kBandThreads) cnt[i] = 0;
+        __syncthreads();
+        constexpr int UN = 4;                                 // aligned groups of four events in flight per thread
+        const int64_t g0 = lo & ~(int64_t)3;
+        for (int64_t i0 = g0 + 4 * (int64_t)tid; i0 < hi; i0 += (int64_t)UN * 4 * kBandThreads) {
+            uint2 xs[UN], ys[UN];
+            unsigned ps[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t i = i0 + (int64_t)u * 4 * kBandThreads;
+                if (i < hi && i + 3 < nev) {
+                    xs[u] = *reinterpret_cast<const uint2*>(x + i);
+                    ys[u] = *reinterpret_cast<const uint2*>(y + i);
+                    ps[u] = *reinterpret_cast<const unsigned*>(p + i);
+                } else {                                      // past the slice, or the last (ragged) group of the whole stream
+                    unsigned xv[4] = {0, 0, 0, 0}, yv[4] = {0, 0, 0, 0}, pv = 0;
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j < hi) { xv[j] = x[i + j]; yv[j] = y[i + j]; pv |= (unsigned)p[i + j] << (8 * j); }
+                    xs[u] = make_uint2(xv[0] | (xv[1] << 16), xv[2] | (xv[3] << 16));
+                    ys[u] = make_uint2(yv[0] | (yv[1] << 16), yv[2] | (yv[3] << 16));
+                    ps[u] = pv;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t i = i0 + (int64_t)u * 4 * kBandThreads;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t e = i + j;
+                    if (e < lo || e >= hi) continue;
+                    const unsigned xv = ((j < 2 ? xs[u].x : xs[u].y) >> (16 * (j & 1))) & 0xffffu;
+                    const unsigned yv = ((j < 2 ? ys[u].x : ys[u].y) >> (16 * (j & 1))) & 0xffffu;
+                    const unsigned pv = (ps[u] >> (8 * j)) & 0xffu;
+                    if (xv >= (unsigned)W || yv >= (unsigned)H) {
+                        if (pass == 0) ++bad;
+                        continue;
+                    }
+                    if (yv < (unsigned)ya || yv >= (unsigned)yb) continue;
+                    const int idx = (pv != 0 ? plane : 0) + (int)(yv - ya) * W + (int)xv;
+                    if (packed) atomicAdd(&cnt[idx >> 1], (idx & 1) ? 65536 : 1);
+                    else atomicAdd(&cnt[idx], 1);
+                }
+            }
+        }
+        __syncthreads();
+        auto count_at = [&](int c, int r, int col) -> int {
+            const int idx = c * plane + r * W + col;
+            return packed ? (int)(((unsigned)cnt[idx >> 1] >> (16 * (idx & 1))) & 0xffffu) : cnt[idx];
+        };
+        if (canvas) {
+            // this pass's rows with their right padding; the last pass of the last band also writes the bottom padding rows
+            const bool last = band == nbands - 1 && pass == npass - 1;
+            const int yend = last ? Hc : yb;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float* dst = canvas + ((((int64_t)b * Tm + k) * 2 + c) * Hc + ya) * Wc;
+                const int total = (yend - ya) * Wc;
+                for (int i = tid; i < total; i += kBandThreads) {
+                    const int r = i / Wc, col = i - r * Wc;
+                    dst[i] = (r < yb - ya && col < W) ? (float)count_at(c, r, col) : 0.0f;
+                }
+            }
+        } else {
+            const int n = (yb - ya) * W;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                int32_t* dst = out + ((((int64_t)b * Tm + k) * 2 + c) * H + ya) * W;
+                for (int i = tid; i < n; i += kBandThreads) {
+                    const int r = i / W, col = i - r * W;
+                    dst[i] = count_at(c, r, col);
+                }
+            }
+        }
+    }
+    if (band == 0 && oob && bad) atomicAdd(oob, bad);
+}
+
 __global__ __launch_bounds__(EAS_BLOCK) void counts_to_canvas_kernel(const int32_t* __restrict__ counts, int64_t F, int H,
                                                                      int W, int Hc, int Wc, float* __restrict__ out) {
     const int64_t total = F * Hc * Wc;
@@ -503,6 +624,30 @@ static int histogram_impl(const uint32_t* t, const uint16_t* x, const uint16_t* 
     const int nbands = rows > 0 ? (H + rows - 1) / rows : kMaxBands + 1;
     const char* force = getenv("EAS_HIST_FORM");      // development switch: "scatter" / "banded"
     const bool dense = nev >= (int64_t)B * Tm * 2048;
+    // 16-bit counters + vector loads when the event arrays allow 8- / 4-byte loads (EAS_HIST_FORM=banded32: the 32-bit form)
+    const bool al16 = ((((uintptr_t)x | (uintptr_t)y) & 7) | ((uintptr_t)p & 3)) == 0 && !(force && force[0] == 'b' && force[6] == '3');
+    int rows16 = kBandLdsBytes / (4 * W);
+    if (rows16 > H) rows16 = H;
+    const int nbands16 = rows16 > 0 ? (H + rows16 - 1) / rows16 : kMaxBands + 1;
+    if (al16 && nbands16 <= kMaxBands && (int64_t)B * Tm < (1 << 24) && (force ? force[0] == 'b' : dense)) {
+        const int r16 = (H + nbands16 - 1) / nbands16;
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute((const void*)event_hist_banded16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBandLdsBytes) != hipSuccess)
+                return EAS_ERR_LAUNCH;
+            attr16 = true;
+        }
+        const int nb = (H + r16 - 1) / r16;
+        const int64_t groups = ((int64_t)B * Tm + 7) / 8;
+        // LDS: packed [2][r16][W] halves, or the fallback's [2][ceil(r16 / 2)][W] words -- the larger of the two
+        const size_t lds16 = (size_t)4 * (((size_t)2 * r16 * W + 1) / 2 > (size_t)2 * ((r16 + 1) / 2) * W ? ((size_t)2 * r16 * W + 1) / 2
+                                                                                                        : (size_t)2 * ((r16 + 1) / 2) * W);
+        hipLaunchKernelGGL(event_hist_banded16_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), lds16, st, t, x, y, p,
+                           sample_offsets, nev, B, Tm, H, W, r16, nb, out, oob_count, canvas, Hc, Wc);
+        EAS_CHECK_LAUNCH();
+        if (canvas && wrote_canvas) *wrote_canvas = 1;
+        return EAS_OK;
+    }
     if (nbands <= kMaxBands && (int64_t)B * Tm < (1 << 24) && (force ? force[0] == 'b' : dense)) {
         rows = (H + nbands - 1) / nbands;              // even bands
         static bool attr_set = false;

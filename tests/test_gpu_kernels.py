@@ -72,7 +72,7 @@ def test_event_histogram_batched_ragged_vs_oracle(dev):
     assert np.array_equal(canvas[..., :H, :W], ref.astype(np.float32)) and canvas[..., H:, :].sum() == 0 and canvas[..., :, W:].sum() == 0
 
 
-@pytest.mark.parametrize('form', ['scatter', 'banded'])
+@pytest.mark.parametrize('form', ['scatter', 'banded', 'banded32'])
 def test_event_histogram_both_forms_golden_and_ragged(dev, form, monkeypatch):
     """The global-atomic scatter form and the LDS-privatised banded form of eas_event_histogram (chosen by event density;
     EAS_HIST_FORM forces one) on every golden case, on a ragged batch with empty samples and out-of-range events, and on a
@@ -119,7 +119,7 @@ def test_event_histogram_both_forms_golden_and_ragged(dev, form, monkeypatch):
     assert np.array_equal(vga[0].cpu().numpy(), events_ref.micro_sum(tv, xv, yv, pv, 3, 480, 640).astype(np.int32))
 
 
-@pytest.mark.parametrize('form', ['scatter', 'banded'])
+@pytest.mark.parametrize('form', ['scatter', 'banded', 'banded32'])
 def test_event_frames_equals_histogram_plus_canvas(dev, form, monkeypatch):
     """eas_event_frames (events -> padded fp32 frames in one call; dense streams never write the int32 counts) equals
     eas_event_histogram followed by eas_counts_to_canvas, in both forms, incl. a sample without events."""
@@ -141,7 +141,7 @@ def test_event_frames_equals_histogram_plus_canvas(dev, form, monkeypatch):
     assert np.array_equal(frames[..., :H, :W].cpu().numpy(), want.astype(np.float32)) and float(frames[1].abs().sum()) == 0
 
 
-@pytest.mark.parametrize('form', ['scatter', 'banded'])
+@pytest.mark.parametrize('form', ['scatter', 'banded', 'banded32'])
 @pytest.mark.parametrize('H,W,Tm,B', [(101, 300, 3, 3), (61, 1000, 2, 5), (7, 5, 5, 2)])
 def test_event_histogram_odd_geometries(dev, form, H, W, Tm, B, monkeypatch):
     """band heights that do not divide the sensor height, widths that are not multiples of 4, B*Tm not a multiple of 8"""
@@ -173,6 +173,36 @@ def test_postprocess_score_ties_keep_anchor_order(dev):
     got = ops.postprocess(_t(pred, dev), 2, 0.1, 0.5)
     want = postprocess_ref.postprocess(pred, 2, 0.1, 0.5)
     assert np.array_equal(got[0].cpu().numpy(), want[0]) and len(want[0]) == 2
+
+
+def test_event_histogram_16_bit_counters_and_their_overflow_path(dev, monkeypatch):
+    """The banded form with two 16-bit counters per LDS word (the default for dense streams): a slice of < 65536 events counts in one
+    pass; a slice with more (here 150 000 and 210 000 events per slice, one pixel hit 70 000 times) takes the two-pass 32-bit path
+    inside the same launch; unaligned event arrays take the 32-bit kernel.  All bit-exact against the oracle, counts and canvas."""
+    from eas_snn_amd import ops
+    from oracle import events_ref
+    monkeypatch.setenv('EAS_HIST_FORM', 'banded')
+    H, W, Tm = 240, 304, 2
+    sizes = [300_000, 40_000, 420_001]
+    parts = [list(events_ref.synth_events(n, H, W, seed=90 + i)) for i, n in enumerate(sizes)]
+    parts[2][1][100_000:170_000] = 17        # 70 000 events of one slice on pixel (y, x) = (200, 17): more than a 16-bit counter holds
+    parts[2][2][100_000:170_000] = 200
+    parts[2][3][100_000:170_000] = 1
+    t, x, y, p = (np.concatenate([q[j] for q in parts]) for j in range(4))
+    off = np.cumsum([0] + sizes).astype(np.int64)
+    ref = events_ref.micro_sum_batch(t, x, y, p, off, Tm, H, W)
+    assert ref.max() >= 70_000
+    args = (_t(t.view(np.int32), dev).view(torch.uint32), _t(x.view(np.int16), dev).view(torch.uint16),
+            _t(y.view(np.int16), dev).view(torch.uint16), _t(p, dev), _t(off, dev), Tm, H, W)
+    out, oob = ops.event_histogram(*args, return_oob=True)
+    assert int(oob) == 0 and np.array_equal(out.cpu().numpy(), ref)
+    fr = ops.event_frames(*args, 256, 320).cpu().numpy()
+    assert np.array_equal(fr[..., :H, :W], ref.astype(np.float32)) and fr[..., H:, :].sum() == 0 and fr[..., :, W:].sum() == 0
+    # event arrays that start at an odd element (views into a larger buffer): no 8-byte loads possible -> the 32-bit band kernel
+    shifted = lambda a, view, dt: (_t(np.concatenate([a[:1], a]).view(view), dev).view(dt) if dt is not None
+                                   else _t(np.concatenate([a[:1], a]), dev))[1:]
+    out_u = ops.event_histogram(args[0], shifted(x, np.int16, torch.uint16), shifted(y, np.int16, torch.uint16), shifted(p, None, None), *args[4:])
+    assert np.array_equal(out_u.cpu().numpy(), ref)
 
 
 def test_event_histogram_full_size_properties(dev):
