@@ -55,6 +55,7 @@ PROTOTYPES = {
     'eas_det_loss': (C.c_int, [C.c_int] + [_P] * 8 + [C.c_int, C.c_int] + [_P] * 3 + [C.c_int] + [_P] * 4 + [C.c_int, _P, _P, _P]),
     'eas_upcat_fwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 5 + [_P]),
     'eas_upcat_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 5 + [_P]),
+    'eas_upcat_planes_fwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 5 + [_P]),
     'eas_focus': (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'eas_event_voxel_grid': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'eas_event_window_search': (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P]),

@@ -33,5 +33,7 @@ class CSPDarknet(nn.Module):
             feats[name] = x                # (spikes, firing_rate) when the stage's last conv emits its rate
             if isinstance(x, tuple):
                 x = x[0]
-        # what leaves the backbone is a real tensor (a stage may have handed its spikes on as planes, see ops.dense)
-        return {k: (v if isinstance(v, tuple) else ops.dense(v)) for k, v in feats.items() if k in self.out_features}
+        # what leaves the backbone is a real tensor (a stage may have handed its spikes on as planes, see ops.dense) -- unless the module
+        # that owns this backbone reads planes itself and says so (YOLOPAFPN: its neck is convolutions and ops.upsample_cat)
+        keep = getattr(self, 'planes_to_owner', False)
+        return {k: (v if (isinstance(v, tuple) or keep) else ops.dense(v)) for k, v in feats.items() if k in self.out_features}

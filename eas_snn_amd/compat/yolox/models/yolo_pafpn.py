@@ -20,6 +20,7 @@ class YOLOPAFPN(nn.Module):
                  depthwise=False, in_dim=3, act='silu'):
         super().__init__()
         self.backbone = CSPDarknet(depth, width, depthwise=depthwise, in_dim=in_dim, act=act)
+        self.backbone.planes_to_owner = True      # converted (full_spike) model: the neck below takes the stages' spikes as planes
         self.in_features = in_features
         self.in_channels = in_channels
         self._build_neck(depth, width, in_channels, depthwise, act)

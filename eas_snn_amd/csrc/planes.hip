@@ -58,6 +58,23 @@ __global__ __launch_bounds__(EAS_BLOCK) void planes_to_f32_kernel(const bf16x8* 
     }
 }
 
+// cat[nearest-upsample(a, x up), b] along the channels, planes in / planes out: every output pixel of every 8-channel group is one 16-byte
+// copy (groups [0, Ca/8) from a at (h / up, w / up), the rest from b)
+__global__ __launch_bounds__(EAS_BLOCK) void upcat_planes_kernel(const bf16x8* __restrict__ a, const bf16x8* __restrict__ b, bf16x8* __restrict__ out,
+                                                                 int64_t M, int Ga, int Gb, int H, int W, int up) {
+    const int Ho = H * up, Wo = W * up, G = Ga + Gb;
+    const int64_t total = M * G * (int64_t)Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int h = (int)(r % Ho);
+        r /= Ho;
+        const int g = (int)(r % G);
+        const int64_t n = r / G;
+        out[i] = g < Ga ? a[((n * Ga + g) * H + h / up) * (int64_t)W + w / up] : b[((n * Gb + (g - Ga)) * Ho + h) * (int64_t)Wo + w];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -83,6 +100,21 @@ int eas_spike_planes_to_f32(const void* planes, int src_ctot, float* x, int dst_
     EAS_CLEAR_ERR();
     hipLaunchKernelGGL(planes_to_f32_kernel, dim3(eas_grid_1d(NI * (C / 8) * (HW / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), (const bf16x8*)planes, x, NI, C,
                        HW, (src_ctot ? src_ctot : C) / 8, dst_ctot ? dst_ctot : C);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// a [M][Ca/8][H*W][8], b [M][Cb/8][(H*up)*(W*up)][8] -> out [M][(Ca+Cb)/8][(H*up)*(W*up)][8]: eas_upcat_fwd on spike planes (the neck of the
+// converted YOLOPAFPN: torch.cat([self.upsample(f), x], 1), yolox/models/yolo_pafpn.py:101-121; up = 1: plain concatenation).  The backward is
+// eas_upcat_bwd on the fp32 gradient.
+int eas_upcat_planes_fwd(const void* a, const void* b, void* out, int64_t M, int Ca, int Cb, int H, int W, int up, eas_stream_t stream) {
+    if (!a || !b || !out || M < 1 || Ca < 1 || Cb < 1 || H < 1 || W < 1 || up < 1) return EAS_ERR_INVALID_ARG;
+    if (Ca % 8 != 0 || Cb % 8 != 0) return EAS_ERR_UNSUPPORTED;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    const int64_t total = M * ((Ca + Cb) / 8) * (int64_t)H * up * W * up;
+    hipLaunchKernelGGL(upcat_planes_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), (const bf16x8*)a, (const bf16x8*)b,
+                       (bf16x8*)out, M, Ca / 8, Cb / 8, H, W, up);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

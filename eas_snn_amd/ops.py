@@ -2167,6 +2167,36 @@ class _UpcatFn(torch.autograd.Function):
         return ga, gb, None
 
 
+class _UpcatPlanesFn(torch.autograd.Function):
+    """upsample + concatenate on spike planes: ghosts in, a ghost out (eas_upcat_planes_fwd); the gradient is fp32 (eas_upcat_bwd)"""
+
+    @staticmethod
+    def forward(ctx, a, b, a_sp, b_sp, up):
+        ctx.set_materialize_grads(False)
+        lead, (Ca, H, W) = tuple(a.shape[:-3]), a.shape[-3:]
+        Cb = b.shape[-3]
+        M = 1
+        for d in lead:
+            M *= d
+        Ho, Wo = H * up, W * up
+        sp = torch.empty(lead + ((Ca + Cb) // 8, Ho * Wo, 8), dtype=torch.bfloat16, device=a_sp.device)
+        _call('eas_upcat', 2 * 2 * sp.numel(), _lib.lib().eas_upcat_planes_fwd, ptr(a_sp), ptr(b_sp), ptr(sp), M, Ca, Cb, H, W, up, stream())
+        ctx.cfg = (tuple(a.shape), tuple(b.shape), M, Ca, Cb, H, W, up)
+        ctx.mark_non_differentiable(sp)
+        return ghost(lead + (Ca + Cb, Ho, Wo), a_sp.device), sp
+
+    @staticmethod
+    def backward(ctx, g, _g_sp):
+        if g is None:
+            return None, None, None, None, None
+        ashape, bshape, M, Ca, Cb, H, W, up = ctx.cfg
+        g = _f32c(g)
+        ga = torch.empty(ashape, dtype=torch.float32, device=g.device)
+        gb = torch.empty(bshape, dtype=torch.float32, device=g.device)
+        check(_lib.lib().eas_upcat_bwd(ptr(g), ptr(ga), ptr(gb), M, Ca, Cb, H, W, up, stream()), 'eas_upcat_bwd')
+        return ga, gb, None, None, None
+
+
 def upcat_supported(a, b, up):
     if os.environ.get('EAS_NO_UPCAT'):         # development switch
         return False
@@ -2177,9 +2207,14 @@ def upcat_supported(a, b, up):
 
 def upsample_cat(a, b, up=2):
     """cat[nearest-upsample(a, x up), b] along channels in one kernel (one more for the backward); up = 1: plain concatenation"""
+    a_sp, b_sp = planes_of(a), planes_of(b)
+    if a_sp is not None and b_sp is not None and planes_enabled():
+        out, sp = _UpcatPlanesFn.apply(a, b, a_sp.contiguous(), b_sp.contiguous(), int(up))
+        out._eas_sp = sp
+        return mark_small_int(out)
     a, b = dense(a), dense(b)
     out = _UpcatFn.apply(a, b, int(up))
-    if up == 1 and is_small_int(a) and is_small_int(b):
+    if is_small_int(a) and is_small_int(b):       # copies of spikes / small integers (nearest upsampling repeats values)
         mark_small_int(out)
     return out
 

@@ -508,6 +508,11 @@ int eas_det_loss(int L, const float* const* reg, const float* const* obj, const 
 int eas_upcat_fwd(const float* a, const float* b, float* out, int64_t M, int Ca, int Cb, int H, int W, int up, eas_stream_t stream);
 int eas_upcat_bwd(const float* grad_out, float* grad_a, float* grad_b, int64_t M, int Ca, int Cb, int H, int W, int up,
                   eas_stream_t stream);
+/* The same on spike planes (see "SPIKE PLANES"): a [M][Ca/8][H*W][8], b [M][Cb/8][(H*up)*(W*up)][8] -> out [M][(Ca+Cb)/8][(H*up)*(W*up)][8], bf16;
+ * Ca, Cb multiples of 8.  The neck of a converted YOLOPAFPN (yolox/models/yolo_pafpn.py:101-121) between two fused layers; backward =
+ * eas_upcat_bwd on the fp32 gradient. */
+int eas_upcat_planes_fwd(const void* a_planes, const void* b_planes, void* out_planes, int64_t M, int Ca, int Cb, int H, int W, int up,
+                         eas_stream_t stream);
 
 /* Focus, space to depth (yolox/models/network_blocks.py:198-213: four strided slices + torch.cat): x [M][C][2*Ho][2*Wo] ->
  * out [M][4*C][Ho][Wo], out[m][k*C+c][h][w] = x[m][c][2h+dy_k][2w+dx_k], (dy,dx) = (0,0),(1,0),(0,1),(1,1); inverse = 1 is the

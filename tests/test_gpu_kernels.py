@@ -1363,6 +1363,46 @@ def test_spike_planes_feed_the_convolutions_bit_identically(dev, T, N, Cin, Cout
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('lead,Ca,Cb,H,W,up', [((3, 2), 32, 16, 8, 10, 2), ((6,), 96, 96, 16, 20, 1), ((2, 1), 8, 200, 4, 6, 2)])
+def test_upsample_concat_on_spike_planes_equals_the_fp32_kernel(dev, lead, Ca, Cb, H, W, up):
+    """eas_upcat_planes_fwd (the converted PAFPN's upsample + concatenate between two fused layers) against eas_upcat_fwd on the same
+    spikes: identical values, identical gradients; mixed inputs (one ghost, one real tensor) take the fp32 kernel."""
+    from eas_snn_amd import ops
+    gen = torch.Generator().manual_seed(Ca + Cb)
+    a = (torch.rand(*lead, Ca, H, W, generator=gen) < 0.3).float().to(dev)
+    b = torch.randint(0, 3, (*lead, Cb, H * up, W * up), generator=gen).float().to(dev)
+    g = torch.randn(*lead, Ca + Cb, H * up, W * up, generator=gen).to(dev)
+    outs = []
+    for planes in (True, False):
+        if planes:
+            xa = ops.ghost(a.shape, dev).detach().requires_grad_(True); xa._eas_sp = ops.to_planes(a)
+            xb = ops.ghost(b.shape, dev).detach().requires_grad_(True); xb._eas_sp = ops.to_planes(b)
+        else:
+            xa, xb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ops.mark_small_int(xa); ops.mark_small_int(xb)
+        if planes:
+            ops._PLANES_SCOPE = True            # as inside a model's forward
+        try:
+            out = ops.upsample_cat(xa, xb, up)
+        finally:
+            ops._PLANES_SCOPE = False
+        assert (ops.planes_of(out) is not None) == planes and ops.is_small_int(out)
+        val = ops.dense(out)
+        val.backward(g)
+        outs.append((val.detach().clone(), xa.grad.clone(), xb.grad.clone()))
+    for x1, x2 in zip(*outs):
+        assert torch.equal(x1, x2)
+    up_a = a.repeat_interleave(up, -2).repeat_interleave(up, -1)
+    assert torch.equal(outs[0][0], torch.cat([up_a, b], -3))
+    ops._PLANES_SCOPE = True
+    try:
+        mixed = ops.upsample_cat(ops.ghost(a.shape, dev, ops.to_planes(a)), ops.mark_small_int(b.clone()), up)
+    finally:
+        ops._PLANES_SCOPE = False
+    assert ops.planes_of(mixed) is None and torch.equal(mixed, outs[0][0])
+
+
+@pytest.mark.gpu
 def test_spike_planes_kernels_are_the_ones_that_run(dev):
     """the planes entry points are reached for the model's layer shapes (no silent unpacking in front of the convolutions)"""
     import torch.nn as nn
