@@ -12,7 +12,8 @@ def _cat2(a, b):
     """torch.cat([a, b], channel axis) with a one-kernel backward (two contiguous gradients instead of two slice copies)"""
     if ops.upcat_supported(a, b, 1):
         return ops.upsample_cat(a, b, 1)
-    return torch.cat([ops.dense(a), ops.dense(b)], -3)
+    out = torch.cat([ops.dense(a), ops.dense(b)], -3)
+    return ops.mark_small_int(out) if ops.is_small_int(a) and ops.is_small_int(b) else out
 
 
 class YOLOPAFPN(nn.Module):
