@@ -23,6 +23,27 @@ def _pred(conv, x):
     return ops.conv2d(x, conv) if type(conv) is nn.Conv2d and x.is_cuda else conv(x)
 
 
+def _inner_conv(block):
+    """the nn.Conv2d of a BaseConv: plain, or the single module inside its SeqToANNContainer once converted; else None"""
+    c = block.conv
+    if isinstance(c, nn.Sequential) and len(c) == 1:
+        c = c[0]
+    return c if type(c) is nn.Conv2d else None
+
+
+def _fusable_pair(a, b, x):
+    """both converted blocks run the fused BN+LIF kernels on a [T,N,C,H,W] input (no rate output, no hooks, fixed-slope surrogate)"""
+    for blk in (a, b):
+        c = _inner_conv(blk)
+        if (c is None or c.stride != (1, 1) or c.groups != 1 or c._forward_hooks or c._forward_pre_hooks or blk.emit_rate
+                or blk._forward_hooks or blk._forward_pre_hooks or not blk.bn.affine or blk.bn.step_mode != 'm'
+                or (blk.bn.momentum is None and blk.bn.training) or getattr(blk.act.surrogate_function, 'hip_id', None) == 'patan'):
+            return False
+    if a.bn.num_features % 8 != 0 or b.bn.num_features % 8 != 0:
+        return False
+    return (x.shape[-1] * x.shape[-2]) % 4 == 0 and x.shape[0] <= 8 and not torch.nn.modules.module._global_forward_hooks
+
+
 def _prod2(t):
     """Product over a last axis of length 2 (box width x height).  ``torch.prod``'s backward inspects the input for zeros
     on the host, which stalls the stream and cannot be captured in a HIP graph; the explicit product has neither problem."""
@@ -77,9 +98,11 @@ class YOLOXHead(nn.Module):
         out = []
         for k in range(len(self.stems)):
             a, b = self.cls_convs[k][0], self.reg_convs[k][0]
-            if isinstance(a, BaseConv) and isinstance(b, BaseConv) and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d \
-                    and a.conv.bias is None and b.conv.bias is None:
-                out.append((f'tower{k}', a.conv, b.conv))
+            if not (isinstance(a, BaseConv) and isinstance(b, BaseConv)):
+                continue
+            ca, cb = _inner_conv(a), _inner_conv(b)          # plain, or inside the SeqToANNContainer of a converted block
+            if ca is not None and cb is not None and ca.bias is None and cb.bias is None:
+                out.append((f'tower{k}', ca, cb))
         return out
 
     def _towers(self, k, x):
@@ -101,6 +124,28 @@ class YOLOXHead(nn.Module):
             for m in list(self.reg_convs[k])[1:]:
                 ra = m(ra)
             return ca, ra
+        if (isinstance(a, BaseConv) and isinstance(b, BaseConv) and a.spiking() and b.spiking() and x.dim() == 5 and x.is_cuda
+                and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_SPIKING_TOWER_DUAL') and _fusable_pair(a, b, x)):
+            # converted head (full_spike_v2): the same for the two spiking towers -- one convolution, the two BN+LIF layers on the channel
+            # halves of its output (as the 1x1 branches of a CSPLayer)
+            from spikingjelly.activation_based import layer as sj_layer
+            ca_, cb_ = _inner_conv(a), _inner_conv(b)
+            x4 = ops.fold_time(x)
+            if ops.conv_dual_ok(x4, ca_, cb_):
+                T, N = x.shape[:2]
+                sink = ops.conv_sink()
+                if sink is not None:
+                    sink(ca_, x4, 1)
+                    sink(cb_, x4, 1)
+                with ops.conv_stats_scope(a.bn._use_batch_stats() and b.bn._use_batch_stats()):
+                    y12 = ops.conv2d_dual(x4, ca_, cb_, self, f'tower{k}')
+                y12 = y12.view(T, N, *y12.shape[1:])
+                ca, ra = sj_layer.fused_pair(a.bn, a.act, b.bn, b.act, y12, planes_a=a.wants_planes(), planes_b=b.wants_planes())
+                for m in list(self.cls_convs[k])[1:]:
+                    ca = m(ca)
+                for m in list(self.reg_convs[k])[1:]:
+                    ra = m(ra)
+                return ca, ra
         return self.cls_convs[k](x), self.reg_convs[k](x)
 
     def _level(self, k, x):

@@ -1010,7 +1010,7 @@ def test_ann_csp_concatenation_in_place_is_bit_identical(dev, monkeypatch, n, H,
         assert torch.equal(b0[k], b1[k]), k
 
 
-@pytest.mark.parametrize('which', ['csp', 'head'])
+@pytest.mark.parametrize('which', ['csp', 'head', 'spiking_head'])
 def test_real_valued_dual_convolution_matches_separate_convolutions(dev, monkeypatch, which):
     """Two real-valued convolutions that read the same input as ONE convolution (ops.conv2d_dual: weights packed from the two
     parameters; ops.bn_silu_pair on the channel halves): conv1 | conv2 of the PAFPN CSPLayer and the first cls / reg tower convolutions
@@ -1025,13 +1025,29 @@ def test_real_valued_dual_convolution_matches_separate_convolutions(dev, monkeyp
         base = CSPLayer(128, 128, n=1, shortcut=False)
         x = torch.randn(8, 128, 16, 20)
         run = lambda net, xd: net(xd)
-    else:
+    elif which == 'head':
         base = YOLOXHead(3, width=0.5)
         x = torch.randn(8, 128, 8, 10)
         run = lambda net, xd: torch.cat(net._towers(2, xd), 1)
+    else:
+        # the converted head of the full_spike_v2 models: the two spiking towers' first 3x3 convolutions as one (+ the BN+LIF pair)
+        from spikingjelly.activation_based import functional, surrogate
+        from yolox.models.yolo_head import SpikingYOLOXHead
+        base = SpikingYOLOXHead(3, width=0.5, spike_fn=surrogate.ATan(2.0), full_spike=True)
+        x = (torch.rand(3, 4, 128, 8, 10) < 0.3).float()
+        ops.mark_small_int(x)
+
+        def run(net, xd):
+            ops.mark_small_int(xd)
+            a, b = net._towers(2, xd)
+            functional.reset_net(net)
+            return torch.cat([ops.dense(a), ops.dense(b)], 2)
     for m in base.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eps, m.momentum = 1e-3, 0.03
+            if which == 'spiking_head':
+                with torch.no_grad():
+                    m.bias.fill_(0.6)          # neurons must fire for the comparison to mean something
     res = []
     for nodual in ('1', ''):
         if nodual:
@@ -1048,6 +1064,8 @@ def test_real_valued_dual_convolution_matches_separate_convolutions(dev, monkeyp
                     {k: b.clone() for k, b in net.named_buffers()}))
     (o0, g0, p0, b0), (o1, g1, p1, b1) = res
     assert torch.equal(o0, o1)
+    if which == 'spiking_head':
+        assert 0.02 < float(o0.mean()) < 0.9
     assert set(p0) == set(p1) and len(p0) > 0
     torch.testing.assert_close(g1, g0, rtol=1e-5, atol=2e-6 * float(g0.abs().max()))
     for k in p0:
