@@ -421,28 +421,71 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     }
 }
 
-// dW[i] = sum over slabs, fixed order: 64 outputs x 4 slice lanes per block, each lane sums every 4th slab in order, then
-// the four partial sums are added in lane order (deterministic)
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int n, int kslices) {
-    __shared__ double part[4][64];
+// dW[i] = sum over slabs in a fixed order (deterministic): slice lane kl = 0..3 adds slabs kl, kl + 4, kl + 8, ... in double, in that order,
+// then the four partial sums are added in lane order.  A block = 4 slice lanes x 64 threads, a thread = 4 consecutive outputs (one 16-byte
+// load per slab, eight slabs in flight: the first form read one float per thread and slab with four in flight and ran at 2 TB/s on the
+// ~1 GB of slabs a step reduces); n not a multiple of 4 or unaligned slabs: one output per thread.  Both forms add the same values in
+// the same order per output.
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slabs, float* __restrict__ gw, int n, int kslices, int block) {
+    __shared__ double part[4][64][4];
     const int o = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + o;
-    double s = 0.0;
+    const bool v4 = (n & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)gw) & 15) == 0;
+    const int per = v4 ? 4 : 1;
+    const int i = (block * 64 + o) * per;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (i < n) {
         int k = kl;
-        for (; k + 12 < kslices; k += 16) {
-            const float a = slabs[(size_t)k * n + i], b = slabs[(size_t)(k + 4) * n + i], c = slabs[(size_t)(k + 8) * n + i],
-                        d = slabs[(size_t)(k + 12) * n + i];
-            s += (double)a;
-            s += (double)b;
-            s += (double)c;
-            s += (double)d;
+        if (v4) {
+            for (; k + 28 < kslices; k += 32) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(slabs + (size_t)(k + 4 * u) * n + i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s[0] += (double)v[u].x; s[1] += (double)v[u].y; s[2] += (double)v[u].z; s[3] += (double)v[u].w;
+                }
+            }
+            for (; k < kslices; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)k * n + i);
+                s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+            }
+        } else {
+            for (; k + 12 < kslices; k += 16) {
+                const float a = slabs[(size_t)k * n + i], b = slabs[(size_t)(k + 4) * n + i], c = slabs[(size_t)(k + 8) * n + i],
+                            d = slabs[(size_t)(k + 12) * n + i];
+                s[0] += (double)a;
+                s[0] += (double)b;
+                s[0] += (double)c;
+                s[0] += (double)d;
+            }
+            for (; k < kslices; k += 4) s[0] += (double)slabs[(size_t)k * n + i];
         }
-        for (; k < kslices; k += 4) s += (double)slabs[(size_t)k * n + i];
     }
-    part[kl][o] = s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[kl][o][j] = s[j];
     __syncthreads();
-    if (kl == 0 && i < n) gw[i] = (float)(((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
+    if (kl == 0 && i < n) {
+        if (v4) {
+            float4 r;
+            r.x = (float)(((part[0][o][0] + part[1][o][0]) + part[2][o][0]) + part[3][o][0]);
+            r.y = (float)(((part[0][o][1] + part[1][o][1]) + part[2][o][1]) + part[3][o][1]);
+            r.z = (float)(((part[0][o][2] + part[1][o][2]) + part[2][o][2]) + part[3][o][2]);
+            r.w = (float)(((part[0][o][3] + part[1][o][3]) + part[2][o][3]) + part[3][o][3]);
+            *reinterpret_cast<float4*>(gw + i) = r;
+        } else {
+            gw[i] = (float)(((part[0][o][0] + part[1][o][0]) + part[2][o][0]) + part[3][o][0]);
+        }
+    }
+}
+
+// outputs a block covers (host side: blocks of a job)
+static inline int wgrad_reduce_blocks(const float* slabs, const float* gw, int n) {
+    const bool v4 = (n & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)gw) & 15) == 0;
+    return (n + (v4 ? 256 : 64) - 1) / (v4 ? 256 : 64);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int n, int kslices) {
+    wgrad_reduce_block(slabs, gw, n, kslices, (int)blockIdx.x);
 }
 
 // The same reduction for MANY weight gradients in one launch (eas_conv_wgrad_reduce_many): a training step has ~80 weight
@@ -460,32 +503,13 @@ struct ReduceJobs {
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_many_kernel(const ReduceJobs jobs) {
-    __shared__ double part[4][64];
     int lo = 0, hi = jobs.njobs;                 // job j owns blocks [first_block[j], first_block[j+1])
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (jobs.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
     }
-    const float* __restrict__ slabs = jobs.slabs[lo];
-    const int n = jobs.n[lo], kslices = jobs.kslices[lo];
-    const int o = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const int i = ((int)blockIdx.x - jobs.first_block[lo]) * 64 + o;
-    double s = 0.0;
-    if (i < n) {                                  // identical summation order to conv_wgrad_reduce_kernel: bit-identical results
-        int k = kl;
-        for (; k + 12 < kslices; k += 16) {
-            const float a = slabs[(size_t)k * n + i], b = slabs[(size_t)(k + 4) * n + i], c = slabs[(size_t)(k + 8) * n + i],
-                        d = slabs[(size_t)(k + 12) * n + i];
-            s += (double)a;
-            s += (double)b;
-            s += (double)c;
-            s += (double)d;
-        }
-        for (; k < kslices; k += 4) s += (double)slabs[(size_t)k * n + i];
-    }
-    part[kl][o] = s;
-    __syncthreads();
-    if (kl == 0 && i < n) jobs.gw[lo][i] = (float)(((part[0][o] + part[1][o]) + part[2][o]) + part[3][o]);
+    // identical summation order to conv_wgrad_reduce_kernel: bit-identical results
+    wgrad_reduce_block(jobs.slabs[lo], jobs.gw[lo], jobs.n[lo], jobs.kslices[lo], (int)blockIdx.x - jobs.first_block[lo]);
 }
 
 int pick_rows(int Ho, int Wo, int cap) {
@@ -759,7 +783,7 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
     const int slabs = wgrad_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, stream);
     if (slabs < 0) return slabs;
     const int n = Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, eas_s(stream), workspace, grad_w, n, slabs);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(workspace, grad_w, n)), dim3(256), 0, eas_s(stream), workspace, grad_w, n, slabs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -789,7 +813,7 @@ int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_str
             if (!q.slabs || !q.grad_w || q.n < 1 || q.slabs_count < 1) return EAS_ERR_INVALID_ARG;
             a.slabs[j] = q.slabs; a.gw[j] = q.grad_w; a.n[j] = q.n; a.kslices[j] = q.slabs_count;
             a.first_block[j] = blocks;
-            blocks += (q.n + 63) / 64;
+            blocks += wgrad_reduce_blocks(q.slabs, q.grad_w, q.n);
         }
         a.first_block[a.njobs] = blocks;
         hipLaunchKernelGGL(conv_wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, eas_s(stream), a);

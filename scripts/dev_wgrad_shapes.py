@@ -22,6 +22,7 @@ for lvl, (H, W) in enumerate([(64, 80), (32, 40), (16, 20), (8, 10)]):
     shapes += [(f'dark{lvl + 2}.0 s2', NI, c // 2, c, 2 * H, 2 * W, 3, 2, True), (f'dark{lvl + 2}.m 3x3', NI, c // 2, c // 2, H, W, 3, 1, True),
                (f'dark{lvl + 2}.c12 1x1', NI, c, c, H, W, 1, 1, True), (f'dark{lvl + 2}.c3 1x1', NI, c, c, H, W, 1, 1, True),
                (f'dgrad-like real 3x3 {c // 2}', NI, c // 2, c // 2, H, W, 3, 1, False)]
+shapes.append(('stem 8->%d real' % b, NI // (5 if which == 'm' else 3), 8, b, 128, 160, 3, 1, False))
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 for idx, (name, NI_, Cin, Cout, H, W, k, s, sp) in enumerate(shapes):
     if only is not None and idx != only:
