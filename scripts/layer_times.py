@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """development: per-layer GPU time of the dense convolutions of one training step (HIP events around the C-ABI calls, tagged with the
 BaseConv that issued them; the dual convolutions of CSPLayer / head towers are issued outside a BaseConv and appear under the tag of
-the previous layer).  usage: layer_times.py [config] [batch]"""
+the previous layer; the ONE batched slab reduction of all weight gradients at the end of the backward pass carries the last tag seen --
+the stem -- so the stem's "eas_conv_wgrad, 2 calls" row is its own weight gradient, ~0.15 ms, plus that reduction, ~0.5 ms).
+usage: layer_times.py [config] [batch]"""
 import os
 import sys
 
