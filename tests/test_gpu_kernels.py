@@ -1134,7 +1134,9 @@ CONV_CASES = [  # NI, Cin, Cout, H, W, k, stride, spikes
     (2, 1024, 512, 8, 10, 1, 1, True), (1, 16, 16, 6, 4, 3, 1, True),
     # output rows wider than the 80-pixel reduction tile: the weight gradient runs in column parts (stem / dark2.0 shapes at 128x160)
     (2, 8, 32, 16, 160, 3, 1, False), (2, 32, 64, 16, 160, 3, 2, False), (2, 32, 32, 8, 96, 3, 1, True), (1, 16, 16, 8, 240, 3, 1, True),
-    (2, 64, 64, 8, 320, 3, 2, True)]
+    (2, 64, 64, 8, 320, 3, 2, True),
+    # single-buffered LDS forms: 3-wave weight-gradient blocks whose double-buffered tile fills the LDS; real-input forward with 2 / 3 chunks
+    (2, 48, 48, 64, 80, 3, 1, False), (2, 48, 96, 32, 160, 3, 2, False), (2, 32, 64, 64, 160, 3, 2, False)]
 
 
 @pytest.mark.gpu
