@@ -334,7 +334,16 @@ class Trainer:
         self.before_train()
         # every iteration ends with reset_net, so the final membrane potentials never need to reach HBM (scoped: restored on exit)
         with ops.no_state_writeback() if self.exp.use_spike not in (False, 'False') else contextlib.nullcontext():
-            self._train_epochs()
+            if self.use_graph:
+                # graph capture wants every node of the iteration (the AccumulateGrad nodes included) on a non-default stream from the
+                # first eager iteration on: the whole loop runs on a stream of its own
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._train_epochs()
+                torch.cuda.current_stream().wait_stream(s)
+            else:
+                self._train_epochs()
 
     def _train_epochs(self):
         for self.epoch in range(self.start_epoch, self.max_epoch):
@@ -364,7 +373,9 @@ class Trainer:
             self._static[0].copy_(inps)
             self._static[1].copy_(targets)
         if self.use_graph and self.step.graphs is None and self._iters_done == 2:
-            self.step.capture(warm=0)                    # two eager iterations have initialised allocator and optimizer state
+            # two eager iterations have initialised allocator and optimizer state.  Recording executes nothing; capture() ends with
+            # one replay, and that replay is this batch's training step
+            self.step.capture(warm=0)
             loss = self.step.loss
         else:
             loss = self.step()

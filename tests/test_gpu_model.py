@@ -656,6 +656,48 @@ def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(de
         torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+def test_trainer_loop_on_the_gpu_graph_replay_equals_eager(dev, tmp_path, monkeypatch):
+    """yolox.core.Trainer.train() -- the loop tools/train_event.py runs -- for one epoch of five iterations on the synthetic loader: two eager
+    iterations, capture, replays (the default) against the SAME loop with the capture replaced by its bookkeeping only (device-side Adam
+    step counters and learning rate, as a captured step needs them), i.e. five eager iterations of the same arithmetic: every batch is
+    trained in both (a capture executes nothing), same learning-rate schedule, and the losses, parameters, BatchNorm buffers and EMA
+    weights are bit-identical.  EAS_TRAIN_GRAPH=0 (host-side learning rate: Adam rounds differently) must run too."""
+    import types
+    from eas_snn_amd import data, ops
+    from yolox.exp import get_exp
+    monkeypatch.setattr(ops, 'VERIFY_SMALL_INT', False)      # the suite's tag check reads the device: not inside a capture
+    from yolox.core.trainer import TrainStep
+    results = []
+    for graph in ('1', 'bookkeeping', '0'):
+        monkeypatch.setenv('EAS_TRAIN_GRAPH', '0' if graph == '0' else '1')
+        if graph == 'bookkeeping':
+            # capture() = bookkeeping + recording (executes nothing) + ONE replay, which is the batch's training step
+            monkeypatch.setattr(TrainStep, 'capture', lambda self, warm=3: (self.make_capturable(), self.eager()))
+        exp = get_exp(None, 'e-yolox-s')
+        exp.merge(BASE_OPTS + ['use_spike', 'True', 'input_size', '(64, 64)', 'test_size', '(64, 64)'])    # (a 2x3 stride-32 map would take the library convolution: not reproducible)
+        exp.max_epoch, exp.print_interval, exp.output_dir = 1, 1, str(tmp_path / graph)
+        exp.get_data_loader = lambda batch_size, is_distributed, no_aug=False, cache_img=None, exp=exp: \
+            data.SyntheticEventLoader(exp, batch_size, iters=5, n_events=3000, sensor_hw=(60, 60))
+        torch.manual_seed(5)
+        tr = exp.get_trainer(types.SimpleNamespace(batch_size=4, fp16=False, experiment_name='loop', ckpt=None, resume=False))
+        tr.train()
+        assert (tr.step.graphs is not None) == (graph == '1') and len(tr.log) == 5
+        assert all(np.isfinite(r['loss']) for r in tr.log)
+        if graph == '0':
+            continue
+        sd = {k: v.clone() for k, v in tr.bare_model.state_dict().items()}
+        ema = {k: v.clone() for k, v in tr.ema_model.ema.state_dict().items()} if tr.use_model_ema else {}
+        results.append((sd, ema, [r['loss'] for r in tr.log], [r['lr'] for r in tr.log]))
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    (sd1, ema1, loss1, lr1), (sd0, ema0, loss0, lr0) = results
+    assert lr1 == lr0
+    assert loss1 == loss0, (loss1, loss0)
+    bad = [k for k in sd1 if not torch.equal(sd1[k], sd0[k])]
+    assert not bad, bad[:5]
+    bad = [k for k in ema1 if not torch.equal(ema1[k], ema0[k])]
+    assert not bad, bad[:5]
+
+
 def test_deferred_weight_gradient_reductions_are_bit_identical(dev):
     """ops.deferred_wgrad_reductions(): the slab reductions of all weight gradients of a backward pass in ONE launch at its end
     (eas_conv_wgrad_reduce_many) -- same loss, every parameter gradient bit-identical to the immediate reductions, also on a second
