@@ -25,8 +25,16 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 
 from eas_snn_amd import ops
 from eas_snn_amd.parallel import BucketedGradAllReduce
-from yolox.utils import (ModelEMA, get_local_rank, get_model_info, get_rank, get_world_size, is_parallel, load_ckpt,
-                         save_checkpoint, setup_logger)
+from yolox.utils import (ModelEMA, adjust_status, all_reduce_norm, get_local_rank, get_model_info, get_rank, get_world_size,
+                         is_parallel, load_ckpt, save_checkpoint, setup_logger, synchronize)
+
+
+def optimizer_capturable(optimizer):
+    """True when ``optimizer.step()`` can be recorded into a HIP graph with the learning rate held in a device scalar: torch's Adam /
+    AdamW with ``capturable`` (or ``fused``) read lr and step counters on the device.  SGD (the reference's other branch,
+    event_yolox_base.py:361-377) and user-supplied optimizers pass ``lr`` as a host number (``alpha=-lr`` -> ``.item()`` on a device
+    tensor = a host synchronisation inside the capture), so their iterations are launched eagerly with a float lr."""
+    return isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)) and all('capturable' in g for g in optimizer.param_groups)
 
 
 def _reset_net(model):
@@ -79,12 +87,18 @@ class TrainStep:
             return type(obj)(self._split_at(v) for v in obj)
         return obj
 
+    def _cut_hook(self, module, inputs, output):
+        return self._split_at(output)
+    # the cut handles spike planes (ghost tensors keep their ``_eas_*`` attributes on the detached leaves): ``ops.packed_weights`` must not
+    # switch the model to fp32 spikes because of this hook, or N > 1 ranks would run a different kernel set than one rank
+    _cut_hook._eas_planes_safe = True
+
     def _forward(self):
         inps, targets = self.inputs_fn()
         hooks = []
         self._cut_pairs = []
         for name in self.cut:
-            hooks.append(self.model.get_submodule(name).register_forward_hook(lambda m, i, o: self._split_at(o)))
+            hooks.append(self.model.get_submodule(name).register_forward_hook(self._cut_hook))
         try:
             self.outputs = self.net(inps, targets)
         finally:
@@ -266,6 +280,9 @@ class Trainer:
         self.start_epoch = 0
         self.file_name = os.path.join(exp.output_dir, getattr(args, 'experiment_name', None) or exp.exp_name)
         self.log = []
+        self.best_ap = 0
+        self.eval_log = []
+        self.save_history_ckpt = getattr(exp, 'save_history_ckpt', False)
         self.step = None
         self.exchange = None
         if self.rank == 0:
@@ -314,9 +331,14 @@ class Trainer:
             self.ema_model = ModelEMA(self.bare_model, 0.9998)
             self.ema_model.updates = self.max_iter * self.start_epoch
         # launch form of the iterations: HIP-graph replay on the GPU unless switched off (EAS_TRAIN_GRAPH=0) or DistributedDataParallel
-        self.use_graph = (self.device != 'cpu' and self.net is self.bare_model and os.environ.get('EAS_TRAIN_GRAPH', '1') == '1')
+        self.use_graph = (self.device != 'cpu' and self.net is self.bare_model and os.environ.get('EAS_TRAIN_GRAPH', '1') == '1'
+                          and optimizer_capturable(self.optimizer))
         self._static = None
         self._iters_done = 0
+        # evaluation between epochs (trainer.py:178-180, 243-248 of the reference); an experiment without an evaluator trains only
+        self.evaluator = None
+        if getattr(self.exp, 'eval_interval', 0) and hasattr(self.exp, 'get_evaluator'):
+            self.evaluator = self.exp.get_evaluator(batch_size=self.args.batch_size, is_distributed=self.is_distributed)
 
     def resume_train(self, model):
         ckpt_file = getattr(self.args, 'ckpt', None)
@@ -350,7 +372,29 @@ class Trainer:
             self.bare_model.head.use_l1 = True          # no_aug from epoch 0 (trainer.py:157, 231-238 of the reference)
             for self.iter, (inps, targets) in enumerate(self.train_loader):
                 self.train_one_iter(inps, targets)
-            self.save_ckpt('latest')
+            self.after_epoch()
+
+    def after_epoch(self):
+        """trainer.py:243-248 of the reference: checkpoint, then every ``eval_interval`` epochs average the BatchNorm statistics over the
+        ranks (they train with per-rank statistics) and evaluate"""
+        self.save_ckpt('latest')
+        if self.evaluator is not None and (self.epoch + 1) % self.exp.eval_interval == 0:
+            all_reduce_norm(self.bare_model)
+            self.evaluate_and_save_model()
+
+    def evaluate_and_save_model(self):
+        """trainer.py:354-386 of the reference: the EMA weights (if any) are what is evaluated and saved"""
+        evalmodel = self.ema_model.ema if self.use_model_ema else self.bare_model
+        with adjust_status(evalmodel, training=False):
+            (ap50_95, ap50, summary), predictions = self.exp.eval(evalmodel, self.evaluator, self.is_distributed, return_outputs=True)
+        update_best = ap50_95 is not None and ap50_95 > self.best_ap
+        if ap50_95 is not None:
+            self.best_ap = max(self.best_ap, ap50_95)
+        self.eval_log.append(dict(epoch=self.epoch, ap50_95=ap50_95, ap50=ap50, summary=summary, images=len(predictions)))
+        synchronize()
+        self.save_ckpt('last_epoch', update_best)
+        if self.save_history_ckpt:
+            self.save_ckpt(f'epoch_{self.epoch + 1}')
 
     def _set_lr(self, lr):
         for g in self.optimizer.param_groups:

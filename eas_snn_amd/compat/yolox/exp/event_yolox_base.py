@@ -173,9 +173,35 @@ class EventExp(BaseExp):
             batch_size = batch_size // dist.get_world_size()
         return SyntheticEventLoader(self, batch_size)
 
+    def get_eval_dataset(self, **kwargs):
+        from eas_snn_amd.data import SyntheticEvalDataset
+        return SyntheticEvalDataset(self, length=int(getattr(self, 'eval_samples', 256)), n_events=int(getattr(self, 'eval_events', 200_000)))
+
+    def get_eval_loader(self, batch_size, is_distributed, **kwargs):
+        """reference: event_yolox_base.py:483-507 -- twice the training batch, split over the ranks, samples rank, rank + world, ...
+        in order (DistributedSampler(shuffle=False)); the streams are synthetic and binned on the GPU"""
+        from eas_snn_amd.data import SyntheticEvalLoader
+        import torch.distributed as dist
+        valdataset = self.get_eval_dataset(**kwargs)
+        batch_size *= 2
+        rank, world = 0, 1
+        if is_distributed:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            batch_size = batch_size // world
+        n = len(valdataset)
+        per_rank = (n + world - 1) // world                 # DistributedSampler pads with the first samples so every rank gets the same count
+        idx = [(rank + k * world) % n for k in range(per_rank)]
+        # synthetic streams on the Gen1 sensor (or on the canvas itself when that is smaller); ``eval_sensor_hw`` / ``eval_events`` override
+        sensor = getattr(self, 'eval_sensor_hw', None) or (min(240, self.test_size[0]), min(304, self.test_size[1]))
+        return SyntheticEvalLoader(self, batch_size, idx, n_events=valdataset.n_events, sensor_hw=tuple(sensor), dataset=valdataset)
+
     def get_evaluator(self, batch_size, is_distributed, testdev=False, legacy=False):
-        raise NotImplementedError('mAP evaluators (COCO / Prophesee) need the real datasets and are out of scope '
-                                  '(SURVEY.md 2.1 #13); parity is checked on logits')
+        """reference: event_yolox_base.py:509-534.  ``eval_proph`` (the Prophesee metric toolbox on real Gen1 / 1 Mpx recordings) has no
+        counterpart here: its inference loop is the same one (psee_evaluator.py:180-215), its metric code needs the datasets."""
+        from yolox.evaluators import EventEvaluator
+        return EventEvaluator(dataloader=self.get_eval_loader(batch_size, is_distributed, testdev=testdev, legacy=legacy),
+                              img_size=self.test_size, confthre=self.test_conf, nmsthre=self.nmsthre, num_classes=self.num_classes,
+                              testdev=testdev, snn_reset=self.use_spike)
 
     def get_trainer(self, args):
         from yolox.core import Trainer

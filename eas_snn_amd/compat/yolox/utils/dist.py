@@ -43,6 +43,40 @@ def is_main_process() -> bool:
     return get_rank() == 0
 
 
+_GLOO_GROUP = None
+
+
+def _object_group():
+    """process group for pickled python objects: the default group on gloo, a gloo twin of it on RCCL (objects live on the host;
+    reference: dist.py:142-152 ``_get_global_gloo_group``)"""
+    global _GLOO_GROUP
+    if dist.get_backend() != 'nccl':
+        return dist.group.WORLD
+    if _GLOO_GROUP is None:
+        _GLOO_GROUP = dist.new_group(backend='gloo')
+    return _GLOO_GROUP
+
+
+def gather(data, dst=0, group=None):
+    """picklable ``data`` of every rank as a list on rank ``dst`` (elsewhere: []); reference: dist.py:233-273"""
+    if get_world_size() == 1:
+        return [data]
+    group = _object_group() if group is None else group
+    out = [None] * dist.get_world_size(group) if dist.get_rank(group) == dst else None
+    dist.gather_object(data, out, dst=dst, group=group)
+    return out if out is not None else []
+
+
+def all_gather(data, group=None):
+    """picklable ``data`` of every rank as a list on every rank; reference: dist.py:195-230"""
+    if get_world_size() == 1:
+        return [data]
+    group = _object_group() if group is None else group
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, data, group=group)
+    return out
+
+
 def synchronize():
     if _ready() and dist.get_world_size() > 1:
         dist.barrier()

@@ -72,6 +72,42 @@ class SyntheticEventLoader:
             frames = events_to_frames(ev, self.exp.Tm, self.sensor_hw, self.exp.input_size)
             yield frames, synth_targets(self.batch_size, self.exp.input_size, dev)
 
+class SyntheticEvalDataset(SyntheticEventDataset):
+    """what the evaluator asks of its dataset (event_evaluator.py:166-169, :348-356): map_val without random augmentation, class / sample names"""
+    map_val, random_aug = True, False
+
+    def __init__(self, exp, length=256, n_events=200_000):
+        super().__init__(exp, length, n_events)
+        self.class_names = [str(i) for i in range(exp.num_classes)]
+        self.sample_names = [f'synthetic_{i:06d}' for i in range(length)]
+
+
+class SyntheticEvalLoader:
+    """Iterable of ``(frames [B,Tl,Tm,2,H,W] fp32 on the GPU, labels [B][n,5] rows (x, y, w, h, cls), (heights, widths), ids)`` -- the tuple
+    the reference's evaluation loader yields (gen1_collact_func; event_evaluator.py:183).  Sample ``i`` is the seeded stream ``i`` on every
+    rank; ``indices`` are this rank's samples (rank, rank + world, ... like DistributedSampler(shuffle=False), event_yolox_base.py:489-494);
+    the last batch may be short."""
+
+    def __init__(self, exp, batch_size, indices, n_events=200_000, sensor_hw=(240, 304), dataset=None):
+        self.exp, self.batch_size, self.indices, self.n_events, self.sensor_hw = exp, batch_size, list(indices), n_events, sensor_hw
+        self.dataset = dataset if dataset is not None else SyntheticEvalDataset(exp, n_events=n_events)
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        H, W = self.sensor_hw
+        for b in range(len(self)):
+            ids = self.indices[b * self.batch_size:(b + 1) * self.batch_size]
+            parts = [synth_event_batch(1, self.n_events, H, W, seed=10_000 + i) for i in ids]
+            ev = {k: np.concatenate([p[k] for p in parts]) for k in ('t', 'x', 'y', 'p')}
+            ev['offsets'] = np.arange(len(ids) + 1, dtype=np.int64) * self.n_events
+            frames = events_to_frames(events_to_device(ev, dev), self.exp.Tm, self.sensor_hw, self.exp.test_size)
+            labels = [torch.tensor([[0.3 * W, 0.4 * H, 0.25 * W, 0.3 * H, float(i % self.exp.num_classes)]]) for i in ids]
+            yield frames, labels, (torch.full((len(ids),), H), torch.full((len(ids),), W)), torch.tensor(ids)
+
+
 # ------------------------------------------------------------------------------------------------ augmentation parameters
 def letterbox_params(ih, iw, h, w, letterbox=True, center=False):
     """(nw, nh, dx, dy, flip) of the deterministic branch of GEN1Dataset.get_random_data (gen1.py:438-483)."""

@@ -1889,6 +1889,13 @@ def conv2d_dual(x, conv_a, conv_b, owner=None, key=None):
     return _ConvDualFn.apply(x, conv_a.weight, conv_b.weight, 1 if small else 3, packs, planes_of(x) if small else None)
 
 
+def _foreign_hooks(m):
+    """the module carries a forward (pre-)hook that may look at a spike tensor, i.e. one that is not marked ``_eas_planes_safe``"""
+    if m._forward_pre_hooks:
+        return True
+    return any(not getattr(h, '_eas_planes_safe', False) for h in m._forward_hooks.values()) if m._forward_hooks else False
+
+
 class packed_weights:
     """``with ops.packed_weights(model):`` around a model forward: packs all convolution weights once (see
     prepack_conv_weights) and makes exactly that packing visible to ``conv2d`` for the duration of the block.  Outside the
@@ -1907,7 +1914,8 @@ class packed_weights:
             mods = list(self.model.modules())
             object.__setattr__(self.model, '_eas_modules', mods)
         # a forward hook anywhere in the model may look at a spike tensor: fp32 spikes throughout then (see "SPIKE PLANES")
-        _PLANES_SCOPE = _PACK_SCOPE is not None and not any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+        # (hooks that declare ``_eas_planes_safe`` -- the trainer's backward cut, which handles ghosts -- do not count)
+        _PLANES_SCOPE = _PACK_SCOPE is not None and not any(_foreign_hooks(m) for m in mods)
 
     def __exit__(self, *exc):
         global _PACK_SCOPE, _PLANES_SCOPE

@@ -390,7 +390,7 @@ class _ToyStateful(torch.nn.Module):
 class _ToyNet(torch.nn.Module):
     def __init__(self):
         super().__init__()
-        self.embedding = torch.nn.Linear(6, 6)
+        self.embedding = torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.BatchNorm1d(6))    # (below the cut: the lower bucket)
         self.backbone = torch.nn.Module()
         self.backbone.backbone = torch.nn.Sequential(torch.nn.Linear(6, 6), _ToyStateful())
         self.head = torch.nn.Linear(6, 3)
@@ -402,7 +402,23 @@ class _ToyNet(torch.nn.Module):
 
 class _ToyExp:
     max_epoch, ema, input_size, test_size, exp_name, use_spike = 1, True, (8, 8), (8, 8), 'toy', 'True'
-    basic_lr_per_img, print_interval = 1e-2 / 4, 1
+    basic_lr_per_img, print_interval, eval_interval = 1e-2 / 4, 1, 1
+
+    class _Evaluator:
+        """records what Trainer.after_epoch hands to ``exp.eval`` (the real loop: test_evaluator_walks_the_eval_tool_sequence)"""
+
+        def __init__(self):
+            self.calls = []
+
+        def evaluate(self, model, distributed=False, half=False, trt_file=None, decoder=None, test_size=None, return_outputs=False):
+            self.calls.append(dict(training=model.training, distributed=distributed, bn_mean=model.embedding[1].running_mean.clone()))
+            return ((0.25, 0.5, 'toy summary'), {0: {}}) if return_outputs else (0.25, 0.5, 'toy summary')
+
+    def get_evaluator(self, batch_size, is_distributed, testdev=False, legacy=False):
+        return self._Evaluator()
+
+    def eval(self, model, evaluator, is_distributed, half=False, return_outputs=False):
+        return evaluator.evaluate(model, is_distributed, half, return_outputs=return_outputs)
 
     def __init__(self, out):
         self.output_dir, self.model = out, None
@@ -443,6 +459,17 @@ def _trainer_worker(tag, out_dir):
     assert tr.exchange is not None and tr.exchange.nbuckets == 2 and tr.step.cut == ('backbone.backbone',)
     assert tr.step.graphs is None and len(tr.log) == 3                      # CPU: eager launches; one log row per iteration
     assert tr.bare_model.backbone.backbone[1].resets == 3 and tr.ema_model.updates == 3
+    # after the epoch: all_reduce_norm made the per-rank BatchNorm statistics equal, THEN the evaluator saw the EMA model in eval mode
+    # (trainer.py:243-248, 354-386 of the reference), the training model is back in training mode, and 'last_epoch' + best are saved
+    rm = [torch.zeros(6) for _ in range(world)]
+    dist.all_gather(rm, tr.bare_model.embedding[1].running_mean)
+    assert torch.equal(rm[0], rm[1]) and float(rm[0].abs().sum()) > 0
+    (call,) = tr.evaluator.calls
+    assert call['training'] is False and call['distributed'] is True and tr.bare_model.training and tr.best_ap == 0.25
+    assert tr.eval_log[0]['ap50'] == 0.5 and tr.eval_log[0]['summary'] == 'toy summary'
+    if rank == 0:
+        for name in ('last_epoch_ckpt.pth', 'best_ckpt.pth'):
+            assert os.path.exists(os.path.join(out_dir, f'toy_{tag}', name)), name
     # every rank ends with the same parameters (same averaged gradients) that differ from the start
     torch.manual_seed(3)
     fresh = _ToyNet()
@@ -470,6 +497,7 @@ def _trainer_worker(tag, out_dir):
         opt.step()
         for gr in opt.param_groups:
             gr['lr'] = sched.update_lr(it + 1)
+    # (the BatchNorm running statistics of ``fresh`` saw both ranks' batches in turn: only parameters are compared)
     for (n, p), q in zip(tr.bare_model.named_parameters(), fresh.parameters()):
         torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6, msg=n)
     if rank == 0:
@@ -494,3 +522,191 @@ def test_trainer_runs_two_ranks_on_gloo(tmp_path):
     r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     assert (tmp_path / 'ok_t_0').exists() and (tmp_path / 'ok_t_1').exists()
+
+
+# ------------------------------------------------------------------------------------------------ the evaluation side of the boundary
+class _ToyDetector(torch.nn.Module):
+    """eval-mode forward: frames [B,1,Tm,2,H,W] -> decoded predictions [B, A, 5 + classes] (cx, cy, w, h, obj, class scores)"""
+
+    def __init__(self, anchors=24, classes=2):
+        super().__init__()
+        self.anchors, self.classes = anchors, classes
+        self.proj = torch.nn.Linear(2 * 4, anchors * (5 + classes))
+        self.neuron = _ToyStateful()
+
+    def forward(self, x, targets=None):
+        f = x.float().mean(dim=(-1, -2)).flatten(1)                          # [B, Tm * 2]
+        r = self.neuron(self.proj(f)).view(-1, self.anchors, 5 + self.classes)
+        box = torch.cat([r[..., :2].sigmoid() * 200.0 + 20.0, r[..., 2:4].sigmoid() * 60.0 + 8.0], -1)
+        return torch.cat([box, r[..., 4:].sigmoid()], -1)
+
+
+class _ToyEvalLoader:
+    """the tuple the reference's evaluation loader yields, on the CPU: sample i is the same on every rank"""
+
+    def __init__(self, batch_size, indices, sensor=(240, 304)):
+        self.batch_size, self.indices, self.sensor = batch_size, list(indices), sensor
+        self.dataset = type('D', (), {'map_val': True, 'random_aug': False, 'class_names': ['a', 'b']})()
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    @staticmethod
+    def sample(i):
+        return torch.rand(1, 4, 2, 8, 10, generator=torch.Generator().manual_seed(500 + i)) * 3
+
+    def __iter__(self):
+        H, W = self.sensor
+        for b in range(len(self)):
+            ids = self.indices[b * self.batch_size:(b + 1) * self.batch_size]
+            yield (torch.stack([self.sample(i) for i in ids]), [torch.tensor([[10., 20., 30., 40., float(i % 2)]]) for i in ids],
+                   (torch.full((len(ids),), H), torch.full((len(ids),), W)), torch.tensor(ids))
+
+
+def _toy_eval_exp(out_dir, n_samples=10):
+    """the real EventExp (options, get_evaluator, eval) with a CPU model and a CPU loader in place of the GPU ones"""
+    from yolox.exp import get_exp
+
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(['num_classes', '2', 'use_spike', 'True', 'test_size', '(256,320)', 'test_conf', '0.3', 'nmsthre', '0.5'])
+    exp.output_dir = out_dir
+
+    def get_model():
+        torch.manual_seed(11)
+        exp.model = _ToyDetector()
+        return exp.model
+
+    def get_eval_loader(batch_size, is_distributed, **kwargs):
+        import torch.distributed as dist
+        assert kwargs == {'testdev': False, 'legacy': False}
+        batch_size *= 2                                                      # event_yolox_base.py:489-491 of the reference
+        rank, world = (dist.get_rank(), dist.get_world_size()) if is_distributed else (0, 1)
+        return _ToyEvalLoader(batch_size // world, range(rank, n_samples, world))
+
+    exp.get_model, exp.get_eval_loader = get_model, get_eval_loader
+    return exp
+
+
+def _oracle_postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
+    from oracle import postprocess_ref
+    out = postprocess_ref.postprocess(prediction.cpu().numpy(), num_classes, conf_thre, nms_thre, class_agnostic)
+    return [None if o is None else torch.from_numpy(o) for o in out]
+
+
+def _eval_tool_main(tag, out_dir, num_gpu):
+    """the call sequence of tools/eval_event.py::main (:124-211) against the mirror; returns what rank 0 got"""
+    import types
+    import yolox.evaluators.event_evaluator as EV
+    from yolox.utils import configure_nccl, fuse_model, get_local_rank, get_model_info, setup_logger
+    EV.postprocess = _oracle_postprocess               # CPU: the checker's NMS stands in for eas_postprocess (which has no CPU form)
+    args = types.SimpleNamespace(batch_size=4, test=False, legacy=False, fp16=False, fuse=True, conf=None, nms=None, tsize=None,
+                                 experiment_name=f'eval_{tag}')
+    exp = _toy_eval_exp(out_dir)
+    is_distributed = num_gpu > 1
+    configure_nccl()
+    rank = get_local_rank()
+    file_name = os.path.join(exp.output_dir, args.experiment_name)
+    if rank == 0:
+        os.makedirs(file_name, exist_ok=True)
+    setup_logger(file_name, distributed_rank=rank, filename='val_log.txt', mode='a')
+    model = exp.get_model()
+    assert 'Params' in get_model_info(model, exp.test_size)
+    evaluator = exp.get_evaluator(args.batch_size, is_distributed, args.test, args.legacy)
+    evaluator.per_class_AP = True
+    evaluator.per_class_AR = True
+    model.eval()
+    model = fuse_model(model)
+    *_, summary = evaluator.evaluate(model, is_distributed, args.fp16, None, None, exp.test_size)
+    return exp, model, evaluator, summary
+
+
+def _expected_detections(exp, model, n_samples=10):
+    """every sample on its own through the model and the checker's NMS, boxes scaled back to the sensor"""
+    want = {}
+    scale = min(exp.test_size[0] / 240.0, exp.test_size[1] / 304.0)
+    with torch.no_grad():
+        for i in range(n_samples):
+            (det,) = _oracle_postprocess(model(_ToyEvalLoader.sample(i)[None]), 2, exp.test_conf, exp.nmsthre)
+            if det is not None:
+                box = det[:, :4] / scale
+                want[i] = sorted((round(float(s), 5), int(c), [round(float(v), 3) for v in (b[0], b[1], b[2] - b[0], b[3] - b[1])])
+                                 for b, s, c in zip(box, det[:, 4] * det[:, 5], det[:, 6]))
+    return want
+
+
+def _check_eval_result(exp, model, evaluator, summary, world):
+    import yolox.utils as U
+    if U.get_rank() != 0:
+        assert summary is None
+        return
+    assert summary.startswith('Average forward time:') and 'Average NMS time:' in summary and 'Average inference time:' in summary
+    # 10 samples, batch 8 / world: the last (short) batch is not timed; statistics = (inference s, NMS s, timed batches) summed over ranks
+    per_rank_batches = {1: 2, 2: 2}[world]
+    st = evaluator.last_statistics.tolist()
+    assert st[2] == world * (per_rank_batches - 1) and st[0] > 0 and st[1] > 0
+    assert model.neuron.resets >= per_rank_batches            # reset_net after every forward (snn_reset = use_spike)
+
+
+def test_evaluator_walks_the_eval_tool_sequence(tmp_path):
+    """tools/eval_event.py::main's calls -- get_model, get_model_info, get_evaluator, fuse_model, evaluator.evaluate(model, distributed,
+    fp16, trt_file, decoder, test_size) -- on the mirror at world size 1: every detection record equals the per-sample restatement."""
+    import yolox.evaluators.event_evaluator as EV
+    saved = EV.postprocess
+    try:
+        exp, model, evaluator, summary = _eval_tool_main('w1', str(tmp_path), 1)
+        _check_eval_result(exp, model, evaluator, summary, 1)
+        (ap50_95, ap50, _), outputs = evaluator.evaluate(model, False, False, None, None, exp.test_size, return_outputs=True)
+        want = _expected_detections(exp, model)
+        assert len(want) >= 8 and sum(len(v) for v in want.values()) >= 20         # the toy detector fires on nearly every sample
+        got = {i: sorted((round(s_, 5), c, [round(v, 3) for v in (b_[0], b_[1], b_[2] - b_[0], b_[3] - b_[1])])
+                         for b_, s_, c in zip(o['bboxes'], o['scores'], o['categories'])) for i, o in outputs.items()}
+        assert got == want
+        # the COCO-style records of one hand-made image: xyxy on the canvas -> xywh on the sensor, score = obj * class confidence
+        recs = evaluator.convert_to_coco_format([torch.tensor([[32., 64., 96., 192., 0.5, 0.8, 1.]]), None], (torch.tensor([128, 128]), torch.tensor([160, 160])),
+                                                torch.tensor([7, 8]))
+        assert recs == [{'image_id': 7, 'category_id': 1, 'bbox': [16.0, 32.0, 32.0, 64.0], 'score': pytest.approx(0.4), 'segmentation': []}]
+        assert ap50_95 is None or ap50_95 >= 0          # no pycocotools here: AP fields None, detections + timings delivered
+        with pytest.raises(NotImplementedError):
+            evaluator.evaluate(model, False, True)
+    finally:
+        EV.postprocess = saved
+
+
+def _eval_worker(tag, out_dir):
+    import torch.distributed as dist
+    exp, model, evaluator, summary = _eval_tool_main(tag, out_dir, dist.get_world_size())
+    _check_eval_result(exp, model, evaluator, summary, dist.get_world_size())
+    (_, _, _), outputs = evaluator.evaluate(model, True, False, None, None, exp.test_size, return_outputs=True)
+    if dist.get_rank() == 0:
+        want = _expected_detections(exp, model)
+        assert sorted(outputs) == sorted(want)                                   # rank 0 holds every rank's images
+        for i, recs in want.items():
+            assert sorted(round(s, 5) for s in outputs[i]['scores']) == sorted(r[0] for r in recs)
+    open(os.path.join(out_dir, f'ok_{tag}_{dist.get_rank()}'), 'w').write('ok')
+
+
+def test_evaluator_two_ranks_on_gloo(tmp_path):
+    """the same sequence at world size 2 (gloo): samples rank, rank + 2, ... per rank, detections gathered to rank 0, statistics reduced"""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import eas_snn_amd\n"
+        "from yolox.core import launch\n"
+        "from test_cpu_host import _eval_worker\n"
+        "if __name__ == '__main__':\n"
+        "    launch(_eval_worker, 2, 1, 0, backend='gloo', dist_url='auto', args=('e', %r))\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), str(tmp_path))
+    script = tmp_path / 'run_eval.py'
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert (tmp_path / 'ok_e_0').exists() and (tmp_path / 'ok_e_1').exists()
+
+
+def test_graph_capture_is_only_used_with_capturable_optimizers():
+    """SGD passes the learning rate as a host number (a device-scalar lr would synchronise inside the capture)"""
+    from yolox.core.trainer import optimizer_capturable
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    assert optimizer_capturable(torch.optim.Adam(p, lr=1e-3)) and optimizer_capturable(torch.optim.AdamW(p, lr=1e-3))
+    assert not optimizer_capturable(torch.optim.SGD(p, lr=1e-3, momentum=0.9, nesterov=True))
+    assert not optimizer_capturable(torch.optim.RMSprop(p, lr=1e-3))

@@ -636,7 +636,14 @@ def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(de
         assert ex.nbuckets == 2
         step = TrainStep(model, opt, lambda: (x, tg), exchange=ex, cut=DEFAULT_CUT)
         assert step.cut == DEFAULT_CUT
-        step()
+        # the cut is a forward hook: it must not switch the model to fp32 spikes (N > 1 ranks would run another kernel set than one rank)
+        made, new_planes = [], ops.new_planes
+        ops.new_planes = lambda *a, **k: (made.append(1), new_planes(*a, **k))[1]
+        try:
+            step()
+        finally:
+            ops.new_planes = new_planes
+        assert made, 'the split step ran without spike planes'
         assert torch.equal(step.loss.detach(), loss0)
         bad = [n for n, p in model.named_parameters() if not torch.equal(p.grad, want[n])]
         assert not bad, f'split backward + buckets differ from the plain backward in {bad[:5]}'
@@ -696,6 +703,97 @@ def test_trainer_loop_on_the_gpu_graph_replay_equals_eager(dev, tmp_path, monkey
     assert not bad, bad[:5]
     bad = [k for k in ema1 if not torch.equal(ema1[k], ema0[k])]
     assert not bad, bad[:5]
+
+
+def test_trainer_loop_with_sgd_stays_eager(dev, tmp_path, monkeypatch):
+    """``optimizer SGD`` (the reference's other branch, event_yolox_base.py:361-377): its step takes the learning rate as a host number, so
+    the Trainer must not capture it -- the loop runs eagerly, with a float lr, and trains"""
+    import types
+    from eas_snn_amd import data
+    from yolox.exp import get_exp
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(BASE_OPTS + ['use_spike', 'True', 'input_size', '(64, 64)', 'test_size', '(64, 64)', 'optimizer', 'SGD'])
+    exp.max_epoch, exp.print_interval, exp.output_dir = 1, 1, str(tmp_path)
+    exp.get_data_loader = lambda batch_size, is_distributed, no_aug=False, cache_img=None: \
+        data.SyntheticEventLoader(exp, batch_size, iters=4, n_events=3000, sensor_hw=(60, 60))
+    torch.manual_seed(5)
+    tr = exp.get_trainer(types.SimpleNamespace(batch_size=4, fp16=False, experiment_name='sgd', ckpt=None, resume=False))
+    before = None
+    tr.train()
+    assert isinstance(tr.optimizer, torch.optim.SGD) and not tr.use_graph and tr.step.graphs is None
+    assert all(isinstance(g['lr'], float) for g in tr.optimizer.param_groups)
+    assert len(tr.log) == 4 and all(np.isfinite(r['loss']) for r in tr.log)
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_evaluator_on_the_gpu(dev, tmp_path):
+    """yolox.evaluators.EventEvaluator (what tools/eval_event.py:209-211 calls) on the GPU: (1) the default form -- two HIP-graph replays
+    per batch -- returns the same detections as eager launches; (2) they equal the checker's post-processing (oracle/postprocess_ref.py)
+    of the model's own logits; (3) fed the ORACLE's logits (the torch-CPU model behind a stand-in module), every detection equals
+    the checker's post-processing of those logits."""
+    from oracle import fill, model_ref, postprocess_ref, sj_ref
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(BASE_OPTS + ['use_spike', 'True', 'input_size', '(64, 96)', 'test_size', '(64, 96)', 'test_conf', '0.00003', 'nmsthre', '0.5'])
+    exp.eval_samples, exp.eval_events, exp.eval_sensor_hw, exp.output_dir = 10, 3000, (60, 76), str(tmp_path)
+    model = exp.get_model()
+    ref = model_ref.build_model(use_spike='True')
+    assert fill.procedural_fill_(model, 2.0, ann_regex=fill.ANN_KEYS['True']) == fill.procedural_fill_(ref, 2.0, ann_regex=fill.ANN_KEYS['True'])
+    model.to(dev).eval()
+    ref.eval()
+    evaluator = exp.get_evaluator(2, False)                       # batch 4: batches of 4, 4, 2 samples
+    assert len(evaluator.dataloader) == 3 and evaluator.dataloader.batch_size == 4
+    (_, _, summary), graphed = evaluator.evaluate(model, False, False, None, None, exp.test_size, return_outputs=True)
+    assert evaluator._graphed is not None and 'Average forward time' in summary and float(evaluator.last_statistics[2]) == 2
+    evaluator.use_graph = False
+    (_, _, _), eager = evaluator.evaluate(model, False, False, None, None, exp.test_size, return_outputs=True)
+    assert sorted(graphed) == sorted(eager) and len(graphed) == 10
+    for i in graphed:
+        assert graphed[i] == eager[i], f'image {i}: graph replay and eager launches disagree'
+    # (2) against the checker on the model's own logits
+    scale = min(64 / 60.0, 96 / 76.0)
+    n_det = 0
+    for frames, labels, info, ids in evaluator.dataloader:
+        with torch.no_grad():
+            logits = model(frames)
+        functional.reset_net(model)
+        want = postprocess_ref.postprocess(logits.cpu().numpy(), 2, exp.test_conf, exp.nmsthre)
+        for i, w in zip(ids.tolist(), want):
+            assert (w is None) == (i not in eager)
+            if w is not None:
+                np.testing.assert_allclose(np.array(eager[i]['bboxes'], np.float32), w[:, :4] / np.float32(scale), rtol=1e-6)
+                np.testing.assert_allclose(np.array(eager[i]['scores'], np.float32), w[:, 4] * w[:, 5], rtol=1e-6)
+                assert eager[i]['categories'] == w[:, 6].astype(int).tolist()
+                n_det += len(w)
+    assert n_det >= 20, 'the confidence threshold left almost nothing to compare'
+
+    # (3) the oracle's logits through the same loop
+    class OracleLogits(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.anchor = torch.nn.Parameter(torch.zeros(1, device=dev))     # tells the evaluator where the model lives
+            self.seen = []
+
+        def forward(self, x):
+            with torch.no_grad():
+                out = ref(x.cpu())
+            sj_ref.reset_net(ref)
+            self.seen.append(out.numpy().copy())
+            return out.to(dev)
+
+    stand_in = OracleLogits()
+    (_, _, _), got = evaluator.evaluate(stand_in, False, False, None, None, exp.test_size, return_outputs=True)
+    k = 0
+    for (frames, labels, info, ids), logits in zip(evaluator.dataloader, stand_in.seen):
+        want = postprocess_ref.postprocess(logits, 2, exp.test_conf, exp.nmsthre)
+        for i, w in zip(ids.tolist(), want):
+            assert (w is None) == (i not in got)
+            if w is not None:
+                np.testing.assert_allclose(np.array(got[i]['bboxes'], np.float32), w[:, :4] / np.float32(scale), rtol=1e-6)
+                assert got[i]['categories'] == w[:, 6].astype(int).tolist()
+                k += len(w)
+    assert k >= 20
 
 
 def test_deferred_weight_gradient_reductions_are_bit_identical(dev):
