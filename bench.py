@@ -414,6 +414,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ops.check_tags('the timed steps')        # a tensor tagged "spikes" that was not: the measured arithmetic would not be the fp32 one
     # Per-kernel durations behind `roofline`: HIP events around every C-ABI call, on the stream the kernels are launched on, in
     # eager steps of this same process right after the timed region (same kernels, same data).  Not inside it: events cannot be
     # recorded into a captured graph, and ~1400 event records per eager step would slow the timed region itself by ~10 %.

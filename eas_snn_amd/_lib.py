@@ -34,8 +34,12 @@ class EasBnPending(C.Structure):
 
 
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
+ABI_VERSION = 5
+
 PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
+    'eas_kernel_trace_begin': (None, []),
+    'eas_kernel_trace_dump': (C.c_int64, [C.c_char_p, C.c_int64]),
     'eas_status_string': (C.c_char_p, [C.c_int]),
     'eas_event_histogram': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_event_histogram_dat': (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
@@ -106,7 +110,7 @@ PROTOTYPES = {
     'eas_conv_wgrad_parts': (C.c_int, [C.c_int] * 7),
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
     'eas_conv_fwd_planes': (C.c_int, [_P] * 4 + [C.c_int] * 7 + [_P, C.c_int, _P]),
-    'eas_spike_planes_from_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
+    'eas_spike_planes_from_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P]),
     'eas_spike_planes_to_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
     'eas_conv_fwd_stats': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P, _P, C.c_int, _P]),
     'eas_conv_fwd_stats_blocks': (C.c_int, [C.c_int] * 8),
@@ -161,7 +165,7 @@ def lib():
             fn = getattr(handle, name)      # AttributeError = ABI mismatch, also loud
             fn.restype = res
             fn.argtypes = args
-        if handle.eas_abi_version() != 4:
+        if handle.eas_abi_version() != ABI_VERSION:
             raise EasHipError('libeas_hip.so ABI version mismatch; rebuild')
         _lib = handle
     return _lib

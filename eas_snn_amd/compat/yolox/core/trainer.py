@@ -432,6 +432,8 @@ class Trainer:
             self.log.append(dict(epoch=self.epoch, iter=self.iter, loss=float(loss), lr=lr, iter_time=time.time() - t0))
 
     def save_ckpt(self, ckpt_name, update_best_ckpt=False):
+        if self.device != 'cpu':
+            ops.check_tags('training up to this checkpoint')     # a mis-tagged spike tensor anywhere since the last check: no checkpoint
         if self.rank != 0:
             return
         save_model = self.ema_model.ema if self.use_model_ema else self.bare_model

@@ -329,7 +329,7 @@ int eas_arsnn_step_fwd(const float* conv_in, const float* conv_rec, const float*
         return EAS_ERR_INVALID_ARG;
     StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, 1.0f, (int64_t)C2 * HW, (int64_t)N * C2 * HW};
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(arsnn_step_fwd_kernel, dim3(eas_grid_1d(c.total / VEC)), dim3(EAS_BLOCK), 0, eas_s(stream), conv_in,
+    EAS_LAUNCH(arsnn_step_fwd_kernel, dim3(eas_grid_1d(c.total / VEC)), dim3(EAS_BLOCK), 0, eas_s(stream), conv_in,
                        conv_rec, v, vsum, seg, t_last, agg, v_out, vsum_out, spike_out, gate_save, vn_save, seg_before,
                        t_last_before, c);
     EAS_CHECK_LAUNCH();
@@ -362,11 +362,11 @@ int eas_arsnn_fused_step_fwd(const float* a_in, const float* wr_in, const float*
 #define EAS_FUSED(K_)                                                                                                                        \
     do {                                                                                                                                     \
         if (a_g)                                                                                                                             \
-            hipLaunchKernelGGL((arsnn_fused_step_fwd_kernel<K_, true>), dim3(tiles), dim3(NT), 0, st, a_in, wr_in, b_in, a_g, wr_g, b_g,     \
+            EAS_LAUNCH((arsnn_fused_step_fwd_kernel<K_, true>), dim3(tiles), dim3(NT), 0, st, a_in, wr_in, b_in, a_g, wr_g, b_g,     \
                                r_const, v, vsum, seg, t_last, agg, v_out, vsum_out, spike_out, gate_save, vn_save, seg_before,               \
                                t_last_before, c, N, H, W);                                                                                    \
         else                                                                                                                                 \
-            hipLaunchKernelGGL((arsnn_fused_step_fwd_kernel<K_, false>), dim3(tiles), dim3(NT), 0, st, a_in, wr_in, b_in, a_g, wr_g, b_g,    \
+            EAS_LAUNCH((arsnn_fused_step_fwd_kernel<K_, false>), dim3(tiles), dim3(NT), 0, st, a_in, wr_in, b_in, a_g, wr_g, b_g,    \
                                r_const, v, vsum, seg, t_last, agg, v_out, vsum_out, spike_out, gate_save, vn_save, seg_before,               \
                                t_last_before, c, N, H, W);                                                                                    \
     } while (0)
@@ -391,7 +391,7 @@ int eas_arsnn_step_bwd(const float* g_v_out, const float* g_vsum_out, const floa
     StepCfg c{t, Ts, readout, spike_attach, soft_reset, thresh, v_reset, sg_alpha, (int64_t)C2 * HW,
               (int64_t)N * C2 * HW};
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(arsnn_step_bwd_kernel, dim3(eas_grid_1d(c.total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_v_out,
+    EAS_LAUNCH(arsnn_step_bwd_kernel, dim3(eas_grid_1d(c.total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_v_out,
                        g_vsum_out, g_spike, g_agg, v_prev, vsum_prev, gate_save, vn_save, seg_before, t_last_before, g_conv,
                        g_v_prev, g_vsum_prev, c);
     EAS_CHECK_LAUNCH();
@@ -406,7 +406,7 @@ int eas_arsnn_tail_fwd(const float* v, const float* vsum, const float* spike_las
         return EAS_ERR_INVALID_ARG;
     const int64_t total = (int64_t)N * C2 * HW;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(arsnn_tail_fwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), v, vsum,
+    EAS_LAUNCH(arsnn_tail_fwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), v, vsum,
                        spike_last, seg, t_last, agg, Tm, Ts, readout, write_zero, total);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -420,7 +420,7 @@ int eas_arsnn_tail_bwd(const float* g_agg, const float* spike_last, const int8_t
         return EAS_ERR_INVALID_ARG;
     const int64_t total = (int64_t)N * C2 * HW;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(arsnn_tail_bwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_agg, spike_last,
+    EAS_LAUNCH(arsnn_tail_bwd_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), g_agg, spike_last,
                        seg, t_last, g_v, g_vsum, Tm, Ts, readout, write_zero, total);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

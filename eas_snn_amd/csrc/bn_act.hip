@@ -236,7 +236,7 @@ int eas_bn_silu_fwd_ex(const float* y, float* mean, float* invstd, const float* 
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin,
+    EAS_LAUNCH(bn_silu_fwd_kernel, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean, invstd, gamma, beta, out, N, C, HW, fin,
                        out_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -267,7 +267,7 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
         constexpr int GPT = 6;
         const int64_t groups = (int64_t)N * (HW / VEC);
         if (small_ok && C >= 64 && groups <= 1024 * GPT) {
-#define EAS_SMALL(NT_) hipLaunchKernelGGL((bn_silu_bwd_small_kernel<NT_, GPT>), dim3(C), dim3(NT_), 0, st, grad_out, y, mean, invstd, gamma, beta, \
+#define EAS_SMALL(NT_) EAS_LAUNCH((bn_silu_bwd_small_kernel<NT_, GPT>), dim3(C), dim3(NT_), 0, st, grad_out, y, mean, invstd, gamma, beta, \
                                            batch_stats, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot)
             if (groups <= 256 * GPT) EAS_SMALL(256);
             else if (groups <= 512 * GPT) EAS_SMALL(512);
@@ -277,10 +277,10 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
             return EAS_OK;
         }
     }
-    hipLaunchKernelGGL(bn_silu_bwd_kernel<false>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
+    EAS_LAUNCH(bn_silu_bwd_kernel<false>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
                        batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_silu_bwd_kernel<true>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
+    EAS_LAUNCH(bn_silu_bwd_kernel<true>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
                        batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

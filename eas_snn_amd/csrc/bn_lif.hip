@@ -474,7 +474,7 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
         // spike planes out: the statistics are finalized by their own small launch (a block of this kernel owns 8 channels: finalizing
         // them inside every block would cost 8x the partial-sum traffic), then one thread = 8 channels x PV pixels
         if (fin.part) {              // publishes mean / invstd (the arrays this launch was given) and updates the running statistics
-            hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(EAS_BLOCK), 0, st, fin);
+            EAS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(EAS_BLOCK), 0, st, fin);
             EAS_CHECK_LAUNCH();
         }
         // one pixel per thread: 8 x T dword loads (each channel row contiguous over the lanes) and T 16-byte stores, few registers, many
@@ -482,14 +482,14 @@ int launch_fwd_t(const float* y, const float* mean, const float* invstd, const f
         // 1.10 ms for the fp32-writing kernel)
         constexpr int PV = 1;
         const int chunks = pick_chunks((int64_t)N * (HW / PV), C / 8);
-        hipLaunchKernelGGL((bn_lif_fwd_sp_kernel<T_, HARD, DI, STRICT, PV>), EAS_CHAN_GRID(chunks, C / 8), dim3(EAS_BLOCK), 0, st, y,
+        EAS_LAUNCH((bn_lif_fwd_sp_kernel<T_, HARD, DI, STRICT, PV>), EAS_CHAN_GRID(chunks, C / 8), dim3(EAS_BLOCK), 0, st, y,
                            mean, invstd, gamma, beta, v_in,
                            v_out, p, planes, res_planes, mean_out, N, C, HW, bcast, ox.y_ctot, out_groups, res_groups);
         EAS_CHECK_LAUNCH();
         return EAS_OK;
     }
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
-    hipLaunchKernelGGL((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
+    EAS_LAUNCH((bn_lif_fwd_kernel<T_, HARD, DI, STRICT>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, y, mean,
                        invstd, gamma, beta, v_in, v_out, p, spikes, mean_out, N, C, HW, bcast, fin, ox);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -517,11 +517,11 @@ int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, co
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     // two passes: the BatchNorm backward needs the channel's sums of dz and dz * xhat before any grad_y; pass 2 recomputes the neuron
     // (cheaper than parking dz: measured)
-    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
+    EAS_LAUNCH((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
                        grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
+    EAS_LAUNCH((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
                        grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
                        grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, grad_alpha);
     EAS_CHECK_LAUNCH();
@@ -558,11 +558,11 @@ static int stats_partial(const float* y, int TN, int C, int HW, double* workspac
     int chunks;
     if (HW % VEC == 0 && (((uintptr_t)y) & 15) == 0) {
         chunks = pick_chunks((int64_t)TN * (HW / VEC), C);
-        hipLaunchKernelGGL(bn_stats_partial, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace, Cy);
+        EAS_LAUNCH(bn_stats_partial, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace, Cy);
     } else {
         if (Cy != C) return EAS_ERR_UNSUPPORTED;
         chunks = pick_chunks((int64_t)TN * HW, C);
-        hipLaunchKernelGGL(bn_stats_partial_scalar, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
+        EAS_LAUNCH(bn_stats_partial_scalar, dim3(chunks, C), dim3(EAS_BLOCK), 0, st, y, TN, C, HW, workspace);
     }
     if (hipGetLastError() != hipSuccess) return EAS_ERR_LAUNCH;
     return chunks;
@@ -577,7 +577,7 @@ int eas_bn_stats(const float* y, int TN, int C, int HW, int replicas, float eps,
     EAS_CLEAR_ERR();
     const int chunks = stats_partial(y, TN, C, HW, workspace, 0, st);
     if (chunks < 0) return chunks;
-    hipLaunchKernelGGL(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, replicas, eps,
+    EAS_LAUNCH(bn_stats_finalize, dim3(C), dim3(EAS_WAVE), 0, st, workspace, chunks, (double)TN * HW, replicas, eps,
                        momentum, mean, invstd, running_mean, running_var);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -1,9 +1,63 @@
 // ABI bookkeeping for libeas_hip.so.
 #include "eas_common.h"
 
+#include <cxxabi.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+
+int eas_trace_on = 0;
+namespace {
+std::mutex trace_mu;
+std::set<std::string> trace_names;
+std::set<const void*> trace_seen;
+}  // namespace
+
+void eas_trace_kernel(const void* host_function) {
+    std::lock_guard<std::mutex> lock(trace_mu);
+    if (!trace_seen.insert(host_function).second) return;
+    const char* mangled = hipKernelNameRefByPtr(host_function, nullptr);
+    if (!mangled) {
+        trace_names.insert("?");
+        return;
+    }
+    int status = 0;
+    char* plain = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    trace_names.insert(status == 0 && plain ? plain : mangled);
+    free(plain);
+}
+
 extern "C" {
 
-int eas_abi_version(void) { return 4; }   // 4: sampler convolutions take weights arranged by eas_smallconv_pack_weights; eas_arsnn_fused_step_fwd, eas_smallconv_bwd_input_dual; 3: eas_conv_fwd_stats, EasBnPending.pitch; 2: eas_bn_lif_fwd_ex gained spikes_u8; eas_conv_fwd_u8 / eas_conv_wgrad_u8, *_patan, eas_stacked_hist_event_sum
+// Kernel-instance trace: begin clears the record and switches it on; dump switches it off and writes the distinct device kernel symbols
+// launched in between, newline separated, into buf (capacity cap bytes incl. the terminator); returns the bytes needed.
+void eas_kernel_trace_begin(void) {
+    std::lock_guard<std::mutex> lock(trace_mu);
+    trace_names.clear();
+    trace_seen.clear();
+    eas_trace_on = 1;
+}
+
+int64_t eas_kernel_trace_dump(char* buf, int64_t cap) {
+    std::lock_guard<std::mutex> lock(trace_mu);
+    eas_trace_on = 0;
+    std::string all;
+    for (const auto& n : trace_names) {
+        all += n;
+        all += '\n';
+    }
+    if (buf && cap > 0) {
+        const size_t n = all.size() < (size_t)(cap - 1) ? all.size() : (size_t)(cap - 1);
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)all.size() + 1;
+}
+
+int eas_abi_version(void) { return 5; }   // 5: eas_spike_planes_from_f32 takes the tag-violation flag (and eas_conv_fwd / _stats really write theirs); 4: sampler convolutions take weights arranged by eas_smallconv_pack_weights; eas_arsnn_fused_step_fwd, eas_smallconv_bwd_input_dual; 3: eas_conv_fwd_stats, EasBnPending.pitch; 2: eas_bn_lif_fwd_ex gained spikes_u8; eas_conv_fwd_u8 / eas_conv_wgrad_u8, *_patan, eas_stacked_hist_event_sum
 
 const char* eas_status_string(int status) {
     switch (status) {

@@ -26,6 +26,7 @@ struct C1Geom {
     int MT, KSTEPS;
     double* stats;                    // BatchNorm statistics in the epilogue (eas_conv_fwd_stats): [Cout][stats_nb][2], stats_nb = gridDim.x
     int stats_nb;
+    int* inexact;                     // x_terms == 1 on fp32 input: OR-ed with 1 when a value is not exact in bf16 (NULL: not reported)
 };
 
 // statistics epilogue of the 1x1 kernels: 4 waves of a block = 4 pixel groups of the same WM * 32 channels
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     }
 
     f32x16 acc[WM][WN];
+    unsigned bad = 0;      // XT == 1 on fp32 input: OR of the bit patterns read (tag check, see the end of the channel loop)
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -171,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             bf16x8 b[XT];
+            if constexpr (XT == 1 && !PL) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bad |= __float_as_uint(raw[n][j]);       // exact in bf16 <=> low 16 pattern bits zero
+            }
             to_terms<XT, TIN>(raw[n], b);
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
@@ -203,6 +209,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         step(r1, ks + 1);
     }
     if (ks < g.KSTEPS) step(r0, ks);
+    }
+
+    if constexpr (XT == 1 && !PL) {
+        if (g.inexact && (bad & 0xffffu)) atomicOr(g.inexact, 1);      // a tensor tagged "spikes / small integers" was not
     }
 
     if (g.stats) {
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         yoff[n] = ok ? (long)img * g.Cout * g.HW + p : -1;
     }
     f32x16 acc[WM][WN];
+    unsigned bad = 0;
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -321,7 +332,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
             for (int t = 0; t < 3; ++t) a[m][t] = As[buf][t * WM + m][lane];
         bf16x8 b[WN][XT];
 #pragma unroll
-        for (int n = 0; n < WN; ++n) to_terms<XT, TIN>(raw[n], b[n]);
+        for (int n = 0; n < WN; ++n) {
+            if constexpr (XT == 1 && !PL) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bad |= __float_as_uint(raw[n][j]);       // exact in bf16 <=> low 16 pattern bits zero
+            }
+            to_terms<XT, TIN>(raw[n], b[n]);
+        }
         if constexpr (XT == 1) {
 #pragma unroll
             for (int ta = 2; ta >= 0; --ta)
@@ -410,6 +427,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
     if (ks < g.KSTEPS) step(r0, 0);
     }
 
+    if constexpr (XT == 1 && !PL) {
+        if (g.inexact && (bad & 0xffffu)) atomicOr(g.inexact, 1);      // a tensor tagged "spikes / small integers" was not
+    }
+
     if (g.stats) {
         __shared__ __align__(16) double red[4 * WM * 64 + 2 * EAS_STATS_SCRATCH];      // [wave][WM * 32][2] doubles, then the waves' float patches
         c1_stats<WM, WN>(acc, yoff, red, g, mt0);
@@ -452,7 +473,7 @@ int launch_c1_shared(const float* x, const bf16x8* wp, const float* bias, float*
     tl_c1_blocks = (int)grid.x;
     if (!y) return EAS_OK;            // geometry query
     if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL((conv1x1_mfma_sharedA_kernel<XT, WM, WN, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    EAS_LAUNCH((conv1x1_mfma_sharedA_kernel<XT, WM, WN, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
@@ -462,7 +483,7 @@ int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1G
     tl_c1_blocks = (int)grid.x;
     if (!y) return EAS_OK;            // geometry query
     if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL((conv1x1_mfma_kernel<XT, WM, WN, RAGK, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    EAS_LAUNCH((conv1x1_mfma_kernel<XT, WM, WN, RAGK, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
@@ -471,9 +492,10 @@ int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1G
 // wave-tile choice and launch for a 1x1 convolution; PL: x is a spike-plane tensor (x_terms 1)
 template <bool PL>
 static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                              hipStream_t st, double* stats = nullptr, int stats_nb = 0) {
+                              hipStream_t st, double* stats = nullptr, int stats_nb = 0, int* inexact = nullptr) {
     C1Geom g{};
     g.stats = stats; g.stats_nb = stats_nb;
+    g.inexact = inexact;
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
     g.tiles_per_img = (HW + 31) / 32;
     g.total_tiles = NI * g.tiles_per_img;
@@ -539,10 +561,10 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
 
 // called by eas_conv_fwd (conv_mfma.hip) for ksize == 1, stride == 1; planes != 0: x is a spike-plane tensor
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes) {
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact) {
     tl_c1_blocks = 0;
-    const int rc = planes ? conv1x1_dispatch_t<true>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st, stats, stats_nb)
-                          : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb);
+    const int rc = planes ? conv1x1_dispatch_t<true>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st, stats, stats_nb, nullptr)
+                          : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb, inexact);
     if (nb_out) *nb_out = tl_c1_blocks;
     return rc;
 }
@@ -823,7 +845,7 @@ int launch_w1_lds(const void* x, const float* gy, float* slabs, W1Geom g, int sl
         attr_set = true;
     }
     dim3 grid(slices, ((g.Cout + 32 * WVM - 1) / (32 * WVM)) * g.ci_blocks);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, gy, slabs, g);
+    EAS_LAUNCH(kern, grid, dim3(256), lds, st, x, gy, slabs, g);
     return EAS_OK;
 }
 

@@ -189,11 +189,16 @@ __global__ void conv_pack_weights_many_kernel(const long long* __restrict__ jobs
 // ---------------------------------------------------------------------------------------------------------------
 // 8 consecutive input channels of one staged pixel -> bf16 term(s) -> one 16-byte LDS store per term
 template <int XT>
-__device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride, const float (&v)[8], int* inexact) {
+__device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride, const float (&v)[8], unsigned& bad) {
     if constexpr (XT == 1) {
+        // the caller promised small integers (spikes, SEW sums): exact in bf16 <=> the low 16 bits of the fp32 pattern are zero.  The
+        // patterns are OR-ed into a per-thread register and looked at once, at the end of the kernel (conv_tile_body).
         bf16x8 t0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t0[j] = (__bf16)v[j];
+        for (int j = 0; j < 8; ++j) {
+            bad |= __float_as_uint(v[j]);
+            t0[j] = (__bf16)v[j];
+        }
         *(bf16x8*)dst = t0;
     } else {
         bf16x8 t0, t1, t2;
@@ -332,6 +337,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     // a whole) reads the zero page with channel stride 0, so nothing branches, waits or needs masking around them
     vecf L[NIT][PL ? 1 : 8];
     u32x4 LP[NIT][PL ? VEC : 1];
+    unsigned bad = 0;       // XT == 1 on fp32 input: OR of the staged bit patterns (stage_store)
     auto fetch = [&](int it, int c0) {
         const bool ok = gofs[it] >= 0 && c0 + gch[it] < g.Cin;
         if constexpr (PL) {
@@ -357,7 +363,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = L[it][j][p];
-                stage_store<XT>(buf + lofs[it] + p * 16, term_stride, v, inexact);
+                stage_store<XT>(buf + lofs[it] + p * 16, term_stride, v, bad);
             }
         }
     };
@@ -452,6 +458,10 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
                 if (it * NT < nitems) commit(nxt, it, c1);
         }
         if (!(g.dbg & 16)) __syncthreads();
+    }
+
+    if constexpr (XT == 1 && !PL) {
+        if (inexact && (bad & 0xffffu)) atomicOr(inexact, 1);      // a tensor tagged "spikes / small integers" was not: say so, loudly
     }
 
     // ---- BatchNorm statistics of the tile (block-uniform branch): per-wave sums over its valid pixels by DPP, the WVN waves that share
@@ -568,7 +578,7 @@ int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(gx_blocks, (sg.g[0].MT + WVM * WM - 1) / (WVM * WM), 4);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, gy, gx, sg);
+    EAS_LAUNCH(kern, grid, dim3(64 * WVM * WVN), lds, st, gy, gx, sg);
     return EAS_OK;
 }
 
@@ -589,7 +599,7 @@ int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, in
     conv_geom_magics(g, VEC, CCH);
     dim3 grid((g.total_rows + g.RT - 1) / g.RT, (g.MT + WVM * WM - 1) / (WVM * WM), g.parts);
     if (g.stats && (int)(grid.x * g.parts) != g.stats_nb) return EAS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
+    EAS_LAUNCH(kern, grid, dim3(64 * WVM * WVN), lds, st, x, wp, bias, y, inexact, g);
     return EAS_OK;
 }
 
@@ -703,7 +713,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
 }  // namespace
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes);
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact);
 
 extern "C" {
 
@@ -718,7 +728,7 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
     EAS_CLEAR_ERR();
     const int M = mode ? Cin : Cout, K = mode ? Cout : Cin;
     const int total = ((M + 31) / 32) * ((K + 15) / 16) * ksize * ksize * 64;
-    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin, ksize,
+    EAS_LAUNCH(conv_pack_weights_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), w, (bf16x8*)packed, Cout, Cin, ksize,
                        mode);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -730,7 +740,7 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream) {
     if (!jobs || njobs < 1) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(conv_pack_weights_many_kernel, dim3(24, njobs), dim3(EAS_BLOCK), 0, eas_s(stream), (const long long*)jobs);
+    EAS_LAUNCH(conv_pack_weights_many_kernel, dim3(24, njobs), dim3(EAS_BLOCK), 0, eas_s(stream), (const long long*)jobs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -805,7 +815,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     }
     if (ksize == 1 && stride == 1) {
         int nb1 = 0;
-        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1, planes ? 1 : 0);
+        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1, planes ? 1 : 0, inexact_flag);
         tl_pixel_blocks = nb1;
     }
 #undef EAS_CONV_DISPATCH

@@ -538,7 +538,7 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
     g.ci_blocks = (g.Cin + 32 * PN - 1) / (32 * PN);
     const int co_blocks = (g.Cout + 32 * PM - 1) / (32 * PM);
     dim3 grid(g.kslices, co_blocks * g.ci_blocks);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, x, gy, slabs, g);
+    EAS_LAUNCH(kern, grid, dim3(NT), lds, st, x, gy, slabs, g);
     return EAS_OK;
 }
 
@@ -783,7 +783,7 @@ int eas_conv_wgrad(const float* x, const float* grad_y, float* grad_w, float* wo
     const int slabs = wgrad_partial(x, grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, stream);
     if (slabs < 0) return slabs;
     const int n = Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(workspace, grad_w, n)), dim3(256), 0, eas_s(stream), workspace, grad_w, n, slabs);
+    EAS_LAUNCH(conv_wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(workspace, grad_w, n)), dim3(256), 0, eas_s(stream), workspace, grad_w, n, slabs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -816,7 +816,7 @@ int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_str
             blocks += wgrad_reduce_blocks(q.slabs, q.grad_w, q.n);
         }
         a.first_block[a.njobs] = blocks;
-        hipLaunchKernelGGL(conv_wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, eas_s(stream), a);
+        EAS_LAUNCH(conv_wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, eas_s(stream), a);
         EAS_CHECK_LAUNCH();
     }
     return EAS_OK;

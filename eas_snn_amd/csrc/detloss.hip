@@ -205,7 +205,7 @@ int eas_det_decode(int L, const float* const* reg, const float* const* obj, cons
     if (int rc = fill_levels(d, L, reg, obj, cls, nullptr, nullptr, nullptr, hw, strides, B, nc)) return rc;
     if (!dec) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(det_decode_kernel, dim3(eas_grid_1d((int64_t)B * d.A)), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec);
+    EAS_LAUNCH(det_decode_kernel, dim3(eas_grid_1d((int64_t)B * d.A)), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -227,10 +227,10 @@ int eas_det_loss(int L, const float* const* reg, const float* const* obj, const 
         if (!d.g_reg[l] || !d.g_obj[l] || !d.g_cls[l]) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
     const int blocks = eas_grid_1d((int64_t)B * d.A, EAS_BLOCK, 1024);
-    hipLaunchKernelGGL(det_loss_kernel, dim3(blocks), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec, gt_boxes, gt_cls, G, fg, matched, matched_iou,
+    EAS_LAUNCH(det_loss_kernel, dim3(blocks), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec, gt_boxes, gt_cls, G, fg, matched, matched_iou,
                        use_l1, workspace);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(det_loss_finalize, dim3(1), dim3(EAS_BLOCK), 0, eas_s(stream), workspace, blocks, num_gts, use_l1, out);
+    EAS_LAUNCH(det_loss_finalize, dim3(1), dim3(EAS_BLOCK), 0, eas_s(stream), workspace, blocks, num_gts, use_l1, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -18,6 +18,18 @@
 
 static inline hipStream_t eas_s(eas_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Kernel-instance trace (eas_kernel_trace_begin / _dump, capi.hip): while it is on, every launch of the library records the symbol of
+// the device kernel it starts -- the names rocprofv3 reports.  tests/test_gpu_bench_shapes.py uses it to prove that every kernel
+// instance a bench step launches is also launched by a test that compares with fp64 / the oracle.  One predictable branch when off.
+extern int eas_trace_on;
+void eas_trace_kernel(const void* host_function);
+#define EAS_LAUNCH(kern, ...)                                                \
+    do {                                                                     \
+        auto eas_kern_ = (kern);                                             \
+        if (eas_trace_on) eas_trace_kernel((const void*)eas_kern_);          \
+        hipLaunchKernelGGL(eas_kern_, __VA_ARGS__);                          \
+    } while (0)
+
 // memory-bound grids: cap at 256 CUs x 8 blocks and grid-stride the rest
 static inline int eas_grid_1d(int64_t work_items, int block = EAS_BLOCK, int max_blocks = 2048 * 4) {
     int64_t b = (work_items + block - 1) / block;

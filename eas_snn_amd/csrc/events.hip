@@ -642,7 +642,7 @@ static int histogram_impl(const uint32_t* t, const uint16_t* x, const uint16_t* 
         // LDS: packed [2][r16][W] halves, or the fallback's [2][ceil(r16 / 2)][W] words -- the larger of the two
         const size_t lds16 = (size_t)4 * (((size_t)2 * r16 * W + 1) / 2 > (size_t)2 * ((r16 + 1) / 2) * W ? ((size_t)2 * r16 * W + 1) / 2
                                                                                                         : (size_t)2 * ((r16 + 1) / 2) * W);
-        hipLaunchKernelGGL(event_hist_banded16_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), lds16, st, t, x, y, p,
+        EAS_LAUNCH(event_hist_banded16_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), lds16, st, t, x, y, p,
                            sample_offsets, nev, B, Tm, H, W, r16, nb, out, oob_count, canvas, Hc, Wc);
         EAS_CHECK_LAUNCH();
         if (canvas && wrote_canvas) *wrote_canvas = 1;
@@ -658,7 +658,7 @@ static int histogram_impl(const uint32_t* t, const uint16_t* x, const uint16_t* 
         }
         const int nb = (H + rows - 1) / rows;
         const int64_t groups = ((int64_t)B * Tm + 7) / 8;
-        hipLaunchKernelGGL(event_hist_banded_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), (size_t)2 * rows * W * 4, st, t, x, y,
+        EAS_LAUNCH(event_hist_banded_kernel, dim3((unsigned)(groups * 8 * nb)), dim3(kBandThreads), (size_t)2 * rows * W * 4, st, t, x, y,
                            p, sample_offsets, B, Tm, H, W, rows, nb, out, oob_count, canvas, Hc, Wc);
         EAS_CHECK_LAUNCH();
         if (canvas && wrote_canvas) *wrote_canvas = 1;
@@ -668,10 +668,10 @@ static int histogram_impl(const uint32_t* t, const uint16_t* x, const uint16_t* 
     if (nev == 0) return EAS_OK;
     const bool vec = (((uintptr_t)t & 15) | ((uintptr_t)x & 7) | ((uintptr_t)y & 7) | ((uintptr_t)p & 3)) == 0;
     if (vec) {
-        hipLaunchKernelGGL(event_hist_kernel<true>, dim3(eas_grid_1d((nev + 3) / 4)), dim3(EAS_BLOCK), 0, st, t, x, y, p,
+        EAS_LAUNCH(event_hist_kernel<true>, dim3(eas_grid_1d((nev + 3) / 4)), dim3(EAS_BLOCK), 0, st, t, x, y, p,
                            nev, sample_offsets, B, Tm, H, W, out, oob_count);
     } else {
-        hipLaunchKernelGGL(event_hist_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev,
+        EAS_LAUNCH(event_hist_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev,
                            sample_offsets, B, Tm, H, W, out, oob_count);
     }
     EAS_CHECK_LAUNCH();
@@ -689,7 +689,7 @@ int eas_event_window_search(const void* records, const int64_t* file_offsets, in
     if (!records || !file_offsets || !label_t || !ranges || F < 1 || B < 1 || window_hi - window_lo < 1 || num_slice < 0) return EAS_ERR_INVALID_ARG;
     if ((uintptr_t)records & 7) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(event_window_search_kernel, dim3((B + EAS_WAVE - 1) / EAS_WAVE), dim3(EAS_WAVE), 0, eas_s(stream), (const uint2*)records,
+    EAS_LAUNCH(event_window_search_kernel, dim3((B + EAS_WAVE - 1) / EAS_WAVE), dim3(EAS_WAVE), 0, eas_s(stream), (const uint2*)records,
                        file_offsets, file_id, label_t, B, window_lo, window_hi, num_slice, ranges);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -703,7 +703,7 @@ int eas_event_histogram_dat_ranges(const void* records, const int64_t* ranges, i
     if (hipMemsetAsync(out, 0, (size_t)B * Tm * 2 * H * W * sizeof(int32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (oob_count && hipMemsetAsync(oob_count, 0, sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
     // the ranges live on the device (no host read): a fixed number of blocks per sample strides over whatever it holds
-    hipLaunchKernelGGL(event_hist_dat_ranges_kernel, dim3(64, B), dim3(EAS_BLOCK), 0, st, (const uint2*)records, ranges, Tm, H, W, out, oob_count);
+    EAS_LAUNCH(event_hist_dat_ranges_kernel, dim3(64, B), dim3(EAS_BLOCK), 0, st, (const uint2*)records, ranges, Tm, H, W, out, oob_count);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -732,10 +732,10 @@ int eas_event_histogram_dat(const void* records, int64_t nev, const int64_t* sam
     if (nev == 0) return EAS_OK;
     const uint2* rec = (const uint2*)records;
     if (((uintptr_t)records & 15) == 0)
-        hipLaunchKernelGGL(event_hist_dat_kernel<true>, dim3(eas_grid_1d((nev + 1) / 2)), dim3(EAS_BLOCK), 0, st, rec, nev, sample_offsets, B,
+        EAS_LAUNCH(event_hist_dat_kernel<true>, dim3(eas_grid_1d((nev + 1) / 2)), dim3(EAS_BLOCK), 0, st, rec, nev, sample_offsets, B,
                            Tm, H, W, out, oob_count);
     else
-        hipLaunchKernelGGL(event_hist_dat_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, rec, nev, sample_offsets, B, Tm, H,
+        EAS_LAUNCH(event_hist_dat_kernel<false>, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, rec, nev, sample_offsets, B, Tm, H,
                            W, out, oob_count);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -746,7 +746,7 @@ int eas_counts_to_canvas(const int32_t* counts, int64_t F, int H, int W, int Hc,
     if (!counts || !out || F < 0 || H < 1 || W < 1 || Hc < H || Wc < W) return EAS_ERR_INVALID_ARG;
     if (F == 0) return EAS_OK;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(counts_to_canvas_kernel, dim3(eas_grid_1d(F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
+    EAS_LAUNCH(counts_to_canvas_kernel, dim3(eas_grid_1d(F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
                        F, H, W, Hc, Wc, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -761,7 +761,7 @@ int eas_event_voxel_grid(const uint32_t* t, const uint16_t* x, const uint16_t* y
     EAS_CLEAR_ERR();
     if (hipMemsetAsync(out, 0, (size_t)B * n_bins * H * W * sizeof(double), st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (nev == 0) return EAS_OK;
-    hipLaunchKernelGGL(voxel_grid_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets,
+    EAS_LAUNCH(voxel_grid_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets,
                        B, n_bins, H, W, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -776,7 +776,7 @@ int eas_event_voxel_cube(const uint32_t* t, const uint16_t* x, const uint16_t* y
     EAS_CLEAR_ERR();
     if (hipMemsetAsync(out, 0, (size_t)B * num_slices * 2 * tbins * H * W * sizeof(int32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (nev == 0) return EAS_OK;
-    hipLaunchKernelGGL(voxel_cube_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets, B, num_slices,
+    EAS_LAUNCH(voxel_cube_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets, B, num_slices,
                        tbins, H, W, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -792,11 +792,11 @@ int eas_event_time_surface(const uint32_t* t, const uint16_t* x, const uint16_t*
     const int64_t total = (int64_t)B * num_slices * 2 * H * W;
     if (hipMemsetAsync(workspace, 0, (size_t)total * sizeof(uint32_t), st) != hipSuccess) return EAS_ERR_LAUNCH;
     if (nev > 0) {
-        hipLaunchKernelGGL(time_surface_scatter_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets, B,
+        EAS_LAUNCH(time_surface_scatter_kernel, dim3(eas_grid_1d(nev)), dim3(EAS_BLOCK), 0, st, t, x, y, p, nev, sample_offsets, B,
                            num_slices, H, W, workspace);
         EAS_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(time_surface_exp_kernel, dim3(eas_grid_1d((int64_t)B * 2 * H * W)), dim3(EAS_BLOCK), 0, st, t, sample_offsets, B,
+    EAS_LAUNCH(time_surface_exp_kernel, dim3(eas_grid_1d((int64_t)B * 2 * H * W)), dim3(EAS_BLOCK), 0, st, t, sample_offsets, B,
                        num_slices, H, W, tau, workspace, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -806,7 +806,7 @@ int eas_counts_letterbox(const int32_t* counts, const int32_t* params, int B, in
                          eas_stream_t stream) {
     if (!counts || !params || !out || B < 1 || F < 1 || H < 1 || W < 1 || Hc < 1 || Wc < 1) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(counts_letterbox_kernel, dim3(eas_grid_1d((int64_t)B * F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
+    EAS_LAUNCH(counts_letterbox_kernel, dim3(eas_grid_1d((int64_t)B * F * Hc * Wc)), dim3(EAS_BLOCK), 0, eas_s(stream), counts,
                        params, B, F, H, W, Hc, Wc, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -122,7 +122,7 @@ int eas_upcat_fwd(const float* a, const float* b, float* out, int64_t M, int Ca,
     if (int rc = check_geom(g)) return rc;
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(eas_grid_1d(M * (Ca + Cb) * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), a, b, out, g);
+    EAS_LAUNCH(upcat_fwd_kernel, dim3(eas_grid_1d(M * (Ca + Cb) * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), a, b, out, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -133,7 +133,7 @@ int eas_upcat_bwd(const float* grad_out, float* grad_a, float* grad_b, int64_t M
     if (int rc = check_geom(g)) return rc;
     if (((uintptr_t)grad_out | (uintptr_t)grad_a | (uintptr_t)grad_b) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(upcat_bwd_kernel, dim3(eas_grid_1d(M * Ca * H * (W / 2) + M * Cb * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0,
+    EAS_LAUNCH(upcat_bwd_kernel, dim3(eas_grid_1d(M * Ca * H * (W / 2) + M * Cb * H * up * (W * up / 4))), dim3(EAS_BLOCK), 0,
                        eas_s(stream), grad_out, grad_a, grad_b, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -145,7 +145,7 @@ int eas_focus(const float* src, float* dst, int64_t M, int C, int Ho, int Wo, in
     if (Wo % 2 != 0) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)src | (uintptr_t)dst) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(focus_kernel, dim3(eas_grid_1d(M * C * Ho * (Wo / 2))), dim3(EAS_BLOCK), 0, eas_s(stream), src, dst, (long long)M, C, Ho, Wo,
+    EAS_LAUNCH(focus_kernel, dim3(eas_grid_1d(M * C * Ho * (Wo / 2))), dim3(EAS_BLOCK), 0, eas_s(stream), src, dst, (long long)M, C, Ho, Wo,
                        inverse);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -235,13 +235,13 @@ int launch_fwd(const float* x, const float* v_in, float* v_out, EasLifParams p, 
     const int grid = eas_grid_1d(M % VEC == 0 ? M / VEC : M);
 #define EAS_CASE(TT)                                                                                              \
     case TT:                                                                                                      \
-        hipLaunchKernelGGL((lif_fwd_kernel<TT, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, x, v_in, v_out, \
+        EAS_LAUNCH((lif_fwd_kernel<TT, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, x, v_in, v_out, \
                            p, spikes, h_save, mean_out, T, M);                                                       \
         break;
     switch (T) {
         EAS_CASE(1) EAS_CASE(2) EAS_CASE(3) EAS_CASE(4) EAS_CASE(5) EAS_CASE(6) EAS_CASE(7) EAS_CASE(8)
         default:
-            hipLaunchKernelGGL((lif_fwd_kernel<0, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, x, v_in, v_out, p,
+            EAS_LAUNCH((lif_fwd_kernel<0, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, x, v_in, v_out, p,
                                spikes, h_save, mean_out, T, M);
     }
 #undef EAS_CASE
@@ -257,11 +257,11 @@ int launch_bwd(const float* grad_s, const float* grad_mean, const float* h_save,
     if (grid > kReduceBlocks) grid = kReduceBlocks;
     float* partial = grad_w ? workspace : nullptr;
     float* partial_a = grad_alpha ? workspace + kReduceBlocks : nullptr;
-    hipLaunchKernelGGL((lif_bwd_kernel<0, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean,
+    EAS_LAUNCH((lif_bwd_kernel<0, HARD, DI, STRICT>), dim3(grid), dim3(EAS_BLOCK), 0, st, grad_s, grad_mean,
                        h_save, v_init, x, p, sg, alpha, alpha_dev, grad_x, partial, partial_a, T, M);
     EAS_CHECK_LAUNCH();
     if (grad_w || grad_alpha) {
-        hipLaunchKernelGGL(lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, partial, grid, p.w_logit, grad_w, partial_a, alpha_dev,
+        EAS_LAUNCH(lif_gradw_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, partial, grid, p.w_logit, grad_w, partial_a, alpha_dev,
                            grad_alpha);
         EAS_CHECK_LAUNCH();
     }
@@ -348,7 +348,7 @@ int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t str
     if (M == 0) return EAS_OK;
     if (((uintptr_t)x | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(time_mean_kernel, dim3(eas_grid_1d(M % VEC == 0 ? M / VEC : M)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, T, M);
+    EAS_LAUNCH(time_mean_kernel, dim3(eas_grid_1d(M % VEC == 0 ? M / VEC : M)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, T, M);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

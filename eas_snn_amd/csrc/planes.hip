@@ -16,9 +16,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // thread = 4 consecutive pixels of one 8-channel group of one image
 __global__ __launch_bounds__(EAS_BLOCK) void planes_from_f32_kernel(const float* __restrict__ x, bf16x8* __restrict__ planes, int64_t NI, int C, int HW,
-                                                                    int src_ctot, int dst_gtot) {
+                                                                    int src_ctot, int dst_gtot, int* __restrict__ inexact) {
     const int G = C / 8, hw4 = HW / 4;
     const int64_t total = NI * G * hw4;
+    unsigned bad = 0;      // OR of the bit patterns: a value is exact in bf16 <=> the low 16 bits of its fp32 pattern are zero
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int q = (int)(i % hw4);
         const int64_t r = i / hw4;
@@ -32,10 +33,15 @@ __global__ __launch_bounds__(EAS_BLOCK) void planes_from_f32_kernel(const float*
         for (int e = 0; e < 4; ++e) {
             bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)reinterpret_cast<const float*>(&v[j])[e];
+            for (int j = 0; j < 8; ++j) {
+                const float f = reinterpret_cast<const float*>(&v[j])[e];
+                bad |= __float_as_uint(f);
+                o[j] = (__bf16)f;
+            }
             dst[e] = o;
         }
     }
+    if (inexact && (bad & 0xffffu)) atomicOr(inexact, 1);      // a tensor promised to hold spikes / small integers does not
 }
 
 __global__ __launch_bounds__(EAS_BLOCK) void planes_to_f32_kernel(const bf16x8* __restrict__ planes, float* __restrict__ x, int64_t NI, int C, int HW,
@@ -80,14 +86,16 @@ __global__ __launch_bounds__(EAS_BLOCK) void upcat_planes_kernel(const bf16x8* _
 extern "C" {
 
 // x [NI][C][HW] fp32 (channels of a [NI][src_ctot][HW] tensor, pointer at the first; 0 = C) -> planes [NI][C/8][HW][8] bf16 (groups of a
-// [NI][dst_ctot/8][HW][8] tensor, pointer at the first group).  Values must be exact in bf16 (spikes, small integers).
-int eas_spike_planes_from_f32(const float* x, int src_ctot, void* planes, int dst_ctot, int64_t NI, int C, int HW, eas_stream_t stream) {
+// [NI][dst_ctot/8][HW][8] tensor, pointer at the first group).  Values must be exact in bf16 (spikes, small integers):
+// *inexact_flag, if not NULL, is OR-ed with 1 when one is not.
+int eas_spike_planes_from_f32(const float* x, int src_ctot, void* planes, int dst_ctot, int64_t NI, int C, int HW, int* inexact_flag,
+                              eas_stream_t stream) {
     if (!x || !planes || NI < 1 || C < 1 || HW < 1) return EAS_ERR_INVALID_ARG;
     if (C % 8 != 0 || HW % 4 != 0 || (src_ctot && src_ctot < C) || (dst_ctot && (dst_ctot < C || dst_ctot % 8 != 0))) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)planes) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(planes_from_f32_kernel, dim3(eas_grid_1d(NI * (C / 8) * (HW / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), x, (bf16x8*)planes, NI, C, HW,
-                       src_ctot ? src_ctot : C, (dst_ctot ? dst_ctot : C) / 8);
+    EAS_LAUNCH(planes_from_f32_kernel, dim3(eas_grid_1d(NI * (C / 8) * (HW / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), x, (bf16x8*)planes, NI, C, HW,
+                       src_ctot ? src_ctot : C, (dst_ctot ? dst_ctot : C) / 8, inexact_flag);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -98,7 +106,7 @@ int eas_spike_planes_to_f32(const void* planes, int src_ctot, float* x, int dst_
     if (C % 8 != 0 || HW % 4 != 0 || (dst_ctot && dst_ctot < C) || (src_ctot && (src_ctot < C || src_ctot % 8 != 0))) return EAS_ERR_UNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)planes) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(planes_to_f32_kernel, dim3(eas_grid_1d(NI * (C / 8) * (HW / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), (const bf16x8*)planes, x, NI, C,
+    EAS_LAUNCH(planes_to_f32_kernel, dim3(eas_grid_1d(NI * (C / 8) * (HW / 4))), dim3(EAS_BLOCK), 0, eas_s(stream), (const bf16x8*)planes, x, NI, C,
                        HW, (src_ctot ? src_ctot : C) / 8, dst_ctot ? dst_ctot : C);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
@@ -113,7 +121,7 @@ int eas_upcat_planes_fwd(const void* a, const void* b, void* out, int64_t M, int
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
     const int64_t total = M * ((Ca + Cb) / 8) * (int64_t)H * up * W * up;
-    hipLaunchKernelGGL(upcat_planes_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), (const bf16x8*)a, (const bf16x8*)b,
+    EAS_LAUNCH(upcat_planes_kernel, dim3(eas_grid_1d(total)), dim3(EAS_BLOCK), 0, eas_s(stream), (const bf16x8*)a, (const bf16x8*)b,
                        (bf16x8*)out, M, Ca / 8, Cb / 8, H, W, up);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -180,7 +180,7 @@ int eas_spp_pool_fwd(const float* x, float* out, int64_t N, int C, int H, int W,
     SppGeom g;
     if (int rc = make_geom(g, N, C, H, W, k0, k1, k2)) return rc;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(spp_fwd_kernel, dim3((unsigned)((g.planes + g.ppb - 1) / g.ppb)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, g);
+    EAS_LAUNCH(spp_fwd_kernel, dim3((unsigned)((g.planes + g.ppb - 1) / g.ppb)), dim3(EAS_BLOCK), 0, eas_s(stream), x, out, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -191,7 +191,7 @@ int eas_spp_pool_bwd(const float* x, const float* grad_out, float* grad_x, int64
     SppGeom g;
     if (int rc = make_geom(g, N, C, H, W, k0, k1, k2)) return rc;
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(spp_bwd_kernel, dim3((unsigned)((g.planes + g.ppb - 1) / g.ppb)), dim3(EAS_BLOCK), 0, eas_s(stream), x, grad_out, grad_x, g);
+    EAS_LAUNCH(spp_bwd_kernel, dim3((unsigned)((g.planes + g.ppb - 1) / g.ppb)), dim3(EAS_BLOCK), 0, eas_s(stream), x, grad_out, grad_x, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

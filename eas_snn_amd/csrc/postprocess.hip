@@ -208,11 +208,11 @@ int eas_postprocess(const float* pred, int B, int A, int ncls, float conf_thre, 
         if (hipFuncSetAttribute((const void*)pp_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxCand * 8) != hipSuccess) return EAS_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pp_sort_kernel, dim3(B), dim3(kSortThreads), lds, st, pred, A, ncls, conf_thre, NP, class_agnostic, ws);
+    EAS_LAUNCH(pp_sort_kernel, dim3(B), dim3(kSortThreads), lds, st, pred, A, ncls, conf_thre, NP, class_agnostic, ws);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pp_mask_kernel, dim3(words, words, B), dim3(EAS_WAVE), 0, st, A, words, nms_thre, class_agnostic, ws);
+    EAS_LAUNCH(pp_mask_kernel, dim3(words, words, B), dim3(EAS_WAVE), 0, st, A, words, nms_thre, class_agnostic, ws);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pp_scan_kernel, dim3(B), dim3(EAS_WAVE), 0, st, A, words, ws, out, out_count);
+    EAS_LAUNCH(pp_scan_kernel, dim3(B), dim3(EAS_WAVE), 0, st, A, words, ws, out, out_count);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

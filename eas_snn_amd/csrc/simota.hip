@@ -199,7 +199,7 @@ static int simota_launch(const float* grids, const float* strides, const float* 
         if (hipFuncSetAttribute((const void*)simota_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 25) != hipSuccess) return EAS_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(simota_kernel, dim3(B), dim3(SB), lds, eas_s(stream), grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls, fg,
+    EAS_LAUNCH(simota_kernel, dim3(B), dim3(SB), lds, eas_s(stream), grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls, fg,
                        matched, matched_iou, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

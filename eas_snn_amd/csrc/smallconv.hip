@@ -305,9 +305,9 @@ int launch_conv_k(int k, const float* x, const float* wr, const float* b, const 
     const bool vecw = (W & 3) == 0 && (((uintptr_t)x) & 15) == 0;
 #define EAS_SC(K_)                                                                                                                             \
     do {                                                                                                                                       \
-        if (vecw) hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, K_, DUAL, true>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, \
+        if (vecw) EAS_LAUNCH((smallconv_kernel<CIN, COUT, K_, DUAL, true>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, \
                                      N, H, W, relu);                                                                                           \
-        else hipLaunchKernelGGL((smallconv_kernel<CIN, COUT, K_, DUAL, false>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N,  \
+        else EAS_LAUNCH((smallconv_kernel<CIN, COUT, K_, DUAL, false>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N,  \
                                 H, W, relu);                                                                                                   \
     } while (0)
     switch (k) {
@@ -324,9 +324,9 @@ int launch_conv_k(int k, const float* x, const float* wr, const float* b, const 
 template <int CIN, int COUT>
 int launch_wgrad_k(int k, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
     switch (k) {
-        case 3: hipLaunchKernelGGL((smallconv_wgrad_kernel<CIN, COUT, 3>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
-        case 5: hipLaunchKernelGGL((smallconv_wgrad_kernel<CIN, COUT, 5>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
-        case 7: hipLaunchKernelGGL((smallconv_wgrad_kernel<CIN, COUT, 7>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
+        case 3: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 3>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
+        case 5: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 5>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
+        case 7: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 7>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
         default: return EAS_ERR_UNSUPPORTED;
     }
     EAS_CHECK_LAUNCH();
@@ -367,7 +367,7 @@ int eas_smallconv_pack_weights(const EasSmallconvPackJob* jobs, int njobs, eas_s
         pj.o_total[j] = q.o_total; pj.o_off[j] = q.o_off;
     }
     EAS_CLEAR_ERR();
-    hipLaunchKernelGGL(smallconv_pack_kernel, dim3(njobs), dim3(256), 0, eas_s(stream), pj);
+    EAS_LAUNCH(smallconv_pack_kernel, dim3(njobs), dim3(256), 0, eas_s(stream), pj);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
@@ -431,7 +431,7 @@ int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w,
         if (rc != EAS_OK) return rc;
     }
     const int nw = Cout * Cin * k * k, nout = nw + Cout;
-    hipLaunchKernelGGL(smallconv_wgrad_finalize, dim3(nout), dim3(EAS_WAVE), 0, st, workspace, nblocks, nout, nw,
+    EAS_LAUNCH(smallconv_wgrad_finalize, dim3(nout), dim3(EAS_WAVE), 0, st, workspace, nblocks, nout, nw,
                        grad_w, grad_b);
     EAS_CHECK_LAUNCH();
     return EAS_OK;

@@ -408,9 +408,9 @@ int sw_launch_k(bool vec, const float* gy, const float* x, float* partial, int n
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(4 * NTH), 2 * S::STAGE_BYTES, st, gy, x, partial, N, H, W);
+        EAS_LAUNCH(kern, dim3(nblocks), dim3(4 * NTH), 2 * S::STAGE_BYTES, st, gy, x, partial, N, H, W);
     } else {
-        hipLaunchKernelGGL((smallconv_wgrad_mfma_kernel<CIN, COUT, K, false>), dim3(nblocks), dim3(NTH), S::LDS_BYTES, st, gy, x, partial, N, H, W);
+        EAS_LAUNCH((smallconv_wgrad_mfma_kernel<CIN, COUT, K, false>), dim3(nblocks), dim3(NTH), S::LDS_BYTES, st, gy, x, partial, N, H, W);
     }
     return EAS_OK;
 }

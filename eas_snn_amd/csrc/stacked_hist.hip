@@ -100,9 +100,9 @@ extern "C" int eas_stacked_hist_event_sum(const uint8_t* hist, const int32_t* n_
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     if (nbins == 10)
-        hipLaunchKernelGGL((stacked_hist_sum_kernel<10>), dim3(grid), dim3(EAS_BLOCK), 0, st, hist, n_valid, Tm, nbins, H, W, Hc, Wc, out, groups);
+        EAS_LAUNCH((stacked_hist_sum_kernel<10>), dim3(grid), dim3(EAS_BLOCK), 0, st, hist, n_valid, Tm, nbins, H, W, Hc, Wc, out, groups);
     else
-        hipLaunchKernelGGL((stacked_hist_sum_kernel<0>), dim3(grid), dim3(EAS_BLOCK), 0, st, hist, n_valid, Tm, nbins, H, W, Hc, Wc, out, groups);
+        EAS_LAUNCH((stacked_hist_sum_kernel<0>), dim3(grid), dim3(EAS_BLOCK), 0, st, hist, n_valid, Tm, nbins, H, W, Hc, Wc, out, groups);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -92,9 +92,9 @@ int eas_spike_sop(const float* x, int64_t NI, int Cin, int H, int W, int ksize, 
     EAS_CLEAR_ERR();
     const int64_t planes = NI * Cin, total = planes * H * W;
     const int blocks = eas_grid_1d((total + 3) / 4, EAS_BLOCK, kMaxBlocks);
-    hipLaunchKernelGGL(spike_sop_partial, dim3(blocks), dim3(EAS_BLOCK), 0, st, x, planes, H, W, ksize, stride, workspace);
+    EAS_LAUNCH(spike_sop_partial, dim3(blocks), dim3(EAS_BLOCK), 0, st, x, planes, H, W, ksize, stride, workspace);
     EAS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(spike_sop_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, workspace, blocks, (double)Cout, out);
+    EAS_LAUNCH(spike_sop_finalize, dim3(1), dim3(EAS_BLOCK), 0, st, workspace, blocks, (double)Cout, out);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -99,8 +99,36 @@ def set_timer(timer):
     _TIMER = timer
 
 
+_CALL_LOG = None     # test infrastructure (``kernel_trace``): list of (C-ABI symbol, argument tuple) of every call made through _call
+
+
+class kernel_trace:
+    """``with ops.kernel_trace() as tr:`` -- afterwards ``tr.kernels`` holds the distinct device kernel symbols the library launched inside
+    the block (the names rocprofv3 reports; eas_kernel_trace_begin / _dump) and ``tr.calls`` the C-ABI calls made through the operators
+    with their arguments.  Test infrastructure: tests/test_gpu_bench_shapes.py replays every convolution geometry of a bench step against
+    fp64 and proves that every kernel instance of the step is one an oracle-compared test has launched."""
+
+    def __enter__(self):
+        global _CALL_LOG
+        self.prev, _CALL_LOG = _CALL_LOG, []
+        self.calls = _CALL_LOG
+        _lib.lib().eas_kernel_trace_begin()
+        return self
+
+    def __exit__(self, *exc):
+        global _CALL_LOG
+        _CALL_LOG = self.prev
+        L = _lib.lib()
+        need = L.eas_kernel_trace_dump(None, 0)
+        buf = C.create_string_buffer(int(need))
+        L.eas_kernel_trace_dump(buf, need)
+        self.kernels = sorted(k for k in buf.value.decode().split('\n') if k)
+
+
 def _call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     """Invoke one C-ABI entry point (optionally bracketed by HIP events) and check its status."""
+    if _CALL_LOG is not None:
+        _CALL_LOG.append((fn.__name__, args))
     if _TIMER is None:
         check(fn(*args), name)
         return
@@ -220,7 +248,8 @@ def to_planes(x):
     C_, H, W = shape[-3:]
     NI = x.numel() // (C_ * H * W)
     sp = torch.empty(shape[:-3] + (C_ // 8, H * W, 8), dtype=torch.bfloat16, device=x.device)
-    check(_lib.lib().eas_spike_planes_from_f32(ptr(x), 0, ptr(sp), 0, NI, C_, H * W, stream()), 'eas_spike_planes_from_f32')
+    check(_lib.lib().eas_spike_planes_from_f32(ptr(x), 0, ptr(sp), 0, NI, C_, H * W, ptr(conv_inexact_flag(x.device)), stream()),
+          'eas_spike_planes_from_f32')
     return sp
 
 
@@ -1443,11 +1472,37 @@ _INEXACT = {}
 
 
 def conv_inexact_flag(device):
-    """Device int32 that eas_conv_fwd ORs with 1 if an input promised to hold small integers (x_terms=1) does not."""
+    """Device int32 that the kernels OR with 1 when a tensor promised to hold spikes / small integers (one exact bf16 term: the fp32
+    one-term convolutions, the conversion to spike planes) holds a value that is not exact in bf16.  One per device, persistent (a
+    captured graph keeps writing the same word), sticky until ``clear_tag_violation``."""
     key = str(device)
     if key not in _INEXACT:
         _INEXACT[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _INEXACT[key]
+
+
+def _tag_flag(x, x_terms):
+    return ptr(conv_inexact_flag(x.device)) if x_terms == 1 else None
+
+
+def tag_violation(device=None):
+    """True when a kernel saw a mis-tagged tensor since the last ``clear_tag_violation`` (host synchronisation: outside timed regions)"""
+    if device is not None:
+        return str(device) in _INEXACT and bool(_INEXACT[str(device)].item())
+    return any(bool(f.item()) for f in _INEXACT.values())
+
+
+def clear_tag_violation():
+    for f in _INEXACT.values():
+        f.zero_()
+
+
+def check_tags(what='this run'):
+    """fail loudly when a tensor tagged "spikes / small integers" was not: its convolutions rounded their input to bf16, i.e. the results
+    of ``what`` are NOT the fp32 results they claim to be.  Called by Trainer.save_ckpt, bench.py (after the timed region) and smoke()."""
+    if tag_violation():
+        raise _lib.EasHipError(f'{what}: a tensor tagged as spikes / small integers held values that are not exact in bf16 -- a one-term '
+                               'convolution or a spike-plane conversion rounded them (mark_small_int on a real-valued tensor?)')
 
 
 def conv_pack_weights(w, mode=0):
@@ -1491,11 +1546,11 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_sp=None):
         if 0 < nb <= CONV_STATS_MAX_BLOCKS:
             stats = torch.empty(Cout * nb * 2, dtype=torch.float64, device=x.device)
             _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd_stats, ptr(x), ptr(packed), ptr(y), NI, Cin, Cout, Hi, Wi,
-                  ksize, stride, x_terms, None, ptr(stats), nb, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+                  ksize, stride, x_terms, _tag_flag(x, x_terms), ptr(stats), nb, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
             _CONV_STATS_SLOT = (y, nb, stats, y._version)
             return y
     _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
-          ksize, stride, x_terms, None, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+          ksize, stride, x_terms, _tag_flag(x, x_terms), stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
     return y
 
 
@@ -1581,6 +1636,8 @@ def _wgrad_finish(ws, gw, nslabs, defer, w=None):
 
 def _partial_call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     """like _call for the *_partial entry points, whose non-negative return value is the slab count"""
+    if _CALL_LOG is not None:
+        _CALL_LOG.append((fn.__name__, args))
     if _TIMER is None:
         rc = fn(*args)
     else:
@@ -1643,8 +1700,8 @@ def is_small_int(t):
 
 def _verify_tags(x, small_int):
     """test-suite check (VERIFY_SMALL_INT, host sync): a tagged tensor is exact in bf16; a ghost's planes hold small integers"""
-    if not (small_int and VERIFY_SMALL_INT):
-        return
+    if not (small_int and VERIFY_SMALL_INT) or torch.cuda.is_current_stream_capturing():     # (a capture cannot read the device; the
+        return                                                                                # eager iterations in front of it did)
     sp = planes_of(x)
     if sp is not None:
         v = sp.float()

@@ -46,6 +46,11 @@ typedef void* eas_stream_t; /* hipStream_t */
 #define EAS_LIF_FIRE_STRICT 8  /* fire on h - v_th > 0 (in-repo LIFCell); else >= 0 (spikingjelly heaviside) */
 
 int eas_abi_version(void);
+/* Kernel-instance trace (test infrastructure): between eas_kernel_trace_begin() and eas_kernel_trace_dump() every launch of the library
+ * records the (demangled) symbol of the device kernel it starts -- the names rocprofv3 --kernel-trace reports.  dump switches the
+ * trace off and writes the distinct symbols, newline separated, into buf (cap bytes incl. the terminator); returns the bytes needed. */
+void eas_kernel_trace_begin(void);
+int64_t eas_kernel_trace_dump(char* buf, int64_t cap);
 const char* eas_status_string(int status);
 
 /* ---------------------------------------------------------------------------------------------
@@ -393,8 +398,10 @@ int eas_conv_fwd_stats_blocks(int NI, int Cin, int Cout, int Hi, int Wi, int ksi
  * (8 consecutive input channels of one pixel) is one 16-byte load, at half the bytes of fp32.  Written by eas_bn_lif_fwd_ex
  * (spikes_planes), read by eas_conv_fwd_planes / eas_conv_wgrad_planes_partial; converted at the borders of the fused path by
  * eas_spike_planes_from_f32 / _to_f32.  C % 8 == 0, HW % 4 == 0, 16-byte aligned.  src_ctot / dst_ctot (0 = C): the C channels are a
- * channel (group) slice of a wider tensor, the pointer at the first of them. */
-int eas_spike_planes_from_f32(const float* x, int src_ctot, void* planes, int dst_ctot, int64_t NI, int C, int HW, eas_stream_t stream);
+ * channel (group) slice of a wider tensor, the pointer at the first of them.  *inexact_flag (may be NULL) is OR-ed with 1 when a value
+ * of x is not exact in bf16, i.e. the tensor did not hold spikes / small integers as promised (same flag as eas_conv_fwd's). */
+int eas_spike_planes_from_f32(const float* x, int src_ctot, void* planes, int dst_ctot, int64_t NI, int C, int HW, int* inexact_flag,
+                              eas_stream_t stream);
 int eas_spike_planes_to_f32(const void* planes, int src_ctot, float* x, int dst_ctot, int64_t NI, int C, int HW, eas_stream_t stream);
 /* eas_conv_fwd / eas_conv_fwd_stats (1x1 and 3x3, stride 1 / 2) reading x as spike planes: the same products summed in the same order as
  * eas_conv_fwd with x_terms = 1 on the fp32 values -- bit-identical y.  stats / nb: NULL / 0, or as eas_conv_fwd_stats.  The geometry

@@ -1169,6 +1169,37 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         assert err < 1e-5, f'{name}: {err:.2e}'
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('Cin,Cout,H,W,k', [(16, 32, 8, 10, 3), (64, 32, 8, 10, 1), (512, 256, 8, 10, 1)])
+def test_mistagged_spike_tensor_fails_loudly(dev, monkeypatch, Cin, Cout, H, W, k):
+    """A real-valued tensor wrongly tagged "spikes / small integers" takes the one-term path (inputs rounded to bf16): the kernels that
+    consume the promise -- the fp32 one-term 3x3 / 1x1 (direct and shared-fragment) forward, the conversion to spike planes -- raise the
+    per-device flag, and ops.check_tags (Trainer.save_ckpt, bench.py, smoke()) turns it into an error.  Honest tags leave it alone."""
+    import torch.nn as nn
+    from eas_snn_amd import _lib, ops
+    monkeypatch.setattr(ops, 'VERIFY_SMALL_INT', False)         # the suite's own (host-side) tag check would catch it first
+    ops.clear_tag_violation()
+    conv = nn.Conv2d(Cin, Cout, k, 1, k // 2, bias=False).to(dev)
+    spikes = torch.randint(0, 4, (2, Cin, H, W), generator=torch.Generator().manual_seed(1)).float().to(dev)
+    ops.conv2d(spikes, conv, small_int=True)
+    ops.to_planes(spikes)
+    ops.conv2d(torch.randn(2, Cin, H, W, device=dev), conv, small_int=False)      # real input on the three-term path: no promise made
+    assert not ops.tag_violation()
+    ops.check_tags('honest tags')
+    real = spikes.clone()
+    real[1, Cin - 1, H - 1, W - 1] = 0.3                        # ONE value that is not exact in bf16
+    ops.conv2d(real, conv, small_int=True)
+    assert ops.tag_violation(dev)
+    with pytest.raises(_lib.EasHipError, match='not exact in bf16'):
+        ops.check_tags('a mis-tagged convolution input')
+    ops.clear_tag_violation()
+    assert not ops.tag_violation()
+    ops.to_planes(real)
+    with pytest.raises(_lib.EasHipError, match='not exact in bf16'):
+        ops.check_tags('a mis-tagged planes conversion')
+    ops.clear_tag_violation()
+
+
 STATS_CASES = [c for c in CONV_CASES if c[2] != 2] + [(6, 64, 96, 32, 40, 1, 1, True), (64, 512, 512, 8, 10, 1, 1, False), (1, 16, 32, 8, 320, 3, 2, False),
                                                    (12, 32, 48, 64, 80, 3, 1, True)]
 
