@@ -351,23 +351,12 @@ def main():
 
     w = workloads.get(args.config)
     batch = args.batch or w['batch']
-    exp = workloads.build_exp(w)
-    exp.ema = False                          # the measured step is forward + backward + exchange + Adam + reset_net
-    exp.output_dir = os.environ.get('EAS_BENCH_OUT', '/tmp/eas_bench_out')
-    torch.manual_seed(80)
     # THE STEP IS THE TRAINER'S: model, optimizer, gradient exchange and the iteration itself (eager or HIP-graph replays) come from
     # yolox.core.Trainer (compat/yolox/core/trainer.py, what tools/train_event.py runs); this file only feeds it and times it.
-    trainer = exp.get_trainer(types.SimpleNamespace(batch_size=batch * world, fp16=False, experiment_name=f'bench_config{w["config"]}',
-                                                     ckpt=None, resume=False))
-    model = trainer.setup(force_exchange=force_ddp)
-    model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
-    model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'    # development switch: 0 = tensor-op SimOTA
-    model.head.fused_loss = os.environ.get('EAS_FUSED_LOSS', '1') == '1'        # development switch: 0 = tensor-op loss terms
     multi = world > 1 or force_ddp
-
-    raw, inputs_fn = workloads.device_inputs(w, batch, args.events, dev, seed=rank)
-    h2d = _H2DFeeder(raw) if args.h2d else None
-    step = trainer.step_fn(inputs_fn)
+    trainer, model, step = workloads.build_trainer(w, batch, dev, events=args.events, world=world, rank=rank, force_exchange=force_ddp)
+    inputs_fn = step.inputs_fn
+    h2d = _H2DFeeder(step.raw_inputs) if args.h2d else None
 
     def one():
         if h2d is not None:

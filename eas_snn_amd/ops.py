@@ -419,6 +419,8 @@ def _pending_stats(L, y, TN, Cc, HW, replicas, eps, momentum, running_mean, runn
                                  ptr(running_var) if momentum is not None else None, nb)
         return pend, stats, 0                # no launch: the consumer adds the convolution's tile sums
     ws = torch.empty(L.eas_bn_workspace_doubles(Cc), dtype=torch.float64, device=dev)
+    if _CALL_LOG is not None:
+        _CALL_LOG.append(('eas_bn_stats_partial', (None, y_ctot, TN, Cc, HW, int(replicas))))
     chunks = L.eas_bn_stats_partial(ptr(y) if y_ptr is None else y_ptr, y_ctot, TN, Cc, HW, ptr(ws), stream())
     if chunks <= 0:
         check(chunks if chunks < 0 else -1, 'eas_bn_stats_partial')

@@ -66,6 +66,28 @@ def device_inputs(w, batch, n_events, device, seed=0):
     raise KeyError(w['input'])
 
 
+def build_trainer(w, batch, device, events=200_000, world=1, rank=0, force_exchange=False, out_dir='/tmp/eas_bench_out'):
+    """The bench's step object for workload ``w``: the reference-shaped ``yolox.core.Trainer`` (model on the device, optimizer, gradient
+    exchange when ``world`` > 1) and its ``TrainStep`` fed by the workload's device pipeline -- what ``bench.py`` times and what
+    tests/test_gpu_bench_shapes.py traces.  Returns (trainer, model, step)."""
+    import os
+    import types
+    exp = build_exp(w)
+    exp.ema = False                          # the measured step is forward + backward + exchange + Adam + reset_net
+    exp.output_dir = os.environ.get('EAS_BENCH_OUT', out_dir)
+    torch.manual_seed(80)
+    trainer = exp.get_trainer(types.SimpleNamespace(batch_size=batch * world, fp16=False, experiment_name=f'bench_config{w["config"]}',
+                                                     ckpt=None, resume=False))
+    model = trainer.setup(force_exchange=force_exchange)
+    model.head.use_l1 = True                 # no_aug from epoch 0 (trainer.py:157, 231-238)
+    model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'    # development switch: 0 = tensor-op SimOTA
+    model.head.fused_loss = os.environ.get('EAS_FUSED_LOSS', '1') == '1'        # development switch: 0 = tensor-op loss terms
+    raw, inputs_fn = device_inputs(w, batch, events, device, seed=rank)
+    step = trainer.step_fn(inputs_fn)
+    step.raw_inputs = raw
+    return trainer, model, step
+
+
 def algorithmic_input_bytes(w, batch, n_events):
     """bytes of raw input one step reads: 9 B per event, or the u8 stacked histogram"""
     if w['input'] == 'events':
