@@ -33,6 +33,21 @@ class EasBnPending(C.Structure):
                 ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('pitch', C.c_int)]
 
 
+class EasLifRange(C.Structure):
+    """include/eas_hip.h EasLifRange: one neuron layer (a range of output channels) of the fused eval step"""
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p), ('w_logit', C.c_void_p),
+                ('k_const', C.c_float), ('v_th', C.c_float), ('planes', C.c_void_p), ('out_f32', C.c_void_p), ('out_ctot', C.c_int),
+                ('out_c0', C.c_int), ('res_planes', C.c_void_p), ('res_f32', C.c_void_p), ('res_ctot', C.c_int), ('rate', C.c_void_p),
+                ('v_in', C.c_void_p), ('v_out', C.c_void_p)]
+
+
+class EasConvBnLifEval(C.Structure):
+    """include/eas_hip.h EasConvBnLifEval"""
+    _fields_ = [('x', C.c_void_p), ('packed_w', C.c_void_p), ('x_terms', C.c_int), ('x_shared', C.c_int), ('T', C.c_int), ('N', C.c_int),
+                ('Cin', C.c_int), ('Cout', C.c_int), ('Hi', C.c_int), ('Wi', C.c_int), ('ksize', C.c_int), ('stride', C.c_int),
+                ('csplit', C.c_int), ('range', EasLifRange * 2)]
+
+
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
 ABI_VERSION = 5
 
@@ -41,6 +56,8 @@ PROTOTYPES = {
     'eas_kernel_trace_begin': (None, []),
     'eas_kernel_trace_dump': (C.c_int64, [C.c_char_p, C.c_int64]),
     'eas_status_string': (C.c_char_p, [C.c_int]),
+    'eas_conv_bn_lif_eval': (C.c_int, [C.POINTER(EasConvBnLifEval), _P]),
+    'eas_conv_bn_lif_eval_supported': (C.c_int, [C.c_int] * 10),
     'eas_event_histogram': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_event_histogram_dat': (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_counts_to_canvas': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

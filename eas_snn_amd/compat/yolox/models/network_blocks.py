@@ -79,6 +79,10 @@ class BaseConv(nn.Module):
         if ops._TIMER is not None:
             ops.set_tag(getattr(self, '_eas_name', None))            # development: per-layer timing (scripts/layer_times.py)
         if self.spiking():
+            if not self.training and ops.fused_eval_ok(x, self.conv, [(self.bn, self.act)]):
+                # eval mode: conv -> BN (running statistics) -> LIF over T as ONE kernel, the convolution output never reaches HBM
+                return ops.conv_bn_lif_eval(x, self.conv, [(self.bn, self.act)], want_mean=self.emit_rate, residual=residual, cats=[cat],
+                                            planes=[self.wants_planes()])
             with ops.conv_stats_scope(self.bn._use_batch_stats()):      # the convolution sums its output for the BN behind it
                 y = self.conv(x)
             return self.bn.fused_with(self.act, y, want_mean=self.emit_rate, residual=residual, cat=cat,
@@ -219,6 +223,17 @@ class CSPLayer(nn.Module):
                 # conv1 and conv2 read the same x: ONE 1x1 convolution with the concatenated weights, then the two BN+LIF layers on
                 # the two channel halves of its output (x read once; the input gradient is one convolution, no branch addition)
                 c1, c2 = self.conv1.conv[0], self.conv2.conv[0]
+                pair = [(self.conv1.bn, self.conv1.act), (self.conv2.bn, self.conv2.act)]
+                if not self.training and ops.fused_eval_ok(x, (c1, c2), pair):
+                    # eval mode: the one convolution for both branches AND their two BN + LIF layers in one kernel
+                    packs = (getattr(self, '_eas_dual_packs', None) or {}).get('c12')
+                    a, b = ops.conv_bn_lif_eval(x, (c1, c2), pair, cats=[None if len(self.m) else (buf, 0, sp_buf), (buf, h, sp_buf)],
+                                                planes=[want_a, sp_buf is not None], packs=ops.current_packs(packs))
+                    if len(self.m):
+                        for blk in self.m[:-1]:
+                            a = blk(a)
+                        a = self.m[-1](a, cat=(buf, 0, sp_buf))
+                    return self.conv3(ops.join_channels(buf, a, b, sp_buf=sp_buf))
                 x4 = ops.fold_time(x)
                 sink = ops.conv_sink()
                 if sink is not None:

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "eas_common.h"
+#include "conv_lif_epi.h"
 
 namespace {
 
@@ -27,6 +28,9 @@ struct C1Geom {
     double* stats;                    // BatchNorm statistics in the epilogue (eas_conv_fwd_stats): [Cout][stats_nb][2], stats_nb = gridDim.x
     int stats_nb;
     int* inexact;                     // x_terms == 1 on fp32 input: OR-ed with 1 when a value is not exact in bf16 (NULL: not reported)
+    // fused eval step conv -> BatchNorm (running statistics) -> LIF over T (kernel template LM = 1, conv_lif_epi.h): NI = samples N, total_tiles
+    // counts SPATIAL 32-pixel tiles, pixel tile n of a wave = time step n (WN == lif.T): image n * N + sample
+    EasLifEpiDev lif;
 };
 
 // statistics epilogue of the 1x1 kernels: 4 waves of a block = 4 pixel groups of the same WM * 32 channels
@@ -65,28 +69,38 @@ __device__ __forceinline__ void to_terms(const TIN (&v)[8], bf16x8 (&b)[XT]) {
 // grad_y): channel validity is then tested per channel instead of per 8-channel group.
 // PL: x is given as spike planes (bf16 [NI][Cin/8][HW][8], one exact term): a lane's 8 channels of its pixel are ONE 16-byte load and
 // already the MFMA operand -- no conversion, an eighth of the load instructions, half the bytes.
-template <int XT, int WM, int WN, bool RAGK = false, bool PL = false>
+template <int XT, int WM, int WN, bool RAGK = false, bool PL = false, int LM = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                               const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     static_assert(!PL || (XT == 1 && !RAGK), "spike planes are one exact bf16 term in whole 8-channel groups");
+    static_assert(LM == 0 || LM == 1, "1x1: time-major fused neuron epilogue only");
+    constexpr bool TM = LM == 1;
     typedef float TIN;
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int mt0 = blockIdx.y * WM;
-    const int tile0 = (blockIdx.x * 4 + wave) * WN;
+    const int tile0 = (blockIdx.x * 4 + wave) * (TM ? 1 : WN);
     if (tile0 >= g.total_tiles && !g.stats) return;      // with statistics every wave reaches the block reduction (its lanes hold no pixel)
 
     // per-lane pixel of each N-tile
     long xoff[WN];    // element offset of (img, channel 8h, pixel) ; -1: no pixel
     long yoff[WN];
+    int l_img[LM ? WN : 1], l_pix[LM ? WN : 1];
+    bool l_ok[LM ? WN : 1];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const int t = tile0 + n;
-        const int img = t / g.tiles_per_img, p = (t - img * g.tiles_per_img) * 32 + r;
+        const int t = TM ? tile0 : tile0 + n;             // time-major: tile n = time step n of the same spatial tile
+        const int smp = t / g.tiles_per_img, p = (t - smp * g.tiles_per_img) * 32 + r;
+        const int img = TM ? n * g.NI + smp : smp;
         const bool ok = t < g.total_tiles && p < g.HW;
         xoff[n] = ok ? (PL ? ((long)img * (g.Cin / 8) + h) * g.HW + p : ((long)img * g.Cin + 8 * h) * g.HW + p) : -1;
         yoff[n] = ok ? (long)img * g.Cout * g.HW + p : -1;
+        if constexpr (LM != 0) {
+            l_img[n] = smp;
+            l_pix[n] = p;
+            l_ok[n] = ok;
+        }
     }
 
     f32x16 acc[WM][WN];
@@ -220,6 +234,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         c1_stats<WM, WN>(acc, yoff, red, g, mt0);
     }
 
+    if constexpr (LM != 0) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+            if (mt0 + m < g.MT) eas_lif_epilogue<WN, LM>(acc[m], g.lif, mt0 + m, h, l_img, l_pix, l_ok);
+        return;
+    }
+
     // lean epilogue: one pointer per (M-tile, pixel tile), rows by multiples of the channel stride, bias once per M-tile,
     // per-element channel check only for a ragged last M-tile
 #pragma unroll
@@ -258,10 +279,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 // (WM x 3 KB per k-step) -- 64 KB per k-step and CU against 768 cycles of MFMA work.  Here the four waves of a block (same
 // output channels, different pixels) share them: the block loads each k-step's WM x 3 fragments once (coalesced 16-byte
 // loads), double-buffers them in LDS and every wave reads its operands with conflict-free ds_read_b128.  One barrier per k-step.
-template <int XT, int WM, int WN, bool PL = false>
+template <int XT, int WM, int WN, bool PL = false, int LM = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     static_assert(!PL || XT == 1, "spike planes are one exact bf16 term");
+    static_assert(LM == 0 || LM == 1, "1x1: time-major fused neuron epilogue only");
+    constexpr bool TM = LM == 1;
     typedef float TIN;
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(x);
     constexpr int NFRAG = WM * 3;                        // 1 KB fragments per k-step
@@ -270,16 +293,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int mt0 = blockIdx.y * WM;
-    const int tile0 = (blockIdx.x * 4 + wave) * WN;
+    const int tile0 = (blockIdx.x * 4 + wave) * (TM ? 1 : WN);
 
     long xoff[WN], yoff[WN];
+    int l_img[LM ? WN : 1], l_pix[LM ? WN : 1];
+    bool l_ok[LM ? WN : 1];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const int t = tile0 + n;
-        const int img = t / g.tiles_per_img, p = (t - img * g.tiles_per_img) * 32 + r;
+        const int t = TM ? tile0 : tile0 + n;             // time-major: tile n = time step n of the same spatial tile
+        const int smp = t / g.tiles_per_img, p = (t - smp * g.tiles_per_img) * 32 + r;
+        const int img = TM ? n * g.NI + smp : smp;
         const bool ok = t < g.total_tiles && p < g.HW;
         xoff[n] = ok ? (PL ? ((long)img * (g.Cin / 8) + h) * g.HW + p : ((long)img * g.Cin + 8 * h) * g.HW + p) : -1;
         yoff[n] = ok ? (long)img * g.Cout * g.HW + p : -1;
+        if constexpr (LM != 0) {
+            l_img[n] = smp;
+            l_pix[n] = p;
+            l_ok[n] = ok;
+        }
     }
     f32x16 acc[WM][WN];
     unsigned bad = 0;
@@ -436,6 +467,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         c1_stats<WM, WN>(acc, yoff, red, g, mt0);
     }
 
+    if constexpr (LM != 0) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+            if (mt0 + m < g.MT) eas_lif_epilogue<WN, LM>(acc[m], g.lif, mt0 + m, h, l_img, l_pix, l_ok);
+        return;
+    }
+
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         if (mt0 + m >= g.MT) continue;
@@ -484,6 +522,16 @@ int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1G
     if (!y) return EAS_OK;            // geometry query
     if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
     EAS_LAUNCH((conv1x1_mfma_kernel<XT, WM, WN, RAGK, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    return EAS_OK;
+}
+
+// fused eval step on spike planes, time-major: a block's four waves = four SPATIAL 32-pixel tiles, each wave all T = WN time steps of its tile
+template <int WM, int WN, bool SHARED>
+int launch_c1_lif(const float* x, const bf16x8* wp, C1Geom g, hipStream_t st, bool query) {
+    if (query) return EAS_OK;
+    dim3 grid((g.total_tiles + 3) / 4, (g.MT + WM - 1) / WM);
+    if constexpr (SHARED) EAS_LAUNCH((conv1x1_mfma_sharedA_kernel<1, WM, WN, true, 1>), grid, dim3(256), 0, st, x, wp, (const float*)nullptr, (float*)nullptr, g);
+    else EAS_LAUNCH((conv1x1_mfma_kernel<1, WM, WN, false, true, 1>), grid, dim3(256), 0, st, x, wp, (const float*)nullptr, (float*)nullptr, g);
     return EAS_OK;
 }
 
@@ -567,6 +615,29 @@ int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias
                           : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb, inexact);
     if (nb_out) *nb_out = tl_c1_blocks;
     return rc;
+}
+
+// 1x1 layer of the fused eval step (eas_conv_bn_lif_eval, conv_mfma.hip): spike planes in, distinct frames per step, T = 3 or 5
+int eas_conv1x1_lif_dispatch(const void* x, const void* packed_w, const EasLifEpiDev& lif, int Cin, int x_terms, int x_shared, hipStream_t st, bool query) {
+    if (x_terms != 2 || x_shared || Cin % 8 != 0 || (lif.T != 3 && lif.T != 5)) return EAS_ERR_UNSUPPORTED;
+    C1Geom g{};
+    g.NI = lif.N; g.Cin = Cin; g.Cout = lif.Cout; g.HW = lif.HW;
+    g.tiles_per_img = (lif.HW + 31) / 32;
+    g.total_tiles = lif.N * g.tiles_per_img;            // spatial tiles
+    g.MT = (lif.Cout + 31) / 32;
+    g.KSTEPS = (Cin + 15) / 16;
+    g.lif = lif;
+    const bf16x8* wp = (const bf16x8*)packed_w;
+    const float* xf = (const float*)x;
+    auto blocks = [&](int m) { return (long)((g.total_tiles + 3) / 4) * ((g.MT + m - 1) / m); };
+    // channel tiles per wave: two (T = 3: 6 accumulator tiles, T = 5: 10; four M-tiles x 3 steps spill) while the grid keeps ~2 blocks per CU
+    int wm = g.MT >= 2 ? 2 : 1;
+    while (wm > 1 && blocks(wm) < 512) wm >>= 1;
+    static const int shared_min = getenv("EAS_C1_SHARED_MIN_CIN") ? atoi(getenv("EAS_C1_SHARED_MIN_CIN")) : 256;
+    if (Cin >= shared_min && g.MT >= 2 && wm >= 2)
+        return lif.T == 3 ? launch_c1_lif<2, 3, true>(xf, wp, g, st, query) : launch_c1_lif<2, 5, true>(xf, wp, g, st, query);
+    if (lif.T == 3) return wm == 2 ? launch_c1_lif<2, 3, false>(xf, wp, g, st, query) : launch_c1_lif<1, 3, false>(xf, wp, g, st, query);
+    return wm == 2 ? launch_c1_lif<2, 5, false>(xf, wp, g, st, query) : launch_c1_lif<1, 5, false>(xf, wp, g, st, query);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "eas_common.h"
+#include "conv_lif_epi.h"
 
 namespace {
 
@@ -66,6 +67,12 @@ struct ConvGeom {
     // its output tile per channel to stats[(co * stats_nb + pixel block) * 2 + {0, 1}] (doubles); stats_nb = gridDim.x * parts
     double* stats;
     int stats_nb;
+    // Fused eval-mode step conv -> BatchNorm (running statistics) -> LIF over T (eas_conv_bn_lif_eval, kernel template LM != 0; see
+    // conv_lif_epi.h).  LM = 1, time-major: NI is the number of SAMPLES N, pixel tile j of a wave is time step j of the wave's 32 spatial
+    // pixels (WN == lif.T) and the staged patch holds lif.T time slices of the block's rows: nseg = lif.T * nseg_s segments, segment
+    // t * nseg_s + s = image t * N + img0 + s.  LM = 2: one convolution result for all T steps (spatial tiles as always).
+    int nseg_s;
+    EasLifEpiDev lif;
 };
 
 // exact n / d for n, d < 2^20 with m = ceil(2^40 / d): a multiply-shift instead of the ~25-instruction integer division
@@ -222,11 +229,13 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
 // PL: x is a spike-plane tensor (bf16 [NI][Cin/8][Hi*Wi][8], one exact term): the 8 channels of a staged pixel are 16 contiguous bytes
 // in HBM and in LDS -- a staging item is VEC 16-byte loads and VEC 16-byte LDS stores, no conversion, half the bytes of fp32.
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0>
 __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
                                                float* __restrict__ y, int* __restrict__ inexact, const ConvGeom& g, const int part,
                                                unsigned char* smem) {
     static_assert(!PL || XT == 1, "spike planes are one exact bf16 term");
+    static_assert(LM == 0 || WM == 1, "the fused neuron epilogue walks one M-tile per wave");
+    constexpr bool TM = LM == 1;   // time-major pixel tiles (conv_lif_epi.h)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     constexpr int PIXB = CCH * 2;  // bytes per staged pixel and term
     constexpr int NSTEPS = (CCH / 16) * TAPS;
@@ -264,17 +273,24 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     // per-lane geometry of the WN pixel columns this lane owns
     int qoff[WN];
     long ybase[WN];
+    int l_img[LM ? WN : 1], l_pix[LM ? WN : 1];     // fused neuron epilogue: sample and pixel (inside its image) of the lane's column of tile j
+    bool l_ok[LM ? WN : 1];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-        const int p = (wn * WN + j) * 32 + r;
+        const int p = TM ? wn * 32 + r : (wn * WN + j) * 32 + r;       // time-major: tile j = time step j of the SAME 32 pixels
         const int pc = p < npix ? p : 0;
         const int rl = fdiv(pc, g.m_Wo), c = pc - rl * g.Wo;
         const int seg = fdiv(rl, g.m_rows_seg), rr = rl - seg * g.rows_seg;
-        qoff[j] = ((seg * g.rows_in + rr * S) * g.RS + c * S + g.qshift) * 16 + h * grp;
+        qoff[j] = (((TM ? j * g.nseg_s + seg : seg) * g.rows_in + rr * S) * g.RS + c * S + g.qshift) * 16 + h * grp;
         const int rho = rho0 + rl;
         const int img = fdiv(rho, g.m_Ho), orow = rho - img * g.Ho;
         const int yr = orow * g.os + g.oph, yc = (part * g.Wo + c) * g.os + g.opw;
         ybase[j] = (p < npix && rho < g.total_rows && yr < g.oH && yc < g.oW) ? (((long)img * g.Cout * g.oH + yr) * g.oW + yc) : -1;
+        if constexpr (LM != 0) {
+            l_img[j] = img;
+            l_pix[j] = yr * g.oW + yc;
+            l_ok[j] = ybase[j] >= 0;
+        }
     }
 
     // per-thread staging items (the same for every channel chunk)
@@ -290,9 +306,12 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         const int gi = fdiv(item, g.m_units), u = item - gi * units;
         const int seg = fdiv(u, g.m_units_seg), rem = u - seg * units_seg;
         const int rl = fdiv(rem, g.m_units_row), cu = rem - rl * units_row;
-        const int ir = r0 * S - g.pad_t + rl, img = img0 + seg;
+        const int ir = r0 * S - g.pad_t + rl;
+        // (time-major: segment t * nseg_s + s of the patch is image t * N + img0 + s; g.NI = N samples there)
+        const int seg_t = TM ? seg / g.nseg_s : 0, seg_s = TM ? seg - seg_t * g.nseg_s : seg;
+        const int img = (TM ? seg_t * g.NI : 0) + img0 + seg_s;
         const int gc = gcol0 + cu * VEC;
-        const bool ok = ir >= 0 && ir < g.Hi && img < g.NI && gc >= 0 && gc < g.Wi;
+        const bool ok = ir >= 0 && ir < g.Hi && img0 + seg_s < g.NI && gc >= 0 && gc < g.Wi;
         gofs[it] = ok ? (PL ? (int)((((size_t)img * (g.Cin / 8)) * g.Hi + ir) * g.Wi + gc)          // planes: in 16-byte units, group 0
                             : (int)((((size_t)img * g.Cin) * g.Hi + ir) * g.Wi + gc)) : -1;
         lofs[it] = ((seg * g.rows_in + rl) * g.RS + g.pad_l + cu * VEC) * 16 + gi * grp;
@@ -481,6 +500,12 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         }
     }
 
+    if constexpr (LM != 0) {
+        // ---- fused BatchNorm (running statistics) + LIF over T: the accumulators are z_t of the lane's neurons, nothing is written but spikes
+        if (mt0 < g.MT) eas_lif_epilogue<WN, LM>(acc[0], g.lif, mt0, h, l_img, l_pix, l_ok);
+        return;
+    }
+
     // ---- epilogue: D tile (col = pixel = lane&31, row = (e&3) + 8*(e>>2) + 4*h) -> y NCHW.  Lean on purpose: one pointer per
     // (M-tile, pixel tile), rows reached by adding multiples of the channel stride; bias values loaded once per M-tile;
     // the per-element channel bound check only for a ragged last M-tile (the epilogue used to be as long as the main loop).
@@ -516,12 +541,12 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     }
 }
 
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0>
 __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
                                                             ConvGeom g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem);
+    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL, LM>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem);
 }
 
 // Input gradient of a stride-2 3x3 convolution in ONE launch: blockIdx.z = parity class of the input pixel, every class a stride-1
@@ -582,9 +607,9 @@ int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
     return EAS_OK;
 }
 
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false>
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0>
 int launch_fwd(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
-    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL>;
+    auto kern = conv_fwd_mfma_kernel<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL, LM>;
     const int nbuf = (g.KSTEPS * 16 <= CCH || g.single) ? 1 : 2;      // one channel chunk: the second (prefetch) buffer is never used
     size_t lds = (size_t)nbuf * g.Q * CCH * 2 * XT;
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
@@ -710,10 +735,76 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
     return cands[best].fn(x, wp, bias, y, inexact, best_g, st);
 }
 
+// Tile choice of the fused eval step (LM = 1: time-major, the wave tile is lif.T time steps of 32 pixels; LM = 2: one result for all steps).
+// Same cost model as dispatch_tile; the block covers 32 * WVN spatial pixels (time-major) whose T time slices are staged side by side.
+template <int TAPS, int S, int XT, int CCH, int VEC, bool PL, int LM>
+int dispatch_tile_lif(const float* x, const bf16x8* wp, ConvGeom g, hipStream_t st, bool query) {
+    struct Cand { int wvm, wvn, threads, nit, wn; launch_fn fn; };
+    constexpr int N8 = XT == 1 ? 2 : 1, N4 = 2;
+#define EAS_LC(WVM_, WVN_, WN_, NIT_) {WVM_, WVN_, 64 * WVM_ * WVN_, NIT_, WN_, launch_fwd<TAPS, S, XT, 1, WN_, WVM_, WVN_, CCH, VEC, NIT_, PL, LM>}
+    // (only the candidates of this LM are instantiated)
+    constexpr int ncand = LM == 1 ? 10 : 4;
+    Cand cands[ncand];
+    if constexpr (LM == 1) {
+        const Cand c[10] = {EAS_LC(2, 4, 3, N8), EAS_LC(4, 2, 3, N8), EAS_LC(1, 8, 3, N8), EAS_LC(1, 4, 3, N4), EAS_LC(2, 2, 3, N4),
+                            EAS_LC(2, 4, 5, N8), EAS_LC(4, 2, 5, N8), EAS_LC(1, 8, 5, N8), EAS_LC(1, 4, 5, N4), EAS_LC(2, 2, 5, N4)};
+        for (int i = 0; i < ncand; ++i) cands[i] = c[i];
+    } else {
+        const Cand c[4] = {EAS_LC(2, 4, 5, N8), EAS_LC(4, 2, 5, N8), EAS_LC(1, 4, 5, N4), EAS_LC(2, 2, 5, N4)};
+        for (int i = 0; i < ncand; ++i) cands[i] = c[i];
+    }
+#undef EAS_LC
+    const int T = g.lif.T;
+    const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
+    int best = -1;
+    double best_cost = 0.0;
+    int best_rank = 0;
+    ConvGeom best_g = g;
+    for (int i = 0; i < ncand; ++i) {
+        const Cand& c = cands[i];
+        if (LM == 1 && c.wn != T) continue;
+        if ((c.wvm - 1) * 32 >= g.Cout && c.wvm != 1) continue;
+        const int nbuf = nchunks == 1 ? 1 : 2;
+        ConvGeom t = g;
+        t.single = 0;
+        const int bn = LM == 1 ? 32 * c.wvn : 32 * c.wn * c.wvn;       // spatial pixels of the block tile
+        bool fits = false;
+        for (int cap = bn; cap >= g.Wo && !fits; cap -= 32) {
+            t.RT = pick_rows(g.Ho, g.Wo, cap);
+            if (t.RT == 0) break;
+            t.rows_seg = t.RT < g.Ho ? t.RT : g.Ho;
+            t.nseg_s = t.RT / t.rows_seg;
+            t.nseg = (LM == 1 ? T : 1) * t.nseg_s;
+            t.rows_in = (t.rows_seg - 1) * S + g.ext_h;
+            t.Q = t.nseg * t.rows_in * t.RS;
+            fits = (size_t)nbuf * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wst / VEC) * (CCH / 8) <= c.nit * c.threads;
+            cap = t.RT * g.Wo;
+        }
+        if (!fits) continue;
+        const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm - 1) / c.wvm);
+        const size_t lds_bytes = (size_t)nbuf * t.Q * CCH * 2 * XT;
+        const int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
+        const double per_tile = XT == 1 ? 96.0 : 192.0, lat = 450.0;
+        const double mfma_part = (c.wn * per_tile > lat ? c.wn * per_tile : lat) / (5.0 * per_tile);
+        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part);
+        // the valid share of the pixel tile matters here (a 32 * WVN pixel block of whole rows): rounds x cost / valid pixels per block
+        const int valid = t.RT * g.Wo;
+        const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
+        const int rank = c.wvm * 4096 + (valid < 4096 ? valid : 4095);
+        if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rank > best_rank)) {
+            best = i; best_cost = cost; best_rank = rank; best_g = t;
+        }
+    }
+    if (best < 0) return EAS_ERR_UNSUPPORTED;
+    if (query) return EAS_OK;
+    return cands[best].fn(x, wp, nullptr, nullptr, nullptr, best_g, st);
+}
+
 }  // namespace
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
                          hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact);
+int eas_conv1x1_lif_dispatch(const void* x, const void* packed_w, const EasLifEpiDev& lif, int Cin, int x_terms, int x_shared, hipStream_t st, bool query);
 
 extern "C" {
 
@@ -823,6 +914,77 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     if (rc != EAS_OK || query) return rc;
     EAS_CHECK_LAUNCH();
     return EAS_OK;
+}
+
+// Fused eval-mode step conv -> BatchNorm (running statistics) -> LIF over T (include/eas_hip.h).  3x3: this file; 1x1: conv1x1_mfma.hip.
+static int conv_lif_impl(const EasConvBnLifEval* d, eas_stream_t stream, bool query) {
+    if (!d) return EAS_ERR_INVALID_ARG;
+    const int T = d->T, N = d->N, Cin = d->Cin, Cout = d->Cout, Hi = d->Hi, Wi = d->Wi, ksize = d->ksize, stride = d->stride;
+    if (T < 1 || T > 8 || N < 1 || Cin < 1 || Cout < 1 || Hi < 1 || Wi < 1) return EAS_ERR_INVALID_ARG;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1) || Cin % 8 != 0 || Cout % 8 != 0 ||
+        d->csplit % 8 != 0 || d->csplit < 8 || d->csplit > Cout)
+        return EAS_ERR_UNSUPPORTED;
+    // inputs: spike planes with distinct frames per step (T = 3 or 5: the wave tile holds the T steps), or one fp32 frame set shared by all steps
+    const bool shared = d->x_shared != 0;
+    if (shared ? (d->x_terms != 1 && d->x_terms != 3) : (d->x_terms != 2 || (T != 3 && T != 5))) return EAS_ERR_UNSUPPORTED;
+    const int pad = ksize / 2;
+    const int Ho = (Hi + 2 * pad - ksize) / stride + 1, Wo = (Wi + 2 * pad - ksize) / stride + 1;
+    if ((Ho * Wo) % 4 != 0 || (ksize == 3 && Wi % 2 != 0)) return EAS_ERR_UNSUPPORTED;
+    EasLifEpiDev lif{};
+    lif.T = T; lif.N = N; lif.HW = Ho * Wo; lif.Cout = Cout; lif.csplit = d->csplit;
+    lif.r[0] = d->range[0];
+    lif.r[1] = d->range[1];
+    if (!query) {
+        if (!d->x || !d->packed_w) return EAS_ERR_INVALID_ARG;
+        if ((uintptr_t)d->x & 15) return EAS_ERR_INVALID_ARG;
+        for (int i = 0; i < (d->csplit < Cout ? 2 : 1); ++i) {
+            const EasLifRange& r = lif.r[i];
+            if ((!r.planes) == (!r.out_f32) || (r.res_planes && r.res_f32) || !r.gamma || !r.beta || !r.mean || !r.invstd) return EAS_ERR_INVALID_ARG;
+            if (r.out_ctot % 8 != 0 || r.out_c0 % 8 != 0 || ((r.res_planes || r.res_f32) && r.res_ctot % 8 != 0)) return EAS_ERR_UNSUPPORTED;
+            if (((uintptr_t)r.planes | (uintptr_t)r.res_planes) & 15) return EAS_ERR_INVALID_ARG;
+        }
+    }
+    EAS_CLEAR_ERR();
+    hipStream_t st = eas_s(stream);
+    int rc = EAS_ERR_UNSUPPORTED;
+    if (ksize == 1) {
+        rc = eas_conv1x1_lif_dispatch(d->x, d->packed_w, lif, Cin, d->x_terms, d->x_shared, st, query);
+    } else {
+        ConvGeom g{};
+        g.NI = N; g.Cin = Cin; g.Cout = Cout; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo;
+        g.RS = Wi + 2 * pad;
+        g.pad_t = g.pad_l = pad;
+        g.ext_h = ksize;
+        for (int t = 0; t < 9; ++t) g.tap_off[t] = (t / 3) * g.RS + (t % 3);
+        g.oH = Ho; g.oW = Wo; g.os = 1; g.oph = g.opw = 0;
+        g.MT = (Cout + 31) / 32;
+        g.KSTEPS = (Cin + 15) / 16;
+        g.total_rows = N * Ho;
+        g.Wst = Wi; g.gx0 = 0; g.qshift = 0; g.parts = 1;
+        g.lif = lif;
+        const bf16x8* wp = (const bf16x8*)d->packed_w;
+        const float* x = (const float*)d->x;
+        const bool v4 = Wi % 4 == 0;
+#define EAS_LIF_DISPATCH(S_)                                                                                                           \
+    rc = !shared ? (v4 ? dispatch_tile_lif<9, S_, 1, 16, 4, true, 1>(x, wp, g, st, query) : dispatch_tile_lif<9, S_, 1, 16, 2, true, 1>(x, wp, g, st, query)) \
+       : d->x_terms == 1 ? (v4 ? dispatch_tile_lif<9, S_, 1, 16, 4, false, 2>(x, wp, g, st, query) : dispatch_tile_lif<9, S_, 1, 16, 2, false, 2>(x, wp, g, st, query)) \
+                         : (v4 ? dispatch_tile_lif<9, S_, 3, 16, 4, false, 2>(x, wp, g, st, query) : dispatch_tile_lif<9, S_, 3, 16, 2, false, 2>(x, wp, g, st, query))
+        if (stride == 1) { EAS_LIF_DISPATCH(1); }
+        else { EAS_LIF_DISPATCH(2); }
+#undef EAS_LIF_DISPATCH
+    }
+    if (rc != EAS_OK || query) return rc;
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_conv_bn_lif_eval(const EasConvBnLifEval* d, eas_stream_t stream) { return conv_lif_impl(d, stream, false); }
+
+int eas_conv_bn_lif_eval_supported(int T, int N, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms, int x_shared) {
+    EasConvBnLifEval d{};
+    d.T = T; d.N = N; d.Cin = Cin; d.Cout = Cout; d.Hi = Hi; d.Wi = Wi; d.ksize = ksize; d.stride = stride; d.x_terms = x_terms; d.x_shared = x_shared;
+    d.csplit = Cout;
+    return conv_lif_impl(&d, nullptr, true) == EAS_OK ? 1 : 0;
 }
 
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,

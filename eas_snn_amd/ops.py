@@ -745,6 +745,201 @@ def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_st
     return spikes, v_out, mo
 
 
+# ------------------------------------------------------------------------------------------------ fused eval step (conv -> BN -> LIF, ONE kernel)
+# In eval mode BatchNorm uses its running statistics, so nothing of a layer has to exist before its neurons can run: eas_conv_bn_lif_eval
+# computes the convolution with the time steps of a pixel side by side in the wave tile, normalises in the epilogue and walks the neuron over
+# T there -- the convolution output never reaches HBM (2 B per neuron-step written as spike planes instead of 4 + 4 + 2).  Same arithmetic
+# as eas_conv_fwd + eas_bn_lif_fwd_ex: bit-identical spikes.  EAS_FUSED_EVAL=0: development switch, the two-kernel path.
+FUSED_EVAL = os.environ.get('EAS_FUSED_EVAL', '1') == '1'
+_LIF_EVAL_SUPPORT = {}
+
+
+def _plain_conv(conv):
+    c = conv[0] if isinstance(conv, torch.nn.Sequential) and len(conv) == 1 else conv
+    if not _static_conv_ok(c) or c.bias is not None or c._forward_hooks or c._forward_pre_hooks:
+        return None
+    return c
+
+
+def _eval_neuron_ok(bn, node):
+    """BatchNorm on running statistics in front of a soft-reset (P)LIF neuron with decay_input = False (what utils_snn.py:44-53 builds)"""
+    if bn._use_batch_stats() or not bn.affine or bn.running_mean is None:
+        return False
+    a = node.lif_args()
+    return (a['flags'] & (FLAG_HARD_RESET | FLAG_DECAY_INPUT | FLAG_FIRE_STRICT)) == 0
+
+
+def fused_eval_ok(x_seq, conv, layers):
+    """``conv`` (nn.Conv2d, possibly inside its SeqToANNContainer) followed by the (bn, node) pairs of ``layers`` on consecutive output-channel
+    ranges can run as eas_conv_bn_lif_eval on ``x_seq`` [T,N,Cin,H,W]"""
+    if not FUSED_EVAL or torch.is_grad_enabled() or _CONV_SINK is not None or torch.nn.modules.module._global_forward_hooks:
+        return False
+    if not (torch.is_tensor(x_seq) and x_seq.is_cuda and x_seq.dim() == 5 and x_seq.dtype == torch.float32):
+        return False
+    if isinstance(conv, tuple):
+        if not dual_weights_ok(*conv):
+            return False
+        c, cout = _plain_conv(conv[0]), conv[0].out_channels + conv[1].out_channels
+    else:
+        c = _plain_conv(conv)
+        cout = c.out_channels if c is not None else 0
+    if c is None or not all(_eval_neuron_ok(bn, node) for bn, node in layers):
+        return False
+    if any(bn.num_features % 8 for bn, _ in layers) or len(layers) > 2 or sum(bn.num_features for bn, _ in layers) != cout:
+        return False
+    T, N, Cin, H, W = x_seq.shape
+    base = getattr(x_seq, '_eas_base', None)
+    if base is not None:
+        xt, shared = (1 if is_small_int(base) else 3), 1
+        if planes_of(base) is not None:
+            return False
+    else:
+        if not is_small_int(x_seq) or Cin % 8 or (H * W) % 4:
+            return False            # distinct real-valued frames per step: no tile form (the wave tile holds T steps of spike planes)
+        xt, shared = 2, 0
+    key = (T, N, Cin, cout, H, W, c.kernel_size[0], c.stride[0], xt, shared)
+    r = _LIF_EVAL_SUPPORT.get(key)
+    if r is None:
+        r = _LIF_EVAL_SUPPORT[key] = bool(_lib.lib().eas_conv_bn_lif_eval_supported(*key))
+    return r
+
+
+def current_packs(packs):
+    """``packs`` if it is the packing made by the forward that is running now (``packed_weights``), else None"""
+    return packs if (packs is not None and _PACK_SCOPE is not None and packs.get('gen') == _PACK_SCOPE) else None
+
+
+def dual_weights_ok(conv_a, conv_b):
+    """two convolutions that read the same input and can run as one with concatenated weights (same geometry, no bias)"""
+    conv_a, conv_b = _plain_conv(conv_a), _plain_conv(conv_b)
+    return (conv_a is not None and conv_b is not None and conv_a.kernel_size == conv_b.kernel_size
+            and conv_a.stride == conv_b.stride == (1, 1) and conv_a.in_channels == conv_b.in_channels)
+
+
+def conv_bn_lif_eval(x_seq, conv, layers, want_mean=False, residual=None, cats=None, planes=None, packs=None):
+    """The fused eval step.  layers: [(bn, node)] or two of them (consecutive output-channel ranges of ``conv``: conv1 | conv2 of a CSPLayer,
+    then ``conv`` is (conv_a, conv_b) and ``packs`` the packing of their concatenated weight or None); cats[i] = (buffer, first channel[,
+    planes of the buffer]) or None; planes[i]: hand the spikes on as spike planes (ghost).  residual: SEW shortcut of a single layer.
+    Returns one spike tensor per layer (a view into the concatenation buffer where given); with want_mean (single layer) (spikes, rate).
+    Caller checked ``fused_eval_ok``."""
+    L = _lib.lib()
+    nl = len(layers)
+    cats = cats or [None] * nl
+    planes = planes or [False] * nl
+    T, N, Cin, H, W = x_seq.shape
+    dev = x_seq.device
+    if isinstance(conv, tuple):
+        ca, cb = _plain_conv(conv[0]), _plain_conv(conv[1])
+        k, stride, Cout = ca.kernel_size[0], ca.stride[0], ca.out_channels + cb.out_channels
+        pk = packs[0] if packs else conv_pack_weights(torch.cat([ca.weight, cb.weight], 0), 0)
+    else:
+        c = _plain_conv(conv)
+        k, stride, Cout = c.kernel_size[0], c.stride[0], c.out_channels
+        pk = getattr(c, '_eas_packs', None)
+        pk = pk[0] if (pk is not None and _PACK_SCOPE is not None and pk.get('gen') == _PACK_SCOPE) else conv_pack_weights(c.weight, 0)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    HW = Ho * Wo
+    base = getattr(x_seq, '_eas_base', None)
+    d = _lib.EasConvBnLifEval()
+    keep = [pk]
+    if base is not None:
+        xb = _f32c(base)
+        keep.append(xb)
+        d.x, d.x_terms, d.x_shared = ptr(xb), (1 if is_small_int(base) else 3), 1
+    else:
+        sp = planes_of(x_seq)
+        if sp is None:
+            _verify_tags(x_seq, True)
+            sp = to_planes(x_seq)                       # a block called on its own with fp32 spikes (tests, hooks): one conversion
+        sp = sp.contiguous()
+        keep.append(sp)
+        d.x, d.x_terms, d.x_shared = ptr(sp), 2, 0
+    d.packed_w = ptr(pk)
+    d.T, d.N, d.Cin, d.Cout, d.Hi, d.Wi, d.ksize, d.stride = T, N, Cin, Cout, H, W, k, stride
+    d.csplit = layers[0][0].num_features
+    assert sum(bn.num_features for bn, _ in layers) == Cout and (nl == 1 or d.csplit < Cout)
+    write_v = _STATE_WRITEBACK
+    outs, rate = [], None
+    for i, (bn, node) in enumerate(layers):
+        r = d.range[i]
+        Cr = bn.num_features
+        a = node.lif_args()
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        keep.append(invstd)
+        r.gamma, r.beta, r.mean, r.invstd = ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(invstd)
+        w = a['w']
+        r.w_logit, r.k_const, r.v_th = (ptr(w) if w is not None else None), float(a['k_const']), float(a['v_th'])
+        cat = cats[i]
+        cat_sp = cat is not None and len(cat) > 2 and cat[2] is not None
+        want_planes = bool(cat_sp or (planes[i] and cat is None)) and SPIKE_PLANES
+        if cat is not None:
+            buf, c0 = cat[0], int(cat[1])
+            out = buf.narrow(2, c0, Cr)
+            r.out_ctot, r.out_c0 = buf.shape[2], c0
+            if cat_sp:
+                assert cat[2].is_contiguous() and cat[2].shape == (T, N, buf.shape[2] // 8, HW, 8)
+                r.planes, r.out_f32 = ptr(cat[2]), None
+            else:
+                assert buf.is_contiguous() and buf.dtype == torch.float32
+                r.planes, r.out_f32 = None, ptr(buf)
+        elif want_planes:
+            sp_out = new_planes(T, N, Cr, Ho, Wo, dev)
+            out = ghost((T, N, Cr, Ho, Wo), dev, sp_out)
+            r.planes, r.out_f32, r.out_ctot, r.out_c0 = ptr(sp_out), None, Cr, 0
+        else:
+            out = torch.empty((T, N, Cr, Ho, Wo), dtype=torch.float32, device=dev)
+            r.planes, r.out_f32, r.out_ctot, r.out_c0 = None, ptr(out), Cr, 0
+        r.res_planes = r.res_f32 = None
+        r.res_ctot = 0
+        small_out = True
+        if residual is not None:
+            assert nl == 1 and residual.shape == (T, N, Cr, Ho, Wo)
+            rs = planes_of(residual)
+            if rs is not None:
+                rs = rs.contiguous()
+                keep.append(rs)
+                r.res_planes, r.res_ctot = ptr(rs), Cr
+            else:
+                rf = _f32c(residual)
+                keep.append(rf)
+                r.res_f32, r.res_ctot = ptr(rf), Cr
+                small_out = is_small_int(residual)
+                if want_planes or cat_sp:
+                    _verify_tags(residual, True)
+                    if not small_out:
+                        raise _lib.EasHipError('a real-valued shortcut cannot be added into spike planes')
+        if want_mean:
+            assert nl == 1
+            rate = torch.empty((N, Cr, Ho, Wo), dtype=torch.float32, device=dev)
+            r.rate = ptr(rate)
+        else:
+            r.rate = None
+        v = node.v
+        if torch.is_tensor(v):
+            if tuple(v.shape) != (N, Cr, Ho, Wo):
+                raise ValueError(f'membrane state {tuple(v.shape)} does not match the layer output {(N, Cr, Ho, Wo)}; call reset()')
+            v_in = _f32c(v.detach())
+        else:
+            v_in = None if v == 0.0 else torch.full((N, Cr, Ho, Wo), float(v), dtype=torch.float32, device=dev)
+        keep.append(v_in)
+        r.v_in = ptr(v_in)
+        v_out = torch.empty((N, Cr, Ho, Wo), dtype=torch.float32, device=dev) if write_v else None
+        r.v_out = ptr(v_out)
+        if v_out is not None:
+            node.v = v_out
+        if small_out:
+            mark_small_int(out)
+        outs.append(out)
+    fl = 2.0 * T * N * Cout * HW * Cin * k * k / (T if d.x_shared else 1)
+    nb = (2 if d.x_terms == 2 else 4) * (N if d.x_shared else T * N) * Cin * H * W + 2 * T * N * Cout * HW
+    _call('eas_conv_bn_lif_eval', nb, L.eas_conv_bn_lif_eval, C.byref(d), stream(), flops=fl, issue_flops=fl * (6 if d.x_terms == 3 else 3))
+    del keep
+    if want_mean:
+        return outs[0], rate
+    return outs if nl > 1 else outs[0]
+
+
 # Number of identical copies the current batch stands for (set by SeqToANNContainer while it runs a stateless block
 # ONCE for T identical time steps): batch-norm statistics are unchanged by replication except for the sample count
 # used in the unbiased running variance.

@@ -411,6 +411,49 @@ int eas_conv_fwd_planes(const void* x_planes, const void* packed_w, const float*
 /* 1 when eas_conv_fwd has a tile for this geometry, else 0 (it would return EAS_ERR_UNSUPPORTED).  3x3 layers whose staged input
  * rows do not fit LDS in one piece (real-valued inputs on rows wider than ~280 pixels) run in 2, 4 or 8 column parts. */
 int eas_conv_fwd_supported(int NI, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms);
+/* ---- Fused eval-mode step: conv -> BatchNorm (running statistics) -> (P)LIF over T in ONE kernel --------------------------------
+ * BaseConv.forward of a converted block in eval mode (yolox/models/network_blocks.py:52-53 after utils_snn.py:16-58; the "fused
+ * conv -> BN -> LIF step" of the north star, eval-folded).  The convolution output never reaches HBM: the matrix-core kernel's
+ * accumulators are the BatchNorm inputs of the lane's neurons for all T steps (the GEMM's pixel index enumerates (time, pixel)), the
+ * epilogue normalises with the running statistics and walks the neuron over T, and only spikes are written -- 2 bytes per neuron-step
+ * as spike planes instead of the 4 (y written) + 4 (y read) + 2 of eas_conv_fwd + eas_bn_lif_fwd_ex.  Same arithmetic
+ * (z = fma(y, gamma*invstd, beta - mean*gamma*invstd), soft reset, fire at >=): spikes bit-identical to the two-kernel path.
+ * Neurons: ParametricLIFNode / LIFNode with decay_input = False, v_reset = None (soft reset), the form utils_snn.py:44-53 builds.
+ *
+ * EasLifRange = one neuron layer = a range of the convolution's output channels: [0, csplit) and [csplit, Cout) (csplit = Cout: one
+ * layer; two: conv1 | conv2 of a CSPLayer computed by one convolution, network_blocks.py:175-188).  Per range: the output as spike
+ * planes [T*N][out_ctot/8][HW][8] or fp32 [T][N][out_ctot][HW], written at channel out_c0 of the destination (concatenation in place);
+ * an optional SEW shortcut (planes or fp32, its channel 0 = the range's first channel) added to the spikes; optional firing rate
+ * [N][C_range][HW] (mean over T of the spikes), initial / final membrane potentials [N][C_range][HW] (NULL: reset value / not kept).
+ * x: spike planes [T*N][Cin/8][Hi*Wi][8] (x_terms = 2), or, with x_shared = 1, fp32 [N][Cin][Hi][Wi] (x_terms 1 / 3) used for every time
+ * step (T identical frames: the first spiking layer behind the stateless stem, spiking_yolox.py:52-57).  csplit, Cout, out_ctot, out_c0,
+ * res_ctot multiples of 8; T 3 or 5 for distinct frames (the wave tile holds the T time steps), 1..8 for x_shared. */
+typedef struct {
+    const float *gamma, *beta, *mean, *invstd;   /* [C_range]: BatchNorm affine parameters, running mean, 1 / sqrt(running var + eps) */
+    const float* w_logit;      /* PLIF: k = sigmoid(*w_logit); NULL: k_const */
+    float k_const, v_th;
+    void* planes;              /* output as spike planes, or */
+    float* out_f32;            /* as fp32 */
+    int out_ctot, out_c0;
+    const void* res_planes;    /* SEW shortcut as planes, or */
+    const float* res_f32;      /* as fp32; both NULL: none */
+    int res_ctot;
+    float* rate;
+    const float* v_in;
+    float* v_out;
+} EasLifRange;
+typedef struct {
+    const void* x;
+    const void* packed_w;      /* eas_conv_pack_weights mode 0 */
+    int x_terms, x_shared;
+    int T, N, Cin, Cout, Hi, Wi, ksize, stride;
+    int csplit;
+    EasLifRange range[2];
+} EasConvBnLifEval;
+int eas_conv_bn_lif_eval(const EasConvBnLifEval* d, eas_stream_t stream);
+/* 1 when eas_conv_bn_lif_eval has a tile for this geometry (else the caller runs eas_conv_fwd + eas_bn_lif_fwd_ex) */
+int eas_conv_bn_lif_eval_supported(int T, int N, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms, int x_shared);
+
 /* Input gradient of a stride-2 3x3 convolution: grad_x[NI][Cin][Hi][Wi] from grad_y[NI][Cout][Ho][Wo] and the weights
  * packed with mode 2 (eas_conv_pack_weights), by parity class of the input pixel (1/2/2/4 taps per class). */
 int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, int NI, int Cin, int Cout, int Hi, int Wi,

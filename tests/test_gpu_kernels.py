@@ -1169,6 +1169,71 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         assert err < 1e-5, f'{name}: {err:.2e}'
 
 
+FUSED_EVAL_CASES = [  # T, N, Cin, Cout, H, W, k, stride
+    (3, 2, 16, 32, 8, 10, 3, 1), (3, 5, 32, 64, 16, 20, 3, 1), (3, 3, 64, 64, 32, 40, 3, 1), (3, 2, 32, 64, 16, 20, 3, 2), (5, 2, 48, 96, 16, 20, 3, 1),
+    (5, 3, 24, 48, 32, 40, 3, 2), (3, 7, 64, 32, 8, 10, 1, 1), (3, 2, 128, 64, 16, 20, 1, 1), (5, 2, 96, 48, 16, 20, 1, 1), (3, 4, 512, 256, 8, 10, 1, 1),
+    (5, 2, 384, 192, 8, 10, 1, 1), (3, 2, 32, 40, 64, 80, 3, 1), (3, 1, 32, 64, 128, 160, 1, 1), (3, 64, 256, 256, 8, 10, 3, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,N,Cin,Cout,H,W,k,s', FUSED_EVAL_CASES)
+@pytest.mark.parametrize('form', ['plain', 'planes_sew_rate'])
+def test_fused_eval_step_is_bit_identical_to_conv_then_bn_lif(dev, monkeypatch, T, N, Cin, Cout, H, W, k, s, form):
+    """eas_conv_bn_lif_eval (conv -> BatchNorm on running statistics -> PLIF over T in ONE kernel, the convolution output never written)
+    against eas_conv_fwd + eas_bn_lif_fwd_ex on the same inputs: spikes, final membrane potentials and firing rate BIT-identical, for
+    3x3 stride 1 / 2 and 1x1 (direct and shared-fragment) layers, T = 3 and 5, tiles spanning images and ragged last tiles; 'plain':
+    fp32 spikes in / out with the state carried in from a previous call; 'planes_sew_rate': planes in, planes out, SEW shortcut from
+    planes (stride 1) and the firing-rate readout."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import functional, surrogate
+    from yolox.models.network_blocks import BaseConv
+    from yolox.utils.utils_snn import convert_to_spiking
+    g = torch.Generator().manual_seed(T * 1000 + Cin + Cout + H)
+    blk = convert_to_spiking(BaseConv(Cin, Cout, k, s), surrogate.ATan(2.0)).to(dev).eval()
+    with torch.no_grad():
+        blk.conv[0].weight.copy_(torch.randn(Cout, Cin, k, k, generator=g) * (1.5 / (Cin * k * k) ** 0.5))
+        blk.bn.weight.copy_(torch.rand(Cout, generator=g) + 0.7)
+        blk.bn.bias.copy_(torch.rand(Cout, generator=g) * 0.8 - 0.2)
+        blk.bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2)
+        blk.bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+        blk.act.w.fill_(0.3)
+    blk.bn.eps = 1e-3
+    x = ((torch.rand(T, N, Cin, H, W, generator=g) < 0.25).float() + (torch.rand(T, N, Cin, H, W, generator=g) < 0.05).float()).to(dev)
+    ops.mark_small_int(x)
+    sew = form == 'planes_sew_rate' and s == 1 and Cin == Cout
+    blk.emit_rate = form == 'planes_sew_rate' and not sew
+    res = None
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'FUSED_EVAL', fused)
+        functional.reset_net(blk)
+        with torch.no_grad(), ops.kernel_trace() as tr:
+            if form == 'plain':
+                blk(x)                                     # leaves a membrane state: the second call starts from it
+                out = blk(x)
+            else:
+                xg = ops.ghost(x.shape, dev, ops.to_planes(x))
+                blk.planes_out = True
+                monkeypatch.setattr(ops, '_PLANES_SCOPE', True)
+                out = blk(xg, residual=xg if sew else None)
+                monkeypatch.setattr(ops, '_PLANES_SCOPE', False)
+        rate = None
+        if isinstance(out, tuple):
+            out, rate = out
+        if form != 'plain':
+            assert ops.planes_of(out) is not None
+        names = [c[0] for c in tr.calls]
+        assert ('eas_conv_bn_lif_eval' in names) == fused, names
+        assert not fused or not any(n.startswith('eas_conv_fwd') or n.startswith('eas_bn_lif') for n in names), names
+        runs.append((ops.dense(out).clone(), blk.act.v.clone(), None if rate is None else rate.clone()))
+    functional.reset_net(blk)
+    (o1, v1, r1), (o0, v0, r0) = runs
+    assert 0.02 < float((o0 > 0).float().mean()) < 0.9, 'the layer must fire for the comparison to mean something'
+    assert torch.equal(o1, o0), f'{int((o1 != o0).sum())} of {o0.numel()} outputs differ'
+    assert torch.equal(v1, v0)
+    assert (r1 is None) == (r0 is None) and (r1 is None or torch.equal(r1, r0))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('Cin,Cout,H,W,k', [(16, 32, 8, 10, 3), (64, 32, 8, 10, 1), (512, 256, 8, 10, 1)])
 def test_mistagged_spike_tensor_fails_loudly(dev, monkeypatch, Cin, Cout, H, W, k):

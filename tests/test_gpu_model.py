@@ -786,6 +786,31 @@ def test_evaluator_on_the_gpu(dev, tmp_path):
     assert k >= 20
 
 
+@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_fullv2_64', 'model_s_true_256x320', 'model_m_fullv2_t5_64x96'])
+def test_eval_forward_with_the_fused_step_is_bit_identical(dev, name, monkeypatch):
+    """The whole eval forward with every converted block as ONE conv -> BN -> LIF kernel (eas_conv_bn_lif_eval, the default in eval mode)
+    against the two-kernel path (EAS_FUSED_EVAL=0): every logit bit-identical; the trace shows the fused entry point took the spiking
+    blocks (the first spiking layer through the shared-input form, the CSPLayer branch pairs as one call)."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import functional
+    g, model = _build(name, dev)
+    model.eval()
+    x = torch.from_numpy(g['x']).to(dev)
+    outs, calls = [], []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'FUSED_EVAL', fused)
+        with torch.no_grad(), ops.no_state_writeback(), ops.kernel_trace() as tr:
+            outs.append(model(x).clone())
+        functional.reset_net(model)
+        calls.append([c[0] for c in tr.calls])
+    nf = calls[0].count('eas_conv_bn_lif_eval')
+    nb = sum(1 for n in calls[1] if n == 'eas_bn_lif_fwd_ex')
+    print(f'{name}: {nf} fused conv->BN->LIF calls replace {nb} BN+LIF calls (+ their convolutions); '
+          f'{sum(1 for n in calls[0] if n == "eas_bn_lif_fwd_ex")} layers stay on the two-kernel path')
+    assert nf >= 0.8 * nb and 'eas_conv_bn_lif_eval' not in calls[1]
+    assert torch.equal(outs[0], outs[1]), f'max |diff| {float((outs[0] - outs[1]).abs().max()):.3g}'
+
+
 def test_deferred_weight_gradient_reductions_are_bit_identical(dev):
     """ops.deferred_wgrad_reductions(): the slab reductions of all weight gradients of a backward pass in ONE launch at its end
     (eas_conv_wgrad_reduce_many) -- same loss, every parameter gradient bit-identical to the immediate reductions, also on a second
