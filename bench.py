@@ -414,20 +414,35 @@ def main():
         step.eager()
     torch.cuda.synchronize()
     ops.set_timer(None)
-    # inference side figure: eval-mode forward of the same batch (no loss, no backward), a few repetitions
+    # inference side figure: eval-mode forward + reset_net of the same batch (no loss, no backward), replayed as a HIP graph like the
+    # evaluator does (yolox/evaluators/event_evaluator.py), for the model as trained and after yolox.utils.fuse_model (tools/eval_event.py --fuse)
     eval_fps = None
     if rank == 0 and not multi:
+        import copy
         from spikingjelly.activation_based import functional
-        model.eval()
-        with torch.no_grad():
-            for _ in range(2):
-                model(inputs_fn()[0]); functional.reset_net(model)
-            torch.cuda.synchronize()
-            t_e = time.perf_counter()
-            for _ in range(5):
-                model(inputs_fn()[0]); functional.reset_net(model)
-            torch.cuda.synchronize()
-            eval_fps = round(5 * batch / (time.perf_counter() - t_e), 1)
+        from yolox.utils import fuse_model
+
+        def eval_rate(net):
+            net.eval()
+
+            def fwd():
+                net(inputs_fn()[0])
+                functional.reset_net(net)
+            with torch.no_grad():
+                for _ in range(2):
+                    fwd()
+                torch.cuda.synchronize()
+                g_ev = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_ev):
+                    fwd()
+                g_ev.replay()
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()
+                for _ in range(10):
+                    g_ev.replay()
+                torch.cuda.synchronize()
+                return round(10 * batch / (time.perf_counter() - t_e), 1)
+        eval_fps = {'value': eval_rate(model), 'fuse_model': eval_rate(fuse_model(copy.deepcopy(model)))}
         model.train()
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -504,7 +519,7 @@ def main():
                            'h2d_per_step': (h2d.describe() if h2d is not None else None)},
                 'roofline': roofline}
         if eval_fps is not None:
-            line['eval_forward_frames_per_s'] = {'value': eval_fps, 'batch': batch, 'note': 'model.eval() forward + reset_net on the same batch, one GPU'}
+            line['eval_forward_frames_per_s'] = dict(eval_fps, batch=batch, note='model.eval() forward + reset_net on the same batch, one GPU, HIP-graph replay (as EventEvaluator); fuse_model: after yolox.utils.fuse_model (eval_event.py --fuse)')
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(w, args.cpu_batch or (8 if w['config'] == 2 else 2), args.events)
         print(json.dumps(line), flush=True)

@@ -126,6 +126,7 @@ PROTOTYPES = {
     'eas_conv_fwd_supported': (C.c_int, [C.c_int] * 8),
     'eas_conv_wgrad_parts': (C.c_int, [C.c_int] * 7),
     'eas_conv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P, _P]),
+    'eas_conv_fwd_act': (C.c_int, [_P] * 4 + [C.c_int] * 9 + [_P, _P]),
     'eas_conv_fwd_planes': (C.c_int, [_P] * 4 + [C.c_int] * 7 + [_P, C.c_int, _P]),
     'eas_spike_planes_from_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P]),
     'eas_spike_planes_to_f32': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
@@ -139,6 +140,8 @@ PROTOTYPES = {
     'eas_conv_wgrad_reduce_many': (C.c_int, [_P, C.c_int, _P]),
     'eas_spp_pool_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
+    'eas_spp_pool_planes_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
+    'eas_spp_pool_planes_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
 }
 
 

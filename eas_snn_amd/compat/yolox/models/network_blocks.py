@@ -70,7 +70,7 @@ class BaseConv(nn.Module):
                                    # by ``enable_spike_planes`` on blocks whose readers take planes or unpack them (ops.dense)
 
     def spiking(self):
-        return isinstance(self.act, sj_neuron.BaseNode) and isinstance(self.bn, sj_layer.BatchNorm2d)
+        return isinstance(self.act, sj_neuron.BaseNode) and isinstance(getattr(self, 'bn', None), sj_layer.BatchNorm2d)
 
     def forward(self, x, residual=None, cat=None):
         """residual / cat: only for converted (spiking) blocks on the fused BN+LIF path -- the SEW shortcut addition and the
@@ -101,10 +101,18 @@ class BaseConv(nn.Module):
     def ann_fusable(self, y):
         """BN + SiLU of this (real-valued) block run as the fused HIP kernel on ``y`` (then the output can also go straight into a
         concatenation buffer)"""
-        return (type(self.bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and self.bn.affine and ops.bn_silu_supported(y)
-                and (self.bn.momentum is not None or not self.bn.training))
+        bn = getattr(self, 'bn', None)          # (None: fuse_model folded it into the convolution)
+        return (type(bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and bn.affine and ops.bn_silu_supported(y)
+                and (bn.momentum is not None or not bn.training))
 
     def fuseforward(self, x):
+        """the forward of a block whose BatchNorm ``fuse_model`` folded into the convolution (network_blocks.py:55-56 of the reference): on the
+        GPU without autograd the activation runs in the convolution's epilogue -- one kernel for the whole block"""
+        if type(self.conv) is nn.Conv2d and isinstance(self.act, nn.SiLU) and x.is_cuda and x.dim() == 4 and self.conv.bias is not None:
+            y = ops.conv_act_eval(x, self.conv, 'silu')
+            if y is not None:
+                return y
+            return self.act(ops.conv2d(x, self.conv))
         return self.act(self.conv(x))
 
 

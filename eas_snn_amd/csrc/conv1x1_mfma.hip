@@ -31,6 +31,7 @@ struct C1Geom {
     // fused eval step conv -> BatchNorm (running statistics) -> LIF over T (kernel template LM = 1, conv_lif_epi.h): NI = samples N, total_tiles
     // counts SPATIAL 32-pixel tiles, pixel tile n of a wave = time step n (WN == lif.T): image n * N + sample
     EasLifEpiDev lif;
+    int act;                          // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act)
 };
 
 // statistics epilogue of the 1x1 kernels: 4 waves of a block = 4 pixel groups of the same WM * 32 channels
@@ -264,11 +265,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
             float* yp = y + yoff[n] + (long)co0 * g.HW;
             if (full) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
             }
         }
     }
@@ -495,11 +496,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
             float* yp = y + yoff[n] + (long)co0 * g.HW;
             if (full) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
             }
         }
     }
@@ -540,10 +541,11 @@ int launch_c1_lif(const float* x, const bf16x8* wp, C1Geom g, hipStream_t st, bo
 // wave-tile choice and launch for a 1x1 convolution; PL: x is a spike-plane tensor (x_terms 1)
 template <bool PL>
 static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                              hipStream_t st, double* stats = nullptr, int stats_nb = 0, int* inexact = nullptr) {
+                              hipStream_t st, double* stats = nullptr, int stats_nb = 0, int* inexact = nullptr, int act = 0) {
     C1Geom g{};
     g.stats = stats; g.stats_nb = stats_nb;
     g.inexact = inexact;
+    g.act = act;
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
     g.tiles_per_img = (HW + 31) / 32;
     g.total_tiles = NI * g.tiles_per_img;
@@ -609,10 +611,10 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
 
 // called by eas_conv_fwd (conv_mfma.hip) for ksize == 1, stride == 1; planes != 0: x is a spike-plane tensor
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact) {
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact, int act) {
     tl_c1_blocks = 0;
-    const int rc = planes ? conv1x1_dispatch_t<true>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st, stats, stats_nb, nullptr)
-                          : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb, inexact);
+    const int rc = planes ? conv1x1_dispatch_t<true>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st, stats, stats_nb, nullptr, act)
+                          : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb, inexact, act);
     if (nb_out) *nb_out = tl_c1_blocks;
     return rc;
 }

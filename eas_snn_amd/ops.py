@@ -750,7 +750,12 @@ def bn_lif_multistep(y_seq, gamma, beta, running_mean, running_var, use_batch_st
 # computes the convolution with the time steps of a pixel side by side in the wave tile, normalises in the epilogue and walks the neuron over
 # T there -- the convolution output never reaches HBM (2 B per neuron-step written as spike planes instead of 4 + 4 + 2).  Same arithmetic
 # as eas_conv_fwd + eas_bn_lif_fwd_ex: bit-identical spikes.  EAS_FUSED_EVAL=0: development switch, the two-kernel path.
-FUSED_EVAL = os.environ.get('EAS_FUSED_EVAL', '1') == '1'
+# EAS_FUSED_EVAL: 'auto' (default) = where it was measured faster than the two kernels (batch 64, MI355X, scripts/dev_fused_layer.py): the 1x1
+# layers on the direct kernel (fewer than 256 input channels: their y round trip is most of their time -- 64->64 at 64x80: 109 us against
+# 166) and the 3x3 stride-1 layers on maps of >= 5120 pixels; the small-map and stride-2 layers (whose T-fold larger blocks quantise worse over
+# the 256 CUs: 64->64 at 32x40 88 us against 80) and the shared-input first layer keep the two-kernel path.  'all' / '1': every eligible
+# layer (the tests); '0': none.
+FUSED_EVAL = {'1': 'all', 'all': 'all', '0': False, 'auto': 'auto'}.get(os.environ.get('EAS_FUSED_EVAL', 'auto'), 'auto')
 _LIF_EVAL_SUPPORT = {}
 
 
@@ -797,6 +802,10 @@ def fused_eval_ok(x_seq, conv, layers):
         if not is_small_int(x_seq) or Cin % 8 or (H * W) % 4:
             return False            # distinct real-valued frames per step: no tile form (the wave tile holds T steps of spike planes)
         xt, shared = 2, 0
+    if FUSED_EVAL == 'auto':
+        k_, s_ = c.kernel_size[0], c.stride[0]
+        if shared or s_ != 1 or (k_ == 1 and Cin >= 256) or (k_ == 3 and H * W < 5120):
+            return False
     key = (T, N, Cin, cout, H, W, c.kernel_size[0], c.stride[0], xt, shared)
     r = _LIF_EVAL_SUPPORT.get(key)
     if r is None:
@@ -1713,7 +1722,7 @@ def conv_pack_weights(w, mode=0):
     return packed
 
 
-def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_sp=None):
+def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_sp=None, act=0):
     """conv2d(x [NI,Cin,H,W], packed weights), padding ksize//2, on the matrix cores.  x_sp: x is a ghost and these are its spike planes
     [NI,Cin/8,H*W,8] (eas_conv_fwd_planes: same result, half the input bytes, no conversion)."""
     _dev(x, packed, bias)
@@ -1738,6 +1747,10 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_sp=None):
             _CONV_STATS_SLOT = (y, nb, stats, y._version)
         return y
     x = _f32c(x)
+    if act:             # y = act(conv + bias) from the epilogue (eas_conv_fwd_act: an eval-mode BaseConv with its BatchNorm folded in)
+        _call('eas_conv_fwd', 4 * (x.numel() + y.numel()), L.eas_conv_fwd_act, ptr(x), ptr(packed), ptr(bias), ptr(y), NI, Cin, Cout, Hi, Wi,
+              ksize, stride, x_terms, int(act), _tag_flag(x, x_terms), stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+        return y
     if _WANT_CONV_STATS and bias is None:
         nb = _conv_stats_blocks(L, (NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms))
         if 0 < nb <= CONV_STATS_MAX_BLOCKS:
@@ -2207,6 +2220,25 @@ def spike_sop(x, ksize, stride, cout):
     return out
 
 
+def conv_act_eval(x, conv, act='silu'):
+    """``act(conv(x))`` for an nn.Conv2d with bias in ONE kernel (eas_conv_fwd_act), no autograd: the eval-mode forward of a real-valued
+    BaseConv whose BatchNorm ``fuse_model`` folded into the convolution (network_blocks.py:55-56).  None when the layer is not eligible
+    (the caller then runs convolution and activation separately)."""
+    if (act != 'silu' or torch.is_grad_enabled() or _CONV_SINK is not None or conv._forward_hooks or conv._forward_pre_hooks
+            or torch.nn.modules.module._global_forward_hooks or not conv_eligible(x, conv)):
+        return None
+    k, s_ = conv.kernel_size[0], conv.stride[0]
+    small = is_small_int(x)
+    xd = dense(x)
+    xt = 1 if small else 3
+    if not conv_fwd_supported(xd.shape[0], xd.shape[1], conv.out_channels, xd.shape[2], xd.shape[3], k, s_, xt):
+        return None
+    _verify_tags(xd, small)
+    packs = getattr(conv, '_eas_packs', None)
+    pk = packs[0] if (packs is not None and _PACK_SCOPE is not None and packs.get('gen') == _PACK_SCOPE) else conv_pack_weights(conv.weight, 0)
+    return conv_fwd_packed(xd, pk, conv.bias, conv.out_channels, k, s_, xt, act=1)
+
+
 def conv2d(x, conv, small_int=None):
     """``conv(x)`` for an ``nn.Conv2d`` on the matrix-core kernels where eligible (else ATen/MIOpen).
     A module that carries forward hooks (RecordHook in energy_estimation, event_evaluator.py:519-523; thop in
@@ -2257,13 +2289,49 @@ class _SPPFn(torch.autograd.Function):
         return gx, None
 
 
+class _SPPPlanesFn(torch.autograd.Function):
+    """the SPP block on spike planes: ghost in (its planes), ghost out -- no fp32 copy of the spikes exists (eas_spp_pool_planes_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, x, sp, ks):
+        lead, (Cc, H, W) = x.shape[:-3], x.shape[-3:]
+        N = 1
+        for d in lead:
+            N *= d
+        out_sp = torch.empty(tuple(lead) + (4 * Cc // 8, H * W, 8), dtype=torch.bfloat16, device=sp.device)
+        _call('eas_spp_pool_fwd', 2 * 5 * N * Cc * H * W, _lib.lib().eas_spp_pool_planes_fwd, ptr(sp), ptr(out_sp), N, Cc, H, W, ks[0], ks[1], ks[2],
+              stream())
+        ctx.save_for_backward(sp)
+        ctx.cfg = (ks, tuple(x.shape), N)
+        ctx.mark_non_differentiable(out_sp)
+        return ghost(tuple(lead) + (4 * Cc, H, W), sp.device), out_sp
+
+    @staticmethod
+    def backward(ctx, g, _g_sp):
+        (sp,) = ctx.saved_tensors
+        ks, shape, N = ctx.cfg
+        Cc, H, W = shape[-3:]
+        g = _f32c(g)
+        gx = torch.empty(shape, dtype=torch.float32, device=g.device)
+        _call('eas_spp_pool_bwd', 4 * 5 * gx.numel() + 2 * gx.numel(), _lib.lib().eas_spp_pool_planes_bwd, ptr(sp), ptr(g), ptr(gx), N, Cc, H, W,
+              ks[0], ks[1], ks[2], stream())
+        return gx, None, None
+
+
 def spp_pool_supported(x, ks):
     return x.is_cuda and x.dtype == torch.float32 and x.dim() in (4, 5) and len(ks) == 3 and all(k % 2 == 1 for k in ks) and (
         x.shape[-1] * x.shape[-2] <= 1024)
 
 
 def spp_pool_cat(x, ks):
-    """cat[x, maxpool_k(x) for k in ks] along the channel axis of x [..., C, H, W] in one kernel (and one for the backward)."""
+    """cat[x, maxpool_k(x) for k in ks] along the channel axis of x [..., C, H, W] in one kernel (and one for the backward).  A ghost (spike
+    planes) stays one: packed 16-bit maxima over 16-byte pixels, and the backward reads x from the planes."""
+    sp = planes_of(x)
+    if sp is not None and x.shape[-3] % 8 == 0 and os.environ.get('EAS_SPP_PLANES', '1') == '1':
+        out, out_sp = _SPPPlanesFn.apply(x, sp.contiguous(), tuple(int(k) for k in ks))
+        out._eas_sp = out_sp
+        out._eas_small_int = True
+        return out
     x = dense(x)
     out = _SPPFn.apply(x, tuple(int(k) for k in ks))
     if is_small_int(x):

@@ -384,6 +384,10 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream);
 int eas_conv_fwd(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
                  int Wi, int ksize, int stride, int x_terms, int* inexact_flag, eas_stream_t stream);
+/* y = act(conv(x) + bias) in one kernel; act: 0 none, 1 SiLU (x * sigmoid(x)).  The eval-mode form of a real-valued BaseConv once
+ * fuse_model folded its BatchNorm into weights and bias (yolox/utils/model_utils.py:35-80, network_blocks.py:55-56 fuseforward). */
+int eas_conv_fwd_act(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi,
+                     int Wi, int ksize, int stride, int x_terms, int act, int* inexact_flag, eas_stream_t stream);
 /* Fused conv -> BN statistics (the conv -> BN -> LIF step of network_blocks.py:52-53 without a statistics pass over y): eas_conv_fwd
  * without bias whose epilogue also sums its output tile per channel -- stats[Cout][nb][2] doubles, (sum, sum of squares) of each of the
  * nb pixel blocks of the launch; nb = eas_conv_fwd_stats_blocks(same geometry) (0 = no tile).  Hand the buffer to the BatchNorm kernel
@@ -494,6 +498,12 @@ int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_str
 int eas_spp_pool_fwd(const float* x, float* out, int64_t N, int C, int H, int W, int k0, int k1, int k2, eas_stream_t stream);
 int eas_spp_pool_bwd(const float* x, const float* grad_out, float* grad_x, int64_t N, int C, int H, int W, int k0, int k1, int k2,
                      eas_stream_t stream);
+/* The same block on SPIKE PLANES (what the spiking dark5 hands to it): x_planes [N][C/8][HW][8] -> out_planes [N][4C/8][HW][8] (channel groups
+ * [0, C/8) = x, then the three pooled copies; packed 16-bit maxima: spikes / small integers are non-negative, so value order = bit order),
+ * and eas_spp_pool_bwd with x read from its planes.  C % 8 == 0. */
+int eas_spp_pool_planes_fwd(const void* x_planes, void* out_planes, int64_t N, int C, int H, int W, int k0, int k1, int k2, eas_stream_t stream);
+int eas_spp_pool_planes_bwd(const void* x_planes, const float* grad_out, float* grad_x, int64_t N, int C, int H, int W, int k0, int k1, int k2,
+                            eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Spike-count / synaptic-operation statistics.  Replaces calc_layer_sop of

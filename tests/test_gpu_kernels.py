@@ -1205,7 +1205,7 @@ def test_fused_eval_step_is_bit_identical_to_conv_then_bn_lif(dev, monkeypatch, 
     res = None
     runs = []
     for fused in (True, False):
-        monkeypatch.setattr(ops, 'FUSED_EVAL', fused)
+        monkeypatch.setattr(ops, 'FUSED_EVAL', 'all' if fused else False)
         functional.reset_net(blk)
         with torch.no_grad(), ops.kernel_trace() as tr:
             if form == 'plain':
@@ -1562,6 +1562,33 @@ def test_spp_pool_cat_matches_maxpool(dev, shape, spikes):
     ref.backward(go)
     assert torch.equal(out.detach().cpu(), ref.detach())
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 2, 16, 8, 10), (3, 64, 256, 8, 10), (5, 3, 24, 12, 20), (7, 2, 8, 6, 8), (2, 8, 6, 6)])
+def test_spp_pool_on_spike_planes_matches_maxpool(dev, shape):
+    """The SPP block on spike planes (eas_spp_pool_planes_fwd: packed 16-bit maxima over 16-byte pixels; eas_spp_pool_planes_bwd: x read from
+    its planes) against three nn.MaxPool2d + cat on the fp32 spikes: the output planes hold exactly the reference, the input gradient equals
+    autograd's (first-maximum tie rule on 0 / 1 / 2 inputs)."""
+    import torch.nn.functional as F
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = (torch.rand(shape, generator=g) < 0.3).float() + (torch.rand(shape, generator=g) < 0.05).float()
+    ks = (5, 9, 13)
+    xd = x.to(dev)
+    ghost = ops.ghost(xd.shape, dev, ops.to_planes(xd)).detach().requires_grad_(True)
+    ghost._eas_sp, ghost._eas_small_int = ops.to_planes(xd), True
+    with ops.kernel_trace() as tr:
+        out = ops.spp_pool_cat(ghost, ks)
+    assert ops.planes_of(out) is not None and [c[0] for c in tr.calls] == ['eas_spp_pool_planes_fwd']
+    go = torch.randn(out.shape, generator=g)
+    ops.dense(out).backward(go.to(dev))
+    xr = x.clone().requires_grad_(True)
+    flat = xr.flatten(0, -4) if xr.dim() > 4 else xr
+    ref = torch.cat([flat] + [F.max_pool2d(flat, k, 1, k // 2) for k in ks], dim=1).view(out.shape)
+    ref.backward(go)
+    assert torch.equal(ops.dense(out).detach().cpu(), ref.detach())
+    np.testing.assert_allclose(ghost.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu
