@@ -37,7 +37,7 @@ F32_MFMA_PEAK_TF = 157.3    # dense f32-input MFMA peak (MI355X_MICROARCH.md, Ma
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same
 # command, scripts/gpu_profile.sh; gfx950 corrections applied by scripts/pmc_summary.py).  C-ABI entry -> device kernels.
-PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')      # config 2; other configurations: pmc_traffic_latest_config<N>.json
 PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel', 'bn_lif_fwd_sp_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
                'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
                'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel'],
@@ -49,11 +49,11 @@ PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_l
                                   'conv1x1_wgrad_lds_kernel[planes]']}
 
 
-def pmc_traffic(entry, launches_per_call):
-    """Average HBM bytes one call of ``entry`` moves, from the committed PMC summary: launch-weighted mean over the device
-    kernels that implement it, times the launches one call makes."""
+def pmc_traffic(entry, launches_per_call, config=2):
+    """Average HBM bytes one call of ``entry`` moves, from the committed PMC summary of this configuration: launch-weighted mean over
+    the device kernels that implement it, times the launches one call makes."""
     try:
-        with open(PMC_FILE) as fh:
+        with open(PMC_FILE if config == 2 else PMC_FILE.replace('.json', f'_config{config}.json')) as fh:
             pmc = json.load(fh)
         ks = [pmc[k] for k in PMC_KERNELS[entry] if k in pmc]
         n = sum(k['launches'] for k in ks)
@@ -417,7 +417,7 @@ def main():
     # inference side figure: eval-mode forward + reset_net of the same batch (no loss, no backward), replayed as a HIP graph like the
     # evaluator does (yolox/evaluators/event_evaluator.py), for the model as trained and after yolox.utils.fuse_model (tools/eval_event.py --fuse)
     eval_fps = None
-    if rank == 0 and not multi:
+    if rank == 0 and not multi and os.environ.get('EAS_BENCH_NO_EVAL') != '1':      # (development: profiles of the training step alone)
         import copy
         from spikingjelly.activation_based import functional
         from yolox.utils import fuse_model
@@ -461,9 +461,9 @@ def main():
         d = summ[dom]
         sec = d['ms'] * 1e-3
         common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4),
-                  'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1) if w['config'] == 2 else None,
+                  'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1, w['config']),
                   'traffic_source': 'committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes over this command (profiles/pmc_traffic_latest.json, '
-                                    'scripts/gpu_profile.sh), not re-measured in this run; config 2 only',
+                                    'scripts/gpu_profile.sh; configs 2 and 3), not re-measured in this run',
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
                   'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'}
@@ -503,7 +503,7 @@ def main():
             hv = hbm_fams[hk]
             roofline['hbm_dominant'] = {'kernel': hk, 'achieved': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                                         'unit': 'GB/s', 'frac': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        'traffic': pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1) if w['config'] == 2 else None,
+                                        'traffic': pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1, w['config']),
                                         'algorithmic_bytes_per_call': round(hv['bytes'] / hv['calls'])}
         metric = ('event-frames/sec (T=3) SYOLOX-S Gen1 304x240' if w['config'] == 2 else f'event-frames/sec, BASELINE config {w["config"]}')
         line = {'metric': metric, 'value': round(frames_total / elapsed, 2),

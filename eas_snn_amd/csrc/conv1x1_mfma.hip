@@ -263,13 +263,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         for (int n = 0; n < WN; ++n) {
             if (yoff[n] < 0) continue;
             float* yp = y + yoff[n] + (long)co0 * g.HW;
-            if (full) {
+            if (g.act) {          // block-uniform: the activation's transcendental never runs for the plain convolution
 #pragma unroll
-                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
+                for (int e = 0; e < 16; ++e)
+                    if (full || co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_silu(acc[m][n][e] + bv[e]);
+            } else if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
             }
         }
     }
@@ -494,13 +498,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         for (int n = 0; n < WN; ++n) {
             if (yoff[n] < 0) continue;
             float* yp = y + yoff[n] + (long)co0 * g.HW;
-            if (full) {
+            if (g.act) {          // block-uniform: the activation's transcendental never runs for the plain convolution
 #pragma unroll
-                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
+                for (int e = 0; e < 16; ++e)
+                    if (full || co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_silu(acc[m][n][e] + bv[e]);
+            } else if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = eas_epi_act(acc[m][n][e] + bv[e], g.act);
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] = acc[m][n][e] + bv[e];
             }
         }
     }

@@ -17,7 +17,7 @@
 typedef __bf16 eas_bf16x4 __attribute__((ext_vector_type(4)));
 
 // activation of the plain convolution epilogue (eas_conv_fwd_act): SiLU as nn.SiLU computes it, x * sigmoid(x) (bn_act.hip uses the same form)
-__device__ __forceinline__ float eas_epi_act(float v, int act) { return act == 1 ? v * eas_sigmoidf(v) : v; }
+__device__ __forceinline__ float eas_epi_silu(float v) { return v * eas_sigmoidf(v); }
 
 typedef EasLifRange EasLifRangeDev;      // one neuron layer of the call (include/eas_hip.h)
 

@@ -414,13 +414,17 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         for (int j = 0; j < WN; ++j) {
             if (ybase[j] < 0) continue;
             float* yp = y + ybase[j] + (long)co0 * cstride;
-            if (full) {
+            if (g.act) {          // block-uniform: the activation's transcendental never runs for the plain convolution
 #pragma unroll
-                for (int e = 0; e < 16; ++e) yp[((e & 3) + 8 * (e >> 2)) * cstride] = eas_epi_act(acc[i][j][e] + bv[e], g.act);
+                for (int e = 0; e < 16; ++e)
+                    if (full || co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[((e & 3) + 8 * (e >> 2)) * cstride] = eas_epi_silu(acc[i][j][e] + bv[e]);
+            } else if (full) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yp[((e & 3) + 8 * (e >> 2)) * cstride] = acc[i][j][e] + bv[e];
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[((e & 3) + 8 * (e >> 2)) * cstride] = eas_epi_act(acc[i][j][e] + bv[e], g.act);
+                    if (co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[((e & 3) + 8 * (e >> 2)) * cstride] = acc[i][j][e] + bv[e];
             }
         }
     }

@@ -1774,7 +1774,7 @@ def conv_fwd_packed(x, packed, bias, Cout, ksize, stride, x_terms, x_sp=None, ac
 # pending is reduced first), any call outside a backward pass.  DistributedDataParallel with copy hooks reads gradients inside the
 # pass: leave the switch off there.  Same summation order either way: bit-identical gradients.
 DEFER_WGRAD_REDUCE = os.environ.get('EAS_DEFER_WGRAD_REDUCE', '0') == '1'
-_PENDING_REDUCE = []          # (slab workspace kept alive, grad_w address, numel, slab count, weight parameter)
+_PENDING_REDUCE = []          # (slab workspace kept alive, grad_w address, numel, slab count, [(parameter, address of its .grad, numel)])
 
 
 class deferred_wgrad_reductions:
@@ -1806,9 +1806,9 @@ def _flush_wgrad_reductions():
     jobs, _PENDING_REDUCE = _PENDING_REDUCE, []
     if not jobs:
         return
-    for ws, gptr, gn, n, w in jobs:
+    for w, wptr, wn in (o for job in jobs for o in job[4]):
         g = w.grad
-        if g is None or g.data_ptr() != gptr or g.numel() != gn or g._version != 0:
+        if g is None or g.data_ptr() != wptr or g.numel() != wn or g._version != 0:
             raise _lib.EasHipError(
                 'deferred_wgrad_reductions: a weight gradient handed to autograd is not (or no longer exclusively) the parameter\'s .grad '
                 '-- gradient hooks, create_graph, a second consumer of the weight or a non-contiguous weight; run this backward pass '
@@ -1827,18 +1827,27 @@ def _can_defer(w):
             and not getattr(w, '_post_accumulate_grad_hooks', None) and w.is_contiguous())
 
 
-def _wgrad_finish(ws, gw, nslabs, defer, w=None):
+def _wgrad_finish(ws, gw, nslabs, defer, w=None, split=None):
     """reduce the slabs in ``ws`` into ``gw``: now, or together with the other weight gradients at the end of the backward pass.
     Only the ADDRESS of ``gw`` is kept (plus the parameter it belongs to): autograd must stay the sole owner of the tensor so that
     AccumulateGrad adopts it as the parameter's ``.grad`` instead of cloning it (a clone would be taken before the reduction has
     run); ``_flush_wgrad_reductions`` checks that this is what happened before it writes."""
-    if defer and w is not None and any(j[4] is w for j in _PENDING_REDUCE):
+    # owners: the parameter(s) whose .grad this gradient becomes -- one, or the two whose row blocks [0, split) / [split, Cout) it holds (the
+    # one weight gradient of two convolutions computed as one: each parameter's .grad is then a view of ``gw``)
+    owners = []
+    if w is not None:
+        if split is None:
+            owners = [(w, gw.data_ptr(), gw.numel())]
+        else:
+            na = split * gw[0].numel()
+            owners = [(w[0], gw.data_ptr(), na), (w[1], gw.data_ptr() + 4 * na, gw.numel() - na)]
+    if defer and owners and any(o[0] is p[0] for j in _PENDING_REDUCE for p in j[4] for o in owners):
         _flush_wgrad_reductions()           # a second contribution to the same weight: autograd adds the two as soon as this returns
         defer = False
-    if defer and w is not None:
+    if defer and owners:
         if not _PENDING_REDUCE:
             torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_reductions)
-        _PENDING_REDUCE.append((ws, gw.data_ptr(), gw.numel(), int(nslabs), w))
+        _PENDING_REDUCE.append((ws, gw.data_ptr(), gw.numel(), int(nslabs), owners))
     else:
         arr = (_lib.EasWgradReduceJob * 1)(_lib.EasWgradReduceJob(ws.data_ptr(), gw.data_ptr(), gw.numel(), int(nslabs)))
         check(_lib.lib().eas_conv_wgrad_reduce_many(arr, 1, stream()), 'eas_conv_wgrad_reduce_many')
@@ -1861,7 +1870,7 @@ def _partial_call(name, nbytes, fn, *args, flops=0.0, issue_flops=0.0):
     return rc
 
 
-def conv_wgrad(x, gy, ksize, stride, x_terms, x_sp=None, defer=False, w=None):
+def conv_wgrad(x, gy, ksize, stride, x_terms, x_sp=None, defer=False, w=None, split=None):
     """grad_w [Cout,Cin,k,k] of conv2d(x, w, stride, padding k//2) given grad_y, on the matrix cores (deterministic).
     x_sp: x is a ghost, these are its spike planes (eas_conv_wgrad_planes_partial)."""
     _dev(gy)
@@ -1885,7 +1894,7 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_sp=None, defer=False, w=None):
         x = _f32c(x)
         ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
                            ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
-    _wgrad_finish(ws, gw, ns, defer, w)
+    _wgrad_finish(ws, gw, ns, defer, w, split)
     return gw
 
 
@@ -2119,7 +2128,11 @@ class _ConvDualFn(torch.autograd.Function):
             pk = ctx.packs[1] if ctx.packs else conv_pack_weights(torch.cat([wa, wb], 0), 1)
             gx = conv_fwd_packed(gy, pk, None, x.shape[1], k, 1, 3)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw = conv_wgrad(x, gy, k, 1, x_terms, x_sp)
+            # ONE weight gradient for the two parameters: its slab reduction waits for the end of the backward pass with all the others
+            # (each parameter adopts its row block of the one tensor as .grad) where that is sound for both, else it runs now
+            both = ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+            gw = conv_wgrad(x, gy, k, 1, x_terms, x_sp, defer=both and _can_defer(wa) and _can_defer(wb), w=(wa, wb) if both else None,
+                            split=Ca if both else None)
             ga, gb = gw[:Ca], gw[Ca:]
         return gx, ga, gb, None, None, None
 
