@@ -338,6 +338,14 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     g.Ho = (Hi + 2 * pad - ksize) / stride + 1;
     g.Wo = (Wi + 2 * pad - ksize) / stride + 1;
     g.RS = Wi + 2 * pad;
+    {
+        // Rows narrower than / not a multiple of the 32-pixel fragment: a fragment's lanes then cross a staged-row boundary, where the pixel
+        // index jumps by RS - Wo + 1.  With (RS - Wo) a multiple of 16 the lanes' 16-byte slots stay distinct modulo 16 across the jump, i.e.
+        // the ds_read_b128 stays conflict-free (scripts/lds_conflict_model.py: 32x40 maps 3.2 -> 2.0 LDS cycles per half wave, 16x20 maps
+        // 4.0 -> 2.0); costs 14 more staged (zero) columns per row.  EAS_CONV_RS_PAD=0: development switch, the tight rows.
+        static const int rs_pad = getenv("EAS_CONV_RS_PAD") ? atoi(getenv("EAS_CONV_RS_PAD")) : 1;
+        if (rs_pad && ksize == 3 && stride == 1 && g.Wo % 32 != 0) g.RS += (16 - ((g.RS - g.Wo) % 16)) % 16;
+    }
     g.pad_t = g.pad_l = pad;
     g.ext_h = ksize;
     for (int t = 0; t < ksize * ksize; ++t) g.tap_off[t] = (t / ksize) * g.RS + (t % ksize);
