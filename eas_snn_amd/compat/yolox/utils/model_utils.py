@@ -30,6 +30,10 @@ def fuse_model(model: nn.Module) -> nn.Module:
             m.conv = fuse_conv_and_bn(m.conv, m.bn)
             delattr(m, 'bn')
             m.forward = m.fuseforward
+    # the module tree changed: the cached list of convolutions whose weights one launch packs per forward (ops.prepack_conv_weights) is stale
+    for holder in model.modules():
+        for attr in ('_eas_pack_plan', '_eas_modules'):
+            holder.__dict__.pop(attr, None)
     return model
 
 

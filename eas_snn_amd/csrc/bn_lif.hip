@@ -321,12 +321,14 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
     int batch_stats, double* __restrict__ part, int nchunks, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
     float* __restrict__ grad_beta, float* __restrict__ grad_w, int N, int C, int HW, int bcast, int gs_ctot, int y_ctot,
-    const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha) {
+    const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha, int c_begin, int c_end, int finalize) {
     __shared__ double red[NW];
     __shared__ float bc[2];
     if (alpha_dev) alpha = fabsf(*alpha_dev);    // learnable slope (EAS_SG_PATAN)
-    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
-    if (c >= C) return;
+    // channels [c_begin, c_end) of the layer: a launch pair (sums, apply) may cover a channel group only, so that the apply pass finds the
+    // group's y / grad_s still in the Infinity Cache (launch_bwd_t)
+    const int c = c_begin + blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    if (c >= c_end) return;
     const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
             }
         }
     }
-    if (APPLY && grad_w && chunk == 0 && c == 0) {
+    if (APPLY && grad_w && finalize && chunk == 0 && c == c_begin) {
         // dL/dw of the (scalar) PLIF decay: fixed-order sum of every (channel, chunk) partial of pass 1, by one block
         double acc = 0.0;
         for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
         const double tot = eas_block_sum<double, NW>(acc, red);
         if (threadIdx.x == 0) *grad_w = (float)tot * (k * (1.0f - k));
     }
-    if (APPLY && grad_alpha && chunk == 0 && c == 0) {
+    if (APPLY && grad_alpha && finalize && chunk == 0 && c == c_begin) {
         // dL/dalpha of the learnable surrogate slope: same fixed-order sum over slot 3 of the partials
         double acc = 0.0;
         for (int i = threadIdx.x; i < C * nchunks; i += blockDim.x) {
@@ -516,15 +518,30 @@ int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, co
                  int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
     // two passes: the BatchNorm backward needs the channel's sums of dz and dz * xhat before any grad_y; pass 2 recomputes the neuron
-    // (cheaper than parking dz: measured)
-    EAS_LAUNCH((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
-                       grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr);
-    EAS_CHECK_LAUNCH();
-    EAS_LAUNCH((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_s,
-                       grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
-                       grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, grad_alpha);
-    EAS_CHECK_LAUNCH();
+    // (cheaper than parking dz: measured).
+    // Channel groups (EAS_BNLIF_BWD_GROUP_MB, development; 0 = one pair of launches for the whole layer): the pair runs group by group with
+    // at most that many MB of y + grad_s per group, so that the apply pass of a group re-reads what its sum pass has just read while it is
+    // still in the 256 MB Infinity Cache.
+    static const int group_mb = getenv("EAS_BNLIF_BWD_GROUP_MB") ? atoi(getenv("EAS_BNLIF_BWD_GROUP_MB")) : 0;
+    int gc = C;
+    if (group_mb > 0) {
+        const double per_channel = (double)N * HW * 4.0 * ((bcast ? 1 : T_) + T_);
+        gc = (int)(group_mb * 1048576.0 / per_channel) / 8 * 8;
+        if (gc < 8) gc = 8;
+        if (gc > C) gc = C;
+    }
+    for (int c0 = 0; c0 < C; c0 += gc) {
+        const int c1 = c0 + gc < C ? c0 + gc : C;
+        const int last = c1 == C;
+        EAS_LAUNCH((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, false>), EAS_CHAN_GRID(chunks, c1 - c0), dim3(EAS_BLOCK), 0, st, grad_s,
+                   grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
+                   grad_gamma, grad_beta, (float*)nullptr, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, (float*)nullptr, c0, c1, 0);
+        EAS_CHECK_LAUNCH();
+        EAS_LAUNCH((bn_lif_bwd_kernel<T_, HARD, DI, STRICT, true>), EAS_CHAN_GRID(chunks, c1 - c0), dim3(EAS_BLOCK), 0, st, grad_s,
+                   grad_mean, y, mean, invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, chunks, grad_y,
+                   grad_gamma, grad_beta, grad_w, N, C, HW, bcast, gs_ctot, y_ctot, alpha_dev, grad_alpha, c0, c1, last);
+        EAS_CHECK_LAUNCH();
+    }
     return EAS_OK;
 }
 

@@ -13,7 +13,13 @@
 //     through LDS as [term][input pixel incl. zero halo][ci chunk] bf16, so each lane's 8 consecutive ci are one 16-byte
 //     ds_read_b128 and the KS*KS taps are plain address offsets into the same image; the two 8-channel halves of a k-step
 //     live in separate planes ([term][8-channel group][pixel][16 B]) so that the 32 lanes of a half-wave read 512 contiguous
-//     bytes (pixel-major 32-byte rows cost a 2-way bank conflict on every fragment read).
+//     bytes (pixel-major 32-byte rows cost a 2-way bank conflict on every fragment read).  Conflict-free reads hold while a
+//     32-pixel fragment stays inside one staged row; a tile that wraps rows jumps by RS - Wo + 1 pixels (2-way and worse on
+//     the 40- / 20- / 10-pixel rows; padding the staged rows to (RS - Wo) % 16 == 0 removes it -- EAS_CONV_RS_PAD, measured
+//     without effect on config 2 and slower on config 3, off by default).  The stride-2 forward reads every second
+//     16-byte slot (2-way) and the staging stores of a thread's VEC consecutive pixels are VEC-way conflicted
+//     (scripts/lds_conflict_model.py reproduces the measured SQ_LDS_BANK_CONFLICT share); the LDS pipe is active for 3-10 %
+//     of these kernels' wave cycles, so neither is what they wait for.
 //   input gradient of a stride-1 conv is the same kernel on grad_y with the weights packed transposed + flipped.
 //
 //   input gradient of a stride-2 3x3 conv: per parity class of the input pixel a stride-1 tap-list convolution (eas_conv_dgrad_s2).
@@ -342,8 +348,10 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
         // Rows narrower than / not a multiple of the 32-pixel fragment: a fragment's lanes then cross a staged-row boundary, where the pixel
         // index jumps by RS - Wo + 1.  With (RS - Wo) a multiple of 16 the lanes' 16-byte slots stay distinct modulo 16 across the jump, i.e.
         // the ds_read_b128 stays conflict-free (scripts/lds_conflict_model.py: 32x40 maps 3.2 -> 2.0 LDS cycles per half wave, 16x20 maps
-        // 4.0 -> 2.0); costs 14 more staged (zero) columns per row.  EAS_CONV_RS_PAD=0: development switch, the tight rows.
-        static const int rs_pad = getenv("EAS_CONV_RS_PAD") ? atoi(getenv("EAS_CONV_RS_PAD")) : 1;
+        // 4.0 -> 2.0); costs 14 more staged (zero) columns per row.  Measured (same box): config 2 unchanged (21.23 / 21.24 ms without,
+        // 21.24 / 21.20 ms with), config 3 SLOWER (45.19 -> 46.7 ms: the wider patches of the 96 / 192-channel layers cost a resident block) --
+        // the LDS pipe is not what these kernels wait for.  Off by default; EAS_CONV_RS_PAD=1: the padded rows.
+        static const int rs_pad = getenv("EAS_CONV_RS_PAD") ? atoi(getenv("EAS_CONV_RS_PAD")) : 0;
         if (rs_pad && ksize == 3 && stride == 1 && g.Wo % 32 != 0) g.RS += (16 - ((g.RS - g.Wo) % 16)) % 16;
     }
     g.pad_t = g.pad_l = pad;
