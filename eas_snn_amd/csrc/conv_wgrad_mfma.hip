@@ -174,7 +174,8 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     // address code was 340 vector-ALU instructions per wave and tile against 45 MFMAs: the kernel was bound by the vector ALU).  Loads are
     // raw buffer loads: the descriptor's base is the tile base, the 8 channel rows of an fp32 item differ by a SCALAR offset, and an item
     // that is out of the image (halo rows, images past NI, channels past the tensor, padding) uses an offset past num_records, for which
-    // the hardware returns zeros without touching memory (the range check covers voffset + soffset: scripts/micro/buffer_oob.hip).
+    // the hardware returns zeros without touching memory (measured on gfx950: the range check covers voffset + soffset, scripts/micro/buffer_oob.hip;
+    // masked items do not rely on it -- their voffset alone is past num_records; launch_wgrad refuses tiles whose span would reach 2^31).
     // Spike-input instances only (BUF): with three-term x the pointer form below measured 5-13 % faster (those instances spend twice the
     // time in MFMAs per tile and lost more to the changed instruction order than they gained).
     constexpr bool BUF = XT == 1;
@@ -529,6 +530,14 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
     if (lds > 160 * 1024 || nitems > (PM * PN == 4 ? 1 : 2) * NT) {
         if (getenv("EAS_CONV_DBG")) fprintf(stderr, "wgrad launch: lds %zu nitems %d NT %d PM %d PN %d VEC %d RT %d Q %d\n", lds, nitems, NT, PM, PN, VEC, g.RT, g.Q);
         return EAS_ERR_UNSUPPORTED;
+    }
+    if constexpr (XT == 1) {
+        // the spike-input instances address a tile's items as 32-bit byte offsets from the tile base in raw buffer loads whose descriptors say
+        // num_records = 2^31 (offsets from there on mean "outside: zeros"): the images of a tile plus the 8 channel rows of an item must stay
+        // below that (far above every EAS-SNN shape: a 64-channel 128x160 image is 5 MB)
+        const size_t img_y = (size_t)g.Cout * g.Ho * g.pitchY * 4, img_x = (size_t)g.Cin * g.Hi * g.pitchX * (XPL ? 2 : 4);
+        const size_t span = (size_t)(g.nseg + 1) * (img_y > img_x ? img_y : img_x) + (size_t)8 * g.Hi * g.pitchX * 4;
+        if (span >= ((size_t)1 << 31)) return EAS_ERR_UNSUPPORTED;
     }
     static bool attr_set = false;
     if (!attr_set) {

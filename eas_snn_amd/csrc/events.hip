@@ -5,6 +5,8 @@
 // int32 `global_atomic_add` without return, so results are bit-exact and order independent.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "eas_common.h"
 
 namespace {
@@ -625,7 +627,7 @@ static int histogram_impl(const uint32_t* t, const uint16_t* x, const uint16_t* 
     const char* force = getenv("EAS_HIST_FORM");      // development switch: "scatter" / "banded"
     const bool dense = nev >= (int64_t)B * Tm * 2048;
     // 16-bit counters + vector loads when the event arrays allow 8- / 4-byte loads (EAS_HIST_FORM=banded32: the 32-bit form)
-    const bool al16 = ((((uintptr_t)x | (uintptr_t)y) & 7) | ((uintptr_t)p & 3)) == 0 && !(force && force[0] == 'b' && force[6] == '3');
+    const bool al16 = ((((uintptr_t)x | (uintptr_t)y) & 7) | ((uintptr_t)p & 3)) == 0 && !(force && strcmp(force, "banded32") == 0);
     int rows16 = kBandLdsBytes / (4 * W);
     if (rows16 > H) rows16 = H;
     const int nbands16 = rows16 > 0 ? (H + rows16 - 1) / rows16 : kMaxBands + 1;
