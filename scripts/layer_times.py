@@ -50,15 +50,18 @@ def main():
         ms = sum(a.elapsed_time(b) for a, b, *_ in items) / reps
         fl = sum(it[3] for it in items) / reps
         isf = sum(it[4] for it in items) / reps
-        rows.append((ms, tag, name, len(items) // reps, fl, isf))
-    rows.sort(reverse=True)
+        # per-launch roofline time: algorithmic bytes at 8 TB/s or bf16 term products at 2.5 PFLOP/s, whichever is longer
+        roof = sum(max(it[2] / 8e12, it[4] / 2.5e15) for it in items) / reps * 1e3
+        hbm_bound = sum(1 for it in items if it[2] / 8e12 >= it[4] / 2.5e15) * 2 > len(items)
+        rows.append((ms, tag, name, len(items) // reps, fl, isf, roof, hbm_bound))
     tot = sum(r[0] for r in rows if r[2] in ('eas_conv_fwd', 'eas_conv_wgrad'))
-    print(f'config {config} batch {batch}: tagged conv time {tot:.2f} ms/step')
-    for ms, tag, name, calls, fl, isf in rows[:70]:
+    print(f'config {config} batch {batch}: tagged conv time {tot:.2f} ms/step; all tagged calls {sum(r[0] for r in rows):.2f} ms/step')
+    by = os.environ.get('EAS_LT_SORT', 'excess')          # excess: time above 1.5 x the launch's roofline time (what a good kernel could return)
+    rows.sort(key=(lambda r: -(r[0] - 1.5 * r[6])) if by == 'excess' else (lambda r: -r[0]))
+    print('    time   roofline  excess  calls  entry point            TF     bound  layer')
+    for ms, tag, name, calls, fl, isf, roof, hbm_bound in rows[:int(os.environ.get('EAS_LT_ROWS', '70'))]:
         tf = fl / ms / 1e9 if ms > 0 and fl > 0 else 0.0
-        ceil = (2500.0 * fl / isf) if isf > 0 else 0.0
-        print(f'{ms:7.3f} ms  {calls:2d} calls  {name:16s} {tf:7.1f} TF  {(tf / ceil if ceil else 0):5.2f} of ceiling   {tag}')
-
+        print(f'{ms:7.3f} ms {roof:7.3f} {ms - 1.5 * roof:7.3f}  {calls:3d}  {name:24s} {tf:6.1f}  {"hbm " if hbm_bound else "mfma"}  {tag}')
 
 if __name__ == '__main__':
     main()
