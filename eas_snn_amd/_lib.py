@@ -48,8 +48,21 @@ class EasConvBnLifEval(C.Structure):
                 ('csplit', C.c_int), ('range', EasLifRange * 2)]
 
 
+class EasBnActRange(C.Structure):
+    """include/eas_hip.h EasBnActRange: one BatchNorm (a range of output channels) of the fused real-valued eval block"""
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p), ('out', C.c_void_p),
+                ('out_ctot', C.c_int), ('out_c0', C.c_int)]
+
+
+class EasConvBnActEval(C.Structure):
+    """include/eas_hip.h EasConvBnActEval"""
+    _fields_ = [('x', C.c_void_p), ('packed_w', C.c_void_p), ('x_terms', C.c_int), ('NI', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int),
+                ('Hi', C.c_int), ('Wi', C.c_int), ('ksize', C.c_int), ('stride', C.c_int), ('act', C.c_int), ('csplit', C.c_int),
+                ('range', EasBnActRange * 2)]
+
+
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
@@ -58,6 +71,7 @@ PROTOTYPES = {
     'eas_status_string': (C.c_char_p, [C.c_int]),
     'eas_conv_bn_lif_eval': (C.c_int, [C.POINTER(EasConvBnLifEval), _P]),
     'eas_conv_bn_lif_eval_supported': (C.c_int, [C.c_int] * 10),
+    'eas_conv_bn_act_eval': (C.c_int, [C.POINTER(EasConvBnActEval), _P, _P]),
     'eas_event_histogram': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_event_histogram_dat': (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_counts_to_canvas': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
@@ -116,9 +130,9 @@ PROTOTYPES = {
     'eas_smallconv_packed_floats': (C.c_int64, [C.c_int] * 3),
     'eas_smallconv_pack_weights': (C.c_int, [_P, C.c_int, _P]),
     'eas_smallconv_bwd_input_dual': (C.c_int, [_P] * 6 + [C.c_int] * 4 + [_P]),
-    'eas_smallconv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 7 + [_P]),
+    'eas_smallconv_fwd': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
     'eas_smallconv_bwd_input': (C.c_int, [_P] * 4 + [C.c_int] * 6 + [_P]),
-    'eas_smallconv_bwd_weight': (C.c_int, [_P] * 5 + [C.c_int] * 6 + [_P]),
+    'eas_smallconv_bwd_weight': (C.c_int, [_P] * 5 + [C.c_int] * 7 + [_P]),
     'eas_smallconv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 3),
     'eas_conv_packed_weight_bytes': (C.c_int64, [C.c_int] * 4),
     'eas_conv_pack_weights': (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),

@@ -97,12 +97,14 @@ class AdaptiveRSNNEmbedding(nn.Module):
             return events.unsqueeze(0).expand(self.Ts, *events.shape)
         if v_record:
             raise NotImplementedError('v_record is a debugging output of the reference and is not provided')
-        ev, _ = _time_major(events)
-        if ev.shape[0] != self.nb_steps:
-            raise ValueError(f'expected {self.nb_steps} micro-slices, got {ev.shape[0]}')
+        # the loader's [B(,Tl),Tm,2,H,W] goes to the operator as it is: the kernels of the fused step read it time-major, newest slice first
+        # (embedding.py:147-156), other configurations make that copy inside
+        ev = events.flatten(end_dim=-5) if events.dim() > 5 else events
+        if ev.shape[1] != self.nb_steps:
+            raise ValueError(f'expected {self.nb_steps} micro-slices, got {ev.shape[1]}')
         agg, rec = ops.arsnn_forward(ev, _stack_params(self.input_conv), _stack_params(self.gate_conv), self.kernel_size,
                                      self.Ts, self.readout, self.spike_attach, self.write_zero, self.abs,
-                                     float(self.thresh), None if self.vreset is None else float(self.vreset), record=record)
+                                     float(self.thresh), None if self.vreset is None else float(self.vreset), record=record, collated=True)
         return (agg, rec.long()) if record else agg
 
 

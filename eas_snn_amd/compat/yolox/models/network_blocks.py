@@ -88,6 +88,10 @@ class BaseConv(nn.Module):
             return self.bn.fused_with(self.act, y, want_mean=self.emit_rate, residual=residual, cat=cat,
                                       planes=self.wants_planes() and x.dim() == 5)
         assert residual is None
+        if (not self.training and type(self.conv) is nn.Conv2d and isinstance(self.act, nn.SiLU) and getattr(self, 'bn', None) is not None
+                and ops.fused_ann_eval_ok(x, self.conv, [self.bn])):
+            # eval mode: conv -> BN (running statistics) -> SiLU as ONE kernel, the convolution output never reaches HBM
+            return ops.conv_bn_act_eval(x, self.conv, [self.bn], cats=[cat])
         with ops.conv_stats_scope(self.bn.training or self.bn.running_mean is None):
             y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if self.ann_fusable(y):
@@ -278,9 +282,15 @@ class CSPLayer(nn.Module):
                 if sink is not None:
                     sink(cs[0], x, 1)
                     sink(cs[1], x, 1)
-                with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (self.conv1.bn, self.conv2.bn))):
-                    y12 = ops.conv2d_dual(x, cs[0], cs[1], self, 'c12')
-                a, b = ops.bn_silu_pair(y12, self.conv1.bn, self.conv2.bn, cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
+                if not self.training and ops.fused_ann_eval_ok(x, (cs[0], cs[1]), [self.conv1.bn, self.conv2.bn]):
+                    # eval mode: the one convolution for both branches AND their BN + SiLU in one kernel
+                    packs = (getattr(self, '_eas_dual_packs', None) or {}).get('c12')
+                    a, b = ops.conv_bn_act_eval(x, (cs[0], cs[1]), [self.conv1.bn, self.conv2.bn],
+                                                cats=[None if len(self.m) else (buf, 0), (buf, h)], packs=ops.current_packs(packs))
+                else:
+                    with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (self.conv1.bn, self.conv2.bn))):
+                        y12 = ops.conv2d_dual(x, cs[0], cs[1], self, 'c12')
+                    a, b = ops.bn_silu_pair(y12, self.conv1.bn, self.conv2.bn, cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
             else:
                 b = self.conv2(x, cat=(buf, h))
                 a = self.conv1(x, cat=None if len(self.m) else (buf, 0))

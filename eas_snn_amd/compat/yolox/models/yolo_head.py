@@ -116,9 +116,14 @@ class YOLOXHead(nn.Module):
             if sink is not None:
                 sink(a.conv, x, 1)
                 sink(b.conv, x, 1)
-            with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (a.bn, b.bn))):
-                y12 = ops.conv2d_dual(x, a.conv, b.conv, self, f'tower{k}')
-            ca, ra = ops.bn_silu_pair(y12, a.bn, b.bn)
+            if not self.training and ops.fused_ann_eval_ok(x, (a.conv, b.conv), [a.bn, b.bn]):
+                # eval mode: the one convolution for both towers AND their BN + SiLU in one kernel
+                packs = (getattr(self, '_eas_dual_packs', None) or {}).get(f'tower{k}')
+                ca, ra = ops.conv_bn_act_eval(x, (a.conv, b.conv), [a.bn, b.bn], packs=ops.current_packs(packs))
+            else:
+                with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (a.bn, b.bn))):
+                    y12 = ops.conv2d_dual(x, a.conv, b.conv, self, f'tower{k}')
+                ca, ra = ops.bn_silu_pair(y12, a.bn, b.bn)
             for m in list(self.cls_convs[k])[1:]:
                 ca = m(ca)
             for m in list(self.reg_convs[k])[1:]:

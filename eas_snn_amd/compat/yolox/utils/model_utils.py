@@ -32,7 +32,7 @@ def fuse_model(model: nn.Module) -> nn.Module:
             m.forward = m.fuseforward
     # the module tree changed: the cached list of convolutions whose weights one launch packs per forward (ops.prepack_conv_weights) is stale
     for holder in model.modules():
-        for attr in ('_eas_pack_plan', '_eas_modules'):
+        for attr in ('_eas_pack_plan', '_eas_pack_plan_fwd', '_eas_modules'):
             holder.__dict__.pop(attr, None)
     return model
 

@@ -32,6 +32,7 @@ struct C1Geom {
     // counts SPATIAL 32-pixel tiles, pixel tile n of a wave = time step n (WN == lif.T): image n * N + sample
     EasLifEpiDev lif;
     int act;                          // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act)
+    EasBnActEpiDev bna;               // BatchNorm (running statistics) + activation in the plain epilogue (eas_conv_bn_act_eval); on = 0: plain store
 };
 
 // statistics epilogue of the 1x1 kernels: 4 waves of a block = 4 pixel groups of the same WM * 32 channels
@@ -74,7 +75,7 @@ template <int XT, int WM, int WN, bool RAGK = false, bool PL = false, int LM = 0
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                               const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     static_assert(!PL || (XT == 1 && !RAGK), "spike planes are one exact bf16 term in whole 8-channel groups");
-    static_assert(LM == 0 || LM == 1, "1x1: time-major fused neuron epilogue only");
+    static_assert(LM == 0 || LM == 1 || LM == 3, "1x1: plain, time-major fused neuron epilogue, or BatchNorm + activation epilogue");
     constexpr bool TM = LM == 1;
     typedef float TIN;
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(x);
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     // per-lane pixel of each N-tile
     long xoff[WN];    // element offset of (img, channel 8h, pixel) ; -1: no pixel
     long yoff[WN];
-    int l_img[LM ? WN : 1], l_pix[LM ? WN : 1];
-    bool l_ok[LM ? WN : 1];
+    int l_img[LM == 1 ? WN : 1], l_pix[LM == 1 ? WN : 1];
+    bool l_ok[LM == 1 ? WN : 1];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int t = TM ? tile0 : tile0 + n;             // time-major: tile n = time step n of the same spatial tile
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         const bool ok = t < g.total_tiles && p < g.HW;
         xoff[n] = ok ? (PL ? ((long)img * (g.Cin / 8) + h) * g.HW + p : ((long)img * g.Cin + 8 * h) * g.HW + p) : -1;
         yoff[n] = ok ? (long)img * g.Cout * g.HW + p : -1;
-        if constexpr (LM != 0) {
+        if constexpr (LM == 1) {
             l_img[n] = smp;
             l_pix[n] = p;
             l_ok[n] = ok;
@@ -235,13 +236,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         c1_stats<WM, WN>(acc, yoff, red, g, mt0);
     }
 
-    if constexpr (LM != 0) {
+    if constexpr (LM == 1) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
             if (mt0 + m < g.MT) eas_lif_epilogue<WN, LM>(acc[m], g.lif, mt0 + m, h, l_img, l_pix, l_ok);
         return;
     }
 
+    if constexpr (LM == 3) {      // BatchNorm (running statistics) + activation on the accumulators (eas_conv_bn_act_eval)
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+            if (mt0 + m < g.MT) eas_bnact_epilogue<WN>(acc[m], g.bna, mt0 + m, h, yoff, (long)g.HW);
+        return;
+    }
     // lean epilogue: one pointer per (M-tile, pixel tile), rows by multiples of the channel stride, bias once per M-tile,
     // per-element channel check only for a ragged last M-tile
 #pragma unroll
@@ -288,7 +295,7 @@ template <int XT, int WM, int WN, bool PL = false, int LM = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
     static_assert(!PL || XT == 1, "spike planes are one exact bf16 term");
-    static_assert(LM == 0 || LM == 1, "1x1: time-major fused neuron epilogue only");
+    static_assert(LM == 0 || LM == 1 || LM == 3, "1x1: plain, time-major fused neuron epilogue, or BatchNorm + activation epilogue");
     constexpr bool TM = LM == 1;
     typedef float TIN;
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(x);
@@ -301,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
     const int tile0 = (blockIdx.x * 4 + wave) * (TM ? 1 : WN);
 
     long xoff[WN], yoff[WN];
-    int l_img[LM ? WN : 1], l_pix[LM ? WN : 1];
-    bool l_ok[LM ? WN : 1];
+    int l_img[LM == 1 ? WN : 1], l_pix[LM == 1 ? WN : 1];
+    bool l_ok[LM == 1 ? WN : 1];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int t = TM ? tile0 : tile0 + n;             // time-major: tile n = time step n of the same spatial tile
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         const bool ok = t < g.total_tiles && p < g.HW;
         xoff[n] = ok ? (PL ? ((long)img * (g.Cin / 8) + h) * g.HW + p : ((long)img * g.Cin + 8 * h) * g.HW + p) : -1;
         yoff[n] = ok ? (long)img * g.Cout * g.HW + p : -1;
-        if constexpr (LM != 0) {
+        if constexpr (LM == 1) {
             l_img[n] = smp;
             l_pix[n] = p;
             l_ok[n] = ok;
@@ -472,13 +479,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         c1_stats<WM, WN>(acc, yoff, red, g, mt0);
     }
 
-    if constexpr (LM != 0) {
+    if constexpr (LM == 1) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
             if (mt0 + m < g.MT) eas_lif_epilogue<WN, LM>(acc[m], g.lif, mt0 + m, h, l_img, l_pix, l_ok);
         return;
     }
 
+    if constexpr (LM == 3) {      // BatchNorm (running statistics) + activation on the accumulators (eas_conv_bn_act_eval)
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+            if (mt0 + m < g.MT) eas_bnact_epilogue<WN>(acc[m], g.bna, mt0 + m, h, yoff, (long)g.HW);
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         if (mt0 + m >= g.MT) continue;
@@ -514,23 +527,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
     }
 }
 
-template <int XT, int WM, int WN, bool PL = false>
+template <int XT, int WM, int WN, bool PL = false, int LM = 0>
 int launch_c1_shared(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
     tl_c1_blocks = (int)grid.x;
     if (!y) return EAS_OK;            // geometry query
     if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
-    EAS_LAUNCH((conv1x1_mfma_sharedA_kernel<XT, WM, WN, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    EAS_LAUNCH((conv1x1_mfma_sharedA_kernel<XT, WM, WN, PL, LM>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
-template <int XT, int WM, int WN, bool RAGK = false, bool PL = false>
+template <int XT, int WM, int WN, bool RAGK = false, bool PL = false, int LM = 0>
 int launch_c1(const float* x, const bf16x8* wp, const float* bias, float* y, C1Geom g, hipStream_t st) {
     dim3 grid((g.total_tiles + 4 * WN - 1) / (4 * WN), (g.MT + WM - 1) / WM);
     tl_c1_blocks = (int)grid.x;
     if (!y) return EAS_OK;            // geometry query
     if (g.stats && (int)grid.x != g.stats_nb) return EAS_ERR_INVALID_ARG;
-    EAS_LAUNCH((conv1x1_mfma_kernel<XT, WM, WN, RAGK, PL>), grid, dim3(256), 0, st, x, wp, bias, y, g);
+    EAS_LAUNCH((conv1x1_mfma_kernel<XT, WM, WN, RAGK, PL, LM>), grid, dim3(256), 0, st, x, wp, bias, y, g);
     return EAS_OK;
 }
 
@@ -549,11 +562,13 @@ int launch_c1_lif(const float* x, const bf16x8* wp, C1Geom g, hipStream_t st, bo
 // wave-tile choice and launch for a 1x1 convolution; PL: x is a spike-plane tensor (x_terms 1)
 template <bool PL>
 static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                              hipStream_t st, double* stats = nullptr, int stats_nb = 0, int* inexact = nullptr, int act = 0) {
+                              hipStream_t st, double* stats = nullptr, int stats_nb = 0, int* inexact = nullptr, int act = 0,
+                              const EasBnActEpiDev* bna = nullptr) {
     C1Geom g{};
     g.stats = stats; g.stats_nb = stats_nb;
     g.inexact = inexact;
     g.act = act;
+    if (bna) g.bna = *bna;
     g.NI = NI; g.Cin = Cin; g.Cout = Cout; g.HW = HW;
     g.tiles_per_img = (HW + 31) / 32;
     g.total_tiles = NI * g.tiles_per_img;
@@ -569,6 +584,7 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
     static const long want = getenv("EAS_C1_BLOCKS") ? atol(getenv("EAS_C1_BLOCKS")) : 512;
     if (blocks(wm, wn) < want) wn = 1;
     while (blocks(wm, wn) < want && wm > 1) wm >>= 1;
+    if (bna && (PL || x_terms != 3 || Cin % 8 != 0)) return EAS_ERR_UNSUPPORTED;     // the BatchNorm + activation epilogue: real-valued fp32 inputs
     if constexpr (PL) {
         if (Cin % 8 != 0 || x_terms != 1) return EAS_ERR_UNSUPPORTED;
     } else if (Cin % 8 != 0) {     // ragged input channels: the direct kernel with per-channel validity (few channels: one pixel tile per wave)
@@ -598,6 +614,14 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
         if (sn == 2) return launch_c1_shared<XT_, 2, 2, PL>(x, wp, bias, y, g, st);                 \
         return launch_c1_shared<XT_, 2, 1, PL>(x, wp, bias, y, g, st);                              \
     } while (0)
+        if constexpr (!PL) {
+            if (bna) {
+                if (sm == 4 && sn == 2) return launch_c1_shared<3, 4, 2, false, 3>(x, wp, bias, y, g, st);
+                if (sm == 4) return launch_c1_shared<3, 4, 1, false, 3>(x, wp, bias, y, g, st);
+                if (sn == 2) return launch_c1_shared<3, 2, 2, false, 3>(x, wp, bias, y, g, st);
+                return launch_c1_shared<3, 2, 1, false, 3>(x, wp, bias, y, g, st);
+            }
+        }
         if (x_terms == 1) EAS_C1S(1);
         if constexpr (!PL) EAS_C1S(3);
 #undef EAS_C1S
@@ -611,6 +635,16 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
         if (wm == 2) return launch_c1<XT_, 2, 1, false, PL>(x, wp, bias, y, g, st);                 \
         return launch_c1<XT_, 1, 1, false, PL>(x, wp, bias, y, g, st);                              \
     } while (0)
+    if constexpr (!PL) {
+        if (bna) {
+            if (wm == 4 && wn == 2) return launch_c1<3, 4, 2, false, false, 3>(x, wp, bias, y, g, st);
+            if (wm == 2 && wn == 2) return launch_c1<3, 2, 2, false, false, 3>(x, wp, bias, y, g, st);
+            if (wm == 1 && wn == 2) return launch_c1<3, 1, 2, false, false, 3>(x, wp, bias, y, g, st);
+            if (wm == 4) return launch_c1<3, 4, 1, false, false, 3>(x, wp, bias, y, g, st);
+            if (wm == 2) return launch_c1<3, 2, 1, false, false, 3>(x, wp, bias, y, g, st);
+            return launch_c1<3, 1, 1, false, false, 3>(x, wp, bias, y, g, st);
+        }
+    }
     if (x_terms == 1) EAS_C1(1);
     if constexpr (!PL) EAS_C1(3);
 #undef EAS_C1
@@ -619,10 +653,11 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
 
 // called by eas_conv_fwd (conv_mfma.hip) for ksize == 1, stride == 1; planes != 0: x is a spike-plane tensor
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact, int act) {
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact, int act, const void* bna) {
     tl_c1_blocks = 0;
-    const int rc = planes ? conv1x1_dispatch_t<true>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st, stats, stats_nb, nullptr, act)
-                          : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb, inexact, act);
+    const EasBnActEpiDev* b = (const EasBnActEpiDev*)bna;
+    const int rc = planes ? conv1x1_dispatch_t<true>(x, packed_w, bias, y, NI, Cin, Cout, HW, 1, st, stats, stats_nb, nullptr, act, b)
+                          : conv1x1_dispatch_t<false>(x, packed_w, bias, y, NI, Cin, Cout, HW, x_terms, st, stats, stats_nb, inexact, act, b);
     if (nb_out) *nb_out = tl_c1_blocks;
     return rc;
 }

@@ -135,3 +135,54 @@ __device__ __forceinline__ void eas_lif_epilogue(const ACC (&acc)[WN], const Eas
         }
     }
 }
+
+// ---- BatchNorm (running statistics) + activation in the epilogue of the PLAIN convolution kernels (eas_conv_bn_act_eval): the eval-mode
+// form of a real-valued BaseConv, "act(bn(conv(x)))" network_blocks.py:52-53 -- the arithmetic of bn_silu_fwd_kernel (bn_act.hip) on the
+// accumulators: scale = gamma * invstd, shift = beta - mean * scale, out = act(fma(y, scale, shift)).
+struct EasBnActEpiDev {
+    int on, act, csplit, Cout;
+    EasBnActRange r[2];
+};
+
+// acc[j]: tile j of the wave (row e = channel mt*32 + (e&3) + 8*(e>>2) + 4*h, column = the lane's pixel); yb[j] = img * Cout * HW + pixel of
+// the lane's column (the offset the plain epilogue stores at), < 0: no pixel.
+template <int WN, typename ACC>
+__device__ __forceinline__ void eas_bnact_epilogue(const ACC (&acc)[WN], const EasBnActEpiDev& B, int mt, int h, const long (&yb)[WN], long HW) {
+    float scale[16], shift[16];
+    float* ob[4];
+    long oct[4];
+    bool qok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = mt * 32 + 8 * q + 4 * h;           // first of the lane's 4 consecutive channels of this quad (a quad lies in one range)
+        qok[q] = c < B.Cout;
+        const int cc = qok[q] ? c : 0;
+        const int ri = cc >= B.csplit ? 1 : 0;
+        const EasBnActRange& R = B.r[ri];
+        const int cr = cc - (ri ? B.csplit : 0);
+        const float4 ga = *reinterpret_cast<const float4*>(R.gamma + cr), be = *reinterpret_cast<const float4*>(R.beta + cr);
+        const float4 mu = *reinterpret_cast<const float4*>(R.mean + cr), is = *reinterpret_cast<const float4*>(R.invstd + cr);
+        scale[4 * q + 0] = ga.x * is.x; scale[4 * q + 1] = ga.y * is.y; scale[4 * q + 2] = ga.z * is.z; scale[4 * q + 3] = ga.w * is.w;
+        shift[4 * q + 0] = be.x - mu.x * scale[4 * q + 0]; shift[4 * q + 1] = be.y - mu.y * scale[4 * q + 1];
+        shift[4 * q + 2] = be.z - mu.z * scale[4 * q + 2]; shift[4 * q + 3] = be.w - mu.w * scale[4 * q + 3];
+        ob[q] = R.out + (long)(R.out_c0 + cr) * HW;
+        oct[q] = (long)R.out_ctot * HW;
+    }
+    const long img_stride = (long)B.Cout * HW;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        if (yb[j] < 0) continue;
+        const long img = yb[j] / img_stride, pix = yb[j] - img * img_stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!qok[q]) continue;
+            float* po = ob[q] + img * oct[q] + pix;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = fmaf(acc[j][4 * q + e], scale[4 * q + e], shift[4 * q + e]);
+                po[(long)e * HW] = B.act ? eas_epi_silu(z) : z;
+            }
+        }
+    }
+}
+

@@ -93,6 +93,16 @@ int dispatch_tile_lif(const float* x, const bf16x8* wp, ConvGeom g, hipStream_t 
 
 int eas_conv1x1_lif_dispatch(const void* x, const void* packed_w, const EasLifEpiDev& lif, int Cin, int x_terms, int x_shared, hipStream_t st, bool query);
 
+// 3x3 convolution whose epilogue is BatchNorm (running statistics) + activation (eas_conv_bn_act_eval, conv_mfma.hip conv_fwd_impl): the
+// plain forward's tile choice (dispatch_tile) over kernels instantiated with LM = 3, fp32 three-term input.  geom: the ConvGeom conv_fwd_impl
+// prepared (g.bna filled in).
+int eas_conv3x3_bna_dispatch(int stride, int v4, const float* x, const void* wp, float* y, const void* geom, hipStream_t st) {
+    const ConvGeom& g = *(const ConvGeom*)geom;
+    const bf16x8* w = (const bf16x8*)wp;
+    if (stride == 1) return v4 ? dispatch_tile<9, 1, 3, 16, 4, false, 3>(x, w, nullptr, y, nullptr, g, st) : dispatch_tile<9, 1, 3, 16, 2, false, 3>(x, w, nullptr, y, nullptr, g, st);
+    return v4 ? dispatch_tile<9, 2, 3, 16, 4, false, 3>(x, w, nullptr, y, nullptr, g, st) : dispatch_tile<9, 2, 3, 16, 2, false, 3>(x, w, nullptr, y, nullptr, g, st);
+}
+
 extern "C" {
 
 // Fused eval-mode step conv -> BatchNorm (running statistics) -> LIF over T (include/eas_hip.h).  3x3: this file; 1x1: conv1x1_mfma.hip.

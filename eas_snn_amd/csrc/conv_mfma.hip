@@ -190,106 +190,12 @@ int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
     return EAS_OK;
 }
 
-// pixel blocks per channel (grid.x * parts) of the tile the last dispatch_tile call of this thread chose: the number of statistics
-// partials eas_conv_fwd_stats writes per channel
-thread_local int tl_pixel_blocks = 0;
-
-template <int TAPS, int S, int XT, int CCH, int VEC, bool PL = false>
-int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
-    // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
-    // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
-    struct Cand { int wm, wvm, bn, threads, nit, wn; launch_fn fn; };
-    constexpr int N8 = XT == 1 ? 2 : 1, N4 = 2;   // staging items per thread (register budget: 2 waves per SIMD either way)
-    // wave tile = 32 channels x WN 32-pixel tiles.  WN = 5 (160 pixels) is the efficient shape; WN = 3 (96 pixels: two 40-pixel rows,
-    // four 20-pixel rows or one 8x10 image) exists for the small maps of the neck / head and of dark4 / dark5, where 160-pixel wave
-    // tiles leave most of the 256 CUs without a block (64 images of 8x10 with 128 channels are 16 eight-wave blocks)
-    const Cand cands[14] = {
-        {1, 2, 640, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8, PL>}, {1, 4, 320, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8, PL>},
-        {1, 8, 160, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8, PL>}, {1, 1, 1280, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8, PL>},
-        {1, 1, 640, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4, PL>}, {1, 2, 320, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4, PL>},
-        {1, 4, 160, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4, PL>},
-        {1, 2, 384, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 4, CCH, VEC, N8, PL>}, {1, 4, 192, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 2, CCH, VEC, N8, PL>},
-        {1, 8, 96, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 8, 1, CCH, VEC, N8, PL>}, {1, 1, 768, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 8, CCH, VEC, N8, PL>},
-        {1, 1, 384, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 4, CCH, VEC, N4, PL>}, {1, 2, 192, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 2, CCH, VEC, N4, PL>},
-        {1, 4, 96, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 1, CCH, VEC, N4, PL>}};
-    // cost model (measured on MI355X, scripts/dev_conv.py, scripts/dev_conv_calls.py): one block per CU; a round of 8-wave blocks costs
-    // ~1.27x a round of 4-wave blocks; a block's time is a fixed part (prologue, first patch, epilogue) plus its MFMA work, which
-    // goes with WN whatever part of the pixel tile is valid
-    int best = -1;
-    double best_cost = 0.0;
-    int best_valid = 0;
-    ConvGeom best_g = g;
-    static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
-    static const int ncand = getenv("EAS_CONV_NCAND") ? atoi(getenv("EAS_CONV_NCAND")) : 14;  // development: 7 = the 160-pixel wave tiles only
-    const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
-    // Single-buffered patch (mode 1): for layers of few channel chunks whose double-buffered patch fills the LDS (real-valued inputs on wide
-    // rows: dark2.0, 135 -> 103 us) -- the second buffer buys one overlapped stage there, a second resident block overlaps everything.
-    // With more chunks the exposed write of every chunk costs more than it gains (4 chunks: 100 -> 122 us, 8: 125 -> 154 us); three
-    // chunks (the 48-channel layers of SYOLOX-M) still gain: config 4 88.0 -> 87.5 ms.
-    static const int single_nch = getenv("EAS_CONV_SINGLE_NCH") ? atoi(getenv("EAS_CONV_SINGLE_NCH")) : 3;      // development: 0 = never
-    static const double single_pen = getenv("EAS_CONV_SINGLE_PEN") ? atof(getenv("EAS_CONV_SINGLE_PEN")) : 1.1;
-    for (int i = 0; i < ncand; ++i)
-      for (int mode = 0; mode < 2; ++mode) {
-        const Cand& c = cands[i];
-        if (force >= 0 && i != force) continue;
-        if (mode == 1 && (XT != 3 || nchunks < 2 || nchunks > single_nch)) continue;      // spike-input layers: 76 -> 84 us (the patch is a third)
-        const int nbuf = (nchunks == 1 || mode == 1) ? 1 : 2;
-        if ((c.wvm * c.wm - 1) * 32 >= g.Cout && !(c.wvm == 1 && c.wm == 1)) continue;   // every wave row (and M-tile) has channels to compute
-        ConvGeom t = g;
-        t.single = mode;
-        bool fits = false;
-        for (int cap = c.bn; cap >= g.Wo && !fits; cap -= 32) {   // shrink the pixel tile until patch + staging slots fit
-            t.RT = pick_rows(g.Ho, g.Wo, cap);
-            if (t.RT == 0) break;
-            t.rows_seg = t.RT < g.Ho ? t.RT : g.Ho;
-            t.nseg = t.RT / t.rows_seg;
-            t.rows_in = (t.rows_seg - 1) * S + g.ext_h;
-            t.Q = t.nseg * t.rows_in * t.RS;
-            fits = (size_t)nbuf * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wst / VEC) * (CCH / 8) <= c.nit * c.threads;
-            cap = t.RT * g.Wo;
-        }
-        if (!fits) continue;
-        const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm)) * g.parts;
-        // resident blocks per CU: one 8-wave block, or two 4-wave blocks when their LDS fits twice (independent barriers
-        // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
-        const size_t lds_bytes = (size_t)nbuf * t.Q * CCH * 2 * XT;
-        int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
-        if (mode == 1) {
-            // worth it only where it buys the second resident block (launch bounds keep the registers of two blocks per CU available)
-            if (2 * lds_bytes > 160 * 1024 || 2 * (2 * lds_bytes) <= 160 * 1024) continue;
-            bpc = 2;
-        }
-        // (two co-resident 4-wave blocks cost 1.2 rounds of one -- but only when there are more blocks than CUs: a grid of <= 256 blocks
-        // puts one block on a CU whatever its LDS size)
-        // a step's MFMAs (3 * WN with one-term inputs, 6 * WN with three) hide the ~450-cycle latency of the next step's weight
-        // fragments only when they last that long: with spike inputs a 3-tile wave (288 MFMA cycles per step) waits on every step and
-        // costs nearly as much as a 5-tile wave (dark5.m.conv2: 71 us against 62 us for the 160-pixel shape the old model ranked behind)
-        static const double lat = getenv("EAS_CONV_STEP_LAT") ? atof(getenv("EAS_CONV_STEP_LAT")) : 450.0;   // development
-        const double per_tile = XT == 1 ? 96.0 : 192.0;
-        const double mfma_part = (c.wn * per_tile > lat ? c.wn * per_tile : lat) / (5.0 * per_tile);
-        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part) *
-                                  (mode == 1 ? single_pen * (c.threads == 512 && blocks > 256 ? 1.2 : 1.0) : 1.0);
-        const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
-        // ties: the larger valid pixel count; among grids of lone blocks (<= 256) first the shape with more waves along the channels
-        // (they share one staged pixel patch: the smaller patch per block is the shorter prologue; 8x10 head layers: 35-38 us against
-        // 44-50 us for the four-pixel-group shape)
-        const int valid = t.RT * g.Wo;
-        static const int tie_wvm = getenv("EAS_CONV_TIE_WVM") ? atoi(getenv("EAS_CONV_TIE_WVM")) : 1;        // development: 0 = lone blocks only
-        const int rank = ((blocks <= 256 || tie_wvm) ? c.wvm * 4096 : 0) + (valid < 4096 ? valid : 4095);
-        if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rank > best_valid)) {
-            best = i; best_cost = cost; best_valid = rank; best_g = t;
-        }
-    }
-    if (best < 0) return EAS_ERR_UNSUPPORTED;
-    tl_pixel_blocks = ((best_g.total_rows + best_g.RT - 1) / best_g.RT) * best_g.parts;
-    if (!y) return EAS_OK;                       // geometry query (eas_conv_fwd_supported): a tile exists, nothing is launched
-    return cands[best].fn(x, wp, bias, y, inexact, best_g, st);
-}
-
 }  // namespace
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
-                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact, int act);
+                         hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact, int act, const void* bna);
+// conv_lif_mfma.hip: the 3x3 tiles with the BatchNorm + activation epilogue (kernel template LM = 3), fp32 three-term input
+int eas_conv3x3_bna_dispatch(int stride, int v4, const float* x, const void* wp, float* y, const void* geom, hipStream_t st);
 
 extern "C" {
 
@@ -326,8 +232,10 @@ int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream)
 // exact in bf16; `inexact_flag`, if given, is set to 1 should any element not be); x_terms = 3: general fp32 input.
 static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                          int stride, int x_terms, int* inexact_flag, eas_stream_t stream, bool query, double* stats = nullptr, int stats_nb = 0,
-                         int* nb_out = nullptr, int act = 0) {
+                         int* nb_out = nullptr, int act = 0, const EasBnActEpiDev* bna = nullptr) {
     if (!query && (!x || !packed_w || !y)) return EAS_ERR_INVALID_ARG;
+    if (bna && (act || stats || bias)) return EAS_ERR_INVALID_ARG;
+    if (bna && x_terms != 3) return EAS_ERR_UNSUPPORTED;      // the epilogue exists for real-valued fp32 inputs (the ANN neck / head)
     if (stats && (bias || stats_nb < 1)) return EAS_ERR_INVALID_ARG;
     if (NI <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return EAS_ERR_INVALID_ARG;
     // x_terms: 1 = fp32 tensor holding small integers (one bf16 term), 3 = general fp32, 2 = SPIKE PLANES (bf16 [NI][Cin/8][Hi*Wi][8], one term)
@@ -366,6 +274,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     g.dbg = dbg;
     g.stats = stats; g.stats_nb = stats_nb;
     g.act = act;
+    if (bna) g.bna = *bna;
     const bf16x8* wp = (const bf16x8*)packed_w;
     hipStream_t st = eas_s(stream);
     int rc = EAS_ERR_UNSUPPORTED;
@@ -396,13 +305,14 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
             g.qshift = hv - pad;
             for (int t = 0; t < ksize * ksize; ++t) g.tap_off[t] = (t / ksize) * g.RS + (t % ksize);
         }
-        if (stride == 1) { EAS_CONV_DISPATCH(9, 1, 16); }
+        if (bna) rc = eas_conv3x3_bna_dispatch(stride, v4 ? 1 : 0, x, wp, query ? nullptr : y, &g, st);
+        else if (stride == 1) { EAS_CONV_DISPATCH(9, 1, 16); }
         else { EAS_CONV_DISPATCH(9, 2, 16); }
         if (force_parts > 0) break;
     }
     if (ksize == 1 && stride == 1) {
         int nb1 = 0;
-        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1, planes ? 1 : 0, inexact_flag, act);
+        rc = eas_conv1x1_dispatch(x, packed_w, bias, query ? nullptr : y, NI, Cin, Cout, Hi * Wi, x_terms, st, stats, stats_nb, &nb1, planes ? 1 : 0, inexact_flag, act, bna);
         tl_pixel_blocks = nb1;
     }
 #undef EAS_CONV_DISPATCH
@@ -424,6 +334,26 @@ int eas_conv_fwd_act(const float* x, const void* packed_w, const float* bias, fl
                      int stride, int x_terms, int act, int* inexact_flag, eas_stream_t stream) {
     if (act < 0 || act > 1) return EAS_ERR_INVALID_ARG;
     return conv_fwd_impl(x, packed_w, bias, y, NI, Cin, Cout, Hi, Wi, ksize, stride, x_terms, inexact_flag, stream, false, nullptr, 0, nullptr, act);
+}
+
+// conv -> BatchNorm (running statistics) -> activation in one kernel (include/eas_hip.h): eas_conv_fwd's tiles, the epilogue normalises and
+// activates the accumulators (conv_lif_epi.h eas_bnact_epilogue) and writes them where the caller's concatenation wants them.
+int eas_conv_bn_act_eval(const EasConvBnActEval* d, int* inexact_flag, eas_stream_t stream) {
+    if (!d || !d->x || !d->packed_w || d->act < 0 || d->act > 1) return EAS_ERR_INVALID_ARG;
+    if (d->Cout % 8 || d->csplit % 8 || d->csplit < 8 || d->csplit > d->Cout) return EAS_ERR_UNSUPPORTED;
+    EasBnActEpiDev b{};
+    b.on = 1; b.act = d->act; b.csplit = d->csplit; b.Cout = d->Cout;
+    const int nr = d->csplit < d->Cout ? 2 : 1;
+    for (int i = 0; i < nr; ++i) {
+        const EasBnActRange& r = d->range[i];
+        const int cr = i ? d->Cout - d->csplit : d->csplit;
+        if (!r.gamma || !r.beta || !r.mean || !r.invstd || !r.out || r.out_c0 < 0 || r.out_c0 + cr > r.out_ctot) return EAS_ERR_INVALID_ARG;
+        if ((((uintptr_t)r.gamma) | ((uintptr_t)r.beta) | ((uintptr_t)r.mean) | ((uintptr_t)r.invstd)) & 15) return EAS_ERR_INVALID_ARG;
+        b.r[i] = r;
+    }
+    if (nr == 1) b.r[1] = b.r[0];
+    return conv_fwd_impl((const float*)d->x, d->packed_w, nullptr, d->range[0].out, d->NI, d->Cin, d->Cout, d->Hi, d->Wi, d->ksize, d->stride,
+                         d->x_terms, inexact_flag, stream, false, nullptr, 0, nullptr, 0, &b);
 }
 
 // eas_conv_fwd (no bias) that also leaves the per-channel sums of its output for the BatchNorm behind it: stats[Cout][nb][2] doubles,

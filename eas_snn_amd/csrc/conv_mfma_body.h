@@ -57,6 +57,7 @@ struct ConvGeom {
     int act;       // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act: an eval-mode BaseConv whose BatchNorm is folded into
                    // weights and bias by fuse_model, yolox/utils/model_utils.py:35-80 -- "return self.act(self.conv(x))", network_blocks.py:55-56)
     EasLifEpiDev lif;
+    EasBnActEpiDev bna;   // BatchNorm (running statistics) + activation in the plain epilogue (eas_conv_bn_act_eval); bna.on = 0: the plain store
 };
 
 // exact n / d for n, d < 2^20 with m = ceil(2^40 / d): a multiply-shift instead of the ~25-instruction integer division
@@ -152,8 +153,9 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     // per-lane geometry of the WN pixel columns this lane owns
     int qoff[WN];
     long ybase[WN];
-    int l_img[LM ? WN : 1], l_pix[LM ? WN : 1];     // fused neuron epilogue: sample and pixel (inside its image) of the lane's column of tile j
-    bool l_ok[LM ? WN : 1];
+    constexpr bool NEURON = LM == 1 || LM == 2;      // fused neuron epilogue (LM = 3: BatchNorm + activation on the plain tiles)
+    int l_img[NEURON ? WN : 1], l_pix[NEURON ? WN : 1];     // fused neuron epilogue: sample and pixel (inside its image) of the lane's column of tile j
+    bool l_ok[NEURON ? WN : 1];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         // time-major: tile j = time step j / M2 of the wave's spatial tile j % M2 (M2 = WN / T spatial tiles per wave)
@@ -167,7 +169,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         const int img = g.bpi ? img0 : fdiv(rho, g.m_Ho), orow = rho - img * g.Ho;       // (ragged tiles: rows past the image belong to nobody)
         const int yr = orow * g.os + g.oph, yc = (part * g.Wo + c) * g.os + g.opw;
         ybase[j] = (p < npix && orow < g.Ho && rho < g.total_rows && yr < g.oH && yc < g.oW) ? (((long)img * g.Cout * g.oH + yr) * g.oW + yc) : -1;
-        if constexpr (LM != 0) {
+        if constexpr (NEURON) {
             l_img[j] = img;
             l_pix[j] = yr * g.oW + yc;
             l_ok[j] = ybase[j] >= 0;
@@ -381,7 +383,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         }
     }
 
-    if constexpr (LM != 0) {
+    if constexpr (NEURON) {
         // ---- fused BatchNorm (running statistics) + LIF over T: the accumulators are z_t of the lane's neurons, nothing is written but spikes
         if (g.dbg & 32) {        // development ablation: the main loop alone (one store keeps the accumulators alive)
             if (acc[0][0][0] == 12345.678f && g.lif.r[0].out_f32) g.lif.r[0].out_f32[0] = acc[0][WN - 1][3];
@@ -395,6 +397,12 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     // (M-tile, pixel tile), rows reached by adding multiples of the channel stride; bias values loaded once per M-tile;
     // the per-element channel bound check only for a ragged last M-tile (the epilogue used to be as long as the main loop).
     const long cstride = (long)g.oH * g.oW;
+    if constexpr (LM == 3) {      // BatchNorm (running statistics) + activation on the accumulators (eas_conv_bn_act_eval)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+            if (mt0 + i < g.MT) eas_bnact_epilogue<WN>(acc[i], g.bna, mt0 + i, h, ybase, cstride);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         if (mt0 + i >= g.MT) continue;
@@ -478,5 +486,101 @@ int pick_rows(int Ho, int Wo, int BN) {
 
 typedef int (*launch_fn)(const float*, const bf16x8*, const float*, float*, int*, ConvGeom, hipStream_t);
 
+
+// pixel blocks per channel (grid.x * parts) of the tile the last dispatch_tile call of this thread chose: the number of statistics
+// partials eas_conv_fwd_stats writes per channel
+thread_local int tl_pixel_blocks = 0;
+
+template <int TAPS, int S, int XT, int CCH, int VEC, bool PL = false, int LM = 0>
+int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y, int* inexact, ConvGeom g, hipStream_t st) {
+    // candidate block tiles {waves along M, waves along N}, each wave one 32-channel M-tile x 5 pixel tiles (160 pixels);
+    // 8-wave blocks (2 waves per SIMD hide each other's staging, LDS and weight latencies) first, widest pixel tile first
+    struct Cand { int wm, wvm, bn, threads, nit, wn; launch_fn fn; };
+    constexpr int N8 = XT == 1 ? 2 : 1, N4 = 2;   // staging items per thread (register budget: 2 waves per SIMD either way)
+    // wave tile = 32 channels x WN 32-pixel tiles.  WN = 5 (160 pixels) is the efficient shape; WN = 3 (96 pixels: two 40-pixel rows,
+    // four 20-pixel rows or one 8x10 image) exists for the small maps of the neck / head and of dark4 / dark5, where 160-pixel wave
+    // tiles leave most of the 256 CUs without a block (64 images of 8x10 with 128 channels are 16 eight-wave blocks)
+    const Cand cands[14] = {
+        {1, 2, 640, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 4, CCH, VEC, N8, PL, LM>}, {1, 4, 320, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 2, CCH, VEC, N8, PL, LM>},
+        {1, 8, 160, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 8, 1, CCH, VEC, N8, PL, LM>}, {1, 1, 1280, 512, N8, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 8, CCH, VEC, N8, PL, LM>},
+        {1, 1, 640, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 1, 4, CCH, VEC, N4, PL, LM>}, {1, 2, 320, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 2, 2, CCH, VEC, N4, PL, LM>},
+        {1, 4, 160, 256, N4, 5, launch_fwd<TAPS, S, XT, 1, 5, 4, 1, CCH, VEC, N4, PL, LM>},
+        {1, 2, 384, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 4, CCH, VEC, N8, PL, LM>}, {1, 4, 192, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 2, CCH, VEC, N8, PL, LM>},
+        {1, 8, 96, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 8, 1, CCH, VEC, N8, PL, LM>}, {1, 1, 768, 512, N8, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 8, CCH, VEC, N8, PL, LM>},
+        {1, 1, 384, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 1, 4, CCH, VEC, N4, PL, LM>}, {1, 2, 192, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 2, 2, CCH, VEC, N4, PL, LM>},
+        {1, 4, 96, 256, N4, 3, launch_fwd<TAPS, S, XT, 1, 3, 4, 1, CCH, VEC, N4, PL, LM>}};
+    // cost model (measured on MI355X, scripts/dev_conv.py, scripts/dev_conv_calls.py): one block per CU; a round of 8-wave blocks costs
+    // ~1.27x a round of 4-wave blocks; a block's time is a fixed part (prologue, first patch, epilogue) plus its MFMA work, which
+    // goes with WN whatever part of the pixel tile is valid
+    int best = -1;
+    double best_cost = 0.0;
+    int best_valid = 0;
+    ConvGeom best_g = g;
+    static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
+    static const int ncand = getenv("EAS_CONV_NCAND") ? atoi(getenv("EAS_CONV_NCAND")) : 14;  // development: 7 = the 160-pixel wave tiles only
+    const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
+    // Single-buffered patch (mode 1): for layers of few channel chunks whose double-buffered patch fills the LDS (real-valued inputs on wide
+    // rows: dark2.0, 135 -> 103 us) -- the second buffer buys one overlapped stage there, a second resident block overlaps everything.
+    // With more chunks the exposed write of every chunk costs more than it gains (4 chunks: 100 -> 122 us, 8: 125 -> 154 us); three
+    // chunks (the 48-channel layers of SYOLOX-M) still gain: config 4 88.0 -> 87.5 ms.
+    static const int single_nch = getenv("EAS_CONV_SINGLE_NCH") ? atoi(getenv("EAS_CONV_SINGLE_NCH")) : 3;      // development: 0 = never
+    static const double single_pen = getenv("EAS_CONV_SINGLE_PEN") ? atof(getenv("EAS_CONV_SINGLE_PEN")) : 1.1;
+    for (int i = 0; i < ncand; ++i)
+      for (int mode = 0; mode < 2; ++mode) {
+        const Cand& c = cands[i];
+        if (force >= 0 && i != force) continue;
+        if (mode == 1 && (XT != 3 || nchunks < 2 || nchunks > single_nch)) continue;      // spike-input layers: 76 -> 84 us (the patch is a third)
+        const int nbuf = (nchunks == 1 || mode == 1) ? 1 : 2;
+        if ((c.wvm * c.wm - 1) * 32 >= g.Cout && !(c.wvm == 1 && c.wm == 1)) continue;   // every wave row (and M-tile) has channels to compute
+        ConvGeom t = g;
+        t.single = mode;
+        bool fits = false;
+        for (int cap = c.bn; cap >= g.Wo && !fits; cap -= 32) {   // shrink the pixel tile until patch + staging slots fit
+            t.RT = pick_rows(g.Ho, g.Wo, cap);
+            if (t.RT == 0) break;
+            t.rows_seg = t.RT < g.Ho ? t.RT : g.Ho;
+            t.nseg = t.RT / t.rows_seg;
+            t.rows_in = (t.rows_seg - 1) * S + g.ext_h;
+            t.Q = t.nseg * t.rows_in * t.RS;
+            fits = (size_t)nbuf * t.Q * CCH * 2 * XT <= 160 * 1024 && t.nseg * t.rows_in * (g.Wst / VEC) * (CCH / 8) <= c.nit * c.threads;
+            cap = t.RT * g.Wo;
+        }
+        if (!fits) continue;
+        const long blocks = (long)((g.total_rows + t.RT - 1) / t.RT) * ((g.MT + c.wvm * c.wm - 1) / (c.wvm * c.wm)) * g.parts;
+        // resident blocks per CU: one 8-wave block, or two 4-wave blocks when their LDS fits twice (independent barriers
+        // overlap one block's prologue/epilogue with the other's MFMA phase: cheaper per round than one 8-wave block)
+        const size_t lds_bytes = (size_t)nbuf * t.Q * CCH * 2 * XT;
+        int bpc = c.threads == 512 ? 1 : (2 * lds_bytes <= 160 * 1024 ? 2 : 1);
+        if (mode == 1) {
+            // worth it only where it buys the second resident block (launch bounds keep the registers of two blocks per CU available)
+            if (2 * lds_bytes > 160 * 1024 || 2 * (2 * lds_bytes) <= 160 * 1024) continue;
+            bpc = 2;
+        }
+        // (two co-resident 4-wave blocks cost 1.2 rounds of one -- but only when there are more blocks than CUs: a grid of <= 256 blocks
+        // puts one block on a CU whatever its LDS size)
+        // a step's MFMAs (3 * WN with one-term inputs, 6 * WN with three) hide the ~450-cycle latency of the next step's weight
+        // fragments only when they last that long: with spike inputs a 3-tile wave (288 MFMA cycles per step) waits on every step and
+        // costs nearly as much as a 5-tile wave (dark5.m.conv2: 71 us against 62 us for the 160-pixel shape the old model ranked behind)
+        static const double lat = getenv("EAS_CONV_STEP_LAT") ? atof(getenv("EAS_CONV_STEP_LAT")) : 450.0;   // development
+        const double per_tile = XT == 1 ? 96.0 : 192.0;
+        const double mfma_part = (c.wn * per_tile > lat ? c.wn * per_tile : lat) / (5.0 * per_tile);
+        const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part) *
+                                  (mode == 1 ? single_pen * (c.threads == 512 && blocks > 256 ? 1.2 : 1.0) : 1.0);
+        const double cost = (double)((blocks + 256 * bpc - 1) / (256 * bpc)) * round_cost;
+        // ties: the larger valid pixel count; among grids of lone blocks (<= 256) first the shape with more waves along the channels
+        // (they share one staged pixel patch: the smaller patch per block is the shorter prologue; 8x10 head layers: 35-38 us against
+        // 44-50 us for the four-pixel-group shape)
+        const int valid = t.RT * g.Wo;
+        static const int tie_wvm = getenv("EAS_CONV_TIE_WVM") ? atoi(getenv("EAS_CONV_TIE_WVM")) : 1;        // development: 0 = lone blocks only
+        const int rank = ((blocks <= 256 || tie_wvm) ? c.wvm * 4096 : 0) + (valid < 4096 ? valid : 4095);
+        if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rank > best_valid)) {
+            best = i; best_cost = cost; best_valid = rank; best_g = t;
+        }
+    }
+    if (best < 0) return EAS_ERR_UNSUPPORTED;
+    tl_pixel_blocks = ((best_g.total_rows + best_g.RT - 1) / best_g.RT) * best_g.parts;
+    if (!y) return EAS_OK;                       // geometry query (eas_conv_fwd_supported): a tile exists, nothing is launched
+    return cands[best].fn(x, wp, bias, y, inexact, best_g, st);
+}
 
 }  // namespace

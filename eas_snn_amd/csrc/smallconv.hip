@@ -24,7 +24,7 @@ template <int CIN, int COUT, int K, bool DUAL, bool VECW>
 __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restrict__ x, const float* __restrict__ wr,
                                                           const float* __restrict__ b, const float* __restrict__ mask,
                                                           float* __restrict__ y, const float* __restrict__ mask2, float* __restrict__ y2, int N,
-                                                          int H, int W, int relu) {
+                                                          int H, int W, int relu, int x_tm) {
     using SG = Stage<CIN, K, VECW>;
     constexpr int LWF = SG::PITCH, PLANE = SG::PLANE;
     constexpr int CO = DUAL ? COUT / 2 : COUT;
@@ -38,8 +38,9 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
     typename SG::Pre pre[St::PER];
     unsigned okm = 0;
     int tile = blockIdx.x;
+    const int xS = x_tm ? N / x_tm : 0;                // x given as collated micro-slices (sc_src_image)
     if (tile < ntiles)
-        okm = st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
+        okm = st.load(x, pre, sc_src_image(tile / (tiles_x * tiles_y), xS, x_tm), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
     for (; tile < ntiles; tile += gridDim.x) {
         const int n = tile / (tiles_x * tiles_y);
         const int ty0 = ((tile / tiles_x) % tiles_y) * TH, tx0 = (tile % tiles_x) * TW;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(NT, 2) void smallconv_kernel(const float* __restric
         __syncthreads();
         const int nxt = tile + gridDim.x;              // next tile's loads fly during this tile's FMAs
         if (nxt < ntiles)
-            okm = st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
+            okm = st.load(x, pre, sc_src_image(nxt / (tiles_x * tiles_y), xS, x_tm), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
         f2 acc[4][COUT / 2];
 #pragma unroll
         for (int op = 0; op < COUT / 2; ++op) {
@@ -135,9 +136,10 @@ __global__ void smallconv_pack_kernel(const PackJobs jobs) {
 // tiles of the block; one shuffle + LDS reduction per block, block partials summed in fixed order afterwards.
 template <int CIN, int COUT, int K>
 __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                             float* __restrict__ partial, int N, int H, int W) {
+                                                             float* __restrict__ partial, int N, int H, int W, int x_tm) {
     using G = Geo<K>;
     constexpr int GROUPS = NT / CIN;
+    const int xS = x_tm ? N / x_tm : 0;           // x given as collated micro-slices (sc_src_image)
     constexpr int UNITS = TH * (TW / 4);
     constexpr int PLANE = G::LH * LWS + 16;
     constexpr int NW = COUT * CIN * K * K;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
     };
     int tile = blockIdx.x;
     if (tile < ntiles) {
-        okm = st.load(x, pre, tile / (tiles_x * tiles_y), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
+        okm = st.load(x, pre, sc_src_image(tile / (tiles_x * tiles_y), xS, x_tm), H, W, ((tile / tiles_x) % tiles_y) * TH, (tile % tiles_x) * TW);
         load_gy(tile);
     }
     for (; tile < ntiles; tile += gridDim.x) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(NT) void smallconv_wgrad_kernel(const float* __rest
         __syncthreads();
         const int nxt = tile + gridDim.x;          // next tile's loads fly during this tile's FMAs
         if (nxt < ntiles) {
-            okm = st.load(x, pre, nxt / (tiles_x * tiles_y), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
+            okm = st.load(x, pre, sc_src_image(nxt / (tiles_x * tiles_y), xS, x_tm), H, W, ((nxt / tiles_x) % tiles_y) * TH, (nxt % tiles_x) * TW);
             load_gy(nxt);
         }
         for (int u = grp; u < UNITS; u += GROUPS) {
@@ -299,16 +301,16 @@ constexpr int kConvBlocks = 256 * 6;
 
 template <int CIN, int COUT, bool DUAL>
 int launch_conv_k(int k, const float* x, const float* wr, const float* b, const float* mask, float* y, const float* mask2, float* y2, int N,
-                  int H, int W, int relu, hipStream_t st) {
+                  int H, int W, int relu, hipStream_t st, int x_tm = 0) {
     int tiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     if (tiles > kConvBlocks) tiles = kConvBlocks;      // persistent blocks loop over tiles with register prefetch
     const bool vecw = (W & 3) == 0 && (((uintptr_t)x) & 15) == 0;
 #define EAS_SC(K_)                                                                                                                             \
     do {                                                                                                                                       \
         if (vecw) EAS_LAUNCH((smallconv_kernel<CIN, COUT, K_, DUAL, true>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, \
-                                     N, H, W, relu);                                                                                           \
+                                     N, H, W, relu, x_tm);                                                                                     \
         else EAS_LAUNCH((smallconv_kernel<CIN, COUT, K_, DUAL, false>), dim3(tiles), dim3(NT), 0, st, x, wr, b, mask, y, mask2, y2, N,  \
-                                H, W, relu);                                                                                                   \
+                                H, W, relu, x_tm);                                                                                             \
     } while (0)
     switch (k) {
         case 3: EAS_SC(3); break;
@@ -322,11 +324,11 @@ int launch_conv_k(int k, const float* x, const float* wr, const float* b, const 
 }
 
 template <int CIN, int COUT>
-int launch_wgrad_k(int k, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
+int launch_wgrad_k(int k, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, int x_tm, hipStream_t st) {
     switch (k) {
-        case 3: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 3>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
-        case 5: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 5>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
-        case 7: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 7>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W); break;
+        case 3: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 3>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W, x_tm); break;
+        case 5: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 5>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W, x_tm); break;
+        case 7: EAS_LAUNCH((smallconv_wgrad_kernel<CIN, COUT, 7>), dim3(nblocks), dim3(NT), 0, st, gy, x, partial, N, H, W, x_tm); break;
         default: return EAS_ERR_UNSUPPORTED;
     }
     EAS_CHECK_LAUNCH();
@@ -348,7 +350,7 @@ bool wgrad_on_mfma(int k) {
 
 // smallconv_wgrad_mfma.hip
 int eas_sw_mfma_partials(const float* gy, const float* x, float* partial, int max_blocks, int N, int Cin, int Cout, int H, int W,
-                         int k, hipStream_t st);
+                         int k, int x_tm, hipStream_t st);
 
 extern "C" {
 
@@ -373,14 +375,14 @@ int eas_smallconv_pack_weights(const EasSmallconvPackJob* jobs, int njobs, eas_s
 }
 
 int eas_smallconv_fwd(const float* x, const float* wr, const float* b, float* y, int N, int Cin, int Cout, int H,
-                      int W, int k, int relu, eas_stream_t stream) {
+                      int W, int k, int relu, int x_tm, eas_stream_t stream) {
     if (!x || !wr || !y || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
-    if (bad_ptr(y) || bad_ptr(wr)) return EAS_ERR_INVALID_ARG;
+    if (bad_ptr(y) || bad_ptr(wr) || x_tm < 0 || (x_tm > 0 && N % x_tm != 0)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
-    if (Cin == 2 && Cout == 4) return launch_conv_k<2, 4, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st);
-    if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st);
-    if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st);
+    if (Cin == 2 && Cout == 4) return launch_conv_k<2, 4, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st, x_tm);
+    if (Cin == 4 && Cout == 4) return launch_conv_k<4, 4, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st, x_tm);
+    if (Cin == 2 && Cout == 2) return launch_conv_k<2, 2, false>(k, x, wr, b, nullptr, y, nullptr, nullptr, N, H, W, relu, st, x_tm);
     return EAS_ERR_UNSUPPORTED;
 }
 
@@ -412,21 +414,22 @@ int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k) {
 }
 
 int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w, float* grad_b, float* workspace,
-                             int N, int Cin, int Cout, int H, int W, int k, eas_stream_t stream) {
+                             int N, int Cin, int Cout, int H, int W, int k, int x_tm, eas_stream_t stream) {
     if (!grad_y || !x || !grad_w || !workspace || N < 1 || H < 1 || W < 1) return EAS_ERR_INVALID_ARG;
+    if (x_tm < 0 || (x_tm > 0 && N % x_tm != 0)) return EAS_ERR_INVALID_ARG;
     hipStream_t st = eas_s(stream);
     EAS_CLEAR_ERR();
     int nblocks;
     if (wgrad_on_mfma(k)) {
-        nblocks = eas_sw_mfma_partials(grad_y, x, workspace, kWgradBlocks, N, Cin, Cout, H, W, k, st);
+        nblocks = eas_sw_mfma_partials(grad_y, x, workspace, kWgradBlocks, N, Cin, Cout, H, W, k, x_tm, st);
         if (nblocks < 0) return nblocks;
     } else {
         const int tiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
         nblocks = tiles < kWgradBlocks ? tiles : kWgradBlocks;
         int rc;
-        if (Cin == 2 && Cout == 4) rc = launch_wgrad_k<2, 4>(k, grad_y, x, workspace, nblocks, N, H, W, st);
-        else if (Cin == 4 && Cout == 4) rc = launch_wgrad_k<4, 4>(k, grad_y, x, workspace, nblocks, N, H, W, st);
-        else if (Cin == 2 && Cout == 2) rc = launch_wgrad_k<2, 2>(k, grad_y, x, workspace, nblocks, N, H, W, st);
+        if (Cin == 2 && Cout == 4) rc = launch_wgrad_k<2, 4>(k, grad_y, x, workspace, nblocks, N, H, W, x_tm, st);
+        else if (Cin == 4 && Cout == 4) rc = launch_wgrad_k<4, 4>(k, grad_y, x, workspace, nblocks, N, H, W, x_tm, st);
+        else if (Cin == 2 && Cout == 2) rc = launch_wgrad_k<2, 2>(k, grad_y, x, workspace, nblocks, N, H, W, x_tm, st);
         else return EAS_ERR_UNSUPPORTED;
         if (rc != EAS_OK) return rc;
     }

@@ -9,6 +9,15 @@ namespace {
 
 constexpr int TH = 16, TW = 64, LWS = 80, NT = 256;
 
+// Image n of a convolution whose input is the COLLATED micro-slice tensor [S][Tm][C][H][W] (trainer.py:99; embedding.py:147-156 flips the
+// time axis and makes it the leading one) read time-major, newest slice first, without that flipped copy: image n = t * S + s is micro-slice
+// Tm - 1 - t of sample s.  Tm = 0: the input is an ordinary [N][C][H][W] tensor.
+__device__ __forceinline__ int sc_src_image(int n, int S, int Tm) {
+    if (Tm == 0) return n;
+    const int t = n / S;
+    return (n - t * S) * Tm + (Tm - 1 - t);
+}
+
 template <int K>
 struct Geo {
     static constexpr int PAD = K / 2;

@@ -109,8 +109,14 @@ __device__ __forceinline__ void sw_load_row(const float* __restrict__ row, bool 
 // !VEC (any W / alignment): 4 waves do both in turn on one buffer.
 template <int CIN, int COUT, int K, bool VEC>
 __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                                                   float* __restrict__ partial, int N, int H, int W) {
+                                                                                   float* __restrict__ partial, int N, int H, int W, int x_tm) {
     using S = Sw<CIN, COUT, K>;
+    const int xS = x_tm ? N / x_tm : 0;                                          // x given as collated micro-slices: image n of the
+    auto x_img = [&](int n) {                                                     // convolution = micro-slice x_tm - 1 - n / xS of sample n % xS
+        if (x_tm == 0) return n;                                                  // (smallconv_core.h sc_src_image)
+        const int t = n / xS;
+        return (n - t * xS) * x_tm + (x_tm - 1 - t);
+    };
     constexpr int PAD = S::PAD;
     constexpr int NBUF = VEC ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // NBUF x STAGE_BYTES
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
         auto issue = [&](Pre& p, int t) {
             int n, h0, w0;
             tile_origin(t, n, h0, w0);
+            const int nx = x_img(n);
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 const int row = h0 + g_dr[j], col = w0 + g_dc[j];
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
                 const bool row_ok = x_valid[j] && row < H;
                 const bool ok0 = row_ok && col >= 0 && col + 4 <= W, ok1 = row_ok && col + 4 >= 0 && col + 8 <= W;
                 const bool ok2 = row_ok && col + 8 < W;
-                const float* prow = x + ((size_t)n * CIN + x_ch[j]) * plane + (size_t)(row_ok ? row : 0) * W + col;
+                const float* prow = x + ((size_t)nx * CIN + x_ch[j]) * plane + (size_t)(row_ok ? row : 0) * W + col;
                 p.xa[j] = *(const float4*)(ok0 ? prow : x);
                 p.xb[j] = *(const float4*)(ok1 ? prow + 4 : x);
                 p.xc[j] = *(ok2 ? prow + 8 : x);
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
                 const int ci = rc % CIN, row_l = rc / CIN;
                 const int h = h0 + row_l;
                 const bool row_ok = h < H;
-                const float* row = x + ((size_t)n * CIN + ci) * plane + (size_t)(row_ok ? h : 0) * W;
+                const float* row = x + ((size_t)x_img(n) * CIN + ci) * plane + (size_t)(row_ok ? h : 0) * W;
                 float v[9];
                 sw_load_row<9>(row, row_ok, w0 - HALO + 8 * c8, W, v);
                 unsigned char* dst = smem + S::G_BYTES + ((row_l * CIN + ci) * S::XP + 8 * c8) * 2;
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(VEC ? 4 * NTH : NTH) void smallconv_wgrad_mfma_kern
 }
 
 template <int CIN, int COUT, int K>
-int sw_launch_k(bool vec, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
+int sw_launch_k(bool vec, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, int x_tm, hipStream_t st) {
     using S = Sw<CIN, COUT, K>;
     if (vec) {
         auto kern = smallconv_wgrad_mfma_kernel<CIN, COUT, K, true>;
@@ -408,22 +415,22 @@ int sw_launch_k(bool vec, const float* gy, const float* x, float* partial, int n
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
             attr_set = true;
         }
-        EAS_LAUNCH(kern, dim3(nblocks), dim3(4 * NTH), 2 * S::STAGE_BYTES, st, gy, x, partial, N, H, W);
+        EAS_LAUNCH(kern, dim3(nblocks), dim3(4 * NTH), 2 * S::STAGE_BYTES, st, gy, x, partial, N, H, W, x_tm);
     } else {
-        EAS_LAUNCH((smallconv_wgrad_mfma_kernel<CIN, COUT, K, false>), dim3(nblocks), dim3(NTH), S::LDS_BYTES, st, gy, x, partial, N, H, W);
+        EAS_LAUNCH((smallconv_wgrad_mfma_kernel<CIN, COUT, K, false>), dim3(nblocks), dim3(NTH), S::LDS_BYTES, st, gy, x, partial, N, H, W, x_tm);
     }
     return EAS_OK;
 }
 
 template <int CIN, int COUT>
-int sw_launch(int k, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, hipStream_t st) {
+int sw_launch(int k, const float* gy, const float* x, float* partial, int nblocks, int N, int H, int W, int x_tm, hipStream_t st) {
     const bool vec = (W & 3) == 0 && ((((uintptr_t)gy) | ((uintptr_t)x)) & 15) == 0;   // float4 staging loads with register prefetch
     int rc;
     if (vec && nblocks > 256) nblocks = 256;             // 8-wave blocks with two LDS buffers: one per CU
     switch (k) {
-        case 3: rc = sw_launch_k<CIN, COUT, 3>(vec, gy, x, partial, nblocks, N, H, W, st); break;
-        case 5: rc = sw_launch_k<CIN, COUT, 5>(vec, gy, x, partial, nblocks, N, H, W, st); break;
-        case 7: rc = sw_launch_k<CIN, COUT, 7>(vec, gy, x, partial, nblocks, N, H, W, st); break;
+        case 3: rc = sw_launch_k<CIN, COUT, 3>(vec, gy, x, partial, nblocks, N, H, W, x_tm, st); break;
+        case 5: rc = sw_launch_k<CIN, COUT, 5>(vec, gy, x, partial, nblocks, N, H, W, x_tm, st); break;
+        case 7: rc = sw_launch_k<CIN, COUT, 7>(vec, gy, x, partial, nblocks, N, H, W, x_tm, st); break;
         default: return EAS_ERR_UNSUPPORTED;
     }
     if (rc != EAS_OK) return rc;
@@ -436,14 +443,14 @@ int sw_launch(int k, const float* gy, const float* x, float* partial, int nblock
 // Internal to the library (smallconv.hip's eas_smallconv_bwd_weight): block partials [nblocks][Cout*Cin*k*k + Cout] of the MFMA
 // form; returns the number of blocks launched (<= max_blocks) or a negative status.
 int eas_sw_mfma_partials(const float* gy, const float* x, float* partial, int max_blocks, int N, int Cin, int Cout, int H, int W,
-                         int k, hipStream_t st) {
+                         int k, int x_tm, hipStream_t st) {
     const int64_t tiles = (int64_t)N * ((H + RB - 1) / RB) * ((W + WC - 1) / WC);
     if (tiles > 0x7fffffff) return EAS_ERR_UNSUPPORTED;
     const int nblocks = tiles < max_blocks ? (int)tiles : max_blocks;
     int rc;
-    if (Cin == 2 && Cout == 4) rc = sw_launch<2, 4>(k, gy, x, partial, nblocks, N, H, W, st);
-    else if (Cin == 4 && Cout == 4) rc = sw_launch<4, 4>(k, gy, x, partial, nblocks, N, H, W, st);
-    else if (Cin == 2 && Cout == 2) rc = sw_launch<2, 2>(k, gy, x, partial, nblocks, N, H, W, st);
+    if (Cin == 2 && Cout == 4) rc = sw_launch<2, 4>(k, gy, x, partial, nblocks, N, H, W, x_tm, st);
+    else if (Cin == 4 && Cout == 4) rc = sw_launch<4, 4>(k, gy, x, partial, nblocks, N, H, W, x_tm, st);
+    else if (Cin == 2 && Cout == 2) rc = sw_launch<2, 2>(k, gy, x, partial, nblocks, N, H, W, x_tm, st);
     else return EAS_ERR_UNSUPPORTED;
     return rc;
 }

@@ -272,6 +272,30 @@ def _f32c(t):
     return t.contiguous()
 
 
+# 1 / sqrt(running_var + eps) of the BatchNorm layers that normalise with their running statistics.  Inside the forward of an eval-mode
+# model (``packed_weights``) all of them are computed by two multi-tensor launches when the forward starts instead of two small launches per
+# layer (SYOLOX-S: 148 launches, 0.67 ms of a 5.7 ms eval forward at batch 64); same arithmetic (x + eps, rsqrt), so the same bits.  Valid
+# for the duration of that forward only -- nothing is cached across forwards (the statistics may change in between).
+_INVSTD_SCOPE = None      # {address of running_var: (eps, invstd)} or None
+
+
+def _eval_invstd(running_var, eps):
+    if _INVSTD_SCOPE is not None:
+        hit = _INVSTD_SCOPE.get(running_var.data_ptr())
+        if hit is not None and hit[0] == float(eps):
+            return hit[1]
+    return torch.rsqrt(running_var + eps)
+
+
+def _invstd_of_eval_model(mods):
+    bns = [m for m in mods if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.running_var is not None and m.running_var.is_cuda
+           and not m.training]
+    if not bns:
+        return None
+    inv = torch._foreach_rsqrt(torch._foreach_add([m.running_var for m in bns], [float(m.eps) for m in bns]))
+    return {m.running_var.data_ptr(): (float(m.eps), t) for m, t in zip(bns, inv)}
+
+
 # ------------------------------------------------------------------------------------------------ K2
 class _LIFFn(torch.autograd.Function):
     @staticmethod
@@ -477,7 +501,7 @@ class _BNLIFFn(torch.autograd.Function):
                 _timer_add('eas_bn_stats', t0, nb_)
         else:
             mean = running_mean
-            invstd = torch.rsqrt(running_var + eps)
+            invstd = _eval_invstd(running_var, eps)
         planes = sp_arg is not None and sp_arg is not False
         res_ctot = 0
         if residual is not None:
@@ -624,7 +648,7 @@ class _BNLIF2Fn(torch.autograd.Function):
                     _timer_add('eas_bn_stats', t0, nb_)
             else:
                 mean = running_mean
-                invstd = torch.rsqrt(running_var + eps)
+                invstd = _eval_invstd(running_var, eps)
             sp = None
             if cat is not None:
                 spikes = cat[0].narrow(2, cat[1], Cc)
@@ -874,7 +898,7 @@ def conv_bn_lif_eval(x_seq, conv, layers, want_mean=False, residual=None, cats=N
         r = d.range[i]
         Cr = bn.num_features
         a = node.lif_args()
-        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        invstd = _eval_invstd(bn.running_var, bn.eps)
         keep.append(invstd)
         r.gamma, r.beta, r.mean, r.invstd = ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(invstd)
         w = a['w']
@@ -1001,7 +1025,7 @@ class _BNSiLUFn(torch.autograd.Function):
         else:
             pend = keep = None
             mean = running_mean
-            invstd = torch.rsqrt(running_var + eps)
+            invstd = _eval_invstd(running_var, eps)
         if cat_buf is not None:
             assert cat_buf.is_contiguous() and cat_buf.dtype == torch.float32 and cat_buf.shape[0] == N and cat_buf.shape[2:] == y.shape[2:]
             out = cat_buf.narrow(1, cat_c0, Cc)
@@ -1063,7 +1087,7 @@ class _BNSiLU2Fn(torch.autograd.Function):
                     _timer_add('eas_bn_stats', t0, nb_)
             else:
                 mean = running_mean
-                invstd = torch.rsqrt(running_var + eps)
+                invstd = _eval_invstd(running_var, eps)
             if cat is not None:
                 out = cat[0].narrow(1, cat[1], Cc)
                 ctot = cat[0].shape[1]
@@ -1306,11 +1330,15 @@ def smallconv_pack(jobs):
     return outs
 
 
-def smallconv_fwd(x, w, b, relu=False, out=None, wr=None):
+def smallconv_fwd(x, w, b, relu=False, out=None, wr=None, x_tm=0):
     """Direct LDS-tiled conv (stride 1, 'same' padding) for the sampler's tiny-channel stacks.  ``out``: a contiguous
     [N,Cout,H,W] destination (e.g. one step's slice of a time-batched buffer) instead of a fresh tensor.  ``wr``: the weight already
-    arranged by ``smallconv_pack`` (mode 0); else it is arranged here."""
+    arranged by ``smallconv_pack`` (mode 0); else it is arranged here.  ``x_tm`` > 0: x is the collated micro-slice tensor
+    [S, x_tm, Cin, H, W] and the result is time-major, newest slice first ([x_tm * S, Cout, H, W]; include/eas_hip.h)."""
     x = _f32c(x)
+    if x_tm:
+        assert x.dim() == 5 and x.shape[1] == x_tm
+        x = x.view(-1, *x.shape[2:])
     N, Cin, H, W = x.shape
     Cout, k = w.shape[0], w.shape[-1]
     if wr is None:
@@ -1318,7 +1346,7 @@ def smallconv_fwd(x, w, b, relu=False, out=None, wr=None):
     y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device) if out is None else out
     assert y.is_contiguous() and y.shape == (N, Cout, H, W)
     _call('eas_smallconv_fwd', 4 * (x.numel() + y.numel()), _lib.lib().eas_smallconv_fwd, ptr(x), ptr(wr), ptr(b), ptr(y), N, Cin, Cout,
-          H, W, k, int(relu), stream())
+          H, W, k, int(relu), int(x_tm), stream())
     return y
 
 
@@ -1346,15 +1374,17 @@ def smallconv_bwd_input_dual(gy, wr8, k, mask_a, mask_b, out_a, out_b):
           ptr(out_a), ptr(out_b), N, H, W, int(k), stream())
 
 
-def smallconv_bwd_weight(gy, x, w):
+def smallconv_bwd_weight(gy, x, w, x_tm=0):
+    """``x_tm`` > 0: x is the collated micro-slice tensor [S, x_tm, Cin, H, W], gy time-major (see ``smallconv_fwd``)"""
     gy, x = _f32c(gy), _f32c(x)
     N, Cout, H, W = gy.shape
+    assert x.numel() == N * w.shape[1] * H * W and (not x_tm or (x.dim() == 5 and x.shape[1] == x_tm))
     Cin, k = w.shape[1], w.shape[-1]
     L = _lib.lib()
     gw, gb = torch.empty_like(w), torch.empty(Cout, dtype=torch.float32, device=gy.device)
     ws = torch.empty(L.eas_smallconv_wgrad_workspace_floats(Cin, Cout, k), dtype=torch.float32, device=gy.device)
     _call('eas_smallconv_bwd_weight', 4 * (gy.numel() + x.numel()), L.eas_smallconv_bwd_weight, ptr(gy), ptr(x), ptr(gw), ptr(gb),
-          ptr(ws), N, Cin, Cout, H, W, k, stream())
+          ptr(ws), N, Cin, Cout, H, W, k, int(x_tm), stream())
     return gw, gb
 
 
@@ -1391,10 +1421,14 @@ class _ARSNNFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
         _dev(ev, *params)
         L = _lib.lib()
-        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = cfg
+        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = cfg[:14]
         ev = _f32c(ev)
-        Tm, N, Cin, H, W = ev.shape
         pin, pg = params[:2 * d_in], params[2 * d_in:]
+        collated = len(cfg) > 14 and cfg[14]     # ev is [N, Tm, Cin, H, W] as the loader collates it; the kernels read it time-major, newest first
+        if collated:
+            N, Tm, Cin, H, W = ev.shape
+        else:
+            Tm, N, Cin, H, W = ev.shape
         HW = H * W
         if HW % 4 != 0:
             raise _lib.EasHipError('sampler needs H*W divisible by 4')
@@ -1407,10 +1441,19 @@ class _ARSNNFn(torch.autograd.Function):
         pk_in, pk_g = pk[:d_in], pk[d_in:]
         fused = bool(ARSNN_FUSED and d_in == 2 and d_gate in (0, 2) and W % 4 == 0 and pin[2].shape[:2] == (4, 4) and pin[0].shape[0] == 4
                      and (d_gate == 0 or (pg[2].shape[:2] == (4, 4) and pg[0].shape[0] == 4)) and _CONV_SINK is None and Tm > 0)
+        ctx.in_collated = bool(collated)
+        if collated and not (fused and not ctx.needs_input_grad[0]):
+            # only the fused step reads the collated layout: everything else gets the flipped, time-major copy (embedding.py:147-156)
+            ev = torch.stack([ev[:, Tm - 1 - t] for t in range(Tm)])
+            collated = False
         if fused:
             # first convolution + ReLU of the input stack for all Tm steps at once; the second one runs inside the step kernel
-            A_in = smallconv_fwd(ev.view(Tm * N, Cin, H, W), pin[0], pin[1], relu=True, wr=pk_in[0]).view(Tm, N, 4, H, W)
-            in_ins = [ev.view(Tm * N, Cin, H, W), A_in.view(Tm * N, 4, H, W)]
+            if collated:
+                A_in = smallconv_fwd(ev, pin[0], pin[1], relu=True, wr=pk_in[0], x_tm=Tm).view(Tm, N, 4, H, W)
+                in_ins = [ev, A_in.view(Tm * N, 4, H, W)]
+            else:
+                A_in = smallconv_fwd(ev.view(Tm * N, Cin, H, W), pin[0], pin[1], relu=True, wr=pk_in[0]).view(Tm, N, 4, H, W)
+                in_ins = [ev.view(Tm * N, Cin, H, W), A_in.view(Tm * N, 4, H, W)]
             X = None
             C2 = 2
         elif d_in:
@@ -1503,6 +1546,7 @@ class _ARSNNFn(torch.autograd.Function):
         ctx.fast0 = fast0
         ctx.fused = fused
         ctx.dims = (Tm, N, Cin, C2, H, W)
+        ctx.collated = bool(collated)
         # ``agg`` is this node's own output unless ``running``: keeping it on ctx would tie output -> grad_fn -> ctx -> output
         # into a reference cycle (Ts*N*C2*H*W floats held until the cyclic GC runs); the backward reads it in running mode only
         # (as a valid dummy pointer).  ``pre_relu`` likewise is ``out`` before the ReLU, a distinct tensor.  The tensors are
@@ -1518,7 +1562,7 @@ class _ARSNNFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_rec):
         L = _lib.lib()
-        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = ctx.cfg
+        k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = ctx.cfg[:14]
         Tm, N, Cin, C2, H, W = ctx.dims
         saved, in_ins, spike_last, seg, tl, pre_relu, agg, gate_in = ctx.saved
         params = ctx.params
@@ -1611,7 +1655,7 @@ class _ARSNNFn(torch.autograd.Function):
         grads_in = [None] * (2 * d_in)
         g = gX.view(Tm * N, 2 * C2, H, W)
         for i in range(d_in - 1, -1, -1):
-            grads_in[2 * i], grads_in[2 * i + 1] = smallconv_bwd_weight(g, in_ins[i], pin[2 * i])
+            grads_in[2 * i], grads_in[2 * i + 1] = smallconv_bwd_weight(g, in_ins[i], pin[2 * i], x_tm=Tm if (i == 0 and ctx.collated) else 0)
             if fused and i == 1:
                 g = gA_in.view(Tm * N, 4, H, W)              # the step loop already produced this input gradient
             elif i > 0 or ctx.ev_needs_grad:
@@ -1619,16 +1663,19 @@ class _ARSNNFn(torch.autograd.Function):
             else:
                 g = None
         g_ev = g.view(Tm, N, Cin, H, W) if ctx.ev_needs_grad else None
+        if g_ev is not None and ctx.in_collated:
+            g_ev = g_ev.flip(0).transpose(0, 1)          # back to the loader's [N, Tm, ...] in forward time order
         return (g_ev, None) + tuple(grads_in) + tuple(grads_g)
 
 
 def arsnn_forward(ev_rev, input_params, gate_params, kernel_size, Ts, readout, spike_attach, write_zero, use_abs, thresh,
-                  v_reset, record=False):
-    """ev_rev: [Tm, N, 2, H, W] micro-slices, newest first.  *_params: [w0, b0, (w1, b1, ...)]."""
+                  v_reset, record=False, collated=False):
+    """ev_rev: [Tm, N, 2, H, W] micro-slices, newest first -- or, with ``collated``, the loader's [N, Tm, 2, H, W] in forward time order
+    (the fused step's kernels then read it newest first themselves: no flipped copy of the input).  *_params: [w0, b0, (w1, b1, ...)]."""
     depth = len(input_params) // 2
     soft = v_reset is None
     cfg = (int(kernel_size), depth, int(Ts), READOUT_IDS[readout], bool(spike_attach), bool(write_zero), bool(use_abs),
-           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record), None, depth, len(gate_params) // 2)
+           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record), None, depth, len(gate_params) // 2, bool(collated))
     return _ARSNNFn.apply(ev_rev, cfg, *input_params, *gate_params)
 
 
@@ -2057,7 +2104,11 @@ def prepack_conv_weights(model):
     traffic for SYOLOX-S, < 0.1 ms) instead of 111 tiny packing kernels; inside a captured HIP graph the launch is part of the
     graph, so every replay packs the weights the optimizer has just written."""
     global _PACK_GEN
-    plan = getattr(model, '_eas_pack_plan', None)
+    # without autograd (inference) only the forward order is packed: a third of the work of the training plan; a consumer that still asks
+    # for a transposed order packs it on demand
+    fwd_only = not torch.is_grad_enabled()
+    plan_attr = '_eas_pack_plan_fwd' if fwd_only else '_eas_pack_plan'
+    plan = getattr(model, plan_attr, None)
     convs = plan['convs'] if plan else [m for m in model.modules() if _static_conv_ok(m) and m.weight.is_cuda]
     if not convs:
         return None
@@ -2072,7 +2123,8 @@ def prepack_conv_weights(model):
         dev = convs[0].weight.device
         for c in convs:
             k, Cout, Cin = c.kernel_size[0], c.out_channels, c.in_channels
-            modes = [0] + ([1] if c.stride == (1, 1) and (k == 1 or Cout % 8 == 0) else []) + ([2] if c.stride == (2, 2) and k == 3 and Cout % 8 == 0 else [])
+            modes = [0] if fwd_only else ([0] + ([1] if c.stride == (1, 1) and (k == 1 or Cout % 8 == 0) else [])
+                                          + ([2] if c.stride == (2, 2) and k == 3 and Cout % 8 == 0 else []))
             d = {}
             for m in modes:
                 d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)
@@ -2081,13 +2133,13 @@ def prepack_conv_weights(model):
         for _, _, a, b in duals:
             k, Ca, Cout, Cin = a.kernel_size[0], a.out_channels, a.out_channels + b.out_channels, a.in_channels
             d = {}
-            for m in (0, 1):
+            for m in ((0,) if fwd_only else (0, 1)):
                 d[m] = torch.empty(L.eas_conv_packed_weight_bytes(Cout, Cin, k, m), dtype=torch.uint8, device=dev)
                 jobs.append([a.weight.data_ptr(), d[m].data_ptr(), Cout, Cin, k, m, b.weight.data_ptr(), Ca])
             dpacks.append(d)
         plan = {'convs': convs, 'packs': packs, 'duals': duals, 'dpacks': dpacks, 'ptrs': ptrs, 'njobs': len(jobs),
                 'jobs': torch.tensor(jobs, dtype=torch.int64).to(dev)}
-        object.__setattr__(model, '_eas_pack_plan', plan)
+        object.__setattr__(model, plan_attr, plan)
     check(L.eas_conv_pack_weights_many(ptr(plan['jobs']), plan['njobs'], stream()), 'eas_conv_pack_weights_many')
     _PACK_GEN += 1
     for c, d in zip(convs, plan['packs']):
@@ -2125,7 +2177,7 @@ class _ConvDualFn(torch.autograd.Function):
         gy = _f32c(gy)
         gx = ga = gb = None
         if ctx.needs_input_grad[0]:
-            pk = ctx.packs[1] if ctx.packs else conv_pack_weights(torch.cat([wa, wb], 0), 1)
+            pk = ctx.packs[1] if ctx.packs and 1 in ctx.packs else conv_pack_weights(torch.cat([wa, wb], 0), 1)
             gx = conv_fwd_packed(gy, pk, None, x.shape[1], k, 1, 3)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             # ONE weight gradient for the two parameters: its slab reduction waits for the end of the backward pass with all the others
@@ -2196,9 +2248,14 @@ class packed_weights:
         # a forward hook anywhere in the model may look at a spike tensor: fp32 spikes throughout then (see "SPIKE PLANES")
         # (hooks that declare ``_eas_planes_safe`` -- the trainer's backward cut, which handles ghosts -- do not count)
         _PLANES_SCOPE = _PACK_SCOPE is not None and not any(_foreign_hooks(m) for m in mods)
+        global _INVSTD_SCOPE
+        self.prev_invstd = _INVSTD_SCOPE
+        if not self.model.training:
+            _INVSTD_SCOPE = _invstd_of_eval_model(mods)
 
     def __exit__(self, *exc):
-        global _PACK_SCOPE, _PLANES_SCOPE
+        global _PACK_SCOPE, _PLANES_SCOPE, _INVSTD_SCOPE
+        _INVSTD_SCOPE = self.prev_invstd
         _PACK_SCOPE, _PLANES_SCOPE = self.prev
         if self.prev[0] is None:
             clear_conv_stats()
@@ -2250,6 +2307,96 @@ def conv_act_eval(x, conv, act='silu'):
     packs = getattr(conv, '_eas_packs', None)
     pk = packs[0] if (packs is not None and _PACK_SCOPE is not None and packs.get('gen') == _PACK_SCOPE) else conv_pack_weights(conv.weight, 0)
     return conv_fwd_packed(xd, pk, conv.bias, conv.out_channels, k, s_, xt, act=1)
+
+
+# ------------------------------------------------------------------------------------------------ fused real-valued eval block (conv -> BN -> SiLU, ONE kernel)
+# The eval-mode forward of an unconverted BaseConv -- the ANN PAFPN neck and head of use_spike=True models -- normalises with running
+# statistics, so the BatchNorm and the activation can run on the convolution's accumulators: eas_conv_bn_act_eval, same arithmetic as
+# eas_conv_fwd + eas_bn_silu_fwd_ex (bit-identical), one launch and 4 instead of 12 bytes per output element.  Unlike ``fuse_model`` nothing
+# is folded into the weights, and the dual convolutions / in-place concatenations of the unfused model stay.  EAS_FUSED_ANN_EVAL=0: the
+# two-kernel path (development).
+FUSED_ANN_EVAL = os.environ.get('EAS_FUSED_ANN_EVAL', '1') == '1'
+
+
+def _ann_eval_bn_ok(bn):
+    return (type(bn) is torch.nn.BatchNorm2d and not bn.training and bn.affine and bn.running_mean is not None and bn.running_var is not None
+            and bn.num_features % 8 == 0 and not bn._forward_hooks and not bn._forward_pre_hooks)
+
+
+def fused_ann_eval_ok(x, conv, bns):
+    """``conv`` (an nn.Conv2d without bias, or a pair that reads the same input and runs as one) followed by the eval-mode BatchNorm2d
+    modules ``bns`` on consecutive output-channel ranges and SiLU can run as eas_conv_bn_act_eval on ``x`` [NI,Cin,H,W]"""
+    if not FUSED_ANN_EVAL or torch.is_grad_enabled() or _CONV_SINK is not None or torch.nn.modules.module._global_forward_hooks:
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        return False
+    convs = conv if isinstance(conv, tuple) else (conv,)
+    if len(convs) != len(bns) or len(convs) > 2 or not all(_ann_eval_bn_ok(bn) for bn in bns):
+        return False
+    for c, bn in zip(convs, bns):
+        if (type(c) is not torch.nn.Conv2d or c.bias is not None or c._forward_hooks or c._forward_pre_hooks or not _static_conv_ok(c)
+                or c.out_channels != bn.num_features):
+            return False
+    c0 = convs[0]
+    if len(convs) == 2 and not (convs[1].kernel_size == c0.kernel_size and convs[1].stride == c0.stride == (1, 1)
+                                and convs[1].in_channels == c0.in_channels):
+        return False
+    if not conv_eligible(x, c0):
+        return False
+    if is_small_int(x):
+        return False        # the epilogue is instantiated for real-valued inputs (three bf16 terms): what the ANN neck / head read
+    cout = sum(c.out_channels for c in convs)
+    return conv_fwd_supported(x.shape[0], x.shape[1], cout, x.shape[2], x.shape[3], c0.kernel_size[0], c0.stride[0], 3)
+
+
+def conv_bn_act_eval(x, conv, bns, cats=None, packs=None, act='silu'):
+    """act(bn(conv(x))) in one kernel (caller checked ``fused_ann_eval_ok``).  conv / bns: one convolution and its BatchNorm, or two that read
+    the same input (``packs``: the packing of their concatenated weight made by ``packed_weights``, or None).  cats[i] = (buffer
+    [NI,Ctot,H,W], first channel) or None.  Returns one tensor per BatchNorm (a view into the buffer where given)."""
+    L = _lib.lib()
+    convs = conv if isinstance(conv, tuple) else (conv,)
+    cats = cats or [None] * len(bns)
+    c0 = convs[0]
+    k, stride = c0.kernel_size[0], c0.stride[0]
+    Cout = sum(c.out_channels for c in convs)
+    NI, Cin, H, W = x.shape
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if len(convs) == 2:
+        pk = packs[0] if packs else conv_pack_weights(torch.cat([convs[0].weight, convs[1].weight], 0), 0)
+    else:
+        pk = getattr(c0, '_eas_packs', None)
+        pk = pk[0] if (pk is not None and _PACK_SCOPE is not None and pk.get('gen') == _PACK_SCOPE) else conv_pack_weights(c0.weight, 0)
+    d = _lib.EasConvBnActEval()
+    xd = _f32c(x)
+    keep = [pk, xd]
+    d.x, d.x_terms = ptr(xd), 3
+    d.packed_w = ptr(pk)
+    d.NI, d.Cin, d.Cout, d.Hi, d.Wi, d.ksize, d.stride = NI, Cin, Cout, H, W, k, stride
+    d.act = 1 if act == 'silu' else 0
+    d.csplit = bns[0].num_features
+    outs = []
+    for i, bn in enumerate(bns):
+        r = d.range[i]
+        Cr = bn.num_features
+        invstd = _eval_invstd(bn.running_var, bn.eps)
+        keep.append(invstd)
+        r.gamma, r.beta, r.mean, r.invstd = ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(invstd)
+        cat = cats[i]
+        if cat is not None:
+            buf, c0_ = cat[0], int(cat[1])
+            assert buf.is_contiguous() and buf.dtype == torch.float32 and tuple(buf.shape) == (NI, buf.shape[1], Ho, Wo)
+            out = buf.narrow(1, c0_, Cr)
+            r.out, r.out_ctot, r.out_c0 = ptr(buf), buf.shape[1], c0_
+        else:
+            out = torch.empty((NI, Cr, Ho, Wo), dtype=torch.float32, device=x.device)
+            r.out, r.out_ctot, r.out_c0 = ptr(out), Cr, 0
+        outs.append(out)
+    fl = 2.0 * NI * Cout * Ho * Wo * Cin * k * k
+    nb = 4 * NI * Cin * H * W + 4 * NI * Cout * Ho * Wo
+    _call('eas_conv_fwd', nb, L.eas_conv_bn_act_eval, C.byref(d), None, stream(), flops=fl, issue_flops=fl * 6)
+    del keep
+    return outs if len(bns) > 1 else outs[0]
 
 
 def conv2d(x, conv, small_int=None):

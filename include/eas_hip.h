@@ -340,9 +340,13 @@ typedef struct {
 } EasSmallconvPackJob;
 int64_t eas_smallconv_packed_floats(int n_in, int k, int o_total);
 int eas_smallconv_pack_weights(const EasSmallconvPackJob* jobs, int njobs, eas_stream_t stream);
-/* x: [N][Cin][H][W], wr: weights packed with mode 0 (o_total = Cout), b: [Cout] (nullable), y: [N][Cout][H][W]; relu != 0 applies max(.,0). */
+/* x: [N][Cin][H][W], wr: weights packed with mode 0 (o_total = Cout), b: [Cout] (nullable), y: [N][Cout][H][W]; relu != 0 applies max(.,0).
+ * x_tm > 0: x is the COLLATED micro-slice tensor [N / x_tm][x_tm][Cin][H][W] as the data loader hands it over (trainer.py:99) and image
+ * n = t * (N / x_tm) + s of the convolution is micro-slice x_tm - 1 - t of sample s -- the "reshape + flip(time) + time first" of
+ * embedding.py:147-156 done by the load addresses instead of a copy of the input; y stays [N][Cout][H][W] in that time-major order.
+ * x_tm = 0: x is [N][Cin][H][W].  N % x_tm == 0. */
 int eas_smallconv_fwd(const float* x, const float* wr, const float* b, float* y, int N, int Cin, int Cout, int H,
-                      int W, int k, int relu, eas_stream_t stream);
+                      int W, int k, int relu, int x_tm, eas_stream_t stream);
 /* grad_x = correlation of grad_y with the flipped, channel-transposed filter (wr: packed with mode 1, o_total = Cin); when
  * relu_mask != NULL (the ReLU output that fed this conv's input, i.e. the tensor the gradient flows back into), grad_x is zeroed
  * where relu_mask <= 0 (fused ReLU backward). */
@@ -353,9 +357,10 @@ int eas_smallconv_bwd_input(const float* grad_y, const float* wr, const float* r
 int eas_smallconv_bwd_input_dual(const float* grad_y, const float* wr, const float* mask_a, const float* mask_b, float* grad_xa,
                                  float* grad_xb, int N, int H, int W, int k, eas_stream_t stream);
 /* grad_w [Cout][Cin][k][k] and grad_b [Cout] (nullable); deterministic two-stage reduction through
- * workspace (eas_smallconv_wgrad_workspace_floats(Cin,Cout,k) floats). */
+ * workspace (eas_smallconv_wgrad_workspace_floats(Cin,Cout,k) floats).  x_tm: as eas_smallconv_fwd (the layout of x; grad_y is always
+ * [N][Cout][H][W]); the images are visited in the same order either way, so the sums are bit-identical to those over a flipped copy. */
 int eas_smallconv_bwd_weight(const float* grad_y, const float* x, float* grad_w, float* grad_b, float* workspace,
-                             int N, int Cin, int Cout, int H, int W, int k, eas_stream_t stream);
+                             int N, int Cin, int Cout, int H, int W, int k, int x_tm, eas_stream_t stream);
 int64_t eas_smallconv_wgrad_workspace_floats(int Cin, int Cout, int k);
 
 /* ---------------------------------------------------------------------------------------------
@@ -457,6 +462,33 @@ typedef struct {
 int eas_conv_bn_lif_eval(const EasConvBnLifEval* d, eas_stream_t stream);
 /* 1 when eas_conv_bn_lif_eval has a tile for this geometry (else the caller runs eas_conv_fwd + eas_bn_lif_fwd_ex) */
 int eas_conv_bn_lif_eval_supported(int T, int N, int Cin, int Cout, int Hi, int Wi, int ksize, int stride, int x_terms, int x_shared);
+
+/* ---- Eval-mode real-valued block: conv -> BatchNorm (running statistics) -> SiLU in ONE kernel ---------------------------------------
+ * BaseConv.forward of an unconverted block in eval mode, "act(bn(conv(x)))" (yolox/models/network_blocks.py:52-53): the ANN PAFPN neck and
+ * head behind the spiking backbone.  The convolution output never reaches HBM: the matrix-core kernel's epilogue normalises its
+ * accumulators with the running statistics (z = fma(y, gamma*invstd, beta - mean*gamma*invstd)), applies the activation and writes the
+ * result -- 4 bytes per element instead of the 4 + 4 + 4 of eas_conv_fwd + eas_bn_silu_fwd_ex, same arithmetic: bit-identical outputs.
+ * Unlike fuse_model's folded weights (eas_conv_fwd_act) nothing is rounded differently from the unfused model, and the block keeps the
+ * forms of the unfused model: EasBnActRange = one BatchNorm = a range of the convolution's output channels, [0, csplit) and
+ * [csplit, Cout) (conv1 | conv2 of a CSPLayer or the cls | reg tower convolutions computed by one convolution), each written at channel
+ * out_c0 of a destination with out_ctot channels (concatenation in place).  x: fp32 [NI][Cin][Hi][Wi], x_terms = 3 (real-valued: what
+ * these blocks read; EAS_ERR_UNSUPPORTED for the spike forms 1 / 2, whose blocks are the converted ones of eas_conv_bn_lif_eval).
+ * act: 0 none, 1 SiLU.  Cin, csplit, Cout multiples of 8.  Geometries: those of eas_conv_fwd (eas_conv_fwd_supported). */
+typedef struct {
+    const float *gamma, *beta, *mean, *invstd;   /* [C_range] */
+    float* out;                                  /* fp32 [NI][out_ctot][Ho][Wo] */
+    int out_ctot, out_c0;
+} EasBnActRange;
+typedef struct {
+    const void* x;
+    const void* packed_w;      /* eas_conv_pack_weights mode 0 */
+    int x_terms;
+    int NI, Cin, Cout, Hi, Wi, ksize, stride;
+    int act;
+    int csplit;
+    EasBnActRange range[2];
+} EasConvBnActEval;
+int eas_conv_bn_act_eval(const EasConvBnActEval* d, int* inexact_flag, eas_stream_t stream);
 
 /* Input gradient of a stride-2 3x3 convolution: grad_x[NI][Cin][Hi][Wi] from grad_y[NI][Cout][Ho][Wo] and the weights
  * packed with mode 2 (eas_conv_pack_weights), by parity class of the input pixel (1/2/2/4 taps per class). */

@@ -39,7 +39,8 @@ def clock(fn, n=10):
     return (time.perf_counter() - t) / n * 1e3
 
 
-for fused in ('auto', 'all', False):
+MODES = ('auto', 'all', False) if not os.environ.get('EAS_DEV_EVAL_ONLY') else (os.environ['EAS_DEV_EVAL_ONLY'],)      # one mode only: for a profile
+for fused in MODES:
     ops.FUSED_EVAL = fused
     with torch.no_grad(), ops.no_state_writeback():
         for _ in range(3):

@@ -1038,6 +1038,54 @@ def test_smallconv_weight_gradient_forms(dev, monkeypatch, cin, cout, k, N, H, W
     assert np.array_equal(gw2.cpu().numpy(), got['mfma'][0]) and np.array_equal(gb2.cpu().numpy(), got['mfma'][1])
 
 
+@pytest.mark.parametrize('cin,cout,k,S,Tm,H,W', [(2, 4, 5, 3, 4, 32, 64), (2, 4, 5, 2, 8, 37, 250), (4, 4, 3, 5, 2, 33, 130), (2, 2, 7, 1, 4, 20, 36),
+                                                 (2, 4, 5, 4, 4, 256, 320)])
+def test_smallconv_reads_collated_micro_slices_time_major(dev, monkeypatch, cin, cout, k, S, Tm, H, W):
+    """x_tm: the sampler's first convolution and its weight gradient read the loader's [S, Tm, C, H, W] tensor as the time-major, newest-first
+    [Tm * S, C, H, W] the reference builds with reshape + flip + transpose (embedding.py:147-156) -- bit-identical to running the same
+    kernels on that flipped copy, for the forward and for both weight-gradient kernels (vector and non-vector staging)."""
+    from eas_snn_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout * 100 + k * 10 + Tm)
+    x = torch.from_numpy(rng.poisson(0.4, (S, Tm, cin, H, W)).astype(np.float32)).to(dev)
+    w = _t((rng.standard_normal((cout, cin, k, k)) * 0.2).astype(np.float32), dev)
+    b = _t(rng.standard_normal(cout).astype(np.float32), dev)
+    gy = _t(rng.standard_normal((Tm * S, cout, H, W)).astype(np.float32), dev)
+    flipped = torch.stack([x[:, Tm - 1 - t] for t in range(Tm)]).reshape(Tm * S, cin, H, W).contiguous()
+    assert torch.equal(ops.smallconv_fwd(x, w, b, relu=True, x_tm=Tm), ops.smallconv_fwd(flipped, w, b, relu=True))
+    for form in ('fma', 'mfma'):
+        monkeypatch.setenv('EAS_SW_FORM', form)
+        gw, gb = ops.smallconv_bwd_weight(gy, x, w, x_tm=Tm)
+        gw0, gb0 = ops.smallconv_bwd_weight(gy, flipped, w)
+        assert torch.equal(gw, gw0) and torch.equal(gb, gb0), form
+        assert float(gw.abs().max()) > 0
+
+
+@pytest.mark.parametrize('Tm,N,H,W,Ts', [(4, 3, 32, 48, 1), (8, 2, 24, 64, 7)])
+def test_sampler_on_the_collated_input_equals_the_flipped_copy(dev, Tm, N, H, W, Ts):
+    """ops.arsnn_forward(collated=True) on the loader's [N, Tm, 2, H, W] (what AdaptiveRSNNEmbedding passes) against the same operator on
+    the explicit flipped, time-major copy: outputs and every parameter gradient bit-identical."""
+    from eas_snn_amd import ops
+    torch.manual_seed(9)
+    ev = torch.poisson(torch.full((N, Tm, 2, H, W), 0.4)).to(dev)
+    pin = [(torch.randn(4, 2, 5, 5) * 0.3), torch.randn(4) * 0.1, torch.randn(4, 4, 5, 5) * 0.2, torch.randn(4) * 0.1]
+    pg = [(torch.randn(4, 2, 5, 5) * 0.3), torch.randn(4) * 0.1, torch.randn(4, 4, 5, 5) * 0.2, torch.randn(4) * 0.1]
+    go = torch.randn(Ts, N, 2, H, W).to(dev)
+    res = []
+    for collated in (True, False):
+        a = [p.clone().to(dev).requires_grad_(True) for p in pin]
+        b = [p.clone().to(dev).requires_grad_(True) for p in pg]
+        e = ev if collated else torch.stack([ev[:, Tm - 1 - t] for t in range(Tm)])
+        with ops.kernel_trace() as tr:
+            out, _ = ops.arsnn_forward(e, a, b, 5, Ts, 'sum', True, True, False, 1.0, 0.0, collated=collated)
+            (out * go).sum().backward()
+        x_tm = [args[-2] for n_, args in tr.calls if n_ in ('eas_smallconv_fwd', 'eas_smallconv_bwd_weight')]
+        assert (Tm in x_tm) == collated, x_tm
+        res.append((out.detach().clone(), [p.grad.clone() for p in a + b]))
+    assert torch.equal(res[0][0], res[1][0]) and float(res[0][0].abs().sum()) > 0
+    for g0, g1 in zip(res[0][1], res[1][1]):
+        assert torch.equal(g0, g1)
+
+
 # ------------------------------------------------------------------------------------------------ BN + SiLU (ANN blocks)
 @pytest.mark.parametrize('N,C,H,W,train', [(4, 16, 12, 20, True), (4, 16, 12, 20, False), (1, 3, 2, 2, True), (64, 128, 32, 40, True),
                                            # channels that fit one block: the one-launch backward (256 / 512 / 1024 threads, ragged last groups)
@@ -1167,6 +1215,53 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
     for name, got, ref in (('y', y, y64), ('grad_x', xd.grad, x64.grad), ('grad_w', conv.weight.grad, w64.grad)):
         err = (got.detach().double().cpu() - ref.detach()).abs().max().item() / ref.detach().abs().max().item()
         assert err < 1e-5, f'{name}: {err:.2e}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('NI,Cin,Ca,Cb,H,W,k,s,spikes', [(3, 64, 32, 0, 8, 10, 1, 1, False), (2, 128, 64, 64, 16, 20, 1, 1, False), (2, 32, 40, 0, 16, 20, 3, 1, False),
+                                                       (2, 64, 64, 0, 32, 40, 3, 2, False), (64, 256, 128, 128, 8, 10, 3, 1, False), (4, 512, 256, 0, 8, 10, 1, 1, True),
+                                                       (2, 96, 48, 48, 32, 40, 1, 1, False), (2, 24, 48, 0, 16, 160, 3, 1, False), (3, 128, 72, 56, 16, 20, 3, 1, True),
+                                                       (64, 128, 128, 128, 32, 40, 3, 1, False), (64, 256, 64, 64, 32, 40, 1, 1, False), (64, 128, 128, 0, 32, 40, 3, 2, False),
+                                                       (64, 512, 256, 0, 8, 10, 1, 1, False), (64, 128, 128, 0, 16, 20, 1, 1, False)])
+@pytest.mark.parametrize('cat', [False, True])
+def test_fused_real_valued_eval_block_is_bit_identical_to_conv_then_bn_silu(dev, NI, Cin, Ca, Cb, H, W, k, s, spikes, cat):
+    """eas_conv_bn_act_eval (conv -> BatchNorm with running statistics -> SiLU in the epilogue of the 1x1 / 3x3 kernels) against eas_conv_fwd
+    followed by eas_bn_silu_fwd_ex on the same inputs: one BatchNorm or two on consecutive channel ranges of one convolution (also with a
+    range boundary inside a 32-channel tile), outputs standalone or written into the channel range of a wider buffer."""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(NI * 1000 + Cin + Ca + H)
+    x = (torch.randint(0, 3, (NI, Cin, H, W), generator=g).float() if spikes else torch.randn(NI, Cin, H, W, generator=g)).to(dev)
+    if spikes:
+        ops.mark_small_int(x)
+    convs, bns = [], []
+    for Cc in ([Ca, Cb] if Cb else [Ca]):
+        c = nn.Conv2d(Cin, Cc, k, s if not Cb else 1, k // 2, bias=False).to(dev)
+        bn = nn.BatchNorm2d(Cc).to(dev).eval()
+        with torch.no_grad():
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) / (Cin * k * k) ** 0.5)
+            bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5); bn.bias.copy_(torch.randn(Cc, generator=g) * 0.3)
+            bn.running_mean.copy_(torch.randn(Cc, generator=g) * 0.2); bn.running_var.copy_(torch.rand(Cc, generator=g) + 0.3)
+        convs.append(c); bns.append(bn)
+    stride = convs[0].stride[0]
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    with torch.no_grad():
+        conv = tuple(convs) if Cb else convs[0]
+        if spikes:       # tagged small-integer inputs (spikes) keep the two-kernel path: the epilogue exists for real-valued inputs
+            assert not ops.fused_ann_eval_ok(x, conv, bns)
+            return
+        assert ops.fused_ann_eval_ok(x, conv, bns)
+        bufs = [torch.zeros(NI, b.num_features + 24, Ho, Wo, device=dev) for b in bns] if cat else None
+        with ops.kernel_trace() as tr:
+            got = ops.conv_bn_act_eval(x, conv, bns, cats=[(bufs[i], 8) for i in range(len(bns))] if cat else None)
+        assert [n for n, _ in tr.calls if n.startswith('eas_conv')] == ['eas_conv_bn_act_eval'], tr.calls
+        got = got if Cb else [got]
+        for i, (c, bn) in enumerate(zip(convs, bns)):
+            want = ops.bn_silu(ops.conv2d(x, c), bn)
+            assert torch.equal(got[i], want), (i, float((got[i] - want).abs().max()))
+            assert float(want.abs().max()) > 0
+            if cat:      # nothing outside the range was touched
+                assert float(bufs[i][:, :8].abs().max()) == 0 and float(bufs[i][:, 8 + bn.num_features:].abs().max()) == 0
 
 
 FUSED_EVAL_CASES = [  # T, N, Cin, Cout, H, W, k, stride

@@ -844,6 +844,33 @@ def test_fuse_model_eval_forward(dev, name):
     assert frac > 0.97, frac
 
 
+@pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_false_64', 'model_s_true_256x320'])
+def test_eval_forward_with_the_fused_real_valued_blocks_is_bit_identical(dev, monkeypatch, name):
+    """Eval mode: every real-valued BaseConv (the ANN PAFPN neck and head; the whole network of the use_spike=False model) runs
+    conv -> BatchNorm (running statistics) -> SiLU as ONE kernel (eas_conv_bn_act_eval), including the pairs of convolutions that run as
+    one (CSPLayer branches, head towers) and the in-place concatenations -- logits bit-identical to the convolution + eas_bn_silu_fwd_ex
+    path (EAS_FUSED_ANN_EVAL=0), and no BatchNorm + SiLU kernel is left in the trace."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import functional
+    g, model = _build(name, dev)
+    model.eval()
+    x = torch.from_numpy(g['x']).to(dev)
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'FUSED_ANN_EVAL', fused)
+        with torch.no_grad(), ops.kernel_trace() as tr:
+            outs[fused] = model(x).clone()
+        functional.reset_net(model)
+        names = [c[0] for c in tr.calls]
+        if fused:
+            nf = names.count('eas_conv_bn_act_eval')
+            assert nf >= 20 and 'eas_bn_silu_fwd_ex' not in names, (nf, sorted(set(names)))
+        else:
+            assert 'eas_conv_bn_act_eval' not in names and names.count('eas_bn_silu_fwd_ex') >= 20
+    assert torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max())
+    assert float(outs[True].abs().max()) > 0
+
+
 def test_deferred_weight_gradient_reductions_are_bit_identical(dev):
     """ops.deferred_wgrad_reductions(): the slab reductions of all weight gradients of a backward pass in ONE launch at its end
     (eas_conv_wgrad_reduce_many) -- same loss, every parameter gradient bit-identical to the immediate reductions, also on a second
