@@ -88,10 +88,10 @@ class BaseConv(nn.Module):
             return self.bn.fused_with(self.act, y, want_mean=self.emit_rate, residual=residual, cat=cat,
                                       planes=self.wants_planes() and x.dim() == 5)
         assert residual is None
-        if (not self.training and type(self.conv) is nn.Conv2d and isinstance(self.act, nn.SiLU) and getattr(self, 'bn', None) is not None
-                and ops.fused_ann_eval_ok(x, self.conv, [self.bn])):
+        norm = self.eval_norm() if not self.training else None
+        if norm is not None and ops.fused_ann_eval_ok(x, self.conv, [norm]):
             # eval mode: conv -> BN (running statistics) -> SiLU as ONE kernel, the convolution output never reaches HBM
-            return ops.conv_bn_act_eval(x, self.conv, [self.bn], cats=[cat])
+            return ops.conv_bn_act_eval(x, self.conv, [norm], cats=[cat])
         with ops.conv_stats_scope(self.bn.training or self.bn.running_mean is None):
             y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if self.ann_fusable(y):
@@ -102,6 +102,24 @@ class BaseConv(nn.Module):
     def wants_planes(self):
         return self.planes_out and ops.planes_enabled()
 
+    def eval_norm(self):
+        """what follows the convolution of a real-valued conv -> BN -> SiLU block in eval mode: its BatchNorm2d, or -- once ``fuse_model`` has
+        folded that into the convolution -- the convolution's bias; None: not such a block (the fused eval kernel does not apply)"""
+        if not isinstance(self.act, nn.SiLU) or type(self.conv) is not nn.Conv2d:
+            return None
+        bn = getattr(self, 'bn', None)
+        if bn is None:
+            return self.conv.bias
+        return bn if type(bn) is nn.BatchNorm2d and not bn.training else None
+
+    def ann_block_ok(self, probe):
+        """the block can write its output into a channel range of a concatenation buffer: BN + SiLU on the fused HIP kernel (training and
+        eval), or -- eval mode, also after ``fuse_model`` -- the whole block as one kernel"""
+        if self.ann_fusable(probe):
+            return True
+        return (not self.training and not torch.is_grad_enabled() and ops.FUSED_ANN_EVAL and self.eval_norm() is not None
+                and probe.is_cuda and probe.dtype == torch.float32 and probe.dim() == 4)
+
     def ann_fusable(self, y):
         """BN + SiLU of this (real-valued) block run as the fused HIP kernel on ``y`` (then the output can also go straight into a
         concatenation buffer)"""
@@ -109,15 +127,25 @@ class BaseConv(nn.Module):
         return (type(bn) is nn.BatchNorm2d and isinstance(self.act, nn.SiLU) and bn.affine and ops.bn_silu_supported(y)
                 and (bn.momentum is not None or not bn.training))
 
-    def fuseforward(self, x):
+    def fuseforward(self, x, residual=None, cat=None):
         """the forward of a block whose BatchNorm ``fuse_model`` folded into the convolution (network_blocks.py:55-56 of the reference): on the
-        GPU without autograd the activation runs in the convolution's epilogue -- one kernel for the whole block"""
+        GPU without autograd bias and activation run in the convolution's epilogue -- one kernel for the whole block, written straight into
+        the caller's concatenation buffer where there is one (cat = (buffer, first channel))"""
+        assert residual is None
+        out = None
         if type(self.conv) is nn.Conv2d and isinstance(self.act, nn.SiLU) and x.is_cuda and x.dim() == 4 and self.conv.bias is not None:
-            y = ops.conv_act_eval(x, self.conv, 'silu')
-            if y is not None:
-                return y
-            return self.act(ops.conv2d(x, self.conv))
-        return self.act(self.conv(x))
+            if not self.training and ops.fused_ann_eval_ok(x, self.conv, [self.conv.bias]):
+                return ops.conv_bn_act_eval(x, self.conv, [self.conv.bias], cats=[cat])
+            out = ops.conv_act_eval(x, self.conv, 'silu')
+            if out is None:
+                out = self.act(ops.conv2d(x, self.conv))
+        if out is None:
+            out = self.act(self.conv(x))
+        if cat is not None:
+            dst = cat[0].narrow(1, int(cat[1]), out.shape[1])
+            dst.copy_(out)
+            return dst
+        return out
 
 
 class DWConv(nn.Module):
@@ -196,9 +224,9 @@ class CSPLayer(nn.Module):
     def eas_dual_convs(self):
         """conv1 | conv2 read the same input: ``ops.packed_weights`` packs their concatenated weight for ``ops.conv2d_dual``"""
         cs = self._branch_convs()
-        if cs is None or cs[0].kernel_size != (1, 1) or cs[1].kernel_size != (1, 1) or cs[0].bias is not None or cs[1].bias is not None \
+        if cs is None or cs[0].kernel_size != (1, 1) or cs[1].kernel_size != (1, 1) or (cs[0].bias is None) != (cs[1].bias is None) \
                 or cs[0].in_channels != cs[1].in_channels or cs[0].groups != 1 or cs[1].groups != 1:
-            return []
+            return []                   # (biases on both: the pair fuse_model folded, whose eval forward still runs as one convolution)
         return [('c12', cs[0], cs[1])]
 
     def _dual_ok(self):
@@ -274,23 +302,23 @@ class CSPLayer(nn.Module):
             h = self.conv2.conv.out_channels
             buf = torch.empty((N, 2 * h) + tuple(x.shape[-2:]), dtype=torch.float32, device=x.device)
             cs = self._branch_convs()
-            if (cs is not None and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL') and self.conv1.ann_fusable(x[:, :1])
-                    and ops.conv_dual_ok(x, cs[0], cs[1])):
+            dual = cs is not None and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL')
+            norms = [self.conv1.eval_norm(), self.conv2.eval_norm()] if (dual and not self.training) else [None]
+            if None not in norms and ops.fused_ann_eval_ok(x, (cs[0], cs[1]), norms):
+                # eval mode (also after fuse_model): the one convolution for both branches AND their BN + SiLU in one kernel
+                packs = (getattr(self, '_eas_dual_packs', None) or {}).get('c12')
+                a, b = ops.conv_bn_act_eval(x, (cs[0], cs[1]), norms, cats=[None if len(self.m) else (buf, 0), (buf, h)],
+                                            packs=ops.current_packs(packs))
+            elif dual and self.conv1.ann_fusable(x[:, :1]) and ops.conv_dual_ok(x, cs[0], cs[1]):
                 # conv1 and conv2 read the same x: ONE 1x1 convolution (weights packed from the two parameters), then the two BN + SiLU
                 # layers on the channel halves of its output; the input gradient is one convolution, no addition of two branch gradients
                 sink = ops.conv_sink()
                 if sink is not None:
                     sink(cs[0], x, 1)
                     sink(cs[1], x, 1)
-                if not self.training and ops.fused_ann_eval_ok(x, (cs[0], cs[1]), [self.conv1.bn, self.conv2.bn]):
-                    # eval mode: the one convolution for both branches AND their BN + SiLU in one kernel
-                    packs = (getattr(self, '_eas_dual_packs', None) or {}).get('c12')
-                    a, b = ops.conv_bn_act_eval(x, (cs[0], cs[1]), [self.conv1.bn, self.conv2.bn],
-                                                cats=[None if len(self.m) else (buf, 0), (buf, h)], packs=ops.current_packs(packs))
-                else:
-                    with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (self.conv1.bn, self.conv2.bn))):
-                        y12 = ops.conv2d_dual(x, cs[0], cs[1], self, 'c12')
-                    a, b = ops.bn_silu_pair(y12, self.conv1.bn, self.conv2.bn, cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
+                with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (self.conv1.bn, self.conv2.bn))):
+                    y12 = ops.conv2d_dual(x, cs[0], cs[1], self, 'c12')
+                a, b = ops.bn_silu_pair(y12, self.conv1.bn, self.conv2.bn, cat_a=None if len(self.m) else (buf, 0), cat_b=(buf, h))
             else:
                 b = self.conv2(x, cat=(buf, h))
                 a = self.conv1(x, cat=None if len(self.m) else (buf, 0))
@@ -315,7 +343,7 @@ class CSPLayer(nn.Module):
         else:
             tail = last
         probe = x[:, :1]          # shape / dtype probe for bn_silu_supported (same H, W as every output of the layer)
-        return tail.ann_fusable(probe) and self.conv2.ann_fusable(probe) and not tail._forward_hooks and not self.conv2._forward_hooks
+        return tail.ann_block_ok(probe) and self.conv2.ann_block_ok(probe) and not tail._forward_hooks and not self.conv2._forward_hooks
 
 
 class Focus(nn.Module):

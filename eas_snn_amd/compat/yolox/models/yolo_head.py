@@ -101,7 +101,7 @@ class YOLOXHead(nn.Module):
             if not (isinstance(a, BaseConv) and isinstance(b, BaseConv)):
                 continue
             ca, cb = _inner_conv(a), _inner_conv(b)          # plain, or inside the SeqToANNContainer of a converted block
-            if ca is not None and cb is not None and ca.bias is None and cb.bias is None:
+            if ca is not None and cb is not None and (ca.bias is None) == (cb.bias is None):      # (biases on both: the pair fuse_model folded)
                 out.append((f'tower{k}', ca, cb))
         return out
 
@@ -109,21 +109,25 @@ class YOLOXHead(nn.Module):
         """cls_convs[k](x), reg_convs[k](x); their first convolutions as ONE convolution where the kernels allow it (x is read once, one
         input gradient instead of two and an addition, twice the blocks on the small maps)"""
         a, b = self.cls_convs[k][0], self.reg_convs[k][0]
-        if (isinstance(a, BaseConv) and isinstance(b, BaseConv) and not a.spiking() and not b.spiking() and x.dim() == 4
-                and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d and not os.environ.get('EAS_NO_DUAL') and not os.environ.get('EAS_NO_ANN_DUAL')
-                and a.ann_fusable(x[:, :1]) and b.ann_fusable(x[:, :1]) and ops.conv_dual_ok(x, a.conv, b.conv)):
+        ann_pair = (isinstance(a, BaseConv) and isinstance(b, BaseConv) and not a.spiking() and not b.spiking() and x.dim() == 4
+                    and type(a.conv) is nn.Conv2d and type(b.conv) is nn.Conv2d and not os.environ.get('EAS_NO_DUAL')
+                    and not os.environ.get('EAS_NO_ANN_DUAL'))
+        norms = [a.eval_norm(), b.eval_norm()] if (ann_pair and not self.training) else [None]
+        if None not in norms and ops.fused_ann_eval_ok(x, (a.conv, b.conv), norms):
+            # eval mode (also after fuse_model): the one convolution for both towers AND their BN + SiLU in one kernel
+            packs = (getattr(self, '_eas_dual_packs', None) or {}).get(f'tower{k}')
+            ca, ra = ops.conv_bn_act_eval(x, (a.conv, b.conv), norms, packs=ops.current_packs(packs))
+        elif ann_pair and a.ann_fusable(x[:, :1]) and b.ann_fusable(x[:, :1]) and ops.conv_dual_ok(x, a.conv, b.conv):
             sink = ops.conv_sink()
             if sink is not None:
                 sink(a.conv, x, 1)
                 sink(b.conv, x, 1)
-            if not self.training and ops.fused_ann_eval_ok(x, (a.conv, b.conv), [a.bn, b.bn]):
-                # eval mode: the one convolution for both towers AND their BN + SiLU in one kernel
-                packs = (getattr(self, '_eas_dual_packs', None) or {}).get(f'tower{k}')
-                ca, ra = ops.conv_bn_act_eval(x, (a.conv, b.conv), [a.bn, b.bn], packs=ops.current_packs(packs))
-            else:
-                with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (a.bn, b.bn))):
-                    y12 = ops.conv2d_dual(x, a.conv, b.conv, self, f'tower{k}')
-                ca, ra = ops.bn_silu_pair(y12, a.bn, b.bn)
+            with ops.conv_stats_scope(all(bn.training or bn.running_mean is None for bn in (a.bn, b.bn))):
+                y12 = ops.conv2d_dual(x, a.conv, b.conv, self, f'tower{k}')
+            ca, ra = ops.bn_silu_pair(y12, a.bn, b.bn)
+        else:
+            ann_pair = False
+        if ann_pair:
             for m in list(self.cls_convs[k])[1:]:
                 ca = m(ca)
             for m in list(self.reg_convs[k])[1:]:

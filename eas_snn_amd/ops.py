@@ -2323,19 +2323,24 @@ def _ann_eval_bn_ok(bn):
             and bn.num_features % 8 == 0 and not bn._forward_hooks and not bn._forward_pre_hooks)
 
 
-def fused_ann_eval_ok(x, conv, bns):
-    """``conv`` (an nn.Conv2d without bias, or a pair that reads the same input and runs as one) followed by the eval-mode BatchNorm2d
-    modules ``bns`` on consecutive output-channel ranges and SiLU can run as eas_conv_bn_act_eval on ``x`` [NI,Cin,H,W]"""
+def fused_ann_eval_ok(x, conv, norms):
+    """``conv`` (an nn.Conv2d, or a pair that reads the same input and runs as one) followed by ``norms`` on consecutive output-channel
+    ranges and SiLU can run as eas_conv_bn_act_eval on ``x`` [NI,Cin,H,W].  norms[i]: the eval-mode BatchNorm2d behind a bias-free
+    convolution, or -- for a block whose BatchNorm ``fuse_model`` folded into the convolution -- that convolution's bias tensor."""
     if not FUSED_ANN_EVAL or torch.is_grad_enabled() or _CONV_SINK is not None or torch.nn.modules.module._global_forward_hooks:
         return False
     if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
         return False
     convs = conv if isinstance(conv, tuple) else (conv,)
-    if len(convs) != len(bns) or len(convs) > 2 or not all(_ann_eval_bn_ok(bn) for bn in bns):
+    if len(convs) != len(norms) or len(convs) > 2:
         return False
-    for c, bn in zip(convs, bns):
-        if (type(c) is not torch.nn.Conv2d or c.bias is not None or c._forward_hooks or c._forward_pre_hooks or not _static_conv_ok(c)
-                or c.out_channels != bn.num_features):
+    for c, nm in zip(convs, norms):
+        if type(c) is not torch.nn.Conv2d or c._forward_hooks or c._forward_pre_hooks or not _static_conv_ok(c) or c.out_channels % 8:
+            return False
+        if torch.is_tensor(nm):
+            if nm is not c.bias or not nm.is_cuda or nm.dtype != torch.float32:
+                return False
+        elif c.bias is not None or not _ann_eval_bn_ok(nm) or c.out_channels != nm.num_features:
             return False
     c0 = convs[0]
     if len(convs) == 2 and not (convs[1].kernel_size == c0.kernel_size and convs[1].stride == c0.stride == (1, 1)
@@ -2349,10 +2354,23 @@ def fused_ann_eval_ok(x, conv, bns):
     return conv_fwd_supported(x.shape[0], x.shape[1], cout, x.shape[2], x.shape[3], c0.kernel_size[0], c0.stride[0], 3)
 
 
+_UNIT_AFFINE = {}
+
+
+def _unit_affine(C_, device):
+    """(ones, zeros) [C]: the BatchNorm constants that make the epilogue compute acc * 1 + bias (a folded block)"""
+    key = (int(C_), str(device))
+    t = _UNIT_AFFINE.get(key)
+    if t is None:
+        t = _UNIT_AFFINE[key] = (torch.ones(C_, dtype=torch.float32, device=device), torch.zeros(C_, dtype=torch.float32, device=device))
+    return t
+
+
 def conv_bn_act_eval(x, conv, bns, cats=None, packs=None, act='silu'):
     """act(bn(conv(x))) in one kernel (caller checked ``fused_ann_eval_ok``).  conv / bns: one convolution and its BatchNorm, or two that read
-    the same input (``packs``: the packing of their concatenated weight made by ``packed_weights``, or None).  cats[i] = (buffer
-    [NI,Ctot,H,W], first channel) or None.  Returns one tensor per BatchNorm (a view into the buffer where given)."""
+    the same input (``packs``: the packing of their concatenated weight made by ``packed_weights``, or None); a bias tensor in place of a
+    BatchNorm = a block folded by ``fuse_model`` (act(conv(x) + bias)).  cats[i] = (buffer [NI,Ctot,H,W], first channel) or None.  Returns one
+    tensor per range (a view into the buffer where given)."""
     L = _lib.lib()
     convs = conv if isinstance(conv, tuple) else (conv,)
     cats = cats or [None] * len(bns)
@@ -2374,14 +2392,18 @@ def conv_bn_act_eval(x, conv, bns, cats=None, packs=None, act='silu'):
     d.packed_w = ptr(pk)
     d.NI, d.Cin, d.Cout, d.Hi, d.Wi, d.ksize, d.stride = NI, Cin, Cout, H, W, k, stride
     d.act = 1 if act == 'silu' else 0
-    d.csplit = bns[0].num_features
+    d.csplit = convs[0].out_channels
     outs = []
     for i, bn in enumerate(bns):
         r = d.range[i]
-        Cr = bn.num_features
-        invstd = _eval_invstd(bn.running_var, bn.eps)
-        keep.append(invstd)
-        r.gamma, r.beta, r.mean, r.invstd = ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(invstd)
+        Cr = convs[i].out_channels if len(convs) > 1 else Cout
+        if torch.is_tensor(bn):          # folded block: z = fma(acc, 1 * 1, bias - 0 * 1) = acc + bias
+            ones, zeros = _unit_affine(Cr, x.device)
+            r.gamma, r.beta, r.mean, r.invstd = ptr(ones), ptr(bn), ptr(zeros), ptr(ones)
+        else:
+            invstd = _eval_invstd(bn.running_var, bn.eps)
+            keep.append(invstd)
+            r.gamma, r.beta, r.mean, r.invstd = ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(invstd)
         cat = cats[i]
         if cat is not None:
             buf, c0_ = cat[0], int(cat[1])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Host-side cost of enqueueing one eager training step (development tool): wall time of step() without waiting for the GPU,
-and a cProfile of where the host spends it."""
+"""Host-side cost of enqueueing one eager training step (development tool): wall time of step.eager() without waiting for the GPU,
+and a cProfile of where the host spends it.  usage: dev_host.py [config]"""
 import cProfile
 import os
 import pstats
@@ -10,55 +10,49 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-import bench
+import eas_snn_amd  # noqa: F401
+from eas_snn_amd import ops, workloads
 
 
 def main():
+    config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     dev = torch.device('cuda:0')
-    import eas_snn_amd
-    from eas_snn_amd import data, ops
-    from spikingjelly.activation_based import functional
-    from yolox.exp import get_exp
-    eas_snn_amd.hip_library()
+    torch.cuda.set_stream(torch.cuda.Stream())
     ops.set_state_writeback(False)
-    exp = get_exp(None, 'e-yolox-s')
-    exp.merge(bench.OPTS)
-    torch.manual_seed(80)
-    model = exp.get_model().to(dev)
-    model.head.use_l1 = True
-    opt = exp.get_optimizer(64)
-    ev = data.events_to_device(data.synth_event_batch(64, 200_000, *bench.SENSOR, seed=0), dev)
-    targets = data.synth_targets(64, bench.CANVAS, dev)
-
-    def step():
-        frames = data.events_to_frames(ev, exp.Tm, bench.SENSOR, bench.CANVAS)
-        out = model(frames, targets)
-        opt.zero_grad(set_to_none=True)
-        out['total_loss'].backward()
-        opt.step()
-        functional.reset_net(model)
-
+    w = workloads.get(config)
+    trainer, model, step = workloads.build_trainer(w, w['batch'], dev, 200_000, out_dir='/tmp/eas_dev_host')
     for _ in range(4):
-        step()
+        step.eager()
     torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        step()
+        step.eager()
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         ts.append(((t1 - t0) * 1e3, (t2 - t0) * 1e3))
     print('enqueue ms / total ms per step:', [(round(a, 1), round(b, 1)) for a, b in ts])
+    calls = []
+    orig = ops._call
+
+    def counting(name, *a, **k):
+        calls.append(name)
+        return orig(name, *a, **k)
+    ops._call = counting
+    step.eager()
+    ops._call = orig
+    print('C-ABI calls through ops._call in one step:', len(calls))
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(3):
-        step()
+        step.eager()
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats('tottime').print_stats(28)
+    st.sort_stats('cumulative').print_stats(30)
 
 
 if __name__ == '__main__':

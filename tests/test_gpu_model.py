@@ -814,7 +814,7 @@ def test_eval_forward_with_the_fused_step_is_bit_identical(dev, name, monkeypatc
 @pytest.mark.parametrize('name', ['model_s_true_64', 'model_s_false_64', 'model_s_true_256x320'])
 def test_fuse_model_eval_forward(dev, name):
     """``yolox.utils.fuse_model`` (tools/eval_event.py --fuse, model_utils.py:35-80): every real-valued BaseConv's BatchNorm folded into its
-    convolution, which then runs convolution + bias + SiLU as ONE kernel (eas_conv_fwd_act).  Folding rounds the weights once more, so the
+    convolution, which then runs convolution + bias + SiLU as ONE kernel (eas_conv_bn_act_eval with unit constants / eas_conv_fwd_act).  Folding rounds the weights once more, so the
     logits are compared at 1e-5 of the tensor's scale, not bit for bit; the trace shows the activation epilogue took the folded blocks
     and no BatchNorm + SiLU kernel is left."""
     import copy
@@ -832,8 +832,11 @@ def test_fuse_model_eval_forward(dev, name):
         got = fused(x).clone()
     functional.reset_net(fused)
     names = [c[0] for c in tr.calls]
-    nact = names.count('eas_conv_fwd_act')
+    # folded blocks: conv + bias + SiLU as one kernel -- eas_conv_bn_act_eval with unit BatchNorm constants (real-valued inputs; keeps the
+    # convolution pairs and in-place concatenations of the unfused model) or eas_conv_fwd_act (inputs tagged as small integers)
+    nact = names.count('eas_conv_fwd_act') + names.count('eas_conv_bn_act_eval')
     assert nact >= 20 and 'eas_bn_silu_fwd_ex' not in names, (nact, sorted(set(names)))
+    assert names.count('eas_conv_bn_act_eval') >= 15, names.count('eas_conv_bn_act_eval')
     if name == 'model_s_true_256x320':
         # (a rounding-level change in front of the spiking backbone is amplified by spike flips at this size, DESIGN section 5: bulk statistics)
         assert abs(float(got[..., 4].median()) - float(want[..., 4].median())) < 0.05
