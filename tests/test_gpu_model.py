@@ -836,7 +836,8 @@ def test_fuse_model_eval_forward(dev, name):
     # convolution pairs and in-place concatenations of the unfused model) or eas_conv_fwd_act (inputs tagged as small integers)
     nact = names.count('eas_conv_fwd_act') + names.count('eas_conv_bn_act_eval')
     assert nact >= 20 and 'eas_bn_silu_fwd_ex' not in names, (nact, sorted(set(names)))
-    assert names.count('eas_conv_bn_act_eval') >= 15, names.count('eas_conv_bn_act_eval')
+    if ops.FUSED_ANN_EVAL:       # (EAS_FUSED_ANN_EVAL=0, development: eas_conv_fwd_act alone)
+        assert names.count('eas_conv_bn_act_eval') >= 15, names.count('eas_conv_bn_act_eval')
     if name == 'model_s_true_256x320':
         # (a rounding-level change in front of the spiking backbone is amplified by spike flips at this size, DESIGN section 5: bulk statistics)
         assert abs(float(got[..., 4].median()) - float(want[..., 4].median())) < 0.05
