@@ -103,6 +103,7 @@ PROTOTYPES = {
                                     _P, _P, _P, C.c_int, C.c_int64, _P]),
     'eas_reduce_workspace_floats': (C.c_int64, [C.c_int64]),
     'eas_time_mean': (C.c_int, [_P, _P, C.c_int, C.c_int64, _P]),
+    'eas_channel_sum': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     'eas_bn_stats': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     'eas_bn_workspace_doubles': (C.c_int64, [C.c_int]),
     'eas_bn_lif_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_int, _P, _P,

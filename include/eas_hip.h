@@ -174,6 +174,10 @@ int eas_lif_bwd_patan(const float* grad_s, const float* grad_mean, const float* 
 
 /* mean over the leading T axis: [T][M] -> [M] (out_features[f].mean(axis=0)). */
 int eas_time_mean(const float* x, float* out, int T, int64_t M, eas_stream_t stream);
+/* out[c] = sum over (n, pixel) of g[n][c][pixel], g fp32 [N][C][HW]: the bias gradient of a convolution (ATen convolution_backward's
+ * grad_bias, i.e. grad_y.sum((0, 2, 3)); the prediction convolutions of the head, yolo_head.py:60-90, carry biases).  One block per
+ * channel, summed in double in a fixed order: deterministic. */
+int eas_channel_sum(const float* g, float* out, int N, int C, int HW, eas_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4 (BN + LIF half of the fused conv -> BN -> LIF step).  Replaces

@@ -1470,6 +1470,20 @@ def test_conv_on_rows_too_wide_for_one_lds_patch_runs_in_column_parts(dev, NI, C
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,C,H,W', [(64, 4, 32, 40), (64, 1, 8, 10), (3, 100, 7, 9), (2, 5, 1, 1), (64, 2, 16, 20)])
+def test_channel_sum_is_the_bias_gradient(dev, N, C, H, W):
+    """eas_channel_sum (the bias gradient of the head's prediction convolutions, one block per channel) against the fp64 sum; run to run
+    the same bits"""
+    from eas_snn_amd import ops
+    g = (torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(N + C)) * torch.rand(1, C, 1, 1) * 3).to(dev)
+    got = ops.channel_sum(g)
+    want = g.double().sum((0, 2, 3))
+    mag = g.double().abs().sum((0, 2, 3))
+    assert torch.all((got.double() - want).abs() <= 1e-6 * mag + 1e-30)
+    assert torch.equal(got, ops.channel_sum(g))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('Cout,H,W', [(1, 8, 10), (4, 16, 20), (2, 32, 40), (100, 8, 8), (3, 48, 80)])
 def test_prediction_conv_input_gradient_on_own_kernel(dev, Cout, H, W):
     """The 1 / 4 / num_classes-channel 1x1 prediction convolutions of the head: their input gradient is eas_conv_fwd on grad_y with
