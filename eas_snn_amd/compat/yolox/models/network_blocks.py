@@ -96,8 +96,15 @@ class BaseConv(nn.Module):
             y = ops.conv2d(x, self.conv) if type(self.conv) is nn.Conv2d and x.is_cuda else self.conv(x)
         if self.ann_fusable(y):
             return ops.bn_silu(y, self.bn, cat=cat)     # the statistics from the convolution + one fused normalise/SiLU pass (HIP)
-        assert cat is None
-        return self.act(self.bn(y))
+        out = self.act(self.bn(y))
+        if cat is not None:
+            # (eval mode only, ``ann_block_ok``: a layer of the block that neither fused kernel takes -- a statistics tap, a map whose size
+            # the kernels do not cover -- still delivers into the caller's concatenation buffer)
+            assert not torch.is_grad_enabled()
+            dst = cat[0].narrow(1, int(cat[1]), out.shape[1])
+            dst.copy_(out)
+            return dst
+        return out
 
     def wants_planes(self):
         return self.planes_out and ops.planes_enabled()

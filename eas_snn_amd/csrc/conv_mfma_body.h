@@ -233,7 +233,16 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
                 a[set][i][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                                               a_rsrc, a_voff, a_soff[i] + t * a_term_bytes + (unsigned)step * 1024u, 0));
     };
+    // weight fragments in flight ahead of the MFMAs: two steps for spike inputs (a step of a one-term layer is 288-480 MFMA cycles per wave,
+    // less than the ~450-cycle latency of the fragment loads it has to cover; the third register set of the 9-step rotation holds them),
+    // one step otherwise.  Measured, same box: config 3 45.89 / 45.94 -> 45.76 / 45.83 ms (its convolution family 22.2 -> 22.0 ms),
+    // config 2 unchanged.  -DEAS_CONV_APF=1: one step everywhere (development).
+#ifndef EAS_CONV_APF
+#define EAS_CONV_APF 2
+#endif
+    constexpr int APF = (EAS_CONV_APF == 2 && XT == 1 && NSETS == 3) ? 2 : 1;
     load_a(0, 0);
+    if constexpr (APF == 2) load_a(1, steps_total > 1 ? 1 : 0);
 
     // loads are unconditional: a row outside the image or a channel group past Cin (Cin % 8 == 0: a group is valid or not as
     // a whole) reads the zero page with channel stride 0, so nothing branches, waits or needs masking around them
@@ -292,8 +301,9 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         for (int s = 0; s < NSTEPS; ++s) {
             const int kk = s / TAPS, tap = s - kk * TAPS;
             ++st;
-            const int stn = (g.dbg & 4) ? 0 : (st < steps_total ? st : steps_total - 1);   // prefetch next step's weights (clamped at the end)
-            load_a((s + 1) % NSETS, stn);
+            const int sta = st + APF - 1;
+            const int stn = (g.dbg & 4) ? 0 : (sta < steps_total ? sta : steps_total - 1);   // prefetch the weights APF steps ahead (clamped at the end)
+            load_a((s + APF) % NSETS, stn);
             if (more) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
