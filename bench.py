@@ -38,7 +38,7 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same
 # command, scripts/gpu_profile.sh; gfx950 corrections applied by scripts/pmc_summary.py).  C-ABI entry -> device kernels.
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')      # config 2; other configurations: pmc_traffic_latest_config<N>.json
-PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel', 'bn_lif_fwd_sp_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
+PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel', 'bn_lif_bwd_small_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel', 'bn_lif_fwd_sp_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
                'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
                'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel'],
                'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel', 'arsnn_fused_step_fwd_kernel'],

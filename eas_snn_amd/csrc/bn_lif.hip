@@ -467,6 +467,157 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_kernel(
     }
 }
 
+// One pass for the layers whose channel fits the registers of one block (8x10 maps at batch 64: 1280 float4 groups per channel and time
+// step): one block per channel keeps y and grad_s of the channel in registers, sums dz and dz * xhat over the block (fixed order), and
+// applies the BatchNorm backward from the registers -- 12 B per neuron-step instead of 20 and one real launch instead of two of ~17 us
+// each (these layers are bound by the launches, not by their 30 MB).  Per element the arithmetic of the two-pass kernels; the per-channel
+// dL/dk / dL/dalpha partials go to the same workspace slots (chunk 0) and a one-block kernel adds them over the channels in fixed order.
+// (first half.)
+template <int T_, bool HARD, bool DI, bool STRICT, int NT_, int GPT>
+__global__ __launch_bounds__(NT_) void bn_lif_bwd_small_kernel(
+    const float* __restrict__ grad_s, const float* __restrict__ grad_mean, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ v_init, EasLifParams p, int sg_id, float alpha,
+    int batch_stats, double* __restrict__ part, float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+    float* __restrict__ grad_beta, int N, int C, int HW, int gs_ctot, int y_ctot, const float* __restrict__ alpha_dev) {
+    constexpr int NWV = NT_ / EAS_WAVE;
+    __shared__ double red[4][NWV];
+    __shared__ float bc[2];
+    if (alpha_dev) alpha = fabsf(*alpha_dev);
+    const int c = blockIdx.x;
+    const float mu = mean[c], istd = invstd[c];
+    const float scale = gamma[c] * istd;
+    const float shift = beta[c] - mu * scale;
+    const float k = eas_lif_k(p);
+    const float omk = 1.0f - k;
+    const bool detach = (p.flags & EAS_LIF_DETACH_RESET) != 0;
+    const int hw4 = HW / VEC;
+    const int groups = N * hw4;
+    const int64_t M = (int64_t)N * C * HW;
+    const int Cy = y_ctot ? y_ctot : C;
+    const int64_t My = (int64_t)N * Cy * HW;
+    const int64_t Mg = gs_ctot ? (int64_t)N * gs_ctot * HW : M;
+    const float invT = 1.0f / (float)T_;
+    float4 ys[GPT][T_], gsv[GPT][T_], v0[GPT];
+    int64_t ybase[GPT];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const int g = threadIdx.x + i * NT_;
+        const int gg = g < groups ? g : groups - 1;          // surplus threads re-read the last group (their results are not used)
+        const int n = gg / hw4, q = gg - n * hw4;
+        const int64_t base = ((int64_t)n * C + c) * (int64_t)HW + (int64_t)q * VEC;
+        ybase[i] = ((int64_t)n * Cy + c) * (int64_t)HW + (int64_t)q * VEC;
+#pragma unroll
+        for (int t = 0; t < T_; ++t) ys[i][t] = *reinterpret_cast<const float4*>(y + (int64_t)t * My + ybase[i]);
+        float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grad_mean) {
+            gm = *reinterpret_cast<const float4*>(grad_mean + base);
+            gm.x *= invT; gm.y *= invT; gm.z *= invT; gm.w *= invT;
+        }
+#pragma unroll
+        for (int t = 0; t < T_; ++t) {
+            gsv[i][t] = gm;
+            if (grad_s) {
+                const int64_t gbase = gs_ctot ? ((int64_t)n * gs_ctot + c) * (int64_t)HW + (int64_t)q * VEC : base;
+                const float4 g4 = *reinterpret_cast<const float4*>(grad_s + (int64_t)t * Mg + gbase);
+                gsv[i][t].x += g4.x; gsv[i][t].y += g4.y; gsv[i][t].z += g4.z; gsv[i][t].w += g4.w;
+            }
+        }
+        const float vr0 = HARD ? p.v_reset : 0.0f;
+        v0[i] = make_float4(vr0, vr0, vr0, vr0);
+        if (v_init) v0[i] = *reinterpret_cast<const float4*>(v_init + base);
+    }
+    // pass 1 (registers): the channel's sums
+    float s1 = 0.f, s2 = 0.f, dk = 0.f, da = 0.f;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        const bool live = threadIdx.x + i * NT_ < groups;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float yv[T_], gs[T_], dz[T_];
+#pragma unroll
+            for (int t = 0; t < T_; ++t) {
+                yv[t] = reinterpret_cast<const float*>(&ys[i][t])[e];
+                gs[t] = reinterpret_cast<const float*>(&gsv[i][t])[e];
+            }
+            float dke = 0.f, dae = 0.f;
+            recompute_dz<T_, HARD, DI, STRICT>(yv, gs, reinterpret_cast<const float*>(&v0[i])[e], scale, shift, k, omk, p, detach, sg_id, alpha, dz, dke, dae);
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < T_; ++t) {
+                    s1 += dz[t];
+                    s2 += dz[t] * ((yv[t] - mu) * istd);
+                }
+                dk += dke;
+                da += dae;
+            }
+        }
+    }
+    double t1 = eas_wave_sum((double)s1), t2 = eas_wave_sum((double)s2), t3 = eas_wave_sum((double)dk), t4 = eas_wave_sum((double)da);
+    if ((threadIdx.x & (EAS_WAVE - 1)) == 0) {
+        const int w = threadIdx.x / EAS_WAVE;
+        red[0][w] = t1; red[1][w] = t2; red[2][w] = t3; red[3][w] = t4;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t1 = t2 = t3 = t4 = 0.0;
+        for (int w = 0; w < NWV; ++w) { t1 += red[0][w]; t2 += red[1][w]; t3 += red[2][w]; t4 += red[3][w]; }
+        const double cnt = (double)T_ * N * HW;
+        bc[0] = (float)(t1 / cnt);
+        bc[1] = (float)(t2 / cnt);
+        grad_beta[c] = (float)t1;
+        grad_gamma[c] = (float)t2;
+        double* o = part + ((int64_t)c * kMaxChunks) * 4;      // chunk 0 of the two-pass layout: read by bn_lif_bwd_scalars_kernel
+        o[0] = t1; o[1] = t2; o[2] = t3; o[3] = sg_id == EAS_SG_PATAN ? t4 : 0.0;
+    }
+    __syncthreads();
+    const float m1 = batch_stats ? bc[0] : 0.f, m2 = batch_stats ? bc[1] : 0.f;
+    // pass 2 (registers): the neuron again, grad_y
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+        if (threadIdx.x + i * NT_ >= groups) continue;
+        float4 outv[T_];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float yv[T_], gs[T_], dz[T_];
+#pragma unroll
+            for (int t = 0; t < T_; ++t) {
+                yv[t] = reinterpret_cast<const float*>(&ys[i][t])[e];
+                gs[t] = reinterpret_cast<const float*>(&gsv[i][t])[e];
+            }
+            float dke = 0.f, dae = 0.f;
+            recompute_dz<T_, HARD, DI, STRICT>(yv, gs, reinterpret_cast<const float*>(&v0[i])[e], scale, shift, k, omk, p, detach, sg_id, alpha, dz, dke, dae);
+#pragma unroll
+            for (int t = 0; t < T_; ++t) reinterpret_cast<float*>(&outv[t])[e] = scale * (dz[t] - m1 - ((yv[t] - mu) * istd) * m2);
+        }
+#pragma unroll
+        for (int t = 0; t < T_; ++t) *reinterpret_cast<float4*>(grad_y + (int64_t)t * My + ybase[i]) = outv[t];
+    }
+}
+
+// dL/dw of the scalar PLIF decay and dL/dalpha of a learnable surrogate slope from the per-channel partials of bn_lif_bwd_small_kernel
+// (slot 2 / 3 of chunk 0), added over the channels in fixed order by one block -- what the apply pass of the two-pass form does at its end
+__global__ __launch_bounds__(EAS_BLOCK) void bn_lif_bwd_scalars_kernel(const double* __restrict__ part, int C, EasLifParams p, float* __restrict__ grad_w,
+                                                                       const float* __restrict__ alpha_dev, float* __restrict__ grad_alpha) {
+    __shared__ double red[NW];
+    const float k = eas_lif_k(p);
+    if (grad_w) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < C; i += blockDim.x) acc += part[((int64_t)i * kMaxChunks) * 4 + 2];
+        const double tot = eas_block_sum<double, NW>(acc, red);
+        if (threadIdx.x == 0) *grad_w = (float)tot * (k * (1.0f - k));
+    }
+    if (grad_alpha) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < C; i += blockDim.x) acc += part[((int64_t)i * kMaxChunks) * 4 + 3];
+        const double tot = eas_block_sum<double, NW>(acc, red);
+        if (threadIdx.x == 0) {
+            const float a = *alpha_dev;
+            *grad_alpha = (float)tot * (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f));
+        }
+    }
+}
+
 template <int T_, bool HARD, bool DI, bool STRICT>
 int launch_fwd_t(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                  const float* v_in, float* v_out, EasLifParams p, float* spikes, float* mean_out, int N, int C, int HW,
@@ -517,6 +668,27 @@ int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, co
                  int batch_stats, float* grad_y, float* grad_gamma, float* grad_beta, float* grad_w, double* ws, int N,
                  int C, int HW, int bcast, int gs_ctot, int y_ctot, const float* alpha_dev, float* grad_alpha, hipStream_t st) {
     const int chunks = pick_chunks((int64_t)N * (HW / VEC), C);
+    {
+        // one block per channel where a channel fits the registers of a block (bn_lif_bwd_small_kernel); EAS_BNLIF_BWD=two keeps the
+        // two-pass launches (development)
+        const char* form = getenv("EAS_BNLIF_BWD");      // (read per call: a test compares the two forms in one process)
+        const bool small_ok = !(form && form[0] == 't');
+        constexpr int GPT = T_ <= 3 ? 3 : (T_ <= 5 ? 2 : 1);         // 8 * T floats per group in registers
+        const int64_t groups = (int64_t)N * (HW / VEC);
+        if (small_ok && !bcast && C >= 64 && groups <= 512 * GPT) {       // (1024-thread blocks are capped at 128 registers: they spill)
+#define EAS_SMALL(NT_) EAS_LAUNCH((bn_lif_bwd_small_kernel<T_, HARD, DI, STRICT, NT_, GPT>), dim3(C), dim3(NT_), 0, st, grad_s, grad_mean, y, mean, \
+                                   invstd, gamma, beta, v_init, p, sg, alpha, batch_stats, ws, grad_y, grad_gamma, grad_beta, N, C, HW, gs_ctot, y_ctot, alpha_dev)
+            if (groups <= 256 * GPT) EAS_SMALL(256);
+            else EAS_SMALL(512);
+#undef EAS_SMALL
+            EAS_CHECK_LAUNCH();
+            if (grad_w || grad_alpha) {
+                EAS_LAUNCH(bn_lif_bwd_scalars_kernel, dim3(1), dim3(EAS_BLOCK), 0, st, ws, C, p, grad_w, alpha_dev, grad_alpha);
+                EAS_CHECK_LAUNCH();
+            }
+            return EAS_OK;
+        }
+    }
     // two passes: the BatchNorm backward needs the channel's sums of dz and dz * xhat before any grad_y; pass 2 recomputes the neuron
     // (cheaper than parking dz: measured).
     // Channel groups (EAS_BNLIF_BWD_GROUP_MB, development; 0 = one pair of launches for the whole layer): the pair runs group by group with

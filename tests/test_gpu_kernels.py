@@ -668,7 +668,10 @@ def test_cpu_tensor_raises(dev):
 
 # ------------------------------------------------------------------------------------------------ K4 BN + LIF
 @pytest.mark.parametrize('T,N,C,H,W,train', [(3, 2, 8, 12, 16, True), (3, 2, 8, 12, 16, False), (5, 1, 5, 6, 10, True),
-                                              (1, 3, 4, 4, 4, True), (8, 1, 3, 2, 2, True)])
+                                              (1, 3, 4, 4, 4, True), (8, 1, 3, 2, 2, True),
+                                              # channels that fit the registers of one block: the one-pass backward (256 / 512 threads, ragged last groups)
+                                              (3, 8, 64, 8, 10, True), (3, 64, 64, 8, 10, True), (5, 32, 96, 8, 10, True), (7, 4, 64, 6, 8, True), (7, 32, 64, 6, 8, True),
+                                              (3, 5, 72, 4, 20, False)])
 def test_bn_lif_fused_vs_oracle(dev, T, N, C, H, W, train):
     from oracle import sj_ref
     from spikingjelly.activation_based import layer, neuron, surrogate
@@ -715,6 +718,35 @@ def test_bn_lif_fused_vs_oracle(dev, T, N, C, H, W, train):
     np.testing.assert_allclose(hbn.running_mean.cpu().numpy(), rbn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(hbn.running_var.cpu().numpy(), rbn.running_var.numpy(), rtol=1e-5, atol=1e-6)
     assert int(hbn.num_batches_tracked) == int(rbn.num_batches_tracked)
+
+
+@pytest.mark.parametrize('T,N,C,H,W', [(3, 64, 64, 8, 10), (3, 7, 128, 8, 10), (5, 32, 64, 8, 10), (7, 3, 64, 6, 8)])
+def test_bn_lif_backward_one_pass_form_equals_the_two_pass_form(dev, monkeypatch, T, N, C, H, W):
+    """eas_bn_lif_bwd for channels that fit one block's registers (one block per channel, sums and apply from the registers;
+    EAS_BNLIF_BWD=two: the two-pass launches) -- grad_y, the BatchNorm parameter gradients and dL/dw agree to summation-order rounding,
+    and the one-pass form repeats bit for bit."""
+    from spikingjelly.activation_based import layer, neuron, surrogate
+    g = torch.Generator().manual_seed(T * 10 + N)
+    y = (torch.randn(T, N, C, H, W, generator=g) * 1.5 + 0.3).to(dev)
+    go = torch.randn(T, N, C, H, W, generator=g).to(dev)
+    res = {}
+    for form in ('two', 'one', 'one'):
+        monkeypatch.setenv('EAS_BNLIF_BWD', form)
+        bn = layer.BatchNorm2d(C, eps=1e-3, momentum=0.03, step_mode='m').to(dev).train()
+        node = neuron.ParametricLIFNode(init_tau=2.0, decay_input=False, v_reset=None, surrogate_function=surrogate.ATan(2.0), step_mode='m').to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.8, 1.6, C)); bn.bias.copy_(torch.linspace(-0.1, 0.6, C))
+        yy = y.clone().requires_grad_(True)
+        s = bn.fused_with(node, yy)
+        s.backward(go)
+        out = (yy.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), node.w.grad.clone())
+        if form == 'one' and 'one' in res:
+            assert all(torch.equal(a, b) for a, b in zip(out, res['one']))
+        res[form] = out
+    scale = float(res['two'][0].abs().max())
+    assert float((res['one'][0] - res['two'][0]).abs().max()) <= 2e-5 * scale
+    for a, b in zip(res['one'][1:], res['two'][1:]):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize('NI,C,H,W', [(1, 8, 2, 2), (6, 64, 16, 20), (3, 200, 8, 12), (2, 32, 5, 8)])
