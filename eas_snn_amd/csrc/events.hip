@@ -448,9 +448,25 @@ __global__ __launch_bounds__(kBandThreads) void event_hist_banded16_kernel(const
             // this pass's rows with their right padding; the last pass of the last band also writes the bottom padding rows
             const bool last = band == nbands - 1 && pass == npass - 1;
             const int yend = last ? Hc : yb;
+            const bool quads = packed && (W & 3) == 0 && (Wc & 3) == 0 && (plane & 3) == 0 && ((uintptr_t)canvas & 15) == 0;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 float* dst = canvas + ((((int64_t)b * Tm + k) * 2 + c) * Hc + ya) * Wc;
+                if (quads) {
+                    // four columns per thread: one 8-byte LDS read of four packed counters, one 16-byte store
+                    const int q4 = Wc / 4, total4 = (yend - ya) * q4;
+                    const unsigned short* c16 = reinterpret_cast<const unsigned short*>(cnt) + c * plane;
+                    for (int i = tid; i < total4; i += kBandThreads) {
+                        const int r = i / q4, col = (i - r * q4) * 4;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (r < yb - ya && col < W) {
+                            const uint2 w = *reinterpret_cast<const uint2*>(c16 + r * W + col);
+                            v = make_float4((float)(w.x & 0xffffu), (float)(w.x >> 16), (float)(w.y & 0xffffu), (float)(w.y >> 16));
+                        }
+                        *reinterpret_cast<float4*>(dst + (int64_t)r * Wc + col) = v;
+                    }
+                    continue;
+                }
                 const int total = (yend - ya) * Wc;
                 for (int i = tid; i < total; i += kBandThreads) {
                     const int r = i / Wc, col = i - r * Wc;
@@ -462,6 +478,15 @@ __global__ __launch_bounds__(kBandThreads) void event_hist_banded16_kernel(const
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 int32_t* dst = out + ((((int64_t)b * Tm + k) * 2 + c) * H + ya) * W;
+                if (packed && (n & 3) == 0 && (plane & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+                    // the band's rows are contiguous in the output as in LDS: four packed counters per 8-byte read, one 16-byte store
+                    const unsigned short* c16 = reinterpret_cast<const unsigned short*>(cnt) + c * plane;
+                    for (int i = tid; i < n / 4; i += kBandThreads) {
+                        const uint2 w = *reinterpret_cast<const uint2*>(c16 + 4 * i);
+                        reinterpret_cast<int4*>(dst)[i] = make_int4((int)(w.x & 0xffffu), (int)(w.x >> 16), (int)(w.y & 0xffffu), (int)(w.y >> 16));
+                    }
+                    continue;
+                }
                 for (int i = tid; i < n; i += kBandThreads) {
                     const int r = i / W, col = i - r * W;
                     dst[i] = count_at(c, r, col);
