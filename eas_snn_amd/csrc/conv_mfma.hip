@@ -140,6 +140,45 @@ __global__ void conv_pack_weights_many_kernel(const long long* __restrict__ jobs
     }
 }
 
+// The same with the work spread evenly: the launch above gives every job the same 24 blocks, so the largest tensors (dark5: 2.4 M weights,
+// two orders) set its duration while the blocks of the ~200 small ones have long finished (103 us for SYOLOX-S against ~25 us of traffic).
+// Here a block takes 256-lane units from ONE list over all jobs: every block builds the jobs' unit prefix in LDS (<= 1024 jobs) and finds
+// the job of a unit by binary search.
+constexpr int kPackJobsMax = 1024;
+__global__ __launch_bounds__(256) void conv_pack_weights_flat_kernel(const long long* __restrict__ jobs, int njobs) {
+    __shared__ int pref[kPackJobsMax + 1];
+    for (int j = threadIdx.x; j < njobs; j += blockDim.x) {
+        const long long* q = jobs + (size_t)j * 8;
+        pref[j + 1] = (pack_total((int)q[2], (int)q[3], (int)q[4], (int)q[5]) + 255) / 256;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pref[0] = 0;
+        for (int j = 0; j < njobs; ++j) pref[j + 1] += pref[j];
+    }
+    __syncthreads();
+    const int units = pref[njobs];
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        int lo = 0, hi = njobs;                       // the job with pref[j] <= u < pref[j + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pref[mid] <= u) lo = mid; else hi = mid;
+        }
+        const long long* q = jobs + (size_t)lo * 8;
+        const float* w = (const float*)q[0];
+        bf16x8* wp = (bf16x8*)q[1];
+        const int Cout = (int)q[2], Cin = (int)q[3], ksize = (int)q[4], mode = (int)q[5];
+        const float* wb = (const float*)q[6];
+        const int ca = (int)q[7];
+        const int total = pack_total(Cout, Cin, ksize, mode);
+        const int idx = (u - pref[lo]) * 256 + (int)threadIdx.x;
+        if (idx < total) {
+            if (mode == 2) pack_fragment_s2dgrad(w, wp, Cout, Cin, idx);
+            else pack_fragment(w, wp, Cout, Cin, ksize * ksize, mode, idx, total, wb, ca);
+        }
+    }
+}
+
 // Input gradient of a stride-2 3x3 convolution in ONE launch: blockIdx.z = parity class of the input pixel, every class a stride-1
 // tap-list convolution over grad_y with its own tap count (1, 2, 2, 4), channel chunk (64, 32, 32, 16: four MFMA steps per chunk
 // each), weights and tile geometry -- the four class kernels used to be four launches, each leaving most CUs idle on the small
@@ -222,7 +261,11 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream) {
     if (!jobs || njobs < 1) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    EAS_LAUNCH(conv_pack_weights_many_kernel, dim3(24, njobs), dim3(EAS_BLOCK), 0, eas_s(stream), (const long long*)jobs);
+    static const bool flat = !(getenv("EAS_PACK_FORM") && getenv("EAS_PACK_FORM")[0] == 'j');      // EAS_PACK_FORM=jobs: 24 blocks per job (development)
+    if (flat && njobs <= kPackJobsMax)
+        EAS_LAUNCH(conv_pack_weights_flat_kernel, dim3(2048), dim3(256), 0, eas_s(stream), (const long long*)jobs, njobs);
+    else
+        EAS_LAUNCH(conv_pack_weights_many_kernel, dim3(24, njobs), dim3(EAS_BLOCK), 0, eas_s(stream), (const long long*)jobs);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }
