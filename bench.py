@@ -40,7 +40,7 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')      # config 2; other configurations: pmc_traffic_latest_config<N>.json
 PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel', 'bn_lif_bwd_small_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel', 'bn_lif_fwd_sp_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
                'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
-               'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel'],
+               'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel', 'event_hist_banded16_kernel'],
                'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel', 'arsnn_fused_step_fwd_kernel'],
                'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel', 'smallconv_wgrad_mfma_kernel'],
                'eas_conv_fwd': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel', 'conv1x1_mfma_sharedA_kernel', 'conv_dgrad_s2_kernel',
@@ -414,6 +414,20 @@ def main():
         step.eager()
     torch.cuda.synchronize()
     ops.set_timer(None)
+    # The first kernel of a step (raw input -> frames: K1 / the stacked-histogram reduction) starts on an idle queue in those eager steps,
+    # so its event pair also spans the host's submission latency (128 us recorded for a 65 us kernel).  Re-timed back to back: eleven calls,
+    # the first dropped, scaled to the three steps the other entries cover.
+    if rank == 0:
+        t_in = ops.KernelTimer()
+        ops.set_timer(t_in)
+        for _ in range(11):
+            step.inputs_fn()
+        torch.cuda.synchronize()
+        ops.set_timer(None)
+        for name, items in t_in.rec.items():
+            if name in timer.rec and len(items) == 11 and len(timer.rec[name]) == timed_steps:
+                timer.rec[name] = items[4:4 + timed_steps]           # calls from the middle of the run: the queue is full
+                timer.input_retimed = name
     # inference side figure: eval-mode forward + reset_net of the same batch (no loss, no backward), replayed as a HIP graph like the
     # evaluator does (yolox/evaluators/event_evaluator.py), for the model as trained and after yolox.utils.fuse_model (tools/eval_event.py --fuse)
     eval_fps = None
@@ -466,7 +480,8 @@ def main():
                                     'scripts/gpu_profile.sh; configs 2 and 3), not re-measured in this run',
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
-                  'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'}
+                  'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'
+                                   + (f'; {timer.input_retimed} (the first kernel of a step, which starts on an idle queue there) re-timed in ten back-to-back calls' if getattr(timer, 'input_retimed', None) else '')}
         if d['flops'] > 0:
             # dense convolutions: bounded by the matrix cores.  achieved = algorithmic flops (2 x MAC of the fp32 convolution) per
             # second against the dense f32 MFMA peak (the arithmetic the path reproduces); every fp32 product is formed from
