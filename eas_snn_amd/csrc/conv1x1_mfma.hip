@@ -344,12 +344,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
         const int mt = (mt0 + m) < g.MT ? (mt0 + m) : g.MT - 1;
         asrc[it] = wp + t * a_term + (size_t)mt * g.KSTEPS * 64 + (q & 63);
     }
-    bf16x8 areg[NLD];
-    auto a_fetch = [&](int ks) {
+    // two register sets: the fragments of k-step s + 2 are requested while step s multiplies and are written to LDS a whole step later --
+    // with one set the commit waited for the load issued just before the step's few MFMAs (WM * WN * 3 or 6 of them: 200-800 cycles
+    // against an L2 / HBM round trip), i.e. every k-step of these many-channel, few-pixel layers ended in an exposed load latency
+    bf16x8 areg0[NLD], areg1[NLD];
+    auto a_fetch = [&](bf16x8 (&areg)[NLD], int ks) {
+        const int kc = ks < g.KSTEPS ? ks : g.KSTEPS - 1;
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) areg[it] = asrc[it][(size_t)ks * 64];
+        for (int it = 0; it < NLD; ++it) areg[it] = asrc[it][(size_t)kc * 64];
     };
-    auto a_commit = [&](int buf) {
+    auto a_commit = [&](const bf16x8 (&areg)[NLD], int buf) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int q = it * 256 + tid;
@@ -424,47 +428,49 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
                     for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][ta], raw[n], acc[m][n], 0, 0, 0);
         };
         bf16x8 q0[WN], q1[WN];
-        a_fetch(0);
+        a_fetch(areg0, 0);
         p_fetch(q0, 0);
-        a_commit(0);
+        a_commit(areg0, 0);
+        a_fetch(areg1, 1);
         __syncthreads();
         int ks = 0;
         for (; ks + 1 < g.KSTEPS; ks += 2) {
-            a_fetch(ks + 1);
+            a_fetch(areg0, ks + 2);
             p_fetch(q1, ks + 1);
             __builtin_amdgcn_sched_barrier(0);
             p_step(q0, 0);
-            a_commit(1);
+            a_commit(areg1, 1);                          // step ks + 1 (requested a whole step ago)
             __syncthreads();
             const int kn = ks + 2 < g.KSTEPS ? ks + 2 : ks + 1;
-            a_fetch(kn);
+            a_fetch(areg1, ks + 3);
             p_fetch(q0, kn);
             __builtin_amdgcn_sched_barrier(0);
             p_step(q1, 1);
-            a_commit(0);
+            a_commit(areg0, 0);                          // step ks + 2
             __syncthreads();
         }
         if (ks < g.KSTEPS) p_step(q0, 0);
     } else {
     TIN r0[WN][8], r1[WN][8];
-    a_fetch(0);
+    a_fetch(areg0, 0);
     x_fetch(r0, 0);
-    a_commit(0);
+    a_commit(areg0, 0);
+    a_fetch(areg1, 1);
     __syncthreads();
     int ks = 0;
     for (; ks + 1 < g.KSTEPS; ks += 2) {
-        a_fetch(ks + 1);
+        a_fetch(areg0, ks + 2);
         x_fetch(r1, ks + 1);
         __builtin_amdgcn_sched_barrier(0);
         step(r0, 0);
-        a_commit(1);
+        a_commit(areg1, 1);                              // step ks + 1 (requested a whole step ago)
         __syncthreads();
         const int kn = ks + 2 < g.KSTEPS ? ks + 2 : ks + 1;
-        a_fetch(kn);
+        a_fetch(areg1, ks + 3);
         x_fetch(r0, kn);
         __builtin_amdgcn_sched_barrier(0);
         step(r1, 1);
-        a_commit(0);
+        a_commit(areg0, 0);                              // step ks + 2
         __syncthreads();
     }
     if (ks < g.KSTEPS) step(r0, 0);
