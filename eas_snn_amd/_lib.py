@@ -61,8 +61,40 @@ class EasConvBnActEval(C.Structure):
                 ('range', EasBnActRange * 2)]
 
 
+class EasConvProblem(C.Structure):
+    """include/eas_hip.h EasConvProblem: one convolution of a grouped launch"""
+    _fields_ = [('x', C.c_void_p), ('packed_w', C.c_void_p), ('bias', C.c_void_p), ('y', C.c_void_p), ('stats', C.c_void_p),
+                ('NI', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('Hi', C.c_int), ('Wi', C.c_int), ('accumulate', C.c_int)]
+
+
+class EasBnSiluFwdProblem(C.Structure):
+    """include/eas_hip.h EasBnSiluFwdProblem"""
+    _fields_ = [('y', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('out', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('HW', C.c_int), ('out_ctot', C.c_int), ('y_ctot', C.c_int),
+                ('pending', EasBnPending)]
+
+
+class EasBnSiluBwdProblem(C.Structure):
+    """include/eas_hip.h EasBnSiluBwdProblem"""
+    _fields_ = [('grad_out', C.c_void_p), ('y', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('grad_y', C.c_void_p), ('grad_gamma', C.c_void_p), ('grad_beta', C.c_void_p),
+                ('workspace', C.c_void_p), ('batch_stats', C.c_int), ('N', C.c_int), ('C', C.c_int), ('HW', C.c_int),
+                ('grad_out_ctot', C.c_int), ('y_ctot', C.c_int)]
+
+
+class EasWgradProblem(C.Structure):
+    """include/eas_hip.h EasWgradProblem"""
+    _fields_ = [('x', C.c_void_p), ('grad_y', C.c_void_p), ('workspace', C.c_void_p), ('NI', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int),
+                ('Hi', C.c_int), ('Wi', C.c_int)]
+
+
+class EasChannelSumProblem(C.Structure):
+    """include/eas_hip.h EasChannelSumProblem"""
+    _fields_ = [('g', C.c_void_p), ('out', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('HW', C.c_int)]
+
+
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
@@ -157,6 +189,13 @@ PROTOTYPES = {
     'eas_spp_pool_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_planes_fwd': (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
     'eas_spp_pool_planes_bwd': (C.c_int, [_P, _P, _P, C.c_int64] + [C.c_int] * 6 + [_P]),
+    'eas_conv_fwd_group_plan': (C.c_int, [C.POINTER(EasConvProblem), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'eas_conv_fwd_group': (C.c_int, [C.POINTER(EasConvProblem), C.c_int, C.c_int, C.c_int, _P]),
+    'eas_bn_silu_fwd_group': (C.c_int, [C.POINTER(EasBnSiluFwdProblem), C.c_int, _P]),
+    'eas_bn_silu_bwd_group': (C.c_int, [C.POINTER(EasBnSiluBwdProblem), C.c_int, _P]),
+    'eas_conv_wgrad_group_plan': (C.c_int, [C.POINTER(EasWgradProblem), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'eas_conv_wgrad_group_partial': (C.c_int, [C.POINTER(EasWgradProblem), C.c_int, C.c_int, C.c_int, _P]),
+    'eas_channel_sum_group': (C.c_int, [C.POINTER(EasChannelSumProblem), C.c_int, _P]),
 }
 
 

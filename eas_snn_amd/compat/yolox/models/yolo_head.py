@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from eas_snn_amd import ops
+from eas_snn_amd import ops_group as G
 from yolox.utils.utils_snn import convert_to_spiking
 
 from .losses import IOUloss
@@ -168,10 +169,73 @@ class YOLOXHead(nn.Module):
     def _prepare(self, x):
         return x
 
+    def _levels_grouped(self, xs):
+        """The raw predictions of ALL levels, stage by stage: the levels are independent until the loss (the reference walks them one after
+        the other, yolo_head.py:149-200), so every stage -- stems, the first tower convolutions (cls | reg as one), the second ones, the
+        prediction convolutions, each with its BatchNorm + SiLU -- runs as ONE grouped launch over the levels (``ops_group``): the 16x20 and
+        8x10 levels ride in the grid of the 32x40 level instead of leaving most of the chip idle in launches of their own, forward and
+        backward.  Training mode of the real-valued head; None = not eligible (the per-level path runs)."""
+        n = len(xs)
+        if not (G.ENABLED and self.training and not self.full_spike and 1 < n <= 4 and torch.is_grad_enabled()):
+            return None
+        blocks = []
+        for k in range(n):
+            cc, rc = self.cls_convs[k], self.reg_convs[k]
+            if len(cc) != 2 or len(rc) != 2:
+                return None
+            blocks.append((self.stems[k], cc[0], rc[0], cc[1], rc[1]))
+        for row in blocks:
+            for b in row:
+                if not (isinstance(b, BaseConv) and not b.spiking() and type(b.conv) is nn.Conv2d and isinstance(b.act, nn.SiLU)
+                        and not b._forward_hooks and not b._forward_pre_hooks and not b.bn._forward_hooks and not b.bn._forward_pre_hooks):
+                    return None
+        stems = [r[0] for r in blocks]
+        if not (G.conv_group_ok(xs, [b.conv for b in stems], 1) and G.bn_silu_group_ok(xs, [b.bn for b in stems])):
+            return None
+        pairs = [(r[1].conv, r[2].conv) for r in blocks]
+        if not self._group_geometry_ok(xs, blocks, pairs):
+            return None
+        # ---- stage 1: stems
+        ys, st = G.conv_group(xs, [b.conv for b in stems], 1, True)
+        s = G.bn_silu_group(ys, st, [(i, 0, b.bn) for i, b in enumerate(stems)])
+        # ---- stage 2: first cls | reg tower convolutions of every level as one convolution each (they read the same stem output)
+        ys, st = G.conv_group(s, pairs, 3, True, owners=[(self, f'tower{k}') for k in range(n)])
+        layers = []
+        for k, r in enumerate(blocks):
+            layers += [(k, 0, r[1].bn), (k, r[1].conv.out_channels, r[2].bn)]
+        o = G.bn_silu_group(ys, st, layers)
+        ca, ra = o[0::2], o[1::2]
+        # ---- stage 3: second tower convolutions, 2 n problems
+        convs2 = [r[3].conv for r in blocks] + [r[4].conv for r in blocks]
+        ys, st = G.conv_group(ca + ra, convs2, 3, True)
+        f = G.bn_silu_group(ys, st, [(i, 0, b.bn) for i, b in enumerate([r[3] for r in blocks] + [r[4] for r in blocks])])
+        cf, rf = f[:n], f[n:]
+        # ---- stage 4: prediction convolutions, 3 n problems
+        cls_o, reg_o, obj_o = G.pred_group(cf, rf, list(self.cls_preds), list(self.reg_preds), list(self.obj_preds))
+        return [(reg_o[k], obj_o[k], cls_o[k]) for k in range(n)]
+
+    def _group_geometry_ok(self, xs, blocks, pairs):
+        """every later stage of ``_levels_grouped`` has a grouped tile plan (cached per input geometry; the stems keep H x W, so the stages'
+        inputs are known by shape before they exist)"""
+        key = tuple(tuple(x.shape) for x in xs)
+        cache = self.__dict__.setdefault('_eas_group_ok', {})
+        if key not in cache:
+            n = len(xs)
+            hs = [G.ShapeProbe((x.shape[0], r[0].conv.out_channels) + tuple(x.shape[2:])) for x, r in zip(xs, blocks)]
+            ok = G.conv_group_ok(hs, pairs, 3)
+            ok = ok and G.conv_group_ok(hs + hs, [r[3].conv for r in blocks] + [r[4].conv for r in blocks], 3)
+            ok = ok and G.pred_group_ok(hs, hs, list(self.cls_preds), list(self.reg_preds), list(self.obj_preds))
+            ok = ok and G.bn_silu_group_ok(hs * 4, [b.bn for r in blocks for b in r[1:]])
+            cache[key] = bool(ok) and n == len(blocks)
+        return cache[key]
+
     def forward(self, xin, labels=None, imgs=None):
         outputs, origin_preds, grids, strides = [], [], [], []
         if self.training and self.fused_loss and self.fused_assign:
-            raws = [self._level(k, self._prepare(x)) for k, x in enumerate(xin)]
+            feats = [self._prepare(x) for x in xin]
+            raws = self._levels_grouped(feats)
+            if raws is None:
+                raws = [self._level(k, x) for k, x in enumerate(feats)]
             regs, objs, clss = [r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws]
             if ops.det_loss_supported(regs, labels, self.iou_loss.loss_type):
                 # decode + assignment + loss terms + their gradient in five launches (ops.det_loss)

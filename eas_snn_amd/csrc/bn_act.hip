@@ -29,15 +29,14 @@ __device__ __forceinline__ float silu_grad(float z) {
     return sg * (1.0f + z * (1.0f - sg));
 }
 
-__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd,
-                                                                const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float* __restrict__ out, int N,
-                                                                int C, int HW, BnFin fin, int out_ctot, int y_ctot) {
+// c / chunk / nchunks_g: the block's channel, its chunk of the channel's float4 groups and the chunks per channel (from blockIdx of a
+// launch of one layer; a grouped launch -- bn_silu_fwd_group_kernel -- maps its flat grid onto (layer, channel, chunk) first)
+__device__ __forceinline__ void bn_silu_fwd_body(const float* __restrict__ y, const float* __restrict__ mean,
+                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* __restrict__ out, int N, int C, int HW, const BnFin& fin,
+                                                 int out_ctot, int y_ctot, const int c, const int chunk, const int nchunks_g) {
     __shared__ float st[2];
-    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
     if (c >= C) return;
-    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const int hw4 = HW / VEC;
     const int64_t groups = (int64_t)N * hw4;
     float mu, istd;
@@ -62,18 +61,27 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __r
     }
 }
 
+__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ out, int N,
+                                                                int C, int HW, BnFin fin, int out_ctot, int y_ctot) {
+    // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    bn_silu_fwd_body(y, mean, invstd, gamma, beta, out, N, C, HW, fin, out_ctot, y_ctot, (int)(blockIdx.z * 8 + blockIdx.x), (int)blockIdx.y,
+                     (int)gridDim.y);
+}
+
 template <bool APPLY>
-__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __restrict__ grad_out, const float* __restrict__ y,
-                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int batch_stats, double* __restrict__ part, int nchunks,
-                                                                float* __restrict__ grad_y, float* __restrict__ grad_gamma,
-                                                                float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot, int y_ctot) {
+__device__ __forceinline__ void bn_silu_bwd_body(const float* __restrict__ grad_out, const float* __restrict__ y,
+                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 int batch_stats, double* __restrict__ part, int nchunks,
+                                                 float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+                                                 float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot, int y_ctot, const int c,
+                                                 const int chunk, const int nchunks_g) {
     __shared__ double red[NW];
     __shared__ float bc[2];
-    const int c = blockIdx.z * 8 + blockIdx.x;      // EAS_CHAN_GRID: the chunks of a channel share an XCD
     if (c >= C) return;
-    const int chunk = blockIdx.y, nchunks_g = gridDim.y;
     const float mu = mean[c], istd = invstd[c];
     const float scale = gamma[c] * istd;
     const float shift = beta[c] - mu * scale;
@@ -135,6 +143,74 @@ __global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __r
             part[((int64_t)c * kMaxChunks + chunk) * 2 + 1] = t2;
         }
     }
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_kernel(const float* __restrict__ grad_out, const float* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int batch_stats, double* __restrict__ part, int nchunks,
+                                                                float* __restrict__ grad_y, float* __restrict__ grad_gamma,
+                                                                float* __restrict__ grad_beta, int N, int C, int HW, int go_ctot, int y_ctot) {
+    // EAS_CHAN_GRID: the chunks of a channel share an XCD
+    bn_silu_bwd_body<APPLY>(grad_out, y, mean, invstd, gamma, beta, batch_stats, part, nchunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot,
+                            y_ctot, (int)(blockIdx.z * 8 + blockIdx.x), (int)blockIdx.y, (int)gridDim.y);
+}
+
+// ---- grouped launches (include/eas_hip.h eas_bn_silu_fwd_group / eas_bn_silu_bwd_group): layer p owns blocks [first[p], first[p + 1]) of
+// the flat grid, 8 * chunks[p] * ceil(C / 8) of them in the order of EAS_CHAN_GRID (channel-in-octet fastest, then chunk, then octet)
+constexpr int kMaxBnGroup = 12;
+struct BnSiluFwdGroup {
+    const float* y[kMaxBnGroup];
+    const float* mean[kMaxBnGroup];
+    const float* invstd[kMaxBnGroup];
+    const float* gamma[kMaxBnGroup];
+    const float* beta[kMaxBnGroup];
+    float* out[kMaxBnGroup];
+    BnFin fin[kMaxBnGroup];
+    int N[kMaxBnGroup], C[kMaxBnGroup], HW[kMaxBnGroup], out_ctot[kMaxBnGroup], y_ctot[kMaxBnGroup], chunks[kMaxBnGroup];
+    int first[kMaxBnGroup + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_fwd_group_kernel(const BnSiluFwdGroup a) {
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int lb = (int)blockIdx.x - a.first[p];
+    const int r = lb >> 3, chunk = r % a.chunks[p], c = (r / a.chunks[p]) * 8 + (lb & 7);
+    bn_silu_fwd_body(a.y[p], a.mean[p], a.invstd[p], a.gamma[p], a.beta[p], a.out[p], a.N[p], a.C[p], a.HW[p], a.fin[p], a.out_ctot[p],
+                     a.y_ctot[p], c, chunk, a.chunks[p]);
+}
+
+struct BnSiluBwdGroup {
+    const float* grad_out[kMaxBnGroup];
+    const float* y[kMaxBnGroup];
+    const float* mean[kMaxBnGroup];
+    const float* invstd[kMaxBnGroup];
+    const float* gamma[kMaxBnGroup];
+    const float* beta[kMaxBnGroup];
+    double* part[kMaxBnGroup];
+    float* grad_y[kMaxBnGroup];
+    float* grad_gamma[kMaxBnGroup];
+    float* grad_beta[kMaxBnGroup];
+    int batch_stats[kMaxBnGroup], N[kMaxBnGroup], C[kMaxBnGroup], HW[kMaxBnGroup], go_ctot[kMaxBnGroup], y_ctot[kMaxBnGroup], chunks[kMaxBnGroup];
+    int first[kMaxBnGroup + 1];
+    int n;
+};
+
+template <bool APPLY>
+__global__ __launch_bounds__(EAS_BLOCK) void bn_silu_bwd_group_kernel(const BnSiluBwdGroup a) {
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int lb = (int)blockIdx.x - a.first[p];
+    const int r = lb >> 3, chunk = r % a.chunks[p], c = (r / a.chunks[p]) * 8 + (lb & 7);
+    bn_silu_bwd_body<APPLY>(a.grad_out[p], a.y[p], a.mean[p], a.invstd[p], a.gamma[p], a.beta[p], a.batch_stats[p], a.part[p], a.chunks[p],
+                            a.grad_y[p], a.grad_gamma[p], a.grad_beta[p], a.N[p], a.C[p], a.HW[p], a.go_ctot[p], a.y_ctot[p], c, chunk,
+                            a.chunks[p]);
 }
 
 // Small maps (the 8x10 / 16x20 levels of neck and head: a channel's N*HW values fit the registers of ONE block): both passes in one
@@ -282,6 +358,77 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
     EAS_CHECK_LAUNCH();
     EAS_LAUNCH(bn_silu_bwd_kernel<true>, EAS_CHAN_GRID(chunks, C), dim3(EAS_BLOCK), 0, st, grad_out, y, mean, invstd, gamma, beta,
                        batch_stats, workspace, chunks, grad_y, grad_gamma, grad_beta, N, C, HW, go_ctot, y_ctot);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_bn_silu_fwd_group(const EasBnSiluFwdProblem* pr, int n, eas_stream_t stream) {
+    if (!pr || n < 1) return EAS_ERR_INVALID_ARG;
+    if (n > kMaxBnGroup) return EAS_ERR_UNSUPPORTED;
+    BnSiluFwdGroup a{};
+    int blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        const EasBnSiluFwdProblem& q = pr[p];
+        int out_ctot = q.out_ctot, y_ctot = q.y_ctot;
+        if (!q.y || !q.mean || !q.invstd || !q.gamma || !q.beta || !q.out || q.N < 1 || q.C < 1 || q.HW < 1 || (out_ctot != 0 && out_ctot < q.C) ||
+            (y_ctot != 0 && y_ctot < q.C))
+            return EAS_ERR_INVALID_ARG;
+        if (out_ctot == q.C) out_ctot = 0;
+        if (y_ctot == q.C) y_ctot = 0;
+        if (q.HW % VEC != 0 || q.C > 65535) return EAS_ERR_UNSUPPORTED;
+        if (((uintptr_t)q.y | (uintptr_t)q.out) & 15) return EAS_ERR_INVALID_ARG;
+        BnFin fin{};
+        const EasBnPending* pend = &q.pending;
+        if (pend->partial) {
+            if (pend->chunks < 1 || pend->chunks > (pend->pitch ? pend->pitch : kMaxChunks) || pend->pitch < 0 || !(pend->count >= 1.0) || pend->replicas < 1) return EAS_ERR_INVALID_ARG;
+            if ((pend->running_mean == nullptr) != (pend->running_var == nullptr)) return EAS_ERR_INVALID_ARG;
+            fin.part = pend->partial; fin.nchunks = pend->chunks; fin.pitch = pend->pitch ? pend->pitch : kMaxChunks; fin.replicas = pend->replicas; fin.count = pend->count;
+            fin.eps = pend->eps; fin.momentum = pend->momentum; fin.mean_out = q.mean; fin.invstd_out = q.invstd;
+            fin.rmean = pend->running_mean; fin.rvar = pend->running_var;
+        }
+        a.y[p] = q.y; a.mean[p] = q.mean; a.invstd[p] = q.invstd; a.gamma[p] = q.gamma; a.beta[p] = q.beta; a.out[p] = q.out;
+        a.fin[p] = fin;
+        a.N[p] = q.N; a.C[p] = q.C; a.HW[p] = q.HW; a.out_ctot[p] = out_ctot; a.y_ctot[p] = y_ctot;
+        a.chunks[p] = pick_chunks((int64_t)q.N * (q.HW / VEC), q.C);
+        a.first[p] = blocks;
+        blocks += 8 * a.chunks[p] * ((q.C + 7) / 8);
+    }
+    a.first[n] = blocks;
+    a.n = n;
+    EAS_CLEAR_ERR();
+    EAS_LAUNCH(bn_silu_fwd_group_kernel, dim3(blocks), dim3(EAS_BLOCK), 0, eas_s(stream), a);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_bn_silu_bwd_group(const EasBnSiluBwdProblem* pr, int n, eas_stream_t stream) {
+    if (!pr || n < 1) return EAS_ERR_INVALID_ARG;
+    if (n > kMaxBnGroup) return EAS_ERR_UNSUPPORTED;
+    BnSiluBwdGroup a{};
+    int blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        const EasBnSiluBwdProblem& q = pr[p];
+        int go_ctot = q.grad_out_ctot, y_ctot = q.y_ctot;
+        if (!q.grad_out || !q.y || !q.mean || !q.invstd || !q.gamma || !q.beta || !q.grad_y || !q.grad_gamma || !q.grad_beta || !q.workspace ||
+            q.N < 1 || q.C < 1 || q.HW < 1 || (go_ctot != 0 && go_ctot < q.C) || (y_ctot != 0 && y_ctot < q.C))
+            return EAS_ERR_INVALID_ARG;
+        if (go_ctot == q.C) go_ctot = 0;
+        if (y_ctot == q.C) y_ctot = 0;
+        if (q.HW % VEC != 0 || q.C > 65535) return EAS_ERR_UNSUPPORTED;
+        if (((uintptr_t)q.y | (uintptr_t)q.grad_out | (uintptr_t)q.grad_y) & 15) return EAS_ERR_INVALID_ARG;
+        a.grad_out[p] = q.grad_out; a.y[p] = q.y; a.mean[p] = q.mean; a.invstd[p] = q.invstd; a.gamma[p] = q.gamma; a.beta[p] = q.beta;
+        a.part[p] = q.workspace; a.grad_y[p] = q.grad_y; a.grad_gamma[p] = q.grad_gamma; a.grad_beta[p] = q.grad_beta;
+        a.batch_stats[p] = q.batch_stats; a.N[p] = q.N; a.C[p] = q.C; a.HW[p] = q.HW; a.go_ctot[p] = go_ctot; a.y_ctot[p] = y_ctot;
+        a.chunks[p] = pick_chunks((int64_t)q.N * (q.HW / VEC), q.C);
+        a.first[p] = blocks;
+        blocks += 8 * a.chunks[p] * ((q.C + 7) / 8);
+    }
+    a.first[n] = blocks;
+    a.n = n;
+    EAS_CLEAR_ERR();
+    EAS_LAUNCH(bn_silu_bwd_group_kernel<false>, dim3(blocks), dim3(EAS_BLOCK), 0, eas_s(stream), a);
+    EAS_CHECK_LAUNCH();
+    EAS_LAUNCH(bn_silu_bwd_group_kernel<true>, dim3(blocks), dim3(EAS_BLOCK), 0, eas_s(stream), a);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -21,23 +21,27 @@ __device__ __attribute__((aligned(32))) float eas_c1_zero_page[8] = {0.f, 0.f, 0
 // pixel blocks (grid.x) of the last launch / geometry query of this thread: the statistics partials per channel
 thread_local int tl_c1_blocks = 0;
 
-struct C1Geom {
+// C1GeomCore: what the plain tiles read (the grouped launch carries up to twelve by value); C1Geom adds the fused eval epilogues' descriptors
+struct C1GeomCore {
     int NI, Cin, Cout, HW;
     int tiles_per_img, total_tiles;   // 32-pixel tiles
     int MT, KSTEPS;
     double* stats;                    // BatchNorm statistics in the epilogue (eas_conv_fwd_stats): [Cout][stats_nb][2], stats_nb = gridDim.x
     int stats_nb;
     int* inexact;                     // x_terms == 1 on fp32 input: OR-ed with 1 when a value is not exact in bf16 (NULL: not reported)
+    int act;                          // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act)
+    int accum;                        // y += conv(x) + bias instead of y = (grouped launches: the second reader's input gradient, EasConvProblem.accumulate)
+};
+struct C1Geom : C1GeomCore {
     // fused eval step conv -> BatchNorm (running statistics) -> LIF over T (kernel template LM = 1, conv_lif_epi.h): NI = samples N, total_tiles
     // counts SPATIAL 32-pixel tiles, pixel tile n of a wave = time step n (WN == lif.T): image n * N + sample
     EasLifEpiDev lif;
-    int act;                          // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act)
     EasBnActEpiDev bna;               // BatchNorm (running statistics) + activation in the plain epilogue (eas_conv_bn_act_eval); on = 0: plain store
 };
 
 // statistics epilogue of the 1x1 kernels: 4 waves of a block = 4 pixel groups of the same WM * 32 channels
-template <int WM, int WN, typename ACC>
-__device__ __forceinline__ void c1_stats(const ACC (&acc)[WM][WN], const long (&yoff)[WN], double* red, const C1Geom& g, int mt0) {
+template <int WM, int WN, typename ACC, typename G>
+__device__ __forceinline__ void c1_stats(const ACC (&acc)[WM][WN], const long (&yoff)[WN], double* red, const G& g, int mt0, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool valid[WN];
 #pragma unroll
@@ -45,7 +49,7 @@ __device__ __forceinline__ void c1_stats(const ACC (&acc)[WM][WN], const long (&
     eas_conv_stats_wave<WM, WN>(acc, valid, reinterpret_cast<float*>(red + 4 * WM * 64) + wave * EAS_STATS_SCRATCH, red + wave * (WM * 64), lane);
     __syncthreads();
     if ((int)threadIdx.x < WM * 32)
-        eas_conv_stats_store(red, WM * 64, 4, (int)threadIdx.x, mt0 * 32 + (int)threadIdx.x, g.Cout, g.stats, g.stats_nb, (int)blockIdx.x);
+        eas_conv_stats_store(red, WM * 64, 4, (int)threadIdx.x, mt0 * 32 + (int)threadIdx.x, g.Cout, g.stats, g.stats_nb, bx);
 }
 
 template <int XT, typename TIN = float>
@@ -71,9 +75,11 @@ __device__ __forceinline__ void to_terms(const TIN (&v)[8], bf16x8 (&b)[XT]) {
 // grad_y): channel validity is then tested per channel instead of per 8-channel group.
 // PL: x is given as spike planes (bf16 [NI][Cin/8][HW][8], one exact term): a lane's 8 channels of its pixel are ONE 16-byte load and
 // already the MFMA operand -- no conversion, an eighth of the load instructions, half the bytes.
-template <int XT, int WM, int WN, bool RAGK = false, bool PL = false, int LM = 0>
-__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
-                                                              const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
+// bx / by: the block's pixel-block and channel-group index (blockIdx.x / .y of a launch of one problem; a grouped launch maps its
+// flat grid onto (problem, block) first -- conv1x1_group_kernel)
+template <int XT, int WM, int WN, bool RAGK, bool PL, int LM, typename G>
+__device__ __forceinline__ void c1_body(const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
+                                        float* __restrict__ y, const G& g, const int bx, const int by) {
     static_assert(!PL || (XT == 1 && !RAGK), "spike planes are one exact bf16 term in whole 8-channel groups");
     static_assert(LM == 0 || LM == 1 || LM == 3, "1x1: plain, time-major fused neuron epilogue, or BatchNorm + activation epilogue");
     constexpr bool TM = LM == 1;
@@ -81,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int mt0 = blockIdx.y * WM;
-    const int tile0 = (blockIdx.x * 4 + wave) * (TM ? 1 : WN);
+    const int mt0 = by * WM;
+    const int tile0 = (bx * 4 + wave) * (TM ? 1 : WN);
     if (tile0 >= g.total_tiles && !g.stats) return;      // with statistics every wave reaches the block reduction (its lanes hold no pixel)
 
     // per-lane pixel of each N-tile
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 
     if (g.stats) {
         __shared__ __align__(16) double red[4 * WM * 64 + 2 * EAS_STATS_SCRATCH];      // [wave][WM * 32][2] doubles, then the waves' float patches
-        c1_stats<WM, WN>(acc, yoff, red, g, mt0);
+        c1_stats<WM, WN>(acc, yoff, red, g, mt0, bx);
     }
 
     if constexpr (LM == 1) {
@@ -270,6 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
         for (int n = 0; n < WN; ++n) {
             if (yoff[n] < 0) continue;
             float* yp = y + yoff[n] + (long)co0 * g.HW;
+            if (g.accum) {        // block-uniform: y += (the second reader of a tensor adds its input gradient to the first one's)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (full || co0 + (e & 3) + 8 * (e >> 2) < g.Cout) yp[(long)((e & 3) + 8 * (e >> 2)) * g.HW] += acc[m][n][e] + bv[e];
+                continue;
+            }
             if (g.act) {          // block-uniform: the activation's transcendental never runs for the plain convolution
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
@@ -284,6 +296,34 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
             }
         }
     }
+}
+
+template <int XT, int WM, int WN, bool RAGK = false, bool PL = false, int LM = 0>
+__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __restrict__ x, const bf16x8* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ y, C1Geom g) {
+    c1_body<XT, WM, WN, RAGK, PL, LM, C1Geom>(x, wp, bias, y, g, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Grouped launch (include/eas_hip.h eas_conv_fwd_group, ksize 1): problem p owns pixel blocks [first[p], first[p + 1]) of grid.x
+constexpr int kMaxGroup1 = 12;
+struct C1GroupArgs {
+    C1GeomCore g[kMaxGroup1];
+    const float* x[kMaxGroup1];
+    const bf16x8* wp[kMaxGroup1];
+    const float* bias[kMaxGroup1];
+    float* y[kMaxGroup1];
+    int first[kMaxGroup1 + 1];
+    int n;
+};
+
+template <int XT, int WM, int WN, bool RAGK>
+__global__ __launch_bounds__(256, 2) void conv1x1_group_kernel(const C1GroupArgs a) {
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    if ((int)blockIdx.y * WM >= a.g[p].MT) return;        // grid.y covers the widest problem
+    c1_body<XT, WM, WN, RAGK, false, 0, C1GeomCore>(a.x[p], a.wp[p], a.bias[p], a.y[p], a.g[p], (int)blockIdx.x - a.first[p], (int)blockIdx.y);
 }
 
 // Variant for layers with many input channels and few pixels (dark5: 256..1024 channels on 15 360 pixels).  There the direct
@@ -482,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_sharedA_kernel(const floa
 
     if (g.stats) {
         __shared__ __align__(16) double red[4 * WM * 64 + 2 * EAS_STATS_SCRATCH];      // [wave][WM * 32][2] doubles, then the waves' float patches
-        c1_stats<WM, WN>(acc, yoff, red, g, mt0);
+        c1_stats<WM, WN>(acc, yoff, red, g, mt0, (int)blockIdx.x);
     }
 
     if constexpr (LM == 1) {
@@ -691,6 +731,67 @@ int eas_conv1x1_lif_dispatch(const void* x, const void* packed_w, const EasLifEp
     return wm == 2 ? launch_c1_lif<2, 5, false>(xf, wp, g, st, query) : launch_c1_lif<1, 5, false>(xf, wp, g, st, query);
 }
 
+// Grouped 1x1 launch (eas_conv_fwd_group, conv_group.hip): one wave-tile shape for all problems -- channel tiles per wave from the
+// narrowest problem (a wave of a wider shape would multiply clamped duplicates), pixel tiles per wave from the group's total block count
+// (the ~2 blocks per CU rule of the single launch).  The direct kernel only (the block-shared weight fragments of the >= 256-channel
+// layers are a different block shape; in a group those layers are the small riders).
+namespace {
+template <int XT, int WM, int WN, bool RAGK>
+int launch_c1_group(const C1GroupArgs& a, int grid_y, hipStream_t st) {
+    EAS_LAUNCH((conv1x1_group_kernel<XT, WM, WN, RAGK>), dim3(a.first[a.n], grid_y), dim3(256), 0, st, a);
+    return EAS_OK;
+}
+}  // namespace
+
+int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t st, int* nb_out, bool query) {
+    if (n > kMaxGroup1 || x_terms != 3) return EAS_ERR_UNSUPPORTED;
+    C1GroupArgs a{};
+    bool ragk = false;
+    int mt_min = 1 << 30, mt_max = 0;
+    for (int p = 0; p < n; ++p) {
+        C1GeomCore& g = a.g[p];
+        const EasConvProblem& q = pr[p];
+        g.NI = q.NI; g.Cin = q.Cin; g.Cout = q.Cout; g.HW = q.Hi * q.Wi;
+        g.tiles_per_img = (g.HW + 31) / 32;
+        g.total_tiles = q.NI * g.tiles_per_img;
+        g.MT = (q.Cout + 31) / 32;
+        g.KSTEPS = (q.Cin + 15) / 16;
+        g.stats = q.stats;
+        g.accum = q.accumulate ? 1 : 0;
+        if (q.stats && q.accumulate) return EAS_ERR_INVALID_ARG;
+        ragk = ragk || q.Cin % 8 != 0;
+        mt_min = g.MT < mt_min ? g.MT : mt_min;
+        mt_max = g.MT > mt_max ? g.MT : mt_max;
+        a.x[p] = (const float*)q.x; a.wp[p] = (const bf16x8*)q.packed_w; a.bias[p] = q.bias; a.y[p] = q.y;
+    }
+    auto blocks = [&](int m, int w) {
+        long b = 0;
+        for (int p = 0; p < n; ++p) b += (long)((a.g[p].total_tiles + 4 * w - 1) / (4 * w)) * ((a.g[p].MT + m - 1) / m);
+        return b;
+    };
+    int wm = mt_min >= 4 ? 4 : (mt_min >= 2 ? 2 : 1), wn = ragk ? 1 : 2;
+    if (blocks(wm, wn) < 512) wn = 1;
+    while (blocks(wm, wn) < 512 && wm > 1) wm >>= 1;
+    if (wm == 2 && wn == 2) wn = 1;          // instantiated shapes: (4,2) (4,1) (2,1) (1,1); ragged input channels: (4,1) (1,1)
+    if (wm == 1) wn = 1;
+    if (ragk && wm == 2) wm = 1;
+    int bx = 0;
+    for (int p = 0; p < n; ++p) {
+        a.first[p] = bx;
+        const int gxp = (a.g[p].total_tiles + 4 * wn - 1) / (4 * wn);
+        a.g[p].stats_nb = gxp;
+        if (nb_out) nb_out[p] = gxp;
+        bx += gxp;
+    }
+    a.first[n] = bx;
+    a.n = n;
+    if (query) return EAS_OK;
+    const int gy = (mt_max + wm - 1) / wm;
+    if (ragk) return wm == 4 ? launch_c1_group<3, 4, 1, true>(a, gy, st) : launch_c1_group<3, 1, 1, true>(a, gy, st);
+    if (wm == 4) return wn == 2 ? launch_c1_group<3, 4, 2, false>(a, gy, st) : launch_c1_group<3, 4, 1, false>(a, gy, st);
+    return wm == 2 ? launch_c1_group<3, 2, 1, false>(a, gy, st) : launch_c1_group<3, 1, 1, false>(a, gy, st);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient of a 1x1 convolution: dW[co][ci] = sum_{n,p} gy[n][co][p] * x[n][ci][p]   (reduction index = pixel).
 // The block stages a [channels] x [KC pixels] slab of grad_y and x with coalesced 16-byte loads (consecutive lanes = consecutive
@@ -722,9 +823,11 @@ __device__ __forceinline__ bf16x8 w1_tr_frag(const unsigned char* p0, const unsi
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int XT, int WVM, int WVN, int NT, int KS, bool XPL = false>
-__global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __restrict__ x_, const float* __restrict__ gy,
-                                                                float* __restrict__ slabs, W1Geom g) {
+// bx / by: the block's pixel slice (and slab) and its (co, ci) block -- blockIdx.x / .y of a launch of one layer, or what the grouped
+// launch (conv1x1_wgrad_group_kernel) derives from its flat grid
+template <int XT, int WVM, int WVN, int NT, int KS, bool XPL>
+__device__ __forceinline__ void conv1x1_wgrad_body(const void* __restrict__ x_, const float* __restrict__ gy, float* __restrict__ slabs,
+                                                   const W1Geom& g, unsigned char* smem, const int bx, const int by) {
     static_assert(!XPL || XT == 1, "spike planes are one exact bf16 term");
     const float* x = reinterpret_cast<const float*>(x_);
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(x_);
@@ -739,11 +842,10 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __re
     constexpr int ITEMS_B = XPL ? (RB / 8) * KC : RB * V4R;             // planes: (8-channel group, pixel) pairs of 16 bytes
     constexpr int ITEMS = ITEMS_A + ITEMS_B;
     constexpr int NIT = (ITEMS + 255) / 256;
-    extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WVN, wn = wave % WVN;
-    const int cob = blockIdx.y / g.ci_blocks, cib = blockIdx.y - cob * g.ci_blocks;
+    const int cob = by / g.ci_blocks, cib = by - cob * g.ci_blocks;
     const int co0 = cob * RA, ci0 = cib * RB;
 
     // staging items: [0, ITEMS_A) grad_y (channel row, float4 index); then x -- fp32: (channel row, float4 index); planes: (group, pixel)
@@ -779,7 +881,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __re
 
     const int chunks_img = g.HW / KC;
     const int total_chunks = g.NI * chunks_img;
-    const int c_begin = blockIdx.x * g.per_slice;
+    const int c_begin = bx * g.per_slice;
     const int c_end = c_begin + g.per_slice < total_chunks ? c_begin + g.per_slice : total_chunks;
 
     f32x4 L[NIT];
@@ -883,7 +985,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __re
     }
 
     // partial sums of this block -> slab [slice][co][ci]; D: col = ci = lane&31, row = co = (e&3) + 8*(e>>2) + 4*h
-    float* slab = slabs + (size_t)blockIdx.x * g.Cout * g.Cin;
+    float* slab = slabs + (size_t)bx * g.Cout * g.Cin;
     const int row0 = co0 + wm * 32 + 4 * h;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -894,6 +996,38 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __re
         for (int e = 0; e < 16; ++e)
             if (row0 + (e & 3) + 8 * (e >> 2) < g.Cout) sp[(size_t)((e & 3) + 8 * (e >> 2)) * g.Cin] = acc[n][e];
     }
+}
+
+template <int XT, int WVM, int WVN, int NT, int KS, bool XPL = false>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __restrict__ x_, const float* __restrict__ gy,
+                                                                float* __restrict__ slabs, W1Geom g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    conv1x1_wgrad_body<XT, WVM, WVN, NT, KS, XPL>(x_, gy, slabs, g, smem, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Grouped launch (eas_conv_wgrad_group_partial, ksize 1): layer p owns blocks [first[p], first[p + 1]) of the flat grid, slices[p] x
+// (co, ci) blocks, slice fastest.  16-pixel chunks (KS = 1) so that every map with HW % 16 == 0 fits the one instance.
+constexpr int kMaxW1Group = 12;
+struct W1GroupArgs {
+    W1Geom g[kMaxW1Group];
+    const void* x[kMaxW1Group];
+    const float* gy[kMaxW1Group];
+    float* slabs[kMaxW1Group];
+    int slices[kMaxW1Group];
+    int first[kMaxW1Group + 1];
+    int n;
+};
+
+template <int XT, int WVM, int WVN, int NT>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_group_kernel(const W1GroupArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int lb = (int)blockIdx.x - a.first[p];
+    const int by = lb / a.slices[p], bx = lb - by * a.slices[p];
+    conv1x1_wgrad_body<XT, WVM, WVN, NT, 1, false>(a.x[p], a.gy[p], a.slabs[p], a.g[p], smem, bx, by);
 }
 
 struct W1Plan { int wvm, wvn, nt, ks, slices; };
@@ -992,4 +1126,76 @@ int eas_conv1x1_wgrad_dispatch(const void* x, const float* gy, float* slabs, int
     return x_terms == 1 ? EAS_W1_SHAPE(1, false) : EAS_W1_SHAPE(3, false);
 #undef EAS_W1_SHAPE
 #undef EAS_W1
+}
+
+// the slab kernels of several 1x1 layers as one grid: one block shape (all layers on the same side of the 32 / 64 output-channel
+// bounds), a common number of 16-pixel chunks per block (see group_tau in conv_wgrad_mfma.hip: same rule)
+namespace {
+template <int WVM, int WVN, int NT>
+int launch_w1_group(const W1GroupArgs& a, int blocks, hipStream_t st, int* res_out) {
+    auto kern = conv1x1_wgrad_group_kernel<3, WVM, WVN, NT>;
+    constexpr int PITCH = 16 * 2 + 16;
+    const size_t lds = (size_t)2 * (3 * 32 * WVM * PITCH + 3 * 32 * WVN * NT * PITCH);
+    static int res = 0;
+    if (res == 0) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        res = nb;
+    }
+    if (res_out) { *res_out = res; return EAS_OK; }
+    EAS_LAUNCH(kern, dim3(blocks), dim3(256), lds, st, a);
+    return EAS_OK;
+}
+}  // namespace
+
+int eas_conv1x1_wgrad_group(const EasWgradProblem* pr, int n, int x_terms, hipStream_t st, int* slabs_out, bool query) {
+    if (n > kMaxW1Group || x_terms != 3) return EAS_ERR_UNSUPPORTED;
+    W1GroupArgs a{};
+    int yz[kMaxW1Group], nc[kMaxW1Group];
+    const int cls0 = pr[0].Cout > 64 ? 2 : (pr[0].Cout > 32 ? 1 : 0);
+    const int wvm = cls0 == 2 ? 4 : (cls0 == 1 ? 2 : 1), wvn = cls0 == 2 ? 1 : (cls0 == 1 ? 2 : 4), nt = cls0 == 2 ? 4 : (cls0 == 1 ? 2 : 1);
+    const int RA = 32 * wvm, RB = 32 * wvn * nt;
+    for (int p = 0; p < n; ++p) {
+        const EasWgradProblem& q = pr[p];
+        if (q.NI <= 0 || q.Cin <= 0 || q.Cout <= 0 || q.Hi <= 0 || q.Wi <= 0) return EAS_ERR_INVALID_ARG;
+        if (!query && (!q.x || !q.grad_y || !q.workspace)) return EAS_ERR_INVALID_ARG;
+        const int HW = q.Hi * q.Wi;
+        const int cls = q.Cout > 64 ? 2 : (q.Cout > 32 ? 1 : 0);
+        if (HW % 16 != 0 || cls != cls0) return EAS_ERR_UNSUPPORTED;
+        W1Geom& g = a.g[p];
+        g.NI = q.NI; g.Cin = q.Cin; g.Cout = q.Cout; g.HW = HW;
+        g.ci_blocks = (q.Cin + RB - 1) / RB;
+        yz[p] = ((q.Cout + RA - 1) / RA) * g.ci_blocks;
+        nc[p] = q.NI * (HW / 16);
+        a.x[p] = q.x; a.gy[p] = q.grad_y; a.slabs[p] = q.workspace;
+    }
+    int res = 2;
+    int rc = cls0 == 2 ? launch_w1_group<4, 1, 4>(a, 0, st, &res) : (cls0 == 1 ? launch_w1_group<2, 2, 2>(a, 0, st, &res) : launch_w1_group<1, 4, 1>(a, 0, st, &res));
+    if (rc != EAS_OK) return rc;
+    // common chunks per block (the rule of group_tau, conv_wgrad_mfma.hip)
+    const long slots = 256L * res;
+    int max_nc = 0;
+    for (int p = 0; p < n; ++p) max_nc = nc[p] > max_nc ? nc[p] : max_nc;
+    int tau = max_nc;
+    long best_cost = -1;
+    for (int t = max_nc; t >= 1; --t) {
+        long blocks = 0;
+        for (int p = 0; p < n; ++p) blocks += (long)((nc[p] + t - 1) / t) * yz[p];
+        if (blocks > 2 * slots && best_cost >= 0) break;
+        const long cost = ((blocks + slots - 1) / slots) * t;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; tau = t; }
+    }
+    int blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        a.g[p].per_slice = tau < nc[p] ? tau : nc[p];
+        a.slices[p] = (nc[p] + a.g[p].per_slice - 1) / a.g[p].per_slice;
+        if (slabs_out) slabs_out[p] = a.slices[p];
+        a.first[p] = blocks;
+        blocks += a.slices[p] * yz[p];
+    }
+    a.first[n] = blocks;
+    a.n = n;
+    if (query) return EAS_OK;
+    return cls0 == 2 ? launch_w1_group<4, 1, 4>(a, blocks, st, nullptr) : (cls0 == 1 ? launch_w1_group<2, 2, 2>(a, blocks, st, nullptr) : launch_w1_group<1, 4, 1>(a, blocks, st, nullptr));
 }

@@ -194,10 +194,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_dgrad_s2_kernel(const 
     const int cls = blockIdx.z;
     if ((int)blockIdx.x * sg.g[cls].RT >= sg.g[cls].total_rows) return;
     switch (cls) {
-        case 0: conv_tile_body<1, 1, 3, WM, WN, WVM, WVN, 64, VEC, NIT>(gy, sg.wp[0], nullptr, gx, nullptr, sg.g[0], 0, smem); break;
-        case 1: conv_tile_body<2, 1, 3, WM, WN, WVM, WVN, 32, VEC, NIT>(gy, sg.wp[1], nullptr, gx, nullptr, sg.g[1], 0, smem); break;
-        case 2: conv_tile_body<2, 1, 3, WM, WN, WVM, WVN, 32, VEC, NIT>(gy, sg.wp[2], nullptr, gx, nullptr, sg.g[2], 0, smem); break;
-        default: conv_tile_body<4, 1, 3, WM, WN, WVM, WVN, 16, VEC, NIT>(gy, sg.wp[3], nullptr, gx, nullptr, sg.g[3], 0, smem); break;
+        case 0: conv_tile_body<1, 1, 3, WM, WN, WVM, WVN, 64, VEC, NIT>(gy, sg.wp[0], nullptr, gx, nullptr, sg.g[0], 0, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x); break;
+        case 1: conv_tile_body<2, 1, 3, WM, WN, WVM, WVN, 32, VEC, NIT>(gy, sg.wp[1], nullptr, gx, nullptr, sg.g[1], 0, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x); break;
+        case 2: conv_tile_body<2, 1, 3, WM, WN, WVM, WVN, 32, VEC, NIT>(gy, sg.wp[2], nullptr, gx, nullptr, sg.g[2], 0, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x); break;
+        default: conv_tile_body<4, 1, 3, WM, WN, WVM, WVN, 16, VEC, NIT>(gy, sg.wp[3], nullptr, gx, nullptr, sg.g[3], 0, smem, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x); break;
     }
 }
 

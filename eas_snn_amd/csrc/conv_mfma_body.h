@@ -17,7 +17,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // staging loads of rows outside the image / channels past Cin read these zeros (channel stride 0) instead of being masked
 __device__ __attribute__((aligned(16))) float eas_conv_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
-struct ConvGeom {
+// ConvGeomCore: everything the plain tiles read.  ConvGeom adds the descriptors of the fused eval epilogues (624 bytes together); the
+// grouped launches (conv_group.hip) carry up to eight ConvGeomCore by value in their kernel arguments.
+struct ConvGeomCore {
     int NI, Cin, Cout, Hi, Wi, Ho, Wo;
     int RT;        // output rows (flattened over images) per block tile
     int rows_seg;  // output rows per image segment inside a tile = min(RT, Ho)
@@ -56,6 +58,9 @@ struct ConvGeom {
     int bpi;
     int act;       // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act: an eval-mode BaseConv whose BatchNorm is folded into
                    // weights and bias by fuse_model, yolox/utils/model_utils.py:35-80 -- "return self.act(self.conv(x))", network_blocks.py:55-56)
+};
+
+struct ConvGeom : ConvGeomCore {
     EasLifEpiDev lif;
     EasBnActEpiDev bna;   // BatchNorm (running statistics) + activation in the plain epilogue (eas_conv_bn_act_eval); bna.on = 0: the plain store
 };
@@ -108,10 +113,12 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // cycles to land.  Halo columns are zeroed once; rows outside the image are written as zeros.
 // PL: x is a spike-plane tensor (bf16 [NI][Cin/8][Hi*Wi][8], one exact term): the 8 channels of a staged pixel are 16 contiguous bytes
 // in HBM and in LDS -- a staging item is VEC 16-byte loads and VEC 16-byte LDS stores, no conversion, half the bytes of fp32.
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0>
+// bx / by / gx: the block's pixel-tile index, channel-group index and the number of pixel tiles of its problem -- blockIdx.x, blockIdx.y,
+// gridDim.x for a launch of one problem; a grouped launch (conv_group.hip) maps its flat grid onto (problem, tile) first.
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0, typename G = ConvGeom>
 __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
-                                               float* __restrict__ y, int* __restrict__ inexact, const ConvGeom& g, const int part,
-                                               unsigned char* smem) {
+                                               float* __restrict__ y, int* __restrict__ inexact, const G& g, const int part,
+                                               unsigned char* smem, const int bx, const int by, const int gx) {
     static_assert(!PL || XT == 1, "spike planes are one exact bf16 term");
     static_assert(LM == 0 || WM == 1, "the fused neuron epilogue walks one M-tile per wave");
     constexpr bool TM = LM == 1;   // time-major pixel tiles (conv_lif_epi.h)
@@ -126,10 +133,10 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WVN, wn = wave % WVN;
     const int r = lane & 31, h = lane >> 5;
-    const int bimg = g.bpi ? (int)blockIdx.x / g.bpi : 0;
-    const int rho0 = g.bpi ? bimg * g.Ho + ((int)blockIdx.x - bimg * g.bpi) * g.RT : (int)blockIdx.x * g.RT;
+    const int bimg = g.bpi ? bx / g.bpi : 0;
+    const int rho0 = g.bpi ? bimg * g.Ho + (bx - bimg * g.bpi) * g.RT : bx * g.RT;
     const int img0 = fdiv(rho0, g.m_Ho), r0 = rho0 - img0 * g.Ho;
-    const int mt0 = (blockIdx.y * WVM + wm) * WM;
+    const int mt0 = (by * WVM + wm) * WM;
     const int term_stride = g.Q * PIXB;
     const int grp = g.Q * 16;      // bytes of one 8-channel group plane: LDS layout [term][8-channel group][pixel][8 ch = 16 B]
     const int buf_bytes = term_stride * XT;
@@ -159,7 +166,8 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         // time-major: tile j = time step j / M2 of the wave's spatial tile j % M2 (M2 = WN / T spatial tiles per wave)
-        const int m2 = TM ? WN / g.lif.T : 1;
+        int m2 = 1;
+        if constexpr (TM) m2 = WN / g.lif.T;
         const int p = TM ? (wn * m2 + j % m2) * 32 + r : (wn * WN + j) * 32 + r;
         const int pc = p < npix ? p : 0;
         const int rl = fdiv(pc, g.m_Wo), c = pc - rl * g.Wo;
@@ -387,9 +395,9 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         __syncthreads();
         if (tid < WVM * WM * 32) {
             const int wmi = tid / (WM * 32), t = tid - wmi * (WM * 32);
-            const int co = (blockIdx.y * WVM + wmi) * WM * 32 + t;
+            const int co = (by * WVM + wmi) * WM * 32 + t;
             eas_conv_stats_store(red + wmi * WVN * (WM * 64), WM * 64, WVN, t, co, g.Cout, g.stats, g.stats_nb,
-                                 (int)blockIdx.x + (int)gridDim.x * part);
+                                 bx + gx * part);
         }
     }
 
@@ -453,10 +461,11 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv_fwd_mfma_kernel(const 
                                                             const float* __restrict__ bias, float* __restrict__ y, int* __restrict__ inexact,
                                                             ConvGeom g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL, LM>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem);
+    conv_tile_body<TAPS, S, XT, WM, WN, WVM, WVN, CCH, VEC, NIT, PL, LM>(x, wp, bias, y, inexact, g, (int)blockIdx.z, smem, (int)blockIdx.x,
+                                                                         (int)blockIdx.y, (int)gridDim.x);
 }
 
-static void conv_geom_magics(ConvGeom& g, int VEC, int CCH) {
+static void conv_geom_magics(ConvGeomCore& g, int VEC, int CCH) {
     const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, units = g.nseg * units_seg;
     const int rows = g.nseg * g.rows_in, per_row = (g.RS - g.Wst) * (CCH * 2 / 16);
     g.m_Wo = fdiv_magic(g.Wo); g.m_rows_seg = fdiv_magic(g.rows_seg); g.m_Ho = fdiv_magic(g.Ho);

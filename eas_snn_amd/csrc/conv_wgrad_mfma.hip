@@ -95,18 +95,19 @@ __device__ __forceinline__ void stage_terms(unsigned char* dst, int term_stride,
 
 // XPL: x is a spike-plane tensor (bf16 [NI][Cin/8][Hi*Wi][8], XT = 1): an x staging item is VEC 16-byte loads copied as they are into
 // the pixel-major LDS image (the 8 channels of a pixel are 16 contiguous bytes in both).
-template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
-__global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                        float* __restrict__ slabs, WgGeom g) {
+// bx / by: the block's pixel slice (its first tile and its slab) and (co, ci) block index -- blockIdx.x / .y of a launch of one layer; a
+// grouped launch (conv_wgrad_group_kernel) maps its flat grid onto (layer, slice, channel block) first
+template <int S, int XT, int PM, int PN, int VEC, bool XPL>
+__device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ slabs,
+                                                const WgGeom& g, unsigned char* smem, const int bx, const int by) {
     static_assert(!XPL || XT == 1, "spike planes are one exact bf16 term");
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NW = 3 * PM * PN, NT = 64 * NW, NIT = PM * PN == 4 ? 1 : 2;   // staging items per thread (register budget of 12-wave blocks)
     constexpr int A_TERM = PM * A_PLANE, A_BYTES = 3 * A_TERM;
-    extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = wave % 3, pair = wave / 3, pm = pair / PN, pn = pair % PN;
-    const int cob = blockIdx.y / g.ci_blocks, cib = blockIdx.y - cob * g.ci_blocks;
+    const int cob = by / g.ci_blocks, cib = by - cob * g.ci_blocks;
     const int co0 = cob * 32 * PM, ci0 = cib * 32 * PN;
     const int b_plane = g.Q * ROWB, b_term = PN * b_plane;
     const int buf_bytes = A_BYTES + XT * b_term;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
     // other groups of its single plane are zeroed once, below)
     const int nbg = PN == 1 ? (g.Cin - ci0 >= 32 ? 4 : (g.Cin - ci0 + 7) / 8) : 4 * PN;
     const int units_row = g.Wst / VEC, units_seg = g.rows_in * units_row, unitsB = g.nseg * units_seg, nB = unitsB * nbg;
-    const int part = g.parts > 1 ? (int)(blockIdx.x % g.parts) : 0;
+    const int part = g.parts > 1 ? bx % g.parts : 0;
     const int ycol0 = part * g.Wo;                              // first grad_y column of this block's tiles
     const int xcol0 = g.parts > 1 ? ycol0 * S - g.hv : 0;       // input column of the first staged unit (may be < 0)
     const int nitems = nA + nB;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
 
-    int tile = blockIdx.x;
+    int tile = bx;
     if (tile < g.ntiles) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
 
     // ---- partial sums of this block -> slab [kslice][co][ci][kh][kw]; D: col = ci = lane&31, row = co = (e&3)+8*(e>>2)+4*(lane>>5)
     const int ci = ci0 + pn * 32 + (lane & 31);
-    float* slab = slabs + (size_t)blockIdx.x * g.Cout * g.Cin * 9;
+    float* slab = slabs + (size_t)bx * g.Cout * g.Cin * 9;
     if (ci < g.Cin) {
         const int cob = co0 + pm * 32 + 4 * (lane >> 5);
         float* d0 = slab + ((size_t)cob * g.Cin + ci) * 9 + kh * 3;
@@ -420,6 +421,40 @@ __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const fl
             }
         }
     }
+}
+
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
+__global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                        float* __restrict__ slabs, WgGeom g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    conv_wgrad_body<S, XT, PM, PN, VEC, XPL>(x, gy, slabs, g, smem, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Grouped launch (include/eas_hip.h eas_conv_wgrad_group_partial): layer p owns blocks [first[p], first[p + 1]) of the flat grid,
+// kslices x (co, ci) blocks of them, slice fastest.  Stride 1, fp32 three-term x, whole-row tiles; a layer's rows are staged in 16-byte
+// units or (10-pixel rows) 8-byte units.
+constexpr int kMaxWgGroup = 8;
+struct WgGroupArgs {
+    WgGeom g[kMaxWgGroup];
+    const float* x[kMaxWgGroup];
+    const float* gy[kMaxWgGroup];
+    float* slabs[kMaxWgGroup];
+    int first[kMaxWgGroup + 1];
+    int vec2[kMaxWgGroup];
+    int n;
+};
+
+template <int XT, int PM, int PN>
+__global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_group_kernel(const WgGroupArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int lb = (int)blockIdx.x - a.first[p];
+    const int ks = a.g[p].kslices, by = lb / ks, bx = lb - by * ks;
+    if (a.vec2[p]) conv_wgrad_body<1, XT, PM, PN, 2, false>(a.x[p], a.gy[p], a.slabs[p], a.g[p], smem, bx, by);
+    else conv_wgrad_body<1, XT, PM, PN, 4, false>(a.x[p], a.gy[p], a.slabs[p], a.g[p], smem, bx, by);
 }
 
 // dW[i] = sum over slabs in a fixed order (deterministic): slice lane kl = 0..3 adds slabs kl, kl + 4, kl + 8, ... in double, in that order,
@@ -704,8 +739,84 @@ WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms
     return wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn, res);
 }
 
+// ---- grouped launch: plan.  Every layer keeps its own (co, ci) blocks; the pixel slices of ALL layers are sized together: a common
+// number of tiles per block tau, slices_p = ceil(ntiles_p / tau), chosen like wg_plan chooses a layer's -- the fewest tile periods
+// (rounds of the chip's block slots x tau), ties to the larger tau (fewer slabs).  A layer alone needs its slices to fill 256 CUs by
+// itself (512 slabs for a 128 -> 128 layer on 32x40 maps); in a group the other layers' blocks fill them.
+template <int XT, int PM, int PN>
+int resident_wgrad_group(size_t lds) {
+    static size_t seen[8];
+    static int val[8], n = 0;
+    for (int i = 0; i < n; ++i)
+        if (seen[i] == lds) return val[i];
+    auto kern = conv_wgrad_group_kernel<XT, PM, PN>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 192 * PM * PN, lds) != hipSuccess || nb < 1) nb = 1;
+    if (n < 8) { seen[n] = lds; val[n] = nb; ++n; }
+    return nb;
+}
+
+// tau for block counts yz[p] and tile counts nt[p]
+int group_tau(const int* yz, const int* nt, int n, long slots) {
+    int max_nt = 0;
+    for (int p = 0; p < n; ++p) max_nt = nt[p] > max_nt ? nt[p] : max_nt;
+    int best = max_nt;
+    long best_cost = -1;
+    for (int tau = max_nt; tau >= 1; --tau) {
+        long blocks = 0;
+        for (int p = 0; p < n; ++p) blocks += (long)((nt[p] + tau - 1) / tau) * yz[p];
+        if (blocks > 4 * slots && best_cost >= 0) break;
+        const long cost = ((blocks + slots - 1) / slots) * tau;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = tau; }
+    }
+    return best;
+}
+
+int wgrad_group3(const EasWgradProblem* pr, int n, int x_terms, hipStream_t st, int* slabs_out, bool query) {
+    if (n > kMaxWgGroup || x_terms != 3) return EAS_ERR_UNSUPPORTED;
+    WgGroupArgs a{};
+    int yz[kMaxWgGroup], nt[kMaxWgGroup];
+    size_t lds = 0;
+    const int pm = pr[0].Cout >= 64 ? 2 : 1;
+    for (int p = 0; p < n; ++p) {
+        const EasWgradProblem& q = pr[p];
+        if (q.NI <= 0 || q.Cin <= 0 || q.Cout <= 0 || q.Hi <= 0 || q.Wi <= 0) return EAS_ERR_INVALID_ARG;
+        if (!query && (!q.x || !q.grad_y || !q.workspace)) return EAS_ERR_INVALID_ARG;
+        if (q.Cin % 8 != 0 || q.Cout % 8 != 0 || q.Wi % 2 != 0 || (q.Cout >= 64 ? 2 : 1) != pm) return EAS_ERR_UNSUPPORTED;
+        WgGeom& g = a.g[p];
+        if (!wg_geom(g, q.NI, q.Cin, q.Cout, q.Hi, q.Wi, 1, x_terms) || g.parts != 1 || g.pn != 1) return EAS_ERR_UNSUPPORTED;
+        if (g.Wo % 2 != 0 || (g.Ho * g.pitchY) % 4 != 0) return EAS_ERR_UNSUPPORTED;
+        a.vec2[p] = (g.Wi % 4 == 0 && g.Wo % 4 == 0) ? 0 : 1;
+        const size_t l = (size_t)2 * (3 * pm * A_PLANE + (size_t)x_terms * g.Q * ROWB);
+        lds = l > lds ? l : lds;
+        g.ci_blocks = (g.Cin + 31) / 32;
+        yz[p] = ((g.Cout + 32 * pm - 1) / (32 * pm)) * g.ci_blocks;
+        nt[p] = g.ntiles;
+        a.x[p] = (const float*)q.x; a.gy[p] = q.grad_y; a.slabs[p] = q.workspace;
+    }
+    if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
+    const int res = pm == 2 ? resident_wgrad_group<3, 2, 1>(lds) : resident_wgrad_group<3, 1, 1>(lds);
+    const int tau = group_tau(yz, nt, n, 256L * res);
+    int blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        a.g[p].kslices = (nt[p] + tau - 1) / tau;
+        a.g[p].single = 0;
+        if (slabs_out) slabs_out[p] = a.g[p].kslices;
+        a.first[p] = blocks;
+        blocks += a.g[p].kslices * yz[p];
+    }
+    a.first[n] = blocks;
+    a.n = n;
+    if (query) return EAS_OK;
+    if (pm == 2) EAS_LAUNCH((conv_wgrad_group_kernel<3, 2, 1>), dim3(blocks), dim3(384), lds, st, a);
+    else EAS_LAUNCH((conv_wgrad_group_kernel<3, 1, 1>), dim3(blocks), dim3(192), lds, st, a);
+    return EAS_OK;
+}
+
 }  // namespace
 
+int eas_conv1x1_wgrad_group(const EasWgradProblem* pr, int n, int x_terms, hipStream_t st, int* slabs_out, bool query);
 int eas_conv1x1_wgrad_slices(int NI, int Cin, int Cout, int HW, int x_terms, int planes);
 int eas_conv1x1_wgrad_dispatch(const void* x, const float* gy, float* slabs, int NI, int Cin, int Cout, int HW, int x_terms, hipStream_t st,
                                int planes);
@@ -808,6 +919,26 @@ int eas_conv_wgrad_partial(const float* x, const float* grad_y, float* workspace
 int eas_conv_wgrad_planes_partial(const void* x_planes, const float* grad_y, float* workspace, int NI, int Cin, int Cout, int Hi, int Wi, int ksize,
                                   int stride, eas_stream_t stream) {
     return wgrad_partial(reinterpret_cast<const float*>(x_planes), grad_y, workspace, NI, Cin, Cout, Hi, Wi, ksize, stride, 2, stream);
+}
+
+// include/eas_hip.h: several layers' slab kernels as one grid
+static int wgrad_group_impl(const EasWgradProblem* pr, int n, int ksize, int x_terms, eas_stream_t stream, int* slabs_out, bool query) {
+    if (!pr || n < 1) return EAS_ERR_INVALID_ARG;
+    if (ksize != 1 && ksize != 3) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    const int rc = ksize == 1 ? eas_conv1x1_wgrad_group(pr, n, x_terms, eas_s(stream), slabs_out, query)
+                              : wgrad_group3(pr, n, x_terms, eas_s(stream), slabs_out, query);
+    if (rc != EAS_OK || query) return rc;
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_conv_wgrad_group_plan(const EasWgradProblem* problems, int n, int ksize, int x_terms, int* slabs_out) {
+    return wgrad_group_impl(problems, n, ksize, x_terms, nullptr, slabs_out, true);
+}
+
+int eas_conv_wgrad_group_partial(const EasWgradProblem* problems, int n, int ksize, int x_terms, eas_stream_t stream) {
+    return wgrad_group_impl(problems, n, ksize, x_terms, stream, nullptr, false);
 }
 
 int eas_conv_wgrad_reduce_many(const EasWgradReduceJob* jobs, int njobs, eas_stream_t stream) {

@@ -116,9 +116,8 @@ int check_geom(const UpcatGeom& g) {
 // Bias gradient of a convolution: out[c] = sum over (n, pixel) of g[n][c][pixel] (ATen: grad_y.sum((0, 2, 3)), a reduce kernel that takes
 // 12-27 us for the 1 / 4 / num_classes-channel prediction maps of the head).  One block per channel, fixed order: every thread sums its
 // strided share in double, the waves and the block add in a fixed tree -- deterministic.
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int C, int HW) {
+__device__ __forceinline__ void channel_sum_body(const float* __restrict__ g, float* __restrict__ out, int N, int C, int HW, const int c) {
     __shared__ double red[4];
-    const int c = blockIdx.x;
     double s = 0.0;
     const int64_t total = (int64_t)N * HW;
     if ((HW & 3) == 0) {
@@ -136,6 +135,26 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     }
     const double t = eas_block_sum<double, 4>(s, red);
     if (threadIdx.x == 0) out[c] = (float)t;
+}
+
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int C, int HW) {
+    channel_sum_body(g, out, N, C, HW, (int)blockIdx.x);
+}
+
+// several tensors in one launch (eas_channel_sum_group): tensor p owns blocks [first[p], first[p] + C[p])
+constexpr int kMaxSumGroup = 16;
+struct ChannelSumGroup {
+    const float* g[kMaxSumGroup];
+    float* out[kMaxSumGroup];
+    int N[kMaxSumGroup], C[kMaxSumGroup], HW[kMaxSumGroup], first[kMaxSumGroup + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void channel_sum_group_kernel(const ChannelSumGroup a) {
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    channel_sum_body(a.g[p], a.out[p], a.N[p], a.C[p], a.HW[p], (int)blockIdx.x - a.first[p]);
 }
 
 }  // namespace
@@ -183,6 +202,27 @@ int eas_channel_sum(const float* g, float* out, int N, int C, int HW, eas_stream
     if ((HW & 3) == 0 && ((uintptr_t)g & 15)) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
     EAS_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, eas_s(stream), g, out, N, C, HW);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_channel_sum_group(const EasChannelSumProblem* pr, int n, eas_stream_t stream) {
+    if (!pr || n < 1) return EAS_ERR_INVALID_ARG;
+    if (n > kMaxSumGroup) return EAS_ERR_UNSUPPORTED;
+    ChannelSumGroup a{};
+    int blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        const EasChannelSumProblem& q = pr[p];
+        if (!q.g || !q.out || q.N < 1 || q.C < 1 || q.HW < 1) return EAS_ERR_INVALID_ARG;
+        if ((q.HW & 3) == 0 && ((uintptr_t)q.g & 15)) return EAS_ERR_INVALID_ARG;
+        a.g[p] = q.g; a.out[p] = q.out; a.N[p] = q.N; a.C[p] = q.C; a.HW[p] = q.HW;
+        a.first[p] = blocks;
+        blocks += q.C;
+    }
+    a.first[n] = blocks;
+    a.n = n;
+    EAS_CLEAR_ERR();
+    EAS_LAUNCH(channel_sum_group_kernel, dim3(blocks), dim3(256), 0, eas_s(stream), a);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -615,6 +615,76 @@ int eas_upcat_planes_fwd(const void* a_planes, const void* b_planes, void* out_p
  * inverse permutation (the backward).  Wo % 2 == 0. */
 int eas_focus(const float* src, float* dst, int64_t M, int C, int Ho, int Wo, int inverse, eas_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Grouped (multi-problem) launches (ABI 7).  The detection head runs the same layers on three pyramid levels that are independent
+ * until the loss (yolox/models/yolo_head.py:149-200: `for k, (cls_conv, reg_conv, stride_this_level, x) in enumerate(zip(...))`),
+ * and the 16x20 / 8x10 levels cannot fill 256 CUs by themselves.  A grouped call takes a table of problems -- each its own geometry,
+ * weights and pointers -- and runs them as ONE grid: blockIdx -> (problem, tile).  Per problem the arithmetic and summation order are
+ * those of the single-problem entry point (eas_conv_fwd / eas_bn_silu_fwd_ex / eas_bn_silu_bwd / eas_conv_wgrad_partial /
+ * eas_channel_sum): outputs are bit-identical for the same tile plan; the BatchNorm partial sums and the weight-gradient slabs are cut
+ * by the GROUP's tile / slice plan (deterministic, fixed order).
+ * EAS_ERR_UNSUPPORTED from a *_plan call: run the problems one by one.  Stride 1, padding ksize / 2, fp32 tensors, x_terms = 3. */
+typedef struct {
+    const void* x;          /* [NI][Cin][Hi][Wi] fp32 (the input gradient: grad_y, Cin / Cout swapped, weights packed with mode 1) */
+    const void* packed_w;   /* eas_conv_pack_weights */
+    const float* bias;      /* nullable [Cout] */
+    float* y;               /* [NI][Cout][Hi][Wi] */
+    double* stats;          /* nullable: per-channel partial sums of y as eas_conv_fwd_stats leaves them, [Cout][nb][2] doubles with
+                               nb = eas_conv_fwd_group_plan's nb_out[problem] */
+    int NI, Cin, Cout, Hi, Wi;
+    int accumulate;         /* ksize 1 only: y += conv(x) -- the second reader of a tensor adds its input gradient in place */
+} EasConvProblem;
+int eas_conv_fwd_group_plan(const EasConvProblem* problems, int n, int ksize, int x_terms, int* nb_out);
+int eas_conv_fwd_group(const EasConvProblem* problems, int n, int ksize, int x_terms, eas_stream_t stream);
+
+/* eas_bn_silu_fwd_ex / eas_bn_silu_bwd for several layers in one launch (two launches for the backward: sums, apply).
+ * workspace: eas_bn_workspace_doubles(C) doubles per problem. */
+typedef struct {
+    const float* y;
+    float* mean;            /* outputs when pending.partial != NULL (batch statistics), inputs otherwise */
+    float* invstd;
+    const float* gamma;
+    const float* beta;
+    float* out;
+    int N, C, HW, out_ctot, y_ctot;
+    EasBnPending pending;
+} EasBnSiluFwdProblem;
+int eas_bn_silu_fwd_group(const EasBnSiluFwdProblem* problems, int n, eas_stream_t stream);
+typedef struct {
+    const float* grad_out;
+    const float* y;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    float* grad_y;
+    float* grad_gamma;
+    float* grad_beta;
+    double* workspace;
+    int batch_stats, N, C, HW, grad_out_ctot, y_ctot;
+} EasBnSiluBwdProblem;
+int eas_bn_silu_bwd_group(const EasBnSiluBwdProblem* problems, int n, eas_stream_t stream);
+
+/* eas_conv_wgrad_partial for several layers in one launch: the pixel slices of every problem are sized for the group's total block count
+ * (a layer alone needs hundreds of slabs to give 256 CUs a block each; in a group a few do).  plan: slabs_out[p] = slabs problem p
+ * writes (workspace = slabs * Cout * Cin * ksize^2 floats), also the count to hand to eas_conv_wgrad_reduce_many. */
+typedef struct {
+    const void* x;          /* [NI][Cin][Hi][Wi] fp32 */
+    const float* grad_y;    /* [NI][Cout][Hi][Wi] */
+    float* workspace;
+    int NI, Cin, Cout, Hi, Wi;
+} EasWgradProblem;
+int eas_conv_wgrad_group_plan(const EasWgradProblem* problems, int n, int ksize, int x_terms, int* slabs_out);
+int eas_conv_wgrad_group_partial(const EasWgradProblem* problems, int n, int ksize, int x_terms, eas_stream_t stream);
+
+/* eas_channel_sum for several tensors in one launch (the bias gradients of the prediction convolutions of all levels) */
+typedef struct {
+    const float* g;
+    float* out;
+    int N, C, HW;
+} EasChannelSumProblem;
+int eas_channel_sum_group(const EasChannelSumProblem* problems, int n, eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
