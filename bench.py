@@ -62,6 +62,24 @@ def pmc_traffic(entry, launches_per_call, config=2):
         return None
 
 
+def pmc_traffic_eval(entry):
+    """HBM bytes per launch of the eval forward's dominant family from the committed PMC pass over the eval forward
+    (profiles/pmc_traffic_eval_latest.json, scripts/prof_eval.sh), or None"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_eval_latest.json')) as fh:
+            pmc = json.load(fh)
+        ks = [pmc[k] for k in PMC_KERNELS_EVAL.get(entry, []) if k in pmc]
+        n = sum(k['launches'] for k in ks)
+        return round(sum(k['hbm_bytes_per_launch'] * k['launches'] for k in ks) / n)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+PMC_KERNELS_EVAL = {'eas_conv_bn_lif_eval': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel', 'conv1x1_mfma_sharedA_kernel', 'conv_fwd_mfma_kernel[planes]',
+                                             'conv1x1_mfma_kernel[planes]', 'conv1x1_mfma_sharedA_kernel[planes]'],
+                    'eas_conv_fwd': PMC_KERNELS['eas_conv_fwd'], 'eas_bn_lif_fwd': PMC_KERNELS['eas_bn_lif_fwd']}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -77,6 +95,7 @@ def parse():
     ap.add_argument('--h2d', action='store_true',
                     help='stream a fresh pinned host batch of raw input to the device every step on a side stream (the reference\'s '
                          'DataPrefetcher shape, yolox/data/data_prefetcher.py:31-44): PCIe-inclusive rate, reported as such')
+    ap.add_argument('--canvas640-child', action='store_true', help=argparse.SUPPRESS)     # internal: the 640x640 side figure's own process
     ap.add_argument('--selftest-cpu', action='store_true',
                     help='no GPU: run the launcher, rendezvous (gloo), barrier / max-over-ranks timing and the trainer\'s step object with the '
                          'bucketed gradient exchange on a stand-in CPU module (tests/test_cpu_host.py)')
@@ -314,6 +333,104 @@ def selftest_cpu(args, world, rank):
         dist.destroy_process_group()
 
 
+def count_launches(step, ops_lib):
+    """Device launches of ONE eager training step: the library's own kernels from its launch counter (exact), the ATen kernels and the
+    runtime's copy / fill kernels from a torch.profiler pass over one more step (None when the profiler is not available)."""
+    import torch
+    torch.cuda.synchronize()
+    c0 = ops_lib.eas_launch_counter()
+    step.eager()
+    torch.cuda.synchronize()
+    own = int(ops_lib.eas_launch_counter() - c0)
+    aten = runtime = None
+    try:
+        from torch.autograd import DeviceType
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            step.eager()
+            torch.cuda.synchronize()
+        names = [e.name for e in prof.events() if e.device_type == DeviceType.CUDA]
+        if names:
+            is_rt = lambda n: n.startswith(('Memcpy', 'Memset')) or '__amd_rocclr' in n or 'hipMemcpy' in n or 'hipMemset' in n
+            runtime = sum(1 for n in names if is_rt(n))
+            aten = sum(1 for n in names if not is_rt(n) and ('at::' in n or 'c10::' in n))
+    except Exception:
+        pass
+    out = {'eas_kernels': own, 'aten_kernels': aten, 'runtime_copies_fills': runtime}
+    out['total'] = own + (aten or 0) + (runtime or 0) if aten is not None else None
+    return out
+
+
+def family_table(summ, per):
+    return {k: dict(calls=v['calls'], ms=round(v['ms'] / per, 4),
+                    GBps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
+                    **({'TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} if v['flops'] > 0 else {}),
+                    roofline_frac=round(v['roof_ms'] / v['ms'], 3) if v['ms'] > 0 else None) for k, v in summ.items()}
+
+
+def dominant_roofline(summ):
+    """the roofline object of the family with the most time in a KernelTimer summary"""
+    dom = max(summ, key=lambda k: summ[k]['ms'])
+    d = summ[dom]
+    sec = d['ms'] * 1e-3
+    if d['flops'] > 0:
+        ceiling = BF16_MFMA_PEAK_TF * d['flops'] / d['issue_flops']
+        achieved = d['flops'] / sec / 1e12
+        r = {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': round(ceiling, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / ceiling, 4),
+             'peak_is': 'bf16 term ceiling: dense bf16 MFMA peak 2500 TFLOP/s / bf16 term products per fp32 product of this family\'s mix',
+             'bf16_issue_frac': round(d['issue_flops'] / sec / 1e12 / BF16_MFMA_PEAK_TF, 4)}
+    else:
+        achieved = d['bytes'] / sec / 1e9
+        r = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4)}
+    r.update({'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'frac_of_per_launch_roofline': round(d['roof_ms'] / d['ms'], 4),
+              'algorithmic_bytes_per_call': round(d['bytes'] / d['calls'])})
+    return r
+
+
+def canvas_640_figure(dev, batch, events):
+    """Side figure (never `value`): the README recipe's canvas.  The reference's published commands never set input_size, so they train at
+    the default (640, 640) (yolox/exp/event_yolox_base.py:66,137) through the letterbox resize of the dataset
+    (yolox/data/datasets/gen1.py:433-455): workload '2b' = config 2's model behind eas_counts_letterbox.  A few HIP-graph replays of the
+    trainer's step + the kernel families of three eager steps."""
+    import gc
+    from eas_snn_amd import ops, workloads
+    w = workloads.get('2b')
+    trainer, model, step = workloads.build_trainer(w, batch, dev, events=events)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    launch = 'eager launches'
+    if trainer.net is trainer.bare_model and os.environ.get('EAS_BENCH_GRAPH', 'auto') != '0':
+        launch = step.capture(warm=2)
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize()
+    n = 8
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    assert torch.isfinite(loss), 'the 640x640 step produced a non-finite loss'
+    ops.check_tags('the 640x640 steps')
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    for _ in range(3):
+        step.eager()
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    summ = timer.summary()
+    r = dominant_roofline(summ)
+    out = {'workload': w['name'], 'batch': batch, 'ms_per_step': round(ms, 3), 'event_frames_per_s': round(batch / ms * 1e3, 1), 'launch': launch,
+           'dominant_family': r['kernel'], 'frac': r['frac'], 'frac_of_per_launch_roofline': r['frac_of_per_launch_roofline'],
+           'fused_detection_loss': bool(getattr(model.head, '_eas_fused_loss_used', False)),
+           'hip_kernel_ms_per_step': {k: round(v['ms'] / 3, 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])[:6]}}
+    del trainer, model, step
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -328,6 +445,14 @@ def main():
         return selftest_cpu(args, world, rank)
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU fallback)'
     torch.cuda.set_device(local_rank)
+    if args.canvas640_child:
+        import eas_snn_amd
+        from eas_snn_amd import ops
+        eas_snn_amd.hip_library()
+        torch.cuda.set_stream(torch.cuda.Stream())
+        ops.set_state_writeback(False)
+        print(json.dumps(canvas_640_figure(torch.device('cuda', local_rank), args.batch or 64, args.events)), flush=True)
+        return
     dev = torch.device('cuda', local_rank)
     force_ddp = os.environ.get('EAS_BENCH_FORCE_DDP') == '1'     # development: exercise the exchange / RCCL path with one rank
     if world > 1 or force_ddp:
@@ -430,7 +555,7 @@ def main():
                 timer.input_retimed = name
     # inference side figure: eval-mode forward + reset_net of the same batch (no loss, no backward), replayed as a HIP graph like the
     # evaluator does (yolox/evaluators/event_evaluator.py), for the model as trained and after yolox.utils.fuse_model (tools/eval_event.py --fuse)
-    eval_fps = None
+    eval_fps = eval_roofline = None
     if rank == 0 and not multi and os.environ.get('EAS_BENCH_NO_EVAL') != '1':      # (development: profiles of the training step alone)
         import copy
         from spikingjelly.activation_based import functional
@@ -457,7 +582,40 @@ def main():
                 torch.cuda.synchronize()
                 return round(10 * batch / (time.perf_counter() - t_e), 1)
         eval_fps = {'value': eval_rate(model), 'fuse_model': eval_rate(fuse_model(copy.deepcopy(model)))}
+        # roofline of the forward pass itself (north_star's first clause; the reference's timers: yolox/evaluators/event_evaluator.py:190-212):
+        # the kernel families of three eager eval forwards (events -> frames -> sampler -> backbone -> neck -> head, reset_net)
+        t_ev = ops.KernelTimer()
+        model.eval()
+        ops.set_timer(t_ev)
+        with torch.no_grad():
+            for _ in range(3):
+                model(inputs_fn()[0])
+                functional.reset_net(model)
+        torch.cuda.synchronize()
+        ops.set_timer(None)
+        ev_summ = t_ev.summary()
+        eval_roofline = dominant_roofline(ev_summ)
+        ev_ms = sum(v['ms'] for v in ev_summ.values()) / 3
+        ev_roof = sum(v['roof_ms'] for v in ev_summ.values()) / 3
+        eval_roofline.update({'traffic': pmc_traffic_eval(eval_roofline['kernel']), 'hip_kernel_ms_per_batch': family_table(ev_summ, 3),
+                              'hip_kernels_ms_per_batch': round(ev_ms, 3), 'replayed_ms_per_batch': round(batch / eval_fps['value'] * 1e3, 3),
+                              'all_families_frac_of_per_launch_roofline': round(ev_roof / ev_ms, 4),
+                              'kernel_timing': 'HIP events on the launch stream, 3 eager eval forwards of this process'})
         model.train()
+    # launches of one step (every rank runs the steps -- the exchange needs all of them --, rank 0 reports)
+    launches = count_launches(step, eas_snn_amd.hip_library()) if (rank == 0 and not multi) else None
+    canvas640 = None
+    if rank == 0 and not multi and w['config'] == 2 and args.batch is None and os.environ.get('EAS_BENCH_NO_640') != '1':
+        # in a child process of its own (started like the ranks of launch_ranks, never an exec): a side figure must not be able to take the
+        # headline line with it -- a failure is reported in its place
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--canvas640-child', '--batch', os.environ.get('EAS_BENCH_640_BATCH', '64'),
+                                '--events', str(args.events)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            last = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            canvas640 = json.loads(last[-1]) if (r.returncode == 0 and last) else {'error': f'rc {r.returncode}: ' + r.stderr.strip()[-300:]}
+        except Exception as exc:
+            canvas640 = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -496,6 +654,8 @@ def main():
             # is the point of the term scheme and makes it useless as a ceiling -- kept as vs_f32_mfma_peak)
             roofline = {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': round(scheme_ceiling, 1), 'unit': 'TFLOP/s',
                         'frac': round(achieved / scheme_ceiling, 4),
+                        'peak_is': 'bf16 term ceiling (not a hardware figure): the dense bf16 MFMA peak divided by the bf16 term products one exact fp32 product costs',
+                        'bf16_issue_frac': round(d['issue_flops'] / sec / 1e12 / BF16_MFMA_PEAK_TF, 4),
                         'peak_note': 'dense bf16 MFMA peak 2500 TFLOP/s / bf16 term products per fp32 product (3 spike inputs, 6 real inputs), weighted by this step',
                         'vs_f32_mfma_peak': round(achieved / F32_MFMA_PEAK_TF, 4), 'f32_mfma_peak_tflops': F32_MFMA_PEAK_TF,
                         'scheme_ceiling_tflops': round(scheme_ceiling, 1), 'frac_of_scheme_ceiling': round(achieved / scheme_ceiling, 4),
@@ -525,7 +685,7 @@ def main():
                 'unit': 'event-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (yolox.core.Trainer step)",
+                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (yolox.core.Trainer step; EMA off: exp.ema = False, the reference's ModelEMA update of trainer.py:120-122 is not in the step)",
                            'baseline_config': w['config'], 'global_batch': batch * world,
                            'events_per_sample': args.events if w['input'] == 'events' else None, 'parallelism': f'dp{world}',
                            'gradient_exchange': ((f'{trainer.exchange.nbuckets} flat bucket(s)' if trainer.exchange is not None else trainer.dp) if multi else None),
@@ -533,6 +693,12 @@ def main():
                            'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3),
                            'h2d_per_step': (h2d.describe() if h2d is not None else None)},
                 'roofline': roofline}
+        line['final_loss'] = float(loss)
+        line['launches_per_step'] = launches
+        if eval_roofline is not None:
+            line['roofline_eval'] = eval_roofline
+        if canvas640 is not None:
+            line['canvas_640'] = canvas640
         if eval_fps is not None:
             line['eval_forward_frames_per_s'] = dict(eval_fps, batch=batch, note='model.eval() forward + reset_net on the same batch, one GPU, HIP-graph replay (as EventEvaluator); fuse_model: after yolox.utils.fuse_model (eval_event.py --fuse)')
         if world == 1 and not args.no_cpu_baseline:

@@ -100,6 +100,7 @@ PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
     'eas_kernel_trace_begin': (None, []),
     'eas_kernel_trace_dump': (C.c_int64, [C.c_char_p, C.c_int64]),
+    'eas_launch_counter': (C.c_int64, []),
     'eas_status_string': (C.c_char_p, [C.c_int]),
     'eas_conv_bn_lif_eval': (C.c_int, [C.POINTER(EasConvBnLifEval), _P]),
     'eas_conv_bn_lif_eval_supported': (C.c_int, [C.c_int] * 10),

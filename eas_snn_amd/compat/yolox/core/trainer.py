@@ -347,6 +347,7 @@ class Trainer:
             ckpt = torch.load(ckpt_file, map_location=self.device)
             model.load_state_dict(ckpt['model'])
             self.optimizer.load_state_dict(ckpt['optimizer'])
+            self.best_ap = ckpt.get('best_ap', 0) or 0          # trainer.py:331 of the reference: a resumed run keeps its best checkpoint
             self.start_epoch = ckpt['start_epoch']
         elif ckpt_file is not None:
             model = load_ckpt(model, torch.load(ckpt_file, map_location=self.device)['model'])
@@ -392,9 +393,9 @@ class Trainer:
             self.best_ap = max(self.best_ap, ap50_95)
         self.eval_log.append(dict(epoch=self.epoch, ap50_95=ap50_95, ap50=ap50, summary=summary, images=len(predictions)))
         synchronize()
-        self.save_ckpt('last_epoch', update_best)
+        self.save_ckpt('last_epoch', update_best, ap=ap50_95)
         if self.save_history_ckpt:
-            self.save_ckpt(f'epoch_{self.epoch + 1}')
+            self.save_ckpt(f'epoch_{self.epoch + 1}', ap=ap50_95)
 
     def _set_lr(self, lr):
         for g in self.optimizer.param_groups:
@@ -431,7 +432,7 @@ class Trainer:
         if (self.iter + 1) % self.exp.print_interval == 0:
             self.log.append(dict(epoch=self.epoch, iter=self.iter, loss=float(loss), lr=lr, iter_time=time.time() - t0))
 
-    def save_ckpt(self, ckpt_name, update_best_ckpt=False):
+    def save_ckpt(self, ckpt_name, update_best_ckpt=False, ap=None):
         if self.device != 'cpu':
             ops.check_tags('training up to this checkpoint')     # a mis-tagged spike tensor anywhere since the last check: no checkpoint
         if self.rank != 0:
@@ -441,5 +442,7 @@ class Trainer:
         for g in opt_state['param_groups']:              # checkpoints keep plain numbers
             if torch.is_tensor(g.get('lr')):
                 g['lr'] = float(g['lr'])
-        state = {'start_epoch': self.epoch + 1, 'model': save_model.state_dict(), 'optimizer': opt_state}
+        # the reference's checkpoint format (trainer.py:393-400): best_ap / curr_ap ride along so that a resumed run does not overwrite
+        # best_ckpt.pth with a worse model at its first evaluation
+        state = {'start_epoch': self.epoch + 1, 'model': save_model.state_dict(), 'optimizer': opt_state, 'best_ap': self.best_ap, 'curr_ap': ap}
         save_checkpoint(state, update_best_ckpt, self.file_name, ckpt_name)

@@ -199,6 +199,13 @@ class EventExp(BaseExp):
         """reference: event_yolox_base.py:509-534.  ``eval_proph`` (the Prophesee metric toolbox on real Gen1 / 1 Mpx recordings) has no
         counterpart here: its inference loop is the same one (psee_evaluator.py:180-215), its metric code needs the datasets."""
         from yolox.evaluators import EventEvaluator
+        if 'gen' in str(self.data_name) and self.eval_proph not in (False, 'False', None, 0):
+            # the README's eval line (readme.md:157-160, --eval_proh) selects PSEEEvaluator there: say so instead of substituting silently
+            import warnings
+            warnings.warn('eval_proph is set: the reference would build PSEEEvaluator (Prophesee metric toolbox, event_yolox_base.py:512-523). '
+                          'Its metric code is outside this package (it needs the toolbox and the real Gen1 / 1 Mpx label files); this run uses '
+                          'EventEvaluator -- the same inference loop, timers and detection records, COCO-style AP instead of the toolbox\'s.',
+                          RuntimeWarning, stacklevel=2)
         return EventEvaluator(dataloader=self.get_eval_loader(batch_size, is_distributed, testdev=testdev, legacy=legacy),
                               img_size=self.test_size, confthre=self.test_conf, nmsthre=self.nmsthre, num_classes=self.num_classes,
                               testdev=testdev, snn_reset=self.use_spike)

@@ -178,6 +178,8 @@ class YOLOXHead(nn.Module):
         n = len(xs)
         if not (G.ENABLED and self.training and not self.full_spike and 1 < n <= 4 and torch.is_grad_enabled()):
             return None
+        if os.environ.get('EAS_NO_DUAL') or os.environ.get('EAS_NO_ANN_DUAL'):      # development switches of the per-level path: honoured by running it
+            return None
         blocks = []
         for k in range(n):
             cc, rc = self.cls_convs[k], self.reg_convs[k]
@@ -237,7 +239,9 @@ class YOLOXHead(nn.Module):
             if raws is None:
                 raws = [self._level(k, x) for k, x in enumerate(feats)]
             regs, objs, clss = [r[0] for r in raws], [r[1] for r in raws], [r[2] for r in raws]
-            if ops.det_loss_supported(regs, labels, self.iou_loss.loss_type):
+            fused = ops.det_loss_supported(regs, labels, self.iou_loss.loss_type)
+            self.__dict__['_eas_fused_loss_used'] = bool(fused)
+            if fused:
                 # decode + assignment + loss terms + their gradient in five launches (ops.det_loss)
                 return ops.det_loss(regs, objs, clss, labels, self.strides, self.num_classes, self.use_l1)
         else:

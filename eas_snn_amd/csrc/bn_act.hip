@@ -339,7 +339,7 @@ int eas_bn_silu_bwd(const float* grad_out, const float* y, const float* mean, co
     {
         // one block per channel where a channel fits the registers of a block (see bn_silu_bwd_small_kernel); EAS_BNSILU_BWD=two keeps
         // the two-pass launches (development)
-        static const bool small_ok = !(getenv("EAS_BNSILU_BWD") && getenv("EAS_BNSILU_BWD")[0] == 't');
+        static const bool small_ok = !(eas_dev_env("EAS_BNSILU_BWD") && eas_dev_env("EAS_BNSILU_BWD")[0] == 't');
         constexpr int GPT = 6;
         const int64_t groups = (int64_t)N * (HW / VEC);
         if (small_ok && C >= 64 && groups <= 1024 * GPT) {

@@ -694,7 +694,7 @@ int launch_bwd_t(const float* grad_s, const float* grad_mean, const float* y, co
     // Channel groups (EAS_BNLIF_BWD_GROUP_MB, development; 0 = one pair of launches for the whole layer): the pair runs group by group with
     // at most that many MB of y + grad_s per group, so that the apply pass of a group re-reads what its sum pass has just read while it is
     // still in the 256 MB Infinity Cache.
-    static const int group_mb = getenv("EAS_BNLIF_BWD_GROUP_MB") ? atoi(getenv("EAS_BNLIF_BWD_GROUP_MB")) : 0;
+    static const int group_mb = eas_dev_env("EAS_BNLIF_BWD_GROUP_MB") ? atoi(eas_dev_env("EAS_BNLIF_BWD_GROUP_MB")) : 0;
     int gc = C;
     if (group_mb > 0) {
         const double per_channel = (double)N * HW * 4.0 * ((bcast ? 1 : T_) + T_);

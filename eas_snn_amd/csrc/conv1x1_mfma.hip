@@ -627,7 +627,7 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
     // least ~2 blocks per CU (x is re-read from L2 by more channel groups, which these small layers can afford).
     int wm = g.MT >= 4 ? 4 : (g.MT >= 2 ? 2 : 1), wn = 2;
     auto blocks = [&](int m, int n) { return (long)((g.total_tiles + 4 * n - 1) / (4 * n)) * ((g.MT + m - 1) / m); };
-    static const long want = getenv("EAS_C1_BLOCKS") ? atol(getenv("EAS_C1_BLOCKS")) : 512;
+    static const long want = eas_dev_env("EAS_C1_BLOCKS") ? atol(eas_dev_env("EAS_C1_BLOCKS")) : 512;
     if (blocks(wm, wn) < want) wn = 1;
     while (blocks(wm, wn) < want && wm > 1) wm >>= 1;
     if (bna && (PL || x_terms != 3 || Cin % 8 != 0)) return EAS_ERR_UNSUPPORTED;     // the BatchNorm + activation epilogue: real-valued fp32 inputs
@@ -642,11 +642,11 @@ static int conv1x1_dispatch_t(const float* x, const void* packed_w, const float*
         return g.MT >= 2 ? launch_c1<3, 2, 1, true>(x, wp, bias, y, g, st) : launch_c1<3, 1, 1, true>(x, wp, bias, y, g, st);
     }
     // many input channels (>= 256): weight-fragment traffic, not HBM, bounds the direct kernel -> block-shared fragments
-    static const int shared_min = getenv("EAS_C1_SHARED_MIN_CIN") ? atoi(getenv("EAS_C1_SHARED_MIN_CIN")) : 256;
+    static const int shared_min = eas_dev_env("EAS_C1_SHARED_MIN_CIN") ? atoi(eas_dev_env("EAS_C1_SHARED_MIN_CIN")) : 256;
     if (Cin >= shared_min && g.MT >= 4) {
         // wave tile of the shared form: shrink it while the grid has fewer than ~2 blocks per CU
         int sm = 4, sn = 2;
-        static const char* force = getenv("EAS_C1_SHARED_SHAPE");     // development: "42", "41", "22", "21"
+        static const char* force = eas_dev_env("EAS_C1_SHARED_SHAPE");     // development: "42", "41", "22", "21"
         if (force) { sm = force[0] - '0'; sn = force[1] - '0'; }
         else {
             constexpr long want_s = 384;       // swept on the dark4 / dark5 shapes (scripts/dev_conv.py c1time)
@@ -724,7 +724,7 @@ int eas_conv1x1_lif_dispatch(const void* x, const void* packed_w, const EasLifEp
     // channel tiles per wave: two (T = 3: 6 accumulator tiles, T = 5: 10; four M-tiles x 3 steps spill) while the grid keeps ~2 blocks per CU
     int wm = g.MT >= 2 ? 2 : 1;
     while (wm > 1 && blocks(wm) < 512) wm >>= 1;
-    static const int shared_min = getenv("EAS_C1_SHARED_MIN_CIN") ? atoi(getenv("EAS_C1_SHARED_MIN_CIN")) : 256;
+    static const int shared_min = eas_dev_env("EAS_C1_SHARED_MIN_CIN") ? atoi(eas_dev_env("EAS_C1_SHARED_MIN_CIN")) : 256;
     if (Cin >= shared_min && g.MT >= 2 && wm >= 2)
         return lif.T == 3 ? launch_c1_lif<2, 3, true>(xf, wp, g, st, query) : launch_c1_lif<2, 5, true>(xf, wp, g, st, query);
     if (lif.T == 3) return wm == 2 ? launch_c1_lif<2, 3, false>(xf, wp, g, st, query) : launch_c1_lif<1, 3, false>(xf, wp, g, st, query);
@@ -1070,7 +1070,7 @@ W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW, int x_terms, bool p
     else res = x_terms == 1 ? EAS_W1R_SHAPE(1, false) : EAS_W1R_SHAPE(3, false);
 #undef EAS_W1R_SHAPE
 #undef EAS_W1R
-    static const int force = getenv("EAS_W1_BLOCKS") ? atoi(getenv("EAS_W1_BLOCKS")) : 0;      // development: the old rule with this target
+    static const int force = eas_dev_env("EAS_W1_BLOCKS") ? atoi(eas_dev_env("EAS_W1_BLOCKS")) : 0;      // development: the old rule with this target
     int best = 1;
     if (force > 0) {
         best = (force + yz - 1) / yz;

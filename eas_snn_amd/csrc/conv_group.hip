@@ -96,7 +96,7 @@ template <int XT>
 int plan_group3(const EasConvProblem* pr, int n, ConvGroupArgs& a, int& best, int& grid_y, size_t& lds, int* nb_out) {
     static const GCand cands[4] = {{4, 1, 5, 2, launch_group3<XT, 5, 4, 1, 2>}, {2, 2, 5, 2, launch_group3<XT, 5, 2, 2, 2>},
                                    {4, 1, 3, 2, launch_group3<XT, 3, 4, 1, 2>}, {2, 2, 3, 2, launch_group3<XT, 3, 2, 2, 2>}};
-    static const int force = getenv("EAS_GROUP3_TILE") ? atoi(getenv("EAS_GROUP3_TILE")) : -1;      // development: force a candidate
+    static const int force = eas_dev_env("EAS_GROUP3_TILE") ? atoi(eas_dev_env("EAS_GROUP3_TILE")) : -1;      // development: force a candidate
     best = -1;
     double best_cost = 0.0;
     ConvGroupArgs best_a = a;

@@ -32,7 +32,7 @@ int dispatch_tile_lif(const float* x, const bf16x8* wp, ConvGeom g, hipStream_t 
     double best_cost = 0.0;
     int best_rank = 0;
     ConvGeom best_g = g;
-    static const int force = getenv("EAS_LIF_TILE") ? atoi(getenv("EAS_LIF_TILE")) : -1;      // development: force a candidate
+    static const int force = eas_dev_env("EAS_LIF_TILE") ? atoi(eas_dev_env("EAS_LIF_TILE")) : -1;      // development: force a candidate
     for (int i = 0; i < ncand; ++i) {
         const Cand& c = cands[i];
         if (force >= 0 && i != force) continue;
@@ -80,7 +80,7 @@ int dispatch_tile_lif(const float* x, const bf16x8* wp, ConvGeom g, hipStream_t 
     }
     if (best < 0) return EAS_ERR_UNSUPPORTED;
     if (query) return EAS_OK;
-    static const bool dbg = getenv("EAS_LIF_DBG") != nullptr;
+    static const bool dbg = eas_dev_env("EAS_LIF_DBG") != nullptr;
     if (dbg)
         fprintf(stderr, "lif tile: LM %d T %d N %d %dx%d Cin %d Cout %d S %d -> cand %d (wvm %d wvn %d wn %d) RT %d nseg %d Q %d lds %zu blocks %ld\n", LM, T, g.NI,
                 g.Ho, g.Wo, g.Cin, g.Cout, S, best, cands[best].wvm, cands[best].wvn, cands[best].wn, best_g.RT, best_g.nseg, best_g.Q,
@@ -151,7 +151,7 @@ static int conv_lif_impl(const EasConvBnLifEval* d, eas_stream_t stream, bool qu
         g.total_rows = N * Ho;
         g.Wst = Wi; g.gx0 = 0; g.qshift = 0; g.parts = 1;
         g.lif = lif;
-        static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
+        static const int dbg = eas_dev_env("EAS_CONV_DBG") ? atoi(eas_dev_env("EAS_CONV_DBG")) : 0;
         g.dbg = dbg;
         const bf16x8* wp = (const bf16x8*)d->packed_w;
         const float* x = (const float*)d->x;

@@ -261,7 +261,7 @@ int eas_conv_pack_weights(const float* w, void* packed, int Cout, int Cin, int k
 int eas_conv_pack_weights_many(const void* jobs, int njobs, eas_stream_t stream) {
     if (!jobs || njobs < 1) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    static const bool flat = !(getenv("EAS_PACK_FORM") && getenv("EAS_PACK_FORM")[0] == 'j');      // EAS_PACK_FORM=jobs: 24 blocks per job (development)
+    static const bool flat = !(eas_dev_env("EAS_PACK_FORM") && eas_dev_env("EAS_PACK_FORM")[0] == 'j');      // EAS_PACK_FORM=jobs: 24 blocks per job (development)
     if (flat && njobs <= kPackJobsMax)
         EAS_LAUNCH(conv_pack_weights_flat_kernel, dim3(2048), dim3(256), 0, eas_s(stream), (const long long*)jobs, njobs);
     else
@@ -302,7 +302,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
         // 4.0 -> 2.0); costs 14 more staged (zero) columns per row.  Measured (same box): config 2 unchanged (21.23 / 21.24 ms without,
         // 21.24 / 21.20 ms with), config 3 SLOWER (45.19 -> 46.7 ms: the wider patches of the 96 / 192-channel layers cost a resident block) --
         // the LDS pipe is not what these kernels wait for.  Off by default; EAS_CONV_RS_PAD=1: the padded rows.
-        static const int rs_pad = getenv("EAS_CONV_RS_PAD") ? atoi(getenv("EAS_CONV_RS_PAD")) : 0;
+        static const int rs_pad = eas_dev_env("EAS_CONV_RS_PAD") ? atoi(eas_dev_env("EAS_CONV_RS_PAD")) : 0;
         if (rs_pad && ksize == 3 && stride == 1 && g.Wo % 32 != 0) g.RS += (16 - ((g.RS - g.Wo) % 16)) % 16;
     }
     g.pad_t = g.pad_l = pad;
@@ -313,7 +313,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
     g.KSTEPS = (Cin + 15) / 16;
     g.total_rows = NI * g.Ho;
     g.Wst = Wi; g.gx0 = 0; g.qshift = 0; g.parts = 1;
-    static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
+    static const int dbg = eas_dev_env("EAS_CONV_DBG") ? atoi(eas_dev_env("EAS_CONV_DBG")) : 0;
     g.dbg = dbg;
     g.stats = stats; g.stats_nb = stats_nb;
     g.act = act;
@@ -331,7 +331,7 @@ static int conv_fwd_impl(const float* x, const void* packed_w, const float* bias
                       : (v4 ? dispatch_tile<TAPS_, S_, 3, CCH_, 4>(x, wp, bias, y, inexact_flag, g, st)                           \
                             : dispatch_tile<TAPS_, S_, 3, CCH_, 2>(x, wp, bias, y, inexact_flag, g, st))
     const ConvGeom g_full = g;
-    static const int force_parts = getenv("EAS_CONV_PARTS") ? atoi(getenv("EAS_CONV_PARTS")) : 0;   // development: force column parts
+    static const int force_parts = eas_dev_env("EAS_CONV_PARTS") ? atoi(eas_dev_env("EAS_CONV_PARTS")) : 0;   // development: force column parts
     for (int parts = force_parts > 0 ? force_parts : 1; parts <= 8 && rc == EAS_ERR_UNSUPPORTED && ksize == 3; parts *= 2) {
         g = g_full;
         if (parts > 1) {
@@ -442,7 +442,7 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
     if (Cout % 8 != 0 || Wo % 2 != 0) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     hipStream_t st = eas_s(stream);
-    static const int dbg = getenv("EAS_CONV_DBG") ? atoi(getenv("EAS_CONV_DBG")) : 0;
+    static const int dbg = eas_dev_env("EAS_CONV_DBG") ? atoi(eas_dev_env("EAS_CONV_DBG")) : 0;
     const int MT = (Cin + 31) / 32, KSTEPS = (Cout + 15) / 16;
     const int cum[4] = {0, 1, 3, 5};
     const bool v4 = Wo % 4 == 0;
@@ -463,7 +463,7 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
         g.dbg = dbg;
         sg.wp[cls] = (const bf16x8*)packed_w + (size_t)3 * MT * KSTEPS * 64 * cum[cls];
     }
-    static const int one_launch = getenv("EAS_S2_FORM") ? (getenv("EAS_S2_FORM")[0] == '1') : 1;   // development: 0 = four launches
+    static const int one_launch = eas_dev_env("EAS_S2_FORM") ? (eas_dev_env("EAS_S2_FORM")[0] == '1') : 1;   // development: 0 = four launches
     if (one_launch) {
         // one block shape for the four classes, a tile geometry per class (their staged patches differ: taps, channel chunk)
         typedef int (*s2_fn)(const float*, float*, S2Geoms, hipStream_t);

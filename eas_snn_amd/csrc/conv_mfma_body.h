@@ -535,15 +535,15 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
     double best_cost = 0.0;
     int best_valid = 0;
     ConvGeom best_g = g;
-    static const int force = getenv("EAS_CONV_TILE") ? atoi(getenv("EAS_CONV_TILE")) : -1;   // development: force a candidate
-    static const int ncand = getenv("EAS_CONV_NCAND") ? atoi(getenv("EAS_CONV_NCAND")) : 14;  // development: 7 = the 160-pixel wave tiles only
+    static const int force = eas_dev_env("EAS_CONV_TILE") ? atoi(eas_dev_env("EAS_CONV_TILE")) : -1;   // development: force a candidate
+    static const int ncand = eas_dev_env("EAS_CONV_NCAND") ? atoi(eas_dev_env("EAS_CONV_NCAND")) : 14;  // development: 7 = the 160-pixel wave tiles only
     const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
     // Single-buffered patch (mode 1): for layers of few channel chunks whose double-buffered patch fills the LDS (real-valued inputs on wide
     // rows: dark2.0, 135 -> 103 us) -- the second buffer buys one overlapped stage there, a second resident block overlaps everything.
     // With more chunks the exposed write of every chunk costs more than it gains (4 chunks: 100 -> 122 us, 8: 125 -> 154 us); three
     // chunks (the 48-channel layers of SYOLOX-M) still gain: config 4 88.0 -> 87.5 ms.
-    static const int single_nch = getenv("EAS_CONV_SINGLE_NCH") ? atoi(getenv("EAS_CONV_SINGLE_NCH")) : 3;      // development: 0 = never
-    static const double single_pen = getenv("EAS_CONV_SINGLE_PEN") ? atof(getenv("EAS_CONV_SINGLE_PEN")) : 1.1;
+    static const int single_nch = eas_dev_env("EAS_CONV_SINGLE_NCH") ? atoi(eas_dev_env("EAS_CONV_SINGLE_NCH")) : 3;      // development: 0 = never
+    static const double single_pen = eas_dev_env("EAS_CONV_SINGLE_PEN") ? atof(eas_dev_env("EAS_CONV_SINGLE_PEN")) : 1.1;
     for (int i = 0; i < ncand; ++i)
       for (int mode = 0; mode < 2; ++mode) {
         const Cand& c = cands[i];
@@ -580,7 +580,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         // a step's MFMAs (3 * WN with one-term inputs, 6 * WN with three) hide the ~450-cycle latency of the next step's weight
         // fragments only when they last that long: with spike inputs a 3-tile wave (288 MFMA cycles per step) waits on every step and
         // costs nearly as much as a 5-tile wave (dark5.m.conv2: 71 us against 62 us for the 160-pixel shape the old model ranked behind)
-        static const double lat = getenv("EAS_CONV_STEP_LAT") ? atof(getenv("EAS_CONV_STEP_LAT")) : 450.0;   // development
+        static const double lat = eas_dev_env("EAS_CONV_STEP_LAT") ? atof(eas_dev_env("EAS_CONV_STEP_LAT")) : 450.0;   // development
         const double per_tile = XT == 1 ? 96.0 : 192.0;
         const double mfma_part = (c.wn * per_tile > lat ? c.wn * per_tile : lat) / (5.0 * per_tile);
         const double round_cost = (c.threads == 512 ? 1.27 : (bpc == 2 && blocks > 256 ? 1.2 : 1.0)) * (0.3 + 0.7 * mfma_part) *
@@ -590,7 +590,7 @@ int dispatch_tile(const float* x, const bf16x8* wp, const float* bias, float* y,
         // (they share one staged pixel patch: the smaller patch per block is the shorter prologue; 8x10 head layers: 35-38 us against
         // 44-50 us for the four-pixel-group shape)
         const int valid = t.RT * g.Wo;
-        static const int tie_wvm = getenv("EAS_CONV_TIE_WVM") ? atoi(getenv("EAS_CONV_TIE_WVM")) : 1;        // development: 0 = lone blocks only
+        static const int tie_wvm = eas_dev_env("EAS_CONV_TIE_WVM") ? atoi(eas_dev_env("EAS_CONV_TIE_WVM")) : 1;        // development: 0 = lone blocks only
         const int rank = ((blocks <= 256 || tie_wvm) ? c.wvm * 4096 : 0) + (valid < 4096 ? valid : 4095);
         if (best < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rank > best_valid)) {
             best = i; best_cost = cost; best_valid = rank; best_g = t;

@@ -563,7 +563,7 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
     const int nbg = PN == 1 && g.Cin < 32 ? (g.Cin + 7) / 8 : 4 * PN;
     const int nitems = (TP / VEC) * 4 * PM + g.nseg * g.rows_in * (g.Wst / VEC) * nbg;
     if (lds > 160 * 1024 || nitems > (PM * PN == 4 ? 1 : 2) * NT) {
-        if (getenv("EAS_CONV_DBG")) fprintf(stderr, "wgrad launch: lds %zu nitems %d NT %d PM %d PN %d VEC %d RT %d Q %d\n", lds, nitems, NT, PM, PN, VEC, g.RT, g.Q);
+        if (eas_dev_env("EAS_CONV_DBG")) fprintf(stderr, "wgrad launch: lds %zu nitems %d NT %d PM %d PN %d VEC %d RT %d Q %d\n", lds, nitems, NT, PM, PN, VEC, g.RT, g.Q);
         return EAS_ERR_UNSUPPORTED;
     }
     if constexpr (XT == 1) {
@@ -619,7 +619,7 @@ WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts
     const int slots = 256 * (resident > 0 ? resident : 1);
     const int step = parts > 1 ? parts : 1;
     int best = step;
-    static const double pen = getenv("EAS_WG_SHARE_PEN") ? atof(getenv("EAS_WG_SHARE_PEN")) : 0.0;      // development
+    static const double pen = eas_dev_env("EAS_WG_SHARE_PEN") ? atof(eas_dev_env("EAS_WG_SHARE_PEN")) : 0.0;      // development
     const int res1 = resident > 0 ? resident : 1;
     double best_cost = -1.0;
     for (int ks = step; ks <= ntiles && (long)ks * yz <= 4L * slots; ks += step) {
@@ -664,8 +664,8 @@ bool wg_geom_cap(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int strid
 // largest tile (<= 80 output pixels) whose double-buffered images and staging items fit the block; whole rows first, then 2, 4
 // and 8 column parts per row
 bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, int x_terms) {
-    static const int force_parts = getenv("EAS_WG_PARTS") ? atoi(getenv("EAS_WG_PARTS")) : 0;      // development switch
-    static const int pn2_s2 = getenv("EAS_WG_PN2_S2") ? atoi(getenv("EAS_WG_PN2_S2")) : 1;       // development switch
+    static const int force_parts = eas_dev_env("EAS_WG_PARTS") ? atoi(eas_dev_env("EAS_WG_PARTS")) : 0;      // development switch
+    static const int pn2_s2 = eas_dev_env("EAS_WG_PN2_S2") ? atoi(eas_dev_env("EAS_WG_PN2_S2")) : 1;       // development switch
     for (int parts = force_parts > 0 ? force_parts : 1; parts <= 8; parts *= 2) {
         for (int cap = TP; cap >= 8; cap /= 2)
           for (int pn = (Cin >= 64 && x_terms == 1 && (stride == 1 || (pn2_s2 && cap == TP))) ? 2 : 1; pn >= 1; --pn) {
@@ -707,9 +707,9 @@ WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms
 #undef EAS_RS
     // single-buffered LDS where the double-buffered tile leaves ONE block per CU and half of it two: the second block overlaps everything
     // the first one waits for, which a second buffer inside one 6- or 12-wave block cannot (a tile's write is exposed instead: +15 %)
-    static const int single_env = getenv("EAS_WG_SINGLE") ? atoi(getenv("EAS_WG_SINGLE")) : -1;      // development: 0 never, 1 whenever it fits twice
+    static const int single_env = eas_dev_env("EAS_WG_SINGLE") ? atoi(eas_dev_env("EAS_WG_SINGLE")) : -1;      // development: 0 never, 1 whenever it fits twice
     single = 0;
-    static const int single_cap = getenv("EAS_WG_SINGLE_CAP") ? atoi(getenv("EAS_WG_SINGLE_CAP")) : 2;       // development
+    static const int single_cap = eas_dev_env("EAS_WG_SINGLE_CAP") ? atoi(eas_dev_env("EAS_WG_SINGLE_CAP")) : 2;       // development
     // (measured: 3-wave blocks -- layers of fewer than 64 output channels on the big maps -- gain 20-30 %: real-input 48 -> 48 channels at
     // 64x80 699 -> 496 us; 6- and 12-wave blocks lose 5-8 %: they already keep the SIMDs' issue slots busy and the exposed write costs more)
     if (single_env != 0 && res == 1 && (p0.pm * p0.pn == 1 || single_env == 1)) {

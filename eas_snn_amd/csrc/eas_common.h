@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/eas_hip.h"
 
@@ -21,14 +22,27 @@ static inline hipStream_t eas_s(eas_stream_t s) { return reinterpret_cast<hipStr
 // Kernel-instance trace (eas_kernel_trace_begin / _dump, capi.hip): while it is on, every launch of the library records the symbol of
 // the device kernel it starts -- the names rocprofv3 reports.  tests/test_gpu_bench_shapes.py uses it to prove that every kernel
 // instance a bench step launches is also launched by a test that compares with fp64 / the oracle.  One predictable branch when off.
-extern int eas_trace_on;
-void eas_trace_kernel(const void* host_function);
+// Both library-internal (hidden visibility: not part of the ABI; eas_launch_counter() reads the count).
+__attribute__((visibility("hidden"))) extern int eas_trace_on;
+__attribute__((visibility("hidden"))) extern long long eas_launch_count;      // every kernel launch of the library since it was loaded
+__attribute__((visibility("hidden"))) void eas_trace_kernel(const void* host_function);
 #define EAS_LAUNCH(kern, ...)                                                \
     do {                                                                     \
         auto eas_kern_ = (kern);                                             \
+        ++eas_launch_count;                                                  \
         if (eas_trace_on) eas_trace_kernel((const void*)eas_kern_);          \
         hipLaunchKernelGGL(eas_kern_, __VA_ARGS__);                          \
     } while (0)
+
+// Development switches (tile / plan overrides, ablations: EAS_CONV_TILE, EAS_WG_SINGLE, EAS_CONV_DBG, ... -- INTEGRATION.md lists them) are read
+// from the environment only in a development build (make DEV=1 -> -DEAS_DEV); the default library has no hidden state of that kind: the
+// expression folds to "not set".  Three switches select between kernel FORMS that are all product code and stay readable by the tests in
+// every build: EAS_HIST_FORM, EAS_BNLIF_BWD, EAS_SW_FORM.
+#ifdef EAS_DEV
+#define eas_dev_env(name) getenv(name)
+#else
+#define eas_dev_env(name) ((const char*)nullptr)
+#endif
 
 // memory-bound grids: cap at 256 CUs x 8 blocks and grid-stride the rest
 static inline int eas_grid_1d(int64_t work_items, int block = EAS_BLOCK, int max_blocks = 2048 * 4) {

@@ -1162,155 +1162,6 @@ def bn_silu(y, bn, cat=None):
     return _BNSiLUFn.apply(y, bn.weight, bn.bias, state)
 
 
-# ------------------------------------------------------------------------------------------------ K1
-def event_histogram(t, x, y, p, sample_offsets, Tm, H, W, return_oob=False):
-    """Per-sample micro-slice count frames: int32 [B, Tm, 2, H, W] (bit-exact 'micro_sum')."""
-    _dev(t, x, y, p, sample_offsets)
-    assert t.dtype == torch.uint32 or t.dtype == torch.int32, 't must be 32-bit timestamps'
-    assert x.dtype in (torch.uint16, torch.int16) and y.dtype in (torch.uint16, torch.int16) and p.dtype in (torch.uint8, torch.int8)
-    assert sample_offsets.dtype == torch.int64
-    B = sample_offsets.numel() - 1
-    out = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=t.device)
-    oob = torch.empty(1, dtype=torch.int32, device=t.device) if return_oob else None
-    _call('eas_event_histogram', 9 * t.numel() + 4 * out.numel(), _lib.lib().eas_event_histogram, ptr(t), ptr(x), ptr(y), ptr(p),
-          t.numel(), ptr(sample_offsets), B, Tm, H, W, ptr(out), ptr(oob), stream())
-    return (out, oob) if return_oob else out
-
-
-def event_histogram_dat(records, sample_offsets, Tm, H, W, return_oob=False):
-    """Count frames int32 [B, Tm, 2, H, W] straight from .dat records: ``records`` is the raw byte image of the events
-    (uint8 [8*nev], or any 8-byte-record view) already on the device; decode + binning happen in one kernel."""
-    _dev(records, sample_offsets)
-    assert sample_offsets.dtype == torch.int64
-    rec = records.contiguous().view(torch.uint8)
-    assert rec.numel() % 8 == 0, '.dat event records are 8 bytes'
-    nev = rec.numel() // 8
-    B = sample_offsets.numel() - 1
-    out = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=rec.device)
-    oob = torch.empty(1, dtype=torch.int32, device=rec.device) if return_oob else None
-    _call('eas_event_histogram_dat', 8 * nev + 4 * out.numel(), _lib.lib().eas_event_histogram_dat, ptr(rec), nev, ptr(sample_offsets), B, Tm,
-          H, W, ptr(out), ptr(oob), stream())
-    return (out, oob) if return_oob else out
-
-
-def event_window_search(records, label_t, window, num_slice, file_offsets=None, file_id=None):
-    """Record ranges int64 [B, 2] of the events GEN1Dataset.search_events returns for every label (gen1.py:217-232), found on the
-    device.  records: the record area(s) of .dat recording(s) already in HBM (uint8 [8*nev] or any 8-byte-record view);
-    label_t int64 [B] label timestamps (us); window = (lo, hi) us relative to the label; file_offsets int64 [F+1] (record index of
-    every recording's first event; default: one recording) and file_id int32 [B]."""
-    _dev(records, label_t, file_offsets, file_id)
-    rec = records.contiguous().view(torch.uint8)
-    assert rec.numel() % 8 == 0 and label_t.dtype == torch.int64
-    nev = rec.numel() // 8
-    if file_offsets is None:
-        file_offsets = torch.tensor([0, nev], dtype=torch.int64, device=rec.device)
-    assert file_offsets.dtype == torch.int64 and (file_id is None or file_id.dtype == torch.int32)
-    B = label_t.numel()
-    ranges = torch.empty((B, 2), dtype=torch.int64, device=rec.device)
-    check(_lib.lib().eas_event_window_search(ptr(rec), ptr(file_offsets.contiguous()), file_offsets.numel() - 1,
-                                             ptr(file_id.contiguous() if file_id is not None else None), ptr(label_t.contiguous()), B,
-                                             int(window[0]), int(window[1]), int(num_slice), ptr(ranges), stream()), 'eas_event_window_search')
-    return ranges
-
-
-def event_histogram_dat_ranges(records, ranges, Tm, H, W, return_oob=False):
-    """Count frames int32 [B, Tm, 2, H, W] of the record ranges [B, 2] (``event_window_search``) of a .dat image in HBM: label
-    timestamps in, frames out, nothing read back to the host in between."""
-    _dev(records, ranges)
-    rec = records.contiguous().view(torch.uint8)
-    assert ranges.dtype == torch.int64 and ranges.dim() == 2 and ranges.shape[1] == 2
-    B = ranges.shape[0]
-    out = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=rec.device)
-    oob = torch.empty(1, dtype=torch.int32, device=rec.device) if return_oob else None
-    _call('eas_event_histogram_dat', 8 * (rec.numel() // 8) + 4 * out.numel(), _lib.lib().eas_event_histogram_dat_ranges, ptr(rec),
-          ptr(ranges.contiguous()), B, Tm, H, W, ptr(out), ptr(oob), stream())
-    return (out, oob) if return_oob else out
-
-
-def event_frames(t, x, y, p, sample_offsets, Tm, H, W, Hc, Wc):
-    """raw events -> fp32 count frames on the zero-padded model canvas [B, Tm, 2, Hc, Wc] in one call (K1 + canvas)."""
-    _dev(t, x, y, p, sample_offsets)
-    B = sample_offsets.numel() - 1
-    out = torch.empty((B, Tm, 2, Hc, Wc), dtype=torch.float32, device=t.device)
-    scratch = torch.empty((B, Tm, 2, H, W), dtype=torch.int32, device=t.device)
-    _call('eas_event_histogram', 9 * t.numel() + 4 * out.numel(), _lib.lib().eas_event_frames, ptr(t), ptr(x), ptr(y), ptr(p), t.numel(),
-          ptr(sample_offsets), B, Tm, H, W, Hc, Wc, ptr(out), ptr(scratch), None, stream())
-    return out
-
-
-def stacked_hist_event_sum(hist, Hc, Wc, nbins=10, n_valid=None):
-    """RVT stacked histogram u8 [B, Tm, 2*nbins, H, W] -> fp32 model input [B, 1, Tm, 2, Hc, Wc]: sum over the time bins of each
-    polarity, zero padded to the canvas (RVTGEN4Dataset.generate_slices 'event_sum' + validation letterbox, rvt_gen4.py:109-125,
-    516-533).  n_valid int32 [B]: samples that supply only their first n_valid[b] slices (zero slices in front)."""
-    _dev(hist, n_valid)
-    assert hist.dtype == torch.uint8 and hist.dim() == 5 and hist.shape[2] == 2 * nbins
-    hist = hist.contiguous()
-    B, Tm, _, H, W = hist.shape
-    if n_valid is not None:
-        assert n_valid.dtype == torch.int32 and n_valid.shape == (B,)
-        n_valid = n_valid.contiguous()
-    out = torch.empty((B, 1, Tm, 2, Hc, Wc), dtype=torch.float32, device=hist.device)
-    _call('eas_stacked_hist_event_sum', hist.numel() + 4 * out.numel(), _lib.lib().eas_stacked_hist_event_sum, ptr(hist), ptr(n_valid), B, Tm,
-          int(nbins), H, W, Hc, Wc, ptr(out), stream())
-    return out
-
-
-def counts_to_canvas(counts, Hc, Wc):
-    """int32 [..., H, W] -> float32 [..., Hc, Wc], zero padded bottom/right."""
-    _dev(counts)
-    assert counts.dtype == torch.int32
-    counts = counts.contiguous()
-    H, W = counts.shape[-2:]
-    F = counts.numel() // (H * W)
-    out = torch.empty(counts.shape[:-2] + (Hc, Wc), dtype=torch.float32, device=counts.device)
-    check(_lib.lib().eas_counts_to_canvas(ptr(counts), F, H, W, Hc, Wc, ptr(out), stream()), 'eas_counts_to_canvas')
-    return out
-
-
-def counts_letterbox(counts, params, Hc, Wc):
-    """int32 counts [B, ..., H, W] -> fp32 [B, ..., Hc, Wc]: per-sample resize (cv2 INTER_LINEAR semantics) to (nw, nh), paste at
-    (dx, dy), optional left-right flip; ``params`` int32 [B, 5] = (nw, nh, dx, dy, flip) (see data.letterbox_params / jitter_params)."""
-    _dev(counts, params)
-    assert counts.dtype == torch.int32 and params.dtype == torch.int32 and params.shape == (counts.shape[0], 5)
-    counts, params = counts.contiguous(), params.contiguous()
-    B, (H, W) = counts.shape[0], counts.shape[-2:]
-    F = counts.numel() // (B * H * W)
-    out = torch.empty(counts.shape[:-2] + (Hc, Wc), dtype=torch.float32, device=counts.device)
-    check(_lib.lib().eas_counts_letterbox(ptr(counts), ptr(params), B, F, H, W, Hc, Wc, ptr(out), stream()), 'eas_counts_letterbox')
-    return out
-
-
-def event_voxel_grid(t, x, y, p, sample_offsets, n_bins, H, W):
-    """float64 [B, n_bins, 1, H, W] bilinear-in-time voxel grid."""
-    _dev(t, x, y, p, sample_offsets)
-    B = sample_offsets.numel() - 1
-    out = torch.empty((B, n_bins, 1, H, W), dtype=torch.float64, device=t.device)
-    check(_lib.lib().eas_event_voxel_grid(ptr(t), ptr(x), ptr(y), ptr(p), t.numel(), ptr(sample_offsets), B, n_bins, H, W,
-                                          ptr(out), stream()), 'eas_event_voxel_grid')
-    return out
-
-
-def event_voxel_cube(t, x, y, p, sample_offsets, num_slices, H, W, tbins=2):
-    """int32 [B, num_slices, 2*tbins, H, W] voxel-cube counts (the reference returns them as float64)."""
-    _dev(t, x, y, p, sample_offsets)
-    B = sample_offsets.numel() - 1
-    out = torch.empty((B, num_slices, 2 * tbins, H, W), dtype=torch.int32, device=t.device)
-    check(_lib.lib().eas_event_voxel_cube(ptr(t), ptr(x), ptr(y), ptr(p), t.numel(), ptr(sample_offsets), B, num_slices, tbins, H, W,
-                                          ptr(out), stream()), 'eas_event_voxel_cube')
-    return out
-
-
-def event_time_surface(t, x, y, p, sample_offsets, num_slices, H, W, tau=50e3):
-    """float64 [B, num_slices, 2, H, W] exponential time surfaces at the end of every micro-slice."""
-    _dev(t, x, y, p, sample_offsets)
-    B = sample_offsets.numel() - 1
-    ws = torch.empty((B, num_slices, 2, H, W), dtype=torch.int32, device=t.device)
-    out = torch.empty((B, num_slices, 2, H, W), dtype=torch.float64, device=t.device)
-    check(_lib.lib().eas_event_time_surface(ptr(t), ptr(x), ptr(y), ptr(p), t.numel(), ptr(sample_offsets), B, num_slices, H, W,
-                                            float(tau), ptr(ws), ptr(out), stream()), 'eas_event_time_surface')
-    return out
-
-
 # ------------------------------------------------------------------------------------------------ K3
 def smallconv_pack(jobs):
     """Arrange sampler convolution weights for the vector-ALU kernels (eas_smallconv_pack_weights; up to 8 per launch).
@@ -2456,323 +2307,6 @@ def conv2d(x, conv, small_int=None):
     return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0], 1 if small_int else 3, packs, planes_of(x) if small_int else None)
 
 
-# ------------------------------------------------------------------------------------------------ SPP pooling block
-class _SPPFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, ks):
-        _dev(x)
-        x = _f32c(x)
-        lead, (Cc, H, W) = x.shape[:-3], x.shape[-3:]
-        N = x.numel() // (Cc * H * W)
-        out = torch.empty(lead + (4 * Cc, H, W), dtype=torch.float32, device=x.device)
-        _call('eas_spp_pool_fwd', 4 * 5 * x.numel(), _lib.lib().eas_spp_pool_fwd, ptr(x), ptr(out), N, Cc, H, W, ks[0], ks[1], ks[2], stream())
-        ctx.save_for_backward(x)
-        ctx.ks = ks
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        g = _f32c(g)
-        Cc, H, W = x.shape[-3:]
-        N = x.numel() // (Cc * H * W)
-        gx = torch.empty_like(x)
-        ks = ctx.ks
-        _call('eas_spp_pool_bwd', 4 * 6 * x.numel(), _lib.lib().eas_spp_pool_bwd, ptr(x), ptr(g), ptr(gx), N, Cc, H, W, ks[0], ks[1], ks[2],
-              stream())
-        return gx, None
-
-
-class _SPPPlanesFn(torch.autograd.Function):
-    """the SPP block on spike planes: ghost in (its planes), ghost out -- no fp32 copy of the spikes exists (eas_spp_pool_planes_fwd / _bwd)"""
-
-    @staticmethod
-    def forward(ctx, x, sp, ks):
-        lead, (Cc, H, W) = x.shape[:-3], x.shape[-3:]
-        N = 1
-        for d in lead:
-            N *= d
-        out_sp = torch.empty(tuple(lead) + (4 * Cc // 8, H * W, 8), dtype=torch.bfloat16, device=sp.device)
-        _call('eas_spp_pool_fwd', 2 * 5 * N * Cc * H * W, _lib.lib().eas_spp_pool_planes_fwd, ptr(sp), ptr(out_sp), N, Cc, H, W, ks[0], ks[1], ks[2],
-              stream())
-        ctx.save_for_backward(sp)
-        ctx.cfg = (ks, tuple(x.shape), N)
-        ctx.mark_non_differentiable(out_sp)
-        return ghost(tuple(lead) + (4 * Cc, H, W), sp.device), out_sp
-
-    @staticmethod
-    def backward(ctx, g, _g_sp):
-        (sp,) = ctx.saved_tensors
-        ks, shape, N = ctx.cfg
-        Cc, H, W = shape[-3:]
-        g = _f32c(g)
-        gx = torch.empty(shape, dtype=torch.float32, device=g.device)
-        _call('eas_spp_pool_bwd', 4 * 5 * gx.numel() + 2 * gx.numel(), _lib.lib().eas_spp_pool_planes_bwd, ptr(sp), ptr(g), ptr(gx), N, Cc, H, W,
-              ks[0], ks[1], ks[2], stream())
-        return gx, None, None
-
-
-def spp_pool_supported(x, ks):
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() in (4, 5) and len(ks) == 3 and all(k % 2 == 1 for k in ks) and (
-        x.shape[-1] * x.shape[-2] <= 1024)
-
-
-def spp_pool_cat(x, ks):
-    """cat[x, maxpool_k(x) for k in ks] along the channel axis of x [..., C, H, W] in one kernel (and one for the backward).  A ghost (spike
-    planes) stays one: packed 16-bit maxima over 16-byte pixels, and the backward reads x from the planes."""
-    sp = planes_of(x)
-    if sp is not None and x.shape[-3] % 8 == 0 and os.environ.get('EAS_SPP_PLANES', '1') == '1':
-        out, out_sp = _SPPPlanesFn.apply(x, sp.contiguous(), tuple(int(k) for k in ks))
-        out._eas_sp = out_sp
-        out._eas_small_int = True
-        return out
-    x = dense(x)
-    out = _SPPFn.apply(x, tuple(int(k) for k in ks))
-    if is_small_int(x):
-        mark_small_int(out)
-    return out
-
-
-# ------------------------------------------------------------------------------------------------ detections
-def postprocess_device(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
-    """(rows [B, A, 7], counts int32 [B]) on the device, no host synchronisation (eas_postprocess)."""
-    _dev(prediction)
-    pred = _f32c(prediction)
-    B, A, row = pred.shape
-    if row != 5 + num_classes:
-        raise ValueError(f'prediction rows have {row} columns, expected 5 + {num_classes}')
-    L = _lib.lib()
-    out = torch.empty((B, A, 7), dtype=torch.float32, device=pred.device)
-    cnt = torch.empty(B, dtype=torch.int32, device=pred.device)
-    ws = torch.empty(L.eas_postprocess_workspace_bytes(B, A), dtype=torch.uint8, device=pred.device)
-    check(L.eas_postprocess(ptr(pred), B, A, int(num_classes), float(conf_thre), float(nms_thre), int(bool(class_agnostic)), ptr(out),
-                            ptr(cnt), ptr(ws), stream()), 'eas_postprocess')
-    return out, cnt
-
-
-def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False):
-    """``yolox.utils.postprocess`` (boxes.py:33-77): list with one [n, 7] tensor per image (None where nothing is kept)."""
-    out, cnt = postprocess_device(prediction, num_classes, conf_thre, nms_thre, class_agnostic)
-    counts = cnt.tolist()                                   # the one host synchronisation: the result is a ragged python list
-    return [out[i, :n] if n else None for i, n in enumerate(counts)]
-
-
-def simota_supported(gt_valid, bbox_preds):
-    return bbox_preds.is_cuda and bbox_preds.dtype == torch.float32 and gt_valid.shape[1] <= 255 and bbox_preds.shape[1] <= 4096
-
-
-@torch.no_grad()
-def simota_assign(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds, obj_preds, cls_preds):
-    """SimOTA assignment for the whole batch in one launch (eas_simota_assign): (fg bool [B,A], matched int64 [B,A],
-    matched_iou float [B,A]) -- the outputs of YOLOXHead._assign."""
-    _dev(grids, strides, gt_boxes, gt_cls, gt_valid, bbox_preds, obj_preds, cls_preds)
-    B, A = bbox_preds.shape[:2]
-    G, nc = gt_valid.shape[1], cls_preds.shape[-1]
-    gr = _f32c(grids.reshape(-1, 2)[:A].float())
-    st = _f32c(strides.reshape(-1)[:A].float())
-    gb, gc = _f32c(gt_boxes.float()), _f32c(gt_cls.float())
-    gv = gt_valid.to(torch.uint8).contiguous()
-    bx, ob, cl = _f32c(bbox_preds.float()), _f32c(obj_preds.float().reshape(B, A)), _f32c(cls_preds.float())
-    fg = torch.empty((B, A), dtype=torch.uint8, device=bx.device)
-    matched = torch.empty((B, A), dtype=torch.int64, device=bx.device)
-    miou = torch.empty((B, A), dtype=torch.float32, device=bx.device)
-    check(_lib.lib().eas_simota_assign(ptr(gr), ptr(st), ptr(gb), ptr(gc), ptr(gv), ptr(bx), ptr(ob), ptr(cl), B, G, A, nc, ptr(fg),
-                                       ptr(matched), ptr(miou), stream()), 'eas_simota_assign')
-    return fg.bool(), matched, miou
-
-
-_ANCHOR_CACHE = {}
-
-
-def _anchor_tables(hws, strides, device):
-    """grids [A,2] and strides [A] of the head levels (cached per geometry and device)"""
-    key = (tuple(hws), tuple(float(s_) for s_ in strides), str(device))
-    t = _ANCHOR_CACHE.get(key)
-    if t is None:
-        gs, ss = [], []
-        for (h, w), s_ in zip(hws, strides):
-            yv, xv = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
-            gs.append(torch.stack((xv, yv), 2).reshape(-1, 2).float())
-            ss.append(torch.full((h * w,), float(s_)))
-        t = _ANCHOR_CACHE[key] = (torch.cat(gs).to(device), torch.cat(ss).to(device))
-    return t
-
-
-def _ptr_array(tensors):
-    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-
-
-class _DetLossFn(torch.autograd.Function):
-    """Decode + SimOTA assignment + loss terms + their gradient for the raw head maps of all levels: five launches forward
-    (eas_det_decode, eas_simota_assign_rows, eas_det_loss x2) plus a few tiny label ops, one multiply backward."""
-
-    @staticmethod
-    def forward(ctx, labels, strides, nc, use_l1, *raw):
-        ctx.set_materialize_grads(False)      # a result nobody differentiates arrives as None in backward, not as a zero tensor
-        L = len(raw) // 3
-        regs, objs, clss = [_f32c(t) for t in raw[0::3]], [_f32c(t) for t in raw[1::3]], [_f32c(t) for t in raw[2::3]]
-        _dev(labels, *regs)
-        lib = _lib.lib()
-        dev = regs[0].device
-        B = regs[0].shape[0]
-        hws = [tuple(r.shape[-2:]) for r in regs]
-        A = sum(h * w for h, w in hws)
-        hw_arr = (C.c_int * (2 * L))(*[v for hw in hws for v in hw])
-        st_arr = (C.c_float * L)(*[float(s_) for s_ in strides])
-        dec = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=dev)
-        check(lib.eas_det_decode(L, _ptr_array(regs), _ptr_array(objs), _ptr_array(clss), hw_arr, st_arr, B, nc, ptr(dec), stream()),
-              'eas_det_decode')
-        labels = labels.float()
-        G = labels.shape[1]
-        nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
-        gt_valid = (torch.arange(G, device=dev)[None] < nlabel[:, None]).to(torch.uint8)
-        gt_cls, gt_boxes = labels[:, :, 0].contiguous(), labels[:, :, 1:5].contiguous()
-        num_gts = nlabel.sum().float()
-        grids, svec = _anchor_tables(hws, strides, dev)
-        fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
-        matched = torch.empty((B, A), dtype=torch.int64, device=dev)
-        miou = torch.empty((B, A), dtype=torch.float32, device=dev)
-        check(lib.eas_simota_assign_rows(ptr(grids), ptr(svec), ptr(gt_boxes), ptr(gt_cls), ptr(gt_valid), ptr(dec), B, G, A, nc, ptr(fg),
-                                         ptr(matched), ptr(miou), stream()), 'eas_simota_assign_rows')
-        g_regs, g_objs, g_clss = [torch.empty_like(t) for t in regs], [torch.empty_like(t) for t in objs], [torch.empty_like(t) for t in clss]
-        out = torch.empty(7, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.eas_det_loss_workspace_doubles(), dtype=torch.float64, device=dev)
-        check(lib.eas_det_loss(L, _ptr_array(regs), _ptr_array(objs), _ptr_array(clss), _ptr_array(g_regs), _ptr_array(g_objs),
-                               _ptr_array(g_clss), hw_arr, st_arr, B, nc, ptr(dec), ptr(gt_boxes), ptr(gt_cls), G, ptr(fg), ptr(matched),
-                               ptr(miou), ptr(num_gts), int(bool(use_l1)), ptr(out), ptr(ws), stream()), 'eas_det_loss')
-        ctx.grads = [g for trip in zip(g_regs, g_objs, g_clss) for g in trip]
-        ctx.scale = out[6]
-        outs = tuple(out[i] for i in range(6))
-        ctx.mark_non_differentiable(*outs[1:])
-        return outs
-
-    @staticmethod
-    def backward(ctx, g_total, *_unused):
-        grads = ctx.grads
-        if g_total is None:
-            return (None,) * (4 + len(grads))
-        torch._foreach_mul_(grads, g_total * ctx.scale)
-        return (None, None, None, None) + tuple(grads)
-
-
-def det_loss_supported(raw_regs, labels, loss_type):
-    A = sum(r.shape[-1] * r.shape[-2] for r in raw_regs)
-    return (raw_regs[0].is_cuda and raw_regs[0].dtype == torch.float32 and len(raw_regs) <= 4 and A <= 4096 and labels.shape[1] <= 255
-            and loss_type == 'iou' and all(r.dim() == 4 for r in raw_regs))
-
-
-def det_loss(regs, objs, clss, labels, strides, num_classes, use_l1):
-    """(total, 5*iou, obj, cls, l1, num_fg/num_gts) of YOLOXHead.get_losses from the raw head maps of every level."""
-    raw = [t for trip in zip(regs, objs, clss) for t in trip]
-    return _DetLossFn.apply(labels, tuple(float(s_) for s_ in strides), int(num_classes), bool(use_l1), *raw)
-
-
-# ------------------------------------------------------------------------------------------------ neck glue
-class _UpcatFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a, b, up):
-        _dev(a, b)
-        a, b = _f32c(a), _f32c(b)
-        lead, (Ca, H, W) = a.shape[:-3], a.shape[-3:]
-        Cb = b.shape[-3]
-        M = a.numel() // (Ca * H * W)
-        out = torch.empty(lead + (Ca + Cb, H * up, W * up), dtype=torch.float32, device=a.device)
-        check(_lib.lib().eas_upcat_fwd(ptr(a), ptr(b), ptr(out), M, Ca, Cb, H, W, up, stream()), 'eas_upcat_fwd')
-        ctx.cfg = (a.shape, b.shape, M, Ca, Cb, H, W, up)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        ashape, bshape, M, Ca, Cb, H, W, up = ctx.cfg
-        g = _f32c(g)
-        ga = torch.empty(ashape, dtype=torch.float32, device=g.device)
-        gb = torch.empty(bshape, dtype=torch.float32, device=g.device)
-        check(_lib.lib().eas_upcat_bwd(ptr(g), ptr(ga), ptr(gb), M, Ca, Cb, H, W, up, stream()), 'eas_upcat_bwd')
-        return ga, gb, None
-
-
-class _UpcatPlanesFn(torch.autograd.Function):
-    """upsample + concatenate on spike planes: ghosts in, a ghost out (eas_upcat_planes_fwd); the gradient is fp32 (eas_upcat_bwd)"""
-
-    @staticmethod
-    def forward(ctx, a, b, a_sp, b_sp, up):
-        ctx.set_materialize_grads(False)
-        lead, (Ca, H, W) = tuple(a.shape[:-3]), a.shape[-3:]
-        Cb = b.shape[-3]
-        M = 1
-        for d in lead:
-            M *= d
-        Ho, Wo = H * up, W * up
-        sp = torch.empty(lead + ((Ca + Cb) // 8, Ho * Wo, 8), dtype=torch.bfloat16, device=a_sp.device)
-        _call('eas_upcat', 2 * 2 * sp.numel(), _lib.lib().eas_upcat_planes_fwd, ptr(a_sp), ptr(b_sp), ptr(sp), M, Ca, Cb, H, W, up, stream())
-        ctx.cfg = (tuple(a.shape), tuple(b.shape), M, Ca, Cb, H, W, up)
-        ctx.mark_non_differentiable(sp)
-        return ghost(lead + (Ca + Cb, Ho, Wo), a_sp.device), sp
-
-    @staticmethod
-    def backward(ctx, g, _g_sp):
-        if g is None:
-            return None, None, None, None, None
-        ashape, bshape, M, Ca, Cb, H, W, up = ctx.cfg
-        g = _f32c(g)
-        ga = torch.empty(ashape, dtype=torch.float32, device=g.device)
-        gb = torch.empty(bshape, dtype=torch.float32, device=g.device)
-        check(_lib.lib().eas_upcat_bwd(ptr(g), ptr(ga), ptr(gb), M, Ca, Cb, H, W, up, stream()), 'eas_upcat_bwd')
-        return ga, gb, None, None, None
-
-
-def upcat_supported(a, b, up):
-    if os.environ.get('EAS_NO_UPCAT'):         # development switch
-        return False
-    return (a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.dim() == b.dim() and a.dim() >= 4
-            and a.shape[:-3] == b.shape[:-3] and b.shape[-2] == a.shape[-2] * up and b.shape[-1] == a.shape[-1] * up
-            and (a.shape[-1] * up) % 4 == 0 and a.shape[-1] % 2 == 0)
-
-
-def upsample_cat(a, b, up=2):
-    """cat[nearest-upsample(a, x up), b] along channels in one kernel (one more for the backward); up = 1: plain concatenation"""
-    a_sp, b_sp = planes_of(a), planes_of(b)
-    if a_sp is not None and b_sp is not None and planes_enabled():
-        out, sp = _UpcatPlanesFn.apply(a, b, a_sp.contiguous(), b_sp.contiguous(), int(up))
-        out._eas_sp = sp
-        return mark_small_int(out)
-    a, b = dense(a), dense(b)
-    out = _UpcatFn.apply(a, b, int(up))
-    if is_small_int(a) and is_small_int(b):       # copies of spikes / small integers (nearest upsampling repeats values)
-        mark_small_int(out)
-    return out
-
-
-class _FocusFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        _dev(x)
-        x = _f32c(x)
-        M, Cc, H, W = x.shape
-        out = torch.empty((M, 4 * Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        check(_lib.lib().eas_focus(ptr(x), ptr(out), M, Cc, H // 2, W // 2, 0, stream()), 'eas_focus')
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        g = _f32c(g)
-        M, C4, Ho, Wo = g.shape
-        gx = torch.empty((M, C4 // 4, 2 * Ho, 2 * Wo), dtype=torch.float32, device=g.device)
-        check(_lib.lib().eas_focus(ptr(g), ptr(gx), M, C4 // 4, Ho, Wo, 1, stream()), 'eas_focus')
-        return gx
-
-
-def focus_supported(x):
-    if os.environ.get('EAS_NO_FOCUS'):         # development switch
-        return False
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-2] % 2 == 0 and x.shape[-1] % 4 == 0
-
-
-def focus(x):
-    """space to depth of Focus.forward: cat(x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]) in one kernel"""
-    return _FocusFn.apply(x)
-
-
 # ------------------------------------------------------------------------------------------------ BN step counters
 _DEFERRED = None
 
@@ -2797,3 +2331,9 @@ def bump_counter(t):
         t.add_(1)
     else:
         _DEFERRED.append(t)
+
+
+# the other kernel families of the operator layer live in modules of their own; ``ops.<name>`` stays the one public namespace
+from .ops_events import *          # noqa: E402,F401,F403  K1 + event representations
+from .ops_glue import *            # noqa: E402,F401,F403  SPP, upsample + concatenate, Focus
+from .ops_det import *             # noqa: E402,F401,F403  post-processing, SimOTA, detection loss

@@ -51,6 +51,9 @@ int eas_abi_version(void);
  * trace off and writes the distinct symbols, newline separated, into buf (cap bytes incl. the terminator); returns the bytes needed. */
 void eas_kernel_trace_begin(void);
 int64_t eas_kernel_trace_dump(char* buf, int64_t cap);
+/* number of device kernels the library has launched since it was loaded (a host-side count: captured launches count when they are
+ * captured, not when the graph is replayed) */
+int64_t eas_launch_counter(void);
 const char* eas_status_string(int status);
 
 /* ---------------------------------------------------------------------------------------------

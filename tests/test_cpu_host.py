@@ -710,3 +710,57 @@ def test_graph_capture_is_only_used_with_capturable_optimizers():
     assert optimizer_capturable(torch.optim.Adam(p, lr=1e-3)) and optimizer_capturable(torch.optim.AdamW(p, lr=1e-3))
     assert not optimizer_capturable(torch.optim.SGD(p, lr=1e-3, momentum=0.9, nesterov=True))
     assert not optimizer_capturable(torch.optim.RMSprop(p, lr=1e-3))
+
+
+def test_eval_proph_is_announced_not_silently_substituted():
+    """README eval line (readme.md:157-160 of the reference, --eval_proh): the reference builds PSEEEvaluator for gen* data
+    (event_yolox_base.py:512-523); the mirror has no Prophesee metric code and says so with a RuntimeWarning while handing out
+    EventEvaluator (same inference loop and records)"""
+    import warnings
+    from yolox.evaluators import EventEvaluator
+    from yolox.exp import get_exp
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(['num_classes', '2', 'data_name', 'gen1', 'eval_proph', 'True', 'input_size', '(64,96)', 'test_size', '(64,96)'])
+    with pytest.warns(RuntimeWarning, match='PSEEEvaluator'):
+        ev = exp.get_evaluator(2, False)
+    assert isinstance(ev, EventEvaluator)
+    exp = get_exp(None, 'e-yolox-s')            # (a fresh one: merge coerces with bool(str), so 'False' would switch the flag ON -- base_exp.py of the reference)
+    exp.merge(['num_classes', '2', 'data_name', 'gen1', 'input_size', '(64,96)', 'test_size', '(64,96)'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert isinstance(exp.get_evaluator(2, False), EventEvaluator)
+
+
+def test_checkpoint_carries_best_ap_and_resume_restores_it(tmp_path):
+    """reference checkpoint format (trainer.py:393-400: start_epoch, model, optimizer, best_ap, curr_ap) and resume (trainer.py:331): a
+    resumed run keeps its best AP, so its first evaluation cannot overwrite best_ckpt.pth with a worse model"""
+    import types
+    from yolox.core.trainer import Trainer
+    tr = Trainer.__new__(Trainer)
+    net = torch.nn.Linear(4, 2)
+    tr.device, tr.rank, tr.use_model_ema, tr.bare_model = 'cpu', 0, False, net
+    tr.optimizer = torch.optim.SGD(net.parameters(), lr=0.1)
+    tr.epoch, tr.best_ap, tr.file_name = 3, 0.4321, str(tmp_path)
+    tr.save_ckpt('latest', ap=0.25)
+    ck = torch.load(os.path.join(str(tmp_path), 'latest_ckpt.pth'), map_location='cpu')
+    assert set(ck) == {'start_epoch', 'model', 'optimizer', 'best_ap', 'curr_ap'}
+    assert ck['best_ap'] == 0.4321 and ck['curr_ap'] == 0.25 and ck['start_epoch'] == 4
+    tr2 = Trainer.__new__(Trainer)
+    tr2.device, tr2.file_name, tr2.best_ap, tr2.start_epoch = 'cpu', str(tmp_path), 0, 0
+    tr2.args = types.SimpleNamespace(ckpt=None, resume=True)
+    tr2.optimizer = torch.optim.SGD(net.parameters(), lr=0.1)
+    tr2.resume_train(torch.nn.Linear(4, 2))
+    assert tr2.best_ap == 0.4321 and tr2.start_epoch == 4
+
+
+def test_workload_2b_is_config_2_at_the_readme_canvas():
+    """the reference's published commands train at the default input_size (640, 640) (event_yolox_base.py:66,137) through the letterbox
+    resize (gen1.py:438-455): workload '2b' = config 2's options at that canvas, 304x240 -> 640x505 pasted top-left"""
+    from eas_snn_amd import data, workloads
+    w2, wb = workloads.get(2), workloads.get('2b')
+    assert wb['config'] == '2b' and wb['canvas'] == (640, 640) and wb['opts'] == w2['opts'] and wb['exp'] == w2['exp']
+    assert data.letterbox_params(*wb['sensor'], *wb['canvas']) == (640, 505, 0, 0, 0)
+    exp = workloads.build_exp(wb)
+    assert tuple(exp.input_size) == (640, 640) and tuple(exp.test_size) == (640, 640)
+    with pytest.raises(KeyError):
+        workloads.get(7)

@@ -30,7 +30,8 @@ pytestmark = pytest.mark.gpu
 
 # kernel families whose every bench instance must have been launched by an oracle-compared run
 FAMILIES = ('conv_fwd_mfma', 'conv1x1_mfma', 'conv_dgrad_s2', 'conv_wgrad_mfma', 'conv1x1_wgrad', 'bn_lif', 'bn_silu', 'bn_stats', 'bn_finalize',
-            'arsnn_', 'smallconv', 'lif_', 'spp_pool', 'planes_', 'upcat', 'focus', 'time_mean')
+            'arsnn_', 'smallconv', 'lif_', 'spp_pool', 'planes_', 'upcat', 'focus', 'time_mean', 'conv3x3_group', 'conv1x1_group',
+            'conv_wgrad_group', 'channel_sum')
 
 
 @pytest.fixture(scope='module')
@@ -150,6 +151,131 @@ def _replay_conv_calls(dev, calls):
             ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), gy.double(), stride=s, padding=k // 2)
             err = _rel(got, ref)
             assert err < 1e-5, f'{key}: weight gradient {err:.2e}'
+    torch.cuda.synchronize()
+    return count
+
+
+def _replay_group_calls(dev, calls):
+    """every distinct GROUPED launch of the step (eas_conv_fwd_group, eas_conv_wgrad_group_partial, eas_bn_silu_fwd_group / _bwd_group,
+    eas_channel_sum_group: the head's pyramid levels as one grid per stage) with the step's own problem tables on seeded inputs against
+    fp64: 1e-5 of the largest magnitude (BatchNorm + SiLU: 2e-5, as the single launches)"""
+    import torch.nn.functional as F
+    from eas_snn_amd import _lib, ops
+    from eas_snn_amd import ops_group as G
+    L = _lib.lib()
+    seen, count = set(), {}
+    for name, a in calls:
+        if name not in ('eas_conv_fwd_group', 'eas_conv_wgrad_group_partial', 'eas_bn_silu_fwd_group', 'eas_bn_silu_bwd_group', 'eas_channel_sum_group'):
+            continue
+        arr, n = a[0], a[1]
+        if name == 'eas_conv_fwd_group':
+            key = (name, a[2]) + tuple((q.NI, q.Cin, q.Cout, q.Hi, q.Wi, bool(q.bias), bool(q.stats), q.accumulate) for q in arr[:n])
+        elif name == 'eas_conv_wgrad_group_partial':
+            key = (name, a[2]) + tuple((q.NI, q.Cin, q.Cout, q.Hi, q.Wi) for q in arr[:n])
+        elif name == 'eas_channel_sum_group':
+            key = (name,) + tuple((q.N, q.C, q.HW) for q in arr[:n])
+        elif name == 'eas_bn_silu_fwd_group':
+            key = (name,) + tuple((q.N, q.C, q.HW, q.y_ctot, q.pending.chunks) for q in arr[:n])
+        else:
+            key = (name,) + tuple((q.N, q.C, q.HW, q.y_ctot, q.grad_out_ctot) for q in arr[:n])
+        if key in seen:
+            continue
+        seen.add(key)
+        count[name] = count.get(name, 0) + 1
+        g = torch.Generator(device='cpu').manual_seed(zlib.crc32(repr(key).encode()) % (2 ** 31))
+        if name == 'eas_conv_fwd_group':
+            k = key[1]
+            probs = key[2:]
+            xs = [torch.randn(NI, Cin, H, W, generator=g).to(dev) for NI, Cin, Cout, H, W, *_ in probs]
+            ws = [(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev) for NI, Cin, Cout, H, W, *_ in probs]
+            bs = [torch.randn(p_[2], generator=g).to(dev) if p_[5] else None for p_ in probs]
+            pks = [ops.conv_pack_weights(w, 0) for w in ws]
+            acc = bool(probs[0][7])
+            ys = [torch.randn(p_[0], p_[2], p_[3], p_[4], generator=g).to(dev) for p_ in probs]
+            before = [y.clone() for y in ys]
+            stats = None
+            if probs[0][6]:
+                nb = G._conv_plan(tuple(p_[:5] for p_ in probs), k)
+                stats = [torch.zeros(p_[2] * b * 2, dtype=torch.float64, device=dev) for p_, b in zip(probs, nb)]
+            G._launch_conv_group(xs, pks, bs if any(b is not None for b in bs) else None, ys, stats, k, accumulate=acc)
+            for i, (x, w, b, y) in enumerate(zip(xs, ws, bs, ys)):
+                ref = _conv64(x, w, b, 1, k // 2)
+                if acc:
+                    ref = ref + before[i].double()
+                assert _rel(y, ref) < 1e-5, f'{key}: problem {i}'
+                if stats is not None:
+                    st = stats[i].view(w.shape[0], -1, 2).sum(1)
+                    y64 = y.double()
+                    assert float(((st[:, 0] - y64.sum((0, 2, 3))).abs() / (y64.abs().sum((0, 2, 3)) + 1e-30)).max()) < 3e-7, f'{key}: tile sums'
+        elif name == 'eas_conv_wgrad_group_partial':
+            k = key[1]
+            probs = key[2:]
+            xs = [torch.randn(NI, Cin, H, W, generator=g).to(dev) for NI, Cin, Cout, H, W in probs]
+            gys = [torch.randn(NI, Cout, H, W, generator=g).to(dev) for NI, Cin, Cout, H, W in probs]
+            ns = G._wgrad_plan(probs, k)
+            parr = (_lib.EasWgradProblem * len(probs))()
+            wss = []
+            for q, x, gy, s_ in zip(parr, xs, gys, ns):
+                ws = torch.empty(s_ * gy.shape[1] * x.shape[1] * k * k, device=dev)
+                wss.append(ws)
+                q.x, q.grad_y, q.workspace = ops.ptr(x), ops.ptr(gy), ops.ptr(ws)
+                q.NI, q.Cin, q.Cout, q.Hi, q.Wi = x.shape[0], x.shape[1], gy.shape[1], x.shape[2], x.shape[3]
+            ops.check(L.eas_conv_wgrad_group_partial(parr, len(probs), k, 3, ops.stream()), name)
+            for x, gy, ws, s_ in zip(xs, gys, wss, ns):
+                gw = torch.empty((gy.shape[1], x.shape[1], k, k), device=dev)
+                ops._wgrad_finish(ws, gw, s_, False)
+                ref = torch.nn.grad.conv2d_weight(x.double(), tuple(gw.shape), gy.double(), padding=k // 2)
+                assert _rel(gw, ref) < 1e-5, f'{key}'
+        elif name == 'eas_channel_sum_group':
+            ts = [torch.randn(N, C_, HW, generator=g).to(dev) for N, C_, HW in key[1:]]
+            parr = (_lib.EasChannelSumProblem * len(ts))()
+            outs = []
+            for q, t in zip(parr, ts):
+                o = torch.empty(t.shape[1], device=dev)
+                outs.append(o)
+                q.g, q.out, q.N, q.C, q.HW = ops.ptr(t), ops.ptr(o), t.shape[0], t.shape[1], t.shape[2]
+            ops.check(L.eas_channel_sum_group(parr, len(ts), ops.stream()), name)
+            for t, o in zip(ts, outs):
+                assert _rel(o, t.double().sum((0, 2))) < 1e-5, key
+        else:
+            # BatchNorm + SiLU forward and backward of the group's layers, each behind a grouped 1x1 convolution that supplies the partial sums
+            # (forward and backward tables of a stage describe the same layers: either replays both)
+            layers = [(q[0], q[1], q[2], q[3]) for q in key[1:]]
+            sig = ('bn', tuple(layers))
+            if sig in seen:
+                continue
+            seen.add(sig)
+            ytot = {}
+            for N, C_, HW, yct in layers:
+                ytot.setdefault((N, HW, yct if yct else C_), []).append(C_)
+            xs, convs, bns, spec = [], [], [], []
+            for (N, HW, Ct), cs in ytot.items():
+                H = 8 if HW % 8 == 0 else 4
+                xs.append(torch.randn(N, 16, H, HW // H, generator=g).to(dev))
+                convs.append(torch.nn.Conv2d(16, Ct, 1, bias=False).to(dev))
+                c0 = 0
+                for C_ in cs:
+                    bn = torch.nn.BatchNorm2d(C_, eps=1e-3, momentum=0.03).to(dev).train()
+                    with torch.no_grad():
+                        bn.weight.copy_(torch.rand(C_, generator=g) + 0.5)
+                        bn.bias.copy_(torch.randn(C_, generator=g) * 0.3)
+                    spec.append((len(xs) - 1, c0, bn))
+                    c0 += C_
+                assert c0 == Ct, key
+            if not G.conv_group_ok(xs, convs, 1):
+                continue                                  # (another mix of maps than a 1x1 group takes: the stage's own replay above covers it)
+            xr = [x.clone().requires_grad_(True) for x in xs]
+            ys, st = G.conv_group(xr, convs, 1, True)
+            outs = G.bn_silu_group(ys, st, spec)
+            gos = [torch.randn(o.shape, generator=g).to(dev) for o in outs]
+            torch.autograd.backward(outs, gos)
+            for (yi, c0, bn), o, go in zip(spec, outs, gos):
+                y64 = ys[yi].detach().double()[:, c0:c0 + bn.num_features].requires_grad_(True)
+                w64, b64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+                ref = F.silu(F.batch_norm(y64, None, None, w64, b64, True, 0.0, 1e-3))
+                ref.backward(go.double())
+                assert _rel(o.detach(), ref.detach()) < 2e-5, key
+                assert _rel(bn.weight.grad, w64.grad) < 2e-5 and _rel(bn.bias.grad, b64.grad) < 2e-5, key
     torch.cuda.synchronize()
     return count
 
@@ -278,7 +404,7 @@ def _planes_vs_fp32_step(dev, exp_name, cfg, shape):
     assert not diff, f'planes vs fp32 spikes: buffer differences in {diff[:5]}'
 
 
-def _neck_head_backward(dev):
+def _neck_head_backward(dev, grouped=False):
     """BASELINE configs[1] at 256x320: the real-valued PAFPN neck and the head in train mode, backward.  The oracle runs a whole training
     step; its backbone firing rates go INTO the HIP neck + head, the oracle's gradients at the nine raw prediction maps go into their
     backward, and every neck / head parameter gradient and the three firing-rate gradients are compared elementwise at the ``_grad_close``
@@ -336,7 +462,11 @@ def _neck_head_backward(dev):
     hip.backbone._features = lambda _x: rates
     with ops.packed_weights(hip):
         fpn = hip.backbone(None)
-        got_raws = [hip.head._level(k, hip.head._prepare(f)) for k, f in enumerate(fpn)]
+        if grouped:          # every stage of the three levels as one grouped launch (ops_group)
+            got_raws = hip.head._levels_grouped([hip.head._prepare(f) for f in fpn])
+            assert got_raws is not None
+        else:
+            got_raws = [hip.head._level(k, hip.head._prepare(f)) for k, f in enumerate(fpn)]
         outs, gouts = [], []
         for k in range(3):
             for j, kind in enumerate(('reg', 'obj', 'cls')):
@@ -401,6 +531,7 @@ def test_every_kernel_instance_of_the_bench_step_is_oracle_checked(dev, config):
     with ops.kernel_trace() as tr:
         counts = _replay_conv_calls(dev, bench.calls)
         counts.update(_replay_bn_calls(dev, bench.calls, cfg.get('T', 3)))
+        counts.update(_replay_group_calls(dev, bench.calls))
     tested |= {_short(k) for k in tr.kernels}
     print(f'config {config}: replayed against fp64 at the bench batch: {counts}')
     assert counts.get('fwd', 0) >= 20 and counts.get('wgrad', 0) >= 15
@@ -415,6 +546,7 @@ def test_every_kernel_instance_of_the_bench_step_is_oracle_checked(dev, config):
             M.test_sampler_parity_at_256x320(dev)
             M.test_neck_and_head_teacher_forced_every_logit(dev, True)
             _neck_head_backward(dev)
+            _neck_head_backward(dev, grouped=True)
     tested |= {_short(k) for k in tr.kernels}
     missing = [k for k in bench_kernels if _family(k) and k not in tested]
     fams = sorted({k.split('<')[0] for k in bench_kernels if _family(k)})

@@ -1804,3 +1804,170 @@ def test_conv_forward_hooks_still_fire(dev):
     h.remove()
     assert seen == [x.shape]
     np.testing.assert_allclose(y0.detach().cpu().numpy(), y1.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ grouped (multi-problem) launches
+HEAD_LEVELS = ((32, 40), (16, 20), (8, 10))
+
+
+def _rel64(got, ref):
+    return float((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('batch', [3, 64])
+@pytest.mark.parametrize('k,cins,cout', [(3, (128, 128, 128), 256), (3, (64, 64, 64), 64), (1, (128, 256, 512), 128), (3, (96, 96, 96, 96), 96)])
+def test_grouped_convolution_equals_the_single_launches(dev, batch, k, cins, cout):
+    """eas_conv_fwd_group (include/eas_hip.h): the convolutions of the head's pyramid levels -- independent until the loss,
+    yolox/models/yolo_head.py:149-200 -- in ONE grid.  Forward and input gradient (weights packed transposed + flipped): every problem's
+    output is bit-identical to eas_conv_fwd's (same tiles' arithmetic, another grid) and within 1e-5 of an fp64 convolution; the
+    BatchNorm partial sums the epilogue leaves add up to the sums of y."""
+    from eas_snn_amd import ops
+    from eas_snn_amd import ops_group as G
+    g = torch.Generator().manual_seed(7 + batch + cout)
+    hws = HEAD_LEVELS + ((4, 6),) if len(cins) == 4 else HEAD_LEVELS
+    ws = [(torch.randn(cout, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(dev) for ci in cins]
+    for mode in (0, 1):
+        if mode == 0:
+            ins = [torch.randn(batch, ci, h, w, generator=g).to(dev) for ci, (h, w) in zip(cins, hws)]
+            couts = [cout] * len(cins)
+        else:
+            ins = [torch.randn(batch, cout, h, w, generator=g).to(dev) for (h, w) in hws]
+            couts = list(cins)
+        geoms = tuple((x.shape[0], x.shape[1], co, x.shape[2], x.shape[3]) for x, co in zip(ins, couts))
+        nb = G._conv_plan(geoms, k)
+        assert nb is not None, geoms
+        pks = [ops.conv_pack_weights(w, mode) for w in ws]
+        ys = [torch.full((x.shape[0], co, x.shape[2], x.shape[3]), float('nan'), device=dev) for x, co in zip(ins, couts)]
+        stats = [torch.full((co * b * 2,), float('nan'), dtype=torch.float64, device=dev) for co, b in zip(couts, nb)]
+        G._launch_conv_group(ins, pks, None, ys, stats, k)
+        for x, w, pk, y, st, co, b in zip(ins, ws, pks, ys, stats, couts, nb):
+            single = ops.conv_fwd_packed(x, pk, None, co, k, 1, 3)
+            assert torch.equal(single, y), (mode, tuple(x.shape))
+            if mode == 0:
+                ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=k // 2)
+            else:
+                ref = torch.nn.grad.conv2d_input((x.shape[0], co, x.shape[2], x.shape[3]), w.double(), x.double(), padding=k // 2)
+            assert _rel64(y, ref) < 1e-5, (mode, tuple(x.shape))
+            s = st.view(co, b, 2).sum(1)
+            y64 = y.double()
+            assert float(((s[:, 0] - y64.sum((0, 2, 3))).abs() / (y64.abs().sum((0, 2, 3)) + 1e-30)).max()) < 3e-7
+            assert float(((s[:, 1] - (y64 * y64).sum((0, 2, 3))).abs() / ((y64 * y64).sum((0, 2, 3)) + 1e-30)).max()) < 3e-7
+
+
+def test_grouped_prediction_convolutions_bias_ragged_channels_and_accumulation(dev):
+    """the 1 / 4 / num_classes-channel prediction convolutions of all levels (yolo_head.py:161-163) as one launch with bias; their input
+    gradients (1, 2, 4 input channels: per-channel validity) as one launch, and a second launch that ADDS the objectness gradient to the
+    box gradient of the same feature map (y += in the epilogue): all bit-identical to the single launches (+ torch's addition)"""
+    from eas_snn_amd import ops
+    from eas_snn_amd import ops_group as G
+    g = torch.Generator().manual_seed(4)
+    batch = 16
+    xs = [torch.randn(batch, 128, h, w, generator=g).to(dev) for (h, w) in HEAD_LEVELS] * 3
+    couts = [2] * 3 + [4] * 3 + [1] * 3
+    ws = [(torch.randn(co, 128, 1, 1, generator=g) / 11.0).to(dev) for co in couts]
+    bs = [torch.randn(co, generator=g).to(dev) for co in couts]
+    pks = [ops.conv_pack_weights(w, 0) for w in ws]
+    ys = [torch.empty((x.shape[0], co, x.shape[2], x.shape[3]), device=dev) for x, co in zip(xs, couts)]
+    G._launch_conv_group(xs, pks, bs, ys, None, 1)
+    for x, w, b, pk, y in zip(xs, ws, bs, pks, ys):
+        assert torch.equal(ops.conv_fwd_packed(x, pk, b, w.shape[0], 1, 1, 3), y)
+        assert _rel64(y, torch.nn.functional.conv2d(x.double(), w.double(), b.double())) < 1e-5
+    gys = [torch.randn(y.shape, generator=g).to(dev) for y in ys]
+    pk1 = [ops.conv_pack_weights(w, 1) for w in ws]
+    gx = [torch.empty_like(x) for x in xs[:6]]
+    G._launch_conv_group(gys[:6], pk1[:6], None, gx, None, 1)
+    first = [t.clone() for t in gx[3:]]
+    G._launch_conv_group(gys[6:], pk1[6:], None, gx[3:], None, 1, accumulate=True)
+    for i in range(6):
+        assert torch.equal(ops.conv_fwd_packed(gys[i], pk1[i], None, 128, 1, 1, 3), gx[i] if i < 3 else first[i - 3]), i
+    for i in range(3):
+        assert torch.equal(first[i] + ops.conv_fwd_packed(gys[6 + i], pk1[6 + i], None, 128, 1, 1, 3), gx[3 + i]), i
+
+
+@pytest.mark.parametrize('batch', [2, 64])
+@pytest.mark.parametrize('k,cin,cout', [(3, 128, 256), (3, 128, 128), (1, 128, 128), (1, 128, 4)])
+def test_grouped_weight_gradient_slabs_vs_fp64(dev, batch, k, cin, cout):
+    """eas_conv_wgrad_group_partial: the slab kernels of several layers as one grid, pixel slices sized for the group; reduced in fixed
+    order like every weight gradient.  Against fp64 (1e-5 of the largest magnitude) and repeatable bit for bit."""
+    from eas_snn_amd import _lib, ops
+    from eas_snn_amd import ops_group as G
+    g = torch.Generator().manual_seed(19 + batch + cout)
+    xs = [torch.randn(batch, cin, h, w, generator=g).to(dev) for (h, w) in HEAD_LEVELS]
+    gys = [torch.randn(batch, cout, h, w, generator=g).to(dev) for (h, w) in HEAD_LEVELS]
+    geoms = tuple((x.shape[0], cin, cout, x.shape[2], x.shape[3]) for x in xs)
+    ns = G._wgrad_plan(geoms, k)
+    assert ns is not None
+
+    def run():
+        arr = (_lib.EasWgradProblem * 3)()
+        wss = []
+        for q, x, gy, s_ in zip(arr, xs, gys, ns):
+            ws = torch.full((s_ * cout * cin * k * k,), float('nan'), device=dev)
+            wss.append(ws)
+            q.x, q.grad_y, q.workspace = ops.ptr(x), ops.ptr(gy), ops.ptr(ws)
+            q.NI, q.Cin, q.Cout, q.Hi, q.Wi = x.shape[0], cin, cout, x.shape[2], x.shape[3]
+        ops.check(_lib.lib().eas_conv_wgrad_group_partial(arr, 3, k, 3, ops.stream()), 'eas_conv_wgrad_group_partial')
+        out = []
+        for ws, s_ in zip(wss, ns):
+            gw = torch.empty((cout, cin, k, k), device=dev)
+            ops._wgrad_finish(ws, gw, s_, False)
+            out.append(gw)
+        return out
+    a, b = run(), run()
+    for x, gy, ga, gb in zip(xs, gys, a, b):
+        assert torch.equal(ga, gb)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), gy.double(), padding=k // 2)
+        assert _rel64(ga, ref) < 1e-5, tuple(x.shape)
+        single = ops.conv_wgrad(x, gy, k, 1, 3)
+        assert _rel64(ga, single.double()) < 1e-5
+
+
+@pytest.mark.parametrize('batch', [2, 64])
+def test_grouped_bn_silu_forward_backward_vs_fp64(dev, batch):
+    """eas_bn_silu_fwd_group / eas_bn_silu_bwd_group behind a grouped convolution (its epilogue's partial sums are the batch statistics):
+    six BatchNorm + SiLU layers -- the two channel halves of three pair outputs -- as one forward launch and two backward launches, against
+    torch in fp64 incl. the running statistics"""
+    import torch.nn.functional as F
+    from eas_snn_amd import ops
+    from eas_snn_amd import ops_group as G
+    g = torch.Generator().manual_seed(23 + batch)
+    xs = [torch.randn(batch, 64, h, w, generator=g).to(dev) for (h, w) in HEAD_LEVELS]
+    pairs = [(torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(dev), torch.nn.Conv2d(64, 32, 3, 1, 1, bias=False).to(dev)) for _ in xs]
+    bns = [(torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.03).to(dev).train(), torch.nn.BatchNorm2d(32, eps=1e-3, momentum=0.03).to(dev).train()) for _ in xs]
+    with torch.no_grad():
+        for pr in bns:
+            for bn in pr:
+                bn.weight.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+                bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.3)
+    assert G.conv_group_ok(xs, pairs, 3)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    ys, st = G.conv_group(xr, pairs, 3, True)
+    layers = []
+    for i, (ba, bb) in enumerate(bns):
+        layers += [(i, 0, ba), (i, 64, bb)]
+    outs = G.bn_silu_group(ys, st, layers)
+    gos = [torch.randn(o.shape, generator=g).to(dev) for o in outs]
+    torch.autograd.backward(outs, gos)
+    j = 0
+    for i, (x, (ca, cb), (ba, bb)) in enumerate(zip(xs, pairs, bns)):
+        x64 = x.double().requires_grad_(True)
+        w64 = torch.cat([ca.weight, cb.weight], 0).detach().double().requires_grad_(True)
+        y64 = F.conv2d(x64, w64, padding=1)
+        refs, params = [], []
+        for bn, sl in ((ba, slice(0, 64)), (bb, slice(64, 96))):
+            gam, bet = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+            refs.append(F.silu(F.batch_norm(y64[:, sl], None, None, gam, bet, True, 0.0, 1e-3)))
+            params.append((bn, gam, bet, y64[:, sl]))
+        torch.autograd.backward(refs, [gos[j].double(), gos[j + 1].double()])
+        for r, o in zip(refs, outs[j:j + 2]):
+            assert _rel64(o.detach(), r.detach()) < 2e-5, i
+        assert _rel64(xr[i].grad, x64.grad) < 5e-5, i
+        gw = torch.cat([ca.weight.grad, cb.weight.grad], 0)
+        assert _rel64(gw, w64.grad) < 5e-5, i
+        for bn, gam, bet, ysl in params:
+            assert _rel64(bn.weight.grad, gam.grad) < 5e-5 and _rel64(bn.bias.grad, bet.grad) < 5e-5, i
+            n = ysl.numel() / ysl.shape[1]
+            mean, var = ysl.detach().mean((0, 2, 3)), ysl.detach().var((0, 2, 3), unbiased=False)
+            assert _rel64(bn.running_mean, 0.03 * mean) < 1e-5
+            assert _rel64(bn.running_var, 0.97 + 0.03 * var * n / (n - 1)) < 1e-5
+        j += 2

@@ -1,4 +1,6 @@
 """GPU parity of the assembled blocks / whole SYOLOX against golden vectors from the reference and the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1361,3 +1363,87 @@ def test_config_shaped_cases_vs_cpu_oracle(dev, name):
     sj_ref.reset_net(ref); functional.reset_net(hip)
     assert lh.shape == lr.shape
     assert _frac_close(lh, lr, RTOL, 1e-4) > 0.95, _frac_close(lh, lr, RTOL, 1e-4)
+
+
+@pytest.mark.parametrize('batch', [2, 64])
+def test_head_with_grouped_launches_equals_the_per_level_head(dev, batch):
+    """YOLOXHead in training mode: every stage of the three pyramid levels as one grouped launch (``_levels_grouped``, ops_group) against
+    the per-level walk of the reference (yolo_head.py:149-200): loss, input gradients, all parameter gradients and the running statistics.
+    The convolutions are bit-identical per problem; BatchNorm sums and weight-gradient slabs are cut by another tile plan (rounding)."""
+    from eas_snn_amd import data, ops
+    from eas_snn_amd import ops_group as G
+    from yolox.models.yolo_head import YOLOXHead
+    torch.manual_seed(5)
+    hd = YOLOXHead(2, width=0.5).to(dev)
+    hd.initialize_biases(1e-2)
+    hd.train()
+    hd.use_l1 = True
+    for m in hd.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-3, 0.03
+    xs0 = [torch.randn(batch, c, h, w, device=dev) for c, (h, w) in zip((128, 256, 512), ((32, 40), (16, 20), (8, 10)))]
+    labels = data.synth_targets(batch, (256, 320), dev)
+    state = {k: v.clone() for k, v in hd.state_dict().items()}
+    res = {}
+    prev = G.ENABLED
+    try:
+        for flag in (False, True):
+            G.ENABLED = flag
+            hd.load_state_dict(state)
+            hd.zero_grad(set_to_none=True)
+            xs = [x.clone().requires_grad_(True) for x in xs0]
+            with ops.packed_weights(hd), ops.kernel_trace() as tr:
+                out = hd(xs, labels)
+                out[0].backward()
+            grouped = any('group_kernel' in k for k in tr.kernels)
+            assert grouped == flag, tr.kernels
+            res[flag] = (out[0].detach().clone(), [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in hd.named_parameters()},
+                         {n: b.clone() for n, b in hd.named_buffers()})
+    finally:
+        G.ENABLED = prev
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=0)
+    for a, b in zip(res[True][1], res[False][1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+    for n in res[False][2]:
+        torch.testing.assert_close(res[True][2][n], res[False][2][n], rtol=1e-4, atol=2e-5 * float(res[False][2][n].abs().max()) + 1e-12, msg=n)
+    for n in res[False][3]:
+        torch.testing.assert_close(res[True][3][n].float(), res[False][3][n].float(), rtol=1e-5, atol=1e-7, msg=n)
+
+
+def _bench_child(extra_env, steps=3, warmup=3, timeout=900):
+    """bench.py in a FRESH child process (the pytest process already holds the GPU and must never exec; the child is an ordinary
+    subprocess with its own HIP context, like the ranks bench.py --gpus N starts); returns its JSON line"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, EAS_BENCH_NO_EVAL='1', EAS_BENCH_NO_640='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, f'bench.py exited with {r.returncode}:\n{r.stderr[-2000:]}'
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert lines, r.stdout[-500:]
+    return json.loads(lines[-1])
+
+
+def test_bench_step_holds_a_live_rccl_communicator(dev):
+    """The N > 1 launch form with a real RCCL communicator in the loop (yolox/core/trainer.py:175-176 wraps the model for N ranks,
+    yolox/core/launch.py:118-142 makes the process group): one rank, process group on the 'nccl' (= RCCL) backend, the bucketed gradient
+    exchange between three HIP-graph replays -- bench.py with EAS_BENCH_FORCE_DDP=1 in a child process.  It must finish, report the
+    exchange it ran, and train exactly like the one-graph step (same loss after the same number of steps)."""
+    plain = _bench_child({})
+    ddp = _bench_child({'EAS_BENCH_FORCE_DDP': '1'})
+    cfg = ddp['config']
+    assert cfg['rccl_ranks'] == 1 and ddp['n_gpus'] == 1
+    assert cfg['launch'].startswith('three hip-graph replays per step'), cfg['launch']
+    assert cfg['gradient_exchange'] == '2 flat bucket(s)', cfg['gradient_exchange']
+    assert plain['config']['launch'] in ('hip-graph replay of the whole step', 'eager launches') and plain['config']['gradient_exchange'] is None
+    a, b = plain['final_loss'], ddp['final_loss']
+    assert np.isfinite(a) and abs(a - b) <= 1e-6 * abs(a), (a, b)
