@@ -172,7 +172,7 @@ class _ConvGroupFn(torch.autograd.Function):
                     else:
                         ops._wgrad_finish(ws, gw, s_, ops._can_defer(was[i]), was[i])
                     gws.append(gw)
-            else:
+            else:       # a subset of the problems (some weights frozen) the group plan does not take: one by one
                 for i in need_w:
                     if dual:
                         both = ctx.needs_input_grad[1 + n + i] and ctx.needs_input_grad[1 + 2 * n + i]
@@ -229,7 +229,9 @@ def conv_group_ok(xs, items, k):
         bwd.append((x.shape[0], cout, x.shape[1], x.shape[2], x.shape[3]))
     if len({(isinstance(it, tuple), (it[0] if isinstance(it, tuple) else it).bias is None) for it in items}) != 1:
         return False
-    return _conv_plan(tuple(fwd), k) is not None and _conv_plan(tuple(bwd), k) is not None
+    # (the weight-gradient slabs too: a map the matrix-core weight gradient does not take -- the 2x3 level of a 64x96 test canvas -- keeps the
+    # per-level operators, which know the library fallback)
+    return _conv_plan(tuple(fwd), k) is not None and _conv_plan(tuple(bwd), k) is not None and _wgrad_plan(tuple(fwd), k) is not None
 
 
 def conv_group(xs, items, k, want_stats, owners=None):
@@ -437,7 +439,7 @@ def pred_group_ok(cls_feats, reg_feats, cls_preds, reg_preds, obj_preds):
         fwd.append((x.shape[0], x.shape[1], c.out_channels, x.shape[2], x.shape[3]))
         bwd.append((x.shape[0], c.out_channels, x.shape[1], x.shape[2], x.shape[3]))
     return (_conv_plan(tuple(fwd), 1) is not None and _conv_plan(tuple(bwd[:2 * n]), 1) is not None
-            and _conv_plan(tuple(bwd[2 * n:]), 1) is not None)
+            and _conv_plan(tuple(bwd[2 * n:]), 1) is not None and _wgrad_plan(tuple(fwd), 1) is not None)
 
 
 def pred_group(cls_feats, reg_feats, cls_preds, reg_preds, obj_preds):

@@ -245,11 +245,15 @@ def _replay_group_calls(dev, calls):
             if sig in seen:
                 continue
             seen.add(sig)
-            ytot = {}
+            ytot = []                    # [(N, HW, Ct), [C of the layers on consecutive channel ranges of one convolution output]] in table order
             for N, C_, HW, yct in layers:
-                ytot.setdefault((N, HW, yct if yct else C_), []).append(C_)
+                Ct = yct if yct else C_
+                if ytot and ytot[-1][0] == (N, HW, Ct) and sum(ytot[-1][1]) < Ct:
+                    ytot[-1][1].append(C_)
+                else:
+                    ytot.append(((N, HW, Ct), [C_]))
             xs, convs, bns, spec = [], [], [], []
-            for (N, HW, Ct), cs in ytot.items():
+            for (N, HW, Ct), cs in ytot:
                 H = 8 if HW % 8 == 0 else 4
                 xs.append(torch.randn(N, 16, H, HW // H, generator=g).to(dev))
                 convs.append(torch.nn.Conv2d(16, Ct, 1, bias=False).to(dev))
