@@ -775,16 +775,27 @@ int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t 
     if (wm == 2 && wn == 2) wn = 1;          // instantiated shapes: (4,2) (4,1) (2,1) (1,1); ragged input channels: (4,1) (1,1)
     if (wm == 1) wn = 1;
     if (ragk && wm == 2) wm = 1;
+    // Grid order: the problems with the longest channel loops first.  Blocks start in blockIdx order and a block's duration goes with its
+    // k-steps (the 512-channel stem of the 8x10 level: 32 dependent steps against 8 on the 32x40 level); at the END of the grid those few
+    // long blocks were the launch's tail (stems of the three levels: 121 us against 49 us for the large level alone).
+    int order[kMaxGroup1];
+    for (int p = 0; p < n; ++p) order[p] = p;
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && a.g[order[j]].KSTEPS > a.g[order[j - 1]].KSTEPS; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    C1GroupArgs b = a;
     int bx = 0;
-    for (int p = 0; p < n; ++p) {
-        a.first[p] = bx;
-        const int gxp = (a.g[p].total_tiles + 4 * wn - 1) / (4 * wn);
-        a.g[p].stats_nb = gxp;
+    for (int i = 0; i < n; ++i) {
+        const int p = order[i];
+        b.g[i] = a.g[p]; b.x[i] = a.x[p]; b.wp[i] = a.wp[p]; b.bias[i] = a.bias[p]; b.y[i] = a.y[p];
+        b.first[i] = bx;
+        const int gxp = (b.g[i].total_tiles + 4 * wn - 1) / (4 * wn);
+        b.g[i].stats_nb = gxp;
         if (nb_out) nb_out[p] = gxp;
         bx += gxp;
     }
-    a.first[n] = bx;
-    a.n = n;
+    b.first[n] = bx;
+    b.n = n;
+    a = b;
     if (query) return EAS_OK;
     const int gy = (mt_max + wm - 1) / wm;
     if (ragk) return wm == 4 ? launch_c1_group<3, 4, 1, true>(a, gy, st) : launch_c1_group<3, 1, 1, true>(a, gy, st);
@@ -1006,7 +1017,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_lds_kernel(const void* __re
 }
 
 // Grouped launch (eas_conv_wgrad_group_partial, ksize 1): layer p owns blocks [first[p], first[p + 1]) of the flat grid, slices[p] x
-// (co, ci) blocks, slice fastest.  16-pixel chunks (KS = 1) so that every map with HW % 16 == 0 fits the one instance.
+// (co, ci) blocks, slice fastest.  HW % 16 == 0; a layer's chunk size is its own (W1GroupArgs.ks2).
 constexpr int kMaxW1Group = 12;
 struct W1GroupArgs {
     W1Geom g[kMaxW1Group];
@@ -1014,6 +1025,7 @@ struct W1GroupArgs {
     const float* gy[kMaxW1Group];
     float* slabs[kMaxW1Group];
     int slices[kMaxW1Group];
+    int ks2[kMaxW1Group];              // 1: 32-pixel chunks (KS = 2), else 16-pixel chunks
     int first[kMaxW1Group + 1];
     int n;
 };
@@ -1027,7 +1039,9 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_group_kernel(const W1GroupA
     p = __builtin_amdgcn_readfirstlane(p);
     const int lb = (int)blockIdx.x - a.first[p];
     const int by = lb / a.slices[p], bx = lb - by * a.slices[p];
-    conv1x1_wgrad_body<XT, WVM, WVN, NT, 1, false>(a.x[p], a.gy[p], a.slabs[p], a.g[p], smem, bx, by);
+    // 32-pixel chunks (two k-steps per barrier) where the map allows it, 16-pixel chunks for the others (the 8x10 level: 80 pixels)
+    if (a.ks2[p]) conv1x1_wgrad_body<XT, WVM, WVN, NT, 2, false>(a.x[p], a.gy[p], a.slabs[p], a.g[p], smem, bx, by);
+    else conv1x1_wgrad_body<XT, WVM, WVN, NT, 1, false>(a.x[p], a.gy[p], a.slabs[p], a.g[p], smem, bx, by);
 }
 
 struct W1Plan { int wvm, wvn, nt, ks, slices; };
@@ -1134,7 +1148,7 @@ namespace {
 template <int WVM, int WVN, int NT>
 int launch_w1_group(const W1GroupArgs& a, int blocks, hipStream_t st, int* res_out) {
     auto kern = conv1x1_wgrad_group_kernel<3, WVM, WVN, NT>;
-    constexpr int PITCH = 16 * 2 + 16;
+    constexpr int PITCH = 16 * 2 * 2 + 16;            // sized for the 32-pixel chunks (KS = 2); the 16-pixel bodies use less
     const size_t lds = (size_t)2 * (3 * 32 * WVM * PITCH + 3 * 32 * WVN * NT * PITCH);
     static int res = 0;
     if (res == 0) {
@@ -1167,7 +1181,8 @@ int eas_conv1x1_wgrad_group(const EasWgradProblem* pr, int n, int x_terms, hipSt
         g.NI = q.NI; g.Cin = q.Cin; g.Cout = q.Cout; g.HW = HW;
         g.ci_blocks = (q.Cin + RB - 1) / RB;
         yz[p] = ((q.Cout + RA - 1) / RA) * g.ci_blocks;
-        nc[p] = q.NI * (HW / 16);
+        a.ks2[p] = HW % 32 == 0 ? 1 : 0;
+        nc[p] = q.NI * (HW / (a.ks2[p] ? 32 : 16));
         a.x[p] = q.x; a.gy[p] = q.grad_y; a.slabs[p] = q.workspace;
     }
     int res = 2;
