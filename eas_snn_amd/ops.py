@@ -1692,8 +1692,59 @@ class deferred_wgrad_reductions:
             # the backward pass did not finish: the gradient tensors of the pending jobs may already be gone (their addresses are all
             # that is kept) -- nothing is written, the jobs are dropped
             _PENDING_REDUCE = []
+            _SIDE['pending'], _SIDE['keep'] = [], []
             return
         _flush_wgrad_reductions()
+
+
+# Weight-gradient slab kernels on a side stream (round 5).  Nothing reads a deferred weight gradient before the end of the backward pass, so
+# its slab kernel is off the pass's dependency chain: with WGRAD_SIDE_BATCH = n > 0 the launches are collected and, n at a time, issued on
+# ONE side stream that forks from the main stream where the batch's last grad_y exists (one cross-stream edge per batch, not per launch:
+# per-launch forks measured slower than no overlap) and joins in front of the batched reduction.  The chain's many small
+# kernels (one or two waves per SIMD on the 8x10 / 16x20 maps) leave most of the chip idle; the slab kernels fill it.  Inputs and
+# workspaces of the launches in flight are kept alive until the join, so the allocator cannot hand their memory to the main stream early.
+WGRAD_SIDE_BATCH = int(os.environ.get('EAS_WGRAD_SIDE', '16'))       # 0: everything on the main stream; 16: swept on config 2 (12 / 15 / 17 / 20 / 24 lose 0.1-0.3 ms of its 0.37 ms)
+WGRAD_SIDE_US = float(os.environ.get('EAS_WGRAD_SIDE_US', '0'))       # a batch also leaves once its estimated kernel time reaches this (0: count only)
+WGRAD_SIDE_AT = tuple(int(v) for v in os.environ.get('EAS_WGRAD_SIDE_AT', '').split(',') if v.strip())   # or: after these launch counts of the pass
+_SIDE = {'stream': None, 'pending': [], 'keep': [], 'dirty': False, 'us': 0.0, 'seen': 0}
+
+
+def _wgrad_launch(job, keep, defer, issue_flops=0.0, nbytes=0.0):
+    """run the slab-kernel launch ``job()`` now, or -- a deferred gradient with the side stream switched on -- with the next batch"""
+    if not (defer and (WGRAD_SIDE_BATCH > 0 or WGRAD_SIDE_US > 0 or WGRAD_SIDE_AT) and DEFER_WGRAD_REDUCE):
+        job()
+        return
+    _SIDE['pending'].append(job)
+    _SIDE['keep'].extend(keep)
+    _SIDE['us'] += max(issue_flops / 1.3e15, nbytes / 5e12) * 1e6
+    _SIDE['seen'] += 1
+    if ((WGRAD_SIDE_BATCH > 0 and len(_SIDE['pending']) >= WGRAD_SIDE_BATCH) or (WGRAD_SIDE_US > 0 and _SIDE['us'] >= WGRAD_SIDE_US)
+            or _SIDE['seen'] in WGRAD_SIDE_AT):
+        _side_flush()
+
+
+def _side_flush():
+    jobs, _SIDE['pending'] = _SIDE['pending'], []
+    _SIDE['us'] = 0.0
+    if not jobs:
+        return
+    if _SIDE['stream'] is None:
+        _SIDE['stream'] = torch.cuda.Stream()
+    side = _SIDE['stream']
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for job in jobs:
+            job()
+    _SIDE['dirty'] = True
+
+
+def _side_join():
+    _side_flush()
+    if _SIDE['dirty']:
+        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
+        _SIDE['dirty'] = False
+    _SIDE['keep'] = []
+    _SIDE['seen'] = 0
 
 
 def _flush_wgrad_reductions():
@@ -1701,6 +1752,7 @@ def _flush_wgrad_reductions():
     still the parameter's ``.grad`` (AccumulateGrad adopted it, nothing has been added to it in place): anything else means the
     deferral was switched on for a backward pass it is not sound for, and fails loudly instead of writing through a stale address."""
     global _PENDING_REDUCE
+    _side_join()                 # slab kernels still pending or running on the side stream: the reduction reads their slabs
     jobs, _PENDING_REDUCE = _PENDING_REDUCE, []
     if not jobs:
         return
@@ -1783,15 +1835,25 @@ def conv_wgrad(x, gy, ksize, stride, x_terms, x_sp=None, defer=False, w=None, sp
     ws = torch.empty(nws, dtype=torch.float32, device=gy.device)
     gw = torch.empty((Cout, Cin, ksize, ksize), dtype=torch.float32, device=gy.device)
     fl = 2.0 * gy.numel() * Cin * ksize * ksize
+    ns = nws // (Cout * Cin * ksize * ksize)         # the slab count the launch returns (checked in the job)
     if x_sp is not None:
         x_sp = x_sp.contiguous()
-        ns = _partial_call('eas_conv_wgrad', 2 * NI * Cin * Hi * Wi + 4 * gy.numel(), L.eas_conv_wgrad_planes_partial, ptr(x_sp), ptr(gy), ptr(ws), NI,
-                           Cin, Cout, Hi, Wi, ksize, stride, stream(), flops=fl, issue_flops=fl * 3)
+
+        def job():
+            got = _partial_call('eas_conv_wgrad', 2 * NI * Cin * Hi * Wi + 4 * gy.numel(), L.eas_conv_wgrad_planes_partial, ptr(x_sp), ptr(gy), ptr(ws),
+                                NI, Cin, Cout, Hi, Wi, ksize, stride, stream(), flops=fl, issue_flops=fl * 3)
+            assert got == ns, (got, ns)
+        keep = (x_sp, gy, ws)
     else:
         _dev(x)
         x = _f32c(x)
-        ns = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout, Hi, Wi,
-                           ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+
+        def job():
+            got = _partial_call('eas_conv_wgrad', 4 * (x.numel() + gy.numel()), L.eas_conv_wgrad_partial, ptr(x), ptr(gy), ptr(ws), NI, Cin, Cout,
+                                Hi, Wi, ksize, stride, x_terms, stream(), flops=fl, issue_flops=fl * (3 if x_terms == 1 else 6))
+            assert got == ns, (got, ns)
+        keep = (x, gy, ws)
+    _wgrad_launch(job, keep, defer, fl * (3 if (x_sp is not None or x_terms == 1) else 6), 4.0 * gy.numel() + (2.0 if x_sp is not None else 4.0) * NI * Cin * Hi * Wi)
     _wgrad_finish(ws, gw, ns, defer, w, split)
     return gw
 

@@ -162,15 +162,19 @@ class _ConvGroupFn(torch.autograd.Function):
                     q.NI, q.Cin, q.Cout, q.Hi, q.Wi = x.shape[0], x.shape[1], gy.shape[1], x.shape[2], x.shape[3]
                     nbytes += 4 * (x.numel() + gy.numel())
                     fl += 2.0 * gy.numel() * x.shape[1] * k * k
-                ops._call('eas_conv_wgrad', nbytes, _lib.lib().eas_conv_wgrad_group_partial, arr, m, k, 3, stream(), flops=fl, issue_flops=6 * fl)
-                for i, ws, s_ in zip(need_w, wss, ns):
+                defers = [(ops._can_defer(was[i]) and (not dual or (ctx.needs_input_grad[1 + n + i] and ctx.needs_input_grad[1 + 2 * n + i]
+                                                                    and ops._can_defer(wbs[i])))) for i in need_w]
+
+                def job(arr=arr, m=m, nbytes=nbytes, fl=fl):
+                    ops._call('eas_conv_wgrad', nbytes, _lib.lib().eas_conv_wgrad_group_partial, arr, m, k, 3, stream(), flops=fl, issue_flops=6 * fl)
+                ops._wgrad_launch(job, [xs[i] for i in need_w] + [gys[i] for i in need_w] + wss, all(defers), 6 * fl, nbytes)
+                for i, ws, s_, df in zip(need_w, wss, ns, defers):
                     gw = torch.empty((gys[i].shape[1], xs[i].shape[1], k, k), dtype=torch.float32, device=ws.device)
                     if dual:
                         both = ctx.needs_input_grad[1 + n + i] and ctx.needs_input_grad[1 + 2 * n + i]
-                        ops._wgrad_finish(ws, gw, s_, both and ops._can_defer(was[i]) and ops._can_defer(wbs[i]), (was[i], wbs[i]) if both else None,
-                                          was[i].shape[0] if both else None)
+                        ops._wgrad_finish(ws, gw, s_, df, (was[i], wbs[i]) if both else None, was[i].shape[0] if both else None)
                     else:
-                        ops._wgrad_finish(ws, gw, s_, ops._can_defer(was[i]), was[i])
+                        ops._wgrad_finish(ws, gw, s_, df, was[i])
                     gws.append(gw)
             else:       # a subset of the problems (some weights frozen) the group plan does not take: one by one
                 for i in need_w:
@@ -405,10 +409,14 @@ class _PredGroupFn(torch.autograd.Function):
                 q.NI, q.Cin, q.Cout, q.Hi, q.Wi = x.shape[0], x.shape[1], gy.shape[1], x.shape[2], x.shape[3]
                 nbytes += 4 * (x.numel() + gy.numel())
                 fl += 2.0 * gy.numel() * x.shape[1]
-            ops._call('eas_conv_wgrad', nbytes, _lib.lib().eas_conv_wgrad_group_partial, arr, m, 1, 3, stream(), flops=fl, issue_flops=6 * fl)
-            for w, gy, x, wsb, s_ in zip(ws, gys, xs, wss, ns):
+            defers = [ops._can_defer(w) for w in ws]
+
+            def job(arr=arr, m=m, nbytes=nbytes, fl=fl):
+                ops._call('eas_conv_wgrad', nbytes, _lib.lib().eas_conv_wgrad_group_partial, arr, m, 1, 3, stream(), flops=fl, issue_flops=6 * fl)
+            ops._wgrad_launch(job, list(xs) + list(gys) + wss, all(defers), 6 * fl, nbytes)
+            for w, gy, x, wsb, s_, df in zip(ws, gys, xs, wss, ns, defers):
                 gw = torch.empty((gy.shape[1], x.shape[1], 1, 1), dtype=torch.float32, device=x.device)
-                ops._wgrad_finish(wsb, gw, s_, ops._can_defer(w), w)
+                ops._wgrad_finish(wsb, gw, s_, df, w)
                 gws.append(gw)
         else:
             for w, gy, x in zip(ws, gys, xs):
