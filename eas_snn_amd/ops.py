@@ -1743,6 +1743,8 @@ def _side_join():
     if _SIDE['dirty']:
         torch.cuda.current_stream().wait_stream(_SIDE['stream'])
         _SIDE['dirty'] = False
+    if os.environ.get('EAS_WGRAD_SIDE_LOG') and _SIDE['seen']:
+        print(f"[eas] side stream: {_SIDE['seen']} slab launches in this pass", flush=True)
     _SIDE['keep'] = []
     _SIDE['seen'] = 0
 
