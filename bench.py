@@ -414,11 +414,13 @@ def canvas_640_figure(dev, batch, events):
     assert torch.isfinite(loss), 'the 640x640 step produced a non-finite loss'
     ops.check_tags('the 640x640 steps')
     timer = ops.KernelTimer()
+    side_batch, ops.WGRAD_SIDE_BATCH = ops.WGRAD_SIDE_BATCH, 0
     ops.set_timer(timer)
     for _ in range(3):
         step.eager()
     torch.cuda.synchronize()
     ops.set_timer(None)
+    ops.WGRAD_SIDE_BATCH = side_batch
     summ = timer.summary()
     r = dominant_roofline(summ)
     out = {'workload': w['name'], 'batch': batch, 'ms_per_step': round(ms, 3), 'event_frames_per_s': round(batch / ms * 1e3, 1), 'launch': launch,
@@ -534,11 +536,15 @@ def main():
     # recorded into a captured graph, and ~1400 event records per eager step would slow the timed region itself by ~10 %.
     # With more than one rank every rank runs these steps (the all-reduces need all of them); rank 0 records.
     timed_steps = 3
+    # (serial launches for these steps: the weight-gradient slab kernels of the timed region run on a side stream under the backward chain,
+    # where an event pair around one of them -- or around a chain kernel they share the chip with -- measures the overlap, not the kernel)
+    side_batch, ops.WGRAD_SIDE_BATCH = ops.WGRAD_SIDE_BATCH, 0
     ops.set_timer(timer)
     for _ in range(timed_steps):
         step.eager()
     torch.cuda.synchronize()
     ops.set_timer(None)
+    ops.WGRAD_SIDE_BATCH = side_batch
     # The first kernel of a step (raw input -> frames: K1 / the stacked-histogram reduction) starts on an idle queue in those eager steps,
     # so its event pair also spans the host's submission latency (128 us recorded for a 65 us kernel).  Re-timed back to back: eleven calls,
     # the first dropped, scaled to the three steps the other entries cover.
@@ -638,7 +644,7 @@ def main():
                                     'scripts/gpu_profile.sh; configs 2 and 3), not re-measured in this run',
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
-                  'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region'
+                  'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region (all launches on one stream there)'
                                    + (f'; {timer.input_retimed} (the first kernel of a step, which starts on an idle queue there) re-timed in ten back-to-back calls' if getattr(timer, 'input_retimed', None) else '')}
         if d['flops'] > 0:
             # dense convolutions: bounded by the matrix cores.  achieved = algorithmic flops (2 x MAC of the fp32 convolution) per
@@ -689,6 +695,8 @@ def main():
                            'baseline_config': w['config'], 'global_batch': batch * world,
                            'events_per_sample': args.events if w['input'] == 'events' else None, 'parallelism': f'dp{world}',
                            'gradient_exchange': ((f'{trainer.exchange.nbuckets} flat bucket(s)' if trainer.exchange is not None else trainer.dp) if multi else None),
+                           'weight_gradient_side_stream': (f'slab kernels in batches of {ops.WGRAD_SIDE_BATCH} on one side stream, joined before the batched reduction'
+                                                           if ops.WGRAD_SIDE_BATCH > 0 else None),
                            'launch': launch, 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                            'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3),
                            'h2d_per_step': (h2d.describe() if h2d is not None else None)},

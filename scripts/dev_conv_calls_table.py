@@ -23,6 +23,7 @@ def main():
     dev = torch.device('cuda:0')
     torch.cuda.set_stream(torch.cuda.Stream())
     ops.set_state_writeback(False)
+    ops.WGRAD_SIDE_BATCH = 0          # one stream: event pairs then measure kernels, not overlap
     trainer, model, step = workloads.build_trainer(w, batch, dev, 200_000, out_dir='/tmp/eas_calls_table')
     for _ in range(3):
         step.eager()

@@ -24,6 +24,7 @@ def main():
     dev = torch.device('cuda:0')
     torch.cuda.set_stream(torch.cuda.Stream())
     ops.set_state_writeback(False)
+    ops.WGRAD_SIDE_BATCH = 0          # one stream: event pairs then measure kernels, not overlap
     exp = workloads.build_exp(w)
     exp.ema = False
     exp.output_dir = '/tmp/eas_layer_times'
