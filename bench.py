@@ -39,13 +39,15 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 # command, scripts/gpu_profile.sh; gfx950 corrections applied by scripts/pmc_summary.py).  C-ABI entry -> device kernels.
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')      # config 2; other configurations: pmc_traffic_latest_config<N>.json
 PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel', 'bn_lif_bwd_small_kernel'], 'eas_bn_lif_fwd': ['bn_lif_fwd_kernel', 'bn_lif_fwd_sp_kernel'], 'eas_bn_stats': ['bn_stats_partial'],
-               'eas_bn_silu_bwd': ['bn_silu_bwd_kernel'], 'eas_bn_silu_fwd': ['bn_silu_fwd_kernel'],
+               'eas_bn_silu_bwd': ['bn_silu_bwd_kernel', 'bn_silu_bwd_small_kernel', 'bn_silu_bwd_group_kernel'],
+               'eas_bn_silu_fwd': ['bn_silu_fwd_kernel', 'bn_silu_fwd_group_kernel'],
                'eas_event_histogram': ['event_hist_kernel', 'event_hist_banded_kernel', 'event_hist_banded16_kernel'],
                'eas_arsnn_step_fwd': ['arsnn_step_fwd_kernel', 'arsnn_fused_step_fwd_kernel'],
                'eas_smallconv_fwd': ['smallconv_kernel'], 'eas_smallconv_bwd_weight': ['smallconv_wgrad_kernel', 'smallconv_wgrad_mfma_kernel'],
                'eas_conv_fwd': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel', 'conv1x1_mfma_sharedA_kernel', 'conv_dgrad_s2_kernel',
-                                'conv_fwd_mfma_kernel[planes]', 'conv1x1_mfma_kernel[planes]', 'conv1x1_mfma_sharedA_kernel[planes]'],
-               'eas_conv_wgrad': ['conv_wgrad_mfma_kernel', 'conv1x1_wgrad_lds_kernel', 'conv_wgrad_mfma_kernel[planes]',
+                                'conv3x3_group_kernel', 'conv1x1_group_kernel', 'conv_fwd_mfma_kernel[planes]', 'conv1x1_mfma_kernel[planes]', 'conv1x1_mfma_sharedA_kernel[planes]'],
+               'eas_conv_wgrad': ['conv_wgrad_mfma_kernel', 'conv1x1_wgrad_lds_kernel', 'conv_wgrad_group_kernel', 'conv1x1_wgrad_group_kernel',
+                                  'conv_wgrad_mfma_kernel[planes]',
                                   'conv1x1_wgrad_lds_kernel[planes]']}
 
 

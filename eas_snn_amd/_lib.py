@@ -105,6 +105,7 @@ PROTOTYPES = {
     'eas_conv_bn_lif_eval': (C.c_int, [C.POINTER(EasConvBnLifEval), _P]),
     'eas_conv_bn_lif_eval_supported': (C.c_int, [C.c_int] * 10),
     'eas_conv_bn_act_eval': (C.c_int, [C.POINTER(EasConvBnActEval), _P, _P]),
+    'eas_conv_bn_act_eval_group': (C.c_int, [C.POINTER(EasConvBnActEval), C.c_int, _P]),
     'eas_event_histogram': (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_event_histogram_dat': (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     'eas_counts_to_canvas': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

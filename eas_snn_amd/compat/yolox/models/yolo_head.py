@@ -216,6 +216,58 @@ class YOLOXHead(nn.Module):
         cls_o, reg_o, obj_o = G.pred_group(cf, rf, list(self.cls_preds), list(self.reg_preds), list(self.obj_preds))
         return [(reg_o[k], obj_o[k], cls_o[k]) for k in range(n)]
 
+    def _levels_grouped_eval(self, xs):
+        """Eval mode: the same stage-by-stage walk with every stage ONE grouped launch of the fused conv -> BatchNorm (running statistics) ->
+        SiLU kernel (``ops_group.conv_bn_act_eval_group``; also for a head folded by ``fuse_model``) and the nine prediction convolutions one
+        launch.  Bit-identical to the per-level forward.  None = not eligible."""
+        n = len(xs)
+        if not (G.ENABLED and not self.training and not self.full_spike and 1 < n <= 4 and not torch.is_grad_enabled()):
+            return None
+        blocks = []
+        for k in range(n):
+            cc, rc = self.cls_convs[k], self.reg_convs[k]
+            if len(cc) != 2 or len(rc) != 2:
+                return None
+            row = (self.stems[k], cc[0], rc[0], cc[1], rc[1])
+            for b in row:
+                if not (isinstance(b, BaseConv) and not b.spiking() and type(b.conv) is nn.Conv2d and b.eval_norm() is not None
+                        and not b._forward_hooks and not b._forward_pre_hooks):
+                    return None
+            blocks.append(row)
+        preds = list(self.cls_preds) + list(self.reg_preds) + list(self.obj_preds)
+        if any(type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.bias is None or c._forward_hooks or c._forward_pre_hooks for c in preds):
+            return None
+        stems = [r[0] for r in blocks]
+        if not G.conv_bn_act_eval_group_ok(xs, [b.conv for b in stems], [[b.eval_norm()] for b in stems], 1):
+            return None
+        s = G.conv_bn_act_eval_group(xs, [b.conv for b in stems], [[b.eval_norm()] for b in stems], 1)
+        pairs = [(r[1].conv, r[2].conv) for r in blocks]
+        pnorms = [[r[1].eval_norm(), r[2].eval_norm()] for r in blocks]
+        convs2 = [r[3].conv for r in blocks] + [r[4].conv for r in blocks]
+        norms2 = [[r[3].eval_norm()] for r in blocks] + [[r[4].eval_norm()] for r in blocks]
+        if not G.conv_bn_act_eval_group_ok(s, pairs, pnorms, 3):
+            return [self._level_from_stem(k, s[k]) for k in range(n)]
+        o = G.conv_bn_act_eval_group(s, pairs, pnorms, 3, owners=[(self, f'tower{k}') for k in range(n)])
+        ca, ra = [p[0] for p in o], [p[1] for p in o]
+        if G.conv_bn_act_eval_group_ok(ca + ra, convs2, norms2, 3):
+            f = G.conv_bn_act_eval_group(ca + ra, convs2, norms2, 3)
+            cf, rf = f[:n], f[n:]
+        else:
+            cf = [blocks[k][3](ca[k]) for k in range(n)]
+            rf = [blocks[k][4](ra[k]) for k in range(n)]
+        if G.pred_eval_ok(cf + rf + rf, preds):
+            po = G.conv_bias_group(cf + rf + rf, preds)
+            cls_o, reg_o, obj_o = po[:n], po[n:2 * n], po[2 * n:]
+        else:
+            cls_o = [_pred(self.cls_preds[k], cf[k]) for k in range(n)]
+            reg_o = [_pred(self.reg_preds[k], rf[k]) for k in range(n)]
+            obj_o = [_pred(self.obj_preds[k], rf[k]) for k in range(n)]
+        return [(reg_o[k], obj_o[k], cls_o[k]) for k in range(n)]
+
+    def _level_from_stem(self, k, x):
+        cls_feat, reg_feat = self._towers(k, x)
+        return _pred(self.reg_preds[k], reg_feat), _pred(self.obj_preds[k], reg_feat), _pred(self.cls_preds[k], cls_feat)
+
     def _group_geometry_ok(self, xs, blocks, pairs):
         """every later stage of ``_levels_grouped`` has a grouped tile plan (cached per input geometry; the stems keep H x W, so the stages'
         inputs are known by shape before they exist)"""
@@ -244,6 +296,11 @@ class YOLOXHead(nn.Module):
             if fused:
                 # decode + assignment + loss terms + their gradient in five launches (ops.det_loss)
                 return ops.det_loss(regs, objs, clss, labels, self.strides, self.num_classes, self.use_l1)
+        elif not self.training:
+            feats = [self._prepare(x) for x in xin]
+            raws = self._levels_grouped_eval(feats)
+            if raws is None:
+                raws = [self._level(k, x) for k, x in enumerate(feats)]
         else:
             raws = None
         for k, (stride, x) in enumerate(zip(self.strides, xin)):

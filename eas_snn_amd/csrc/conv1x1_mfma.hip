@@ -32,6 +32,9 @@ struct C1GeomCore {
     int act;                          // epilogue activation on (acc + bias): 0 none, 1 SiLU (eas_conv_fwd_act)
     int accum;                        // y += conv(x) + bias instead of y = (grouped launches: the second reader's input gradient, EasConvProblem.accumulate)
 };
+struct C1GeomBna : C1GeomCore {      // + the BatchNorm / activation epilogue (LM = 3) of a grouped eas_conv_bn_act_eval
+    EasBnActEpiDev bna;
+};
 struct C1Geom : C1GeomCore {
     // fused eval step conv -> BatchNorm (running statistics) -> LIF over T (kernel template LM = 1, conv_lif_epi.h): NI = samples N, total_tiles
     // counts SPATIAL 32-pixel tiles, pixel tile n of a wave = time step n (WN == lif.T): image n * N + sample
@@ -306,8 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(const float* __res
 
 // Grouped launch (include/eas_hip.h eas_conv_fwd_group, ksize 1): problem p owns pixel blocks [first[p], first[p + 1]) of grid.x
 constexpr int kMaxGroup1 = 12;
-struct C1GroupArgs {
-    C1GeomCore g[kMaxGroup1];
+template <typename G>
+struct C1GroupArgsT {
+    G g[kMaxGroup1];
     const float* x[kMaxGroup1];
     const bf16x8* wp[kMaxGroup1];
     const float* bias[kMaxGroup1];
@@ -315,15 +319,16 @@ struct C1GroupArgs {
     int first[kMaxGroup1 + 1];
     int n;
 };
+typedef C1GroupArgsT<C1GeomCore> C1GroupArgs;
 
-template <int XT, int WM, int WN, bool RAGK>
-__global__ __launch_bounds__(256, 2) void conv1x1_group_kernel(const C1GroupArgs a) {
+template <int XT, int WM, int WN, bool RAGK, int LM = 0, typename G = C1GeomCore>
+__global__ __launch_bounds__(256, 2) void conv1x1_group_kernel(const C1GroupArgsT<G> a) {
     int p = 0;
     for (int i = 1; i < a.n; ++i)
         if ((int)blockIdx.x >= a.first[i]) p = i;
     p = __builtin_amdgcn_readfirstlane(p);
     if ((int)blockIdx.y * WM >= a.g[p].MT) return;        // grid.y covers the widest problem
-    c1_body<XT, WM, WN, RAGK, false, 0, C1GeomCore>(a.x[p], a.wp[p], a.bias[p], a.y[p], a.g[p], (int)blockIdx.x - a.first[p], (int)blockIdx.y);
+    c1_body<XT, WM, WN, RAGK, false, LM, G>(a.x[p], a.wp[p], a.bias[p], a.y[p], a.g[p], (int)blockIdx.x - a.first[p], (int)blockIdx.y);
 }
 
 // Variant for layers with many input channels and few pixels (dark5: 256..1024 channels on 15 360 pixels).  There the direct
@@ -741,9 +746,24 @@ int launch_c1_group(const C1GroupArgs& a, int grid_y, hipStream_t st) {
     EAS_LAUNCH((conv1x1_group_kernel<XT, WM, WN, RAGK>), dim3(a.first[a.n], grid_y), dim3(256), 0, st, a);
     return EAS_OK;
 }
+// the same launch with the BatchNorm / activation epilogue (grouped eas_conv_bn_act_eval)
+template <int WM, int WN>
+int launch_c1_group_bna(const C1GroupArgs& a, const EasBnActEpiDev* bna, const int* order, int grid_y, hipStream_t st) {
+    C1GroupArgsT<C1GeomBna> b{};
+    for (int i = 0; i < a.n; ++i) {
+        static_cast<C1GeomCore&>(b.g[i]) = a.g[i];
+        b.g[i].bna = bna[order[i]];
+        b.x[i] = a.x[i]; b.wp[i] = a.wp[i]; b.bias[i] = nullptr; b.y[i] = a.y[i];
+    }
+    for (int i = 0; i <= a.n; ++i) b.first[i] = a.first[i];
+    b.n = a.n;
+    EAS_LAUNCH((conv1x1_group_kernel<3, WM, WN, false, 3, C1GeomBna>), dim3(b.first[b.n], grid_y), dim3(256), 0, st, b);
+    return EAS_OK;
+}
 }  // namespace
 
-int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t st, int* nb_out, bool query) {
+int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t st, int* nb_out, bool query, const void* bna_) {
+    const EasBnActEpiDev* bna = (const EasBnActEpiDev*)bna_;
     if (n > kMaxGroup1 || x_terms != 3) return EAS_ERR_UNSUPPORTED;
     C1GroupArgs a{};
     bool ragk = false;
@@ -798,6 +818,11 @@ int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t 
     a = b;
     if (query) return EAS_OK;
     const int gy = (mt_max + wm - 1) / wm;
+    if (bna) {
+        if (ragk) return EAS_ERR_UNSUPPORTED;
+        if (wm == 4) return wn == 2 ? launch_c1_group_bna<4, 2>(a, bna, order, gy, st) : launch_c1_group_bna<4, 1>(a, bna, order, gy, st);
+        return wm == 2 ? launch_c1_group_bna<2, 1>(a, bna, order, gy, st) : launch_c1_group_bna<1, 1>(a, bna, order, gy, st);
+    }
     if (ragk) return wm == 4 ? launch_c1_group<3, 4, 1, true>(a, gy, st) : launch_c1_group<3, 1, 1, true>(a, gy, st);
     if (wm == 4) return wn == 2 ? launch_c1_group<3, 4, 2, false>(a, gy, st) : launch_c1_group<3, 4, 1, false>(a, gy, st);
     return wm == 2 ? launch_c1_group<3, 2, 1, false>(a, gy, st) : launch_c1_group<3, 1, 1, false>(a, gy, st);

@@ -13,8 +13,9 @@ namespace {
 
 constexpr int kMaxGroup = 8;
 
-struct ConvGroupArgs {
-    ConvGeomCore g[kMaxGroup];
+template <typename G>
+struct ConvGroupArgsT {
+    G g[kMaxGroup];
     const float* x[kMaxGroup];
     const bf16x8* wp[kMaxGroup];
     const float* bias[kMaxGroup];
@@ -23,9 +24,12 @@ struct ConvGroupArgs {
     int vec2[kMaxGroup];           // 1: the problem's rows are staged in 2-pixel units (Wi % 4 != 0)
     int n;
 };
+typedef ConvGroupArgsT<ConvGeomCore> ConvGroupArgs;
 
-template <int XT, int WN, int WVM, int WVN, int NIT>
-__global__ __launch_bounds__(64 * WVM * WVN, 2) void conv3x3_group_kernel(const ConvGroupArgs a) {
+// LM = 0: the plain epilogue (y, bias, BatchNorm partial sums); LM = 3: BatchNorm (running statistics) + activation on the accumulators
+// (grouped eas_conv_bn_act_eval: the eval-mode head), G = the geometry type that carries what the epilogue reads
+template <int XT, int WN, int WVM, int WVN, int NIT, int LM = 0, typename G = ConvGeomCore>
+__global__ __launch_bounds__(64 * WVM * WVN, 2) void conv3x3_group_kernel(const ConvGroupArgsT<G> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     int p = 0;
     for (int i = 1; i < a.n; ++i)
@@ -34,16 +38,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, 2) void conv3x3_group_kernel(const 
     const int bx = (int)blockIdx.x - a.first[p], gx = a.first[p + 1] - a.first[p];
     if ((int)blockIdx.y * WVM >= a.g[p].MT) return;        // grid.y covers the widest problem: no channels left for this block (whole block exits)
     if (a.vec2[p])
-        conv_tile_body<9, 1, XT, 1, WN, WVM, WVN, 16, 2, NIT, false, 0, ConvGeomCore>(a.x[p], a.wp[p], a.bias[p], a.y[p], nullptr, a.g[p], 0, smem, bx,
-                                                                                     (int)blockIdx.y, gx);
+        conv_tile_body<9, 1, XT, 1, WN, WVM, WVN, 16, 2, NIT, false, LM, G>(a.x[p], a.wp[p], a.bias[p], a.y[p], nullptr, a.g[p], 0, smem, bx,
+                                                                            (int)blockIdx.y, gx);
     else
-        conv_tile_body<9, 1, XT, 1, WN, WVM, WVN, 16, 4, NIT, false, 0, ConvGeomCore>(a.x[p], a.wp[p], a.bias[p], a.y[p], nullptr, a.g[p], 0, smem, bx,
-                                                                                     (int)blockIdx.y, gx);
+        conv_tile_body<9, 1, XT, 1, WN, WVM, WVN, 16, 4, NIT, false, LM, G>(a.x[p], a.wp[p], a.bias[p], a.y[p], nullptr, a.g[p], 0, smem, bx,
+                                                                            (int)blockIdx.y, gx);
 }
 
-template <int XT, int WN, int WVM, int WVN, int NIT>
-int launch_group3(const ConvGroupArgs& a, int grid_y, size_t lds, hipStream_t st) {
-    auto kern = conv3x3_group_kernel<XT, WN, WVM, WVN, NIT>;
+template <int XT, int WN, int WVM, int WVN, int NIT, int LM, typename G>
+int launch_group3(const ConvGroupArgsT<G>& a, int grid_y, size_t lds, hipStream_t st) {
+    auto kern = conv3x3_group_kernel<XT, WN, WVM, WVN, NIT, LM, G>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return EAS_ERR_LAUNCH;
@@ -53,8 +57,18 @@ int launch_group3(const ConvGroupArgs& a, int grid_y, size_t lds, hipStream_t st
     return EAS_OK;
 }
 
-typedef int (*group3_fn)(const ConvGroupArgs&, int, size_t, hipStream_t);
-struct GCand { int wvm, wvn, wn, nit; group3_fn fn; };
+struct GCand { int wvm, wvn, wn, nit; };
+static const GCand kCands[4] = {{4, 1, 5, 2}, {2, 2, 5, 2}, {4, 1, 3, 2}, {2, 2, 3, 2}};
+
+template <int XT, int LM, typename G>
+int launch_cand3(int i, const ConvGroupArgsT<G>& a, int grid_y, size_t lds, hipStream_t st) {
+    switch (i) {
+        case 0: return launch_group3<XT, 5, 4, 1, 2, LM, G>(a, grid_y, lds, st);
+        case 1: return launch_group3<XT, 5, 2, 2, 2, LM, G>(a, grid_y, lds, st);
+        case 2: return launch_group3<XT, 3, 4, 1, 2, LM, G>(a, grid_y, lds, st);
+        default: return launch_group3<XT, 3, 2, 2, 2, LM, G>(a, grid_y, lds, st);
+    }
+}
 
 // geometry of one 3x3 stride-1 problem (padding 1), before a tile is chosen: conv_fwd_impl's set-up
 void base_geom(ConvGeomCore& g, const EasConvProblem& q) {
@@ -92,27 +106,26 @@ bool fit_tile(ConvGeomCore& t, const GCand& c, int vec) {
 }
 
 // One tile shape for all problems of the group: the cost model of dispatch_tile (conv_mfma_body.h) over the SUM of the problems' blocks.
-template <int XT>
-int plan_group3(const EasConvProblem* pr, int n, ConvGroupArgs& a, int& best, int& grid_y, size_t& lds, int* nb_out) {
-    static const GCand cands[4] = {{4, 1, 5, 2, launch_group3<XT, 5, 4, 1, 2>}, {2, 2, 5, 2, launch_group3<XT, 5, 2, 2, 2>},
-                                   {4, 1, 3, 2, launch_group3<XT, 3, 4, 1, 2>}, {2, 2, 3, 2, launch_group3<XT, 3, 2, 2, 2>}};
+template <int XT, typename G>
+int plan_group3(const EasConvProblem* pr, int n, ConvGroupArgsT<G>& a, int& best, int& grid_y, size_t& lds, int* nb_out) {
+    const GCand* cands = kCands;
     static const int force = eas_dev_env("EAS_GROUP3_TILE") ? atoi(eas_dev_env("EAS_GROUP3_TILE")) : -1;      // development: force a candidate
     best = -1;
     double best_cost = 0.0;
-    ConvGroupArgs best_a = a;
+    ConvGroupArgsT<G> best_a = a;
     for (int i = 0; i < 4; ++i) {
         if (force >= 0 && i != force) continue;
         const GCand& c = cands[i];
         int cout_min = 1 << 30;
         for (int p = 0; p < n; ++p) cout_min = pr[p].Cout < cout_min ? pr[p].Cout : cout_min;
         if ((c.wvm - 1) * 32 >= cout_min) continue;          // every wave row has channels to compute in every problem
-        ConvGroupArgs t = a;
+        ConvGroupArgsT<G> t = a;
         bool ok = true;
         double load = 0.0;
         size_t lds_max = 0;
         int gy = 1, blocks_x = 0;
         for (int p = 0; p < n && ok; ++p) {
-            ConvGeomCore& g = t.g[p];
+            G& g = t.g[p];
             base_geom(g, pr[p]);
             const int vec = pr[p].Wi % 4 == 0 ? 4 : 2;
             t.vec2[p] = vec == 2;
@@ -147,7 +160,7 @@ int plan_group3(const EasConvProblem* pr, int n, ConvGroupArgs& a, int& best, in
     const size_t stats_lds = (size_t)c.wvm * c.wvn * (EAS_STATS_SCRATCH * sizeof(float) + 64 * sizeof(double));
     bool any_stats = false;
     for (int p = 0; p < n; ++p) {
-        ConvGeomCore& g = a.g[p];
+        G& g = a.g[p];
         const int gxp = a.first[p + 1] - a.first[p];
         if (nb_out) nb_out[p] = gxp;
         g.stats = pr[p].stats;
@@ -164,19 +177,28 @@ int plan_group3(const EasConvProblem* pr, int n, ConvGroupArgs& a, int& best, in
 
 template <int XT>
 int group3(const EasConvProblem* pr, int n, hipStream_t st, int* nb_out, bool query) {
-    static const GCand cands[4] = {{4, 1, 5, 2, launch_group3<XT, 5, 4, 1, 2>}, {2, 2, 5, 2, launch_group3<XT, 5, 2, 2, 2>},
-                                   {4, 1, 3, 2, launch_group3<XT, 3, 4, 1, 2>}, {2, 2, 3, 2, launch_group3<XT, 3, 2, 2, 2>}};
     ConvGroupArgs a{};
     int best = -1, grid_y = 1;
     size_t lds = 0;
-    const int rc = plan_group3<XT>(pr, n, a, best, grid_y, lds, nb_out);
+    const int rc = plan_group3<XT, ConvGeomCore>(pr, n, a, best, grid_y, lds, nb_out);
     if (rc != EAS_OK || query) return rc;
-    return cands[best].fn(a, grid_y, lds, st);
+    return launch_cand3<XT, 0, ConvGeomCore>(best, a, grid_y, lds, st);
+}
+
+// grouped eas_conv_bn_act_eval, 3x3: the same plan, every problem's BatchNorm / activation descriptor in its geometry
+int group3_bna(const EasConvProblem* pr, const EasBnActEpiDev* bna, int n, hipStream_t st) {
+    ConvGroupArgsT<ConvGeomBna> a{};
+    int best = -1, grid_y = 1;
+    size_t lds = 0;
+    const int rc = plan_group3<3, ConvGeomBna>(pr, n, a, best, grid_y, lds, nullptr);
+    if (rc != EAS_OK) return rc;
+    for (int p = 0; p < n; ++p) a.g[p].bna = bna[p];
+    return launch_cand3<3, 3, ConvGeomBna>(best, a, grid_y, lds, st);
 }
 
 }  // namespace
 
-int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t st, int* nb_out, bool query);
+int eas_conv1x1_group(const EasConvProblem* pr, int n, int x_terms, hipStream_t st, int* nb_out, bool query, const void* bna = nullptr);
 
 static int conv_group_impl(const EasConvProblem* pr, int n, int ksize, int x_terms, eas_stream_t stream, int* nb_out, bool query) {
     if (!pr || n < 1) return EAS_ERR_INVALID_ARG;
@@ -208,6 +230,39 @@ int eas_conv_fwd_group_plan(const EasConvProblem* problems, int n, int ksize, in
 
 int eas_conv_fwd_group(const EasConvProblem* problems, int n, int ksize, int x_terms, eas_stream_t stream) {
     return conv_group_impl(problems, n, ksize, x_terms, stream, nullptr, false);
+}
+
+// include/eas_hip.h: eas_conv_bn_act_eval for several layers in one launch (the eval-mode head: the three pyramid levels of a stage)
+int eas_conv_bn_act_eval_group(const EasConvBnActEval* ds, int n, eas_stream_t stream) {
+    if (!ds || n < 1) return EAS_ERR_INVALID_ARG;
+    if (n > kMaxGroup) return EAS_ERR_UNSUPPORTED;
+    EasConvProblem pr[kMaxGroup] = {};
+    EasBnActEpiDev bna[kMaxGroup] = {};
+    const int ksize = ds[0].ksize;
+    for (int p = 0; p < n; ++p) {
+        const EasConvBnActEval* d = &ds[p];
+        if (!d->x || !d->packed_w || d->act < 0 || d->act > 1) return EAS_ERR_INVALID_ARG;
+        if (d->ksize != ksize || d->stride != 1 || d->x_terms != 3 || (ksize != 1 && ksize != 3)) return EAS_ERR_UNSUPPORTED;
+        if (d->Cout % 8 || d->Cin % 8 || d->csplit % 8 || d->csplit < 8 || d->csplit > d->Cout || (ksize == 3 && d->Wi % 2 != 0)) return EAS_ERR_UNSUPPORTED;
+        EasBnActEpiDev& b = bna[p];
+        b.on = 1; b.act = d->act; b.csplit = d->csplit; b.Cout = d->Cout;
+        const int nr = d->csplit < d->Cout ? 2 : 1;
+        for (int i = 0; i < nr; ++i) {
+            const EasBnActRange& r = d->range[i];
+            const int cr = i ? d->Cout - d->csplit : d->csplit;
+            if (!r.gamma || !r.beta || !r.mean || !r.invstd || !r.out || r.out_c0 < 0 || r.out_c0 + cr > r.out_ctot) return EAS_ERR_INVALID_ARG;
+            if ((((uintptr_t)r.gamma) | ((uintptr_t)r.beta) | ((uintptr_t)r.mean) | ((uintptr_t)r.invstd)) & 15) return EAS_ERR_INVALID_ARG;
+            b.r[i] = r;
+        }
+        if (nr == 1) b.r[1] = b.r[0];
+        pr[p].x = d->x; pr[p].packed_w = d->packed_w; pr[p].y = d->range[0].out;
+        pr[p].NI = d->NI; pr[p].Cin = d->Cin; pr[p].Cout = d->Cout; pr[p].Hi = d->Hi; pr[p].Wi = d->Wi;
+    }
+    EAS_CLEAR_ERR();
+    const int rc = ksize == 1 ? eas_conv1x1_group(pr, n, 3, eas_s(stream), nullptr, false, bna) : group3_bna(pr, bna, n, eas_s(stream));
+    if (rc != EAS_OK) return rc;
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
 }
 
 }  // extern "C"

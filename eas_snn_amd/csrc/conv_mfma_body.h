@@ -60,6 +60,11 @@ struct ConvGeomCore {
                    // weights and bias by fuse_model, yolox/utils/model_utils.py:35-80 -- "return self.act(self.conv(x))", network_blocks.py:55-56)
 };
 
+// the plain tiles + the BatchNorm / activation epilogue (LM = 3): what a grouped eas_conv_bn_act_eval carries per problem
+struct ConvGeomBna : ConvGeomCore {
+    EasBnActEpiDev bna;
+};
+
 struct ConvGeom : ConvGeomCore {
     EasLifEpiDev lif;
     EasBnActEpiDev bna;   // BatchNorm (running statistics) + activation in the plain epilogue (eas_conv_bn_act_eval); bna.on = 0: the plain store

@@ -458,3 +458,91 @@ def pred_group(cls_feats, reg_feats, cls_preds, reg_preds, obj_preds):
     cfg = dict(n=n, packs=packs)
     res = _PredGroupFn.apply(cfg, *cls_feats, *reg_feats, *[c.weight for c in convs], *[c.bias for c in convs])
     return list(res[:n]), list(res[n:2 * n]), list(res[2 * n:])
+
+
+# ------------------------------------------------------------------------------------------------ eval mode: conv -> BN -> SiLU of several layers, one launch
+def conv_bn_act_eval_group_ok(xs, items, norms, k):
+    """items[i] (an nn.Conv2d, or a pair that reads the same input) with norms[i] (their eval-mode BatchNorm2d modules, or -- after
+    fuse_model -- bias tensors) can run as ONE grouped eas_conv_bn_act_eval on the inputs xs: every problem passes the single-launch check
+    (``ops.fused_ann_eval_ok``) and the group has a common tile plan"""
+    if not ENABLED or len(xs) > 8:
+        return False
+    geoms = []
+    for x, it, nm in zip(xs, items, norms):
+        convs = it if isinstance(it, tuple) else (it,)
+        if not ops.fused_ann_eval_ok(x, it, list(nm)) or convs[0].kernel_size != (k, k) or convs[0].stride != (1, 1):
+            return False
+        geoms.append((x.shape[0], x.shape[1], sum(c.out_channels for c in convs), x.shape[2], x.shape[3]))
+    return _conv_plan(tuple(geoms), k) is not None
+
+
+def conv_bn_act_eval_group(xs, items, norms, k, owners=None):
+    """[act(bn(conv_i(x_i)))] in one launch (caller checked ``conv_bn_act_eval_group_ok``); returns per problem one tensor, or two for a pair"""
+    n = len(xs)
+    arr = (_lib.EasConvBnActEval * n)()
+    keep, results = [], []
+    nbytes, fl = 0, 0.0
+    for i, (d, x, it, nm) in enumerate(zip(arr, xs, items, norms)):
+        convs = it if isinstance(it, tuple) else (it,)
+        c0 = convs[0]
+        NI, Cin, H, W = x.shape
+        Cout = sum(c.out_channels for c in convs)
+        if len(convs) == 2:
+            packs = None
+            if owners is not None and owners[i] is not None:
+                packs = (getattr(owners[i][0], '_eas_dual_packs', None) or {}).get(owners[i][1])
+                packs = ops.current_packs(packs)
+            pk = packs[0] if packs else ops.conv_pack_weights(torch.cat([convs[0].weight, convs[1].weight], 0), 0)
+        else:
+            pk = _pack_of(c0, 0)
+            pk = pk[0] if pk is not None else ops.conv_pack_weights(c0.weight, 0)
+        xd = ops._f32c(x)
+        keep += [pk, xd]
+        d.x, d.x_terms, d.packed_w = ptr(xd), 3, ptr(pk)
+        d.NI, d.Cin, d.Cout, d.Hi, d.Wi, d.ksize, d.stride = NI, Cin, Cout, H, W, k, 1
+        d.act = 1
+        d.csplit = convs[0].out_channels
+        outs = []
+        for j, bn in enumerate(nm):
+            r = d.range[j]
+            Cr = convs[j].out_channels if len(convs) > 1 else Cout
+            if torch.is_tensor(bn):              # a block folded by fuse_model: z = acc * 1 + bias
+                ones, zeros = ops._unit_affine(Cr, x.device)
+                r.gamma, r.beta, r.mean, r.invstd = ptr(ones), ptr(bn), ptr(zeros), ptr(ones)
+            else:
+                invstd = ops._eval_invstd(bn.running_var, bn.eps)
+                keep.append(invstd)
+                r.gamma, r.beta, r.mean, r.invstd = ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(invstd)
+            out = torch.empty((NI, Cr, H, W), dtype=torch.float32, device=x.device)
+            r.out, r.out_ctot, r.out_c0 = ptr(out), Cr, 0
+            outs.append(out)
+        results.append(outs if len(nm) > 1 else outs[0])
+        fl += 2.0 * NI * Cout * H * W * Cin * k * k
+        nbytes += 4 * NI * (Cin + Cout) * H * W
+    ops._call('eas_conv_fwd', nbytes, _lib.lib().eas_conv_bn_act_eval_group, arr, n, stream(), flops=fl, issue_flops=6 * fl)
+    del keep
+    return results
+
+
+def pred_eval_ok(xs, convs):
+    if not ENABLED or len(xs) > 12 or torch.is_grad_enabled() or ops.conv_sink() is not None or torch.nn.modules.module._global_forward_hooks:
+        return False
+    geoms = []
+    for x, c in zip(xs, convs):
+        if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and c.in_channels == x.shape[1] and c.in_channels % 8 == 0
+                and c.stride == (1, 1) and c.padding == (0, 0) and c.groups == 1) or ops.is_small_int(x):
+            return False
+        geoms.append((x.shape[0], x.shape[1], c.out_channels, x.shape[2], x.shape[3]))
+    return _conv_plan(tuple(geoms), 1) is not None
+
+
+def conv_bias_group(xs, convs):
+    """[conv_i(x_i) + bias_i] of plain 1x1 convolutions in one launch, no autograd (the prediction convolutions of the eval-mode head)"""
+    pks = []
+    for c in convs:
+        pk = _pack_of(c, 0)
+        pks.append(pk[0] if pk is not None else ops.conv_pack_weights(c.weight, 0))
+    xs = [ops._f32c(x) for x in xs]
+    ys = [torch.empty((x.shape[0], c.out_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x, c in zip(xs, convs)]
+    _launch_conv_group(xs, pks, [c.bias for c in convs], ys, None, 1)
+    return ys

@@ -640,6 +640,10 @@ typedef struct {
 int eas_conv_fwd_group_plan(const EasConvProblem* problems, int n, int ksize, int x_terms, int* nb_out);
 int eas_conv_fwd_group(const EasConvProblem* problems, int n, int ksize, int x_terms, eas_stream_t stream);
 
+/* eas_conv_bn_act_eval (above) for several layers in one launch: the eval-mode head's stage over its pyramid levels.  Same descriptors, same
+ * arithmetic per problem (bit-identical outputs); all problems ksize 1 or all ksize 3, stride 1, x_terms 3.  n <= 8. */
+int eas_conv_bn_act_eval_group(const EasConvBnActEval* problems, int n, eas_stream_t stream);
+
 /* eas_bn_silu_fwd_ex / eas_bn_silu_bwd for several layers in one launch (two launches for the backward: sums, apply).
  * workspace: eas_bn_workspace_doubles(C) doubles per problem. */
 typedef struct {

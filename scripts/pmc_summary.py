@@ -51,8 +51,8 @@ READ_WIDTH = [
     (r'bn_lif|bn_silu|bn_stats|lif_fwd|lif_bwd|spp_pool|upcat|focus|planes_', '16'),
     (r'arsnn|smallconv', '16'),
     (r'conv1x1_mfma.*<.*true>|conv_fwd_mfma.*true>|conv_wgrad_mfma.*true>|conv1x1_wgrad.*true>', '16'),     # spike planes: 16-byte loads
-    (r'conv1x1_mfma|conv1x1_wgrad', '4'),                                                                   # fp32 NCHW: one dword per channel row
-    (r'conv_fwd_mfma|conv_wgrad_mfma|conv_dgrad_s2', '16'),
+    (r'conv1x1_mfma|conv1x1_wgrad|conv1x1_group', '4'),                                                     # fp32 NCHW: one dword per channel row
+    (r'conv_fwd_mfma|conv_wgrad_mfma|conv_dgrad_s2|conv3x3_group|conv_wgrad_group', '16'),
     (r'event_|histogram', '4'),
 ]
 

@@ -1448,3 +1448,40 @@ def test_bench_step_holds_a_live_rccl_communicator(dev):
     assert plain['config']['launch'] == 'hip-graph replay of the whole step' and plain['config']['gradient_exchange'] is None
     a, b = plain['final_loss'], ddp['final_loss']
     assert np.isfinite(a) and abs(a - b) <= 1e-6 * abs(a), (a, b)
+
+
+@pytest.mark.parametrize('batch', [2, 64])
+@pytest.mark.parametrize('fuse', [False, True])
+def test_eval_head_with_grouped_launches_is_bit_identical(dev, batch, fuse):
+    """eval mode: every stage of the head's three levels as ONE grouped launch of the fused conv -> BatchNorm (running statistics) -> SiLU
+    kernel (eas_conv_bn_act_eval_group) and the nine prediction convolutions as one launch, against the per-level forward
+    (yolo_head.py:149-200 of the reference; after fuse_model: model_utils.py:35-80): same arithmetic per problem, bit-identical detections"""
+    from eas_snn_amd import ops
+    from eas_snn_amd import ops_group as G
+    from yolox.models.yolo_head import YOLOXHead
+    from yolox.utils import fuse_model
+    torch.manual_seed(9)
+    hd = YOLOXHead(2, width=0.5).to(dev)
+    hd.initialize_biases(1e-2)
+    with torch.no_grad():
+        for m in hd.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    hd.eval()
+    if fuse:
+        hd = fuse_model(hd)
+    xs = [torch.randn(batch, c, h, w, device=dev) for c, (h, w) in zip((128, 256, 512), ((32, 40), (16, 20), (8, 10)))]
+    res = {}
+    prev = G.ENABLED
+    try:
+        for flag in (False, True):
+            G.ENABLED = flag
+            with torch.no_grad(), ops.packed_weights(hd), ops.kernel_trace() as tr:
+                res[flag] = hd(xs).clone()
+            assert any('group_kernel' in k for k in tr.kernels) == flag, tr.kernels
+    finally:
+        G.ENABLED = prev
+    assert torch.isfinite(res[True]).all() and torch.equal(res[True], res[False])
