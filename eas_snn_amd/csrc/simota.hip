@@ -48,6 +48,11 @@ __device__ __forceinline__ float bce01(float p, bool t) {
     return t ? -lp : -lq;
 }
 
+// BIG (A > 4096: the 640x640 canvas has 8400 anchors, 25 B of state each would not fit LDS): the three per-anchor floats that are only
+// touched in the per-gt fold (least cost so far, its IoU, the first match's IoU) live in the OUTPUT arrays until the last pass overwrites
+// them with the results -- (best_cost, iou_first) as the two halves of the anchor's int64 `matched` slot, iou_best in `matched_iou`.  A
+// thread always walks the same anchors (a = tid, tid + SB, ...), so it only ever reads back what it wrote itself.  LDS: 13 B per anchor.
+template <bool BIG>
 __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ grids, const float* __restrict__ strides,
                                                     const float* __restrict__ gt_boxes, const float* __restrict__ gt_cls,
                                                     const unsigned char* __restrict__ gt_valid, const float* __restrict__ bbox,
@@ -57,10 +62,14 @@ __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ gr
     extern __shared__ __align__(16) unsigned char smem[];
     float* iou = (float*)smem;                         // [A] of the current gt
     float* cost = iou + g.A;                           // [A]
-    float* best_cost = cost + g.A;                     // [A] least cost over the gts so far
-    float* iou_best = best_cost + g.A;                 // [A] iou of that gt
-    float* iou_first = iou_best + g.A;                 // [A] iou of the first matching gt
-    unsigned char* cand = (unsigned char*)(iou_first + g.A);   // [A]
+    const int b_ = blockIdx.x;
+    float* pair = reinterpret_cast<float*>(matched + (size_t)b_ * g.A);
+    // [A] least cost over the gts so far / iou of that gt / iou of the first matching gt: LDS, or (BIG) parked in the output arrays
+    float* best_cost = BIG ? pair : cost + g.A;
+    float* iou_best = BIG ? matched_iou + (size_t)b_ * g.A : best_cost + g.A;
+    float* iou_first = BIG ? pair + 1 : iou_best + g.A;
+    constexpr int PS = BIG ? 2 : 1;                    // element stride of best_cost / iou_first
+    unsigned char* cand = BIG ? (unsigned char*)(cost + g.A) : (unsigned char*)(iou_first + g.A);   // [A]
     unsigned char* cnt = cand + g.A;                   // [A] number of matching gts (saturating)
     unsigned char* first_g = cnt + g.A;                // [A]
     unsigned char* best_g = first_g + g.A;             // [A]
@@ -88,9 +97,9 @@ __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ gr
         cnt[a] = 0;
         first_g[a] = 0;
         best_g[a] = 0;
-        best_cost[a] = 1e12f;
+        best_cost[PS * a] = 1e12f;
         iou_best[a] = 0.0f;
-        iou_first[a] = 0.0f;
+        iou_first[PS * a] = 0.0f;
     }
     __syncthreads();
 
@@ -158,11 +167,11 @@ __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ gr
         // fold this gt into the per-anchor state
         for (int a = tid; a < g.A; a += SB) {
             if (removed[a] && cand[a]) {
-                if (cnt[a] == 0) { first_g[a] = (unsigned char)q; iou_first[a] = iou[a]; }
+                if (cnt[a] == 0) { first_g[a] = (unsigned char)q; iou_first[PS * a] = iou[a]; }
                 if (cnt[a] < 255) cnt[a] = cnt[a] + 1;
             }
             // argmin over ALL label rows: rows before the first valid one hold 1e12 and win ties by their lower index
-            if (cost[a] < best_cost[a] && !(cost[a] >= 1e12f)) { best_cost[a] = cost[a]; best_g[a] = (unsigned char)q; iou_best[a] = iou[a]; }
+            if (cost[a] < best_cost[PS * a] && !(cost[a] >= 1e12f)) { best_cost[PS * a] = cost[a]; best_g[a] = (unsigned char)q; iou_best[a] = iou[a]; }
         }
         __syncthreads();
     }
@@ -170,10 +179,15 @@ __global__ __launch_bounds__(SB) void simota_kernel(const float* __restrict__ gr
         const int c = cnt[a];
         int m = 0;
         float mi = 0.0f;
-        if (c == 1) { m = first_g[a]; mi = iou_first[a]; }
+        if (c == 1) { m = first_g[a]; mi = iou_first[PS * a]; }
         else if (c > 1) { m = best_g[a]; mi = iou_best[a]; }
         fg[(size_t)b * g.A + a] = c > 0;
-        matched[(size_t)b * g.A + a] = m;
+        if constexpr (BIG) {
+            const long long m64 = m;                   // the slot held (best_cost, iou_first) as floats until now: a byte copy, so that the
+            __builtin_memcpy(pair + 2 * a, &m64, 8);   // compiler orders it behind the float reads above whatever the types say
+        } else {
+            matched[(size_t)b * g.A + a] = m;
+        }
         matched_iou[(size_t)b * g.A + a] = mi;
     }
 }
@@ -184,23 +198,27 @@ extern "C" {
 
 // grids [A][2], strides [A], gt_boxes [B][G][4] (cx, cy, w, h), gt_cls [B][G] (float class ids), gt_valid [B][G] (0/1),
 // bbox [B][A][4] decoded (cx, cy, w, h), obj [B][A], cls [B][A][nc] raw logits.
-// Out: fg [B][A] (0/1), matched [B][A] int64 (gt row, 0 where none), matched_iou [B][A].  G <= 255, A <= 4096.
+// Out: fg [B][A] (0/1), matched [B][A] int64 (gt row, 0 where none), matched_iou [B][A].  G <= 255, A <= 12288 (above 4096 anchors part of the per-anchor state is parked in the output arrays).
 static int simota_launch(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls, const unsigned char* gt_valid,
                          const float* bbox, const float* obj, const float* cls, int sb, int so, int sc, int B, int G, int A, int nc,
                          unsigned char* fg, long long* matched, float* matched_iou, eas_stream_t stream) {
     if (!grids || !strides || !gt_boxes || !gt_cls || !gt_valid || !bbox || !obj || !cls || !fg || !matched || !matched_iou) return EAS_ERR_INVALID_ARG;
     if (B < 1 || G < 1 || A < 1 || nc < 1) return EAS_ERR_INVALID_ARG;
-    if (G > 255 || A > 4096) return EAS_ERR_UNSUPPORTED;
+    if (G > 255 || A > 12288) return EAS_ERR_UNSUPPORTED;
     EAS_CLEAR_ERR();
     SimGeom g{B, G, A, nc, A < 10 ? A : 10, sb, so, sc};
-    const size_t lds = (size_t)A * (5 * 4 + 5);
+    const bool big = A > 4096;                          // (the 640x640 canvas: 8400 anchors)
+    const size_t lds = (size_t)A * (big ? 2 * 4 + 5 : 5 * 4 + 5);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)simota_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 25) != hipSuccess) return EAS_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)simota_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 25) != hipSuccess) return EAS_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)simota_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 13) != hipSuccess) return EAS_ERR_LAUNCH;
         attr_set = true;
     }
-    EAS_LAUNCH(simota_kernel, dim3(B), dim3(SB), lds, eas_s(stream), grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls, fg,
-                       matched, matched_iou, g);
+    if (big) EAS_LAUNCH(simota_kernel<true>, dim3(B), dim3(SB), lds, eas_s(stream), grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls, fg,
+                        matched, matched_iou, g);
+    else EAS_LAUNCH(simota_kernel<false>, dim3(B), dim3(SB), lds, eas_s(stream), grids, strides, gt_boxes, gt_cls, gt_valid, bbox, obj, cls, fg,
+                    matched, matched_iou, g);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

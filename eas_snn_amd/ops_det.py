@@ -37,7 +37,7 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
 
 
 def simota_supported(gt_valid, bbox_preds):
-    return bbox_preds.is_cuda and bbox_preds.dtype == torch.float32 and gt_valid.shape[1] <= 255 and bbox_preds.shape[1] <= 4096
+    return bbox_preds.is_cuda and bbox_preds.dtype == torch.float32 and gt_valid.shape[1] <= 255 and bbox_preds.shape[1] <= 12288
 
 
 @torch.no_grad()
@@ -136,7 +136,7 @@ class _DetLossFn(torch.autograd.Function):
 
 def det_loss_supported(raw_regs, labels, loss_type):
     A = sum(r.shape[-1] * r.shape[-2] for r in raw_regs)
-    return (raw_regs[0].is_cuda and raw_regs[0].dtype == torch.float32 and len(raw_regs) <= 4 and A <= 4096 and labels.shape[1] <= 255
+    return (raw_regs[0].is_cuda and raw_regs[0].dtype == torch.float32 and len(raw_regs) <= 4 and A <= 12288 and labels.shape[1] <= 255
             and loss_type == 'iou' and all(r.dim() == 4 for r in raw_regs))
 
 

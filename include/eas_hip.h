@@ -571,7 +571,7 @@ int eas_postprocess(const float* pred, int B, int A, int ncls, float conf_thre, 
  * get_assignments + dynamic_k_matching, yolox/models/spiking_yolo_head.py:401-560 (inherited YOLOXHead logic), looping over
  * each image's VALID ground-truth rows only.  grids [A][2], strides [A]; gt_boxes [B][G][4] (cx, cy, w, h), gt_cls [B][G]
  * (class ids as floats), gt_valid [B][G] (0/1 bytes); bbox [B][A][4] decoded boxes, obj [B][A] and cls [B][A][nc] raw logits.
- * Out: fg [B][A] (0/1), matched [B][A] (int64 ground-truth row, 0 where none), matched_iou [B][A].  G <= 255, A <= 4096. */
+ * Out: fg [B][A] (0/1), matched [B][A] (int64 ground-truth row, 0 where none), matched_iou [B][A].  G <= 255, A <= 12288 (above 4096 anchors -- the 640x640 canvas has 8400 -- part of the per-anchor state is parked in the output arrays). */
 int eas_simota_assign(const float* grids, const float* strides, const float* gt_boxes, const float* gt_cls,
                       const unsigned char* gt_valid, const float* bbox, const float* obj, const float* cls, int B, int G, int A,
                       int nc, unsigned char* fg, long long* matched, float* matched_iou, eas_stream_t stream);

@@ -16,7 +16,7 @@ python3 $ROOT/scripts/pmc_summary.py --calibrate $OUT/calib $OUT/fetch_calibrati
 cat $OUT/fetch_calibration.txt
 bash $ROOT/scripts/gpu_profile.sh $TAG/config2 $OUT/fetch_calibration.json 2
 bash $ROOT/scripts/gpu_profile.sh $TAG/config3 $OUT/fetch_calibration.json 3
-export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_EVAL=1
+export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_EVAL=1 EAS_BENCH_NO_640=1
 for c in 4 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c$c -- python3 $ROOT/bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_c$c.log 2>&1
   find $OUT/stats_c$c -name '*kernel_stats.csv' -exec cp {} $OUT/config${c}_kernel_stats.csv \;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): pmc_conv_step.sh <tag> [bench args] -- SQ counters of every dense-convolution kernel of ONE eager bench.py step
 # (two passes of 8 SQ counters + GRBM_GUI_ACTIVE, kernel-trace only), summarised per kernel symbol by scripts/pmc_conv_summary.py
-export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_EVAL=1
+export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_EVAL=1 EAS_BENCH_NO_640=1
 TAG=${1:-pmc_conv}; shift
 ARGS=${*:---steps 1 --warmup 1 --no-cpu-baseline}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1026,7 +1026,7 @@ def test_energy_estimation_matches_the_reference_function(dev):
         stats.energy_estimation(hip, [batches[0][:2].to(dev)], T=3)
 
 
-@pytest.mark.parametrize('B,G,nc,hw,seed', [(4, 50, 2, (64, 96), 1), (3, 12, 100, (64, 64), 2), (2, 50, 3, (256, 320), 3)])
+@pytest.mark.parametrize('B,G,nc,hw,seed', [(4, 50, 2, (64, 96), 1), (3, 12, 100, (64, 64), 2), (2, 50, 3, (256, 320), 3), (3, 50, 2, (640, 640), 5)])
 def test_fused_simota_assignment_equals_tensor_form(dev, B, G, nc, hw, seed):
     """eas_simota_assign (one launch over the valid label rows) against YOLOXHead._assign (the batch-wide tensor formulation
     that the golden train-loss fixtures pin): foreground mask, matched rows and matched IoUs.  Inputs: random decoded
@@ -1069,7 +1069,7 @@ def test_fused_simota_assignment_equals_tensor_form(dev, B, G, nc, hw, seed):
     assert multi > 0
 
 
-@pytest.mark.parametrize('nc,use_l1,hw,seed', [(2, True, (64, 96), 1), (2, False, (64, 96), 2), (100, True, (64, 64), 3), (3, True, (256, 320), 4)])
+@pytest.mark.parametrize('nc,use_l1,hw,seed', [(2, True, (64, 96), 1), (2, False, (64, 96), 2), (100, True, (64, 64), 3), (3, True, (256, 320), 4), (2, True, (640, 640), 6)])
 def test_fused_detection_loss_equals_tensor_form(dev, nc, use_l1, hw, seed):
     """ops.det_loss (eas_det_decode + eas_simota_assign_rows + eas_det_loss: decode, assignment, loss terms and their
     gradient in five launches) against the tensor-op get_losses of the same head on the same features and labels: the six
