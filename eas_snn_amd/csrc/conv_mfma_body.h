@@ -132,7 +132,13 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     constexpr int NSTEPS = (CCH / 16) * TAPS;
     constexpr int NT = 64 * WVM * WVN;   // threads; NIT = staging items per thread per chunk (upper bound, surplus skipped block-uniformly)
     constexpr bool SPREAD = NSTEPS >= 2 * NIT;   // commit item i after step NSTEPS-NIT+i, else after the last step
-    constexpr bool BPF = XT == 1 && NSTEPS > 1;   // B-fragment prefetch one step ahead
+    // B-fragment prefetch one step ahead: spike inputs (one term: WN fragments), and -- EAS_CONV_BPF3, round 5 -- real-valued inputs on the
+    // 96-pixel wave tiles (3 x 3 fragments, 36 registers per set): those are the tiles of the small maps, where a SIMD holds one or two waves and
+    // the LDS round trip of a step's nine ds_read_b128 sat exposed in front of its 18 MFMAs
+#ifndef EAS_CONV_BPF3
+#define EAS_CONV_BPF3 1
+#endif
+    constexpr bool BPF = NSTEPS > 1 && (XT == 1 || (EAS_CONV_BPF3 && XT == 3 && WN <= 3 && WM == 1));
     static_assert(WVM * WVN == 4 || WVM * WVN == 8, "4 or 8 waves per block");
     static_assert(CCH % 16 == 0, "ci chunk is a multiple of the MFMA k");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -303,7 +309,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 
     const int nchunks = (g.KSTEPS * 16 + CCH - 1) / CCH;
     int st = 0;
-    bf16x8 bq[NSETS][WN];
+    bf16x8 bq[NSETS][WN][BPF ? XT : 1];
     for (int c = 0; c < nchunks; ++c) {
         const bool single = g.single != 0;
         const unsigned char* cur = smem + (single ? 0 : (c & 1)) * buf_bytes;
@@ -332,16 +338,22 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
                 if (s == 0) {
                     const int toff0 = g.tap_off[0] * 16;
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) bq[0][j] = *(const bf16x8*)(cur + qoff[j] + toff0);
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int t = 0; t < XT; ++t) bq[0][j][t] = *(const bf16x8*)(cur + t * term_stride + qoff[j] + toff0);
                 }
                 if (s + 1 < NSTEPS) {
                     const int kk1 = (s + 1) / TAPS, tap1 = (s + 1) - kk1 * TAPS;
                     const int toff1 = g.tap_off[tap1] * 16 + kk1 * 2 * grp;
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) bq[(s + 1) % NSETS][j] = *(const bf16x8*)(cur + qoff[j] + toff1);
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int t = 0; t < XT; ++t) bq[(s + 1) % NSETS][j][t] = *(const bf16x8*)(cur + t * term_stride + qoff[j] + toff1);
                 }
 #pragma unroll
-                for (int j = 0; j < WN; ++j) b[j][0] = bq[s % NSETS][j];
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int t = 0; t < XT; ++t) b[j][t] = bq[s % NSETS][j][t];
             } else {
                 const int toff = g.tap_off[tap] * 16 + kk * 2 * grp;
 #pragma unroll
