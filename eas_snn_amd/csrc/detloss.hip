@@ -174,6 +174,39 @@ __global__ __launch_bounds__(EAS_BLOCK) void det_loss_finalize(const double* __r
     }
 }
 
+// labels [B][G][5] (class, cx, cy, w, h; zero rows = padding) -> what the assignment and the loss read: gt_valid [B][G] (row g < number of
+// rows whose five values sum to > 0, the reference's `nlabel = (labels.sum(dim=2) > 0).sum(dim=1)`, yolo_head.py:277-278), gt_cls [B][G],
+// gt_boxes [B][G][4], num_gts = sum of nlabel.  One block: ten tiny tensor operators of the step's dependency chain as one launch.
+__global__ __launch_bounds__(EAS_BLOCK) void det_labels_kernel(const float* __restrict__ labels, int B, int G, unsigned char* __restrict__ gt_valid,
+                                                               float* __restrict__ gt_cls, float* __restrict__ gt_boxes, float* __restrict__ num_gts) {
+    __shared__ int nl[1024];
+    __shared__ int total;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        int n = 0;
+        for (int q = 0; q < G; ++q) {
+            const float* r = labels + ((size_t)b * G + q) * 5;
+            n += ((((r[0] + r[1]) + r[2]) + r[3]) + r[4]) > 0.0f ? 1 : 0;       // (label values are non-negative: the sign test does not depend on the summation order)
+        }
+        nl[b] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int b = 0; b < B; ++b) t += nl[b];
+        total = t;
+    }
+    for (int i = threadIdx.x; i < B * G; i += blockDim.x) {
+        const int b = i / G, q = i - b * G;
+        const float* r = labels + (size_t)i * 5;
+        gt_valid[i] = q < nl[b];
+        gt_cls[i] = r[0];
+        gt_boxes[(size_t)i * 4 + 0] = r[1]; gt_boxes[(size_t)i * 4 + 1] = r[2];
+        gt_boxes[(size_t)i * 4 + 2] = r[3]; gt_boxes[(size_t)i * 4 + 3] = r[4];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *num_gts = (float)total;
+}
+
 int fill_levels(DetLevels& d, int L, const float* const* reg, const float* const* obj, const float* const* cls, float* const* g_reg,
                 float* const* g_obj, float* const* g_cls, const int* hw, const float* strides, int B, int nc) {
     if (L < 1 || L > kMaxLevels || B < 1 || nc < 1 || !reg || !obj || !cls || !hw || !strides) return EAS_ERR_INVALID_ARG;
@@ -231,6 +264,17 @@ int eas_det_loss(int L, const float* const* reg, const float* const* obj, const 
                        use_l1, workspace);
     EAS_CHECK_LAUNCH();
     EAS_LAUNCH(det_loss_finalize, dim3(1), dim3(EAS_BLOCK), 0, eas_s(stream), workspace, blocks, num_gts, use_l1, out);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// labels [B][G][5] fp32 -> gt_valid [B][G] u8, gt_cls [B][G], gt_boxes [B][G][4], num_gts (device float): the label preparation of
+// YOLOXHead.get_losses (yolo_head.py:272-277 of the mirror; reference yolo_head.py:277-300) as one launch.  B <= 1024.
+int eas_det_labels(const float* labels, int B, int G, unsigned char* gt_valid, float* gt_cls, float* gt_boxes, float* num_gts, eas_stream_t stream) {
+    if (!labels || !gt_valid || !gt_cls || !gt_boxes || !num_gts || B < 1 || G < 1) return EAS_ERR_INVALID_ARG;
+    if (B > 1024) return EAS_ERR_UNSUPPORTED;
+    EAS_CLEAR_ERR();
+    EAS_LAUNCH(det_labels_kernel, dim3(1), dim3(EAS_BLOCK), 0, eas_s(stream), labels, B, G, gt_valid, gt_cls, gt_boxes, num_gts);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -101,12 +101,20 @@ class _DetLossFn(torch.autograd.Function):
         dec = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=dev)
         check(lib.eas_det_decode(L, _ptr_array(regs), _ptr_array(objs), _ptr_array(clss), hw_arr, st_arr, B, nc, ptr(dec), stream()),
               'eas_det_decode')
-        labels = labels.float()
+        labels = _f32c(labels.float())
         G = labels.shape[1]
-        nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
-        gt_valid = (torch.arange(G, device=dev)[None] < nlabel[:, None]).to(torch.uint8)
-        gt_cls, gt_boxes = labels[:, :, 0].contiguous(), labels[:, :, 1:5].contiguous()
-        num_gts = nlabel.sum().float()
+        if B <= 1024 and labels.shape[2] == 5:
+            # nlabel, the valid-row mask, class / box columns and the label count as ONE launch instead of ten tiny tensor operators
+            gt_valid = torch.empty((B, G), dtype=torch.uint8, device=dev)
+            gt_cls = torch.empty((B, G), dtype=torch.float32, device=dev)
+            gt_boxes = torch.empty((B, G, 4), dtype=torch.float32, device=dev)
+            num_gts = torch.empty((), dtype=torch.float32, device=dev)
+            check(lib.eas_det_labels(ptr(labels), B, G, ptr(gt_valid), ptr(gt_cls), ptr(gt_boxes), ptr(num_gts), stream()), 'eas_det_labels')
+        else:
+            nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
+            gt_valid = (torch.arange(G, device=dev)[None] < nlabel[:, None]).to(torch.uint8)
+            gt_cls, gt_boxes = labels[:, :, 0].contiguous(), labels[:, :, 1:5].contiguous()
+            num_gts = nlabel.sum().float()
         grids, svec = _anchor_tables(hws, strides, dev)
         fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
         matched = torch.empty((B, A), dtype=torch.int64, device=dev)

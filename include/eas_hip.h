@@ -590,6 +590,9 @@ int eas_simota_assign_rows(const float* grids, const float* strides, const float
  * eas_det_loss: out[0..5] = total, 5*iou, obj, cls, l1, num_fg/num_gts and out[6] = 1/num_fg; g_reg / g_obj / g_cls (host
  *   arrays of device pointers, shapes of the raw maps, every element written) receive d(total * num_fg)/d(raw map): the caller
  *   multiplies them by grad_total * out[6].  num_gts: device float scalar.  workspace: eas_det_loss_workspace_doubles(). */
+/* label preparation of the loss as one launch: labels [B][G][5] (class, cx, cy, w, h; all-zero rows = padding) -> gt_valid [B][G] (row index <
+ * number of rows whose values sum to > 0), gt_cls [B][G], gt_boxes [B][G][4], num_gts (device float).  B <= 1024. */
+int eas_det_labels(const float* labels, int B, int G, uint8_t* gt_valid, float* gt_cls, float* gt_boxes, float* num_gts, eas_stream_t stream);
 int eas_det_decode(int L, const float* const* reg, const float* const* obj, const float* const* cls, const int* hw,
                    const float* strides, int B, int nc, float* dec, eas_stream_t stream);
 int64_t eas_det_loss_workspace_doubles(void);
