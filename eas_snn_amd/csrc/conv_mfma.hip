@@ -233,6 +233,8 @@ int launch_s2(const float* gy, float* gx, S2Geoms sg, hipStream_t st) {
 
 int eas_conv1x1_dispatch(const float* x, const void* packed_w, const float* bias, float* y, int NI, int Cin, int Cout, int HW, int x_terms,
                          hipStream_t st, double* stats, int stats_nb, int* nb_out, int planes, int* inexact, int act, const void* bna);
+// conv_s2d.hip: the stride-2 input gradient with the four parity classes in one tile
+int eas_conv_dgrad_s2c_dispatch(const float* gy, const void* packed_w, float* gx, int NI, int Cin, int Cout, int Hi, int Wi, hipStream_t st, bool query);
 // conv_lif_mfma.hip: the 3x3 tiles with the BatchNorm + activation epilogue (kernel template LM = 3), fp32 three-term input
 int eas_conv3x3_bna_dispatch(int stride, int v4, const float* x, const void* wp, float* y, const void* geom, hipStream_t st);
 
@@ -463,7 +465,17 @@ int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, 
         g.dbg = dbg;
         sg.wp[cls] = (const bf16x8*)packed_w + (size_t)3 * MT * KSTEPS * 64 * cum[cls];
     }
-    static const int one_launch = eas_dev_env("EAS_S2_FORM") ? (eas_dev_env("EAS_S2_FORM")[0] == '1') : 1;   // development: 0 = four launches
+    // development: EAS_S2_FORM=1 the class kernels in one launch (round 4), 0 = in four launches; default: the four classes in one tile
+    static const char form = eas_dev_env("EAS_S2_FORM") ? eas_dev_env("EAS_S2_FORM")[0] : 'c';
+    if (form == 'c') {
+        const int rc = eas_conv_dgrad_s2c_dispatch(grad_y, packed_w, grad_x, NI, Cin, Cout, Hi, Wi, st, false);
+        if (rc == EAS_OK) {
+            EAS_CHECK_LAUNCH();
+            return EAS_OK;
+        }
+        if (rc != EAS_ERR_UNSUPPORTED) return rc;
+    }
+    const int one_launch = form != '0';
     if (one_launch) {
         // one block shape for the four classes, a tile geometry per class (their staged patches differ: taps, channel chunk)
         typedef int (*s2_fn)(const float*, float*, S2Geoms, hipStream_t);

@@ -120,12 +120,19 @@ __device__ __forceinline__ void stage_store(unsigned char* dst, int term_stride,
 // in HBM and in LDS -- a staging item is VEC 16-byte loads and VEC 16-byte LDS stores, no conversion, half the bytes of fp32.
 // bx / by / gx: the block's pixel-tile index, channel-group index and the number of pixel tiles of its problem -- blockIdx.x, blockIdx.y,
 // gridDim.x for a launch of one problem; a grouped launch (conv_group.hip) maps its flat grid onto (problem, tile) first.
-template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0, typename G = ConvGeom>
+// NC = 4: the input gradient of a stride-2 3x3 convolution with the four parity classes of the gx pixel in ONE tile (conv_s2d.hip): x is
+// grad_y, the nine taps come in class-major order (class 2 * ph + pw has (ph + 1) * (pw + 1) taps, weights packed with mode 2), tap t
+// accumulates into the accumulators of its class -- acc[.][class * WN + j] -- and the epilogue writes gx[2a + ph][2b + pw] of the lane's
+// grad_y position (a, b): both column parities of a row in one 8-byte store, i.e. whole lines from one block.
+constexpr int kS2Cls[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3}, kS2Lt[9] = {0, 0, 1, 0, 1, 0, 1, 2, 3}, kS2Ntap[4] = {1, 2, 2, 4}, kS2Cum[4] = {0, 1, 3, 5};
+
+template <int TAPS, int S, int XT, int WM, int WN, int WVM, int WVN, int CCH, int VEC, int NIT, bool PL = false, int LM = 0, typename G = ConvGeom, int NC = 1>
 __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, const bf16x8* __restrict__ wp, const float* __restrict__ bias,
                                                float* __restrict__ y, int* __restrict__ inexact, const G& g, const int part,
                                                unsigned char* smem, const int bx, const int by, const int gx) {
     static_assert(!PL || XT == 1, "spike planes are one exact bf16 term");
     static_assert(LM == 0 || WM == 1, "the fused neuron epilogue walks one M-tile per wave");
+    static_assert(NC == 1 || (NC == 4 && TAPS == 9 && S == 1 && LM == 0 && CCH == 16 && !PL), "NC = 4: the stride-2 input gradient");
     constexpr bool TM = LM == 1;   // time-major pixel tiles (conv_lif_epi.h)
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     constexpr int PIXB = CCH * 2;  // bytes per staged pixel and term
@@ -138,7 +145,10 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 #ifndef EAS_CONV_BPF3
 #define EAS_CONV_BPF3 1
 #endif
-    constexpr bool BPF = NSTEPS > 1 && (XT == 1 || (EAS_CONV_BPF3 && XT == 3 && WN <= 3 && WM == 1));
+#ifndef EAS_S2C_BPF
+#define EAS_S2C_BPF 0
+#endif
+    constexpr bool BPF = NSTEPS > 1 && (XT == 1 || (EAS_CONV_BPF3 && XT == 3 && WN <= 3 && WM == 1 && (NC == 1 || EAS_S2C_BPF)));
     static_assert(WVM * WVN == 4 || WVM * WVN == 8, "4 or 8 waves per block");
     static_assert(CCH % 16 == 0, "ci chunk is a multiple of the MFMA k");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,6 +184,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     constexpr bool NEURON = LM == 1 || LM == 2;      // fused neuron epilogue (LM = 3: BatchNorm + activation on the plain tiles)
     int l_img[NEURON ? WN : 1], l_pix[NEURON ? WN : 1];     // fused neuron epilogue: sample and pixel (inside its image) of the lane's column of tile j
     bool l_ok[NEURON ? WN : 1];
+    bool ok_r1[NC == 4 ? WN : 1], ok_c1[NC == 4 ? WN : 1];      // NC = 4: row 2a + 1 / column 2b + 1 of the lane's position exist in gx
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         // time-major: tile j = time step j / M2 of the wave's spatial tile j % M2 (M2 = WN / T spatial tiles per wave)
@@ -192,6 +203,10 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
             l_img[j] = img;
             l_pix[j] = yr * g.oW + yc;
             l_ok[j] = ybase[j] >= 0;
+        }
+        if constexpr (NC == 4) {
+            ok_r1[j] = yr + 1 < g.oH;
+            ok_c1[j] = yc + 1 < g.oW;
         }
     }
 
@@ -220,11 +235,11 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
         gch[it] = gi * 8;
     }
 
-    f32x16 acc[WM][WN];
+    f32x16 acc[WM][WN * NC];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN * NC; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -241,9 +256,13 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int mt = (mt0 + i) < g.MT ? (mt0 + i) : (g.MT - 1);
-        a_soff[i] = __builtin_amdgcn_readfirstlane((unsigned)mt * steps_total * 1024u);
+        a_soff[i] = __builtin_amdgcn_readfirstlane(NC == 4 ? (unsigned)mt * g.KSTEPS : (unsigned)mt * steps_total * 1024u);
     }
     bf16x8 a[NSETS][WM][3];
+    // NC = 4: the mode-2 pack keeps every class by itself -- [class][term][M-tile][k-step][tap of the class][lane]; a_soff = M-tile * KSTEPS
+    // there, and a step's fragment sits at 3 * mk * cum(class) + term * mk * ntap(class) + ((M-tile * KSTEPS + k-step) * ntap + tap) KB with
+    // mk = MT * KSTEPS KB (all of it scalar arithmetic on compile-time class constants)
+    const unsigned a_mk = (unsigned)g.MT * g.KSTEPS * 1024u;
     auto load_a = [&](int set, int step) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -251,6 +270,16 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
             for (int t = 0; t < 3; ++t)
                 a[set][i][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                                               a_rsrc, a_voff, a_soff[i] + t * a_term_bytes + (unsigned)step * 1024u, 0));
+    };
+    auto load_a4 = [&](int set, int ks, int tap) {      // tap: a constant once the step loop is unrolled
+        const int cls = kS2Cls[tap], nt = kS2Ntap[cls];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                a[set][i][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              a_rsrc, a_voff, a_mk * (unsigned)(3 * kS2Cum[cls] + t * nt) +
+                                                                                  ((a_soff[i] + (unsigned)ks) * nt + kS2Lt[tap]) * 1024u, 0));
     };
     // weight fragments in flight ahead of the MFMAs: two steps for spike inputs (a step of a one-term layer is 288-480 MFMA cycles per wave,
     // less than the ~450-cycle latency of the fragment loads it has to cover; the third register set of the 9-step rotation holds them),
@@ -260,7 +289,8 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 #define EAS_CONV_APF 2
 #endif
     constexpr int APF = (EAS_CONV_APF == 2 && XT == 1 && NSETS == 3) ? 2 : 1;
-    load_a(0, 0);
+    if constexpr (NC == 4) load_a4(0, 0, 0);
+    else load_a(0, 0);
     if constexpr (APF == 2) load_a(1, steps_total > 1 ? 1 : 0);
 
     // loads are unconditional: a row outside the image or a channel group past Cin (Cin % 8 == 0: a group is valid or not as
@@ -322,7 +352,12 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
             ++st;
             const int sta = st + APF - 1;
             const int stn = (g.dbg & 4) ? 0 : (sta < steps_total ? sta : steps_total - 1);   // prefetch the weights APF steps ahead (clamped at the end)
-            load_a((s + APF) % NSETS, stn);
+            if constexpr (NC == 4) {
+                const int ksn = c * (CCH / 16) + (s + APF) / TAPS;
+                load_a4((s + APF) % NSETS, ksn < g.KSTEPS ? ksn : g.KSTEPS - 1, (s + APF) % TAPS);
+            } else {
+                load_a((s + APF) % NSETS, stn);
+            }
             if (more) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
@@ -374,13 +409,14 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
                         for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][ta], b[j][0], acc[i][j], 0, 0, 0);
             } else {
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                const int cj = NC == 4 ? kS2Cls[tap] * WN : 0;      // the accumulators of the tap's parity class
 #pragma unroll
                 for (int q = 0; q < 6; ++q)
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+                            acc[i][cj + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[i][PA[q]], b[j][PB[q]], acc[i][cj + j], 0, 0, 0);
             }
             if (SPREAD && more && !single) {
 #pragma unroll
@@ -403,7 +439,7 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
 
     // ---- BatchNorm statistics of the tile (block-uniform branch): per-wave sums over its valid pixels by DPP, the WVN waves that share
     // the channels added in wave order, one float2 per channel and block.  The staging buffers are free after the last barrier.
-    if (g.stats) {
+    if constexpr (NC == 1) if (g.stats) {
         double* red = reinterpret_cast<double*>(smem + (size_t)WVM * WVN * EAS_STATS_SCRATCH * sizeof(float));
         bool valid[WN];
 #pragma unroll
@@ -432,6 +468,49 @@ __device__ __forceinline__ void conv_tile_body(const float* __restrict__ x, cons
     // (M-tile, pixel tile), rows reached by adding multiples of the channel stride; bias values loaded once per M-tile;
     // the per-element channel bound check only for a ragged last M-tile (the epilogue used to be as long as the main loop).
     const long cstride = (long)g.oH * g.oW;
+    if constexpr (NC == 4) {
+        // gx[2a + ph][2b + pw] of the lane's grad_y position: ybase is the (ph, pw) = (0, 0) pixel; even row width and an 8-byte aligned tensor
+        // (block-uniform) -> the two column parities leave as one 8-byte store, 32 lanes = 256 contiguous bytes
+        const bool pair = (g.oW & 1) == 0 && ((uintptr_t)y & 7) == 0;
+        if (g.dbg & 64) {        // development ablation: the main loop alone (one store keeps the accumulators alive)
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < WN * NC; ++j) sum += acc[0][j][3];
+            if (sum == 12345.678f) y[0] = sum;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            if (mt0 + i >= g.MT) continue;
+            const int co0 = (mt0 + i) * 32 + 4 * h;
+            const bool full = (mt0 + i) * 32 + 32 <= g.Cout;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (ybase[j] < 0) continue;
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    if (ph && !ok_r1[j]) continue;
+                    float* yp = y + ybase[j] + (long)co0 * cstride + ph * g.oW;
+                    const f32x16& v0 = acc[i][(2 * ph) * WN + j];
+                    const f32x16& v1 = acc[i][(2 * ph + 1) * WN + j];
+                    if (pair) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (full || co0 + (e & 3) + 8 * (e >> 2) < g.Cout)
+                                *reinterpret_cast<float2*>(yp + ((e & 3) + 8 * (e >> 2)) * cstride) = make_float2(v0[e], v1[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (full || co0 + (e & 3) + 8 * (e >> 2) < g.Cout) {
+                                yp[((e & 3) + 8 * (e >> 2)) * cstride] = v0[e];
+                                if (ok_c1[j]) yp[((e & 3) + 8 * (e >> 2)) * cstride + 1] = v1[e];
+                            }
+                    }
+                }
+            }
+        }
+        return;
+    }
     if constexpr (LM == 3) {      // BatchNorm (running statistics) + activation on the accumulators (eas_conv_bn_act_eval)
 #pragma unroll
         for (int i = 0; i < WM; ++i)

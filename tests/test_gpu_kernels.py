@@ -1249,6 +1249,38 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         assert err < 1e-5, f'{name}: {err:.2e}'
 
 
+S2_DGRAD_CASES = [  # NI, Cin, Cout, Hi, Wi
+    (3, 32, 64, 12, 20), (2, 40, 24, 9, 12), (5, 72, 48, 7, 8), (2, 16, 16, 64, 96), (4, 96, 200, 10, 36), (1, 8, 8, 2, 4), (7, 64, 64, 16, 20),
+    (2, 32, 16, 11, 19), (3, 64, 32, 5, 39), (2, 8, 32, 128, 160), (6, 128, 64, 32, 40), (2, 256, 40, 16, 20), (9, 48, 8, 8, 12)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('NI,Cin,Cout,H,W', S2_DGRAD_CASES)
+def test_stride2_input_gradient_all_parity_classes_in_one_tile(dev, NI, Cin, Cout, H, W):
+    """eas_conv_dgrad_s2 (conv_s2d.hip: the four parity classes of the gx pixel in one tile, 8-byte interleaved stores) against an fp64
+    input gradient: odd heights and widths (the last row / column has no odd neighbour; odd widths take the 4-byte stores), channel counts that
+    are no multiple of the 32-channel tile or the 16-channel chunk, whole images per tile and ragged row tiles, staging items of 1 / 2 / 4
+    positions.  grad_x starts as NaN: every element must be written."""
+    from eas_snn_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(NI * 100 + Cin + H)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(NI, Cout, Ho, Wo, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(dev)
+    gx = torch.full((NI, Cin, H, W), float('nan'), device=dev)
+    pk = ops.conv_pack_weights(w, 2)
+    ops.check(L.eas_conv_dgrad_s2(ops.ptr(gy), ops.ptr(pk), ops.ptr(gx), NI, Cin, Cout, H, W, ops.stream()), 'eas_conv_dgrad_s2')
+    ref = torch.nn.grad.conv2d_input((NI, Cin, H, W), w.double(), gy.double(), stride=2, padding=1)
+    assert not torch.isnan(gx).any(), 'grad_x has unwritten elements'
+    err = float((gx.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, f'{err:.2e}'
+    # a view that is only 4-byte aligned: the epilogue falls back to 4-byte stores
+    buf = torch.full((gx.numel() + 1,), float('nan'), device=dev)
+    gx2 = buf[1:].view_as(gx)
+    ops.check(L.eas_conv_dgrad_s2(ops.ptr(gy), ops.ptr(pk), ops.ptr(gx2), NI, Cin, Cout, H, W, ops.stream()), 'eas_conv_dgrad_s2')
+    assert torch.equal(gx2, gx), 'the 4-byte store path differs'
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('NI,Cin,Ca,Cb,H,W,k,s,spikes', [(3, 64, 32, 0, 8, 10, 1, 1, False), (2, 128, 64, 64, 16, 20, 1, 1, False), (2, 32, 40, 0, 16, 20, 3, 1, False),
                                                        (2, 64, 64, 0, 32, 40, 3, 2, False), (64, 256, 128, 128, 8, 10, 3, 1, False), (4, 512, 256, 0, 8, 10, 1, 1, True),
