@@ -94,7 +94,7 @@ class EasChannelSumProblem(C.Structure):
 
 
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
@@ -183,6 +183,8 @@ PROTOTYPES = {
     'eas_conv_fwd_stats': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P, _P, C.c_int, _P]),
     'eas_conv_fwd_stats_blocks': (C.c_int, [C.c_int] * 8),
     'eas_conv_dgrad_s2': (C.c_int, [_P] * 3 + [C.c_int] * 5 + [_P]),
+    'eas_conv_dgrad_small_supported': (C.c_int, [C.c_int] * 5),
+    'eas_conv_dgrad_small': (C.c_int, [_P] * 3 + [C.c_int] * 5 + [_P]),
     'eas_conv_wgrad_workspace_floats': (C.c_int64, [C.c_int] * 8),
     'eas_conv_wgrad': (C.c_int, [_P] * 4 + [C.c_int] * 8 + [_P]),
     'eas_conv_wgrad_partial': (C.c_int, [_P] * 3 + [C.c_int] * 8 + [_P]),

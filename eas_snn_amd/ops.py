@@ -1937,6 +1937,10 @@ def channel_sum(g):
     return out
 
 
+# EAS_SMALL_DGRAD=0: the stem's input gradient through eas_conv_fwd (8 of 32 tile rows), as before round 5
+SMALL_DGRAD = os.environ.get('EAS_SMALL_DGRAD', '1') != '0'
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, x_terms, packs, x_sp=None):
@@ -1978,7 +1982,18 @@ class _ConvFn(torch.autograd.Function):
                 k == 1 or (w.shape[0] % 8 == 0 and gy.shape[-1] % 2 == 0 and (gy.shape[-1] * gy.shape[-2]) % 4 == 0))
         own_d2 = (ctx.needs_input_grad[0] and stride == 2 and k == 3 and w.shape[0] % 8 == 0
                   and gy.shape[-1] % 2 == 0 and conv_fwd_supported(gy.shape[0], w.shape[0], Cin, gy.shape[2], gy.shape[3] + 2, k, 1, 3))
-        if own_d:
+        small_d = (SMALL_DGRAD and ctx.needs_input_grad[0] and stride == 1 and k == 3 and w.dtype == torch.float32
+                   and _lib.lib().eas_conv_dgrad_small_supported(gy.shape[0], Cin, w.shape[0], gy.shape[2], gy.shape[3]))
+        if small_d:
+            # at most 8 input channels (the stem): the taps stacked along M instead of 8 rows of a 32-row tile (conv_small_dgrad.hip)
+            gx = torch.empty((gy.shape[0], Cin, gy.shape[2], gy.shape[3]), dtype=torch.float32, device=gy.device)
+            fl = 2.0 * gy.numel() * Cin * 9
+            ksteps = (w.shape[0] + 15) // 16
+            _call('eas_conv_fwd', 4 * (gx.numel() + gy.numel()), _lib.lib().eas_conv_dgrad_small, ptr(gy), ptr(_f32c(w)), ptr(gx), gy.shape[0], Cin,
+                  w.shape[0], gy.shape[2], gy.shape[3], stream(), flops=fl,
+                  issue_flops=6 * 2.0 * gy.shape[0] * gy.shape[2] * gy.shape[3] * 96 * 16 * ksteps)
+            own_d = True
+        elif own_d:
             pk = packs[1] if packs and 1 in packs else conv_pack_weights(w, 1)
             gx = conv_fwd_packed(gy, pk, None, Cin, k, 1, 3)
         elif own_d2:

@@ -502,6 +502,15 @@ int eas_conv_bn_act_eval(const EasConvBnActEval* d, int* inexact_flag, eas_strea
 int eas_conv_dgrad_s2(const float* grad_y, const void* packed_w, float* grad_x, int NI, int Cin, int Cout, int Hi, int Wi,
                       eas_stream_t stream);
 
+/* ABI 8.  Input gradient of a 3x3 stride-1 convolution (padding 1) with at most 8 input channels -- the stem of CSPDarknet
+ * (yolox/models/darknet.py: BaseConv(in_channels = 8 sampler channels, 32) ahead of dark2), whose gradient flows on into the event sampler:
+ * grad_x[NI][Cin][H][W] from grad_y[NI][Cout][H][W] (Cout <= 64) and the fp32 weights [Cout][Cin][3][3] themselves (no packed form).
+ * Replaces eas_conv_fwd on grad_y with mode-1 weights there: the nine taps are stacked along the M dimension of the matrix-core tiles
+ * (72 of 96 rows used instead of 8 of 32) and shifted afterwards on the fp32 results (csrc/conv_small_dgrad.hip).  Same exact bf16-term
+ * products; fixed summation order.  eas_conv_dgrad_small_supported: 1 when the geometry is taken. */
+int eas_conv_dgrad_small_supported(int NI, int Cin, int Cout, int H, int W);
+int eas_conv_dgrad_small(const float* grad_y, const float* w, float* grad_x, int NI, int Cin, int Cout, int H, int W, eas_stream_t stream);
+
 /* grad_w[Cout][Cin][3][3] of a 3x3 convolution (padding 1, stride 1 or 2) from x[NI][Cin][Hi][Wi] and
  * grad_y[NI][Cout][Ho][Wo] (ATen convolution_backward, weight part).  Reduction over output pixels on the matrix
  * cores (csrc/conv_wgrad_mfma.hip): grad_y as three exact bf16 terms, x as one (x_terms = 1, spikes / small integers)

@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(handle, n), f'{n} declared in include/eas_hip.h but not exported'
     assert sorted(eas_snn_amd._lib.PROTOTYPES) == names           # ctypes table covers exactly the header
     lib = eas_snn_amd.hip_library()
-    assert lib.eas_abi_version() == eas_snn_amd._lib.ABI_VERSION == 7
+    assert lib.eas_abi_version() == eas_snn_amd._lib.ABI_VERSION == 8
     assert lib.eas_status_string(-1).decode().startswith('invalid argument')
     assert lib.eas_bn_workspace_doubles(32) > 0 and lib.eas_reduce_workspace_floats(1 << 20) > 0
 

@@ -29,7 +29,7 @@ import test_gpu_model as M
 pytestmark = pytest.mark.gpu
 
 # kernel families whose every bench instance must have been launched by an oracle-compared run
-FAMILIES = ('conv_fwd_mfma', 'conv1x1_mfma', 'conv_dgrad_s2', 'conv_wgrad_mfma', 'conv1x1_wgrad', 'bn_lif', 'bn_silu', 'bn_stats', 'bn_finalize',
+FAMILIES = ('conv_fwd_mfma', 'conv1x1_mfma', 'conv_dgrad_s2', 'conv_dgrad_small', 'conv_wgrad_mfma', 'conv1x1_wgrad', 'bn_lif', 'bn_silu', 'bn_stats', 'bn_finalize',
             'arsnn_', 'smallconv', 'lif_', 'spp_pool', 'planes_', 'upcat', 'focus', 'time_mean', 'conv3x3_group', 'conv1x1_group',
             'conv_wgrad_group', 'channel_sum')
 
@@ -100,6 +100,8 @@ def _replay_conv_calls(dev, calls):
             key = ('fwd',) + tuple(a[4:11]) + (2, a[2] is not None, a[11] is not None)
         elif name == 'eas_conv_dgrad_s2':
             key = ('dgrad_s2',) + tuple(a[3:8])
+        elif name == 'eas_conv_dgrad_small':
+            key = ('dgrad_small',) + tuple(a[3:8])
         elif name == 'eas_conv_wgrad_partial':
             key = ('wgrad',) + tuple(a[3:11])
         elif name == 'eas_conv_wgrad_planes_partial':
@@ -132,6 +134,15 @@ def _replay_conv_calls(dev, calls):
                 ssum, ssq = y64.sum((0, 2, 3)), (y64 * y64).sum((0, 2, 3))
                 assert float(((st[:, 0] - ssum).abs() / (y64.abs().sum((0, 2, 3)) + 1e-30)).max()) < 3e-7, f'{key}: tile sums'
                 assert float(((st[:, 1] - ssq).abs() / (ssq + 1e-30)).max()) < 3e-7, f'{key}: tile sums of squares'
+        elif key[0] == 'dgrad_small':
+            NI, Cin, Cout, H, W = key[1:]
+            gy = torch.randn(NI, Cout, H, W, generator=gw).to(dev)
+            w = (torch.randn(Cout, Cin, 3, 3, generator=gw) / (Cin * 9) ** 0.5).to(dev)
+            gx = torch.full((NI, Cin, H, W), float('nan'), device=dev)
+            ops.check(L.eas_conv_dgrad_small(ops.ptr(gy), ops.ptr(w), ops.ptr(gx), NI, Cin, Cout, H, W, ops.stream()), 'eas_conv_dgrad_small')
+            ref = torch.nn.grad.conv2d_input((NI, Cin, H, W), w.double(), gy.double(), stride=1, padding=1)
+            err = _rel(gx, ref)
+            assert err < 1e-5, f'{key}: small-channel input gradient {err:.2e}'
         elif key[0] == 'dgrad_s2':
             NI, Cin, Cout, H, W = key[1:]
             gy = torch.randn(NI, Cout, H // 2, W // 2, generator=gw).to(dev)

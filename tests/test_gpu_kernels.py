@@ -1249,6 +1249,49 @@ def test_conv_mfma_forward_dgrad_wgrad_vs_fp64(dev, NI, Cin, Cout, H, W, k, s, s
         assert err < 1e-5, f'{name}: {err:.2e}'
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('NI,Cin,Cout,H,W', [(2, 8, 32, 16, 20), (3, 8, 32, 37, 61), (1, 2, 16, 5, 7), (2, 5, 24, 9, 30), (4, 8, 64, 12, 31), (2, 3, 40, 1, 64),
+                                               (1, 8, 48, 70, 3), (64, 8, 32, 128, 160), (2, 1, 8, 33, 95)])
+def test_small_channel_input_gradient_taps_stacked_along_m(dev, NI, Cin, Cout, H, W):
+    """eas_conv_dgrad_small (the stem's input gradient: nine taps stacked along the M dimension, column shifts as lane shifts, row shifts as
+    running sums) against an fp64 input gradient: widths that are no multiple of the 30-column slice, fewer than 8 input channels, output
+    channel counts that are no multiple of the 16-channel k-step, strips with a short last strip, one-row and three-column images; the
+    config-2 geometry itself.  grad_x starts as NaN: every element must be written.  Two calls agree bit for bit."""
+    from eas_snn_amd import _lib, ops
+    L = _lib.lib()
+    assert L.eas_conv_dgrad_small_supported(NI, Cin, Cout, H, W) == 1
+    g = torch.Generator().manual_seed(NI * 100 + Cin + H)
+    gy = torch.randn(NI, Cout, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(dev)
+    gx = torch.full((NI, Cin, H, W), float('nan'), device=dev)
+    ops.check(L.eas_conv_dgrad_small(ops.ptr(gy), ops.ptr(w), ops.ptr(gx), NI, Cin, Cout, H, W, ops.stream()), 'eas_conv_dgrad_small')
+    assert not torch.isnan(gx).any(), 'grad_x has unwritten elements'
+    ref = torch.nn.grad.conv2d_input((NI, Cin, H, W), w.double(), gy.double(), stride=1, padding=1)
+    err = float((gx.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, f'{err:.2e}'
+    gx2 = torch.empty_like(gx)
+    ops.check(L.eas_conv_dgrad_small(ops.ptr(gy), ops.ptr(w), ops.ptr(gx2), NI, Cin, Cout, H, W, ops.stream()), 'eas_conv_dgrad_small')
+    assert torch.equal(gx, gx2)
+    assert L.eas_conv_dgrad_small_supported(NI, 9, Cout, H, W) == 0 and L.eas_conv_dgrad_small_supported(NI, Cin, 65, H, W) == 0
+
+
+@pytest.mark.gpu
+def test_stem_convolution_backward_takes_the_small_channel_kernel(dev):
+    """ops.conv2d on an 8-channel input: its input gradient comes from eas_conv_dgrad_small (kernel trace) and matches fp64"""
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    conv = nn.Conv2d(8, 32, 3, 1, 1, bias=False).to(dev)
+    x = torch.randn(2, 8, 32, 40, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(2, 32, 32, 40, generator=g).to(dev)
+    with ops.kernel_trace() as tr:
+        y = ops.conv2d(x, conv)
+        y.backward(gy)
+    assert any('conv_dgrad_small' in k for k in tr.kernels), tr.kernels
+    ref = torch.nn.grad.conv2d_input(x.shape, conv.weight.detach().double(), gy.double(), stride=1, padding=1)
+    assert float((x.grad.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
 S2_DGRAD_CASES = [  # NI, Cin, Cout, Hi, Wi
     (3, 32, 64, 12, 20), (2, 40, 24, 9, 12), (5, 72, 48, 7, 8), (2, 16, 16, 64, 96), (4, 96, 200, 10, 36), (1, 8, 8, 2, 4), (7, 64, 64, 16, 20),
     (2, 32, 16, 11, 19), (3, 64, 32, 5, 39), (2, 8, 32, 128, 160), (6, 128, 64, 32, 40), (2, 256, 40, 16, 20), (9, 48, 8, 8, 12)]
