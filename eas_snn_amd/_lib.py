@@ -93,6 +93,12 @@ class EasChannelSumProblem(C.Structure):
     _fields_ = [('g', C.c_void_p), ('out', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('HW', C.c_int)]
 
 
+class EasPredDgradProblem(C.Structure):
+    """include/eas_hip.h EasPredDgradProblem"""
+    _fields_ = [('gy_a', C.c_void_p), ('w_a', C.c_void_p), ('Ka', C.c_int), ('gy_b', C.c_void_p), ('w_b', C.c_void_p), ('Kb', C.c_int),
+                ('gx', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('HW', C.c_int)]
+
+
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
 ABI_VERSION = 8
 
@@ -201,6 +207,7 @@ PROTOTYPES = {
     'eas_conv_wgrad_group_plan': (C.c_int, [C.POINTER(EasWgradProblem), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'eas_conv_wgrad_group_partial': (C.c_int, [C.POINTER(EasWgradProblem), C.c_int, C.c_int, C.c_int, _P]),
     'eas_channel_sum_group': (C.c_int, [C.POINTER(EasChannelSumProblem), C.c_int, _P]),
+    'eas_pred_dgrad_group': (C.c_int, [C.POINTER(EasPredDgradProblem), C.c_int, _P]),
 }
 
 

@@ -22,6 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kSdCols = 30;      // useful columns of a 32-lane slice
 
+__device__ __attribute__((aligned(16))) float eas_sd_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ void sd_split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
     hi = (__bf16)v;
     const float r1 = v - (float)hi;
@@ -37,15 +39,8 @@ struct SdGeom {
     int nwaves;
 };
 
-#ifndef EAS_SD_OCC
-#define EAS_SD_OCC 1
-#endif
-#ifndef EAS_SD_PF
-#define EAS_SD_PF 1
-#endif
-
 template <int KS>      // k-steps of 16 grad_y channels: Cout <= 16 * KS
-__global__ __launch_bounds__(256, EAS_SD_OCC) void conv_dgrad_small_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+__global__ __launch_bounds__(256) void conv_dgrad_small_kernel(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
                                                                 const SdGeom g) {
     __shared__ bf16x8 wa[3][KS][3][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,30 +74,31 @@ __global__ __launch_bounds__(256, EAS_SD_OCC) void conv_dgrad_small_kernel(const
     const int nb_up = ((lane + 1) & 63) * 4, nb_dn = ((lane + 63) & 63) * 4;      // ds_bpermute addresses of the lanes x + 1 / x - 1
 
     float cur[KS * 8], nxt[KS * 8];
-#if EAS_SD_PF == 2
-    float nx2[KS * 8];
-#endif
+    // the loads are unconditional: a column outside the image or a channel past Cout reads the zero page (channel stride 0), so the 8 * KS
+    // loads of a row are in flight together (as conditional loads every one of them was a branch of its own)
+    // (element offsets of the lane's channels inside its image, computed once: NI * Cout * H * W < 2^31; -1 = the zero page)
+    int choff[KS * 8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) choff[s * 8 + j] = (colok && 16 * s + 8 * hh + j < g.Cout) ? (16 * s + j) * (int)plane : -1;
     auto load_row = [&](int q, float (&v)[KS * 8]) {
-        const bool rowok = q >= 0 && q < g.H;                  // wave-uniform
+        if (q >= 0 && q < g.H) {                               // wave-uniform
+            const float* row = src + (size_t)q * g.W;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool ok = rowok && colok && 16 * s + 8 * hh + j < g.Cout;
-                v[s * 8 + j] = ok ? src[(size_t)(16 * s + j) * plane + (size_t)q * g.W] : 0.0f;
+            for (int k = 0; k < KS * 8; ++k) {
+                const float* p = choff[k] >= 0 ? row + choff[k] : eas_sd_zero_page;
+                v[k] = *p;
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KS * 8; ++k) v[k] = 0.0f;
+        }
     };
     float sp[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};      // rows q - 1, q, q + 1 of grad_x
     load_row(y0 - 1, cur);
-#if EAS_SD_PF == 2
-    load_row(y0, nxt);
-#endif
     for (int q = y0 - 1; q <= y1; ++q) {
-#if EAS_SD_PF == 2
-        if (q + 1 < y1) load_row(q + 2, nx2);
-#else
         if (q < y1) load_row(q + 1, nxt);
-#endif
         if (q >= 0 && q < g.H) {
             bf16x8 b[KS][3];
 #pragma unroll
@@ -114,11 +110,9 @@ __global__ __launch_bounds__(256, EAS_SD_OCC) void conv_dgrad_small_kernel(const
                     b[s][0][j] = a0; b[s][1][j] = a1; b[s][2][j] = a2;
                 }
             f32x16 acc[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
-            // smallest term products first; consecutive MFMAs go to different accumulators
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // smallest term products first; consecutive MFMAs go to different accumulators; the first product of a tile starts from the
+            // constant zero operand (no 48 register writes per row)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int s = 0; s < KS; ++s)
@@ -126,7 +120,7 @@ __global__ __launch_bounds__(256, EAS_SD_OCC) void conv_dgrad_small_kernel(const
                 for (int p = 0; p < 6; ++p)
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][s][PA[p]][lane], b[s][PB[p]], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][s][PA[p]][lane], b[s][PB[p]], (s == 0 && p == 0) ? zero : acc[i], 0, 0, 0);
             // accumulator element e of tile i: tap 4 * i + (e >> 2), channel 4 * hh + (e & 3) of the lane's pixel
 #pragma unroll
             for (int kh = 2; kh >= 0; --kh)
@@ -157,12 +151,7 @@ __global__ __launch_bounds__(256, EAS_SD_OCC) void conv_dgrad_small_kernel(const
             sn[cc] = 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < KS * 8; ++k) {
-            cur[k] = nxt[k];
-#if EAS_SD_PF == 2
-            nxt[k] = nx2[k];
-#endif
-        }
+        for (int k = 0; k < KS * 8; ++k) cur[k] = nxt[k];
     }
 }
 

@@ -157,6 +157,61 @@ __global__ __launch_bounds__(256) void channel_sum_group_kernel(const ChannelSum
     channel_sum_body(a.g[p], a.out[p], a.N[p], a.C[p], a.HW[p], (int)blockIdx.x - a.first[p]);
 }
 
+// Input gradient of the head's 1x1 prediction convolutions (eas_pred_dgrad_group): gx[n][c][p] = sum_k wa[k][c] * ga[n][k][p] (+ the same for a
+// second reader of the input: obj_preds next to reg_preds, yolo_head.py:161-163 of the reference) with 1 / 4 / num_classes reduction channels.
+// As matrix-core "convolutions" with K padded to 16 these took two launches and 100 us per step for 110 MB of stores; here every thread
+// holds the (<= 8) grad_y values of four pixels and writes 32 channels of them: plain fp32 FMAs in the fixed order k = 0 .. K-1 (first reader,
+// then second), store-bound.
+constexpr int kMaxPredGroup = 8, kPredK = 8, kPredCg = 32;
+struct PredDgradGroup {
+    const float* ga[kMaxPredGroup];
+    const float* gb[kMaxPredGroup];
+    const float* wa[kMaxPredGroup];
+    const float* wb[kMaxPredGroup];
+    float* gx[kMaxPredGroup];
+    int Ka[kMaxPredGroup], Kb[kMaxPredGroup], N[kMaxPredGroup], C[kMaxPredGroup], HW[kMaxPredGroup], qblocks[kMaxPredGroup], first[kMaxPredGroup + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void pred_dgrad_group_kernel(const PredDgradGroup a) {
+    __shared__ float ws[kPredK][kPredCg];
+    int p = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) p = i;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int b = (int)blockIdx.x - a.first[p];
+    const int cg = b / a.qblocks[p], qb = b - cg * a.qblocks[p];
+    const int Ka = a.Ka[p], Kb = a.Kb[p], C = a.C[p], HW = a.HW[p], K = Ka + Kb;
+    const int c0 = cg * kPredCg;
+    for (int i = threadIdx.x; i < K * kPredCg; i += blockDim.x) {
+        const int k = i / kPredCg, c = c0 + i % kPredCg;
+        ws[k][i % kPredCg] = c < C ? (k < Ka ? a.wa[p][(size_t)k * C + c] : a.wb[p][(size_t)(k - Ka) * C + c]) : 0.0f;
+    }
+    __syncthreads();
+    const int hw4 = HW / 4;
+    const long long i = (long long)qb * 256 + threadIdx.x;
+    if (i >= (long long)a.N[p] * hw4) return;
+    const int n = (int)(i / hw4), q = (int)(i - (long long)n * hw4);
+    float4 g[kPredK];
+#pragma unroll
+    for (int k = 0; k < kPredK; ++k) {
+        if (k < Ka) g[k] = *reinterpret_cast<const float4*>(a.ga[p] + ((size_t)n * Ka + k) * HW + 4 * q);
+        else if (k < K) g[k] = *reinterpret_cast<const float4*>(a.gb[p] + ((size_t)n * Kb + (k - Ka)) * HW + 4 * q);
+        else g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* out = a.gx[p] + ((size_t)n * C + c0) * HW + 4 * q;
+    const int nc = C - c0 < kPredCg ? C - c0 : kPredCg;
+    for (int c = 0; c < nc; ++c) {
+        float4 v = make_float4(ws[0][c] * g[0].x, ws[0][c] * g[0].y, ws[0][c] * g[0].z, ws[0][c] * g[0].w);
+#pragma unroll
+        for (int k = 1; k < kPredK; ++k)
+            if (k < K) {
+                const float wk = ws[k][c];
+                v.x = fmaf(wk, g[k].x, v.x); v.y = fmaf(wk, g[k].y, v.y); v.z = fmaf(wk, g[k].z, v.z); v.w = fmaf(wk, g[k].w, v.w);
+            }
+        *reinterpret_cast<float4*>(out + (size_t)c * HW) = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -223,6 +278,32 @@ int eas_channel_sum_group(const EasChannelSumProblem* pr, int n, eas_stream_t st
     a.n = n;
     EAS_CLEAR_ERR();
     EAS_LAUNCH(channel_sum_group_kernel, dim3(blocks), dim3(256), 0, eas_s(stream), a);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+int eas_pred_dgrad_group(const EasPredDgradProblem* pr, int n, eas_stream_t stream) {
+    if (!pr || n < 1) return EAS_ERR_INVALID_ARG;
+    if (n > kMaxPredGroup) return EAS_ERR_UNSUPPORTED;
+    PredDgradGroup a{};
+    long long blocks = 0;
+    for (int p = 0; p < n; ++p) {
+        const EasPredDgradProblem& q = pr[p];
+        if (!q.gy_a || !q.w_a || !q.gx || q.Ka < 1 || q.Kb < 0 || (q.Kb > 0 && (!q.gy_b || !q.w_b)) || q.N < 1 || q.C < 1 || q.HW < 1) return EAS_ERR_INVALID_ARG;
+        if (q.Ka + q.Kb > kPredK || (q.HW & 3) != 0) return EAS_ERR_UNSUPPORTED;
+        if (((uintptr_t)q.gy_a | (uintptr_t)q.gy_b | (uintptr_t)q.gx) & 15) return EAS_ERR_INVALID_ARG;
+        const long long quads = (long long)q.N * (q.HW / 4);
+        a.ga[p] = q.gy_a; a.gb[p] = q.Kb ? q.gy_b : q.gy_a; a.wa[p] = q.w_a; a.wb[p] = q.Kb ? q.w_b : q.w_a; a.gx[p] = q.gx;
+        a.Ka[p] = q.Ka; a.Kb[p] = q.Kb; a.N[p] = q.N; a.C[p] = q.C; a.HW[p] = q.HW;
+        a.qblocks[p] = (int)((quads + 255) / 256);
+        a.first[p] = (int)blocks;
+        blocks += (long long)a.qblocks[p] * ((q.C + kPredCg - 1) / kPredCg);
+        if (blocks >= (1LL << 31)) return EAS_ERR_UNSUPPORTED;
+    }
+    a.first[n] = (int)blocks;
+    a.n = n;
+    EAS_CLEAR_ERR();
+    EAS_LAUNCH(pred_dgrad_group_kernel, dim3((unsigned)blocks), dim3(256), 0, eas_s(stream), a);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

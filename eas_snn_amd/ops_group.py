@@ -357,6 +357,10 @@ def bn_silu_group(ys, stats, layers):
     return list(_BNSiLUGroupFn.apply(cfg, *tensors))
 
 
+# EAS_PRED_DGRAD=0: the prediction convolutions' input gradients as two grouped matrix-core launches (before eas_pred_dgrad_group)
+PRED_DGRAD_FMA = os.environ.get('EAS_PRED_DGRAD', '1') != '0'
+
+
 class _PredGroupFn(torch.autograd.Function):
     """The 1x1 prediction convolutions of all levels (cls_preds[k](cls_feat_k), reg_preds[k](reg_feat_k), obj_preds[k](reg_feat_k);
     yolo_head.py:161-163 of the reference) as ONE forward launch.  Backward: the input gradients as two launches -- (cls, reg) of all
@@ -389,11 +393,26 @@ class _PredGroupFn(torch.autograd.Function):
         packs = cfg['packs']
         gys = [ops._f32c(g) if g is not None else torch.zeros((x.shape[0], w.shape[0]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
                for g, x, w in zip(grads, xs, ws)]
-        pk1 = [packs[i][1] if packs[i] is not None and 1 in packs[i] else ops.conv_pack_weights(ws[i], 1) for i in range(3 * n)]
         gcf = [torch.empty_like(t) for t in cf]
         grf = [torch.empty_like(t) for t in rf]
-        _launch_conv_group(gys[:2 * n], pk1[:2 * n], None, gcf + grf, None, 1)
-        _launch_conv_group(gys[2 * n:], pk1[2 * n:], None, grf, None, 1, accumulate=True)
+        if PRED_DGRAD_FMA and 2 * n <= 8 and all(w.dtype == torch.float32 and w.is_contiguous() for w in ws) and all(
+                (t.shape[2] * t.shape[3]) % 4 == 0 for t in xs) and all(ws[n + i].shape[0] + ws[2 * n + i].shape[0] <= 8 and ws[i].shape[0] <= 8
+                                                                         for i in range(n)):
+            # 1 / 4 / num_classes reduction channels: store-bound fp32 FMAs instead of matrix-core tiles with K padded to 16; obj joins reg
+            arr = (_lib.EasPredDgradProblem * (2 * n))()
+            nbytes = 0
+            for i in range(n):
+                for q, gy_a, w_a, gy_b, w_b, gx in ((arr[i], gys[i], ws[i], None, None, gcf[i]),
+                                                    (arr[n + i], gys[n + i], ws[n + i], gys[2 * n + i], ws[2 * n + i], grf[i])):
+                    q.gy_a, q.w_a, q.Ka = ptr(gy_a), ptr(w_a), w_a.shape[0]
+                    q.gy_b, q.w_b, q.Kb = (ptr(gy_b), ptr(w_b), w_b.shape[0]) if gy_b is not None else (None, None, 0)
+                    q.gx, q.N, q.C, q.HW = ptr(gx), gx.shape[0], gx.shape[1], gx.shape[2] * gx.shape[3]
+                    nbytes += 4 * (gx.numel() + gy_a.numel() + (gy_b.numel() if gy_b is not None else 0))
+            ops._call('eas_conv_fwd', nbytes, _lib.lib().eas_pred_dgrad_group, arr, 2 * n, stream())
+        else:
+            pk1 = [packs[i][1] if packs[i] is not None and 1 in packs[i] else ops.conv_pack_weights(ws[i], 1) for i in range(3 * n)]
+            _launch_conv_group(gys[:2 * n], pk1[:2 * n], None, gcf + grf, None, 1)
+            _launch_conv_group(gys[2 * n:], pk1[2 * n:], None, grf, None, 1, accumulate=True)
         geoms = tuple((x.shape[0], x.shape[1], g.shape[1], x.shape[2], x.shape[3]) for x, g in zip(xs, gys))
         ns = _wgrad_plan(geoms, 1)
         gws = []

@@ -704,6 +704,23 @@ typedef struct {
 } EasChannelSumProblem;
 int eas_channel_sum_group(const EasChannelSumProblem* problems, int n, eas_stream_t stream);
 
+/* ABI 8.  Input gradients of 1x1 convolutions with very few OUTPUT channels -- the head's prediction convolutions (yolo_head.py:161-163 of
+ * the reference: cls_preds / reg_preds / obj_preds, num_classes / 4 / 1 channels) -- for several inputs in one launch (n <= 8):
+ *   gx[n][c][p] = sum_k w_a[k][c] * gy_a[n][k][p]  (+ sum_k w_b[k][c] * gy_b[n][k][p] for a second convolution reading the same input:
+ *   obj_preds next to reg_preds; Kb = 0: none),  Ka + Kb <= 8, HW % 4 == 0, tensors 16-byte aligned.
+ * w_a / w_b are the fp32 weights of the convolutions ([K][C][1][1]).  Plain fp32 FMAs in the fixed order k = 0 .. (first reader, then second). */
+typedef struct {
+    const float* gy_a;
+    const float* w_a;
+    int Ka;
+    const float* gy_b;
+    const float* w_b;
+    int Kb;
+    float* gx;
+    int N, C, HW;
+} EasPredDgradProblem;
+int eas_pred_dgrad_group(const EasPredDgradProblem* problems, int n, eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1276,6 +1276,44 @@ def test_small_channel_input_gradient_taps_stacked_along_m(dev, NI, Cin, Cout, H
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,C,nc', [(2, 128, 2), (64, 128, 2), (3, 72, 3)])
+def test_prediction_convolution_input_gradients_as_fp32_fma(dev, N, C, nc):
+    """eas_pred_dgrad_group (cls / reg+obj input gradients of all levels in one launch) against fp64, ragged channel groups included;
+    two calls agree bit for bit; too many reduction channels / ragged pixel counts are refused."""
+    from eas_snn_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + C)
+    hws = [(32, 40), (16, 20), (8, 10)]
+    arr = (_lib.EasPredDgradProblem * 6)()
+    keep, refs, outs = [], [], []
+    for i, (h, w_) in enumerate(hws):
+        gc, gr, go = (torch.randn(N, k, h, w_, generator=g).to(dev) for k in (nc, 4, 1))
+        wc, wr, wo = (torch.randn(k, C, 1, 1, generator=g).to(dev) for k in (nc, 4, 1))
+        xc = torch.full((N, C, h, w_), float('nan'), device=dev)
+        xr = torch.full((N, C, h, w_), float('nan'), device=dev)
+        keep += [gc, gr, go, wc, wr, wo]
+        outs += [xc, xr]
+        refs += [torch.einsum('nkhw,kc->nchw', gc.double(), wc.double()[:, :, 0, 0]),
+                 torch.einsum('nkhw,kc->nchw', gr.double(), wr.double()[:, :, 0, 0]) + torch.einsum('nkhw,kc->nchw', go.double(), wo.double()[:, :, 0, 0])]
+        for q, ga, wa, gb, wb, gx in ((arr[2 * i], gc, wc, None, None, xc), (arr[2 * i + 1], gr, wr, go, wo, xr)):
+            q.gy_a, q.w_a, q.Ka = ops.ptr(ga), ops.ptr(wa), wa.shape[0]
+            q.gy_b, q.w_b, q.Kb = (ops.ptr(gb), ops.ptr(wb), wb.shape[0]) if gb is not None else (None, None, 0)
+            q.gx, q.N, q.C, q.HW = ops.ptr(gx), N, C, h * w_
+    ops.check(L.eas_pred_dgrad_group(arr, 6, ops.stream()), 'eas_pred_dgrad_group')
+    first = [o.clone() for o in outs]
+    for o, r in zip(outs, refs):
+        assert not torch.isnan(o).any()
+        assert float((o.double() - r).abs().max() / r.abs().max()) < 1e-6
+    ops.check(L.eas_pred_dgrad_group(arr, 6, ops.stream()), 'eas_pred_dgrad_group')
+    assert all(torch.equal(a, b) for a, b in zip(first, outs))
+    arr[1].Kb = 5
+    assert L.eas_pred_dgrad_group(arr, 6, ops.stream()) == -2
+    arr[1].Kb = 1
+    arr[0].HW = 1278
+    assert L.eas_pred_dgrad_group(arr, 6, ops.stream()) == -2
+
+
+@pytest.mark.gpu
 def test_stem_convolution_backward_takes_the_small_channel_kernel(dev):
     """ops.conv2d on an 8-channel input: its input gradient comes from eas_conv_dgrad_small (kernel trace) and matches fp64"""
     import torch.nn as nn
