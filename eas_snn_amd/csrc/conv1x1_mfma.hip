@@ -1115,7 +1115,8 @@ W1Plan w1_plan(W1Geom& g, int NI, int Cin, int Cout, int HW, int x_terms, bool p
         best = (force + yz - 1) / yz;
         if (best > total_chunks) best = total_chunks;
     } else {
-        const long slots = 256L * res;
+        static const int slot_pct = eas_dev_env("EAS_WG_SLOT_PCT") ? atoi(eas_dev_env("EAS_WG_SLOT_PCT")) : 100;      // development (conv_wgrad_mfma.hip wg_plan)
+        const long slots = 256L * res * slot_pct / 100;
         long best_cost = -1;
         for (int sl = 1; sl <= total_chunks && (long)sl * yz <= 2 * slots; ++sl) {
             const long rounds = ((long)sl * yz + slots - 1) / slots;
@@ -1214,7 +1215,8 @@ int eas_conv1x1_wgrad_group(const EasWgradProblem* pr, int n, int x_terms, hipSt
     int rc = cls0 == 2 ? launch_w1_group<4, 1, 4>(a, 0, st, &res) : (cls0 == 1 ? launch_w1_group<2, 2, 2>(a, 0, st, &res) : launch_w1_group<1, 4, 1>(a, 0, st, &res));
     if (rc != EAS_OK) return rc;
     // common chunks per block (the rule of group_tau, conv_wgrad_mfma.hip)
-    const long slots = 256L * res;
+    static const int slot_pct_g = eas_dev_env("EAS_WG_SLOT_PCT") ? atoi(eas_dev_env("EAS_WG_SLOT_PCT")) : 100;      // development
+    const long slots = 256L * res * slot_pct_g / 100;
     int max_nc = 0;
     for (int p = 0; p < n; ++p) max_nc = nc[p] > max_nc ? nc[p] : max_nc;
     int tau = max_nc;

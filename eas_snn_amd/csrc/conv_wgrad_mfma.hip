@@ -53,6 +53,7 @@ struct WgGeom {
     int parts, Wst, lpad, qshift, hv;
     int pn;                  // ci tiles per block chosen by wg_geom (1 or 2)
     int single;              // one LDS buffer (the next tile is written after a barrier): where that lets a CU hold two blocks instead of one
+    int nit;                 // staging items per thread the tile needs (wg_geom): 3 = the NITX = 3 instances (stride 2, spike inputs, 6-wave blocks)
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -97,13 +98,15 @@ __device__ __forceinline__ void stage_terms(unsigned char* dst, int term_stride,
 // the pixel-major LDS image (the 8 channels of a pixel are 16 contiguous bytes in both).
 // bx / by: the block's pixel slice (its first tile and its slab) and (co, ci) block index -- blockIdx.x / .y of a launch of one layer; a
 // grouped launch (conv_wgrad_group_kernel) maps its flat grid onto (layer, slice, channel block) first
-template <int S, int XT, int PM, int PN, int VEC, bool XPL>
+// NITX: staging items per thread, 0 = the rule below (1 for the 12-wave blocks, else 2); 3 = the stride-2 spike-input tiles whose x patch
+// (four input pixels per output pixel) does not fit two items per thread at 80 output pixels (wg_geom, WgGeom.nit)
+template <int S, int XT, int PM, int PN, int VEC, bool XPL, int NITX = 0>
 __device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ slabs,
                                                 const WgGeom& g, unsigned char* smem, const int bx, const int by) {
     static_assert(!XPL || XT == 1, "spike planes are one exact bf16 term");
     typedef float vecf __attribute__((ext_vector_type(VEC)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NW = 3 * PM * PN, NT = 64 * NW, NIT = PM * PN == 4 ? 1 : 2;   // staging items per thread (register budget of 12-wave blocks)
+    constexpr int NW = 3 * PM * PN, NT = 64 * NW, NIT = NITX ? NITX : (PM * PN == 4 ? 1 : 2);   // staging items per thread (register budget of 12-wave blocks)
     constexpr int A_TERM = PM * A_PLANE, A_BYTES = 3 * A_TERM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = wave % 3, pair = wave / 3, pm = pair / PN, pn = pair % PN;
@@ -423,11 +426,11 @@ __device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ x, con
     }
 }
 
-template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false, int NITX = 0>
 __global__ __launch_bounds__(192 * PM * PN) void conv_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                         float* __restrict__ slabs, WgGeom g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    conv_wgrad_body<S, XT, PM, PN, VEC, XPL>(x, gy, slabs, g, smem, (int)blockIdx.x, (int)blockIdx.y);
+    conv_wgrad_body<S, XT, PM, PN, VEC, XPL, NITX>(x, gy, slabs, g, smem, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Grouped launch (include/eas_hip.h eas_conv_wgrad_group_partial): layer p owns blocks [first[p], first[p + 1]) of the flat grid,
@@ -555,14 +558,14 @@ int pick_rows(int Ho, int Wo, int cap) {
     return best;
 }
 
-template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false, int NITX = 0>
 int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStream_t st) {
-    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL>;
+    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL, NITX>;
     constexpr int NT = 192 * PM * PN;
     const size_t lds = (size_t)(g.single ? 1 : 2) * (3 * PM * A_PLANE + (size_t)XT * PN * g.Q * ROWB);
     const int nbg = PN == 1 && g.Cin < 32 ? (g.Cin + 7) / 8 : 4 * PN;
     const int nitems = (TP / VEC) * 4 * PM + g.nseg * g.rows_in * (g.Wst / VEC) * nbg;
-    if (lds > 160 * 1024 || nitems > (PM * PN == 4 ? 1 : 2) * NT) {
+    if (lds > 160 * 1024 || nitems > (NITX ? NITX : (PM * PN == 4 ? 1 : 2)) * NT) {
         if (eas_dev_env("EAS_CONV_DBG")) fprintf(stderr, "wgrad launch: lds %zu nitems %d NT %d PM %d PN %d VEC %d RT %d Q %d\n", lds, nitems, NT, PM, PN, VEC, g.RT, g.Q);
         return EAS_ERR_UNSUPPORTED;
     }
@@ -587,13 +590,13 @@ int launch_wgrad(const float* x, const float* gy, float* slabs, WgGeom g, hipStr
 }
 
 // blocks of this kernel instance a CU holds at once with `lds` bytes of dynamic LDS (registers, waves and LDS all count), cached
-template <int S, int XT, int PM, int PN, int VEC, bool XPL = false>
+template <int S, int XT, int PM, int PN, int VEC, bool XPL = false, int NITX = 0>
 int resident_wgrad(size_t lds) {
     static size_t seen[16];
     static int val[16], n = 0;
     for (int i = 0; i < n; ++i)
         if (seen[i] == lds) return val[i];
-    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL>;
+    auto kern = conv_wgrad_mfma_kernel<S, XT, PM, PN, VEC, XPL, NITX>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 192 * PM * PN, lds) != hipSuccess || nb < 1) nb = 1;
@@ -616,7 +619,8 @@ WgPlan wg_plan(int Cin, int Cout, int stride, int x_terms, int ntiles, int parts
     // (slots = 256 CUs x the blocks of THIS kernel instance a CU really holds: registers, waves and LDS -- 108 KB of double-buffered LDS
     // leave one, where the old rule of thumb "4 / (pm pn)" assumed two and sized the grid for 512 slots: 2.25 rounds).  The slice count
     // with the fewest tile periods wins; ties go to fewer slabs.  resident = 0: geometry search only (pm / pn are all it reads).
-    const int slots = 256 * (resident > 0 ? resident : 1);
+    static const int slot_pct = eas_dev_env("EAS_WG_SLOT_PCT") ? atoi(eas_dev_env("EAS_WG_SLOT_PCT")) : 100;      // development: share of the chip a launch is sized for
+    const int slots = 256 * (resident > 0 ? resident : 1) * slot_pct / 100;
     const int step = parts > 1 ? parts : 1;
     int best = step;
     static const double pen = eas_dev_env("EAS_WG_SHARE_PEN") ? atof(eas_dev_env("EAS_WG_SHARE_PEN")) : 0.0;      // development
@@ -676,7 +680,15 @@ bool wg_geom(WgGeom& g, int NI, int Cin, int Cout, int Hi, int Wi, int stride, i
             const size_t lds = (size_t)2 * (3 * p.pm * A_PLANE + (size_t)x_terms * p.pn * g.Q * ROWB);
             const int nbg = p.pn == 1 && Cin < 32 ? (Cin + 7) / 8 : 4 * p.pn;
             const int nitems = (TP / vec) * 4 * p.pm + g.nseg * g.rows_in * (g.Wst / vec) * nbg;
-            if (lds <= 160 * 1024 && nitems <= (p.pm * p.pn == 4 ? 1 : 2) * 192 * p.pm * p.pn) return true;
+            const int nt = 192 * p.pm * p.pn;
+            g.nit = p.pm * p.pn == 4 ? 1 : 2;
+            if (lds <= 160 * 1024 && nitems <= g.nit * nt) return true;
+            // stride 2, spike inputs, 64-output-channel blocks: a third item per thread keeps the 80-pixel tile (dark5.0 at 16x20 -> 8x10: 1000
+            // items for 384 threads; with two the tile shrank to 40 pixels -- half of every MFMA step on zeros, twice the barriers: 296 -> 199 us)
+            if (stride == 2 && x_terms == 1 && p.pm == 2 && p.pn == 1 && cap == TP && lds <= 160 * 1024 && nitems <= 3 * nt) {
+                g.nit = 3;
+                return true;
+            }
         }
         if (force_parts > 0) break;
     }
@@ -689,6 +701,12 @@ WgPlan wg_plan_final(const WgGeom& g, int Cin, int Cout, int stride, int x_terms
     const size_t lds = (size_t)2 * (3 * p0.pm * A_PLANE + (size_t)x_terms * p0.pn * g.Q * ROWB);
     const bool v4 = g.parts > 1 || (g.Wi % 4 == 0 && g.Wo % 4 == 0);
     int res = 1;
+    if (g.nit == 3) {        // (wg_geom: stride 2, one term, pm 2, pn 1; never single-buffered)
+        res = planes ? (v4 ? resident_wgrad<2, 1, 2, 1, 4, true, 3>(lds) : resident_wgrad<2, 1, 2, 1, 2, true, 3>(lds))
+                     : (v4 ? resident_wgrad<2, 1, 2, 1, 4, false, 3>(lds) : resident_wgrad<2, 1, 2, 1, 2, false, 3>(lds));
+        single = 0;
+        return wg_plan(Cin, Cout, stride, x_terms, g.ntiles, g.parts, g.pn, res);
+    }
 #define EAS_RS(S_, XT_, PM_, PN_, PL_) (v4 ? resident_wgrad<S_, XT_, PM_, PN_, 4, PL_>(lds) : resident_wgrad<S_, XT_, PM_, PN_, 2, PL_>(lds))
 #define EAS_RS_SHAPE(S_, XT_, PL_)                                              \
     do {                                                                        \
@@ -797,7 +815,8 @@ int wgrad_group3(const EasWgradProblem* pr, int n, int x_terms, hipStream_t st, 
     }
     if (lds > 160 * 1024) return EAS_ERR_UNSUPPORTED;
     const int res = pm == 2 ? resident_wgrad_group<3, 2, 1>(lds) : resident_wgrad_group<3, 1, 1>(lds);
-    const int tau = group_tau(yz, nt, n, 256L * res);
+    static const int slot_pct_g = eas_dev_env("EAS_WG_SLOT_PCT") ? atoi(eas_dev_env("EAS_WG_SLOT_PCT")) : 100;      // development (wg_plan)
+    const int tau = group_tau(yz, nt, n, 256L * res * slot_pct_g / 100);
     int blocks = 0;
     for (int p = 0; p < n; ++p) {
         a.g[p].kslices = (nt[p] + tau - 1) / tau;
@@ -883,7 +902,10 @@ static int wgrad_partial(const float* x, const float* grad_y, float* workspace, 
         else if (p.pn == 2) rc = EAS_WG(S_, XT_, 1, 2, PL_);                   \
         else rc = EAS_WG(S_, XT_, 1, 1, PL_);                                  \
     } while (0)
-    if (planes && stride == 1) EAS_WG_SHAPE(1, 1, true);
+    if (g.nit == 3)
+        rc = planes ? (v4 ? launch_wgrad<2, 1, 2, 1, 4, true, 3>(x, grad_y, workspace, g, st) : launch_wgrad<2, 1, 2, 1, 2, true, 3>(x, grad_y, workspace, g, st))
+                    : (v4 ? launch_wgrad<2, 1, 2, 1, 4, false, 3>(x, grad_y, workspace, g, st) : launch_wgrad<2, 1, 2, 1, 2, false, 3>(x, grad_y, workspace, g, st));
+    else if (planes && stride == 1) EAS_WG_SHAPE(1, 1, true);
     else if (planes) EAS_WG_SHAPE(2, 1, true);
     else if (stride == 1 && x_terms == 1) EAS_WG_SHAPE(1, 1, false);
     else if (stride == 1) EAS_WG_SHAPE(1, 3, false);
