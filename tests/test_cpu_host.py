@@ -764,3 +764,18 @@ def test_workload_2b_is_config_2_at_the_readme_canvas():
     assert tuple(exp.input_size) == (640, 640) and tuple(exp.test_size) == (640, 640)
     with pytest.raises(KeyError):
         workloads.get(7)
+
+
+def test_graft_entry_build_runs_on_a_machine_without_a_gpu():
+    """__graft_entry__.build() -- what the driver calls on the CPU container each round: compiles (here: finds up to date) every HIP source for
+    gfx950, builds the oracle's C restatement, imports the package and the compat namespaces.  (It once pinned the ABI number of a past round.)"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module('__graft_entry__')
+    entry.build()
+    assert callable(entry.smoke)
+
