@@ -12,7 +12,8 @@ import torch
 import eas_snn_amd
 from eas_snn_amd import ops, workloads
 
-FWD = {'eas_conv_fwd': (4, 12, 11), 'eas_conv_fwd_stats': (3, 11, 10), 'eas_conv_fwd_planes': (4, 11, None), 'eas_conv_dgrad_s2': (3, 8, None)}
+FWD = {'eas_conv_fwd': (4, 12, 11), 'eas_conv_fwd_stats': (3, 11, 10), 'eas_conv_fwd_planes': (4, 11, None), 'eas_conv_dgrad_s2': (3, 8, None),
+       'eas_conv_dgrad_small': (3, 8, None)}
 WG = {'eas_conv_wgrad_partial': (3, 11), 'eas_conv_wgrad_planes_partial': (3, 10)}
 
 
@@ -46,7 +47,7 @@ def main():
             elif n in FWD:
                 lo, hi, _ = FWD[n]
                 g = a[lo:hi]
-                geo = (f'{g[0]}x{g[1]}->{g[2]}@{g[3]}x{g[4]}' + (f' k{g[5]} s{g[6]}' if len(g) > 6 else ' k3 s2 dgrad') + (f' xt{g[7]}' if len(g) > 7 else ''))
+                geo = (f'{g[0]}x{g[1]}->{g[2]}@{g[3]}x{g[4]}' + (f' k{g[5]} s{g[6]}' if len(g) > 6 else (' k3 s2 dgrad' if n == 'eas_conv_dgrad_s2' else ' k3 s1 dgrad (stacked taps)')) + (f' xt{g[7]}' if len(g) > 7 else ''))
             else:
                 lo, hi = WG[n]
                 g = a[lo:hi]
