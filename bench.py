@@ -575,7 +575,8 @@ def main():
             def fwd():
                 net(inputs_fn()[0])
                 functional.reset_net(net)
-            with torch.no_grad():
+            # (ops.frozen_weights: what EventEvaluator.evaluate opens around its loop -- weights packed once per evaluation, not per batch)
+            with torch.no_grad(), ops.frozen_weights(net):
                 for _ in range(2):
                     fwd()
                 torch.cuda.synchronize()

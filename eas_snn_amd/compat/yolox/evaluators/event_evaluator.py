@@ -111,12 +111,20 @@ class EventEvaluator:
         ds = getattr(self.dataloader, 'dataset', None)
         assert ds is None or (getattr(ds, 'map_val', True) and not getattr(ds, 'random_aug', False)), \
             'the dataset must be set as the mode of map val. and not random_aug'
+        dev = next(model.parameters()).device
+        graph_ok = self.use_graph and dev.type == 'cuda' and decoder is None
+        if dev.type == 'cuda':
+            # nobody writes weights or BatchNorm statistics between the first and the last batch: pack / derive them once (ops.frozen_weights)
+            from eas_snn_amd import ops
+            with ops.frozen_weights(model):
+                return self._evaluate_loop(model, distributed, decoder, return_outputs, dev, graph_ok)
+        return self._evaluate_loop(model, distributed, decoder, return_outputs, dev, graph_ok)
+
+    def _evaluate_loop(self, model, distributed, decoder, return_outputs, dev, graph_ok):
         data_list, output_data, gt_dict = [], {}, {}
         inference_time = nms_time = 0.0
         n_batches = len(self.dataloader)
         n_samples = max(n_batches - 1, 1)
-        dev = next(model.parameters()).device
-        graph_ok = self.use_graph and dev.type == 'cuda' and decoder is None
         for cur_iter, (imgs, labels, info_imgs, ids) in enumerate(self.dataloader):
             with torch.no_grad():                       # (the reference: inference_mode; graph replays write ordinary static buffers)
                 imgs = imgs.to(dev, torch.float32)

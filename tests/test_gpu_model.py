@@ -1410,6 +1410,62 @@ def test_head_with_grouped_launches_equals_the_per_level_head(dev, batch):
         torch.testing.assert_close(res[True][3][n].float(), res[False][3][n].float(), rtol=1e-5, atol=1e-7, msg=n)
 
 
+@pytest.mark.gpu
+def test_frozen_weights_scope_reuses_the_packs_and_never_serves_stale_ones(dev):
+    """ops.frozen_weights (the evaluator's loop): inside the block an eval forward launches no weight-packing kernel and gives the bits of an
+    ordinary forward; a HIP graph captured inside it follows weights AND BatchNorm statistics changed between two blocks (the next
+    evaluation after more training), because entering a block refreshes the same buffers; outside a block nothing is cached."""
+    from eas_snn_amd import ops
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(BASE_OPTS + ['use_spike', 'True'])          # the 256x320 canvas: every layer on the own kernels (bit-reproducible)
+    from oracle import fill
+    model = exp.get_model()
+    fill.procedural_fill_(model, 2.0, ann_regex=fill.ANN_KEYS['True'])       # weights that make every layer fire
+    model = model.to(dev).eval()
+    torch.manual_seed(11)
+    for m in model.modules():          # statistics that are not the initial (0, 1): the BatchNorm constants matter
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_var.uniform_(0.5, 2.0)
+            m.running_mean.normal_(0.0, 0.1)
+    x = torch.from_numpy(np.random.default_rng(3).poisson(0.5, (2, 1, 4, 2, 256, 320)).astype(np.float32)).to(dev)
+
+    def fwd():
+        out = model(x)
+        functional.reset_net(model)
+        return out
+    with torch.no_grad():
+        ref = fwd().clone()
+        assert torch.equal(fwd(), ref)                                   # the eval forward itself is reproducible
+        with ops.frozen_weights(model):
+            with ops.kernel_trace() as tr:
+                a = fwd().clone()
+            assert not any('pack_weights_flat' in k or 'pack_weights_many' in k for k in tr.kernels), tr.kernels      # (the model-wide packing launch)
+            assert torch.equal(a, ref)
+            fwd()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fwd()
+            g.replay()
+            assert torch.equal(out, ref)
+        with ops.kernel_trace() as tr:
+            fwd()
+        assert any('pack_weights_flat' in k or 'pack_weights_many' in k for k in tr.kernels)              # outside the block: packed per forward again
+        for m in model.modules():                                        # "more training": every weight and every statistic moves, in place
+            if isinstance(m, torch.nn.Conv2d) and m.kernel_size in ((1, 1), (3, 3)):
+                m.weight.mul_(1.25)
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.mul_(0.5)
+        ref2 = fwd().clone()
+        assert not torch.equal(ref2, ref)
+        with ops.frozen_weights(model):
+            g.replay()                                                   # the graph of the first block
+            assert torch.equal(out, ref2)
+            assert torch.equal(fwd(), ref2)
+
+
 def _bench_child(extra_env, steps=3, warmup=3, timeout=900):
     """bench.py in a FRESH child process (the pytest process already holds the GPU and must never exec; the child is an ordinary
     subprocess with its own HIP context, like the ranks bench.py --gpus N starts); returns its JSON line"""
