@@ -126,6 +126,7 @@ PROTOTYPES = {
     'eas_simota_assign': (C.c_int, [_P] * 8 + [C.c_int] * 4 + [_P] * 4),
     'eas_simota_assign_rows': (C.c_int, [_P] * 6 + [C.c_int] * 4 + [_P] * 4),
     'eas_det_decode': (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    'eas_det_decode_eval': (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     'eas_det_labels': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     'eas_det_loss_workspace_doubles': (C.c_int64, []),
     'eas_det_loss': (C.c_int, [C.c_int] + [_P] * 8 + [C.c_int, C.c_int] + [_P] * 3 + [C.c_int] + [_P] * 4 + [C.c_int, _P, _P, _P]),

@@ -19,6 +19,10 @@ from .losses import IOUloss
 from .network_blocks import BaseConv, DWConv
 
 
+# EAS_FUSED_EVAL_DECODE=0: the inference output through the tensor operators of the reference (sigmoid, cat, grid arithmetic)
+FUSED_EVAL_DECODE = os.environ.get('EAS_FUSED_EVAL_DECODE', '1') != '0'
+
+
 def _pred(conv, x):
     """prediction conv through ops.conv2d (own kernels where eligible, and visible to the statistics tap of eas_snn_amd.stats)"""
     return ops.conv2d(x, conv) if type(conv) is nn.Conv2d and x.is_cuda else conv(x)
@@ -326,6 +330,11 @@ class YOLOXHead(nn.Module):
     def assemble_eval(self, raws):
         """inference output [B, A, 5 + num_classes] from the per-level raw maps (reg, obj, cls): sigmoid on objectness / classes,
         levels concatenated along the anchors, boxes decoded (yolo_head.py:187-199 of the reference)"""
+        if (self.decode_in_inference and FUSED_EVAL_DECODE and not torch.is_grad_enabled() and ops.det_decode_eval_supported(raws)
+                and raws[0][2].shape[1] == self.num_classes):
+            # sigmoid + concatenations + grid / stride decode: ~25 tensor operators as one launch (eas_det_decode_eval)
+            self.hw = [r.shape[-2:] for r, _, _ in raws]
+            return ops.det_decode_eval(raws, self.strides, self.num_classes)
         outputs = [torch.cat([reg_out, obj_out.sigmoid(), cls_out.sigmoid()], 1) for reg_out, obj_out, cls_out in raws]
         self.hw = [o.shape[-2:] for o in outputs]
         out = torch.cat([o.flatten(start_dim=2) for o in outputs], dim=2).permute(0, 2, 1)

@@ -37,6 +37,10 @@ __device__ __forceinline__ int level_of(const DetLevels& d, int a) {
     return l;
 }
 
+__device__ __forceinline__ float sigmoidf_(float x);
+
+// SIG: objectness and class columns as probabilities (the inference output, eas_det_decode_eval); else the logits (the loss reads those)
+template <bool SIG>
 __global__ __launch_bounds__(EAS_BLOCK) void det_decode_kernel(DetLevels d, float* __restrict__ dec) {
     const int64_t total = (int64_t)d.B * d.A;
     const int row = 5 + d.nc;
@@ -51,9 +55,10 @@ __global__ __launch_bounds__(EAS_BLOCK) void det_decode_kernel(DetLevels d, floa
         o[1] = (r[HW] + gy) * s;
         o[2] = expf(r[2 * (size_t)HW]) * s;
         o[3] = expf(r[3 * (size_t)HW]) * s;
-        o[4] = d.obj[l][(size_t)b * HW + pix];
+        const float ob = d.obj[l][(size_t)b * HW + pix];
+        o[4] = SIG ? sigmoidf_(ob) : ob;
         const float* c = d.cls[l] + (size_t)b * d.nc * HW + pix;
-        for (int k = 0; k < d.nc; ++k) o[5 + k] = c[(size_t)k * HW];
+        for (int k = 0; k < d.nc; ++k) o[5 + k] = SIG ? sigmoidf_(c[(size_t)k * HW]) : c[(size_t)k * HW];
     }
 }
 
@@ -238,7 +243,20 @@ int eas_det_decode(int L, const float* const* reg, const float* const* obj, cons
     if (int rc = fill_levels(d, L, reg, obj, cls, nullptr, nullptr, nullptr, hw, strides, B, nc)) return rc;
     if (!dec) return EAS_ERR_INVALID_ARG;
     EAS_CLEAR_ERR();
-    EAS_LAUNCH(det_decode_kernel, dim3(eas_grid_1d((int64_t)B * d.A)), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec);
+    EAS_LAUNCH(det_decode_kernel<false>, dim3(eas_grid_1d((int64_t)B * d.A)), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec);
+    EAS_CHECK_LAUNCH();
+    return EAS_OK;
+}
+
+// The inference output of YOLOXHead (yolo_head.py:187-199 + decode_outputs :201-216 of the reference): per level cat[reg, sigmoid(obj),
+// sigmoid(cls)], the levels concatenated along the anchors, boxes decoded with grid and stride -- ~25 tensor operators as ONE launch.
+int eas_det_decode_eval(int L, const float* const* reg, const float* const* obj, const float* const* cls, const int* hw, const float* strides,
+                        int B, int nc, float* dec, eas_stream_t stream) {
+    DetLevels d;
+    if (int rc = fill_levels(d, L, reg, obj, cls, nullptr, nullptr, nullptr, hw, strides, B, nc)) return rc;
+    if (!dec) return EAS_ERR_INVALID_ARG;
+    EAS_CLEAR_ERR();
+    EAS_LAUNCH(det_decode_kernel<true>, dim3(eas_grid_1d((int64_t)B * d.A)), dim3(EAS_BLOCK), 0, eas_s(stream), d, dec);
     EAS_CHECK_LAUNCH();
     return EAS_OK;
 }

@@ -142,6 +142,29 @@ class _DetLossFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+def det_decode_eval_supported(raws):
+    return (len(raws) <= 4 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 for trip in raws for t in trip)
+            and sum(r.shape[-1] * r.shape[-2] for r, _, _ in raws) < (1 << 24))
+
+
+@torch.no_grad()
+def det_decode_eval(raws, strides, num_classes):
+    """inference output [B, A, 5 + num_classes] of YOLOXHead from the raw (reg, obj, cls) maps of its levels: sigmoid on objectness and
+    classes, levels along the anchors, boxes decoded -- one launch (eas_det_decode_eval)."""
+    regs, objs, clss = [_f32c(r) for r, _, _ in raws], [_f32c(o) for _, o, _ in raws], [_f32c(c) for _, _, c in raws]
+    _dev(*regs)
+    L = len(regs)
+    B = regs[0].shape[0]
+    hws = [tuple(r.shape[-2:]) for r in regs]
+    A = sum(h * w for h, w in hws)
+    hw_arr = (C.c_int * (2 * L))(*[v for hw in hws for v in hw])
+    st_arr = (C.c_float * L)(*[float(s_) for s_ in strides])
+    dec = torch.empty((B, A, 5 + num_classes), dtype=torch.float32, device=regs[0].device)
+    _call('eas_det_decode', 4 * 2 * dec.numel(), _lib.lib().eas_det_decode_eval, L, _ptr_array(regs), _ptr_array(objs), _ptr_array(clss), hw_arr,
+          st_arr, B, int(num_classes), ptr(dec), stream())
+    return dec
+
+
 def det_loss_supported(raw_regs, labels, loss_type):
     A = sum(r.shape[-1] * r.shape[-2] for r in raw_regs)
     return (raw_regs[0].is_cuda and raw_regs[0].dtype == torch.float32 and len(raw_regs) <= 4 and A <= 12288 and labels.shape[1] <= 255

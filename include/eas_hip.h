@@ -604,6 +604,10 @@ int eas_simota_assign_rows(const float* grids, const float* strides, const float
 int eas_det_labels(const float* labels, int B, int G, uint8_t* gt_valid, float* gt_cls, float* gt_boxes, float* num_gts, eas_stream_t stream);
 int eas_det_decode(int L, const float* const* reg, const float* const* obj, const float* const* cls, const int* hw,
                    const float* strides, int B, int nc, float* dec, eas_stream_t stream);
+/* ABI 8.  eas_det_decode with sigmoid on the objectness and class columns: the INFERENCE output of YOLOXHead.forward (yolo_head.py:187-199:
+ * per level cat[reg, obj.sigmoid(), cls.sigmoid()], levels concatenated along the anchors) after decode_outputs (:201-216) in one launch. */
+int eas_det_decode_eval(int L, const float* const* reg, const float* const* obj, const float* const* cls, const int* hw,
+                        const float* strides, int B, int nc, float* dec, eas_stream_t stream);
 int64_t eas_det_loss_workspace_doubles(void);
 int eas_det_loss(int L, const float* const* reg, const float* const* obj, const float* const* cls, float* const* g_reg,
                  float* const* g_obj, float* const* g_cls, const int* hw, const float* strides, int B, int nc, const float* dec,

@@ -2,7 +2,7 @@
 """development (GPU box): which Python lines of the eager training step launch the ATen glue kernels (fills, adds, copies, sums).
 torch.profiler with stacks over ONE eager step of the bench's trainer; device time of every aten:: operator grouped by the innermost
 frame inside this repository.
-usage: dev_aten_sources.py [config]"""
+usage: dev_aten_sources.py [config] [eval]      (eval: one eager eval forward + reset_net, as the evaluator runs it, instead of a training step)"""
 import collections
 import os
 import sys
@@ -23,11 +23,25 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream())
     ops.set_state_writeback(False)
     trainer, model, step = workloads.build_trainer(w, w['batch'], dev, 200_000, out_dir='/tmp/eas_aten_sources')
+    if len(sys.argv) > 2 and sys.argv[2] == 'eval':
+        from spikingjelly.activation_based import functional
+        model.eval()
+        _, inputs_fn = workloads.device_inputs(w, w['batch'], 200_000, dev, seed=0)
+
+        def run():
+            model(inputs_fn()[0])
+            functional.reset_net(model)
+        ctx = torch.no_grad()
+        ctx.__enter__()
+        scope = ops.frozen_weights(model)
+        scope.__enter__()
+    else:
+        run = step.eager
     for _ in range(3):
-        step.eager()
+        run()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
-        step.eager()
+        run()
         torch.cuda.synchronize()
     groups = collections.defaultdict(lambda: [0, 0.0])
     for ev in prof.events():

@@ -1411,6 +1411,35 @@ def test_head_with_grouped_launches_equals_the_per_level_head(dev, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,nc,hws', [(2, 2, ((32, 40), (16, 20), (8, 10))), (3, 100, ((24, 32), (12, 16), (6, 8))), (64, 2, ((80, 80), (40, 40), (20, 20)))])
+def test_inference_output_of_the_head_in_one_launch(dev, B, nc, hws):
+    """eas_det_decode_eval against the tensor operators of YOLOXHead's inference path (yolo_head.py:187-216 of the reference: sigmoid on
+    objectness / classes, cat along the anchors, (xy + grid) * stride, exp(wh) * stride): boxes bit-identical, probabilities within 2 ulp."""
+    from eas_snn_amd import ops
+    from yolox.models.yolo_head import YOLOXHead
+    g = torch.Generator().manual_seed(B + nc)
+    raws = [tuple(torch.randn(B, c, h, w, generator=g).to(dev) for c in (4, 1, nc)) for h, w in hws]
+    hd = YOLOXHead(nc, width=0.5)
+    hd.decode_in_inference = True
+    import yolox.models.yolo_head as yh
+    prev = yh.FUSED_EVAL_DECODE
+    try:
+        with torch.no_grad():
+            yh.FUSED_EVAL_DECODE = True
+            with ops.kernel_trace() as tr:
+                got = hd.assemble_eval(raws)
+            assert any('det_decode' in k for k in tr.kernels), tr.kernels
+            yh.FUSED_EVAL_DECODE = False
+            want = hd.assemble_eval(raws)
+    finally:
+        yh.FUSED_EVAL_DECODE = prev
+    assert got.shape == want.shape == (B, sum(h * w for h, w in hws), 5 + nc)
+    assert torch.equal(got[..., :2], want[..., :2])
+    torch.testing.assert_close(got[..., 2:4], want[..., 2:4], rtol=3e-7, atol=0)
+    torch.testing.assert_close(got[..., 4:], want[..., 4:], rtol=3e-7, atol=1e-9)
+
+
+@pytest.mark.gpu
 def test_frozen_weights_scope_reuses_the_packs_and_never_serves_stale_ones(dev):
     """ops.frozen_weights (the evaluator's loop): inside the block an eval forward launches no weight-packing kernel and gives the bits of an
     ordinary forward; a HIP graph captured inside it follows weights AND BatchNorm statistics changed between two blocks (the next
