@@ -87,6 +87,7 @@ class _ConvGroupFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, *tensors):
+        ctx.set_materialize_grads(False)      # outputs nobody differentiates (the statistics handed to the BatchNorm launch) arrive as None, not as zero-filled tensors
         n, k, dual, has_bias, want_stats = cfg['n'], cfg['k'], cfg['dual'], cfg['has_bias'], cfg['want_stats']
         xs = [ops._f32c(t) for t in tensors[:n]]
         was = tensors[n:2 * n]
@@ -274,6 +275,7 @@ class _BNSiLUGroupFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, *tensors):
+        ctx.set_materialize_grads(False)      # outputs nobody differentiates (the statistics handed to the BatchNorm launch) arrive as None, not as zero-filled tensors
         ny, items = cfg['ny'], cfg['items']
         m = len(items)
         ys = [ops._f32c(t) for t in tensors[:ny]]
@@ -369,6 +371,7 @@ class _PredGroupFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, *tensors):
+        ctx.set_materialize_grads(False)      # outputs nobody differentiates (the statistics handed to the BatchNorm launch) arrive as None, not as zero-filled tensors
         n = cfg['n']
         cf = [ops._f32c(t) for t in tensors[:n]]
         rf = [ops._f32c(t) for t in tensors[n:2 * n]]
