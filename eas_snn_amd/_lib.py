@@ -238,6 +238,27 @@ def _bind_host_hip_runtime():
     C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
+_PRIVATE_STREAMS = []
+
+
+def private_stream():
+    """A torch stream on a HIP stream of its own (hipStreamCreateWithFlags), NOT one of the 32 pooled streams ``torch.cuda.Stream()`` hands out
+    round-robin.  Every stream that may end up inside a graph capture is made here: ProcessGroupNCCL takes its internal stream from the same
+    pool, and when a pooled stream that happens to be THAT one is put into capture, the process group's watchdog thread -- which keeps
+    querying the end events of collectives recorded on it -- fails with hipErrorCapturedEvent ("operation not permitted on an event last
+    recorded in a capturing stream") and aborts the process.  Seen in roughly one of ten runs of the one-rank RCCL bench."""
+    import torch
+    _bind_host_hip_runtime()
+    rt = C.CDLL(None)                    # the process-wide symbol scope: the HIP runtime torch loaded
+    handle = C.c_void_p()
+    rc = rt.hipStreamCreateWithFlags(C.byref(handle), C.c_uint(1))          # hipStreamNonBlocking
+    if rc != 0 or not handle.value:
+        raise EasHipError(f'hipStreamCreateWithFlags failed ({rc})')
+    st = torch.cuda.ExternalStream(handle.value)
+    _PRIVATE_STREAMS.append(st)          # lives as long as the process (graphs recorded on it are replayed until the end)
+    return st
+
+
 def lib():
     """The loaded library; raises (loudly) when it has not been built."""
     global _lib

@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 from torch.nn.parallel import DistributedDataParallel as DDP
 
-from eas_snn_amd import ops
+from eas_snn_amd import _lib, ops
 from eas_snn_amd.parallel import BucketedGradAllReduce
 from yolox.utils import (ModelEMA, adjust_status, all_reduce_norm, get_local_rank, get_model_info, get_rank, get_world_size,
                          is_parallel, load_ckpt, save_checkpoint, setup_logger, synchronize)
@@ -143,7 +143,7 @@ class TrainStep:
             self.exchange.reduce(0)
             return
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = _lib.private_stream()
         self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
             self.exchange.reduce(0)
@@ -193,9 +193,16 @@ class TrainStep:
         # on the capturing stream by the autograd thread are recorded either way.
         mode = 'thread_local' if dist.is_initialized() else 'global'
 
+        if getattr(self, '_capture_stream', None) is None:
+            self._capture_stream = _lib.private_stream()      # never a pooled stream: ProcessGroupNCCL's own stream is one of those
+
         def graph(g, pool=None):
             torch.cuda.synchronize()
-            return torch.cuda.graph(g, pool=pool, capture_error_mode=mode)
+            if dist.is_initialized():
+                # the watchdog retires finished collectives at its next poll (every 100 ms): give it that poll, so that it holds no event at
+                # all while a capture is open (one run in ten died with hipErrorCapturedEvent in the watchdog's event query otherwise)
+                time.sleep(0.3)
+            return torch.cuda.graph(g, pool=pool, stream=self._capture_stream, capture_error_mode=mode)
         if self.exchange is None:
             g = torch.cuda.CUDAGraph()
             with graph(g):
@@ -360,7 +367,7 @@ class Trainer:
             if self.use_graph:
                 # graph capture wants every node of the iteration (the AccumulateGrad nodes included) on a non-default stream from the
                 # first eager iteration on: the whole loop runs on a stream of its own
-                s = torch.cuda.Stream()
+                s = _lib.private_stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     self._train_epochs()

@@ -36,7 +36,8 @@ class _GraphedBatch:
         from eas_snn_amd import ops
         self.static_in = imgs.clone()
         self.key = self.signature(model, imgs)
-        side = torch.cuda.Stream()
+        from eas_snn_amd import _lib
+        side = _lib.private_stream()          # the capture stream: never a pooled stream (the process group's stream is one of those)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), ops.no_state_writeback() if snn_reset else _null():
             for _ in range(2):                           # allocator warm-up on the capture stream

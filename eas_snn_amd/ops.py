@@ -1729,7 +1729,7 @@ def _side_flush():
     if not jobs:
         return
     if _SIDE['stream'] is None:
-        _SIDE['stream'] = torch.cuda.Stream()
+        _SIDE['stream'] = _lib.private_stream()          # joins graph captures: never a pooled stream (see there)
     side = _SIDE['stream']
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
