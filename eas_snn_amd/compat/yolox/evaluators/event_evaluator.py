@@ -46,6 +46,9 @@ class _GraphedBatch:
                     _reset_net(model)
                 ops.postprocess_device(out, num_classes, confthre, nmsthre)
             torch.cuda.synchronize()
+            if torch.distributed.is_initialized():
+                time.sleep(0.3)                          # the process group's watchdog retires finished collectives at its next poll: it must hold
+                                                         # no event while a capture is open (trainer.py TrainStep.capture)
             self.g_fwd, self.g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             mode = 'thread_local' if torch.distributed.is_initialized() else 'global'
             with torch.cuda.graph(self.g_fwd, stream=side, capture_error_mode=mode):
