@@ -42,7 +42,7 @@ def clock(fn, n=10):
 MODES = ('auto', 'all', False) if not os.environ.get('EAS_DEV_EVAL_ONLY') else (os.environ['EAS_DEV_EVAL_ONLY'],)      # one mode only: for a profile
 for fused in MODES:
     ops.FUSED_EVAL = fused
-    with torch.no_grad(), ops.no_state_writeback():
+    with torch.no_grad(), ops.no_state_writeback(), ops.frozen_weights(model):      # (frozen_weights: as EventEvaluator.evaluate runs its loop)
         for _ in range(3):
             fwd()
         eager = clock(fwd)
