@@ -209,6 +209,10 @@ PROTOTYPES = {
     'eas_conv_wgrad_group_partial': (C.c_int, [C.POINTER(EasWgradProblem), C.c_int, C.c_int, C.c_int, _P]),
     'eas_channel_sum_group': (C.c_int, [C.POINTER(EasChannelSumProblem), C.c_int, _P]),
     'eas_pred_dgrad_group': (C.c_int, [C.POINTER(EasPredDgradProblem), C.c_int, _P]),
+    'eas_adam_table_entry_bytes': (C.c_int, []),
+    'eas_adam_chunk': (C.c_int, []),
+    'eas_adam_step': (C.c_int, [_P, C.c_int, C.c_longlong, C.c_double, C.c_double, C.c_double, _P]),
+    'eas_adam_advance_steps': (C.c_int, [_P, C.c_int, _P]),
 }
 
 

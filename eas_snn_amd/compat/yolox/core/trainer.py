@@ -239,6 +239,8 @@ class TrainStep:
             self.graphs = (g_a, g_b)
             self.launch = 'two hip-graph replays per step (fwd+bwd+pack | adam+reset) with the eager RCCL all-reduce between them'
         torch.cuda.synchronize()
+        if hasattr(self.optimizer, 'sync_tables'):
+            self.optimizer.sync_tables()              # eas_snn_amd.optim.FusedAdam: the pointer table of the captured step (not copyable inside a capture)
         self.replay()                                 # warm-up replay
         return self.launch
 

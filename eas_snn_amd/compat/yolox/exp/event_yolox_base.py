@@ -137,7 +137,11 @@ class EventExp(BaseExp):
             # same update rule as the reference's torch.optim.Adam; on the GPU the single-kernel-per-group implementation
             # (40 small foreach kernels per step become 5)
             on_gpu = all(p.is_cuda for p in bn_w + conv_w + biases + neuron_p + emb_p)
-            opt = torch.optim.Adam(bn_w, lr=lr, amsgrad=False, **({'fused': True} if on_gpu else {}))
+            if on_gpu:
+                from eas_snn_amd.optim import FusedAdam          # torch.optim.Adam subclass: the step of all groups as one launch (EAS_FUSED_ADAM=0: torch's)
+                opt = FusedAdam(bn_w, lr=lr, amsgrad=False)
+            else:
+                opt = torch.optim.Adam(bn_w, lr=lr, amsgrad=False)
         else:
             opt = torch.optim.SGD(bn_w, lr=lr, momentum=self.momentum, nesterov=True)
         opt.add_param_group({'params': conv_w, 'weight_decay': self.weight_decay})

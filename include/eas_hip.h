@@ -725,6 +725,20 @@ typedef struct {
 } EasPredDgradProblem;
 int eas_pred_dgrad_group(const EasPredDgradProblem* problems, int n, eas_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ABI 8.  Adam step of every parameter group in one launch (csrc/adam.hip): torch.optim.Adam as the reference builds it
+ * (yolox/exp/event_yolox_base.py:352-414: BN weights | convolution weights with weight decay | biases | neuron parameters | sampler parameters),
+ * update rule and float / double promotions of torch's fused kernel (ADAM_MODE::ORIGINAL, no amsgrad, no grad scaler).
+ * table: DEVICE array of ntensors entries of eas_adam_table_entry_bytes() = 80 bytes:
+ *   { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* step (fp32 device scalar); const float* lr_ptr (device scalar or NULL);
+ *     double lr (used when lr_ptr is NULL); double weight_decay; int64 numel; int64 first_block }
+ * first_block = prefix sum of ceil(numel / eas_adam_chunk()) over the entries, total_blocks = the sum.  eas_adam_step takes step number
+ * *step + 1 on every tensor WITHOUT writing the counters; eas_adam_advance_steps (called right after it) adds 1 to each. */
+int eas_adam_table_entry_bytes(void);
+int eas_adam_chunk(void);
+int eas_adam_step(const void* table, int ntensors, long long total_blocks, double beta1, double beta2, double eps, eas_stream_t stream);
+int eas_adam_advance_steps(const void* table, int ntensors, eas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1314,6 +1314,55 @@ def test_prediction_convolution_input_gradients_as_fp32_fma(dev, N, C, nc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('capturable', [False, True])
+def test_adam_step_of_all_groups_in_one_launch_matches_torch_fused_adam(dev, capturable):
+    """eas_snn_amd.optim.FusedAdam (eas_adam_step: every parameter group in one launch) against torch.optim.Adam(fused=True) on the same
+    parameters and gradients for six steps: five groups as the reference builds them (weight decay on one, an own learning rate on another),
+    tensor sizes around the 4096-element chunk and the 4-element vector, learning rate as a python float and -- capturable -- as a device
+    scalar.  Parameters and both moments agree to a few ulp (the kernels contract multiply-adds differently), step counters exactly, and the
+    state dict of one loads into the other."""
+    from eas_snn_amd import ops
+    from eas_snn_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64,), (128, 64, 3, 3), (4097,), (3,), (256, 128, 1, 1), (1,), (5000, 3), (32, 8, 3, 3)]
+    base = [torch.randn(s_, generator=g) for s_ in shapes]
+
+    def build(cls):
+        ps = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+        kw = dict(lr=1e-3, amsgrad=False)
+        opt = cls(ps[:2], **kw) if cls is FusedAdam else cls(ps[:2], fused=True, **kw)
+        opt.add_param_group({'params': ps[2:4], 'weight_decay': 5e-4})
+        opt.add_param_group({'params': ps[4:5]})
+        opt.add_param_group({'params': ps[5:6]})
+        opt.add_param_group({'params': ps[6:], 'lr': 3e-4})
+        return ps, opt
+    pa, oa = build(FusedAdam)
+    pb, ob = build(torch.optim.Adam)
+    for it in range(6):
+        grads = [torch.randn(s_, generator=g).to(dev) * (0.1 + it) for s_ in shapes]
+        for ps in (pa, pb):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone()
+        if capturable and it == 2:          # from now on as a captured trainer runs it: device step counters, learning rates as device scalars
+            for o in (oa, ob):
+                for gr_ in o.param_groups:
+                    gr_['capturable'] = True
+                    gr_['lr'] = torch.tensor(float(gr_['lr']), dtype=torch.float32, device=dev)
+        with ops.kernel_trace() as tr:
+            oa.step()
+        assert any('adam_step_kernel' in k for k in tr.kernels), tr.kernels
+        ob.step()
+    for p, q in zip(pa, pb):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-7)
+        sa, sb = oa.state[p], ob.state[q]
+        assert float(sa['step']) == float(sb['step']) == 6.0
+        torch.testing.assert_close(sa['exp_avg'], sb['exp_avg'], rtol=2e-6, atol=1e-6 * float(sb['exp_avg'].abs().max()))
+        torch.testing.assert_close(sa['exp_avg_sq'], sb['exp_avg_sq'], rtol=2e-6, atol=1e-6 * float(sb['exp_avg_sq'].abs().max()))
+    ob.load_state_dict(oa.state_dict())
+    oa.load_state_dict(ob.state_dict())
+
+
+@pytest.mark.gpu
 def test_stem_convolution_backward_takes_the_small_channel_kernel(dev):
     """ops.conv2d on an 8-channel input: its input gradient comes from eas_conv_dgrad_small (kernel trace) and matches fp64"""
     import torch.nn as nn
