@@ -51,35 +51,46 @@ PMC_KERNELS = {'eas_bn_lif_bwd': ['bn_lif_bwd_kernel', 'bn_lif_bwd_small_kernel'
                                   'conv1x1_wgrad_lds_kernel[planes]']}
 
 
+# the sources a family's kernels are built from: a committed PMC figure is only quoted while they are what it was measured on
+_CONV_SRC = ['conv_mfma.hip', 'conv_mfma_body.h', 'conv1x1_mfma.hip', 'conv_group.hip', 'conv_s2d.hip', 'conv_lif_epi.h', 'conv_small_dgrad.hip', 'eas_common.h']
+FAMILY_SOURCES = {'eas_conv_fwd': _CONV_SRC, 'eas_conv_wgrad': ['conv_wgrad_mfma.hip', 'conv1x1_mfma.hip', 'eas_common.h'],
+                  'eas_bn_lif_bwd': ['bn_lif.hip', 'eas_common.h'], 'eas_bn_lif_fwd': ['bn_lif.hip', 'eas_common.h'], 'eas_bn_stats': ['bn_lif.hip', 'eas_common.h'],
+                  'eas_bn_silu_bwd': ['bn_act.hip', 'eas_common.h'], 'eas_bn_silu_fwd': ['bn_act.hip', 'eas_common.h'],
+                  'eas_event_histogram': ['events.hip', 'eas_common.h'], 'eas_arsnn_step_fwd': ['arsnn.hip', 'smallconv_core.h', 'eas_common.h'],
+                  'eas_smallconv_fwd': ['smallconv.hip', 'smallconv_core.h', 'eas_common.h'],
+                  'eas_smallconv_bwd_weight': ['smallconv.hip', 'smallconv_wgrad_mfma.hip', 'smallconv_core.h', 'eas_common.h']}
+
+
+def csrc_hashes():
+    import hashlib
+    d = os.path.join(ROOT, 'eas_snn_amd', 'csrc')
+    return {f: hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest()[:16] for f in sorted(os.listdir(d)) if f.endswith(('.hip', '.h'))}
+
+
 def pmc_traffic(entry, launches_per_call, config=2):
-    """Average HBM bytes one call of ``entry`` moves, from the committed PMC summary of this configuration: launch-weighted mean over
-    the device kernels that implement it, times the launches one call makes."""
+    """-> (bytes, reason).  Average HBM bytes one call of ``entry`` moves, from the committed PMC summary of this configuration:
+    launch-weighted mean over the device kernels that implement it, times the launches one call makes.  The summary records the hashes of
+    the kernel sources it was measured on (scripts/pmc_summary.py); when a source of this family has changed since, the figure is stale
+    and is NOT quoted: (None, why)."""
+    path = PMC_FILE if config == 2 else PMC_FILE.replace('.json', f'_config{config}.json')
     try:
-        with open(PMC_FILE if config == 2 else PMC_FILE.replace('.json', f'_config{config}.json')) as fh:
+        with open(path) as fh:
             pmc = json.load(fh)
+    except (OSError, ValueError):
+        return None, f'no PMC summary for this configuration ({os.path.basename(path)})'
+    recorded = (pmc.get('_meta') or {}).get('csrc_sha16')
+    if not recorded:
+        return None, f'{os.path.basename(path)} does not record the kernel sources it was measured on'
+    now = csrc_hashes()
+    changed = [f for f in FAMILY_SOURCES.get(entry, sorted(now)) if recorded.get(f) != now.get(f)]
+    if changed:
+        return None, f'stale: {", ".join(changed)} changed after the PMC passes of {os.path.basename(path)}; re-run scripts/gpu_profile.sh'
+    try:
         ks = [pmc[k] for k in PMC_KERNELS[entry] if k in pmc]
         n = sum(k['launches'] for k in ks)
-        return round(sum(k['hbm_bytes_per_launch'] * k['launches'] for k in ks) / n * launches_per_call)
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None
-
-
-def pmc_traffic_eval(entry):
-    """HBM bytes per launch of the eval forward's dominant family from the committed PMC pass over the eval forward
-    (profiles/pmc_traffic_eval_latest.json, scripts/prof_eval.sh), or None"""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_eval_latest.json')) as fh:
-            pmc = json.load(fh)
-        ks = [pmc[k] for k in PMC_KERNELS_EVAL.get(entry, []) if k in pmc]
-        n = sum(k['launches'] for k in ks)
-        return round(sum(k['hbm_bytes_per_launch'] * k['launches'] for k in ks) / n)
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None
-
-
-PMC_KERNELS_EVAL = {'eas_conv_bn_lif_eval': ['conv_fwd_mfma_kernel', 'conv1x1_mfma_kernel', 'conv1x1_mfma_sharedA_kernel', 'conv_fwd_mfma_kernel[planes]',
-                                             'conv1x1_mfma_kernel[planes]', 'conv1x1_mfma_sharedA_kernel[planes]'],
-                    'eas_conv_fwd': PMC_KERNELS['eas_conv_fwd'], 'eas_bn_lif_fwd': PMC_KERNELS['eas_bn_lif_fwd']}
+        return round(sum(k['hbm_bytes_per_launch'] * k['launches'] for k in ks) / n * launches_per_call), None
+    except (KeyError, ValueError, ZeroDivisionError):
+        return None, f'{os.path.basename(path)} holds no kernel of {entry}'
 
 
 def parse():
@@ -291,20 +302,42 @@ def selftest_cpu(args, world, rank):
     if os.environ.get('EAS_BENCH_SELFTEST_FAIL_RANK') == str(rank):     # test hook: this rank dies before the rendezvous
         sys.exit(7)
     w = workloads.get(args.config)
-    if world > 1:
-        dist.init_process_group('gloo')
+    # The order of the GPU path at N > 1 (main() below, Trainer.train_one_iter): step object with an UNBOUND exchange -> record
+    # (capture(restore=True): warm-up launches, state put back; on the CPU nothing is recorded, the protocol is the same) -> process group
+    # -> bind (rank 0's parameters into place) -> steps.
     torch.manual_seed(rank)
     net = _StandIn()
-    exchange = BucketedGradAllReduce(net, split=DEFAULT_LOWER) if world > 1 else None
-    if world > 1:
-        ref = _StandIn()
-        ref.load_state_dict(net.state_dict())           # rank 0's values after the constructor's broadcast: a plain-backward twin
-    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    twin = _StandIn()
+    twin.load_state_dict(net.state_dict())              # this rank's initial values, for the group-first order below
+    exchange = BucketedGradAllReduce(net, split=DEFAULT_LOWER, world=world) if world > 1 else None
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
     x = torch.full((8, 16), float(rank + 1)) + torch.arange(16.0) * 0.01
     step = TrainStep(net, opt, lambda: (x, None), exchange=exchange, reset=False, defer_wgrad=False, cut=DEFAULT_CUT)
+    assert exchange is None or not exchange.bound
+    step.capture(warm=2, restore=True)
+    if world > 1:
+        assert not dist.is_initialized()
+        dist.init_process_group('gloo')
+        exchange.bind()
+        assert exchange.bound and exchange.world == world
+    losses = [float(step().detach()) for _ in range(3)]
+    same_as_group_first = None
+    if world > 1:
+        # the order of rounds 1-5 (group first, the exchange's constructor broadcasts, steps from the first one on) on the twin: same losses
+        opt2 = torch.optim.Adam(twin.parameters(), lr=1e-2)
+        ex2 = BucketedGradAllReduce(twin, split=DEFAULT_LOWER)
+        step2 = TrainStep(twin, opt2, lambda: (x, None), exchange=ex2, reset=False, defer_wgrad=False, cut=DEFAULT_CUT)
+        losses2 = [float(step2().detach()) for _ in range(3)]
+        assert losses == losses2, f'record-then-rendezvous differs from rendezvous-first: {losses} vs {losses2}'
+        assert all(torch.equal(p, q) for p, q in zip(net.parameters(), twin.parameters()))
+        same_as_group_first = True
+        ref = _StandIn()
+    for g in opt.param_groups:
+        g['lr'] = 0.0                                   # the timed steps below leave the parameters alone (the gradient check needs that)
     for _ in range(args.warmup):
         step()
     if world > 1:
+        ref.load_state_dict(net.state_dict())           # a plain-backward twin of the current values
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -329,7 +362,8 @@ def selftest_cpu(args, world, rank):
         print(json.dumps({'selftest': True, 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': round(float(el) / args.steps * 1e3, 4), 'backend': 'gloo',
                           'gradient_exchange': (f'{exchange.nbuckets} buckets' if exchange is not None else None),
-                          'config': {'workload': w['name'], 'config': w['config']},
+                          'order': 'record (restore) -> init_process_group -> bind -> steps', 'same_losses_as_group_first_order': same_as_group_first,
+                          'first_losses': losses, 'config': {'workload': w['name'], 'config': w['config']},
                           'spawned_by_bench': os.environ.get('EAS_BENCH_SPAWNED') == '1'}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -387,6 +421,98 @@ def dominant_roofline(summ):
     r.update({'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4), 'frac_of_per_launch_roofline': round(d['roof_ms'] / d['ms'], 4),
               'algorithmic_bytes_per_call': round(d['bytes'] / d['calls'])})
     return r
+
+
+def ema_side_figure(trainer, step, inputs_fn, n=10):
+    """Side figure (never `value`): the same step WITH the weight average the reference keeps by default (exp.ema = True,
+    event_yolox_base.py:116; ModelEMA.update after every optimizer.step(), trainer.py:120-121).  The average is made by the optimizer's own
+    launch (FusedAdam.attach_ema, eas_adam_step_ex), so the step stays one HIP-graph replay; timed back to back with the headline's graph in
+    the same process, alternating, so that the difference is the average and not the box."""
+    ema = trainer.make_ema(0.9998, 0)
+    if getattr(ema, '_fused_in', None) is not trainer.optimizer:
+        return {'error': 'the optimizer of this run does not take the weight average into its launch'}
+    try:
+        step_e = trainer.step_fn(inputs_fn, ema=ema)
+        form = step_e.capture(warm=2)
+
+        def clock(fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        off, on = [], []
+        for _ in range(3):
+            off.append(clock(step.replay))
+            on.append(clock(step_e.replay))
+        assert torch.isfinite(step_e.loss), 'the step with the weight average produced a non-finite loss'
+        return {'ema_on_ms_per_step': round(min(on), 3), 'ema_off_ms_per_step_same_run': round(min(off), 3),
+                'difference_ms': round(min(on) - min(off), 3), 'launch': form, 'updates_on_device': trainer.optimizer.ema_updates_on_device(),
+                'note': 'ModelEMA (decay 0.9998, ramp 2000) over every floating-point state-dict entry, made inside the one Adam launch; '
+                        'best of 3 x %d replays each, alternating with the headline graph' % n}
+    finally:
+        trainer.optimizer.detach_ema()
+
+
+def parity_against_oracle(w, model, raw, dev):
+    """Part of the CPU-baseline leg (the only place this file touches oracle/, and only as the checker): the HIP path against the CPU
+    restatement on two samples of THIS run's input with THIS run's weights (the state after the timed steps) -- event binning bit-exact or
+    not, and the share of eval-mode detection logits within 1e-4 (relative + absolute) end to end at the bench canvas.  The spiking backbone
+    amplifies a rounding-level spike flip (chaotic cascade), so the end-to-end share is reported as measured, next to
+    the per-layer teacher-forced figures of the GPU test-suite (profiles/parity_teacher_forced_latest.json when its source hashes match)."""
+    from oracle import events_ref, model_ref, sj_ref
+    from spikingjelly.activation_based import functional
+    from eas_snn_amd import data
+    out = {'samples': 2, 'canvas': list(w['canvas'])}
+    try:
+        B, Tm, sensor, canvas = 2, w['Tm'], tuple(w['sensor']), tuple(w['canvas'])
+        if w['input'] == 'events':
+            offs = raw['offsets'][:B + 1]
+            n = int(offs[B])
+            ev = {k: raw[k][:n] for k in ('t', 'x', 'y', 'p')}
+            frames = data.events_to_frames(dict(ev, offsets=offs), Tm, sensor, canvas)
+            counts = events_ref.micro_sum_batch(*(ev[k].cpu().numpy() for k in ('t', 'x', 'y', 'p')), offs.cpu().numpy(), Tm, *sensor)
+            got = frames[:, 0, :, :, :sensor[0], :sensor[1]].cpu().numpy()
+            pad_clear = bool(frames.sum().item() == float(got.sum()))
+            out['binning'] = 'bit_exact' if (np.array_equal(got, counts.astype(np.float32)) and pad_clear) else 'MISMATCH'
+            out['binning_events_checked'] = n
+        else:
+            from eas_snn_amd import ops
+            frames = ops.stacked_hist_event_sum(raw[:B], *canvas)
+            want = np.stack([events_ref.stacked_hist_event_sum(raw[b].cpu().numpy(), Tm, *sensor)[0] for b in range(B)])
+            got = frames[:, 0, :, :, :sensor[0], :sensor[1]].cpu().numpy()
+            out['binning'] = 'bit_exact' if np.array_equal(got, want.astype(np.float32)) else 'MISMATCH'
+        ref = model_ref.build_model(**w['oracle'])
+        ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+        was_training = model.training
+        model.eval()
+        ref.eval()
+        with torch.no_grad():
+            lh = model(frames).cpu().numpy()
+            lr = ref(frames.cpu()).numpy()
+        functional.reset_net(model)
+        sj_ref.reset_net(ref)
+        model.train(was_training)
+        close = np.isclose(lh, lr, rtol=1e-4, atol=1e-4)
+        rel = np.abs(lh - lr) / (np.abs(lr) + 1e-4)
+        out.update({'logits_within_1e-4_share_end_to_end': round(float(close.mean()), 6), 'logits_median_rel_err': float(np.median(rel)),
+                    'logits_compared': int(lh.size), 'tolerance': 'rtol 1e-4 + atol 1e-4 (north_star: 1e-4 relative)'})
+    except Exception as exc:                                     # a side figure must not take the line with it
+        out['error'] = f'{type(exc).__name__}: {exc}'[:300]
+    # per-layer figures of the teacher-forced GPU tests (tests/parity_report.py writes them; quoted only for the kernel sources of this build)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'parity_teacher_forced_latest.json')) as fh:
+            tf = json.load(fh)
+        recorded, now = (tf.get('_meta') or {}).get('csrc_sha16') or {}, csrc_hashes()
+        stale = [f for f in now if recorded.get(f) != now.get(f)]
+        if stale:
+            out['teacher_forced'] = {'unavailable': f'stale: {", ".join(stale[:4])} changed after tests/parity_report.py ran'}
+        else:
+            out['teacher_forced'] = {k: v for k, v in tf.items() if not k.startswith('_')}
+    except (OSError, ValueError):
+        out['teacher_forced'] = {'unavailable': 'profiles/parity_teacher_forced_latest.json not present'}
+    return out
 
 
 def canvas_640_figure(dev, batch, events):
@@ -466,7 +592,13 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29533')
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
+        # The RCCL process group is created AFTER the step's HIP graphs are recorded (trainer.join_ranks below): ProcessGroupNCCL's watchdog
+        # thread polls events of collectives in flight, and no capture may be open while it does.  Until then rank and world size come from
+        # the rendezvous parameters (yolox.utils.dist.defer_process_group, what yolox.core.launch does for its workers too).
+        from datetime import timedelta
+        import eas_snn_amd  # noqa: F401  (puts the compat namespace -- yolox, spikingjelly -- on the path)
+        from yolox.utils import dist as comm
+        comm.defer_process_group('nccl', 'env://', world, rank, timedelta(minutes=30), local_size=world, local_rank=local_rank, device_id=dev)
 
     # everything runs on one non-default stream: autograd's AccumulateGrad nodes remember the stream they were created on,
     # and a later graph capture breaks if that was the default stream
@@ -508,7 +640,9 @@ def main():
     t_tot = time.perf_counter() - t_a
     probe = {}
     if mode in ('1', 'auto') and trainer.net is trainer.bare_model:
-        step.capture(warm=3)
+        # multi: recorded before the process group exists, the warm-up launches' effect on model and optimizer state put back afterwards
+        # (every rank then takes rank 0's parameters in join_ranks, as DistributedDataParallel's constructor would hand them out)
+        step.capture(warm=3, restore=multi)
         if not multi and mode == 'auto':
             def clock(fn, n=4):
                 torch.cuda.synchronize()
@@ -521,6 +655,14 @@ def main():
             if probe['eager_ms'] < probe['graph_ms']:
                 step.uncapture()                     # eager is faster on this host right now
     launch = step.launch
+    if multi:
+        trainer.join_ranks()                     # init_process_group (RCCL), rank 0's parameters into place
+        assert dist.is_initialized() and dist.get_world_size() == world and (trainer.exchange is None or trainer.exchange.bound)
+        # The first collectives build the communicator's rings: not in the timed region.  Four steps, because the recording above left no
+        # trace (restore) where the one-GPU path keeps its three warm-up launches and the closing replay: both paths reach the timed region
+        # after the same number of training steps (tests/test_gpu_model.py compares their losses).
+        for _ in range(4):
+            one()
     timer = ops.KernelTimer() if rank == 0 else None
     torch.cuda.synchronize()
     if world > 1:
@@ -606,15 +748,25 @@ def main():
         eval_roofline = dominant_roofline(ev_summ)
         ev_ms = sum(v['ms'] for v in ev_summ.values()) / 3
         ev_roof = sum(v['roof_ms'] for v in ev_summ.values()) / 3
-        eval_roofline.update({'traffic': pmc_traffic_eval(eval_roofline['kernel']), 'hip_kernel_ms_per_batch': family_table(ev_summ, 3),
+        # (no PMC pass over the eval forward exists: its traffic is not claimed)
+        eval_roofline.update({'traffic': None, 'hip_kernel_ms_per_batch': family_table(ev_summ, 3),
                               'hip_kernels_ms_per_batch': round(ev_ms, 3), 'replayed_ms_per_batch': round(batch / eval_fps['value'] * 1e3, 3),
                               'all_families_frac_of_per_launch_roofline': round(ev_roof / ev_ms, 4),
                               'kernel_timing': 'HIP events on the launch stream, 3 eager eval forwards of this process'})
         model.train()
     # launches of one step (every rank runs the steps -- the exchange needs all of them --, rank 0 reports)
     launches = count_launches(step, eas_snn_amd.hip_library()) if (rank == 0 and not multi) else None
+    # (side figures that record further graphs or start a child process: never under a profiler -- rocprofv3 follows the child, whose kernel
+    # statistics would land next to, or over, this process's)
+    profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROFILER_', 'ROCPROF_')) for k in os.environ)
+    ema_figure = None
+    if rank == 0 and not multi and step.graphs is not None and os.environ.get('EAS_BENCH_NO_EMA') != '1' and not profiled:
+        try:
+            ema_figure = ema_side_figure(trainer, step, inputs_fn)
+        except Exception as exc:
+            ema_figure = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     canvas640 = None
-    if rank == 0 and not multi and w['config'] == 2 and args.batch is None and os.environ.get('EAS_BENCH_NO_640') != '1':
+    if rank == 0 and not multi and w['config'] == 2 and args.batch is None and os.environ.get('EAS_BENCH_NO_640') != '1' and not profiled:
         # in a child process of its own (started like the ranks of launch_ranks, never an exec): a side figure must not be able to take the
         # headline line with it -- a failure is reported in its place
         import subprocess
@@ -641,10 +793,12 @@ def main():
         dom = max(summ, key=lambda k: summ[k]['ms'])
         d = summ[dom]
         sec = d['ms'] * 1e-3
+        traffic, traffic_why = pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1, w['config'])
         common = {'kernel': dom, 'avg_launch_ms': round(d['ms'] / d['calls'], 4),
-                  'traffic': pmc_traffic(dom, 2 if dom in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1, w['config']),
-                  'traffic_source': 'committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes over this command (profiles/pmc_traffic_latest.json, '
-                                    'scripts/gpu_profile.sh; configs 2 and 3), not re-measured in this run',
+                  'traffic': traffic,
+                  'traffic_source': ('committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes over this command (profiles/pmc_traffic_latest.json, '
+                                     'scripts/gpu_profile.sh; configs 2 and 3) on kernel sources whose hashes match this build\'s; not re-measured in this run'
+                                     if traffic is not None else traffic_why),
                   'algorithmic_bytes_per_call': round(d['bytes'] / d['calls']), 'hip_kernel_ms_per_step': fam,
                   'hip_share_of_step': round(sum(v['ms'] for v in summ.values()) / timed_steps / (elapsed / args.steps * 1e3), 4),
                   'kernel_timing': 'HIP events on the launch stream, 3 eager steps of this process right after the timed region (all launches on one stream there)'
@@ -685,16 +839,17 @@ def main():
         if hbm_fams:
             hk = max(hbm_fams, key=lambda k: hbm_fams[k]['ms'])
             hv = hbm_fams[hk]
+            h_traffic, h_why = pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1, w['config'])
             roofline['hbm_dominant'] = {'kernel': hk, 'achieved': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                                         'unit': 'GB/s', 'frac': round(hv['bytes'] / (hv['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        'traffic': pmc_traffic(hk, 2 if hk in ('eas_bn_lif_bwd', 'eas_bn_silu_bwd') else 1, w['config']),
+                                        'traffic': h_traffic, **({'traffic_unavailable': h_why} if h_traffic is None else {}),
                                         'algorithmic_bytes_per_call': round(hv['bytes'] / hv['calls'])}
         metric = ('event-frames/sec (T=3) SYOLOX-S Gen1 304x240' if w['config'] == 2 else f'event-frames/sec, BASELINE config {w["config"]}')
         line = {'metric': metric, 'value': round(frames_total / elapsed, 2),
                 'unit': 'event-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (yolox.core.Trainer step; EMA off: exp.ema = False, the reference's ModelEMA update of trainer.py:120-122 is not in the step)",
+                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (yolox.core.Trainer step; EMA off: exp.ema = False -- the same step WITH the reference's ModelEMA update of trainer.py:120-122 is the side figure weight_average.ema_on_ms_per_step)",
                            'baseline_config': w['config'], 'global_batch': batch * world,
                            'events_per_sample': args.events if w['input'] == 'events' else None, 'parallelism': f'dp{world}',
                            'gradient_exchange': ((f'{trainer.exchange.nbuckets} flat bucket(s)' if trainer.exchange is not None else trainer.dp) if multi else None),
@@ -704,7 +859,7 @@ def main():
                            'launch_probe_ms_per_step': probe, 'host_enqueue_share_of_step': round(t_enq / t_tot, 3),
                            'h2d_per_step': (h2d.describe() if h2d is not None else None)},
                 'roofline': roofline}
-        line['final_loss'] = float(loss)
+        line['final_loss'] = float(loss.detach())
         line['launches_per_step'] = launches
         if eval_roofline is not None:
             line['roofline_eval'] = eval_roofline
@@ -712,7 +867,10 @@ def main():
             line['canvas_640'] = canvas640
         if eval_fps is not None:
             line['eval_forward_frames_per_s'] = dict(eval_fps, batch=batch, note='model.eval() forward + reset_net on the same batch, one GPU, HIP-graph replay (as EventEvaluator); fuse_model: after yolox.utils.fuse_model (eval_event.py --fuse)')
+        if ema_figure is not None:
+            line['weight_average'] = ema_figure
         if world == 1 and not args.no_cpu_baseline:
+            line['parity'] = parity_against_oracle(w, model, step.raw_inputs, dev)
             line['cpu_baseline'] = cpu_baseline(w, args.cpu_batch or (8 if w['config'] == 2 else 2), args.events)
         print(json.dumps(line), flush=True)
     if world > 1 or force_ddp:
@@ -756,7 +914,10 @@ def mfma_busy_measured():
     try:
         with open(os.path.join(ROOT, 'profiles', 'conv_sq_counters_latest.json')) as fh:
             c = json.load(fh)
-        rows = [v for k, v in c.items() if 'smallconv' not in k and v.get('mfma_busy_frac') is not None and v.get('total_us_under_profiler')]
+        recorded, now = (c.get('_meta') or {}).get('csrc_sha16') or {}, csrc_hashes()
+        if any(recorded.get(f) != now.get(f) for f in set(_CONV_SRC + FAMILY_SOURCES['eas_conv_wgrad'])):
+            return None                      # measured on other kernel sources than this build's: not quoted (scripts/pmc_conv_step.sh re-measures)
+        rows = [v for k, v in c.items() if not k.startswith('_') and 'smallconv' not in k and v.get('mfma_busy_frac') is not None and v.get('total_us_under_profiler')]
         return round(sum(v['mfma_busy_frac'] * v['total_us_under_profiler'] for v in rows) / sum(v['total_us_under_profiler'] for v in rows), 4)
     except (OSError, KeyError, ValueError, ZeroDivisionError, TypeError):
         return None

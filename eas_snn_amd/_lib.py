@@ -99,8 +99,14 @@ class EasPredDgradProblem(C.Structure):
                 ('gx', C.c_void_p), ('N', C.c_int), ('C', C.c_int), ('HW', C.c_int)]
 
 
+class EasAdamHyper(C.Structure):
+    """include/eas_hip.h EasAdamHyper"""
+    _fields_ = [('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('group_lr', C.c_double * 16), ('ema_updates', C.c_void_p),
+                ('ema_decay', C.c_double), ('ema_ramp', C.c_double)]
+
+
 # name -> (restype, argtypes) ; one line per prototype of include/eas_hip.h
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 PROTOTYPES = {
     'eas_abi_version': (C.c_int, []),
@@ -213,6 +219,8 @@ PROTOTYPES = {
     'eas_adam_chunk': (C.c_int, []),
     'eas_adam_step': (C.c_int, [_P, C.c_int, C.c_longlong, C.c_double, C.c_double, C.c_double, _P]),
     'eas_adam_advance_steps': (C.c_int, [_P, C.c_int, _P]),
+    'eas_adam_step_ex': (C.c_int, [_P, C.c_int, C.c_longlong, C.POINTER(EasAdamHyper), _P]),
+    'eas_adam_advance_steps_ex': (C.c_int, [_P, C.c_int, _P, _P]),
 }
 
 

@@ -65,8 +65,10 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
     def _use_batch_stats(self):
         return self.training or (self.running_mean is None and self.running_var is None)
 
-    def can_fuse(self, y_seq):
-        return bool(self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
+    def can_fuse(self, y_seq, node=None):
+        # (a forward hook on this module or on the neuron wants the module CALLED: the fused kernel pair would skip both)
+        watched = self._forward_hooks or self._forward_pre_hooks or (node is not None and (node._forward_hooks or node._forward_pre_hooks))
+        return bool(not watched and self.affine and self.step_mode == 'm' and ops.bn_lif_supported(y_seq, y_seq.shape[0])
                     and (self.momentum is not None or not self.training))
 
     def fused_with(self, node, y_seq, want_mean=False, residual=None, cat=None, planes=False):
@@ -75,7 +77,7 @@ class BatchNorm2d(nn.BatchNorm2d, base.StepModule):
         channel[, spike planes of the buffer]): the result is written into that channel range of the buffer and returned as
         a view; planes: the result is written as bf16 spike planes and the returned tensor is the ghost that carries them
         (eas_snn_amd.ops "SPIKE PLANES")."""
-        if not self.can_fuse(y_seq):
+        if not self.can_fuse(y_seq, node):
             if cat is not None:
                 raise RuntimeError('in-place concatenation needs the fused BN+LIF path (callers check network_blocks._fusable)')
             y_seq = y_seq.contiguous()

@@ -2,13 +2,18 @@
 
 Same signature and behaviour as the reference's ``launch``.  Differences that matter on MI355X:
 ``backend='nccl'`` is RCCL on PyTorch-ROCm; HSA_ENABLE_IPC_MODE_LEGACY=0 is exported to the workers (dmabuf IPC);
-the rendezvous address stays 127.0.0.1 (single node)."""
+the rendezvous address stays 127.0.0.1 (single node).
+
+With the RCCL backend a worker does not create its process group before ``main_func`` runs: it hands the rendezvous parameters to
+``yolox.utils.dist.defer_process_group`` and the group comes into being at the first use -- which for the Trainer is right after it has
+recorded its HIP graphs (a capture must never be open while ProcessGroupNCCL's watchdog thread polls events).  Rank
+and world size are known from the parameters all along.  ``EAS_LAZY_PG=0`` restores the reference's order (group first); ``all`` defers on
+every backend (the CPU tests walk the deferred order on gloo)."""
 import os
 import sys
 from datetime import timedelta
 
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import yolox.utils.dist as comm
@@ -50,11 +55,8 @@ def _distributed_worker(local_rank, main_func, world_size, num_gpus_per_machine,
         assert num_gpus_per_machine <= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
     global_rank = machine_rank * num_gpus_per_machine + local_rank
-    dist.init_process_group(backend=backend, init_method=dist_url, world_size=world_size, rank=global_rank, timeout=timeout)
-    assert comm._LOCAL_PROCESS_GROUP is None
-    for i in range(world_size // num_gpus_per_machine):
-        pg = dist.new_group(list(range(i * num_gpus_per_machine, (i + 1) * num_gpus_per_machine)))
-        if i == machine_rank:
-            comm._LOCAL_PROCESS_GROUP = pg
-    comm.synchronize()
+    comm.defer_process_group(backend, dist_url, world_size, global_rank, timeout, local_size=num_gpus_per_machine, local_rank=local_rank)
+    lazy = os.environ.get('EAS_LAZY_PG', '1')
+    if not (lazy == 'all' or (lazy == '1' and backend == 'nccl')):
+        comm.ensure_process_group()         # default group, the machine-local group, one barrier (launch.py:118-147 of the reference)
     main_func(*args)

@@ -14,6 +14,13 @@ What is different from the reference's loop, and why (MI355X):
   ``DistributedDataParallel`` (trainer.py:174-176) -- same averaged gradients, per-rank BatchNorm statistics like
   ``broadcast_buffers=False``; ``EAS_DP=ddp`` selects DistributedDataParallel (eager launches only: its hooks cannot be captured).
 * the learning rate lives in a device scalar per parameter group, so the schedule keeps working under graph replay.
+* the weight average (``ModelEMA.update`` after every step, trainer.py:120-121) is part of ``TrainStep`` and rides in the optimizer's
+  one launch (``FusedAdam.attach_ema``): ``ema = True`` -- the default of event_yolox_base.py:116 -- keeps graph replay.
+* order of capture and rendezvous: the graphs are recorded at the FIRST iteration, on that iteration's batch, with model / optimizer /
+  average state snapshotted and put back afterwards (``capture(restore=True)``: recording needs a few warm-up launches), and only then
+  is the process group created (``yolox.utils.ensure_process_group``; ``yolox.core.launch`` defers it) and rank 0's parameters
+  broadcast into place.  No HIP-graph capture is ever open while ProcessGroupNCCL's watchdog thread exists -- the thread that aborted
+  one run in fourteen with hipErrorCapturedEvent when captures followed the rendezvous.
 """
 import contextlib
 import os
@@ -25,8 +32,8 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 
 from eas_snn_amd import _lib, ops
 from eas_snn_amd.parallel import BucketedGradAllReduce
-from yolox.utils import (ModelEMA, adjust_status, all_reduce_norm, get_local_rank, get_model_info, get_rank, get_world_size,
-                         is_parallel, load_ckpt, save_checkpoint, setup_logger, synchronize)
+from yolox.utils import (ModelEMA, adjust_status, all_reduce_norm, ensure_process_group, get_local_rank, get_model_info, get_rank,
+                         get_world_size, is_parallel, load_ckpt, save_checkpoint, setup_logger, synchronize, wait_process_group_idle)
 
 
 def optimizer_capturable(optimizer):
@@ -42,6 +49,10 @@ def _reset_net(model):
     functional.reset_net(model)
 
 
+class _NoCapture(Exception):
+    """raised inside TrainStep.capture when recording is not safe; the step stays eager"""
+
+
 class TrainStep:
     """One training iteration.  ``inputs_fn() -> (inps, targets)`` produces the batch on the device (inside the captured region:
     e.g. the event histogram of raw events held in static buffers, or ``exp.preprocess`` of static input tensors).
@@ -53,8 +64,9 @@ class TrainStep:
     rest) so that the gradient buckets of the upper part are exchanged while the lower part's backward still runs.  Only used
     with an exchange (N > 1)."""
 
-    def __init__(self, model, optimizer, inputs_fn, exchange=None, net=None, reset=True, defer_wgrad=True, cut=()):
+    def __init__(self, model, optimizer, inputs_fn, exchange=None, net=None, reset=True, defer_wgrad=True, cut=(), ema=None):
         self.model, self.optimizer, self.inputs_fn = model, optimizer, inputs_fn
+        self.ema = ema                                           # yolox.utils.ModelEMA or None: updated right after the optimizer step
         self.net = model if net is None else net                 # DistributedDataParallel wrapper, if any
         self.exchange = exchange                                 # BucketedGradAllReduce or None
         self.reset = reset
@@ -134,6 +146,8 @@ class TrainStep:
         if self.exchange is not None:
             self.exchange.attach()
         self.optimizer.step()
+        if self.ema is not None:
+            self.ema.update(self.model)         # trainer.py:120-121 of the reference; a no-launch count when the optimizer's launch made it
         if self.reset:
             _reset_net(self.model)
 
@@ -180,29 +194,93 @@ class TrainStep:
             if torch.is_tensor(st_.get('step')):
                 st_['step'] = st_['step'].to(dev)
 
-    def capture(self, warm=3):
-        """record the iteration into HIP graph(s); returns a description of the launch form.  Not with DistributedDataParallel."""
+    def ema_capturable(self):
+        """a weight average can be part of a captured step only when the optimizer's launch makes it (device-side decay ramp)"""
+        return self.ema is None or getattr(self.ema, '_fused_in', None) is self.optimizer
+
+    # ---- state that the warm-up launches of a capture must not leave behind
+    def _snapshot(self):
+        mods = [self.model] + ([self.ema.ema] if self.ema is not None else [])
+        tensors = [t for m in mods for t in m.state_dict().values()]
+        snap = {'tensors': [(t, t.clone()) for t in tensors], 'opt': {}, 'ema_updates': None if self.ema is None else self.ema.updates}
+        for p, st_ in self.optimizer.state.items():
+            snap['opt'][p] = {k: v.clone() for k, v in st_.items() if torch.is_tensor(v)}
+        return snap
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        """in place: every address a recorded graph holds stays valid"""
+        for t, saved in snap['tensors']:
+            t.copy_(saved)
+        for p, st_ in self.optimizer.state.items():
+            before = snap['opt'].get(p)
+            for k, v in st_.items():
+                if not torch.is_tensor(v):
+                    continue
+                if before is not None and k in before:
+                    v.copy_(before[k])
+                else:
+                    v.zero_()                                   # created by the warm-up steps: Adam's initial moments and step count are zeros
+        if self.ema is not None:
+            self.ema.updates = snap['ema_updates']
+            fused = getattr(self.ema, '_fused_in', None)
+            if fused is not None and fused._eas_ema is not None:
+                fused._eas_ema['counter'].fill_(float(self.ema.updates))
+
+    def capture(self, warm=3, restore=False):
+        """record the iteration into HIP graph(s); returns a description of the launch form.  Not with DistributedDataParallel.
+
+        restore: model, optimizer and weight-average state are snapshotted first and put back (in place) at the end, so the ``warm``
+        eager launches and the closing replay leave no trace -- the form for recording BEFORE training starts (and before the process
+        group exists).  On a model without a device there is nothing to record: the warm-up / restore protocol runs and the step stays
+        eager (the CPU tests walk the N-rank order with it)."""
         if self.net is not self.model:
             raise RuntimeError('DistributedDataParallel iterations cannot be captured (reducer hooks); use the bucketed exchange')
-        self.make_capturable()
+        if not self.ema_capturable():
+            raise RuntimeError('a step with a weight average can only be captured when FusedAdam.attach_ema makes the average')
+        on_gpu = next(self.model.parameters()).is_cuda
+        snap = self._snapshot() if restore else None
+        if on_gpu:
+            self.make_capturable()
         for _ in range(warm):
             self.eager()
+        if not on_gpu:
+            if restore:
+                self._restore(snap)
+            return self.launch
         torch.cuda.synchronize()
-        # With a process group alive, its watchdog thread polls events of collectives in flight: nothing may be pending when a capture
-        # starts (synchronize), and the capture only polices the capturing thread's own API calls (thread_local) -- kernels launched
-        # on the capturing stream by the autograd thread are recorded either way.
-        mode = 'thread_local' if dist.is_initialized() else 'global'
+        # A process group that exists already (a caller that did not defer it): ProcessGroupNCCL's watchdog thread polls the events of
+        # collectives in flight and must hold none while a capture is open -- wait for exactly that condition (flight recorder), record with
+        # thread_local error mode (the capture polices only the capturing thread's own API calls; kernels launched on the capturing
+        # stream by the autograd thread are recorded either way).  Without the recorder the step stays eager rather than risk the abort.
+        live_group = dist.is_initialized()
+        mode = 'thread_local' if live_group else 'global'
 
         if getattr(self, '_capture_stream', None) is None:
             self._capture_stream = _lib.private_stream()      # never a pooled stream: ProcessGroupNCCL's own stream is one of those
 
         def graph(g, pool=None):
             torch.cuda.synchronize()
-            if dist.is_initialized():
-                # the watchdog retires finished collectives at its next poll (every 100 ms): give it that poll, so that it holds no event at
-                # all while a capture is open (one run in ten died with hipErrorCapturedEvent in the watchdog's event query otherwise)
-                time.sleep(0.3)
+            if live_group and not wait_process_group_idle():
+                raise _NoCapture()
             return torch.cuda.graph(g, pool=pool, stream=self._capture_stream, capture_error_mode=mode)
+        scope = self.optimizer.capture_scope() if hasattr(self.optimizer, 'capture_scope') else contextlib.nullcontext()
+        try:
+            with scope:
+                self._record(graph)
+        except _NoCapture:
+            self.graphs, self.launch = None, 'eager launches (a live process group without a flight recorder: nothing recorded)'
+            if restore:
+                self._restore(snap)
+            return self.launch
+        torch.cuda.synchronize()
+        self.replay()                                 # warm-up replay
+        if restore:
+            self._restore(snap)
+            torch.cuda.synchronize()
+        return self.launch
+
+    def _record(self, graph):
         if self.exchange is None:
             g = torch.cuda.CUDAGraph()
             with graph(g):
@@ -238,14 +316,11 @@ class TrainStep:
                 self._update()
             self.graphs = (g_a, g_b)
             self.launch = 'two hip-graph replays per step (fwd+bwd+pack | adam+reset) with the eager RCCL all-reduce between them'
-        torch.cuda.synchronize()
-        if hasattr(self.optimizer, 'sync_tables'):
-            self.optimizer.sync_tables()              # eas_snn_amd.optim.FusedAdam: the pointer table of the captured step (not copyable inside a capture)
-        self.replay()                                 # warm-up replay
-        return self.launch
 
     def replay(self):
         gs = self.graphs
+        if self.ema is not None:
+            self.ema.updates += 1                 # the host mirror of the device counter the recorded optimizer launch advances
         if len(gs) == 1:
             gs[0].replay()
         elif len(gs) == 2:
@@ -318,17 +393,35 @@ class Trainer:
                 self.net = DDP(model, device_ids=[self.local_rank] if self.device != 'cpu' else None, broadcast_buffers=False,
                                gradient_as_bucket_view=True)
             else:
-                self.exchange = BucketedGradAllReduce(model, split=DEFAULT_LOWER if self.dp == 'buckets' else ())
+                # (binds to the process group -- and broadcasts rank 0's parameters -- now if the group exists, else at join_ranks())
+                self.exchange = BucketedGradAllReduce(model, split=DEFAULT_LOWER if self.dp == 'buckets' else (), world=get_world_size())
         self.model = self.net
         return model
 
-    def step_fn(self, inputs_fn, reset=None):
+    def step_fn(self, inputs_fn, reset=None, ema=None):
         """the training iteration of this trainer as a ``TrainStep`` (what ``train_one_iter`` runs and ``bench.py`` measures)"""
         if reset is None:
             reset = self.exp.use_spike not in (False, 'False')
         cut = DEFAULT_CUT if (self.exchange is not None and self.exchange.nbuckets > 1) else ()
         return TrainStep(self.bare_model, self.optimizer, inputs_fn, exchange=self.exchange, net=self.net, reset=reset,
-                         defer_wgrad=os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1', cut=cut)
+                         defer_wgrad=os.environ.get('EAS_DEFER_WGRAD_REDUCE', '1') == '1', cut=cut, ema=ema)
+
+    def make_ema(self, decay=0.9998, updates=0):
+        """the weight average of the loop (trainer.py:169-171 of the reference); on the GPU its update becomes part of the optimizer's launch"""
+        ema = ModelEMA(self.bare_model, decay)
+        ema.updates = updates
+        if self.device != 'cpu' and hasattr(self.optimizer, 'attach_ema') and os.environ.get('EAS_FUSED_EMA', '1') == '1':
+            self.optimizer.attach_ema(ema, self.bare_model)
+        return ema
+
+    def join_ranks(self):
+        """create the (deferred) process group and take rank 0's parameter values -- after the graphs are recorded, before the first
+        training step.  A no-op on one rank or when the launcher created the group itself."""
+        ensure_process_group()
+        if self.exchange is not None and not self.exchange.bound and dist.is_initialized():
+            self.exchange.bind()
+            if self.use_model_ema and getattr(self, 'ema_model', None) is not None:
+                self.ema_model.ema.load_state_dict(self.bare_model.state_dict())     # the average starts from the broadcast values (in place)
 
     def before_train(self):
         self.setup()
@@ -336,12 +429,12 @@ class Trainer:
                                                      no_aug=True, cache_img=getattr(self.args, 'cache', None))
         self.max_iter = len(self.train_loader)
         self.lr_scheduler = self.exp.get_lr_scheduler(self.exp.basic_lr_per_img * self.args.batch_size, self.max_iter)
-        if self.use_model_ema:
-            self.ema_model = ModelEMA(self.bare_model, 0.9998)
-            self.ema_model.updates = self.max_iter * self.start_epoch
+        self.ema_model = self.make_ema(0.9998, self.max_iter * self.start_epoch) if self.use_model_ema else None
         # launch form of the iterations: HIP-graph replay on the GPU unless switched off (EAS_TRAIN_GRAPH=0) or DistributedDataParallel
+        # (or a weight average the optimizer's launch does not make: its decay would be a host number frozen into the graph)
         self.use_graph = (self.device != 'cpu' and self.net is self.bare_model and os.environ.get('EAS_TRAIN_GRAPH', '1') == '1'
-                          and optimizer_capturable(self.optimizer))
+                          and optimizer_capturable(self.optimizer)
+                          and (self.ema_model is None or getattr(self.ema_model, '_fused_in', None) is self.optimizer))
         self._static = None
         self._iters_done = 0
         # evaluation between epochs (trainer.py:178-180, 243-248 of the reference); an experiment without an evaluator trains only
@@ -419,23 +512,19 @@ class Trainer:
         if self._static is None:
             # static input buffers: every batch is copied into them, so an iteration captured once can be replayed on new data
             self._static = (inps.clone(), targets.clone())
-            self.step = self.step_fn(lambda: self.exp.preprocess(self._static[0], self._static[1], self.input_size))
+            self.step = self.step_fn(lambda: self.exp.preprocess(self._static[0], self._static[1], self.input_size), ema=self.ema_model)
             if self.use_graph:
                 for g in self.optimizer.param_groups:    # the schedule writes a device scalar the captured Adam reads
                     g['lr'] = torch.tensor(float(g['lr']), dtype=torch.float32, device=self.device)
+                # record on this first batch, leaving no trace (restore): the warm-up launches initialise allocator and optimizer state,
+                # the state is put back, and only then does the process group come into being (join_ranks)
+                self.step.capture(warm=2, restore=True)
+            self.join_ranks()
         else:
             self._static[0].copy_(inps)
             self._static[1].copy_(targets)
-        if self.use_graph and self.step.graphs is None and self._iters_done == 2:
-            # two eager iterations have initialised allocator and optimizer state.  Recording executes nothing; capture() ends with
-            # one replay, and that replay is this batch's training step
-            self.step.capture(warm=0)
-            loss = self.step.loss
-        else:
-            loss = self.step()
+        loss = self.step()                               # forward, backward, exchange, optimizer (+ weight average), reset_net
         self._iters_done += 1
-        if self.use_model_ema:
-            self.ema_model.update(self.bare_model)
         lr = self.lr_scheduler.update_lr(self.epoch * self.max_iter + self.iter + 1)
         self._set_lr(lr)
         if (self.iter + 1) % self.exp.print_interval == 0:

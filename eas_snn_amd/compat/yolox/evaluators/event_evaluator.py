@@ -8,7 +8,10 @@ reference's COCO-style ``data_list`` / image-wise dict shapes gathered to rank 0
 What is different, and why (MI355X): on the GPU the two timed phases of a batch are two HIP-graph replays (the eval forward + reset_net
 is ~350 launches whose enqueue time would otherwise bound a 6 ms forward; the post-processing is ``eas_postprocess``, one launch for
 the whole batch instead of per-image torchvision NMS).  The graphs are recorded on static input / output buffers per (model, batch
-shape) and dropped when a parameter or buffer of the model moved.
+shape) -- the full batch and the short last batch each keep theirs across evaluations -- and dropped when a parameter or buffer of the
+model moved.  With a live RCCL process group a capture waits until the group's watchdog thread holds no event
+(``yolox.utils.wait_process_group_idle``: a condition read from the flight recorder, not a delay); where that cannot be established
+the evaluator launches eagerly.
 
 mAP itself (COCO API) is outside the hot path: it is computed when ``pycocotools`` is importable, else the AP fields
 are ``None`` and the summary says so -- detections, timings and the loop are what this file provides."""
@@ -19,7 +22,7 @@ from collections import ChainMap, defaultdict
 
 import torch
 
-from yolox.utils import gather, get_rank, is_main_process, postprocess, synchronize, time_synchronized
+from yolox.utils import gather, get_rank, is_main_process, postprocess, synchronize, time_synchronized, wait_process_group_idle
 
 __all__ = ['EventEvaluator']
 
@@ -27,6 +30,10 @@ __all__ = ['EventEvaluator']
 def _reset_net(model):
     from spikingjelly.activation_based.functional import reset_net
     reset_net(model)
+
+
+class _NoGraph(Exception):
+    """recording is not safe right now (a live process group whose watchdog cannot be observed): the caller launches eagerly"""
 
 
 class _GraphedBatch:
@@ -46,15 +53,19 @@ class _GraphedBatch:
                     _reset_net(model)
                 ops.postprocess_device(out, num_classes, confthre, nmsthre)
             torch.cuda.synchronize()
-            if torch.distributed.is_initialized():
-                time.sleep(0.3)                          # the process group's watchdog retires finished collectives at its next poll: it must hold
-                                                         # no event while a capture is open (trainer.py TrainStep.capture)
+            live_group = torch.distributed.is_initialized()
+            # ProcessGroupNCCL's watchdog polls the events of collectives it has not retired yet; it must hold none while a capture is
+            # open (trainer.py TrainStep.capture).  Wait for that condition; if it cannot be observed, do not record.
+            if live_group and not wait_process_group_idle():
+                raise _NoGraph()
             self.g_fwd, self.g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            mode = 'thread_local' if torch.distributed.is_initialized() else 'global'
+            mode = 'thread_local' if live_group else 'global'
             with torch.cuda.graph(self.g_fwd, stream=side, capture_error_mode=mode):
                 self.out = model(self.static_in)
                 if snn_reset:
                     _reset_net(model)
+            if live_group and not wait_process_group_idle():
+                raise _NoGraph()
             with torch.cuda.graph(self.g_post, stream=side, capture_error_mode=mode):
                 self.rows, self.counts = ops.postprocess_device(self.out, num_classes, confthre, nmsthre)
         torch.cuda.current_stream().wait_stream(side)
@@ -101,7 +112,8 @@ class EventEvaluator:
         # 'False' in the reference -- resetting a network without neurons is a no-op, so that quirk is harmless and kept
         self.snn_reset = snn_reset
         self.use_graph = os.environ.get('EAS_EVAL_GRAPH', '1') == '1'
-        self._graphed = None
+        self._graphed = {}                  # signature -> _GraphedBatch (full batch, short last batch)
+        self.graphs_recorded = 0
         self.last_statistics = None
 
     # ------------------------------------------------------------------ the loop
@@ -134,9 +146,10 @@ class EventEvaluator:
                 imgs = imgs.to(dev, torch.float32)
                 # the last batch may be short: not timed, as in the reference (:191-193)
                 timed = cur_iter < n_batches - 1
-                batch = self._graph_for(model, imgs) if graph_ok else None
+                batch = self._graph_for(model, imgs) if (graph_ok and self.use_graph) else None
                 if timed:
-                    start = time.time()
+                    # the device is idle when the clock starts: the loader's event binning and the copy of the batch above are not "forward"
+                    start = time_synchronized()
                 if batch is not None:
                     outputs = batch.forward(imgs)
                 else:
@@ -175,10 +188,21 @@ class EventEvaluator:
         return eval_results
 
     def _graph_for(self, model, imgs):
-        g = self._graphed
-        if g is None or g.key != _GraphedBatch.signature(model, imgs):
-            self._graphed = g = None                    # free the old graphs' pool before recording new ones
-            g = self._graphed = _GraphedBatch(model, imgs, bool(self.snn_reset), self.num_classes, self.confthre, self.nmsthre)
+        """the recorded batch for this (model, parameter addresses, input shape); a loader whose last batch is short alternates between two
+        signatures in every evaluation -- both stay recorded"""
+        key = _GraphedBatch.signature(model, imgs)
+        g = self._graphed.get(key)
+        if g is None:
+            for k in [k for k in self._graphed if k[0] != key[0] or k[3] != key[3]]:
+                del self._graphed[k]                    # another model, or this one's tensors moved: free those graphs' pools first
+            if len(self._graphed) >= 4:
+                self._graphed.pop(next(iter(self._graphed)))
+            try:
+                g = self._graphed[key] = _GraphedBatch(model, imgs, bool(self.snn_reset), self.num_classes, self.confthre, self.nmsthre)
+                self.graphs_recorded += 1
+            except _NoGraph:
+                self.use_graph = False                  # eager launches from here on (see the module docstring)
+                return None
         return g
 
     # ------------------------------------------------------------------ detections -> COCO-style records (:265-323)

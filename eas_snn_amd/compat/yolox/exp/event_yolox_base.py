@@ -172,9 +172,9 @@ class EventExp(BaseExp):
 
     def get_data_loader(self, batch_size, is_distributed, no_aug=False, cache_img=None):
         from eas_snn_amd.data import SyntheticEventLoader
-        import torch.distributed as dist
+        from yolox.utils import get_world_size      # (answers from the launcher's parameters while the process group is still deferred)
         if is_distributed:
-            batch_size = batch_size // dist.get_world_size()
+            batch_size = batch_size // get_world_size()
         return SyntheticEventLoader(self, batch_size)
 
     def get_eval_dataset(self, **kwargs):
@@ -185,12 +185,12 @@ class EventExp(BaseExp):
         """reference: event_yolox_base.py:483-507 -- twice the training batch, split over the ranks, samples rank, rank + world, ...
         in order (DistributedSampler(shuffle=False)); the streams are synthetic and binned on the GPU"""
         from eas_snn_amd.data import SyntheticEvalLoader
-        import torch.distributed as dist
+        from yolox.utils import get_rank, get_world_size
         valdataset = self.get_eval_dataset(**kwargs)
         batch_size *= 2
         rank, world = 0, 1
         if is_distributed:
-            rank, world = dist.get_rank(), dist.get_world_size()
+            rank, world = get_rank(), get_world_size()
             batch_size = batch_size // world
         n = len(valdataset)
         per_rank = (n + world - 1) // world                 # DistributedSampler pads with the first samples so every rank gets the same count

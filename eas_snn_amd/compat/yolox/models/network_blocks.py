@@ -47,6 +47,7 @@ def _pool_ksize(m):
 def _fusable(block, x):
     """a converted BaseConv (1x1 or 3x3, stride 1) whose BN+LIF runs on the fused HIP kernels for a 5-D CUDA spike tensor"""
     return (isinstance(block, BaseConv) and block.spiking() and x.dim() == 5 and x.is_cuda and not block.emit_rate
+            and not (block.bn._forward_hooks or block.bn._forward_pre_hooks or block.act._forward_hooks or block.act._forward_pre_hooks)
             and block.bn.affine and block.bn.step_mode == 'm' and (block.bn.momentum is not None or not block.bn.training)
             and (x.shape[-1] * x.shape[-2]) % 4 == 0 and x.shape[0] <= 8 and _stride1(block.conv))
 
@@ -114,6 +115,8 @@ class BaseConv(nn.Module):
         folded that into the convolution -- the convolution's bias; None: not such a block (the fused eval kernel does not apply)"""
         if not isinstance(self.act, nn.SiLU) or type(self.conv) is not nn.Conv2d:
             return None
+        if self.act._forward_hooks or self.act._forward_pre_hooks:
+            return None                 # somebody watches the activation module: it has to be called (the fused kernel would skip it)
         bn = getattr(self, 'bn', None)
         if bn is None:
             return self.conv.bias

@@ -2,8 +2,10 @@
 updates)``, ``.ema``, ``.updates``, ``.decay(n)``, ``.update(model)``; ``is_parallel``).
 
 The average covers every floating-point entry of the state dict (parameters and BatchNorm running statistics); integer
-entries (``num_batches_tracked``) keep the value they were copied with.  The update is two multi-tensor launches for the
-whole model instead of two launches per tensor."""
+entries (``num_batches_tracked``) keep the value they were copied with.  The update rounds like the reference's three tensor
+operators per entry (``v *= d``; ``(1 - d) * m``; ``v += ...``, ema.py:57-60) but as multi-tensor launches for the whole model;
+on the GPU ``eas_snn_amd.optim.FusedAdam.attach_ema`` folds it into the optimizer's one launch (csrc/adam.hip), after which
+``update`` only counts: the decay ramp then lives in a device counter and the update survives HIP-graph replay."""
 import copy
 import math
 
@@ -25,7 +27,9 @@ def _bare(model):
 class ModelEMA:
     def __init__(self, model, decay=0.9999, updates=0):
         self.nominal_decay = float(decay)
+        self.ramp = _RAMP
         self.updates = updates
+        self._fused_in = None           # the optimizer whose step makes this update (FusedAdam.attach_ema)
         self.ema = copy.deepcopy(_bare(model))
         self.ema.eval()
         self.ema.requires_grad_(False)
@@ -37,6 +41,8 @@ class ModelEMA:
     @torch.no_grad()
     def update(self, model):
         self.updates += 1
+        if self._fused_in is not None:
+            return                      # made by the optimizer step that has just run (one launch for Adam + average)
         keep = self.decay(self.updates)
         live = _bare(model).state_dict()
         avg, cur = [], []
@@ -46,4 +52,4 @@ class ModelEMA:
                 cur.append(live[name].detach().to(tensor.dtype))
         if avg:
             torch._foreach_mul_(avg, keep)
-            torch._foreach_add_(avg, cur, alpha=1.0 - keep)
+            torch._foreach_add_(avg, torch._foreach_mul(cur, 1.0 - keep))

@@ -61,7 +61,7 @@ int64_t eas_kernel_trace_dump(char* buf, int64_t cap) {
 // kernel launches the library has issued since it was loaded (bench.py: launches per step)
 int64_t eas_launch_counter(void) { return (int64_t)eas_launch_count; }
 
-int eas_abi_version(void) { return 8; }   // 8: eas_conv_dgrad_small(_supported), eas_pred_dgrad_group, eas_det_decode_eval, eas_adam_step / eas_adam_advance_steps; 7: eas_launch_counter; grouped (multi-problem) launches: eas_conv_fwd_group(_plan), eas_bn_silu_fwd_group / _bwd_group, eas_conv_wgrad_group_partial(_plan), eas_channel_sum_group; 6: eas_smallconv_fwd / eas_smallconv_bwd_weight take x_tm (input read as collated micro-slices, time-major newest first), eas_conv_bn_act_eval; 5: eas_conv_bn_lif_eval (fused eval step), kernel-instance trace, eas_spike_planes_from_f32 takes the tag-violation flag (and eas_conv_fwd / _stats really write theirs); 4: sampler convolutions take weights arranged by eas_smallconv_pack_weights; eas_arsnn_fused_step_fwd, eas_smallconv_bwd_input_dual; 3: eas_conv_fwd_stats, EasBnPending.pitch; 2: eas_bn_lif_fwd_ex gained spikes_u8; eas_conv_fwd_u8 / eas_conv_wgrad_u8, *_patan, eas_stacked_hist_event_sum
+int eas_abi_version(void) { return 9; }   // 9: eas_adam_step_ex / eas_adam_advance_steps_ex (weight average in the optimizer launch, group learning rates as arguments; table entries 96 bytes); 8: eas_conv_dgrad_small(_supported), eas_pred_dgrad_group, eas_det_decode_eval, eas_adam_step / eas_adam_advance_steps; 7: eas_launch_counter; grouped (multi-problem) launches: eas_conv_fwd_group(_plan), eas_bn_silu_fwd_group / _bwd_group, eas_conv_wgrad_group_partial(_plan), eas_channel_sum_group; 6: eas_smallconv_fwd / eas_smallconv_bwd_weight take x_tm (input read as collated micro-slices, time-major newest first), eas_conv_bn_act_eval; 5: eas_conv_bn_lif_eval (fused eval step), kernel-instance trace, eas_spike_planes_from_f32 takes the tag-violation flag (and eas_conv_fwd / _stats really write theirs); 4: sampler convolutions take weights arranged by eas_smallconv_pack_weights; eas_arsnn_fused_step_fwd, eas_smallconv_bwd_input_dual; 3: eas_conv_fwd_stats, EasBnPending.pitch; 2: eas_bn_lif_fwd_ex gained spikes_u8; eas_conv_fwd_u8 / eas_conv_wgrad_u8, *_patan, eas_stacked_hist_event_sum
 
 const char* eas_status_string(int status) {
     switch (status) {

@@ -814,6 +814,12 @@ def fused_eval_ok(x_seq, conv, layers):
         cout = c.out_channels if c is not None else 0
     if c is None or not all(_eval_neuron_ok(bn, node) for bn, node in layers):
         return False
+    # a forward (pre-)hook on anything the fused kernel stands in for -- the convolution's SeqToANNContainer, the BatchNorm, the neuron --
+    # would silently stop firing (the modules are not called): such a block takes the module-by-module path
+    watched = [m for cv in (conv if isinstance(conv, tuple) else (conv,)) if isinstance(cv, torch.nn.Module) for m in (cv,)]
+    watched += [m for pair in layers for m in pair]
+    if any(m._forward_hooks or m._forward_pre_hooks for m in watched):
+        return False
     if any(bn.num_features % 8 for bn, _ in layers) or len(layers) > 2 or sum(bn.num_features for bn, _ in layers) != cout:
         return False
     T, N, Cin, H, W = x_seq.shape

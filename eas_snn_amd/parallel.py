@@ -10,7 +10,9 @@ still runs -- the overlap DDP gets from its reducer hooks, without the per-param
 share 0.83 of a 32 ms step with DDP, 0.60 without) and without anything that cannot sit between HIP-graph replays.
 xGMI is point to point (7 links x ~153 GB/s per GPU): a ring all-reduce of SYOLOX-S's 35.8 MB is ~0.6 ms on eight GPUs, SYOLOX-M's
 101 MB ~1.2-1.7 ms; few large collectives are the right shape for it.
-Initial parameter values are broadcast from rank 0 exactly as DDP's constructor does.
+Initial parameter values are broadcast from rank 0 exactly as DDP's constructor does -- at construction when the process group exists,
+else at ``bind()``: the object can be built, run (without exchange) and captured into HIP graphs BEFORE ``init_process_group``, so that no
+capture is ever open while ProcessGroupNCCL's watchdog thread exists; the broadcast writes the parameters in place afterwards.
 """
 import torch
 import torch.distributed as dist
@@ -25,8 +27,9 @@ class BucketedGradAllReduce:
     replays, ``attach`` at the start of a captured optimizer step.  ``attach`` launches nothing: it makes every ``p.grad`` a view
     of the reduced buffer, which the optimizer reads in place."""
 
-    def __init__(self, module, split=(), process_group=None, broadcast_parameters=True):
+    def __init__(self, module, split=(), process_group=None, broadcast_parameters=True, world=None):
         self.group = process_group
+        self._broadcast = bool(broadcast_parameters)
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         lower = tuple(s + '.' for s in split)
         is_low = [bool(lower) and n.startswith(lower) for n, _ in named]
@@ -34,14 +37,26 @@ class BucketedGradAllReduce:
         self.buckets = [g for g in groups if g]
         self.params = [p for g in self.buckets for p in g]
         self.sizes = [[p.numel() for p in g] for g in self.buckets]
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.world = int(world) if world else 1         # until bind(): the size the launcher announced (reduce() is a no-op without a group)
         self.flat = [None] * len(self.buckets)
         self.views = [None] * len(self.buckets)
-        if broadcast_parameters and dist.is_initialized():
+        self.bound = False
+        if dist.is_initialized():
+            self.bind(process_group)
+
+    def bind(self, process_group=None):
+        """attach to the (now existing) process group: world size, and rank 0's parameter values into every rank's parameters, in place
+        (the addresses recorded into HIP graphs stay valid)"""
+        if self.bound or not dist.is_initialized():
+            return
+        self.group = process_group if process_group is not None else self.group
+        self.world = dist.get_world_size(self.group)
+        self.bound = True
+        if self._broadcast:
             with torch.no_grad():
                 for g, sz in zip(self.buckets, self.sizes):
                     flat = torch.cat([p.detach().reshape(-1) for p in g])
-                    dist.broadcast(flat, src=0, group=process_group)
+                    dist.broadcast(flat, src=0, group=self.group)
                     torch._foreach_copy_([p.detach() for p in g], [c.view_as(p) for c, p in zip(flat.split(sz), g)])
 
     @property
@@ -79,7 +94,7 @@ class BucketedGradAllReduce:
             for i in range(self.nbuckets):
                 self.reduce(i)
             return
-        if dist.is_initialized():
+        if self.bound:
             dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
                 self.flat[b].mul_(1.0 / self.world)
@@ -92,7 +107,7 @@ class BucketedGradAllReduce:
 
     def sync(self):
         """average the gradients over the ranks (call between backward and the optimizer step)"""
-        if self.world == 1 and not dist.is_initialized():
+        if self.world == 1 and not self.bound:
             return
         self.pack()
         self.reduce()
@@ -102,5 +117,5 @@ class BucketedGradAllReduce:
 class FlatGradAllReduce(BucketedGradAllReduce):
     """one bucket: every gradient in ONE flat buffer, ONE all-reduce per step"""
 
-    def __init__(self, module, process_group=None, broadcast_parameters=True):
-        super().__init__(module, (), process_group, broadcast_parameters)
+    def __init__(self, module, process_group=None, broadcast_parameters=True, world=None):
+        super().__init__(module, (), process_group, broadcast_parameters, world)

@@ -729,15 +729,39 @@ int eas_pred_dgrad_group(const EasPredDgradProblem* problems, int n, eas_stream_
  * ABI 8.  Adam step of every parameter group in one launch (csrc/adam.hip): torch.optim.Adam as the reference builds it
  * (yolox/exp/event_yolox_base.py:352-414: BN weights | convolution weights with weight decay | biases | neuron parameters | sampler parameters),
  * update rule and float / double promotions of torch's fused kernel (ADAM_MODE::ORIGINAL, no amsgrad, no grad scaler).
- * table: DEVICE array of ntensors entries of eas_adam_table_entry_bytes() = 80 bytes:
+ * table: DEVICE array of ntensors entries of eas_adam_table_entry_bytes() = 96 bytes (ABI 9; 80 in ABI 8):
  *   { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* step (fp32 device scalar); const float* lr_ptr (device scalar or NULL);
- *     double lr (used when lr_ptr is NULL); double weight_decay; int64 numel; int64 first_block }
+ *     float* ema (ABI 9: the tensor's twin in the averaged model, or NULL); double lr (used when lr_ptr is NULL and group < 0); double weight_decay;
+ *     int64 numel; int64 first_block; int32 group (ABI 9: >= 0 selects EasAdamHyper.group_lr[group]; -1: lr above); int32 pad }
  * first_block = prefix sum of ceil(numel / eas_adam_chunk()) over the entries, total_blocks = the sum.  eas_adam_step takes step number
- * *step + 1 on every tensor WITHOUT writing the counters; eas_adam_advance_steps (called right after it) adds 1 to each. */
+ * *step + 1 on every tensor WITHOUT writing the counters; eas_adam_advance_steps (called right after it) adds 1 to each.
+ * An entry with grad == NULL takes no Adam step (exp_avg / exp_avg_sq / step unused): a tensor only the average follows. */
 int eas_adam_table_entry_bytes(void);
 int eas_adam_chunk(void);
 int eas_adam_step(const void* table, int ntensors, long long total_blocks, double beta1, double beta2, double eps, eas_stream_t stream);
 int eas_adam_advance_steps(const void* table, int ntensors, eas_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ABI 9.  The weight average of the training loop inside the optimizer launch, and learning rates that change every step without a new table.
+ * Replaces ModelEMA.update (yolox/utils/ema.py:44-60), which the reference calls right after optimizer.step() every iteration
+ * (yolox/core/trainer.py:120-121; ema = True is the default of yolox/exp/event_yolox_base.py:116):
+ *     d = ema_decay * (1 - exp(-n / ema_ramp))  (double; n = *ema_updates + 1, the update being taken; the reference: 0.9998, 2000)
+ *     ema = ema * (float)d;  ema = ema + (float)(1 - d) * param          (param = the value AFTER this step's Adam update)
+ * for every entry whose `ema` pointer is set -- parameters in the same pass that writes them, BatchNorm running statistics (float buffers
+ * of the state dict) as entries with grad == NULL.  ema_updates is a DEVICE double that eas_adam_advance_steps_ex increments after the step, so
+ * a step captured into a HIP graph keeps the reference's ramp going; ema_updates == NULL: no entry may carry an `ema` pointer.
+ * group_lr: learning rates of up to EAS_ADAM_MAX_GROUPS parameter groups as launch arguments (an eager trainer whose scheduler hands out a new
+ * python float every iteration re-uses its table; a captured trainer uses lr_ptr device scalars instead). */
+#define EAS_ADAM_MAX_GROUPS 16
+typedef struct {
+    double beta1, beta2, eps;
+    double group_lr[EAS_ADAM_MAX_GROUPS];
+    const double* ema_updates;
+    double ema_decay;
+    double ema_ramp;
+} EasAdamHyper;
+int eas_adam_step_ex(const void* table, int ntensors, long long total_blocks, const EasAdamHyper* hyper, eas_stream_t stream);
+int eas_adam_advance_steps_ex(const void* table, int ntensors, double* ema_updates, eas_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/ab_$VAR
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export EAS_BENCH_GRAPH=0
+# (side figures off: the 640x640 one runs in a child process the profiler would follow, writing a second kernel_stats.csv)
+export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_640=1 EAS_BENCH_NO_EMA=1
 for v in $A $B; do
   export $VAR=$v
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s_$v -- python3 $ROOT/bench.py --config $CFG --steps 5 --warmup 3 --no-cpu-baseline > $OUT/log_$v.txt 2>&1

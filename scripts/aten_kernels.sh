@@ -5,7 +5,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/aten
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_EVAL=1
+# (side figures off: the 640x640 one runs in a child process the profiler would follow, writing a second kernel_stats.csv)
+export EAS_BENCH_GRAPH=0 EAS_BENCH_NO_EVAL=1 EAS_BENCH_NO_640=1 EAS_BENCH_NO_EMA=1
 STEPS=${1:-6}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s -- python3 $ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline > $OUT/log.txt 2>&1
 find $OUT/s -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;

@@ -66,11 +66,12 @@ for fused in MODES:
     for (tag, name), items in timer.tagged.items():
         PER_LAYER.setdefault(tag, {})[fused] = PER_LAYER.setdefault(tag, {}).get(fused, 0.0) + sum(a.elapsed_time(b) for a, b, *_ in items)
 if os.environ.get('EAS_DEV_EVAL_LAYERS'):
-    print('per layer (ms): fused / two-kernel')
-    for tag, d in sorted(PER_LAYER.items(), key=lambda kv: -(kv[1].get(True, 0) - kv[1].get(False, 0))):
-        if tag and (d.get(True) or d.get(False)):
+    # the modes of the loop above are the keys: 'auto' (the default selection), 'all' (every eligible layer fused), False (two kernels)
+    print('per layer (ms): all fused / two-kernel   (auto)')
+    for tag, d in sorted(PER_LAYER.items(), key=lambda kv: -(kv[1].get('all', 0) - kv[1].get(False, 0))):
+        if tag and (d.get('all') or d.get(False)):
             m_ = model.get_submodule(tag)
             c_ = getattr(m_, 'conv', None)
             c_ = c_[0] if isinstance(c_, torch.nn.Sequential) else c_
             desc = f'{c_.in_channels}->{c_.out_channels} k{c_.kernel_size[0]} s{c_.stride[0]}' if isinstance(c_, torch.nn.Conv2d) else ''
-            print(f'  {d.get(True, 0):.3f}  {d.get(False, 0):.3f}   {tag}  {desc}')
+            print(f"  {d.get('all', 0):.3f}  {d.get(False, 0):.3f}  ({d.get('auto', 0):.3f})   {tag}  {desc}")

@@ -66,8 +66,12 @@ def main():
             e['lds_bank_conflict_share'] = round(e.get('SQ_LDS_BANK_CONFLICT', 0.0) / e['SQ_LDS_IDX_ACTIVE'], 4)
         out[k] = e
     order = sorted(out, key=lambda k: -(out[k]['total_us_under_profiler'] or 0))
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'eas_snn_amd', 'csrc')
+    meta = {'csrc_sha16': {f: hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest()[:16] for f in sorted(os.listdir(d)) if f.endswith(('.hip', '.h'))},
+            'note': 'sha256[:16] of every file under eas_snn_amd/csrc at the time of the counter passes (bench.py quotes mfma_busy_measured only while they match)'}
     with open(out_path, 'w') as fh:
-        json.dump({k: out[k] for k in order}, fh, indent=1)
+        json.dump(dict({k: out[k] for k in order}, _meta=meta), fh, indent=1)
     for k in order:
         e = out[k]
         print(f"{k[:64]:64s} n={e['launches']:3d} {e['total_us_under_profiler'] or 0:9.1f} us  mfma_busy {e.get('mfma_busy_frac', float('nan')):.3f}  "

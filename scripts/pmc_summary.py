@@ -86,6 +86,13 @@ def calibrate(d, out_json):
         json.dump(out, fh, indent=1, sort_keys=True)
 
 
+def csrc_hashes():
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'eas_snn_amd', 'csrc')
+    return {f: hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest()[:16]
+            for f in sorted(os.listdir(d)) if f.endswith(('.hip', '.h'))}
+
+
 def main():
     if sys.argv[1] == '--calibrate':
         return calibrate(sys.argv[2], sys.argv[3])
@@ -106,9 +113,13 @@ def main():
                   'note': ('FETCH_SIZE KiB x %.3f (%s) + WRITE_SIZE KiB' %
                            (factor, 'measured for this load width by scripts/micro/fetch_calib' if cls in cal else
                             'gfx950 wide-read correction of MI355X_MICROARCH.md; this width not calibrated in this run'))}
+    # what the kernels were built from: bench.py only quotes these figures while the sources of the family it quotes them for are unchanged
+    out['_meta'] = {'csrc_sha16': csrc_hashes(), 'note': 'sha256[:16] of every file under eas_snn_amd/csrc at the time of the PMC passes'}
     with open(sys.argv[3], 'w') as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     for k, v in out.items():
+        if k.startswith('_'):
+            continue
         print(f"{k:40s} n={v['launches']:5d} fetch {v['fetch_bytes_per_launch'] / 1e6:9.3f} MB write {v['write_bytes_per_launch'] / 1e6:9.3f} MB")
 
 

@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(handle, n), f'{n} declared in include/eas_hip.h but not exported'
     assert sorted(eas_snn_amd._lib.PROTOTYPES) == names           # ctypes table covers exactly the header
     lib = eas_snn_amd.hip_library()
-    assert lib.eas_abi_version() == eas_snn_amd._lib.ABI_VERSION == 8
+    assert lib.eas_abi_version() == eas_snn_amd._lib.ABI_VERSION == 9
     assert lib.eas_status_string(-1).decode().startswith('invalid argument')
     assert lib.eas_bn_workspace_doubles(32) > 0 and lib.eas_reduce_workspace_floats(1 << 20) > 0
 
@@ -144,14 +144,21 @@ def _worker_main(tag, out_dir):
     import torch.distributed as dist
     import yolox.utils as U
     from yolox.utils.allreduce_norm import all_reduce_norm
+    lazy = os.environ.get('EAS_LAZY_PG') == 'all'
+    assert dist.is_initialized() == (not lazy)          # deferred launch: the first use of the default group below creates it
     rank, world = U.get_rank(), U.get_world_size()
-    assert world == 2 and U.get_local_rank() == rank
+    assert world == 2 and U.get_local_rank() == rank and U.get_local_size() == 2
+    if lazy and tag == 'ddp_first':
+        # what tools/eval_event.py does right after launch: a DistributedDataParallel constructor reaches for the default group
+        torch.nn.parallel.DistributedDataParallel(torch.nn.Linear(3, 1, bias=False), broadcast_buffers=False)
+        assert dist.is_initialized()
     torch.manual_seed(rank)
     net = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 1), torch.nn.BatchNorm2d(4))
     with torch.no_grad():
         net[1].running_mean.fill_(float(rank + 1))
         net[1].weight.fill_(float(10 * (rank + 1)))
     all_reduce_norm(net)
+    assert dist.is_initialized() and U.get_rank() == rank and U.get_local_rank() == rank
     assert torch.allclose(net[1].running_mean, torch.full((4,), 1.5)) and torch.allclose(net[1].weight, torch.full((4,), 15.0))
     # weak-scaling bookkeeping used by bench.py: value = all ranks' units / max-over-ranks time
     el = torch.tensor([1.0 + rank], dtype=torch.float64)
@@ -184,22 +191,25 @@ def _worker_main(tag, out_dir):
     open(os.path.join(out_dir, f'ok_{tag}_{rank}'), 'w').write('ok')
 
 
-def test_launch_two_ranks_gloo(tmp_path):
-    """yolox.core.launch with world_size 2 on the gloo backend (the RCCL path differs only in the backend string)."""
+@pytest.mark.parametrize('lazy,tag', [('0', 't'), ('all', 't'), ('all', 'ddp_first')])
+def test_launch_two_ranks_gloo(tmp_path, lazy, tag):
+    """yolox.core.launch with world_size 2 on the gloo backend (the RCCL path differs only in the backend string).  lazy: the launcher
+    defers the process group (its default on RCCL): rank / world size answer from the rendezvous parameters, and the first thing that
+    reaches for the default group -- a collective, or a DistributedDataParallel constructor -- creates it."""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import eas_snn_amd\n"
         "from yolox.core import launch\n"
         "from test_cpu_host import _worker_main\n"
         "if __name__ == '__main__':\n"
-        "    launch(_worker_main, 2, 1, 0, backend='gloo', dist_url='auto', args=('t', %r))\n"
-    ) % (ROOT, os.path.join(ROOT, 'tests'), str(tmp_path))
+        "    launch(_worker_main, 2, 1, 0, backend='gloo', dist_url='auto', args=(%r, %r))\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), tag, str(tmp_path))
     script = tmp_path / 'run_launch.py'
     script.write_text(code)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', EAS_LAZY_PG=lazy)
     r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert (tmp_path / 'ok_t_0').exists() and (tmp_path / 'ok_t_1').exists()
+    assert (tmp_path / f'ok_{tag}_0').exists() and (tmp_path / f'ok_{tag}_1').exists()
 
 
 def test_model_ema_and_exp_lookup(tmp_path):
@@ -296,6 +306,10 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['spawned_by_bench'] and rec['gradient_exchange'] == '2 buckets'
     assert rec['config']['config'] == 2
+    # the order of the GPU path at N > 1: record with restore, THEN init_process_group, bind, steps -- and the first three losses equal
+    # those of the group-first order of earlier rounds (bench.py selftest_cpu compares them on every rank)
+    assert rec['order'].startswith('record (restore) -> init_process_group') and rec['same_losses_as_group_first_order'] is True
+    assert len(rec['first_losses']) == 3
 
 
 def test_bench_selftest_takes_the_other_baseline_configs():
@@ -433,9 +447,8 @@ class _ToyExp:
         return torch.optim.Adam(self.model.parameters(), lr=self.basic_lr_per_img * batch_size)
 
     def get_data_loader(self, batch_size, is_distributed, no_aug=False, cache_img=None):
-        import torch.distributed as dist
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        g = torch.Generator().manual_seed(100 + rank)
+        from yolox.utils import get_rank           # (answers from the launcher's parameters while the process group is still deferred)
+        g = torch.Generator().manual_seed(100 + get_rank())
         return [(torch.randn(4, 6, generator=g), torch.randn(4, 3, generator=g)) for _ in range(3)]
 
     def get_lr_scheduler(self, lr, iters_per_epoch):
@@ -452,10 +465,22 @@ def _trainer_worker(tag, out_dir):
     import types
     import torch.distributed as dist
     from yolox.core import Trainer
-    rank, world = dist.get_rank(), dist.get_world_size()
+    from yolox.utils import dist as comm
+    from yolox.utils import get_local_rank, get_rank, get_world_size
+    lazy = os.environ.get('EAS_LAZY_PG') == 'all'
+    # deferred launch: no process group yet, but rank / world size are known from the launcher's parameters
+    assert comm.process_group_deferred() == lazy and dist.is_initialized() == (not lazy)
+    rank, world = get_rank(), get_world_size()
+    assert world == 2 and rank in (0, 1) and get_local_rank() == rank
     exp = _ToyExp(out_dir)
     tr = Trainer(exp, types.SimpleNamespace(batch_size=8, fp16=False, experiment_name=f'toy_{tag}', ckpt=None, resume=False))
+    seen = []
+    join = tr.join_ranks
+    tr.join_ranks = lambda: (seen.append((dist.is_initialized(), tr.step is not None, tr.exchange.bound)), join())
     tr.train()
+    # the group comes into being inside join_ranks -- after the step object exists (on the GPU: after its graphs are recorded) -- and the
+    # exchange binds to it there
+    assert seen == [(not lazy, True, not lazy)] and dist.is_initialized() and tr.exchange.bound and tr.exchange.world == 2
     assert tr.exchange is not None and tr.exchange.nbuckets == 2 and tr.step.cut == ('backbone.backbone',)
     assert tr.step.graphs is None and len(tr.log) == 3                      # CPU: eager launches; one log row per iteration
     assert tr.bare_model.backbone.backbone[1].resets == 3 and tr.ema_model.updates == 3
@@ -505,9 +530,12 @@ def _trainer_worker(tag, out_dir):
     open(os.path.join(out_dir, f'ok_{tag}_{rank}'), 'w').write('ok')
 
 
-def test_trainer_runs_two_ranks_on_gloo(tmp_path):
+@pytest.mark.parametrize('lazy', ['0', 'all'])
+def test_trainer_runs_two_ranks_on_gloo(tmp_path, lazy):
     """The drop-in Trainer at world size 2 (gloo): its TrainStep -- the object bench.py measures -- with the bucketed exchange and the
-    backward pass split at the backbone, against a single-process restatement (plain backward, gradients averaged by hand)."""
+    backward pass split at the backbone, against a single-process restatement (plain backward, gradients averaged by hand).  Both launch
+    orders: the reference's (process group first) and the deferred one the RCCL backend uses (``yolox.core.launch`` hands the rendezvous
+    to ``defer_process_group``; the Trainer creates the group in ``join_ranks``, after its step is built / recorded) -- same result."""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import eas_snn_amd\n"
@@ -518,7 +546,7 @@ def test_trainer_runs_two_ranks_on_gloo(tmp_path):
     ) % (ROOT, os.path.join(ROOT, 'tests'), str(tmp_path))
     script = tmp_path / 'run_trainer.py'
     script.write_text(code)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', EAS_LAZY_PG=lazy)
     r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     assert (tmp_path / 'ok_t_0').exists() and (tmp_path / 'ok_t_1').exists()

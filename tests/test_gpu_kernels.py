@@ -1363,6 +1363,152 @@ def test_adam_step_of_all_groups_in_one_launch_matches_torch_fused_adam(dev, cap
 
 
 @pytest.mark.gpu
+def test_fused_adam_capture_is_opt_in_and_a_recorded_step_replays_like_torch(dev):
+    """a HIP-graph capture of FusedAdam.step() records the own kernel only inside ``capture_scope()`` (which fills the pointer table
+    when it closes); a capture nobody announced records torch's implementation instead of launches against a table that is never filled.
+    Both recorded forms are replayed five times against torch.optim.Adam(fused=True, capturable=True) stepping eagerly on the same gradients."""
+    from eas_snn_amd import ops
+    from eas_snn_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64,), (96, 32, 3, 3), (4097,), (3,), (1,)]
+    base = [torch.randn(s_, generator=g) for s_ in shapes]
+
+    def build(cls):
+        ps = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+        opt = cls(ps[:2], lr=1e-3, amsgrad=False, capturable=True) if cls is FusedAdam else cls(ps[:2], lr=1e-3, amsgrad=False, fused=True, capturable=True)
+        opt.add_param_group({'params': ps[2:], 'weight_decay': 5e-4})
+        for gr_ in opt.param_groups:
+            gr_['lr'] = torch.tensor(float(gr_['lr']), dtype=torch.float32, device=dev)
+        return ps, opt
+    for armed in (True, False):
+        pa, oa = build(FusedAdam)
+        pb, ob = build(torch.optim.Adam)
+        grads = [torch.zeros(s_, device=dev) for s_ in shapes]           # static gradient buffers the recorded step reads
+        for ps in (pa, pb):
+            for p, gr in zip(ps, grads):
+                p.grad = gr
+        fresh = [torch.randn(s_, generator=g).to(dev) for s_ in shapes]
+        for gr, f in zip(grads, fresh):
+            gr.copy_(f)
+        oa.step(); ob.step()                                              # one eager step: optimizer state exists
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with ops.kernel_trace() as tr:
+                if armed:
+                    with oa.capture_scope():
+                        with torch.cuda.graph(graph, stream=side):
+                            oa.step()
+                else:
+                    with torch.cuda.graph(graph, stream=side):
+                        oa.step()
+        torch.cuda.current_stream().wait_stream(side)
+        assert any('adam_step_kernel' in k for k in tr.kernels) == armed, (armed, tr.kernels)
+        for it in range(5):
+            for gr, s_ in zip(grads, shapes):
+                gr.copy_(torch.randn(s_, generator=g).to(dev) * (0.5 + it))
+            graph.replay()
+            ob.step()
+        torch.cuda.synchronize()
+        for p, q in zip(pa, pb):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-7)
+            assert float(oa.state[p]['step']) == float(ob.state[q]['step']) == 6.0
+            torch.testing.assert_close(oa.state[p]['exp_avg'], ob.state[q]['exp_avg'], rtol=2e-6, atol=1e-6 * float(ob.state[q]['exp_avg'].abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graph', [False, True])
+def test_weight_average_inside_the_adam_launch_matches_the_reference_update(dev, graph):
+    """``FusedAdam.attach_ema`` makes ModelEMA's update (yolox/utils/ema.py:44-60 of the reference: d = 0.9998 * (1 -
+    exp(-n / 2000));  v *= d;  v += (1 - d) * model) part of the optimizer's launch, the decay ramp from a device counter.  Against the
+    reference's three tensor operators per entry applied after a torch.optim.Adam step on a twin: parameters in the optimizer, a parameter
+    without gradient, BatchNorm running statistics (average only), the integer buffer untouched; eager and as a HIP-graph replay (the ramp
+    must keep moving); bit-identical averages given bit-identical parameters, 1e-7 otherwise."""
+    import math
+    import torch.nn as nn
+    from eas_snn_amd import ops
+    from eas_snn_amd.optim import FusedAdam
+    from yolox.utils import ModelEMA
+    torch.manual_seed(4)
+
+    def net():
+        m = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1), nn.BatchNorm2d(16), nn.Conv2d(16, 8, 1), nn.BatchNorm2d(8))
+        m[2].bias.requires_grad_(False)                  # a frozen parameter: the average follows it without an Adam step
+        return m.to(dev)
+    a, b = net(), net()
+    b.load_state_dict(a.state_dict())
+    oa = FusedAdam([p for p in a.parameters() if p.requires_grad], lr=1e-2, amsgrad=False, capturable=True)
+    ob = torch.optim.Adam([p for p in b.parameters() if p.requires_grad], lr=1e-2, amsgrad=False, fused=True, capturable=True)
+    start = 37                                           # a resumed run: the ramp does not start at zero
+    ema = ModelEMA(a, 0.9998, updates=start)
+    oa.attach_ema(ema, a)
+    want = {k: v.clone() for k, v in b.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    grads = [torch.zeros_like(p) for p in a.parameters() if p.requires_grad]
+    for m_, in ((a,), (b,)):
+        for p, gr in zip([p for p in m_.parameters() if p.requires_grad], grads):
+            p.grad = gr
+
+    def one_a():
+        oa.step()
+        ema.update(a)
+    with ops.kernel_trace() as tr:
+        one_a()                                          # eager: state exists
+    assert any('adam_step_kernel' in k for k in tr.kernels)
+    g_ = None
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side), oa.capture_scope(), torch.cuda.graph(g_, stream=side):
+            oa.step()
+        torch.cuda.current_stream().wait_stream(side)
+    n = start
+
+    def ref_update():
+        nonlocal n
+        n += 1
+        d = 0.9998 * (1 - math.exp(-n / 2000))
+        for k, v in want.items():
+            if v.dtype.is_floating_point:
+                v *= d
+                v += (1.0 - d) * b.state_dict()[k].detach()
+    ob.step()
+    ref_update()
+    for it in range(6):
+        for gr in grads:
+            gr.copy_(torch.randn(gr.shape, generator=g).to(dev))
+        with torch.no_grad():                            # the forward pass of a training step moves the BatchNorm statistics
+            for m_ in (a, b):
+                m_[1].running_mean.add_(0.01 * (it + 1))
+                m_[3].running_var.mul_(1.0 + 0.01 * it)
+                m_[1].num_batches_tracked.add_(1)
+        if graph:
+            g_.replay()
+            ema.updates += 1
+        else:
+            one_a()
+        ob.step()
+        ref_update()
+    torch.cuda.synchronize()
+    assert ema.updates == n == oa.ema_updates_on_device() == start + 7
+    got, live_a, live_b = ema.ema.state_dict(), a.state_dict(), b.state_dict()
+    for k, v in want.items():
+        if not v.dtype.is_floating_point:
+            assert torch.equal(got[k], torch.zeros_like(got[k])), k           # copied at construction, never averaged
+            continue
+        if torch.equal(live_a[k], live_b[k]):
+            assert torch.equal(got[k], v), f'{k}: the average differs although the averaged tensor is bit-identical'
+        torch.testing.assert_close(got[k], v, rtol=1e-6, atol=1e-7, msg=k)
+    oa.detach_ema()
+    before = {k: v.clone() for k, v in ema.ema.state_dict().items()}
+    oa.step()
+    ema.update(a)                                        # detached: the multi-tensor form of the same three operators
+    assert any(not torch.equal(before[k], v) for k, v in ema.ema.state_dict().items() if v.dtype.is_floating_point)
+
+
+@pytest.mark.gpu
 def test_stem_convolution_backward_takes_the_small_channel_kernel(dev):
     """ops.conv2d on an 8-channel input: its input gradient comes from eas_conv_dgrad_small (kernel trace) and matches fp64"""
     import torch.nn as nn

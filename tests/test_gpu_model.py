@@ -656,11 +656,12 @@ def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(de
 
 
 def test_trainer_loop_on_the_gpu_graph_replay_equals_eager(dev, tmp_path, monkeypatch):
-    """yolox.core.Trainer.train() -- the loop tools/train_event.py runs -- for one epoch of five iterations on the synthetic loader: two eager
-    iterations, capture, replays (the default) against the SAME loop with the capture replaced by its bookkeeping only (device-side Adam
-    step counters and learning rate, as a captured step needs them), i.e. five eager iterations of the same arithmetic: every batch is
-    trained in both (a capture executes nothing), same learning-rate schedule, and the losses, parameters, BatchNorm buffers and EMA
-    weights are bit-identical.  EAS_TRAIN_GRAPH=0 (host-side learning rate: Adam rounds differently) must run too."""
+    """yolox.core.Trainer.train() -- the loop tools/train_event.py runs -- for one epoch of five iterations on the synthetic loader: the
+    step recorded on the first batch (warm-up launches, capture, one replay, then model / optimizer / weight-average state put back:
+    ``capture(restore=True)``) and five replays (the default) against the SAME loop with the capture replaced by its bookkeeping only
+    (device-side Adam step counters and learning rate, as a captured step needs them), i.e. five eager iterations of the same arithmetic:
+    same learning-rate schedule, and the losses, parameters, BatchNorm buffers and EMA weights (made by the optimizer's launch in both) are
+    bit-identical -- so recording leaves no trace.  EAS_TRAIN_GRAPH=0 (host-side learning rate: Adam rounds differently) must run too."""
     import types
     from eas_snn_amd import data, ops
     from yolox.exp import get_exp
@@ -671,7 +672,8 @@ def test_trainer_loop_on_the_gpu_graph_replay_equals_eager(dev, tmp_path, monkey
         monkeypatch.setenv('EAS_TRAIN_GRAPH', '0' if graph == '0' else '1')
         if graph == 'bookkeeping':
             # capture() = bookkeeping + recording (executes nothing) + ONE replay, which is the batch's training step
-            monkeypatch.setattr(TrainStep, 'capture', lambda self, warm=3: (self.make_capturable(), self.eager()))
+            # (the Trainer records on its first batch with restore=True, then runs that batch's step: the bookkeeping twin records nothing)
+            monkeypatch.setattr(TrainStep, 'capture', lambda self, warm=3, restore=False: self.make_capturable())
         exp = get_exp(None, 'e-yolox-s')
         exp.merge(BASE_OPTS + ['use_spike', 'True', 'input_size', '(64, 64)', 'test_size', '(64, 64)'])    # (a 2x3 stride-32 map would take the library convolution: not reproducible)
         exp.max_epoch, exp.print_interval, exp.output_dir = 1, 1, str(tmp_path / graph)
@@ -718,6 +720,57 @@ def test_trainer_loop_with_sgd_stays_eager(dev, tmp_path, monkeypatch):
     torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+@pytest.mark.parametrize('train', [False, True])
+def test_forward_hooks_on_container_batchnorm_and_neuron_fire_on_every_path(dev, train):
+    """ADVICE r4 / VERDICT r5 next #8: the fused paths stand in for module calls -- eas_conv_bn_lif_eval for (container, BatchNorm, neuron), the
+    BN + LIF kernel pair for (BatchNorm, neuron).  A forward hook on ANY of the three must keep firing: the block then takes the
+    module-by-module path.  Hooks on the convolution container, the BatchNorm and the neuron of every converted block of SYOLOX-S: each fires
+    exactly once per forward, eval and train mode, and the result stays the model's (logits close to the un-hooked forward; the
+    module-by-module BatchNorm rounds differently from the fused kernel, so not bit-identical)."""
+    import collections
+    from oracle import fill
+    from spikingjelly.activation_based import functional
+    from yolox.exp import get_exp
+    from yolox.models.network_blocks import BaseConv
+    exp = get_exp(None, 'e-yolox-s')
+    exp.merge(BASE_OPTS + ['use_spike', 'True', 'input_size', '(64, 64)', 'test_size', '(64, 64)'])
+    model = exp.get_model()
+    fill.procedural_fill_(model, 2.0, ann_regex=fill.ANN_KEYS['True'])
+    model.to(dev).train(train)
+    model.head.use_l1 = True
+    x = torch.from_numpy(fill.poisson_events((2, 1, 4, 2, 64, 64), 0.5, seed=3)).to(dev)
+    tg = torch.zeros(2, 50, 5, device=dev)
+    tg[:, 0] = torch.tensor([0, 20.0, 24.0, 16.0, 20.0])
+
+    def run():
+        with torch.no_grad():
+            out = model(x, tg)['total_loss'] if train else model(x)
+        functional.reset_net(model)
+        return out.float().cpu()
+    plain = run()
+    fired = collections.Counter()
+    handles, watched = [], []
+    for name, m in model.named_modules():
+        if isinstance(m, BaseConv) and m.spiking():
+            for part in ('conv', 'bn', 'act'):
+                key = f'{name}.{part}'
+                watched.append(key)
+                handles.append(getattr(m, part).register_forward_hook(lambda mod, i, o, key=key: fired.update([key])))
+    assert len(watched) == 3 * 34
+    hooked = run()
+    for h in handles:
+        h.remove()
+    silent = [k for k in watched if fired[k] != 1]
+    assert not silent, f'hooks that did not fire exactly once: {silent[:6]} ({len(silent)} of {len(watched)})'
+    assert torch.isfinite(hooked).all()
+    if train:
+        assert abs(float(hooked) - float(plain)) <= 0.05 * abs(float(plain)) + 1e-3
+    else:
+        assert float(np.isclose(hooked.numpy(), plain.numpy(), rtol=1e-3, atol=1e-3).mean()) >= 0.9
+    again = run()                                    # hooks gone: the fused paths are back, bit for bit
+    assert torch.equal(again, plain)
+
+
 def test_evaluator_on_the_gpu(dev, tmp_path):
     """yolox.evaluators.EventEvaluator (what tools/eval_event.py:209-211 calls) on the GPU: (1) the default form -- two HIP-graph replays
     per batch -- returns the same detections as eager launches; (2) they equal the checker's post-processing (oracle/postprocess_ref.py)
@@ -737,7 +790,11 @@ def test_evaluator_on_the_gpu(dev, tmp_path):
     evaluator = exp.get_evaluator(2, False)                       # batch 4: batches of 4, 4, 2 samples
     assert len(evaluator.dataloader) == 3 and evaluator.dataloader.batch_size == 4
     (_, _, summary), graphed = evaluator.evaluate(model, False, False, None, None, exp.test_size, return_outputs=True)
-    assert evaluator._graphed is not None and 'Average forward time' in summary and float(evaluator.last_statistics[2]) == 2
+    assert len(evaluator._graphed) == 2 and 'Average forward time' in summary and float(evaluator.last_statistics[2]) == 2
+    # the loader's last batch is short: the full and the short batch each keep their recording, a second evaluation records nothing new
+    assert evaluator.graphs_recorded == 2
+    (_, _, _), again = evaluator.evaluate(model, False, False, None, None, exp.test_size, return_outputs=True)
+    assert evaluator.graphs_recorded == 2 and again == graphed
     evaluator.use_graph = False
     (_, _, _), eager = evaluator.evaluate(model, False, False, None, None, exp.test_size, return_outputs=True)
     assert sorted(graphed) == sorted(eager) and len(graphed) == 10
@@ -1507,7 +1564,7 @@ def _bench_child(extra_env, steps=3, warmup=3, timeout=900):
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     # EAS_BENCH_GRAPH=1: graph replay without the eager-against-replay probe of the one-GPU warm-up (eight more steps than the exchange path runs)
-    env = dict(os.environ, EAS_BENCH_NO_EVAL='1', EAS_BENCH_NO_640='1', EAS_BENCH_GRAPH='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+    env = dict(os.environ, EAS_BENCH_NO_EVAL='1', EAS_BENCH_NO_640='1', EAS_BENCH_NO_EMA='1', EAS_BENCH_GRAPH='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
