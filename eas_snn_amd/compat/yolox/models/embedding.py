@@ -95,17 +95,18 @@ class AdaptiveRSNNEmbedding(nn.Module):
     def forward(self, events, record=False, v_record=False):
         if events.dim() < 5:        # parameter-registration passthrough used by get_model_info (embedding.py:144-146)
             return events.unsqueeze(0).expand(self.Ts, *events.shape)
-        if v_record:
-            raise NotImplementedError('v_record is a debugging output of the reference and is not provided')
         # the loader's [B(,Tl),Tm,2,H,W] goes to the operator as it is: the kernels of the fused step read it time-major, newest slice first
         # (embedding.py:147-156), other configurations make that copy inside
         ev = events.flatten(end_dim=-5) if events.dim() > 5 else events
         if ev.shape[1] != self.nb_steps:
             raise ValueError(f'expected {self.nb_steps} micro-slices, got {ev.shape[1]}')
-        agg, rec = ops.arsnn_forward(ev, _stack_params(self.input_conv), _stack_params(self.gate_conv), self.kernel_size,
-                                     self.Ts, self.readout, self.spike_attach, self.write_zero, self.abs,
-                                     float(self.thresh), None if self.vreset is None else float(self.vreset), record=record, collated=True)
-        return (agg, rec.long()) if record else agg
+        agg, rec, *vrec = ops.arsnn_forward(ev, _stack_params(self.input_conv), _stack_params(self.gate_conv), self.kernel_size,
+                                            self.Ts, self.readout, self.spike_attach, self.write_zero, self.abs,
+                                            float(self.thresh), None if self.vreset is None else float(self.vreset), record=record, collated=True,
+                                            v_record=bool(v_record) and not record)
+        if record:
+            return agg, rec.long()
+        return (agg, vrec[0]) if v_record else agg      # embedding.py:221-226: ``record`` wins over ``v_record``
 
 
 class _TimeFlat(nn.Module):

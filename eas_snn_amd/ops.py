@@ -1282,6 +1282,7 @@ class _ARSNNFn(torch.autograd.Function):
         ev = _f32c(ev)
         pin, pg = params[:2 * d_in], params[2 * d_in:]
         collated = len(cfg) > 14 and cfg[14]     # ev is [N, Tm, Cin, H, W] as the loader collates it; the kernels read it time-major, newest first
+        v_record = len(cfg) > 15 and cfg[15]     # embedding.py:180: the potentials of the neurons that did not fire, step after step (debugging output)
         if collated:
             N, Tm, Cin, H, W = ev.shape
         else:
@@ -1349,6 +1350,8 @@ class _ARSNNFn(torch.autograd.Function):
         zero_rec = None if (d_gate or fused) else torch.zeros((N, 2 * C2, H, W), device=dev)
         saved = []
         t_rec = []
+        v_rec = []
+        recording = bool(record or v_record)     # the reference leaves its loop once every pixel has Ts segments (:200-201): nothing is recorded after
         for t in range(Tm):
             if _CONV_SINK is not None and d_gate:
                 _CONV_SINK.sampler_spikes.append(spike)
@@ -1387,8 +1390,15 @@ class _ARSNNFn(torch.autograd.Function):
             if need_grad:
                 saved.append((g_ins, v, vsum, gate, vn, seg_b, tl_b))
             v, vsum, spike = v_n, vs_n, sp_n
-            if record:
-                t_rec.append(tl.to(torch.int32))
+            if recording:
+                if record:
+                    t_rec.append(tl.to(torch.int32))
+                if v_record:
+                    # where the neuron did not fire the potential after the reset IS the pre-reset potential (vn * 1 + v_reset * 0, or
+                    # vn - thresh * 0): the state tensor the step kernel wrote serves as the reference's ``vmem_no_reset``
+                    v_rec.append(v_n[sp_n == 0])
+                if not running and int(seg.min()) >= Ts:          # (a host synchronisation: only these debugging outputs pay it)
+                    recording = False
         pre_relu = None
         if running:
             out = vsum if running == 'sum' else v
@@ -1412,12 +1422,12 @@ class _ARSNNFn(torch.autograd.Function):
         ctx.params = params
         ctx.ev_needs_grad = ctx.needs_input_grad[0]
         rec = torch.stack(t_rec) if record else None
-        if rec is not None:
-            ctx.mark_non_differentiable(rec)
-        return out, rec
+        vrec = torch.cat(v_rec) if v_record else None
+        ctx.mark_non_differentiable(*[t_ for t_ in (rec, vrec) if t_ is not None])
+        return out, rec, vrec
 
     @staticmethod
-    def backward(ctx, g_out, _g_rec):
+    def backward(ctx, g_out, _g_rec=None, _g_vrec=None):
         L = _lib.lib()
         k, depth, Ts, readout, sat, wz, ab, thresh, v_reset, soft, record, running, d_in, d_gate = ctx.cfg[:14]
         Tm, N, Cin, C2, H, W = ctx.dims
@@ -1526,14 +1536,15 @@ class _ARSNNFn(torch.autograd.Function):
 
 
 def arsnn_forward(ev_rev, input_params, gate_params, kernel_size, Ts, readout, spike_attach, write_zero, use_abs, thresh,
-                  v_reset, record=False, collated=False):
+                  v_reset, record=False, collated=False, v_record=False):
     """ev_rev: [Tm, N, 2, H, W] micro-slices, newest first -- or, with ``collated``, the loader's [N, Tm, 2, H, W] in forward time order
     (the fused step's kernels then read it newest first themselves: no flipped copy of the input).  *_params: [w0, b0, (w1, b1, ...)]."""
     depth = len(input_params) // 2
     soft = v_reset is None
     cfg = (int(kernel_size), depth, int(Ts), READOUT_IDS[readout], bool(spike_attach), bool(write_zero), bool(use_abs),
-           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record), None, depth, len(gate_params) // 2, bool(collated))
-    return _ARSNNFn.apply(ev_rev, cfg, *input_params, *gate_params)
+           float(thresh), 0.0 if soft else float(v_reset), soft, bool(record), None, depth, len(gate_params) // 2, bool(collated), bool(v_record))
+    out, rec, vrec = _ARSNNFn.apply(ev_rev, cfg, *input_params, *gate_params)
+    return (out, rec, vrec) if v_record else (out, rec)
 
 
 def gated_recurrence(ev_or_x, input_params, gate_params, kernel_size, readout, relu, thresh, v_reset):

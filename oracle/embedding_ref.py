@@ -95,11 +95,12 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_uniform_(m.weight, nonlinearity='sigmoid')
 
-    def forward(self, events, record=False):
+    def forward(self, events, record=False, v_record=False):
         if events.dim() < 5:  # parameter-registration passthrough (embedding.py:144-146)
             ev, _ = torch.broadcast_tensors(events, torch.zeros((self.Ts,) + events.shape))
             return ev
         ev = _to_time_major_reversed(events)
+        v_list = []
         Tm = self.nb_steps
         spike = torch.zeros_like(ev[0])
         v = torch.zeros_like(ev[0])
@@ -120,6 +121,7 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
             else:
                 v = vn * (1 - spike) + self.vreset * spike         # :135-138
             vsum = vsum + vn                                       # :179
+            v_list.append(vn[(1 - spike).bool()])                  # :180 (returned with v_record=True)
             fired = spike.bool()
             if self.readout == 'sum':
                 val = vsum
@@ -158,7 +160,9 @@ class AdaptiveRSNNEmbeddingRef(nn.Module):
         out = torch.stack(agg)
         if self.abs:
             out = F.relu(out)
-        return (out, torch.stack(t_record)) if record else out
+        if record:
+            return out, torch.stack(t_record)
+        return (out, torch.cat(v_list)) if v_record else out       # :221-226
 
 
 class SpikeCountEmbeddingRef(nn.Module):

@@ -281,6 +281,32 @@ def gen_events():
          micro_sum=ms.astype(np.int32), oob=np.int64((~inside).sum()))
 
 
+# ----------------------------------------------------------------------------- a5: the v_record output (embedding.py:141,180,223-224)
+def gen_vrecord():
+    """AdaptiveRSNNEmbedding.forward(..., v_record=True): the pre-reset potentials of the neurons that did NOT fire, step after step (the
+    reference's debugging output) for three of the arsnn_* cases (same inputs and weights as those fixtures: only the new output is stored)"""
+    from yolox.models.embedding import AdaptiveRSNNEmbedding
+    from yolox.models.activation import Rectangle
+    from yolox.utils.util import warp_decay
+    from oracle.fill import poisson_events, procedural_fill_
+    cases = {'readme': (5, 2, 1, 'sum', True, True, False, 4, 0.0, 2.0), 'soft_reset': (5, 2, 2, 'sum', True, True, False, 4, None, 3.0),
+             'ts1_plain': (5, 1, 1, 'sum', False, False, False, 4, 0.0, 2.0), 'ts7_tm8': (5, 2, 7, 'sum', True, True, False, 8, 0.0, 4.0)}
+    arrays = {}
+    for name, (k, depth, Ts, readout, sat, wz, ab, Tm, vreset, gain) in cases.items():
+        m = AdaptiveRSNNEmbedding(kernel_size=k, in_channel=2, out_channel=2, Ts=Ts, spike_attach=sat, write_zero=wz, abs=ab, depth=depth,
+                                  readout=readout, nb_steps=Tm, vreset=vreset, thresh=1.0, spike_fn=Rectangle,
+                                  decay=torch.nn.Parameter(warp_decay(0.5)))
+        crc = procedural_fill_(m, conv_gain=gain)
+        x = torch.from_numpy(poisson_events((2, 1, Tm, 2, 24, 32), 0.6, seed=zlib.crc32(name.encode()) % 1000))
+        with torch.no_grad():
+            out, v_rec = m(x, v_record=True)
+        prev = np.load(os.path.join(OUT, f'arsnn_{name}.npz'))
+        assert int(prev['crc']) == crc and np.array_equal(prev['x'], _np(x)) and np.array_equal(prev['out'], _np(out))
+        arrays[f'{name}/v_record'] = _np(v_rec)
+        print(f'    {name}: {v_rec.numel()} recorded potentials')
+    save('vrecord_arsnn', **arrays)
+
+
 # ----------------------------------------------------------------------------- a5/a7 embeddings
 def gen_embeddings():
     from yolox.models.embedding import (AdaptiveRSNNEmbedding, LIFEmbedding, SpikeCountEmbedding,
@@ -766,7 +792,7 @@ def main():
     for w in which:
         print(f'[{w}]')
         {'events': gen_events, 'embeddings': gen_embeddings, 'lif': gen_lif_layer, 'blocks': gen_blocks,
-         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy, 'window': gen_window_search, 'model_train_m': gen_model_train_m}[w]()
+         'models': gen_models, 'reps': gen_event_reps, 'augment': gen_augment, 'patan': gen_patan, 'stacked_hist': gen_stacked_hist, 'energy': gen_energy, 'window': gen_window_search, 'model_train_m': gen_model_train_m, 'vrecord': gen_vrecord}[w]()
     assert not os.path.exists(os.path.join(REF, 'yolox', '__pycache__')), 'bytecode leaked into the reference'
 
 

@@ -1592,6 +1592,65 @@ def test_bench_step_holds_a_live_rccl_communicator(dev):
     assert np.isfinite(a) and abs(a - b) <= 1e-6 * abs(a), (a, b)
 
 
+_LIVE_GROUP_CHILD = r"""
+import os, sys, types
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import eas_snn_amd
+from eas_snn_amd import ops, workloads
+from yolox.utils import wait_process_group_idle
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', '2000')
+dist.init_process_group('nccl', device_id=dev)                    # the group exists BEFORE anything is recorded (a caller that did not defer it)
+torch.cuda.set_stream(torch.cuda.Stream())
+ops.set_state_writeback(False)
+w = workloads.get(2)
+trainer, model, step = workloads.build_trainer(w, 4, dev, events=20000, world=1, rank=0, force_exchange=True, out_dir=%r)
+assert trainer.exchange is not None and trainer.exchange.bound
+for _ in range(3):
+    step()                                                        # eager steps with real all-reduces in flight
+assert wait_process_group_idle() is True, 'the flight recorder is not available: captures with a live group would stay eager'
+form = step.capture(warm=1)
+assert form.startswith('three hip-graph replays'), form
+losses = []
+for _ in range(4):
+    losses.append(float(step().detach()))
+torch.cuda.synchronize()
+assert all(l == l and abs(l) < 1e6 for l in losses), losses
+# the evaluator with the group alive: records its two graphs per batch shape after the same condition wait
+from yolox.exp import get_exp
+exp = workloads.build_exp(w)
+exp.eval_samples, exp.eval_events = 8, 20000
+ev = exp.get_evaluator(2, False)
+dist.all_reduce(torch.ones(4, device=dev))
+ev.evaluate(model, False, False, None, None, exp.test_size)
+assert ev.use_graph and ev.graphs_recorded >= 1, (ev.use_graph, ev.graphs_recorded)
+dist.destroy_process_group()
+print('LIVE_GROUP_OK', form[:40], losses)
+"""
+
+
+def test_capture_with_a_live_process_group_waits_for_the_watchdog(dev, tmp_path):
+    """The condition wait that replaced the 0.3 s sleeps of round 5: a caller that created the RCCL process group BEFORE recording
+    (not bench.py, not the Trainer -- they record first -- but e.g. the evaluator under tools/eval_event.py's DistributedDataParallel
+    wrapper) gets its HIP graphs recorded after ``wait_process_group_idle`` has seen the watchdog retire every collective (flight
+    recorder), never after a delay.  Child process: one-rank group on 'nccl', eager steps with all-reduces, TrainStep.capture and the
+    evaluator's recording with the group alive, replays."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / 'live_group.py'
+    script.write_text(_LIVE_GROUP_CHILD % (root, str(tmp_path / 'out')))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and 'LIVE_GROUP_OK' in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize('batch', [2, 64])
 @pytest.mark.parametrize('fuse', [False, True])
 def test_eval_head_with_grouped_launches_is_bit_identical(dev, batch, fuse):
