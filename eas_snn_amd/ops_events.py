@@ -7,9 +7,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from . import ops as _o
 from ._lib import check, ptr, stream
-from .ops import _call, _dev, _f32c, _timer_add, _timer_mark
+from .ops_core import _call, _dev, _f32c, _timer_add, _timer_mark
 
 
 # ------------------------------------------------------------------------------------------------ K1

@@ -8,9 +8,8 @@ import os
 import torch
 
 from . import _lib
-from . import ops as _o
 from ._lib import check, ptr, stream
-from .ops import _call, _dev, _f32c, _timer_add, _timer_mark, dense, ghost, is_small_int, mark_small_int, planes_enabled, planes_of
+from .ops_core import _call, _dev, _f32c, _timer_add, _timer_mark, dense, ghost, is_small_int, mark_small_int, planes_enabled, planes_of
 
 
 # ------------------------------------------------------------------------------------------------ SPP pooling block

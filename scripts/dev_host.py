@@ -40,9 +40,13 @@ def main():
     def counting(name, *a, **k):
         calls.append(name)
         return orig(name, *a, **k)
-    ops._call = counting
+    from eas_snn_amd import ops_bn, ops_conv, ops_core, ops_det, ops_events, ops_glue, ops_lif, ops_sampler
+    fams = (ops, ops_core, ops_lif, ops_bn, ops_sampler, ops_conv, ops_events, ops_glue, ops_det)     # every family module calls its own ``_call`` name
+    for m_ in fams:
+        m_._call = counting
     step.eager()
-    ops._call = orig
+    for m_ in fams:
+        m_._call = orig
     print('C-ABI calls through ops._call in one step:', len(calls))
     pr = cProfile.Profile()
     pr.enable()

@@ -26,9 +26,10 @@ def rec(name, nbytes, fn, *args, **kw):
 
 with ops.no_state_writeback():
     step.eager()
-    ops._partial_call = rec
+    from eas_snn_amd import ops_conv
+    ops_conv._partial_call = rec            # (the name the weight-gradient operators call lives in their family module)
     step.eager()
-    ops._partial_call = orig
+    ops_conv._partial_call = orig
 torch.cuda.synchronize()
 rows.sort(reverse=True)
 print(f'config {cfg}: {len(rows)} weight gradients, slabs written + read once each: {sum(r[0] for r in rows):.0f} MB per step')

@@ -629,12 +629,13 @@ def test_train_step_split_backward_buckets_and_graph_replay_are_bit_identical(de
         step = TrainStep(model, opt, lambda: (x, tg), exchange=ex, cut=DEFAULT_CUT)
         assert step.cut == DEFAULT_CUT
         # the cut is a forward hook: it must not switch the model to fp32 spikes (N > 1 ranks would run another kernel set than one rank)
-        made, new_planes = [], ops.new_planes
-        ops.new_planes = lambda *a, **k: (made.append(1), new_planes(*a, **k))[1]
+        from eas_snn_amd import ops_bn                   # (the BN + LIF operators allocate the planes they write: watch the name THEY call)
+        made, new_planes = [], ops_bn.new_planes
+        ops_bn.new_planes = lambda *a, **k: (made.append(1), new_planes(*a, **k))[1]
         try:
             step()
         finally:
-            ops.new_planes = new_planes
+            ops_bn.new_planes = new_planes
         assert made, 'the split step ran without spike planes'
         assert torch.equal(step.loss.detach(), loss0)
         bad = [n for n, p in model.named_parameters() if not torch.equal(p.grad, want[n])]
