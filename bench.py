@@ -423,17 +423,19 @@ def dominant_roofline(summ):
     return r
 
 
-def ema_side_figure(trainer, step, inputs_fn, n=10):
-    """Side figure (never `value`): the same step WITH the weight average the reference keeps by default (exp.ema = True,
-    event_yolox_base.py:116; ModelEMA.update after every optimizer.step(), trainer.py:120-121).  The average is made by the optimizer's own
-    launch (FusedAdam.attach_ema, eas_adam_step_ex), so the step stays one HIP-graph replay; timed back to back with the headline's graph in
-    the same process, alternating, so that the difference is the average and not the box."""
-    ema = trainer.make_ema(0.9998, 0)
-    if getattr(ema, '_fused_in', None) is not trainer.optimizer:
-        return {'error': 'the optimizer of this run does not take the weight average into its launch'}
+def ema_off_side_figure(trainer, step, inputs_fn, n=10):
+    """Side figure (never `value`): the same step WITHOUT the weight average, i.e. what rounds 1-5 measured (exp.ema = False).  The headline
+    step keeps the reference's default (exp.ema = True, event_yolox_base.py:116: ModelEMA.update after every optimizer.step(),
+    trainer.py:120-121) -- the average is made by the optimizer's own launch (FusedAdam.attach_ema, eas_adam_step_ex), so the step stays one
+    HIP-graph replay.  Both graphs are timed back to back in this process, alternating, so that the difference is the average and not the box."""
+    ema = step.ema
+    if ema is None or getattr(ema, '_fused_in', None) is not trainer.optimizer:
+        return {'error': 'the headline step of this run carries no weight average made by the optimizer launch'}
+    updates = trainer.optimizer.ema_updates_on_device()
+    trainer.optimizer.detach_ema()           # the headline graph keeps replaying with ITS table (average included); new recordings get none
     try:
-        step_e = trainer.step_fn(inputs_fn, ema=ema)
-        form = step_e.capture(warm=2)
+        step_off = trainer.step_fn(inputs_fn, ema=None)
+        form = step_off.capture(warm=2)
 
         def clock(fn):
             torch.cuda.synchronize()
@@ -444,15 +446,15 @@ def ema_side_figure(trainer, step, inputs_fn, n=10):
             return (time.perf_counter() - t) / n * 1e3
         off, on = [], []
         for _ in range(3):
-            off.append(clock(step.replay))
-            on.append(clock(step_e.replay))
-        assert torch.isfinite(step_e.loss), 'the step with the weight average produced a non-finite loss'
-        return {'ema_on_ms_per_step': round(min(on), 3), 'ema_off_ms_per_step_same_run': round(min(off), 3),
-                'difference_ms': round(min(on) - min(off), 3), 'launch': form, 'updates_on_device': trainer.optimizer.ema_updates_on_device(),
-                'note': 'ModelEMA (decay 0.9998, ramp 2000) over every floating-point state-dict entry, made inside the one Adam launch; '
-                        'best of 3 x %d replays each, alternating with the headline graph' % n}
+            on.append(clock(step.replay))
+            off.append(clock(step_off.replay))
+        assert torch.isfinite(step_off.loss), 'the step without the weight average produced a non-finite loss'
+        return {'ema_on_ms_per_step': round(min(on), 3), 'ema_off_ms_per_step': round(min(off), 3), 'difference_ms': round(min(on) - min(off), 3),
+                'launch': form, 'updates_on_device_before': updates,
+                'note': 'ModelEMA (decay 0.9998, ramp 2000) over every floating-point state-dict entry, made inside the one Adam launch of the '
+                        'headline step; best of 3 x %d replays each of the headline graph and of the same step recorded without it, alternating' % n}
     finally:
-        trainer.optimizer.detach_ema()
+        trainer.optimizer.attach_ema(ema, trainer.bare_model)
 
 
 def parity_against_oracle(w, model, raw, dev):
@@ -639,7 +641,7 @@ def main():
     torch.cuda.synchronize()
     t_tot = time.perf_counter() - t_a
     probe = {}
-    if mode in ('1', 'auto') and trainer.net is trainer.bare_model:
+    if mode in ('1', 'auto') and trainer.net is trainer.bare_model and step.ema_capturable():
         # multi: recorded before the process group exists, the warm-up launches' effect on model and optimizer state put back afterwards
         # (every rank then takes rank 0's parameters in join_ranks, as DistributedDataParallel's constructor would hand them out)
         step.capture(warm=3, restore=multi)
@@ -762,7 +764,7 @@ def main():
     ema_figure = None
     if rank == 0 and not multi and step.graphs is not None and os.environ.get('EAS_BENCH_NO_EMA') != '1' and not profiled:
         try:
-            ema_figure = ema_side_figure(trainer, step, inputs_fn)
+            ema_figure = ema_off_side_figure(trainer, step, inputs_fn)
         except Exception as exc:
             ema_figure = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     canvas640 = None
@@ -849,7 +851,7 @@ def main():
                 'unit': 'event-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (yolox.core.Trainer step; EMA off: exp.ema = False -- the same step WITH the reference's ModelEMA update of trainer.py:120-122 is the side figure weight_average.ema_on_ms_per_step)",
+                'config': {'workload': f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + ModelEMA update + reset_net (yolox.core.Trainer step with the reference's defaults: exp.ema = True, trainer.py:120-122; the average is made inside the one Adam launch -- the same step without it: side figure weight_average.ema_off_ms_per_step)" if step.ema is not None else f"{w['name']}, batch {batch}/GPU, raw input -> frames -> fwd + bwd + Adam + reset_net (EMA off)",
                            'baseline_config': w['config'], 'global_batch': batch * world,
                            'events_per_sample': args.events if w['input'] == 'events' else None, 'parallelism': f'dp{world}',
                            'gradient_exchange': ((f'{trainer.exchange.nbuckets} flat bucket(s)' if trainer.exchange is not None else trainer.dp) if multi else None),

@@ -410,7 +410,8 @@ class Trainer:
         """the weight average of the loop (trainer.py:169-171 of the reference); on the GPU its update becomes part of the optimizer's launch"""
         ema = ModelEMA(self.bare_model, decay)
         ema.updates = updates
-        if self.device != 'cpu' and hasattr(self.optimizer, 'attach_ema') and os.environ.get('EAS_FUSED_EMA', '1') == '1':
+        if (self.device != 'cpu' and hasattr(self.optimizer, 'attach_ema') and self.optimizer.takes_ema()
+                and os.environ.get('EAS_FUSED_EMA', '1') == '1'):
             self.optimizer.attach_ema(ema, self.bare_model)
         return ema
 

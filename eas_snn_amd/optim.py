@@ -38,6 +38,10 @@ class FusedAdam(torch.optim.Adam):
         self._eas_ema_serial = 0
 
     # ---- weight average (ModelEMA) inside the step
+    def takes_ema(self):
+        """this optimizer's step runs on the own kernel (so a weight average can ride in its launch): switched on, and every group eligible"""
+        return ENABLED and len(self.param_groups) <= _MAX_GROUPS and all(self._eligible(g) for g in self.param_groups)
+
     def attach_ema(self, ema, model):
         """From now on ``step()`` also takes the update ``ema.update(model)`` would make (same arithmetic, see csrc/adam.hip); ``ema.update``
         itself only counts.  ``ema``: yolox.utils.ModelEMA; ``model``: the module whose state dict it averages."""

@@ -85,14 +85,17 @@ def device_inputs(w, batch, n_events, device, seed=0):
     raise KeyError(w['input'])
 
 
-def build_trainer(w, batch, device, events=200_000, world=1, rank=0, force_exchange=False, out_dir='/tmp/eas_bench_out'):
+def build_trainer(w, batch, device, events=200_000, world=1, rank=0, force_exchange=False, out_dir='/tmp/eas_bench_out', ema=True):
     """The bench's step object for workload ``w``: the reference-shaped ``yolox.core.Trainer`` (model on the device, optimizer, gradient
     exchange when ``world`` > 1) and its ``TrainStep`` fed by the workload's device pipeline -- what ``bench.py`` times and what
-    tests/test_gpu_bench_shapes.py traces.  Returns (trainer, model, step)."""
+    tests/test_gpu_bench_shapes.py traces.  Returns (trainer, model, step).
+
+    ema: the weight average the reference keeps by default (``exp.ema = True``, event_yolox_base.py:116; ``ModelEMA.update`` after every
+    ``optimizer.step()``, trainer.py:120-121) is part of the step -- made inside the optimizer's one launch (FusedAdam.attach_ema)."""
     import os
     import types
     exp = build_exp(w)
-    exp.ema = False                          # the measured step is forward + backward + exchange + Adam + reset_net
+    exp.ema = bool(ema)                      # the measured step: forward + backward + exchange + Adam (+ weight average) + reset_net
     exp.output_dir = os.environ.get('EAS_BENCH_OUT', out_dir)
     torch.manual_seed(80)
     trainer = exp.get_trainer(types.SimpleNamespace(batch_size=batch * world, fp16=False, experiment_name=f'bench_config{w["config"]}',
@@ -102,7 +105,8 @@ def build_trainer(w, batch, device, events=200_000, world=1, rank=0, force_excha
     model.head.fused_assign = os.environ.get('EAS_FUSED_ASSIGN', '1') == '1'    # development switch: 0 = tensor-op SimOTA
     model.head.fused_loss = os.environ.get('EAS_FUSED_LOSS', '1') == '1'        # development switch: 0 = tensor-op loss terms
     raw, inputs_fn = device_inputs(w, batch, events, device, seed=rank)
-    step = trainer.step_fn(inputs_fn)
+    trainer.ema_model = trainer.make_ema(0.9998, 0) if ema else None       # (what Trainer.before_train does; join_ranks re-copies it after the broadcast)
+    step = trainer.step_fn(inputs_fn, ema=trainer.ema_model)
     step.raw_inputs = raw
     return trainer, model, step
 

@@ -42,6 +42,8 @@ def main():
             'flip_fraction_overall': st['flips'] / max(st['steps'], 1), 'flip_fraction_worst_layer': st['worst_flip'],
             'membrane_rel_err_worst': st['worst_v'], 'membrane_tolerance': M.RTOL,
             'prediction_conv_worst_element_in_units_of_1e-4': st['pred_worst']}
+    # one whole training step against the reference's own step (fixtures from the unmodified reference classes): achieved figures
+    out['train_step_vs_reference_fixture'] = {name: M._train_step_figures(dev, name) for name in M.TRAIN_STEP_FIXTURES}
     if '--backward' in sys.argv:
         sb = M._teacher_forced_backward(dev, 'e-yolox-s', dict(use_spike='True'), (2, 1, 4, 2, 256, 320), 34)
         out['backward'] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in sb.items()} if isinstance(sb, dict) else None
