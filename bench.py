@@ -490,12 +490,38 @@ def parity_against_oracle(w, model, raw, dev):
         was_training = model.training
         model.eval()
         ref.eval()
-        with torch.no_grad():
-            lh = model(frames).cpu().numpy()
-            lr = ref(frames.cpu()).numpy()
+        # where the two forwards part: the sampler's output and the four backbone stages (spike tensors or firing rates) -- the share of
+        # elements that differ.  A rounding-level flip of a neuron that sits on its threshold is amplified stage by stage;
+        # the per-layer bar with the oracle's input at every layer is the teacher-forced figures below.
+        stages, seen = ['embedding', 'backbone.backbone.dark2', 'backbone.backbone.dark3', 'backbone.backbone.dark4', 'backbone.backbone.dark5'], {}
+
+        def tap(store, name):
+            def hook(mod, inp, outp):
+                o = outp[0] if isinstance(outp, (tuple, list)) else outp
+                if torch.is_tensor(o):
+                    store[name] = o.detach().float().cpu().numpy()
+            return hook
+        handles = []
+        for tag, net in (('hip', model), ('ref', ref)):
+            seen[tag] = {}
+            for name in stages:
+                try:
+                    handles.append(net.get_submodule(name).register_forward_hook(tap(seen[tag], name)))
+                except AttributeError:
+                    pass
+        try:
+            with torch.no_grad():
+                lh = model(frames).cpu().numpy()
+                lr = ref(frames.cpu()).numpy()
+        finally:
+            for h in handles:
+                h.remove()
         functional.reset_net(model)
         sj_ref.reset_net(ref)
         model.train(was_training)
+        out['differing_share_by_stage'] = {
+            name.split('.')[-1]: round(float((~np.isclose(seen['hip'][name], seen['ref'][name], rtol=1e-4, atol=1e-5)).mean()), 8)
+            for name in stages if name in seen['hip'] and name in seen['ref'] and seen['hip'][name].shape == seen['ref'][name].shape}
         close = np.isclose(lh, lr, rtol=1e-4, atol=1e-4)
         rel = np.abs(lh - lr) / (np.abs(lr) + 1e-4)
         out.update({'logits_within_1e-4_share_end_to_end': round(float(close.mean()), 6), 'logits_median_rel_err': float(np.median(rel)),

@@ -29,18 +29,27 @@ def defer_process_group(backend, init_method, world_size, rank, timeout, local_s
                     local_size=int(local_size or world_size), local_rank=int(rank if local_rank is None else local_rank), extra=init_kwargs)
     if not _HOOKED:
         # every torch.distributed call without an explicit group (and DistributedDataParallel's constructor) asks for the default group
-        # through this accessor: a deferred initialisation happens there instead of "Default process group has not been initialized"
+        # through this accessor: a deferred initialisation happens there instead of "Default process group has not been initialized".
+        # (A private accessor of torch: if this torch does not have it, nothing is deferred -- the group is created right here, the
+        # reference's order, and captures with a live group take the condition wait below.)
         import sys
-        from torch.distributed import distributed_c10d as c10d
-        inner = c10d._get_default_group
+        try:
+            from torch.distributed import distributed_c10d as c10d
+            inner = c10d._get_default_group
+        except (ImportError, AttributeError):
+            ensure_process_group()
+            return
 
         def _get_default_group():
             if _PENDING is not None:
                 ensure_process_group()
             return inner()
         for mod in list(sys.modules.values()):        # modules that imported the accessor by name (torch.nn.parallel.distributed) hold their own reference
-            if getattr(mod, '_get_default_group', None) is inner:
-                mod._get_default_group = _get_default_group
+            try:
+                if getattr(mod, '_get_default_group', None) is inner:
+                    mod._get_default_group = _get_default_group
+            except Exception:
+                pass
         _HOOKED = True
 
 
