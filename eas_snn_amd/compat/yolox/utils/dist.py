@@ -87,8 +87,12 @@ def wait_process_group_idle(limit_s=30.0):
     if not _ready() or dist.get_backend() != 'nccl':
         return True
     try:
+        # the recorder only lists collectives when it was switched on BEFORE the group was created (ensure_process_group does that); a group
+        # somebody else created without it would look idle at all times
+        if int(os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '0')) <= 0:
+            return False
         from torch._C._distributed_c10d import _dump_nccl_trace
-    except ImportError:
+    except (ImportError, ValueError):
         return False
     if torch.cuda.is_available():
         torch.cuda.synchronize()

@@ -1628,6 +1628,11 @@ assert trainer.exchange is not None and trainer.exchange.bound
 for _ in range(3):
     step()                                                        # eager steps with real all-reduces in flight
 assert wait_process_group_idle() is True, 'the flight recorder is not available: captures with a live group would stay eager'
+import pickle
+from torch._C._distributed_c10d import _dump_nccl_trace
+seen = pickle.loads(_dump_nccl_trace(True, False, False))['entries']           # every recorded collective, retired ones included
+assert len(seen) >= 6, f'the flight recorder lists {len(seen)} collectives after three exchanged steps: it is not recording'
+assert not pickle.loads(_dump_nccl_trace(True, False, True))['entries']        # ... and none of them is still held by the watchdog
 form = step.capture(warm=1)
 assert form.startswith('three hip-graph replays'), form
 losses = []
