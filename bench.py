@@ -28,6 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# kernel arguments in device memory: the HIP runtime's default on this image; an inherited HIP_FORCE_DEV_KERNARG=0 costs the 452 launches of a
+# step +0.55 ms (HISTORY.md D, round 6).  Has to be in the environment before the runtime initialises.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -253,7 +253,7 @@ def _bind_host_hip_runtime():
 _PRIVATE_STREAMS = []
 
 
-def private_stream(priority=None):
+def private_stream():
     """A torch stream on a HIP stream of its own (hipStreamCreateWithFlags), NOT one of the 32 pooled streams ``torch.cuda.Stream()`` hands out
     round-robin.  Every stream that may end up inside a graph capture is made here: ProcessGroupNCCL takes its internal stream from the same
     pool, and when a pooled stream that happens to be THAT one is put into capture, the process group's watchdog thread -- which keeps
@@ -263,10 +263,9 @@ def private_stream(priority=None):
     _bind_host_hip_runtime()
     rt = C.CDLL(None)                    # the process-wide symbol scope: the HIP runtime torch loaded
     handle = C.c_void_p()
-    if priority is None:
-        rc = rt.hipStreamCreateWithFlags(C.byref(handle), C.c_uint(1))          # hipStreamNonBlocking
-    else:       # development (EAS_WGRAD_SIDE_PRIO): lower number = higher priority, clamped by the runtime to the device's range
-        rc = rt.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(int(priority)))
+    # (default priority on purpose: a stream of another priority -- higher or lower, the chain's or the slab kernels' -- inside a recorded
+    # step costs +7.7 ms per replay on this runtime, HISTORY.md D round 6)
+    rc = rt.hipStreamCreateWithFlags(C.byref(handle), C.c_uint(1))          # hipStreamNonBlocking
     if rc != 0 or not handle.value:
         raise EasHipError(f'hipStreamCreateWithFlags failed ({rc})')
     st = torch.cuda.ExternalStream(handle.value)

@@ -257,8 +257,7 @@ class TrainStep:
         mode = 'thread_local' if live_group else 'global'
 
         if getattr(self, '_capture_stream', None) is None:
-            prio = os.environ.get('EAS_CAPTURE_PRIO')          # development: stream priority of the chain's stream
-            self._capture_stream = _lib.private_stream(None if prio in (None, '') else int(prio))      # never a pooled stream: ProcessGroupNCCL's own stream is one of those
+            self._capture_stream = _lib.private_stream()      # never a pooled stream: ProcessGroupNCCL's own stream is one of those
 
         def graph(g, pool=None):
             torch.cuda.synchronize()

@@ -344,8 +344,7 @@ def _side_flush():
     if not jobs:
         return
     if opctx.side['stream'] is None:
-        prio = os.environ.get('EAS_WGRAD_SIDE_PRIO')          # development: stream priority of the slab kernels' stream
-        opctx.side['stream'] = _lib.private_stream(None if prio in (None, '') else int(prio))          # joins graph captures: never a pooled stream (see there)
+        opctx.side['stream'] = _lib.private_stream()          # joins graph captures: never a pooled stream (see there)
     side = opctx.side['stream']
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
