@@ -541,7 +541,15 @@ def parity_against_oracle(w, model, raw, dev):
         if stale:
             out['teacher_forced'] = {'unavailable': f'stale: {", ".join(stale[:4])} changed after tests/parity_report.py ran'}
         else:
-            out['teacher_forced'] = {k: v for k, v in tf.items() if not k.startswith('_')}
+            out['teacher_forced'] = {k: tf[k] for k in ('model', 'canvas', 'eval', 'train') if k in tf}
+            steps = tf.get('train_step_vs_reference_fixture') or {}
+            if steps:           # one training step against the reference's own step (fixtures from the unmodified reference classes), condensed
+                out['train_step_vs_reference_fixture'] = {
+                    'fixtures': sorted(steps), 'gradient_elements': sum(f['gradient_elements'] for f in steps.values()),
+                    'gradient_elements_within_1e-3_share_min': min(f['gradient_elements_within_tol_share'] for f in steps.values()),
+                    'loss_rel_err_max': max(max(f['loss_rel_err'].values()) for f in steps.values()),
+                    'gradnorm_rel_err_median_max': max(f['gradnorm_rel_err_median'] for f in steps.values()),
+                    'gradnorm_rel_err_max': max(f['gradnorm_rel_err_max'] for f in steps.values())}
     except (OSError, ValueError):
         out['teacher_forced'] = {'unavailable': 'profiles/parity_teacher_forced_latest.json not present'}
     return out

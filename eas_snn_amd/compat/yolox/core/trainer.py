@@ -265,6 +265,7 @@ class TrainStep:
                 raise _NoCapture()
             return torch.cuda.graph(g, pool=pool, stream=self._capture_stream, capture_error_mode=mode)
         scope = self.optimizer.capture_scope() if hasattr(self.optimizer, 'capture_scope') else contextlib.nullcontext()
+        counted = None if self.ema is None else self.ema.updates
         try:
             with scope:
                 self._record(graph)
@@ -273,6 +274,8 @@ class TrainStep:
             if restore:
                 self._restore(snap)
             return self.launch
+        if self.ema is not None:
+            self.ema.updates = counted                # recording ran ema.update()'s count, but no kernel: the host mirror follows the device counter
         torch.cuda.synchronize()
         self.replay()                                 # warm-up replay
         if restore:

@@ -701,6 +701,10 @@ def test_trainer_loop_on_the_gpu_graph_replay_equals_eager(dev, tmp_path, monkey
         tr.train()
         assert (tr.step.graphs is not None) == (graph == '1') and len(tr.log) == 5
         assert all(np.isfinite(r['loss']) for r in tr.log)
+        if tr.use_model_ema and getattr(tr.ema_model, '_fused_in', None) is tr.optimizer:
+            # five iterations = five updates of the weight average, on the host mirror and on the device counter that drives the decay ramp
+            # (recording and its warm-up launches leave no trace in either)
+            assert tr.ema_model.updates == 5 == tr.optimizer.ema_updates_on_device(), (tr.ema_model.updates, tr.optimizer.ema_updates_on_device())
         if graph == '0':
             continue
         sd = {k: v.clone() for k, v in tr.bare_model.state_dict().items()}
