@@ -117,7 +117,7 @@ def check(path):
     def visit_class(cls, cls_scope, outer):
         for stmt in cls.body:
             if isinstance(stmt, (ast.FunctionDef, ast.AsyncFunctionDef)):
-                visit(ast.Module(body=[stmt], type_ignores=[]), Scope(cls, outer) if False else _method_parent(cls_scope, outer))
+                visit(ast.Module(body=[stmt], type_ignores=[]), _method_parent(cls_scope, outer))
             else:
                 visit(ast.Module(body=[stmt], type_ignores=[]), cls_scope)
 
