@@ -28,18 +28,27 @@ class BaseExp(metaclass=ABCMeta):
             return '\n'.join(f'{k}: {v}' for k, v in rows)
 
     def merge(self, cfg_list):
+        """``[key, text, key, text, ...]``: every key the experiment already has takes ``text`` coerced to the TYPE of its current value
+        (base_exp.py:67-90 of the reference); keys it does not have are skipped silently"""
         assert len(cfg_list) % 2 == 0, f'length must be even, check value here: {cfg_list}'
-        for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
-            if not hasattr(self, k):
-                continue                                   # unknown keys are ignored, as upstream
-            src = getattr(self, k)
-            if isinstance(src, (list, tuple)):
-                v = [t.strip() for t in v.strip('[]()').split(',')]
-                if len(src) > 0:
-                    v = [type(src[0])(t) for t in v]
-            if src is not None and type(src) != type(v):
-                try:
-                    v = type(src)(v)
-                except Exception:
-                    v = ast.literal_eval(v)
-            setattr(self, k, v)
+        for i in range(0, len(cfg_list), 2):
+            key, text = cfg_list[i], cfg_list[i + 1]
+            if hasattr(self, key):
+                setattr(self, key, _coerce(getattr(self, key), text))
+
+
+def _coerce(default, text):
+    """the override ``text`` in the type of ``default``.  Sequences: brackets stripped, split at commas, items in the type of the default's
+    first item (an empty default keeps strings), then the default's own sequence type.  Everything else: ``type(default)(text)`` -- which
+    makes ``bool('False')`` True and keeps ``use_spike`` a string, quirks the reference's recipes rely on -- with ``ast.literal_eval`` as the
+    fallback when that constructor refuses; a ``None`` default keeps the text."""
+    value = text
+    if isinstance(default, (list, tuple)):
+        items = [part.strip() for part in text.strip('[]()').split(',')]
+        value = [type(default[0])(item) for item in items] if len(default) else items
+    if default is None or type(default) is type(value):
+        return value
+    try:
+        return type(default)(value)
+    except Exception:
+        return ast.literal_eval(value)

@@ -93,6 +93,51 @@ def test_exp_merge_type_coercion_quirks():
     assert exp.get_slice_args()['window'] == (-200000, 0)
 
 
+def test_exp_merge_equals_the_reference_merge():
+    """``BaseExp.merge`` against the reference's own method (yolox/exp/base_exp.py:67-90, imported here where the reference tree exists) on the
+    same defaults and overrides: ints, floats, strings, the ``bool('False')`` quirk, None defaults, tuples / lists (brackets or not, empty
+    defaults), unknown keys, a literal_eval fallback, and overrides that raise -- same value, same type, same exception"""
+    ref_file = '/root/reference/yolox/exp/base_exp.py'
+    if not os.path.exists(ref_file):
+        pytest.skip('reference tree not present')
+    import importlib.util
+    from yolox.exp.base_exp import BaseExp as Ours
+    prev = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True                       # nothing is ever written into the reference tree
+    try:
+        spec = importlib.util.spec_from_file_location('_ref_base_exp', ref_file)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)                     # (its ``from yolox.utils import LRScheduler`` resolves to the compat namespace)
+    finally:
+        sys.dont_write_bytecode = prev
+
+    def concrete(base):
+        return type('X', (base,), {n: (lambda self, *a, **k: None) for n in getattr(base, '__abstractmethods__', ())})
+    R, O = concrete(ref.BaseExp), concrete(Ours)
+    defaults = dict(a=3, b=0.5, c='str', d=True, e=None, f=(256, 320), g=[1.0, 2.0], h=(), i=[], j=(0.1, 0.2), k=False)
+    cases = [['a', '7'], ['a', '7.5'], ['b', '2'], ['c', 'True'], ['d', 'False'], ['e', 'xyz'], ['f', '(640,640)'], ['f', '[320, 480]'],
+             ['g', '[3,4]'], ['h', '(1,2)'], ['i', '[a,b]'], ['j', '(0.5, 1)'], ['k', '0'], ['zzz', '1'], ['a', '[1]'], ['f', '640,  512'],
+             ['b', '1e-3'], ['g', 'x'], ['f', '(a,b)'], ['a', '1', 'b', '2', 'a', '5']]
+    for cs in cases:
+        r, o = R(), O()
+        for key, v in defaults.items():
+            setattr(r, key, v)
+            setattr(o, key, v)
+        errs = []
+        for obj in (r, o):
+            try:
+                obj.merge(list(cs))
+                errs.append(None)
+            except Exception as exc:
+                errs.append(type(exc).__name__)
+        assert errs[0] == errs[1], (cs, errs)
+        for key in set(cs[0::2]):
+            vr, vo = getattr(r, key, '<absent>'), getattr(o, key, '<absent>')
+            assert vr == vo and type(vr) is type(vo), (cs, key, vr, vo)
+    with pytest.raises(AssertionError):
+        O().merge(['a'])
+
+
 @pytest.mark.parametrize('name,use_spike,extra', [('model_s_true_64', 'True', []), ('model_s_full_64', 'full_spike', []),
                                                   ('model_s_fullv2_64', 'full_spike_v2', []), ('model_s_false_64', 'False', []),
                                                   ('model_m_fullv2_t5_64x96', 'full_spike_v2', ['T', '5']),
