@@ -6,23 +6,28 @@ from eas_snn_amd import ops
 from .network_blocks import BaseConv, CSPLayer, DWConv, Focus, SPPBottleneck
 
 
+# stage name, width as a multiple of the stem's, CSPLayer depth as a multiple of the base depth, last stage (SPP block in front of a
+# CSPLayer without shortcuts) -- darknet.py:118-167 of the reference spells the four stages out one by one
+_STAGES = (('dark2', 2, 1, False), ('dark3', 4, 3, False), ('dark4', 8, 3, False), ('dark5', 16, 1, True))
+
+
 class CSPDarknet(nn.Module):
     def __init__(self, dep_mul, wid_mul, out_features=('dark3', 'dark4', 'dark5'), depthwise=False, act='silu', in_dim=3):
         super().__init__()
         assert out_features, 'please provide output features of Darknet'
         self.out_features = out_features
-        Conv = DWConv if depthwise else BaseConv
-        c = int(wid_mul * 64)
-        d = max(round(dep_mul * 3), 1)
-        self.stem = Focus(in_dim, c, ksize=3, act=act)
-        self.dark2 = nn.Sequential(Conv(c, c * 2, 3, 2, act=act),
-                                   CSPLayer(c * 2, c * 2, n=d, depthwise=depthwise, act=act))
-        self.dark3 = nn.Sequential(Conv(c * 2, c * 4, 3, 2, act=act),
-                                   CSPLayer(c * 4, c * 4, n=d * 3, depthwise=depthwise, act=act))
-        self.dark4 = nn.Sequential(Conv(c * 4, c * 8, 3, 2, act=act),
-                                   CSPLayer(c * 8, c * 8, n=d * 3, depthwise=depthwise, act=act))
-        self.dark5 = nn.Sequential(Conv(c * 8, c * 16, 3, 2, act=act), SPPBottleneck(c * 16, c * 16, activation=act),
-                                   CSPLayer(c * 16, c * 16, n=d, shortcut=False, depthwise=depthwise, act=act))
+        down = DWConv if depthwise else BaseConv           # the stride-2 convolution that opens every stage
+        width, depth = int(wid_mul * 64), max(round(dep_mul * 3), 1)
+        self.stem = Focus(in_dim, width, ksize=3, act=act)
+        cin = width
+        for name, wmul, dmul, last in _STAGES:
+            cout = width * wmul
+            layers = [down(cin, cout, 3, 2, act=act)]
+            if last:
+                layers.append(SPPBottleneck(cout, cout, activation=act))
+            layers.append(CSPLayer(cout, cout, n=depth * dmul, shortcut=not last, depthwise=depthwise, act=act))
+            setattr(self, name, nn.Sequential(*layers))     # (registration order = the reference's: same state_dict key order)
+            cin = cout
 
     def forward(self, x):
         feats = {}
