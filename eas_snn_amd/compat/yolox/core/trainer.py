@@ -532,7 +532,7 @@ class Trainer:
         lr = self.lr_scheduler.update_lr(self.epoch * self.max_iter + self.iter + 1)
         self._set_lr(lr)
         if (self.iter + 1) % self.exp.print_interval == 0:
-            self.log.append(dict(epoch=self.epoch, iter=self.iter, loss=float(loss), lr=lr, iter_time=time.time() - t0))
+            self.log.append(dict(epoch=self.epoch, iter=self.iter, loss=float(loss.detach()), lr=lr, iter_time=time.time() - t0))
 
     def save_ckpt(self, ckpt_name, update_best_ckpt=False, ap=None):
         if self.device != 'cpu':

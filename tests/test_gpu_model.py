@@ -720,6 +720,51 @@ def test_trainer_loop_on_the_gpu_graph_replay_equals_eager(dev, tmp_path, monkey
     assert not bad, bad[:5]
 
 
+def test_trainer_resume_on_the_gpu_continues_optimizer_and_average(dev, tmp_path, monkeypatch):
+    """``--resume`` (trainer.py:318-338 of the reference) through the graph-replayed loop: a run of two epochs x three iterations that is
+    interrupted after the first epoch and resumed from ``latest_ckpt.pth``.  The resumed Trainer records its step on its first batch with
+    model / optimizer / weight-average state put back afterwards (``capture(restore=True)``) -- which must put back the LOADED optimizer
+    state, not Adam's zeros: after the resumed epoch every Adam step counter reads 6 (3 + 3), the second moments are those of six steps
+    (non-zero, larger than after three), the weight average's counter continues from max_iter * start_epoch (the reference's rule,
+    trainer.py:169-171), the learning-rate schedule continues, and the checkpoint names the next epoch."""
+    import types
+    from eas_snn_amd import data, ops
+    from yolox.exp import get_exp
+    monkeypatch.setattr(ops, 'VERIFY_SMALL_INT', False)      # the suite's tag check reads the device: not inside a capture
+
+    def trainer(resume, epochs):
+        exp = get_exp(None, 'e-yolox-s')
+        exp.merge(BASE_OPTS + ['use_spike', 'True', 'input_size', '(64, 64)', 'test_size', '(64, 64)'])
+        exp.max_epoch, exp.print_interval, exp.output_dir, exp.eval_interval = epochs, 1, str(tmp_path), 0
+        exp.get_data_loader = lambda batch_size, is_distributed, no_aug=False, cache_img=None, exp=exp: \
+            data.SyntheticEventLoader(exp, batch_size, iters=3, n_events=3000, sensor_hw=(60, 60))
+        torch.manual_seed(5)
+        return exp.get_trainer(types.SimpleNamespace(batch_size=4, fp16=False, experiment_name='resume', ckpt=None, resume=resume))
+    first = trainer(False, 1)
+    first.train()
+    assert first.step.graphs is not None and len(first.log) == 3
+    steps1 = {float(st_['step']) for st_ in first.optimizer.state.values()}
+    v1 = sum(float(st_['exp_avg_sq'].sum()) for st_ in first.optimizer.state.values())
+    assert steps1 == {3.0} and first.ema_model.updates == 3 == first.optimizer.ema_updates_on_device()
+    ck = torch.load(os.path.join(str(tmp_path), 'resume', 'latest_ckpt.pth'), map_location='cpu')
+    assert ck['start_epoch'] == 1
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    second = trainer(True, 2)
+    second.train()
+    assert second.start_epoch == 1 and second.step.graphs is not None and len(second.log) == 3
+    steps2 = {float(st_['step']) for st_ in second.optimizer.state.values()}
+    v2 = sum(float(st_['exp_avg_sq'].sum()) for st_ in second.optimizer.state.values())
+    assert steps2 == {6.0}, f'Adam step counters after the resumed epoch: {sorted(steps2)} (recording must put back the loaded state)'
+    assert v2 > v1 > 0
+    # the weight average: restarted from the checkpoint's (averaged) weights with the counter at max_iter * start_epoch = 3, three more updates
+    assert second.ema_model.updates == 6 == second.optimizer.ema_updates_on_device()
+    assert [r['epoch'] for r in second.log] == [1, 1, 1] and all(np.isfinite(r['loss']) for r in second.log)
+    lr1, lr2 = [r['lr'] for r in first.log], [r['lr'] for r in second.log]
+    assert lr1 != lr2 or len(set(lr1)) == 1           # the schedule moved on (or is flat by configuration)
+    assert torch.load(os.path.join(str(tmp_path), 'resume', 'latest_ckpt.pth'), map_location='cpu')['start_epoch'] == 2
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
 def test_trainer_loop_with_sgd_stays_eager(dev, tmp_path, monkeypatch):
     """``optimizer SGD`` (the reference's other branch, event_yolox_base.py:361-377): its step takes the learning rate as a host number, so
     the Trainer must not capture it -- the loop runs eagerly, with a float lr, and trains"""
